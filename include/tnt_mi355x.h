@@ -1,0 +1,207 @@
+/*
+ * tnt_mi355x.h -- C ABI of the MI355X-native ThermonucleotideBLAST hot path.
+ *
+ * The reference (jgans/thermonucleotideBLAST v2.77) has no plugin/FFI seam; its
+ * per-target inner loop is the body of the `while(true)` work loop inside
+ * `#pragma omp parallel` in tntblast_local.cpp:388-793, which calls the three
+ * C++ entry points declared in tntblast.h:409-472 (amplicon / padlock / hybrid)
+ * once per (target, assay).  This header is the batch-granular replacement for
+ * that loop body: a whole assay set against a device-resident batch of targets.
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No C++/torch types cross
+ * the boundary.  All functions return 0 on success and a negative TNT_E_* code
+ * on failure; tnt_last_error() returns the message (the reference throws
+ * `const char*` literals, throw.h:17-18, caught in tntblast_local.cpp:1377-1391).
+ *
+ * The same structs (and the same function signatures with the prefixes
+ * `tntor_` / `tntref_`) are implemented by the CPU restatement under oracle/
+ * and by the harness that links the reference's own objects (oracle/_ref), so
+ * parity tests can diff the three implementations field by field.
+ */
+#ifndef TNT_MI355X_H
+#define TNT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNT_ABI_VERSION 1
+
+/* Longest oligo the gfx950 bind kernel accepts: one wavefront lane per query
+ * row (reference cap is MAX_SEQUENCE_LENGTH 1024, nuc_cruc.h:80).           */
+#define TNT_MAX_OLIGO 64
+/* NUM_FLANK_BASE, tntblast.h:76 */
+#define TNT_FLANK 4
+/* window = oligo + 2*flank (bind_oligo.cpp:139-142) */
+#define TNT_MAX_WINDOW (TNT_MAX_OLIGO + 2 * TNT_FLANK)
+/* alignment text: 3 lines of "5' " + <=(L+W) columns + " 3'" (nuc_cruc_output.cpp:8-213) */
+#define TNT_ALIGN_TEXT 448
+
+/* error codes */
+#define TNT_OK 0
+#define TNT_E_ARG (-1)      /* bad argument */
+#define TNT_E_DEVICE (-2)   /* no GPU / HIP failure: there is NO CPU fallback */
+#define TNT_E_LIMIT (-3)    /* oligo longer than TNT_MAX_OLIGO, overflow of a device list */
+#define TNT_E_UNSUPPORTED (-4)
+
+/* assay formats, numerically equal to hybrid_sig.h:19 */
+enum { TNT_ASSAY_PCR = 0, TNT_ASSAY_PROBE = 1, TNT_ASSAY_PADLOCK = 2, TNT_ASSAY_MIPS = 3 };
+/* target strands, numerically equal to seq.h:38-42 */
+enum { TNT_STRAND_PLUS = 1, TNT_STRAND_MINUS = 2, TNT_STRAND_BOTH = 3 };
+/* hybrid_sig::PLUS / MINUS, hybrid_sig.h:117 */
+enum { TNT_PLUS = 0, TNT_MINUS = 1 };
+
+/* 1-byte target base codes, seq.h:12-35 (input format of the path) */
+enum {
+	TNT_DB_A = 0, TNT_DB_C, TNT_DB_G, TNT_DB_T, TNT_DB_I, TNT_DB_M, TNT_DB_R, TNT_DB_S, TNT_DB_V,
+	TNT_DB_W, TNT_DB_Y, TNT_DB_H, TNT_DB_K, TNT_DB_D, TNT_DB_B, TNT_DB_N, TNT_DB_GAP, TNT_DB_UNKNOWN
+};
+
+/* The Options fields the hot path consumes (options.h:33-76, defaults options.h:85-170,
+ * tntblast.h:19-76); used at tntblast_local.cpp:232-234,363-367,566-624.               */
+typedef struct tnt_options {
+	float min_primer_tm, max_primer_tm;     /* -e / -x */
+	float min_primer_dg, max_primer_dg;     /* -z / -g */
+	float min_probe_tm, max_probe_tm;       /* -E / -X */
+	float min_probe_dg, max_probe_dg;       /* -Z / -G */
+	float salt;                             /* -s  [Na+] (M) */
+	float primer_strand;                    /* -t  Ct primers */
+	float probe_strand;                     /* -T  Ct probe */
+	float asymmetric_strand_ratio;          /* -y  forward = ratio * primer_strand */
+	float target_t;                         /* --temperature (K) */
+	int32_t primer_clamp;                   /* --primer-clamp (3') */
+	int32_t min_max_primer_clamp;           /* --min-max-primer-clamp, -1 = off */
+	int32_t probe_clamp_5, probe_clamp_3;   /* --probe-clamp5/3 */
+	int32_t max_gap, max_mismatch, max_poly_degen;
+	int32_t max_len;                        /* -l */
+	int32_t assay_format;                   /* -A */
+	int32_t target_strand;                  /* --target-strand */
+	int32_t hash_word_size;                 /* -W (3..8) */
+	int32_t single_primer_pcr;              /* --single-primer-pcr */
+	int32_t allow_dangle_5, allow_dangle_3; /* --dangle5/3 */
+	int32_t use_dinkelbach;                 /* --dinkelbach */
+} tnt_options;
+
+/* One expanded (non-degenerate) assay: expand_degenerate_signatures, tntblast_util.cpp:579-713.
+ * Absent oligos are NULL.  *_degen are the Ct divisors (amplicon_search.cpp:85-87).       */
+typedef struct tnt_assay {
+	int32_t id;
+	int32_t degen_id;
+	const char *forward;
+	const char *reverse;
+	const char *probe;
+	int32_t forward_degen, reverse_degen, probe_degen;
+} tnt_assay;
+
+/* Result payload of one hit = hybrid_sig (hybrid_sig.h:121-164) without the host-side
+ * string-table indices; alignment strings are carried inline.                          */
+typedef struct tnt_hit {
+	int32_t assay_id, degen_id, seq_index;
+	int32_t amplicon_start, amplicon_stop;  /* amplicon_range */
+	int32_t probe_start, probe_stop;        /* probe_range */
+	float forward_tm, reverse_tm, probe_tm;
+	float forward_dH, forward_dS, reverse_dH, reverse_dS, probe_dH, probe_dS;
+	int32_t primer_strand, probe_strand;    /* TNT_PLUS / TNT_MINUS */
+	int32_t forward_primer_clamp, reverse_primer_clamp;
+	int32_t forward_mm, forward_gap, reverse_mm, reverse_gap, probe_mm, probe_gap;
+	/* which oligo of the assay sits in the forward / reverse slot (0 = forward oligo,
+	 * 1 = reverse oligo): single-primer amplicons swap identities, amplicon_search.cpp:453-463 */
+	int32_t forward_oligo, reverse_oligo;
+	int32_t has_primers, has_probe;
+	char forward_align[TNT_ALIGN_TEXT];
+	char reverse_align[TNT_ALIGN_TEXT];
+	char probe_align[TNT_ALIGN_TEXT];
+} tnt_hit;
+
+/* One seed after the per-(oligo,strand) diagonal de-duplication of
+ * match_oligo_to_{minus,plus}_strand (bind_oligo.cpp:84-122).                      */
+typedef struct tnt_seed {
+	int32_t seq_index;
+	int32_t oligo;      /* index into the context's unique-oligo table */
+	int32_t strand;     /* TNT_MINUS: DNAHash::find, TNT_PLUS: find_complement */
+	int32_t query_loc;  /* DNAHash_iterator::offset() = index in the word list (seq_hash.h:214) */
+	int32_t target_loc; /* k-mer start in the target */
+} tnt_seed;
+
+/* Outcome of one oligo/window binding = what bind_oligo_to_{minus,plus}_strand derives from
+ * NucCruc for one seed (bind_oligo.cpp:502-748).                                            */
+typedef struct tnt_bind {
+	int32_t status;     /* 0 bound; 1 tm, 2 dg, 3 anchor5, 4 anchor3, 5 mismatch, 6 gap, 7 poly-degen rejected */
+	int32_t target_start, target_stop; /* window [start, stop) */
+	float tm, dH, dS, dg;
+	int32_t anchor5, anchor3, num_mm, num_gap, poly_degen;
+	int32_t loc5, loc3;
+	int32_t q_first, q_last, t_first, t_last; /* alignment_range, nuc_cruc_anchor.cpp:379-396 */
+	int32_t valid;      /* curr_align.valid */
+	int32_t dp_max;     /* align_dimer return value */
+	int32_t n_max;      /* number of maximal cells */
+	char align[TNT_ALIGN_TEXT];
+} tnt_bind;
+
+/* explicit bind request (unit-level entry to the bind kernel) */
+typedef struct tnt_bind_req {
+	int32_t seq_index;
+	int32_t oligo;      /* unique-oligo index */
+	int32_t strand;     /* TNT_MINUS / TNT_PLUS */
+	int32_t query_loc, target_loc;
+	int32_t role;       /* 0 primer thresholds, 1 probe thresholds */
+	float ct;           /* strand concentration */
+} tnt_bind_req;
+
+typedef struct tnt_ctx tnt_ctx; /* one per GPU, single caller */
+typedef struct tnt_db tnt_db;   /* device-resident packed targets */
+
+void tnt_options_default(tnt_options *opt);
+int tnt_abi_version(void);
+
+/* Context = options + assay set + thermodynamic tables resident on `device`. */
+int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_assays, int device, tnt_ctx **out);
+void tnt_ctx_destroy(tnt_ctx *ctx);
+const char *tnt_last_error(const tnt_ctx *ctx); /* ctx may be NULL: last creation error */
+
+/* unique-oligo table of the context (assay oligos de-duplicated by string) */
+int tnt_ctx_num_oligos(const tnt_ctx *ctx);
+const char *tnt_ctx_oligo(const tnt_ctx *ctx, int i);
+
+/* NucCruc::update_dp_param result (nuc_cruc.cpp:340-487): 2401 int32 */
+int tnt_ctx_delta_g(const tnt_ctx *ctx, int32_t *out2401);
+
+/* Pack a batch of targets onto the GPU.  `codes` = concatenated 1-byte codes (seq.h:12-35),
+ * `offsets[n_targets+1]` = start of each target.  Replaces read_bio_seq + DNAHash::hash
+ * (tntblast_local.cpp:510,534).  `first_seq_index` = global index of target 0.            */
+int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, size_t n_targets,
+                  uint32_t first_seq_index, tnt_db **out);
+void tnt_db_destroy(tnt_db *db);
+size_t tnt_db_num_targets(const tnt_db *db);
+uint64_t tnt_db_num_bases(const tnt_db *db);
+
+/* The hot path: seeds -> cull -> bind -> pair for every (target, assay).  Hits are owned by
+ * the context until the next tnt_search / tnt_ctx_destroy.                                  */
+int tnt_search(tnt_ctx *ctx, tnt_db *db, const tnt_hit **hits, size_t *n_hits);
+
+/* Asynchronous form used by bench.py: enqueue on the context's stream, no host sync. */
+int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db);
+int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits);
+
+/* per-stage device timings of the last search, in ms (HIP events on the context stream) */
+typedef struct tnt_timing {
+	float seed_ms, bind_ms, pair_ms, total_ms;
+	uint64_t n_seeds, n_binds, n_bound, n_hits;
+} tnt_timing;
+int tnt_last_timing(tnt_ctx *ctx, tnt_timing *out);
+
+/* Unit-level entries (parity tests of SURVEY 8a rows a1-a3 and a5-a14). */
+int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds);
+int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out);
+
+/* amplicon / probe text of a hit, copied from the packed targets (amplicon_search.cpp:508-537,
+ * probe_search.cpp:138-152): returns length written (without NUL) or <0.                      */
+int tnt_hit_sequence(tnt_ctx *ctx, tnt_db *db, const tnt_hit *hit, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNT_MI355X_H */
