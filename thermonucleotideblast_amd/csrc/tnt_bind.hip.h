@@ -1,0 +1,839 @@
+// tnt_bind.hip.h -- gfx950 bind kernel: one wavefront LANE per (oligo, target-window) pair.
+//
+// Replaces, for one seed, everything bind_oligo_to_{minus,plus}_strand derives from NucCruc
+// (bind_oligo.cpp:502-748 / :1202-1446): window load, align_dimer (nuc_cruc.cpp:492-696),
+// tm_dimer / enumerate_dimer_alignments / trace_back (nuc_cruc.cpp:973-1170,1409-1618,2517-2540),
+// evaluate_alignment (nuc_cruc.cpp:1620-2299), anchors / mismatch / gap / poly-degen counts
+// (nuc_cruc_anchor.cpp, nuc_cruc.h:389-483), the threshold cascade and, for bound oligos,
+// the alignment text (nuc_cruc_output.cpp:74-205).
+//
+// Layout choices:
+//  * DP is swept column-major; the previous column's (M, I_query, I_target) of every query row
+//    lives in VGPRs (static unroll over LMAX rows), so the recurrence needs no LDS traffic.
+//  * delta_g (9.6 KB) and the best_base_pair LUT are staged in LDS once per workgroup; the
+//    target window of every lane sits in LDS as bytes [column][lane].
+//  * one 16-bit trace word per cell goes to an HBM scratch slab laid out [cell][lane] so a
+//    wavefront writes 128 contiguous bytes per cell; the traceback reads it back (L2 resident).
+//  * float scoring uses no FMA contraction (-ffp-contract=off), IEEE division, and host-computed
+//    logarithms, so Tm/dH/dS are bit-identical to the reference's float32 arithmetic.
+#ifndef TNT_BIND_HIP_H
+#define TNT_BIND_HIP_H
+
+#include <hip/hip_runtime.h>
+#include "tnt_dev.h"
+
+namespace tnt {
+
+struct BindArgs {
+	const Tables *tab;
+	DbView db;
+	const uint8_t *olig_base;  // [n][MAX_OLIGO] BASE codes, 5'->3'
+	const uint32_t *olig_rev;  // [n][MAX_OLIGO/8] reversed (row i-1 = query[L-i]), 4 bits per base
+	const int32_t *olig_len;
+	const Slot *slots;
+	const Thresh *thresh;
+	const Item *items;
+	uint32_t n_items;
+	const uint32_t *n_items_dev; // when set, the item count is read from the device counter
+	int32_t *result;           // per item: pool index (>= 0) or -status
+	BoundRec *pool;
+	uint32_t pool_cap;
+	uint32_t *pool_count;
+	BindFull *full;            // optional (unit-level API): full record per item
+	uint16_t *trace;           // scratch, per block slot
+	uint16_t *cols;
+	uint16_t *best;
+	uint32_t *stack;
+	uint32_t *err;
+};
+
+constexpr int BIND_THREADS = 256;
+constexpr unsigned long long WC_MASK = // watson_and_crick[], nuc_cruc.cpp:229-238
+	(1ull << P_AT) | (1ull << P_TA) | (1ull << P_CG) | (1ull << P_GC) | (1ull << (bA * NB + bI)) | (1ull << (bI * NB + bA)) |
+	(1ull << (bT * NB + bI)) | (1ull << (bI * NB + bT)) | (1ull << (bG * NB + bI)) | (1ull << (bI * NB + bG)) |
+	(1ull << (bC * NB + bI)) | (1ull << (bI * NB + bC)) | (1ull << (bI * NB + bI));
+
+__device__ __forceinline__ bool is_wc(int pair) { return (WC_MASK >> pair) & 1ull; }
+__device__ __forceinline__ bool is_virtual(int b) { return b == bE || b == bGAP; }
+__device__ __forceinline__ bool non_virtual_pair(int p) { return (p % NB < bE) && (p / NB < bE); }
+__device__ __forceinline__ bool pair_has_gap(int p) { return (p % NB == bGAP) || (p / NB >= bGAP); }
+
+// is_complemetary_base, nuc_cruc_anchor.cpp:8-139 (bit0 A, bit1 T, bit2 G, bit3 C); BASE codes 0..17
+__device__ const uint8_t c_query_mask[18] = {1, 8, 4, 2, 15, 0, 0, 1 | 8, 4 | 1, 4 | 8, 4 | 8 | 1, 1 | 2, 2 | 8, 1 | 8 | 2, 4 | 2, 4 | 1 | 2, 4 | 2 | 8, 15};
+// the target base is mapped to its complement first
+__device__ const uint8_t c_target_mask[18] = {2, 4, 8, 1, 15, 0, 0, 2 | 4, 8 | 2, 8 | 4, 8 | 4 | 2, 2 | 1, 1 | 4, 2 | 4 | 1, 8 | 1, 8 | 2 | 1, 8 | 1 | 4, 15};
+__device__ __forceinline__ bool is_complementary(int q, int t) { return (c_query_mask[q] & c_target_mask[t]) != 0; }
+
+// seq.h code (0..15) -> BASE code of the base itself (bind_oligo.cpp:1227-1276) ...
+__device__ __forceinline__ int db_same(int c) { return c < 5 ? c : c + 2; }
+// ... and of its complement (bind_oligo.cpp:524-573): A C G T I M R S V W Y H K D B N -> T G C A I K Y S B W R D M H V N
+__device__ const uint8_t c_db_comp[16] = {bT, bG, bC, bA, bI, bK, bY, bS, bB, bW, bR, bD, bM, bH, bV, bN};
+__device__ __forceinline__ int db_comp(int c) { return c_db_comp[c]; }
+
+// per-lane evaluation context for the serial tail
+struct LaneCtx {
+	const Tables *tab;
+	const uint8_t *lut;       // LDS best_base_pair LUT
+	const uint8_t *win;       // LDS window base of this lane: win[k * BIND_THREADS]
+	const uint8_t *query;     // global oligo bases 5'->3'
+	uint16_t *cols;           // scratch alignment columns of this lane, stride BIND_THREADS
+	int L, W;
+	float log_ct;
+};
+
+__device__ __forceinline__ int lut_pair(const uint8_t *lut, int x, int y)
+{
+	return ((x | y) < NB) ? x * NB + y : int(lut[x * 18 + y]);
+}
+
+__device__ __forceinline__ int col_q(uint16_t c) { return c & 31; }
+__device__ __forceinline__ int col_t(uint16_t c) { return (c >> 5) & 31; }
+__device__ __forceinline__ uint16_t mk_col(int q, int t) { return uint16_t(q | (t << 5)); }
+
+struct Score {
+	float dH, dS, tm;
+	bool ok;
+};
+
+// evaluate_alignment (HETERO_DIMER), nuc_cruc.cpp:1620-2299.  Columns k0..k1-1 of c.cols.
+__device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1)
+{
+	const Tables &T = *c.tab;
+	const float *Hh = T.H, *Ss = T.S;
+	const uint8_t *lut = c.lut;
+#define COLQ(k) col_q(c.cols[(k) * BIND_THREADS])
+#define COLT(k) col_t(c.cols[(k) * BIND_THREADS])
+	int terminal = P__, lastlast = P__, last = P__, curp = P__;
+	float dH = T.init_H;
+	float dS = T.init_S + 0.0f;
+	unsigned nqg = 0, ntg = 0, nmm = 0, num_base = 0;
+	bool terminal_5 = false;
+	const int n = k1 - k0;
+
+	{
+		const int q0 = COLQ(k0), t0 = COLT(k0);
+		curp = lut_pair(lut, q0, t0);
+		if (is_wc(curp)) {
+			terminal_5 = true;
+			if (curp == P_AT || curp == P_TA) {
+				dH += T.at_H;
+				dS += T.at_S;
+			}
+		}
+		num_base += is_virtual(q0) ? 0 : 1;
+		num_base += is_virtual(t0) ? 0 : 1;
+	}
+
+	for (int k = 1; k < n; k++) {
+		const uint16_t cw = c.cols[(k0 + k) * BIND_THREADS];
+		const int qk = col_q(cw), tk = col_t(cw);
+		lastlast = last;
+		last = curp;
+		curp = lut_pair(lut, qk, tk);
+		const bool align_start = (k == 1), align_stop = (k == n - 1);
+		const bool in_loop = (qk == bGAP) || (tk == bGAP) || (!is_wc(last) && !is_wc(curp));
+
+		if (!in_loop) {
+			if (align_start && !is_wc(last) && non_virtual_pair(last)) { // frayed start, :1726-1745
+				int tmp = lut_pair(lut, last / NB, bE);
+				dH += Hh[tmp * NBP + curp];
+				dS += Ss[tmp * NBP + curp];
+				tmp = lut_pair(lut, bE, last % NB);
+				dH += Hh[tmp * NBP + curp];
+				dS += Ss[tmp * NBP + curp];
+			} else if (align_stop && !is_wc(curp) && non_virtual_pair(curp)) { // frayed stop, :1747-1763
+				int tmp = lut_pair(lut, qk, bE);
+				dH += Hh[last * NBP + tmp];
+				dS += Ss[last * NBP + tmp];
+				tmp = lut_pair(lut, bE, tk);
+				dH += Hh[last * NBP + tmp];
+				dS += Ss[last * NBP + tmp];
+			} else {
+				dH += Hh[last * NBP + curp];
+				dS += Ss[last * NBP + curp];
+			}
+			num_base += is_virtual(qk) ? 0 : 1;
+			num_base += is_virtual(tk) ? 0 : 1;
+		}
+
+		if (is_wc(curp) || curp == P_EE) { // :1794
+			terminal = curp;
+			if (!terminal_5) {
+				terminal_5 = true;
+				if (curp == P_AT || curp == P_TA) {
+					dH += T.at_H;
+					dS += T.at_S;
+				}
+			}
+			const unsigned max_gap = nqg > ntg ? nqg : ntg;
+			if (nmm > 1 || (max_gap > 0 && nmm == 1)) { // internal loop, :1824
+				const unsigned gap_diff = (nqg > ntg) ? nqg - ntg : ntg - nqg;
+				const unsigned loop_size = nmm * 2 + gap_diff;
+				if (loop_size == 2 && (last == P_GT || last == P_TG) && (lastlast == P_GT || lastlast == P_TG)) {
+					dH += Hh[lastlast * NBP + last];
+					dS += Ss[lastlast * NBP + last];
+					num_base += 2;
+				} else {
+					dS += T.loop_S[loop_size];
+					dS += float(gap_diff) * T.asym_S;
+					int rhs_q = k - 1, rhs_t = k - 1;
+					dH -= Hh[last * NBP + curp];
+					dS -= Ss[last * NBP + curp];
+					if (!pair_has_gap(last)) { // right terminal mismatch, :1923-1935
+						dH += Hh[last * NBP + curp];
+						dS += Ss[last * NBP + curp];
+					} else { // :1936-1992
+						int mm = P__;
+						if (last / NB == bGAP) {
+							while (true) {
+								const int qq = COLQ(k0 + rhs_q);
+								if (!is_virtual(qq)) {
+									mm = lut_pair(lut, qq, last % NB);
+									break;
+								}
+								if (rhs_q == 0) break;
+								rhs_q--;
+							}
+						} else {
+							while (true) {
+								const int tt = COLT(k0 + rhs_t);
+								if (!is_virtual(tt)) {
+									mm = lut_pair(lut, last / NB, tt);
+									break;
+								}
+								if (rhs_t == 0) break;
+								rhs_t--;
+							}
+						}
+						dH += Hh[mm * NBP + curp];
+						dS += Ss[mm * NBP + curp];
+					}
+					// left terminal mismatch, :2000-2077
+					int lhs_q = k - 1, lhs_t = k - 1;
+					while (true) {
+						const int pm = lut_pair(lut, COLQ(k0 + lhs_q), COLT(k0 + lhs_t));
+						if (is_wc(pm)) {
+							lhs_q++, lhs_t++;
+							if (COLQ(k0 + lhs_q) != bGAP && COLT(k0 + lhs_t) != bGAP) {
+								const int mm = lut_pair(lut, COLQ(k0 + lhs_q), COLT(k0 + lhs_t));
+								dH -= Hh[pm * NBP + mm];
+								dS -= Ss[pm * NBP + mm];
+							} else {
+								num_base += 2;
+								while (COLQ(k0 + lhs_q) == bGAP) lhs_q++;
+								while (COLT(k0 + lhs_t) == bGAP) lhs_t++;
+							}
+							const int mm = lut_pair(lut, COLQ(k0 + lhs_q), COLT(k0 + lhs_t));
+							dH += Hh[pm * NBP + mm];
+							dS += Ss[pm * NBP + mm];
+							break;
+						}
+						if (lhs_q == 0) break;
+						lhs_q--, lhs_t--;
+					}
+					if (rhs_q != lhs_q) num_base++;
+					if (rhs_t != lhs_t) num_base++;
+				}
+			} else if (nqg || ntg) { // bulge, :2105-2185
+				const unsigned bulge = nqg > ntg ? nqg : ntg;
+				if (bulge == 1) {
+					dH += Hh[lastlast * NBP + curp];
+					dS += Ss[lastlast * NBP + curp];
+				}
+				dS += T.bulge_S[bulge];
+				if (bulge != 1 && (qk == bA || qk == bT)) dS += T.bulge_at_S;
+				if (bulge != 1) { // has_AT_initiation, :2888-2905
+					int i = k;
+					do {
+						i--;
+					} while (i != 0 && (COLQ(k0 + i) == bGAP || COLT(k0 + i) == bGAP));
+					const int p = lut_pair(lut, COLQ(k0 + i), COLT(k0 + i));
+					if (p == P_AT || p == P_TA) dS += T.bulge_at_S;
+				}
+			}
+			nqg = ntg = nmm = 0;
+		} else {
+			nmm += (!is_virtual(qk) && !is_virtual(tk)) ? 1 : 0;
+		}
+		nqg += (qk == bGAP) ? 1 : 0;
+		ntg += (tk == bGAP) ? 1 : 0;
+	}
+#undef COLQ
+#undef COLT
+	if (terminal == P_AT || terminal == P_TA) {
+		dH += T.at_H;
+		dS += T.at_S;
+	}
+	Score s;
+	s.dH = dH;
+	s.dS = dS;
+	s.tm = 0.0f;
+	s.ok = false;
+	if (dH >= 0.0f) return s; // :2253
+	dS += T.salt * (0.5f * float(num_base) - 1.0f) * T.log_na; // :2270
+	const float tm = dH / (1.9872e-3f * c.log_ct + dS) - 273.15f; // :2291
+	s.dS = dS;
+	s.tm = tm > 0.0f ? tm : 0.0f;
+	s.ok = true;
+	return s;
+}
+
+struct AlignInfo {
+	int k0, k1;               // column range inside the scratch buffer
+	int fm_q, fm_t, lm_q, lm_t;
+};
+
+// The bind kernel proper.  LMAX = rows kept in registers (oligos of this launch have L <= LMAX).
+template <int LMAX, bool FULL>
+__global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
+{
+	constexpr int WMAX = LMAX + 2 * FLANK;
+	constexpr int NCOLS = LMAX + WMAX + 4;
+
+	__shared__ int32_t s_dg[NBP * NBP];
+	__shared__ uint8_t s_lut[18 * 18 + 4];
+	__shared__ uint8_t s_win[WMAX * BIND_THREADS];
+
+	const int tid = threadIdx.x;
+	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) s_dg[i] = a.tab->dg[i];
+	for (int i = tid; i < 18 * 18; i += BIND_THREADS) s_lut[i] = a.tab->bbp[i];
+	__syncthreads();
+
+	const Tables &T = *a.tab;
+	uint16_t *trace = a.trace + size_t(blockIdx.x) * (size_t(LMAX) * WMAX * BIND_THREADS) + tid;
+	uint16_t *cols = a.cols + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
+	uint16_t *best = a.best + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
+	uint32_t *stack = a.stack + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
+	uint8_t *win = s_win + tid;
+
+	const uint32_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_items;
+	for (uint32_t base = blockIdx.x * BIND_THREADS; base < n_items; base += gridDim.x * BIND_THREADS) {
+		const uint32_t idx = base + tid;
+		const bool active = idx < n_items;
+
+		// ------------------------------------------------------------------ item decode
+		Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
+		const Slot slot = a.slots[active ? it.slot : 0];
+		const int L = active ? a.olig_len[slot.oligo] : 0;
+		const bool minus = (it.info & ITEM_MINUS) != 0;
+		const int qloc = int(it.info & 255u);
+		const uint32_t tlen = a.db.len[it.target];
+		// bind_oligo.cpp:502-505
+		int start = int(it.tloc) - (qloc + FLANK);
+		if (start < 0) start = 0;
+		int stop = start + L + 2 * FLANK;
+		if (stop > int(tlen)) stop = int(tlen);
+		int W = 0;
+
+		// ------------------------------------------------------------------ window load (Q6: codes > 15 are skipped)
+		if (active) {
+			const uint32_t *pk = a.db.packed + a.db.word_off[it.target];
+			const uint32_t e0 = a.db.exc_off[it.target], e1 = a.db.exc_off[it.target + 1];
+			uint32_t e = e0;
+			int nskip = 0;
+			if (e1 > e0) {
+				// first exception at or after `start`
+				uint32_t lo = e0, hi = e1;
+				while (lo < hi) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (a.db.exc_pos[mid] < uint32_t(start)) lo = mid + 1;
+					else hi = mid;
+				}
+				e = lo;
+				for (uint32_t x = e; x < e1 && a.db.exc_pos[x] < uint32_t(stop); x++)
+					if (a.db.exc_code[x] > 15) nskip++;
+			}
+			W = (stop - start) - nskip;
+			int r = 0;
+			for (int pos = start; pos < stop; pos++) {
+				int code = int((pk[pos >> 4] >> ((pos & 15) * 2)) & 3u);
+				if (e < e1 && a.db.exc_pos[e] == uint32_t(pos)) {
+					code = a.db.exc_code[e];
+					e++;
+				}
+				if (code > 15) continue;
+				if (minus) win[(W - 1 - r) * BIND_THREADS] = uint8_t(db_comp(code));
+				else win[r * BIND_THREADS] = uint8_t(db_same(code));
+				r++;
+			}
+		}
+
+		// ------------------------------------------------------------------ DP fill (align_dimer, nuc_cruc.cpp:492-696)
+		uint32_t qpk[LMAX / 8];
+#pragma unroll
+		for (int w = 0; w < LMAX / 8; w++) qpk[w] = active ? a.olig_rev[slot.oligo * (MAX_OLIGO / 8) + w] : 0u;
+
+		int oM[LMAX], oQ[LMAX], oT[LMAX];
+#pragma unroll
+		for (int i = 0; i < LMAX; i++) oM[i] = oQ[i] = oT[i] = -1;
+
+		int gmax = -1, nmax = 0, max_i = 0, max_j = 0;
+		int pt = bGAP, pgap = P__;
+		// uniform trip count over the wavefront keeps the unrolled body convergent
+		int Wwave = W;
+		for (int o = 32; o > 0; o >>= 1) {
+			const int other = __shfl_xor(Wwave, o);
+			Wwave = other > Wwave ? other : Wwave;
+		}
+		for (int j = 1; j <= Wwave; j++) {
+			const bool colok = j <= W;
+			const int t = colok ? int(win[(j - 1) * BIND_THREADS]) : bGAP;
+			const int cq = lut_pair(s_lut, t, bGAP);
+			const int v5 = s_dg[pgap * NBP + cq];
+			int aM = -1, aQ = -1, aT = -1, bM = -1, bT = -1;
+#pragma unroll
+			for (int i = 1; i <= LMAX; i++) {
+				if (colok && i <= L) {
+					const int q = int((qpk[(i - 1) >> 3] >> (((i - 1) & 7) * 4)) & 15u);
+					const int pq = (i == 1) ? bGAP : int((qpk[(i - 2) >> 3] >> (((i - 2) & 7) * 4)) & 15u);
+					const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
+					const int cur = lut_pair(s_lut, t, q);
+					const int p1 = lut_pair(s_lut, pt, pq);
+					const int p3 = bGAP * NB + pq;
+					const int p4 = lut_pair(s_lut, pt, q);
+					const int p5 = lut_pair(s_lut, t, pq);
+					const int ct = bGAP * NB + q;
+
+					const int dg1 = (aM > 0 ? aM : 0) - s_dg[p1 * NBP + cur];
+					const int dg2 = (aQ > 0 ? aQ : 0) - s_dg[pgap * NBP + cur];
+					const int dg3 = (aT > 0 ? aT : 0) - s_dg[p3 * NBP + cur];
+					int M, tw;
+					if (dg1 >= dg2) {
+						if (dg1 >= dg3) {
+							M = dg1;
+							tw = 1 | (dg1 == dg2 ? 4 : 0) | (dg1 == dg3 ? 2 : 0);
+						} else {
+							M = dg3;
+							tw = 2;
+						}
+					} else {
+						if (dg2 >= dg3) {
+							M = dg2;
+							tw = 4 | (dg2 == dg3 ? 2 : 0);
+						} else {
+							M = dg3;
+							tw = 2;
+						}
+					}
+					int ins = (cM > 0 ? cM : 0) - s_dg[p4 * NBP + cq];
+					int ext = (cQ > 0 ? cQ : 0) - v5;
+					int Iq;
+					if (ins >= ext) {
+						Iq = ins;
+						tw |= TW_IQ_FROM_M | (ins == ext ? TW_IQ_FROM_IQ : 0);
+					} else {
+						Iq = ext;
+						tw |= TW_IQ_FROM_IQ;
+					}
+					ins = (bM > 0 ? bM : 0) - s_dg[p5 * NBP + ct];
+					ext = (bT > 0 ? bT : 0) - s_dg[p3 * NBP + ct];
+					int It;
+					if (ins >= ext) {
+						It = ins;
+						tw |= TW_IT_FROM_M | (ins == ext ? TW_IT_FROM_IT : 0);
+					} else {
+						It = ext;
+						tw |= TW_IT_FROM_IT;
+					}
+					tw |= (M < 0 ? TW_M_NEG : 0) | (M == 0 ? TW_M_ZERO : 0) | (Iq < 0 ? TW_IQ_NEG : 0) | (It < 0 ? TW_IT_NEG : 0);
+					// running maximum in visiting (column-major) order; the set of cells equal to the final
+					// maximum is recovered from these flags, its row-major order from the cell coordinates
+					if (M > gmax) {
+						gmax = M;
+						nmax = 1;
+						max_i = i;
+						max_j = j;
+						tw |= TW_NEWMAX;
+					} else if (M == gmax) {
+						if (nmax == 0) {
+							max_i = i;
+							max_j = j;
+						}
+						nmax++;
+						tw |= TW_EQMAX;
+					}
+					trace[((j - 1) * LMAX + (i - 1)) * BIND_THREADS] = uint16_t(tw);
+					aM = cM, aQ = cQ, aT = cT;
+					bM = M, bT = It;
+					oM[i - 1] = M, oQ[i - 1] = Iq, oT[i - 1] = It;
+				}
+			}
+			pt = t;
+			pgap = cq;
+		}
+
+		// ------------------------------------------------------------------ serial tail
+		if (!active) continue;
+
+		LaneCtx c;
+		c.tab = a.tab;
+		c.lut = s_lut;
+		c.win = win;
+		c.query = a.olig_base + size_t(slot.oligo) * MAX_OLIGO;
+		c.cols = cols;
+		c.L = L;
+		c.W = W;
+		c.log_ct = slot.log_ct;
+
+		bool best_valid = false;
+		float best_dH = 0.0f, best_dS = 0.0f, best_tm = 0.0f;
+		AlignInfo bi = {0, 0, 0, 0, 0, 0};
+
+#define TRACE_AT(I, J) trace[(((J)-1) * LMAX + ((I)-1)) * BIND_THREADS]
+#define QUERY(K) int(c.query[(K)])
+#define TARGET(K) int(win[(K) * BIND_THREADS])
+
+		// tm_dimer: every maximal cell in row-major order (nuc_cruc.cpp:2533-2537)
+		const long first_pos = long(max_j) * (LMAX + 1) + max_i; // column-major rank of the first maximal cell
+		int scan_i = 1, scan_j = 0;
+		for (int mc = 0; mc < nmax; mc++) {
+			int ci, cj;
+			if (nmax == 1) {
+				ci = max_i;
+				cj = max_j;
+			} else {
+				// rare: several maximal cells; walk the matrix row-major for the next flagged one
+				while (true) {
+					scan_j++;
+					if (scan_j > W) {
+						scan_j = 1;
+						scan_i++;
+					}
+					if (scan_i > L) break; // cannot happen: nmax flagged cells exist
+					const int tw = TRACE_AT(scan_i, scan_j);
+					const long pos = long(scan_j) * (LMAX + 1) + scan_i;
+					if ((tw & (TW_NEWMAX | TW_EQMAX)) && pos >= first_pos) break;
+				}
+				if (scan_i > L) break;
+				ci = scan_i;
+				cj = scan_j;
+			}
+
+			// ---------------- enumerate_dimer_alignments, nuc_cruc.cpp:973-1170
+			bool first_time = true;
+			int sp = 0;
+			int zero_count = -1;
+			unsigned trace_count = 0;
+			float best_dg = best_dH - T.temperature * best_dS;
+			while (true) {
+				if (!first_time && sp == 0 && zero_count <= 0) break;
+				if (16u < trace_count) break;
+				trace_count++;
+				first_time = false;
+
+				// ---------------- trace_back, nuc_cruc.cpp:1409-1618
+				AlignInfo al;
+				al.k0 = 1;
+				int n = 0; // columns written at cols[1 + n]
+				int li = ci, lj = cj;
+				al.fm_q = L - li;
+				al.fm_t = lj - 1;
+				al.lm_q = 0;
+				al.lm_t = 0;
+				int truncate_at_zero = 0;
+				bool count_zeros = false;
+				if (zero_count < 0) {
+					zero_count = 0;
+					count_zeros = true;
+				} else {
+					truncate_at_zero = zero_count--;
+				}
+				int key = -1;
+				int mask = 1;
+				while (true) {
+					bool valid = true;
+					int local;
+					if (((mask & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1)) > 1) { // PATH_SPLIT
+						int f = 0;
+						for (; f < sp; f++)
+							if (int(stack[f * BIND_THREADS] & 0xFFFFu) == key) break;
+						if (f == sp) {
+							const int curb = (mask & 1) ? 1 : ((mask & 2) ? 2 : 4);
+							if (sp < NCOLS) {
+								stack[sp * BIND_THREADS] = uint32_t(key) | (uint32_t(mask) << 16) | (uint32_t(curb) << 20);
+								sp++;
+							} else {
+								atomicOr(a.err, ERR_STACK_OVERFLOW);
+							}
+							local = curb;
+						} else {
+							local = int((stack[f * BIND_THREADS] >> 20) & 15u);
+						}
+					} else {
+						local = mask;
+					}
+					// border cells hold M = I_query = I_target = -1 (nuc_cruc.h:531-536)
+					const bool inside = (li >= 1 && lj >= 1);
+					const int tw = inside ? int(TRACE_AT(li, lj)) : (TW_M_NEG | TW_IQ_NEG | TW_IT_NEG);
+					const int cidx = li * (WMAX + 1) + lj;
+					if (local == 1) { // query_target
+						if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
+							valid = false;
+						} else {
+							if (tw & TW_M_NEG) valid = false;
+							else if (tw & TW_M_ZERO) {
+								if (count_zeros) zero_count++;
+								else if (--truncate_at_zero == 0) valid = false;
+							}
+							cols[(1 + n) * BIND_THREADS] = mk_col(QUERY(L - li), TARGET(lj - 1));
+							n++;
+							al.lm_q = L - li;
+							al.lm_t = lj - 1;
+							mask = tw & TW_M_MASK;
+							key = cidx * 4 + 0;
+							li--, lj--;
+						}
+					} else if (local == 4) { // gap_target: GAP in the query strand, state I_query
+						if (lj < 1) {
+							valid = false;
+						} else {
+							if (tw & TW_IQ_NEG) valid = false;
+							cols[(1 + n) * BIND_THREADS] = mk_col(bGAP, TARGET(lj - 1));
+							n++;
+							al.lm_q = L - li + 1;
+							al.lm_t = lj - 1;
+							mask = ((tw & TW_IQ_FROM_M) ? 1 : 0) | ((tw & TW_IQ_FROM_IQ) ? 4 : 0);
+							key = cidx * 4 + 1;
+							lj--;
+						}
+					} else { // query_gap: GAP in the target strand, state I_target
+						if (li > L || li < 1 /* Q7 fence */) {
+							valid = false;
+						} else {
+							if (tw & TW_IT_NEG) valid = false;
+							cols[(1 + n) * BIND_THREADS] = mk_col(QUERY(L - li), bGAP);
+							n++;
+							al.lm_q = L - li;
+							al.lm_t = lj;
+							mask = ((tw & TW_IT_FROM_M) ? 1 : 0) | ((tw & TW_IT_FROM_IT) ? 2 : 0);
+							key = cidx * 4 + 2;
+							li--;
+						}
+					}
+					if (!valid) break;
+				}
+				al.k1 = 1 + n;
+
+				// trim frayed ends, :1022-1054
+				while (al.k1 > al.k0) {
+					const uint16_t cw = cols[(al.k1 - 1) * BIND_THREADS];
+					if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
+					if (!is_virtual(col_q(cw))) --al.lm_q;
+					if (!is_virtual(col_t(cw))) ++al.lm_t;
+					al.k1--;
+				}
+				while (al.k1 > al.k0) {
+					const uint16_t cw = cols[al.k0 * BIND_THREADS];
+					if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
+					if (!is_virtual(col_q(cw))) ++al.fm_q;
+					if (!is_virtual(col_t(cw))) --al.fm_t;
+					al.k0++;
+				}
+				// advance the branch odometer, :1058-1066
+				if (zero_count == 0 && sp > 0) {
+					while (sp > 0) {
+						uint32_t e = stack[(sp - 1) * BIND_THREADS];
+						const int m = int((e >> 16) & 15u);
+						int cb = int((e >> 20) & 15u);
+						bool more = false;
+						while ((cb = cb << 1) < 8)
+							if (cb & m) {
+								more = true;
+								break;
+							}
+						if (more) {
+							stack[(sp - 1) * BIND_THREADS] = (e & 0xFFFFFu) | (uint32_t(cb) << 20);
+							break;
+						}
+						sp--;
+					}
+					zero_count = -1;
+				}
+				// dangling ends, :1088-1137 (off by default, tntblast.h:55-56)
+				if (T.dangle5 && (al.fm_q != 0 || al.fm_t != W - 1)) {
+					int qb, tb;
+					if (al.fm_q == 0) qb = bE;
+					else qb = QUERY(--al.fm_q);
+					if (al.fm_t == W - 1) tb = bE;
+					else tb = TARGET(++al.fm_t);
+					if (al.k1 == al.k0) al.k0 = al.k1 = 1; // empty alignment: restart inside the buffer
+					al.k0--;
+					cols[al.k0 * BIND_THREADS] = mk_col(qb, tb);
+				}
+				if (T.dangle3 && (al.lm_q != L - 1 || al.lm_t != 0)) {
+					int qb, tb;
+					if (al.lm_q == L - 1) qb = bE;
+					else qb = QUERY(++al.lm_q);
+					if (al.lm_t == 0) tb = bE;
+					else tb = TARGET(--al.lm_t);
+					cols[al.k1 * BIND_THREADS] = mk_col(qb, tb);
+					al.k1++;
+				}
+				if (al.k1 - al.k0 < 3) continue; // :1148
+
+				const Score s = evaluate_alignment(c, al.k0, al.k1);
+				if (s.ok) {
+					const float local_dg = s.dH - T.temperature * s.dS;
+					if (!best_valid || local_dg < best_dg) { // :1160-1167
+						best_valid = true;
+						best_dg = local_dg;
+						best_dH = s.dH;
+						best_dS = s.dS;
+						best_tm = s.tm;
+						bi = al;
+						for (int k = al.k0; k < al.k1; k++) best[k * BIND_THREADS] = cols[k * BIND_THREADS];
+					}
+				}
+			}
+		}
+
+		// ------------------------------------------------------------------ thresholds, bind_oligo.cpp:600-714
+		const Thresh th = a.thresh[slot.thresh];
+		const float tm = best_tm;
+		const float dg = best_dH - T.temperature * best_dS; // delta_G(), nuc_cruc.h:1217
+		int status = 0;
+		if (tm < th.min_tm || tm > th.max_tm) status = 1;
+		else if (dg < th.min_dg || dg > th.max_dg) status = 2;
+
+		int a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0, loc5 = 0, loc3 = 0;
+		if (best_valid && (FULL || status == 0)) {
+			const int front_q = col_q(best[bi.k0 * BIND_THREADS]), front_t = col_t(best[bi.k0 * BIND_THREADS]);
+			const int back_q = col_q(best[(bi.k1 - 1) * BIND_THREADS]), back_t = col_t(best[(bi.k1 - 1) * BIND_THREADS]);
+			{ // anchor5_query, nuc_cruc_anchor.cpp:143-192
+				int qi = 0, ti = bi.fm_q + bi.fm_t;
+				bool go = !(front_t == bE);
+				if (front_q == bE) ti--;
+				if (ti >= W) go = false;
+				while (go) {
+					if (qi >= L || ti < 0) break;
+					if (!is_complementary(QUERY(qi), TARGET(ti))) break;
+					a5++, qi++, ti--;
+				}
+			}
+			{ // anchor3_query, nuc_cruc_anchor.cpp:249-298
+				int qi = L - 1, ti = (bi.lm_q + bi.lm_t + 1) - L;
+				bool go = !(back_t == bE);
+				if (back_q == bE) ti++;
+				if (ti >= W || ti < 0) go = false;
+				while (go) {
+					if (qi < 0 || ti >= W) break;
+					if (!is_complementary(QUERY(qi), TARGET(ti))) break;
+					a3++, qi--, ti++;
+				}
+			}
+			{ // num_mismatch_by_query / num_gap / max_contiguous_target_degen, nuc_cruc.h:389-483
+				int aligned = 0, run = 0;
+				for (int k = bi.k0; k < bi.k1; k++) {
+					const uint16_t cw = best[k * BIND_THREADS];
+					const int q = col_q(cw), t = col_t(cw);
+					if (!is_virtual(q)) {
+						if (!is_virtual(t) && !is_complementary(q, t)) mm++;
+						aligned++;
+					}
+					gap += (q == bGAP) + (t == bGAP);
+					if (t >= bM && t <= bN) {
+						run++;
+						if (run > poly) poly = run;
+					} else {
+						run = 0;
+					}
+				}
+				mm += L - aligned;
+			}
+			if (!status) {
+				if (a5 < th.clamp5) status = 3;
+				else if (a3 < th.clamp3) status = 4;
+				else if (mm > th.max_mm) status = 5;
+				else if (gap > th.max_gap) status = 6;
+				else if (poly > th.max_poly) status = 7;
+			}
+			// alignment_range (nuc_cruc_anchor.cpp:379-396) -> plus-strand footprint
+			const int qf = bi.fm_q, ql = bi.lm_q, tf = bi.lm_t, tl = bi.fm_t;
+			loc5 = loc3 = start;
+			if (minus) { // bind_oligo.cpp:721-731
+				loc5 += (stop - start - 1) - tl;
+				loc3 += (stop - start - 1) - tf;
+				loc5 -= qf;
+				loc3 += (L - 1) - ql;
+			} else { // bind_oligo.cpp:1424-1434
+				loc5 += tf;
+				loc3 += tl;
+				loc3 += qf;
+				loc5 -= (L - 1) - ql;
+			}
+		} else if (!best_valid && !status) {
+			status = 8; // SURVEY Q11 fence: no alignment is never a bind
+		}
+
+		// ------------------------------------------------------------------ output
+		char *text = nullptr;
+		int32_t res = -status;
+		BoundRec *rec = nullptr;
+		if (status == 0 && !FULL) {
+			const uint32_t slotp = atomicAdd(a.pool_count, 1u);
+			if (slotp < a.pool_cap) {
+				rec = a.pool + slotp;
+				rec->loc5 = loc5, rec->loc3 = loc3;
+				rec->tm = tm, rec->dH = best_dH, rec->dS = best_dS;
+				rec->a5 = a5, rec->a3 = a3, rec->mm = mm, rec->gap = gap;
+				text = rec->text;
+				res = int32_t(slotp);
+			} else {
+				atomicOr(a.err, ERR_POOL_OVERFLOW);
+				res = -100;
+			}
+		}
+		if (FULL) {
+			BindFull &f = a.full[idx];
+			f.status = status, f.target_start = start, f.target_stop = stop;
+			f.tm = tm, f.dH = best_dH, f.dS = best_dS, f.dg = dg;
+			f.a5 = a5, f.a3 = a3, f.mm = mm, f.gap = gap, f.poly = poly;
+			f.loc5 = loc5, f.loc3 = loc3;
+			f.q_first = bi.fm_q, f.q_last = bi.lm_q, f.t_first = bi.lm_t, f.t_last = bi.fm_t;
+			f.valid = best_valid ? 1 : 0;
+			f.dp_max = gmax;
+			f.n_max = nmax;
+			f.text[0] = 0;
+			if (best_valid) text = f.text;
+		} else {
+			a.result[idx] = res;
+		}
+
+		if (text) { // operator<<(ostream&, NucCruc), nuc_cruc_output.cpp:74-205
+			const char *bm = "ACGTI$-MRSVWYHKDBN";
+			int prefix = bi.fm_q < (W - 1 - bi.fm_t) ? bi.fm_q : (W - 1 - bi.fm_t);
+			if (prefix < 0) prefix = 0;
+			int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
+			if (suffix < 0) suffix = 0;
+			int o = 0;
+			text[o++] = '5', text[o++] = '\'', text[o++] = ' ';
+			for (int i = 0; i < prefix; i++) text[o++] = bm[QUERY(bi.fm_q - prefix + i)];
+			for (int k = bi.k0; k < bi.k1; k++) text[o++] = bm[col_q(best[k * BIND_THREADS])];
+			for (int i = 0; i < suffix; i++) text[o++] = bm[QUERY(bi.lm_q + 1 + i)];
+			text[o++] = ' ', text[o++] = '3', text[o++] = '\'', text[o++] = '\n';
+			text[o++] = ' ', text[o++] = ' ', text[o++] = ' ';
+			for (int i = 0; i < prefix; i++)
+				text[o++] = is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ';
+			for (int k = bi.k0; k < bi.k1; k++) {
+				const uint16_t cw = best[k * BIND_THREADS];
+				text[o++] = is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ';
+			}
+			for (int i = 0; i < suffix; i++)
+				text[o++] = is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ';
+			text[o++] = '\n';
+			text[o++] = '3', text[o++] = '\'', text[o++] = ' ';
+			for (int i = prefix; i > 0; i--) text[o++] = bm[TARGET(bi.fm_t + i)];
+			for (int k = bi.k0; k < bi.k1; k++) text[o++] = bm[col_t(best[k * BIND_THREADS])];
+			for (int i = 1; i <= suffix; i++) text[o++] = bm[TARGET(bi.lm_t - i)];
+			text[o++] = ' ', text[o++] = '5', text[o++] = '\'';
+			text[o] = 0;
+			if (rec) rec->text_len = o;
+		}
+#undef TRACE_AT
+#undef QUERY
+#undef TARGET
+	}
+}
+
+} // namespace tnt
+#endif

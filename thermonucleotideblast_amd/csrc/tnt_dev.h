@@ -1,0 +1,150 @@
+// tnt_dev.h -- structures shared by the host side (tnt_host.hip) and the gfx950 kernels
+// (tnt_kernels.hip).  Product code: must not include anything from oracle/.
+#ifndef TNT_DEV_H
+#define TNT_DEV_H
+
+#include <stdint.h>
+
+namespace tnt {
+
+// BASE::nucleic_acid, nuc_cruc.h:181-188
+enum : int { bA = 0, bC, bG, bT, bI, bE, bGAP, bM, bR, bS, bV, bW, bY, bH, bK, bD, bB, bN };
+constexpr int NB = 7;    // NUM_BASE
+constexpr int NBP = 49;  // NUM_BASE_PAIR
+constexpr int P_AT = bA * NB + bT, P_TA = bT * NB + bA, P_CG = bC * NB + bG, P_GC = bG * NB + bC;
+constexpr int P_GT = bG * NB + bT, P_TG = bT * NB + bG, P_EE = bE * NB + bE, P__ = bGAP * NB + bGAP;
+
+constexpr int MAX_OLIGO = 64;             // TNT_MAX_OLIGO
+constexpr int FLANK = 4;                  // NUM_FLANK_BASE, tntblast.h:76
+constexpr int MAX_WINDOW = MAX_OLIGO + 2 * FLANK;
+constexpr int MAX_COLS = MAX_OLIGO + MAX_WINDOW + 4; // longest traceback path + dangles
+constexpr int ALIGN_TEXT = 448;           // TNT_ALIGN_TEXT
+
+// trace word of one DP cell (16 bits), see bind kernel
+constexpr int TW_M_MASK = 7;      // bits 0-2: M_trace (im1_jm1=1, im1_j=2, i_jm1=4; nuc_cruc.h:62-64)
+constexpr int TW_IQ_FROM_M = 8;   // I_query_trace & im1_jm1
+constexpr int TW_IQ_FROM_IQ = 16; // I_query_trace & i_jm1
+constexpr int TW_IT_FROM_M = 32;  // I_target_trace & im1_jm1
+constexpr int TW_IT_FROM_IT = 64; // I_target_trace & im1_j
+constexpr int TW_M_NEG = 128, TW_M_ZERO = 256, TW_IQ_NEG = 512, TW_IT_NEG = 1024;
+constexpr int TW_NEWMAX = 2048, TW_EQMAX = 4096;
+
+// Thermodynamic tables resident in HBM (19 KB floats + 9.6 KB ints); delta_g is staged into LDS.
+struct Tables {
+	int32_t dg[NBP * NBP];  // update_dp_param, nuc_cruc.cpp:340-487
+	float H[NBP * NBP];     // param_H (== loop terminal H, nuc_cruc_santa_lucia.cpp:591-595)
+	float S[NBP * NBP];
+	float loop_S[513];
+	float bulge_S[513];
+	uint8_t bbp[18 * 18];   // best_base_pair LUT, nuc_cruc.cpp:14-213 (row = first argument)
+	uint8_t pad0[4];
+	float init_H, init_S, at_H, at_S, salt, asym_S, bulge_at_S;
+	float temperature;      // target_T
+	float log_na;           // logf([Na+]) computed on the host (no device logf: bit-exactness)
+	int32_t dangle5, dangle3;
+	int32_t word_size;      // hash word length k
+};
+
+// threshold cascade of bind_oligo.cpp:600-714
+struct Thresh {
+	float min_tm, max_tm, min_dg, max_dg;
+	int32_t clamp5, clamp3, max_gap, max_mm, max_poly;
+	int32_t pad[3];
+};
+
+// one (assay, role) = one oligo with its strand concentration and threshold set
+struct Slot {
+	int32_t oligo;   // unique-oligo index
+	float log_ct;    // logf(strand concentration), host computed
+	int32_t thresh;  // index into Thresh table
+	int32_t assay;   // expanded assay index (or -1)
+};
+
+// bind work item (one seed that survived the first cull)
+struct Item {
+	uint32_t target;  // target index inside the packed batch
+	uint32_t tloc;    // seed target_loc
+	uint32_t slot;    // Slot index
+	uint32_t info;    // bits 0-7 query_loc (word index), bit 8 strand (0 plus, 1 minus), bits 9-11 role group
+};
+constexpr uint32_t ITEM_MINUS = 1u << 8;
+
+// result of one bind; pool record only exists for bound items
+struct BoundRec {
+	int32_t loc5, loc3;
+	float tm, dH, dS;
+	int32_t a5, a3, mm, gap;
+	int32_t text_len;   // strlen(text)
+	int32_t pad[2];
+	char text[ALIGN_TEXT];
+};
+
+// full per-item record (unit-level API tnt_bind_batch), mirrors tnt_bind
+struct BindFull {
+	int32_t status, target_start, target_stop;
+	float tm, dH, dS, dg;
+	int32_t a5, a3, mm, gap, poly;
+	int32_t loc5, loc3;
+	int32_t q_first, q_last, t_first, t_last;
+	int32_t valid, dp_max, n_max;
+	char text[ALIGN_TEXT];
+};
+
+// per (target, assay) group of items emitted by the seed kernel in first-cull order
+struct Group {
+	uint32_t target;
+	uint32_t assay;   // expanded assay index | GROUP_* flags
+	uint32_t first;   // first item
+	uint32_t count;
+};
+constexpr uint32_t GROUP_MINUS_FIRST = 1u << 31; // bind the minus strand first (amplicon_search.cpp:131)
+constexpr uint32_t GROUP_ASSAY_MASK = (1u << 24) - 1u;
+
+// packed targets in HBM
+struct DbView {
+	const uint32_t *packed;     // 2 bits/base (code & 3), 16 bases per word, each target starts on a 16-byte boundary
+	const uint64_t *word_off;   // [n+1] first word of each target
+	const uint32_t *len;        // [n] bases
+	const uint32_t *exc_off;    // [n+1] range in the exception lists (codes > 3)
+	const uint32_t *exc_pos;    // position inside the target, ascending
+	const uint8_t *exc_code;    // seq.h code (4..17)
+	uint32_t n_targets;
+	uint32_t first_seq_index;
+};
+
+// mirrors tnt_hit (include/tnt_mi355x.h); written by the pairing kernels
+struct Hit {
+	int32_t assay_id, degen_id, seq_index;
+	int32_t amplicon_start, amplicon_stop, probe_start, probe_stop;
+	float forward_tm, reverse_tm, probe_tm;
+	float forward_dH, forward_dS, reverse_dH, reverse_dS, probe_dH, probe_dS;
+	int32_t primer_strand, probe_strand;
+	int32_t forward_primer_clamp, reverse_primer_clamp;
+	int32_t forward_mm, forward_gap, reverse_mm, reverse_gap, probe_mm, probe_gap;
+	int32_t forward_oligo, reverse_oligo;
+	int32_t has_primers, has_probe;
+	char forward_align[ALIGN_TEXT];
+	char reverse_align[ALIGN_TEXT];
+	char probe_align[ALIGN_TEXT];
+};
+
+// expanded assay as the kernels see it
+struct AssayDev {
+	int32_t id, degen_id;
+	int32_t slot_f, slot_r, slot_p; // Slot indices (or -1)
+	int32_t kind;                   // 0 PCR (amplicon), 1 padlock/MIPS, 2 probe (hybrid)
+	int32_t has_probe;
+	int32_t pad;
+};
+
+// seed-table entry: one query word of one (assay, role, strand)
+//   bits 0-6 word index, bit 7 strand (1 = minus / DNAHash::find, 0 = plus / find_complement),
+//   bits 8-9 role (0 F, 1 R, 2 P), bits 10-31 expanded assay index
+constexpr uint32_t WT_MINUS = 1u << 7;
+
+// status word set by kernels
+constexpr uint32_t ERR_SEED_OVERFLOW = 1, ERR_ITEM_OVERFLOW = 2, ERR_POOL_OVERFLOW = 4, ERR_HIT_OVERFLOW = 8,
+                   ERR_GROUP_OVERFLOW = 16, ERR_LIST_OVERFLOW = 32, ERR_STACK_OVERFLOW = 64;
+
+} // namespace tnt
+#endif

@@ -1,0 +1,1051 @@
+// tnt_host.hip -- host side of libtnt_mi355x.so: the C ABI of include/tnt_mi355x.h on top of the
+// gfx950 kernels (tnt_seed.hip.h, tnt_bind.hip.h, tnt_pair.hip.h).
+//
+// Product code.  There is NO CPU fallback: every entry point that computes needs a HIP device and
+// fails with TNT_E_DEVICE otherwise.  Nothing here includes or links anything under oracle/.
+//
+// Host-side restatements needed to set the kernels up (tables, query words) cite the reference:
+//   update_dp_param            nuc_cruc.cpp:340-487
+//   resolve_degenerate / best_base_pair   nuc_cruc.cpp:14-213
+//   build_word_list<string>    seq_hash.h:287-374
+//   strand concentrations      tntblast_local.cpp:232-234, amplicon_search.cpp:85-87, nuc_cruc.h:890-910
+//   assay dispatch             tntblast_local.cpp:559-626
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tnt_mi355x.h"
+#include "tnt_dev.h"
+#include "tnt_seed.hip.h"
+#include "tnt_bind.hip.h"
+#include "tnt_pair.hip.h"
+#include "santalucia_tables.inc"
+
+using namespace tnt;
+
+static_assert(sizeof(Hit) == sizeof(tnt_hit), "device Hit must mirror tnt_hit");
+static_assert(MAX_OLIGO == TNT_MAX_OLIGO && ALIGN_TEXT == TNT_ALIGN_TEXT && FLANK == TNT_FLANK, "ABI constants");
+
+namespace {
+
+std::string g_create_error;
+
+#define HIP_TRY(expr, ctx_err)                                                          \
+	do {                                                                                \
+		hipError_t e_ = (expr);                                                         \
+		if (e_ != hipSuccess) {                                                         \
+			(ctx_err) = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+			return TNT_E_DEVICE;                                                        \
+		}                                                                               \
+	} while (0)
+
+inline float f32(unsigned int bits)
+{
+	float f;
+	memcpy(&f, &bits, 4);
+	return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side tables
+
+int resolve(int x, int partner) // resolve_degenerate, nuc_cruc.cpp:14-201 (B falls through into N, :163-197)
+{
+	switch (x) {
+	case bM: return partner == bT ? bA : (partner == bG ? bC : bA);
+	case bR: return partner == bT ? bA : (partner == bC ? bG : bA);
+	case bS: return partner == bG ? bC : (partner == bC ? bG : bG);
+	case bV: return partner == bG ? bC : (partner == bC ? bG : bA);
+	case bW: return partner == bA ? bT : bA;
+	case bY: return partner == bG ? bC : bT;
+	case bH: return partner == bT ? bA : (partner == bG ? bC : (partner == bA ? bT : bA));
+	case bK: return partner == bC ? bG : bT;
+	case bD: return partner == bC ? bG : (partner == bT ? bA : (partner == bA ? bT : bA));
+	case bB:
+	case bN: return partner == bA ? bT : (partner == bT ? bA : (partner == bG ? bC : (partner == bC ? bG : bA)));
+	default: return x;
+	}
+}
+
+void fill_tables(Tables &T, const tnt_options &opt)
+{
+	memset(&T, 0, sizeof(T));
+	for (int k = 0; k < TNT_SL_NN_COUNT; k++) {
+		T.H[TNT_SL_NN[k][0]] = f32(TNT_SL_NN[k][1]);
+		T.S[TNT_SL_NN[k][0]] = f32(TNT_SL_NN[k][2]);
+	}
+	for (int i = 0; i < 513; i++) {
+		T.loop_S[i] = f32(TNT_SL_LOOP_S[i]);
+		T.bulge_S[i] = f32(TNT_SL_BULGE_S[i]);
+	}
+	T.init_H = f32(TNT_SL_INIT_H);
+	T.init_S = f32(TNT_SL_INIT_S);
+	T.at_H = f32(TNT_SL_AT_CLOSING_H);
+	T.at_S = f32(TNT_SL_AT_CLOSING_S);
+	T.salt = f32(TNT_SL_SALT);
+	T.asym_S = f32(TNT_SL_ASYM_LOOP_S);
+	T.bulge_at_S = f32(TNT_SL_BULGE_AT_S);
+	T.temperature = opt.target_t;
+	T.log_na = logf(opt.salt);
+	T.dangle5 = opt.allow_dangle_5 ? 1 : 0;
+	T.dangle3 = opt.allow_dangle_3 ? 1 : 0;
+	T.word_size = opt.hash_word_size;
+	for (int x = 0; x < 18; x++)
+		for (int y = 0; y < 18; y++) T.bbp[x * 18 + y] = uint8_t(resolve(x, y) * NB + resolve(y, x));
+
+	// update_dp_param, nuc_cruc.cpp:340-487; supplementary parameters nuc_cruc.cpp:271-300
+	bool wc[NBP];
+	memset(wc, 0, sizeof(wc));
+	wc[P_AT] = wc[P_TA] = wc[P_CG] = wc[P_GC] = true;
+	for (int b = bA; b <= bI; b++) wc[b * NB + bI] = wc[bI * NB + b] = true;
+	const float Tk = opt.target_t;
+	const float salt_correction = T.salt * logf(opt.salt);
+	const float loop_sc = salt_correction * 3.08f, bulge_sc = salt_correction * 0.69f;
+	const float tmatch_sc = salt_correction * 0.56f, tmis_sc = salt_correction * 1.31f;
+	auto scale = [](float x) { return int32_t(x * 10000.0f); };
+	for (int i = 0; i < NBP * NBP; i++) T.dg[i] = scale(T.H[i] - Tk * (T.S[i] + salt_correction));
+	const int32_t v_at = std::max(0, scale(-4.474f - Tk * (-2.091e-2f + tmatch_sc)));
+	const int32_t v_gc = std::max(0, scale(-3.000f - Tk * (-1.318e-2f + tmatch_sc)));
+	const int32_t v_mm = std::max(0, scale(-2.421f - Tk * (-1.180e-2f + tmis_sc)));
+	const int32_t v_loop = std::max(0, scale(-5.779f - Tk * (-2.330e-2f + loop_sc)));
+	const int32_t v_bulge = std::max(0, scale(5.247e-1f - Tk * (3.318e-4f + bulge_sc)));
+	for (int i = bA; i <= bI; i++)
+		for (int j = bA; j <= bI; j++) {
+			const int cur = i * NB + j;
+			const int32_t v = !wc[cur] ? v_mm : ((cur == P_GC || cur == P_CG) ? v_gc : v_at); // inosine pairs == AT (:289-290)
+			for (int k = bA; k <= bI; k++) {
+				const int p1 = k * NB + bGAP, p2 = bGAP * NB + k;
+				T.dg[cur * NBP + p1] = T.dg[p1 * NBP + cur] = T.dg[cur * NBP + p2] = T.dg[p2 * NBP + cur] = v;
+			}
+			for (int k = bA; k <= bI; k++)
+				for (int l = bA; l <= bI; l++)
+					if (!wc[cur] && !wc[k * NB + l]) T.dg[cur * NBP + k * NB + l] = v_loop;
+		}
+	for (int i = bA; i <= bI; i++)
+		for (int j = bA; j <= bI; j++) {
+			T.dg[(i * NB + bGAP) * NBP + (j * NB + bGAP)] = v_bulge;
+			T.dg[(bGAP * NB + i) * NBP + (bGAP * NB + j)] = v_bulge;
+		}
+}
+
+int char_to_base(char c) // expanded oligos only: A C G T I (degenerate_na.cpp:81-133 expands the rest)
+{
+	switch (c) {
+	case 'A': case 'a': return bA;
+	case 'C': case 'c': return bC;
+	case 'G': case 'g': return bG;
+	case 'T': case 't': return bT;
+	case 'I': case 'i': return bI;
+	default: return -1;
+	}
+}
+
+// build_word_list<std::string>, seq_hash.h:287-374, in the packed stream's little-endian word convention
+// (first base of the k-mer in the lowest two bits)
+std::vector<uint16_t> word_list(const std::string &oligo, bool complement, int k)
+{
+	std::vector<uint16_t> w;
+	if (size_t(k) > oligo.size()) return w;
+	const uint32_t wmask = (1u << (2 * k)) - 1u;
+	uint32_t word = 0;
+	size_t run = 0;
+	const long n = long(oligo.size());
+	for (long s = 0; s < n; s++) {
+		const char c = complement ? oligo[n - 1 - s] : oligo[s];
+		int b = -1;
+		switch (c) {
+		case 'A': case 'a': b = complement ? 3 : 0; break;
+		case 'T': case 't': b = complement ? 0 : 3; break;
+		case 'C': case 'c': b = complement ? 2 : 1; break;
+		case 'G': case 'g': b = complement ? 1 : 2; break;
+		default: break;
+		}
+		++run;
+		if (b >= 0) word = (word >> 2) | (uint32_t(b) << (2 * (k - 1)));
+		else run = 0;
+		if (run >= size_t(k)) w.push_back(uint16_t(word & wmask));
+	}
+	return w;
+}
+
+// minimal parallel-for on std::thread (host packing only; no OpenMP runtime dependency)
+template <class F> void parallel_for(size_t n, F f)
+{
+	const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	if (n < 4096 || hw == 1) {
+		for (size_t i = 0; i < n; i++) f(i);
+		return;
+	}
+	std::vector<std::thread> th;
+	const size_t per = (n + hw - 1) / hw;
+	for (unsigned w = 0; w < hw; w++) {
+		const size_t b = w * per, e = std::min(n, b + per);
+		if (b >= e) break;
+		th.emplace_back([=]() {
+			for (size_t i = b; i < e; i++) f(i);
+		});
+	}
+	for (auto &t : th) t.join();
+}
+
+template <class T> struct DevBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	hipError_t alloc(size_t count)
+	{
+		release();
+		n = count;
+		return hipMalloc((void **)&p, std::max<size_t>(1, count) * sizeof(T));
+	}
+	hipError_t upload(const std::vector<T> &v)
+	{
+		hipError_t e = alloc(v.size());
+		if (e != hipSuccess) return e;
+		if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+		return e;
+	}
+	void release()
+	{
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		n = 0;
+	}
+	~DevBuf() { release(); }
+};
+
+} // namespace
+
+struct tnt_db {
+	tnt_ctx *ctx = nullptr;
+	std::vector<uint32_t> h_packed; // host copy (tnt_hit_sequence)
+	std::vector<uint64_t> h_word_off;
+	std::vector<uint32_t> h_len, h_exc_off, h_exc_pos;
+	std::vector<uint8_t> h_exc_code;
+	DevBuf<uint32_t> packed, len, exc_off, exc_pos;
+	DevBuf<uint64_t> word_off;
+	DevBuf<uint8_t> exc_code;
+	size_t n_targets = 0;
+	uint64_t n_bases = 0;
+	uint32_t max_len = 0;
+	uint32_t first_seq_index = 0;
+};
+
+struct tnt_ctx {
+	std::string err;
+	int device = 0;
+	tnt_options opt;
+	hipStream_t stream = nullptr;
+
+	std::vector<std::string> oligos;
+	std::vector<AssayDev> h_assays;
+	std::vector<Slot> h_slots;
+	std::vector<float> h_slot_ct;
+	int lmax = 24; // template instance of the bind kernel
+	size_t n_entries = 0;
+	std::vector<uint32_t> chunk_begin; // assay chunks for the seed kernel (+ end)
+
+	Tables h_tab;
+	DevBuf<Tables> tab;
+	DevBuf<uint8_t> olig_base;
+	DevBuf<uint32_t> olig_rev;
+	DevBuf<int32_t> olig_len;
+	DevBuf<Slot> slots;
+	DevBuf<Thresh> thresh;
+	DevBuf<AssayDev> assays;
+	DevBuf<uint32_t> wt_off, wt_ent, wl_off;
+	DevBuf<uint16_t> wlist;
+
+	// work buffers
+	DevBuf<Item> items;
+	DevBuf<int32_t> result;
+	DevBuf<Group> groups;
+	DevBuf<uint32_t> active;
+	DevBuf<BoundRec> pool;
+	DevBuf<Hit> hits;
+	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
+	DevBuf<uint16_t> trace, cols, best;
+	DevBuf<uint32_t> stack;
+	DevBuf<SeedOut> seeds_out;
+	int bind_blocks = 0;
+
+	std::vector<tnt_hit> h_hits;
+	std::vector<tnt_seed> h_seeds;
+	tnt_timing timing;
+	std::vector<hipEvent_t> events;
+	size_t n_batches = 0;
+	uint64_t acc_items = 0, acc_bound = 0;
+	bool pending = false;
+
+	~tnt_ctx()
+	{
+		for (hipEvent_t e : events) (void)hipEventDestroy(e);
+		if (stream) (void)hipStreamDestroy(stream);
+	}
+};
+
+namespace {
+
+enum { C_ITEMS = 0, C_GROUPS, C_POOL, C_HITS, C_ERR, C_SEEDS, C_ACTIVE, C_COUNT = 8 };
+
+constexpr size_t ITEM_CAP = size_t(96) << 20;  // bind work items per internal batch
+constexpr size_t GROUP_CAP = size_t(64) << 20;
+constexpr size_t POOL_CAP = size_t(4) << 20;
+constexpr size_t HIT_CAP = size_t(1) << 20;
+
+DbView make_view(const tnt_db *db, size_t t0, size_t t1)
+{
+	DbView v;
+	v.packed = db->packed.p;
+	v.word_off = db->word_off.p + t0;
+	v.len = db->len.p + t0;
+	v.exc_off = db->exc_off.p + t0;
+	v.exc_pos = db->exc_pos.p;
+	v.exc_code = db->exc_code.p;
+	v.n_targets = uint32_t(t1 - t0);
+	v.first_seq_index = db->first_seq_index + uint32_t(t0);
+	return v;
+}
+
+template <bool FULL> void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks)
+{
+	switch (c->lmax) {
+	case 24: hipLaunchKernelGGL((bind_kernel<24, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
+	case 32: hipLaunchKernelGGL((bind_kernel<32, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
+	case 48: hipLaunchKernelGGL((bind_kernel<48, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
+	default: hipLaunchKernelGGL((bind_kernel<64, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
+	}
+}
+
+int ensure_work_buffers(tnt_ctx *c)
+{
+	if (c->items.p) return TNT_OK;
+	HIP_TRY(c->items.alloc(ITEM_CAP), c->err);
+	HIP_TRY(c->result.alloc(ITEM_CAP), c->err);
+	HIP_TRY(c->groups.alloc(GROUP_CAP), c->err);
+	HIP_TRY(c->active.alloc(GROUP_CAP), c->err);
+	HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
+	HIP_TRY(c->hits.alloc(HIT_CAP), c->err);
+	HIP_TRY(c->counters.alloc(C_COUNT), c->err);
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, c->device), c->err);
+	c->bind_blocks = prop.multiProcessorCount * 4;
+	const size_t lm = size_t(c->lmax), wm = lm + 2 * FLANK, nc = lm + wm + 4;
+	HIP_TRY(c->trace.alloc(size_t(c->bind_blocks) * lm * wm * BIND_THREADS), c->err);
+	HIP_TRY(c->cols.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
+	HIP_TRY(c->best.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
+	HIP_TRY(c->stack.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
+	return TNT_OK;
+}
+
+BindArgs bind_args(tnt_ctx *c, const DbView &v)
+{
+	BindArgs a;
+	memset(&a, 0, sizeof(a));
+	a.tab = c->tab.p;
+	a.db = v;
+	a.olig_base = c->olig_base.p;
+	a.olig_rev = c->olig_rev.p;
+	a.olig_len = c->olig_len.p;
+	a.slots = c->slots.p;
+	a.thresh = c->thresh.p;
+	a.items = c->items.p;
+	a.result = c->result.p;
+	a.pool = c->pool.p;
+	a.pool_cap = uint32_t(POOL_CAP);
+	a.pool_count = c->counters.p + C_POOL;
+	a.trace = c->trace.p;
+	a.cols = c->cols.p;
+	a.best = c->best.p;
+	a.stack = c->stack.p;
+	a.err = c->counters.p + C_ERR;
+	return a;
+}
+
+const char *err_text(uint32_t e)
+{
+	if (e & ERR_SEED_OVERFLOW) return "seed list of one target overflowed the LDS buffer (target too long for this assay chunk)";
+	if (e & ERR_ITEM_OVERFLOW) return "bind work-item buffer overflow";
+	if (e & ERR_POOL_OVERFLOW) return "bound-oligo pool overflow";
+	if (e & ERR_HIT_OVERFLOW) return "hit buffer overflow";
+	if (e & ERR_GROUP_OVERFLOW) return "group buffer overflow";
+	if (e & ERR_LIST_OVERFLOW) return "more than 64 seeds for one (target, assay)";
+	if (e & ERR_STACK_OVERFLOW) return "traceback branch stack overflow";
+	return "unknown device error";
+}
+
+} // namespace
+
+extern "C" {
+
+int tnt_abi_version(void) { return TNT_ABI_VERSION; }
+
+void tnt_options_default(tnt_options *o) // options.h:85-170, tntblast.h:19-76
+{
+	memset(o, 0, sizeof(*o));
+	o->min_primer_tm = 0.0f, o->max_primer_tm = 9999.0f;
+	o->min_primer_dg = -9999.0f, o->max_primer_dg = 0.0f;
+	o->min_probe_tm = 0.0f, o->max_probe_tm = 9999.0f;
+	o->min_probe_dg = -9999.0f, o->max_probe_dg = 0.0f;
+	o->salt = 50.0e-3f;
+	o->primer_strand = 9.0e-7f;
+	o->probe_strand = 2.5e-7f;
+	o->asymmetric_strand_ratio = 1.0f;
+	o->target_t = 310.15f;
+	o->primer_clamp = 0;
+	o->min_max_primer_clamp = -1;
+	o->max_gap = o->max_mismatch = 999;
+	o->max_poly_degen = 3;
+	o->max_len = 2000;
+	o->assay_format = TNT_ASSAY_PCR;
+	o->target_strand = TNT_STRAND_BOTH;
+	o->hash_word_size = 7;
+	o->single_primer_pcr = 1;
+}
+
+const char *tnt_last_error(const tnt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_assays, int device, tnt_ctx **out)
+{
+	if (!opt || !out || (!assays && n_assays)) {
+		g_create_error = "null argument";
+		return TNT_E_ARG;
+	}
+	if (opt->hash_word_size < 3 || opt->hash_word_size > 8) {
+		g_create_error = "hash word size must be 3..8 (options.cpp -W)";
+		return TNT_E_ARG;
+	}
+	if (opt->use_dinkelbach) {
+		g_create_error = "--dinkelbach is not implemented on the GPU path";
+		return TNT_E_UNSUPPORTED;
+	}
+	if (!(opt->salt >= 1.0e-6f && opt->salt <= 1.0f)) { // NucCruc::salt, nuc_cruc.h:852-867
+		g_create_error = "[Na+] out of range";
+		return TNT_E_ARG;
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+		g_create_error = "no usable HIP device (this library has no CPU fallback)";
+		return TNT_E_DEVICE;
+	}
+	tnt_ctx *c = new tnt_ctx;
+	c->device = device;
+	c->opt = *opt;
+	memset(&c->timing, 0, sizeof(c->timing));
+	std::string &err = g_create_error;
+#define FAIL(code, msg)   \
+	do {                  \
+		err = (msg);      \
+		delete c;         \
+		return (code);    \
+	} while (0)
+	if (hipSetDevice(device) != hipSuccess) FAIL(TNT_E_DEVICE, "hipSetDevice failed");
+	if (hipStreamCreate(&c->stream) != hipSuccess) FAIL(TNT_E_DEVICE, "hipStreamCreate failed");
+
+	// ---- unique oligos
+	std::map<std::string, int> index;
+	auto intern = [&](const char *s) -> int {
+		if (!s) return -1;
+		auto it = index.find(s);
+		if (it != index.end()) return it->second;
+		const int id = int(c->oligos.size());
+		index[s] = id;
+		c->oligos.push_back(s);
+		return id;
+	};
+	// ---- slots and thresholds
+	std::vector<Thresh> th(4);
+	auto mk = [&](float a, float b, float cc, float d, int c5, int c3) {
+		Thresh t;
+		memset(&t, 0, sizeof(t));
+		t.min_tm = a, t.max_tm = b, t.min_dg = cc, t.max_dg = d, t.clamp5 = c5, t.clamp3 = c3;
+		t.max_gap = opt->max_gap, t.max_mm = opt->max_mismatch, t.max_poly = opt->max_poly_degen;
+		return t;
+	};
+	th[0] = mk(opt->min_primer_tm, opt->max_primer_tm, opt->min_primer_dg, opt->max_primer_dg, 0, opt->primer_clamp);
+	th[1] = mk(opt->min_probe_tm, opt->max_probe_tm, opt->min_probe_dg, opt->max_probe_dg, opt->probe_clamp_5, opt->probe_clamp_3);
+	th[2] = mk(opt->min_probe_tm, opt->max_probe_tm, opt->min_probe_dg, opt->max_probe_dg, opt->probe_clamp_5, 0); // padlock upstream
+	th[3] = mk(opt->min_probe_tm, opt->max_probe_tm, opt->min_probe_dg, opt->max_probe_dg, 0, opt->probe_clamp_3); // padlock downstream
+
+	const float fwd_strand = opt->asymmetric_strand_ratio * opt->primer_strand; // tntblast_local.cpp:232-234
+	const float rev_strand = opt->primer_strand;
+
+	size_t max_L = 0;
+	for (size_t i = 0; i < n_assays; i++) {
+		const tnt_assay &A = assays[i];
+		AssayDev d;
+		memset(&d, 0, sizeof(d));
+		d.id = A.id, d.degen_id = A.degen_id;
+		d.slot_f = d.slot_r = d.slot_p = -1;
+		const bool primers = A.forward && A.reverse;
+		if (!primers && !A.probe) FAIL(TNT_E_ARG, "assay without oligos");
+		if (primers && (A.forward_degen <= 0 || A.reverse_degen <= 0)) FAIL(TNT_E_ARG, "degeneracy divisor must be >= 1");
+		if (A.probe && A.probe_degen <= 0) FAIL(TNT_E_ARG, "degeneracy divisor must be >= 1");
+		// dispatch, tntblast_local.cpp:559-626
+		if (primers) {
+			if (opt->assay_format == TNT_ASSAY_PCR) d.kind = 0;
+			else if (opt->assay_format == TNT_ASSAY_PADLOCK || opt->assay_format == TNT_ASSAY_MIPS) d.kind = 1;
+			else d.kind = -1; // the reference's switch has no case: no results
+		} else {
+			d.kind = 2;
+		}
+		d.has_probe = (primers && A.probe && d.kind == 0) ? 1 : 0;
+		auto add_slot = [&](const char *s, float ct, int thr) -> int {
+			const int o = intern(s);
+			Slot sl;
+			sl.oligo = o;
+			sl.log_ct = logf(ct * 1.0f); // nuc_cruc.cpp:2291 with heterodimer_inv_alpha = 1
+			sl.thresh = thr;
+			sl.assay = int(i);
+			c->h_slots.push_back(sl);
+			c->h_slot_ct.push_back(ct);
+			return int(c->h_slots.size()) - 1;
+		};
+		if (primers && d.kind >= 0) {
+			// strand(c, 0) = c - 0.5f*0 (nuc_cruc.h:890-910)
+			const float fs = fwd_strand / A.forward_degen - 0.5f * 0.0f, rs = rev_strand / A.reverse_degen - 0.5f * 0.0f;
+			d.slot_f = add_slot(A.forward, fs, d.kind == 0 ? 0 : 3);
+			d.slot_r = add_slot(A.reverse, rs, d.kind == 0 ? 0 : 2);
+		}
+		if (A.probe && (d.kind == 2 || d.has_probe)) {
+			const float ps = opt->probe_strand / A.probe_degen;
+			d.slot_p = add_slot(A.probe, ps, 1);
+		}
+		c->h_assays.push_back(d);
+	}
+	for (const std::string &o : c->oligos) {
+		if (o.size() > size_t(TNT_MAX_OLIGO)) FAIL(TNT_E_LIMIT, "oligo longer than TNT_MAX_OLIGO (64) bases");
+		if (o.empty()) FAIL(TNT_E_ARG, "empty oligo");
+		for (char ch : o)
+			if (char_to_base(ch) < 0) FAIL(TNT_E_ARG, "oligos must be expanded to A/C/G/T/I (expand_degenerate_signatures)");
+		max_L = std::max(max_L, o.size());
+	}
+	c->lmax = max_L <= 24 ? 24 : (max_L <= 32 ? 32 : (max_L <= 48 ? 48 : 64));
+
+	// ---- tables
+	fill_tables(c->h_tab, *opt);
+	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
+	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 8), 0);
+	std::vector<int32_t> ol(std::max<size_t>(1, c->oligos.size()), 0);
+	for (size_t i = 0; i < c->oligos.size(); i++) {
+		const std::string &o = c->oligos[i];
+		const int L = int(o.size());
+		ol[i] = L;
+		for (int k = 0; k < L; k++) {
+			ob[i * MAX_OLIGO + k] = uint8_t(char_to_base(o[k]));
+			const uint32_t b = uint32_t(char_to_base(o[L - 1 - k])); // row k+1 of the DP uses query[L-(k+1)]
+			orv[i * (MAX_OLIGO / 8) + (k >> 3)] |= b << ((k & 7) * 4);
+		}
+	}
+
+	// ---- inverted query-word table
+	const int k = opt->hash_word_size;
+	const size_t n_words = size_t(1) << (2 * k);
+	std::vector<uint32_t> wl_off(c->h_assays.size() * 6 + 1, 0);
+	std::vector<uint16_t> wlist;
+	std::vector<std::vector<uint32_t>> buckets(n_words);
+	std::vector<size_t> entries_per_assay(c->h_assays.size(), 0);
+	for (size_t ai = 0; ai < c->h_assays.size(); ai++) {
+		const AssayDev &d = c->h_assays[ai];
+		const int slots3[3] = {d.slot_f, d.slot_r, d.slot_p};
+		for (int role = 0; role < 3; role++)
+			for (int minus = 0; minus < 2; minus++) {
+				const size_t li = (ai * 3 + role) * 2 + minus;
+				wl_off[li] = uint32_t(wlist.size());
+				if (slots3[role] < 0) continue;
+				// PCR binds both strands; probes and padlocks honour --target-strand (probe_search.cpp:93,163,
+				// padlock_search.cpp:97,238)
+				if (d.kind != 0 && !(opt->target_strand & (minus ? TNT_STRAND_MINUS : TNT_STRAND_PLUS))) continue;
+				const std::string &o = c->oligos[c->h_slots[slots3[role]].oligo];
+				const std::vector<uint16_t> w = word_list(o, minus == 0, k); // plus strand: find_complement
+				if (w.size() > 127) FAIL(TNT_E_LIMIT, "too many query words");
+				if (ai >= (size_t(1) << 22)) FAIL(TNT_E_LIMIT, "too many assays");
+				for (size_t wi = 0; wi < w.size(); wi++) {
+					buckets[w[wi]].push_back(uint32_t(wi) | (minus ? WT_MINUS : 0u) | (uint32_t(role) << 8) | (uint32_t(ai) << 10));
+					wlist.push_back(w[wi]);
+				}
+				entries_per_assay[ai] += w.size();
+			}
+	}
+	wl_off[c->h_assays.size() * 6] = uint32_t(wlist.size());
+	std::vector<uint32_t> wt_off(n_words + 1, 0), wt_ent;
+	for (size_t w = 0; w < n_words; w++) {
+		wt_off[w] = uint32_t(wt_ent.size());
+		wt_ent.insert(wt_ent.end(), buckets[w].begin(), buckets[w].end());
+	}
+	wt_off[n_words] = uint32_t(wt_ent.size());
+	c->n_entries = wt_ent.size();
+	(void)entries_per_assay;
+
+	hipError_t e = hipSuccess;
+	std::vector<Tables> tv(1, c->h_tab);
+	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
+	    (e = c->olig_rev.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
+	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
+	    (e = c->assays.upload(c->h_assays)) != hipSuccess || (e = c->wt_off.upload(wt_off)) != hipSuccess ||
+	    (e = c->wt_ent.upload(wt_ent)) != hipSuccess || (e = c->wl_off.upload(wl_off)) != hipSuccess ||
+	    (e = c->wlist.upload(wlist)) != hipSuccess)
+		FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
+#undef FAIL
+	*out = c;
+	return TNT_OK;
+}
+
+void tnt_ctx_destroy(tnt_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	delete ctx;
+}
+
+int tnt_ctx_num_oligos(const tnt_ctx *ctx) { return ctx ? int(ctx->oligos.size()) : 0; }
+const char *tnt_ctx_oligo(const tnt_ctx *ctx, int i)
+{
+	return (ctx && i >= 0 && i < int(ctx->oligos.size())) ? ctx->oligos[i].c_str() : nullptr;
+}
+
+int tnt_ctx_delta_g(const tnt_ctx *ctx, int32_t *out2401)
+{
+	if (!ctx || !out2401) return TNT_E_ARG;
+	// read back what the kernels actually use
+	Tables *t = new Tables;
+	const hipError_t e = hipMemcpy(t, ctx->tab.p, sizeof(Tables), hipMemcpyDeviceToHost);
+	if (e == hipSuccess) memcpy(out2401, t->dg, sizeof(t->dg));
+	delete t;
+	return e == hipSuccess ? TNT_OK : TNT_E_DEVICE;
+}
+
+int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, size_t n_targets, uint32_t first_seq_index,
+                  tnt_db **out)
+{
+	if (!ctx || !out || !offsets || (!codes && n_targets && offsets[n_targets] > 0)) return TNT_E_ARG;
+	(void)hipSetDevice(ctx->device);
+	tnt_db *db = new tnt_db;
+	db->ctx = ctx;
+	db->n_targets = n_targets;
+	db->first_seq_index = first_seq_index;
+	db->h_word_off.resize(n_targets + 1);
+	db->h_len.resize(std::max<size_t>(1, n_targets));
+	db->h_exc_off.assign(n_targets + 1, 0);
+	uint64_t words = 0;
+	for (size_t t = 0; t < n_targets; t++) {
+		const uint64_t len = offsets[t + 1] - offsets[t];
+		if (offsets[t + 1] < offsets[t] || len >= (uint64_t(1) << 31)) {
+			ctx->err = "bad target offsets";
+			delete db;
+			return TNT_E_ARG;
+		}
+		db->h_word_off[t] = words;
+		db->h_len[t] = uint32_t(len);
+		db->max_len = std::max(db->max_len, uint32_t(len));
+		db->n_bases += len;
+		words += ((len + 15) / 16 + 3) / 4 * 4; // 16-byte aligned rows: a wavefront reads whole dwordx4 lines
+	}
+	db->h_word_off[n_targets] = words;
+	db->h_packed.assign(words + 4, 0u);
+	// exceptions: count first (codes > 3 keep their low two bits in the stream)
+	std::vector<uint32_t> exc_count(n_targets + 1, 0);
+	parallel_for(n_targets, [&](size_t t) {
+		const uint8_t *s = codes + offsets[t];
+		const uint32_t len = db->h_len[t];
+		uint32_t *pk = db->h_packed.data() + db->h_word_off[t];
+		uint32_t ne = 0;
+		for (uint32_t i = 0; i < len; i++) {
+			const uint8_t cde = s[i];
+			pk[i >> 4] |= uint32_t(cde & 3u) << ((i & 15u) * 2u);
+			ne += cde > 3;
+		}
+		exc_count[t] = ne;
+	});
+	for (size_t t = 0; t < n_targets; t++) db->h_exc_off[t + 1] = db->h_exc_off[t] + exc_count[t];
+	db->h_exc_pos.resize(std::max<size_t>(1, db->h_exc_off[n_targets]));
+	db->h_exc_code.resize(std::max<size_t>(1, db->h_exc_off[n_targets]));
+	parallel_for(n_targets, [&](size_t t) {
+		if (!exc_count[t]) return;
+		const uint8_t *s = codes + offsets[t];
+		uint32_t o = db->h_exc_off[t];
+		for (uint32_t i = 0; i < db->h_len[t]; i++)
+			if (s[i] > 3) {
+				db->h_exc_pos[o] = i;
+				db->h_exc_code[o] = s[i] > 17 ? uint8_t(17) : s[i];
+				o++;
+			}
+	});
+	hipError_t e;
+	if ((e = db->packed.upload(db->h_packed)) != hipSuccess || (e = db->word_off.upload(db->h_word_off)) != hipSuccess ||
+	    (e = db->len.upload(db->h_len)) != hipSuccess || (e = db->exc_off.upload(db->h_exc_off)) != hipSuccess ||
+	    (e = db->exc_pos.upload(db->h_exc_pos)) != hipSuccess || (e = db->exc_code.upload(db->h_exc_code)) != hipSuccess) {
+		ctx->err = std::string("target upload: ") + hipGetErrorString(e);
+		delete db;
+		return TNT_E_DEVICE;
+	}
+	*out = db;
+	return TNT_OK;
+}
+
+void tnt_db_destroy(tnt_db *db)
+{
+	if (!db) return;
+	if (db->ctx) {
+		(void)hipSetDevice(db->ctx->device);
+		(void)hipStreamSynchronize(db->ctx->stream);
+	}
+	delete db;
+}
+
+size_t tnt_db_num_targets(const tnt_db *db) { return db ? db->n_targets : 0; }
+uint64_t tnt_db_num_bases(const tnt_db *db) { return db ? db->n_bases : 0; }
+
+// One internal batch: seed -> bind -> filter -> pair, all on the context stream.
+static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seeds_only)
+{
+	const DbView v = make_view(db, t0, t1);
+	uint32_t *cnt = c->counters.p;
+	// hits and the error word accumulate over batches; the rest restarts
+	HIP_TRY(hipMemsetAsync(cnt + C_ITEMS, 0, sizeof(uint32_t) * 3, c->stream), c->err);
+	HIP_TRY(hipMemsetAsync(cnt + C_ACTIVE, 0, sizeof(uint32_t), c->stream), c->err);
+
+	hipEvent_t ev[4];
+	for (int i = 0; i < 4; i++) {
+		HIP_TRY(hipEventCreate(&ev[i]), c->err);
+		c->events.push_back(ev[i]);
+	}
+	HIP_TRY(hipEventRecord(ev[0], c->stream), c->err);
+
+	SeedArgs s;
+	memset(&s, 0, sizeof(s));
+	s.db = v;
+	s.word_size = c->opt.hash_word_size;
+	s.wt_off = c->wt_off.p;
+	s.wt_ent = c->wt_ent.p;
+	s.wlist = c->wlist.p;
+	s.wl_off = c->wl_off.p;
+	s.assays = c->assays.p;
+	s.max_len = c->opt.max_len;
+	s.single_primer_pcr = c->opt.single_primer_pcr;
+	if (!seeds_only) {
+		s.items = c->items.p;
+		s.item_cap = uint32_t(ITEM_CAP);
+		s.item_count = cnt + C_ITEMS;
+		s.groups = c->groups.p;
+		s.group_cap = uint32_t(GROUP_CAP);
+		s.group_count = cnt + C_GROUPS;
+	} else {
+		s.seeds_out = c->seeds_out.p;
+		s.seeds_cap = uint32_t(c->seeds_out.n);
+		s.seeds_count = cnt + C_SEEDS;
+	}
+	s.err = cnt + C_ERR;
+	const int seed_blocks = int(std::min<size_t>(t1 - t0, size_t(c->bind_blocks) * 8));
+	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
+		s.assay_begin = c->chunk_begin[ch];
+		s.assay_end = c->chunk_begin[ch + 1];
+		hipLaunchKernelGGL(seed_kernel, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
+	}
+	HIP_TRY(hipEventRecord(ev[1], c->stream), c->err);
+	if (seeds_only) return TNT_OK;
+
+	BindArgs b = bind_args(c, v);
+	b.n_items = 0; // read from the device counter
+	b.n_items_dev = cnt + C_ITEMS;
+	launch_bind<false>(c, b, c->bind_blocks);
+	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
+
+	FilterArgs f;
+	f.groups = c->groups.p;
+	f.n_groups = cnt + C_GROUPS;
+	f.result = c->result.p;
+	f.active = c->active.p;
+	f.n_active = cnt + C_ACTIVE;
+	hipLaunchKernelGGL(filter_kernel, dim3(c->bind_blocks * 4), dim3(256), 0, c->stream, f);
+
+	PairArgs p;
+	memset(&p, 0, sizeof(p));
+	p.groups = c->groups.p;
+	p.active = c->active.p;
+	p.n_active = cnt + C_ACTIVE;
+	p.items = c->items.p;
+	p.result = c->result.p;
+	p.pool = c->pool.p;
+	p.assays = c->assays.p;
+	p.db = v;
+	p.max_len = c->opt.max_len;
+	p.single_primer_pcr = c->opt.single_primer_pcr;
+	p.min_max_primer_clamp = c->opt.min_max_primer_clamp;
+	p.assay_format = c->opt.assay_format;
+	p.target_strand = c->opt.target_strand;
+	p.hits = c->hits.p;
+	p.hit_cap = uint32_t(HIT_CAP);
+	p.hit_count = cnt + C_HITS;
+	p.err = cnt + C_ERR;
+	hipLaunchKernelGGL(pair_kernel, dim3(256), dim3(PAIR_THREADS), 0, c->stream, p);
+	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
+	HIP_TRY(hipGetLastError(), c->err);
+	return TNT_OK;
+}
+
+// Assay chunks for the seed kernel and target batches sized so the expected number of seeds fits.
+static void plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
+{
+	const double words = double(size_t(1) << (2 * c->opt.hash_word_size));
+	const double per_base = double(c->n_entries) / words; // expected raw seeds per target base
+	const double maxlen = std::max<double>(1.0, db->max_len);
+	// chunk so that a target of the longest length yields <= SEED_CAP/2 seeds on average
+	size_t n_assays = c->h_assays.size();
+	double ent_per_assay = n_assays ? double(c->n_entries) / double(n_assays) : 1.0;
+	size_t per_chunk = size_t(std::max(1.0, (SEED_CAP / 2) * words / (maxlen * std::max(1.0, ent_per_assay))));
+	per_chunk = std::min<size_t>(per_chunk, SEED_MAX_ASSAYS);
+	c->chunk_begin.clear();
+	for (size_t a = 0; a < n_assays; a += per_chunk) c->chunk_begin.push_back(uint32_t(a));
+	c->chunk_begin.push_back(uint32_t(n_assays));
+	// batch of targets: expected kept seeds (<= raw) must stay below ITEM_CAP / 2
+	const double avg_len = db->n_targets ? double(db->n_bases) / double(db->n_targets) : 1.0;
+	const double per_target = std::max(1.0, per_base * avg_len);
+	double tb = (double(ITEM_CAP) / 2.0) / per_target;
+	const double gb = (double(GROUP_CAP) / 2.0) / std::max<double>(1.0, double(n_assays));
+	tb = std::min(tb, gb);
+	targets_per_batch = size_t(std::max(1.0, std::min(tb, double(std::max<size_t>(1, db->n_targets)))));
+}
+
+int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
+{
+	if (!ctx || !db || db->ctx != ctx) return TNT_E_ARG;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx);
+	if (rc) return rc;
+	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+	ctx->events.clear();
+	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	size_t tpb = 1;
+	plan(ctx, db, tpb);
+	ctx->n_batches = 0;
+	for (size_t t0 = 0; t0 < db->n_targets; t0 += tpb) {
+		rc = enqueue_batch(ctx, db, t0, std::min(db->n_targets, t0 + tpb), false);
+		if (rc) return rc;
+		ctx->n_batches++;
+	}
+	ctx->pending = true;
+	return TNT_OK;
+}
+
+int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
+{
+	if (!ctx || !ctx->pending) return TNT_E_ARG;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	uint32_t cnt[C_COUNT];
+	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	ctx->pending = false;
+	if (cnt[C_ERR]) {
+		ctx->err = err_text(cnt[C_ERR]);
+		return TNT_E_LIMIT;
+	}
+	const size_t n = std::min<size_t>(cnt[C_HITS], HIT_CAP);
+	ctx->h_hits.resize(n);
+	if (n) HIP_TRY(hipMemcpy(ctx->h_hits.data(), ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
+	// stage timings
+	tnt_timing &T = ctx->timing;
+	memset(&T, 0, sizeof(T));
+	for (size_t b = 0; b + 3 < ctx->events.size(); b += 4) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, ctx->events[b], ctx->events[b + 1]) == hipSuccess) T.seed_ms += ms;
+		if (hipEventElapsedTime(&ms, ctx->events[b + 1], ctx->events[b + 2]) == hipSuccess) T.bind_ms += ms;
+		if (hipEventElapsedTime(&ms, ctx->events[b + 2], ctx->events[b + 3]) == hipSuccess) T.pair_ms += ms;
+	}
+	if (ctx->events.size() >= 4) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, ctx->events.front(), ctx->events.back()) == hipSuccess) T.total_ms = ms;
+	}
+	T.n_binds = cnt[C_ITEMS]; // last batch only when several batches ran; see tnt_last_timing
+	T.n_bound = cnt[C_POOL];
+	T.n_hits = n;
+	if (hits) *hits = ctx->h_hits.data();
+	if (n_hits) *n_hits = n;
+	return TNT_OK;
+}
+
+int tnt_search(tnt_ctx *ctx, tnt_db *db, const tnt_hit **hits, size_t *n_hits)
+{
+	const int rc = tnt_search_enqueue(ctx, db);
+	if (rc) return rc;
+	return tnt_search_collect(ctx, hits, n_hits);
+}
+
+int tnt_last_timing(tnt_ctx *ctx, tnt_timing *out)
+{
+	if (!ctx || !out) return TNT_E_ARG;
+	*out = ctx->timing;
+	return TNT_OK;
+}
+
+int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
+{
+	if (!ctx || !db || db->ctx != ctx || !seeds || !n_seeds) return TNT_E_ARG;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx);
+	if (rc) return rc;
+	size_t tpb = 1;
+	plan(ctx, db, tpb);
+	const double words = double(size_t(1) << (2 * ctx->opt.hash_word_size));
+	const size_t cap = size_t(double(db->n_bases) * double(ctx->n_entries) / words * 2.0) + (1u << 20);
+	HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err);
+	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	rc = enqueue_batch(ctx, db, 0, db->n_targets, true);
+	if (rc) return rc;
+	uint32_t cnt[C_COUNT];
+	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	if (cnt[C_ERR]) {
+		ctx->err = err_text(cnt[C_ERR]);
+		return TNT_E_LIMIT;
+	}
+	if (cnt[C_SEEDS] > cap) {
+		ctx->err = "seed output overflow";
+		return TNT_E_LIMIT;
+	}
+	std::vector<SeedOut> raw(cnt[C_SEEDS]);
+	if (!raw.empty()) HIP_TRY(hipMemcpy(raw.data(), ctx->seeds_out.p, raw.size() * sizeof(SeedOut), hipMemcpyDeviceToHost), ctx->err);
+	ctx->seeds_out.release();
+	// (assay, role) -> unique oligo; shared oligos yield the same seed several times
+	std::vector<tnt_seed> out;
+	out.reserve(raw.size());
+	for (const SeedOut &s : raw) {
+		const AssayDev &d = ctx->h_assays[s.assay_role >> 2];
+		const int role = int(s.assay_role & 3u);
+		const int slot = role == 0 ? d.slot_f : (role == 1 ? d.slot_r : d.slot_p);
+		tnt_seed o;
+		o.seq_index = int(db->first_seq_index + s.target);
+		o.oligo = ctx->h_slots[slot].oligo;
+		o.strand = s.strand_minus ? TNT_MINUS : TNT_PLUS;
+		o.query_loc = int(s.query_loc);
+		o.target_loc = int(s.target_loc);
+		out.push_back(o);
+	}
+	auto key = [](const tnt_seed &a, const tnt_seed &b) {
+		if (a.seq_index != b.seq_index) return a.seq_index < b.seq_index;
+		if (a.oligo != b.oligo) return a.oligo < b.oligo;
+		if (a.strand != b.strand) return a.strand > b.strand; // minus first
+		const int da = a.query_loc - a.target_loc, dbb = b.query_loc - b.target_loc;
+		return da < dbb;
+	};
+	std::sort(out.begin(), out.end(), key);
+	out.erase(std::unique(out.begin(), out.end(),
+	                      [](const tnt_seed &a, const tnt_seed &b) {
+		                      return a.seq_index == b.seq_index && a.oligo == b.oligo && a.strand == b.strand &&
+		                             a.query_loc == b.query_loc && a.target_loc == b.target_loc;
+	                      }),
+	          out.end());
+	ctx->h_seeds.swap(out);
+	*seeds = ctx->h_seeds.data();
+	*n_seeds = ctx->h_seeds.size();
+	return TNT_OK;
+}
+
+int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out)
+{
+	if (!ctx || !db || db->ctx != ctx || (!req && n) || (!out && n)) return TNT_E_ARG;
+	if (n == 0) return TNT_OK;
+	if (n > ITEM_CAP) return TNT_E_LIMIT;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx);
+	if (rc) return rc;
+	// one temporary slot per request (arbitrary strand concentration)
+	std::vector<Slot> slots(n);
+	std::vector<Item> items(n);
+	for (size_t i = 0; i < n; i++) {
+		const tnt_bind_req &r = req[i];
+		const size_t t = size_t(r.seq_index) - db->first_seq_index;
+		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc > 255 ||
+		    r.target_loc < 0 || !(r.ct > 0.0f)) {
+			ctx->err = "bad bind request";
+			return TNT_E_ARG;
+		}
+		slots[i].oligo = r.oligo;
+		slots[i].log_ct = logf((r.ct - 0.5f * 0.0f) * 1.0f);
+		slots[i].thresh = r.role == 1 ? 1 : 0;
+		slots[i].assay = -1;
+		items[i].target = uint32_t(t);
+		items[i].tloc = uint32_t(r.target_loc);
+		items[i].slot = uint32_t(i);
+		items[i].info = uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u);
+	}
+	DevBuf<Slot> dslots;
+	DevBuf<BindFull> dfull;
+	HIP_TRY(dslots.upload(slots), ctx->err);
+	HIP_TRY(dfull.alloc(n), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	BindArgs b = bind_args(ctx, make_view(db, 0, db->n_targets));
+	b.slots = dslots.p;
+	b.n_items = uint32_t(n);
+	b.n_items_dev = nullptr;
+	b.full = dfull.p;
+	launch_bind<true>(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + BIND_THREADS - 1) / BIND_THREADS)));
+	HIP_TRY(hipGetLastError(), ctx->err);
+	uint32_t cnt[C_COUNT];
+	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	if (cnt[C_ERR]) {
+		ctx->err = err_text(cnt[C_ERR]);
+		return TNT_E_LIMIT;
+	}
+	std::vector<BindFull> full(n);
+	HIP_TRY(hipMemcpy(full.data(), dfull.p, n * sizeof(BindFull), hipMemcpyDeviceToHost), ctx->err);
+	for (size_t i = 0; i < n; i++) {
+		const BindFull &f = full[i];
+		tnt_bind &o = out[i];
+		memset(&o, 0, sizeof(o));
+		o.status = f.status, o.target_start = f.target_start, o.target_stop = f.target_stop;
+		o.tm = f.tm, o.dH = f.dH, o.dS = f.dS, o.dg = f.dg;
+		o.anchor5 = f.a5, o.anchor3 = f.a3, o.num_mm = f.mm, o.num_gap = f.gap, o.poly_degen = f.poly;
+		o.loc5 = f.loc5, o.loc3 = f.loc3;
+		o.q_first = f.q_first, o.q_last = f.q_last, o.t_first = f.t_first, o.t_last = f.t_last;
+		o.valid = f.valid, o.dp_max = f.dp_max, o.n_max = f.n_max;
+		memcpy(o.align, f.text, TNT_ALIGN_TEXT);
+		o.align[TNT_ALIGN_TEXT - 1] = 0;
+	}
+	return TNT_OK;
+}
+
+int tnt_hit_sequence(tnt_ctx *ctx, tnt_db *db, const tnt_hit *hit, char *buf, size_t cap)
+{
+	if (!ctx || !db || !hit || !buf) return TNT_E_ARG;
+	const size_t t = size_t(hit->seq_index) - db->first_seq_index;
+	if (t >= db->n_targets) return TNT_E_ARG;
+	const uint32_t len = db->h_len[t];
+	const uint32_t *pk = db->h_packed.data() + db->h_word_off[t];
+	auto code_at = [&](int pos) -> int {
+		int code = int((pk[pos >> 4] >> ((pos & 15) * 2)) & 3u);
+		const uint32_t *b = db->h_exc_pos.data() + db->h_exc_off[t], *e = db->h_exc_pos.data() + db->h_exc_off[t + 1];
+		const uint32_t *it = std::lower_bound(b, e, uint32_t(pos));
+		if (it != e && *it == uint32_t(pos)) code = db->h_exc_code[it - db->h_exc_pos.data()];
+		return code;
+	};
+	static const char *same = "ACGTIMRSVWYHKDBN-?", *comp = "TGCAIKYSBWRDMHVN-?";
+	const bool primers = hit->has_primers != 0;
+	const int start = primers ? hit->amplicon_start : hit->probe_start;
+	const int stop = primers ? hit->amplicon_stop : hit->probe_stop;
+	if (stop < start) return TNT_E_ARG;
+	const size_t n = size_t(stop - start + 1);
+	if (n + 1 > cap) return TNT_E_LIMIT;
+	// amplicon_search.cpp:508-537, padlock_search.cpp:206-218,339-351, probe_search.cpp:138-152,208-222:
+	// plus orientation copies the target, minus orientation its reverse complement; '-' outside
+	const bool minus = primers ? (hit->primer_strand == TNT_MINUS) : (hit->probe_strand == TNT_MINUS);
+	for (size_t i = 0; i < n; i++) {
+		const int pos = minus ? stop - int(i) : start + int(i);
+		char ch = '-';
+		if (pos >= 0 && pos < int(len)) ch = minus ? comp[code_at(pos)] : same[code_at(pos)];
+		buf[i] = ch;
+	}
+	buf[n] = 0;
+	return int(n);
+}
+
+} // extern "C"

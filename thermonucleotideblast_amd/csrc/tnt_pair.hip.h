@@ -1,0 +1,440 @@
+// tnt_pair.hip.h -- gfx950 pairing kernel: one lane per (target, assay) group of bind results.
+//
+// Replaces, given the bind outcome of every culled seed:
+//  * PCR / TaqMan: the bind / cull sequence and the O(F x R [x P]) pairing loops of amplicon()
+//    (amplicon_search.cpp:131-674) including sort_by_oligo_loc (:12-26), cull_oligo_match
+//    (:679-765), the per-oligo de-duplication of bind_oligo_to_*_strand's mask overload
+//    (bind_oligo.cpp:806-826, sort_by_bound_match :49-82);
+//  * padlock / MIPS: padlock() (padlock_search.cpp:62-361) on top of the hash overload's
+//    de-duplication (bind_oligo.cpp:431-453);
+//  * probes: hybrid() (probe_search.cpp:67-230).
+//
+// The reference interleaves binding and culling (bind F, cull, bind R, cull, ...).  Binding a seed
+// does not depend on the list it sits in, so every seed that survives the FIRST cull is bound up
+// front by the bind kernel and this kernel replays the reference's exact sequence of list
+// operations on the results.  Culls only ever remove entries, so the replay sees the same lists.
+#ifndef TNT_PAIR_HIP_H
+#define TNT_PAIR_HIP_H
+
+#include <hip/hip_runtime.h>
+#include "tnt_dev.h"
+
+namespace tnt {
+
+constexpr int PAIR_THREADS = 64;
+constexpr int PAIR_MAX = 64; // entries of one (target, assay) group (== LIST_MAX of the seed kernel)
+
+struct PairArgs {
+	const Group *groups;
+	uint32_t n_groups;
+	const uint32_t *active;     // indices of the groups with at least one bound item (filter_kernel)
+	const uint32_t *n_active;
+	const Item *items;
+	const int32_t *result;
+	const BoundRec *pool;
+	const AssayDev *assays;
+	DbView db;
+	int max_len;
+	int single_primer_pcr;
+	int min_max_primer_clamp;
+	int assay_format; // TNT_ASSAY_*
+	int target_strand;
+	Hit *hits;
+	uint32_t hit_cap;
+	uint32_t *hit_count;
+	uint32_t *err;
+};
+
+enum : uint8_t { MF = 1, MR = 2, MP = 4, MPLUS = 8, MMINUS = 16, MVALID = 32 }; // oligo_info, tntblast.h:147-154
+
+struct Entry {
+	int32_t loc5, loc3;
+	uint32_t tloc;
+	int32_t rec;  // pool index or < 0
+	uint8_t mask;
+};
+
+__device__ __forceinline__ void copy_text(char *dst, const char *src)
+{
+	int i = 0;
+	for (; i < ALIGN_TEXT - 1 && src[i]; i++) dst[i] = src[i];
+	dst[i] = 0;
+}
+
+__device__ void init_hit(Hit &h, const AssayDev &A, int seq_index)
+{
+	// hybrid_sig::init(), hybrid_sig.h:54-110
+	h.assay_id = A.id, h.degen_id = A.degen_id, h.seq_index = seq_index;
+	h.amplicon_start = h.amplicon_stop = h.probe_start = h.probe_stop = 0;
+	h.forward_tm = h.reverse_tm = h.probe_tm = -1.0f;
+	h.forward_dH = h.reverse_dH = h.probe_dH = 100.0f;
+	h.forward_dS = h.reverse_dS = h.probe_dS = 0.0f;
+	h.primer_strand = h.probe_strand = 0;
+	h.forward_primer_clamp = h.reverse_primer_clamp = -1;
+	h.forward_mm = h.forward_gap = h.reverse_mm = h.reverse_gap = h.probe_mm = h.probe_gap = -1;
+	h.forward_oligo = 0, h.reverse_oligo = 1;
+	h.has_primers = (A.slot_f >= 0 && A.slot_r >= 0) ? 1 : 0;
+	h.has_probe = (A.slot_p >= 0) ? 1 : 0;
+	h.forward_align[0] = h.reverse_align[0] = h.probe_align[0] = 0;
+}
+
+// sort_by_oligo_loc, amplicon_search.cpp:12-26 (mixed keys)
+__device__ __forceinline__ bool oligo_loc_less(const Entry &x, const Entry &y)
+{
+	if (!(x.loc5 + x.loc3) || !(y.loc5 + y.loc3)) return x.tloc < y.tloc;
+	if (x.loc5 == y.loc5) return x.loc3 < y.loc3;
+	return x.loc5 < y.loc5;
+}
+
+// sort_by_bound_match, bind_oligo.cpp:49-82 (alignment.size() is 3 * columns + constant)
+__device__ __forceinline__ bool bound_less(const Entry &x, const Entry &y, const BoundRec *pool)
+{
+	if (x.loc5 != y.loc5) return x.loc5 < y.loc5;
+	if (x.loc3 != y.loc3) return x.loc3 < y.loc3;
+	const BoundRec &a = pool[x.rec], &b = pool[y.rec];
+	if (a.tm == b.tm) {
+		if (a.mm == b.mm) return a.text_len > b.text_len;
+		return a.mm > b.mm;
+	}
+	return a.tm > b.tm;
+}
+
+// oligo_info::operator<, tntblast.h:230-242
+__device__ __forceinline__ bool info_less(const Entry &x, const Entry &y, const BoundRec *pool)
+{
+	if (x.loc5 != y.loc5) return x.loc5 < y.loc5;
+	if (x.loc3 != y.loc3) return x.loc3 < y.loc3;
+	return pool[x.rec].tm > pool[y.rec].tm;
+}
+
+struct List {
+	Entry e[PAIR_MAX];
+	int n;
+};
+
+// stable insertion sort == std::list::sort for a strict weak order
+template <class Less> __device__ void stable_sort(Entry *e, int n, Less less)
+{
+	for (int i = 1; i < n; i++) {
+		const Entry x = e[i];
+		int j = i - 1;
+		while (j >= 0 && less(x, e[j])) {
+			e[j + 1] = e[j];
+			j--;
+		}
+		e[j + 1] = x;
+	}
+}
+
+// cull_oligo_match, amplicon_search.cpp:679-765; returns the (minus, plus) "strand counts" the way the
+// reference computes them (mask of the element FOLLOWING each valid one, :748-755; end() counts nothing)
+__device__ void cull(List &l, int max_len, bool has_probe, bool single_primer, int &cnt_minus, int &cnt_plus)
+{
+	const uint32_t threshold = uint32_t(max_len) + 50u;
+	stable_sort(l.e, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); });
+	for (int i = 0; i < l.n; i++) l.e[i].mask &= uint8_t(~MVALID);
+	for (int f = 0; f < l.n; f++) {
+		if (l.e[f].mask & (MPLUS | MP)) continue;
+		for (int r = f + 1; r < l.n; r++) {
+			if ((l.e[r].tloc - l.e[f].tloc) > threshold) break;
+			if (l.e[r].mask & (MMINUS | MP)) continue;
+			if (!single_primer && ((l.e[f].mask & (MR | MF)) == (l.e[r].mask & (MR | MF)))) continue;
+			if (has_probe) {
+				for (int p = f + 1; p < r; p++)
+					if (l.e[p].mask & MP) {
+						l.e[p].mask |= MVALID;
+						l.e[f].mask |= MVALID;
+						l.e[r].mask |= MVALID;
+					}
+			} else {
+				l.e[f].mask |= MVALID;
+				l.e[r].mask |= MVALID;
+			}
+		}
+	}
+	cnt_minus = cnt_plus = 0;
+	// The reference advances the iterator first and then reads ->mask, i.e. it looks at the element that
+	// FOLLOWS each valid one in the list as it stands (invalid successors are still present at that time).
+	for (int i = 0; i < l.n; i++) {
+		if ((l.e[i].mask & MVALID) && i + 1 < l.n) {
+			cnt_minus += (l.e[i + 1].mask & MMINUS) ? 1 : 0;
+			cnt_plus += (l.e[i + 1].mask & MPLUS) ? 1 : 0;
+		}
+	}
+	int o = 0;
+	for (int i = 0; i < l.n; i++)
+		if (l.e[i].mask & MVALID) l.e[o++] = l.e[i];
+	l.n = o;
+}
+
+// bind_oligo_to_{minus,plus}_strand, mask overload: list surgery of bind_oligo.cpp:476-500,806-826
+__device__ void bind_step(List &l, uint8_t want, const BoundRec *pool)
+{
+	Entry cur[PAIR_MAX];
+	int nc = 0;
+	int o = 0;
+	for (int i = 0; i < l.n; i++) {
+		if ((l.e[i].mask & want) != want) {
+			l.e[o++] = l.e[i];
+			continue;
+		}
+		if (l.e[i].rec >= 0) cur[nc++] = l.e[i]; // bound; unbound seeds are dropped (curr_oligo.pop_front)
+	}
+	l.n = o;
+	if (nc == 0) return;
+	// curr_oligo was filled with push_front: reverse, then stable sort
+	for (int i = 0; i < nc / 2; i++) {
+		const Entry t = cur[i];
+		cur[i] = cur[nc - 1 - i];
+		cur[nc - 1 - i] = t;
+	}
+	stable_sort(cur, nc, [pool](const Entry &x, const Entry &y) { return bound_less(x, y, pool); });
+	l.e[l.n++] = cur[0];
+	for (int i = 1; i < nc; i++)
+		if (l.e[l.n - 1].loc5 != cur[i].loc5 || l.e[l.n - 1].loc3 != cur[i].loc3) l.e[l.n++] = cur[i];
+}
+
+struct PairArgs;
+__device__ void pair_group(const PairArgs &a, const Group G);
+
+__device__ Hit *alloc_hit(const PairArgs &a)
+{
+	const uint32_t o = atomicAdd(a.hit_count, 1u);
+	if (o >= a.hit_cap) {
+		atomicOr(a.err, ERR_HIT_OVERFLOW);
+		return nullptr;
+	}
+	return a.hits + o;
+}
+
+// Groups whose seeds all failed to bind produce nothing: compact the rest so the (scratch heavy)
+// pairing kernel only runs where there is something to pair.
+struct FilterArgs {
+	const Group *groups;
+	const uint32_t *n_groups; // device counter written by the seed kernel
+	const int32_t *result;
+	uint32_t *active;
+	uint32_t *n_active;
+};
+
+__global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
+{
+	const uint32_t n = *a.n_groups;
+	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+		const Group G = a.groups[g];
+		bool any = false;
+		for (uint32_t i = 0; i < G.count; i++) any |= a.result[G.first + i] >= 0;
+		if (any) a.active[atomicAdd(a.n_active, 1u)] = g;
+	}
+}
+
+__global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(PairArgs a)
+{
+	const uint32_t n_active = *a.n_active;
+	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS)
+		pair_group(a, a.groups[a.active[gi]]);
+}
+
+__device__ void pair_group(const PairArgs &a, const Group G)
+{
+	const AssayDev A = a.assays[G.assay & GROUP_ASSAY_MASK];
+	const int seq_index = int(a.db.first_seq_index + G.target);
+	const BoundRec *pool = a.pool;
+
+	if (G.count > uint32_t(PAIR_MAX)) {
+		atomicOr(a.err, ERR_LIST_OVERFLOW);
+		return;
+	}
+
+	List l;
+	l.n = int(G.count);
+	bool any_bound = false;
+	for (int i = 0; i < l.n; i++) {
+		const Item it = a.items[G.first + i];
+		const int32_t res = a.result[G.first + i];
+		Entry &e = l.e[i];
+		e.tloc = it.tloc;
+		e.rec = res >= 0 ? res : -1;
+		e.loc5 = e.loc3 = 0;
+		const uint32_t role = (it.info >> 9) & 3u;
+		e.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((it.info & ITEM_MINUS) ? MMINUS : MPLUS));
+		if (res >= 0) any_bound = true;
+	}
+	if (!any_bound) return;
+
+	if (A.kind == 0) {
+		// ---------------------------------------------------------------- amplicon(), amplicon_search.cpp:128-674
+		const bool has_probe = A.has_probe != 0;
+		const bool single = a.single_primer_pcr != 0;
+		// strand counts of the first cull were taken by the seed kernel on the full list (:128-131)
+		const bool minus_first = (G.assay & GROUP_MINUS_FIRST) != 0;
+		int d0, d1;
+		for (int s = 0; s < 4; s++) {
+			const bool fwd = (s % 2) == 0;
+			const bool minus = minus_first ? (s < 2) : (s >= 2);
+			// a bound entry takes its coordinates from the bind result
+			const uint8_t want = uint8_t((fwd ? MF : MR) | (minus ? MMINUS : MPLUS));
+			for (int i = 0; i < l.n; i++)
+				if ((l.e[i].mask & want) == want && l.e[i].rec >= 0) {
+					l.e[i].loc5 = pool[l.e[i].rec].loc5;
+					l.e[i].loc3 = pool[l.e[i].rec].loc3;
+				}
+			bind_step(l, want, pool);
+			if (s < 3) {
+				cull(l, a.max_len, has_probe, single, d0, d1);
+				if (l.n == 0 && !(minus_first && s == 2)) return;
+			}
+		}
+		if (has_probe) {
+			cull(l, a.max_len, has_probe, single, d0, d1);
+			if (l.n == 0) return;
+			for (int pass = 0; pass < 2; pass++) {
+				const uint8_t want = uint8_t(MP | (pass == 0 ? MMINUS : MPLUS));
+				for (int i = 0; i < l.n; i++)
+					if ((l.e[i].mask & want) == want && l.e[i].rec >= 0) {
+						l.e[i].loc5 = pool[l.e[i].rec].loc5;
+						l.e[i].loc3 = pool[l.e[i].rec].loc3;
+					}
+				bind_step(l, want, pool);
+			}
+		}
+		stable_sort(l.e, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }); // :356
+
+		const bool apply_mm = a.min_max_primer_clamp >= 0;
+		const uint32_t min_max_clamp = apply_mm ? uint32_t(a.min_max_primer_clamp) : 0u;
+		for (int f = 0; f < l.n; f++) {
+			const Entry &F = l.e[f];
+			if (F.mask & (MPLUS | MP)) continue;
+			for (int r = f + 1; r < l.n; r++) {
+				const Entry &R = l.e[r];
+				if (R.mask & (MMINUS | MP)) continue;
+				if (!single && ((F.mask & (MR | MF)) == (R.mask & (MR | MF)))) continue;
+				if (F.loc3 >= R.loc5) continue;
+				if ((R.loc3 - F.loc5 + 1) > a.max_len) continue;
+				const BoundRec &bf = pool[F.rec], &br = pool[R.rec];
+				if (apply_mm && uint32_t(bf.a3 > br.a3 ? bf.a3 : br.a3) <= min_max_clamp) continue;
+
+				Hit h;
+				init_hit(h, A, seq_index);
+				if ((F.mask & MR) && (R.mask & MR)) h.forward_oligo = 1; // :453-457
+				if ((F.mask & MF) && (R.mask & MF)) h.reverse_oligo = 0; // :459-463
+				h.primer_strand = (F.mask & MF) ? 0 : 1;
+				h.amplicon_start = F.loc5;
+				h.amplicon_stop = R.loc3;
+				const bool swap = (F.mask & MR) && (R.mask & MF); // :478-483
+				const BoundRec &fo = swap ? br : bf, &ro = swap ? bf : br;
+				h.forward_tm = fo.tm, h.reverse_tm = ro.tm;
+				h.forward_dH = fo.dH, h.reverse_dH = ro.dH;
+				h.forward_dS = fo.dS, h.reverse_dS = ro.dS;
+				h.forward_mm = fo.mm, h.reverse_mm = ro.mm;
+				h.forward_gap = fo.gap, h.reverse_gap = ro.gap;
+				h.forward_primer_clamp = fo.a3, h.reverse_primer_clamp = ro.a3;
+
+				if (has_probe) {
+					for (int p = f + 1; p < r; p++) {
+						const Entry &P = l.e[p];
+						if (!(P.mask & MP)) continue;
+						if (!(P.loc5 >= F.loc5 && P.loc3 <= R.loc3)) continue; // :418
+						if ((P.mask & (MPLUS | MMINUS)) == (F.mask & (MPLUS | MMINUS))) {
+							if (P.loc5 <= F.loc3) continue;
+						} else {
+							if (P.loc3 >= R.loc5) continue;
+						}
+						Hit *out = alloc_hit(a);
+						if (!out) return;
+						const BoundRec &bp = pool[P.rec];
+						*out = h;
+						out->probe_start = P.loc5, out->probe_stop = P.loc3;
+						out->probe_tm = bp.tm, out->probe_dH = bp.dH, out->probe_dS = bp.dS;
+						out->probe_mm = bp.mm, out->probe_gap = bp.gap;
+						out->probe_strand = (P.mask & MPLUS) ? 0 : 1;
+						copy_text(out->forward_align, fo.text);
+						copy_text(out->reverse_align, ro.text);
+						copy_text(out->probe_align, bp.text);
+					}
+				} else {
+					Hit *out = alloc_hit(a);
+					if (!out) return;
+					*out = h;
+					copy_text(out->forward_align, fo.text);
+					copy_text(out->reverse_align, ro.text);
+				}
+			}
+		}
+		return;
+	}
+
+	// -------------------------------------------------------------------- hash-overload assays
+	// items arrive per list (minus-up, minus-down, plus-up, plus-down) in diagonal order; each list keeps
+	// its bound entries, sorted by oligo_info::operator< (stable) and de-duplicated by (loc5, loc3)
+	// (bind_oligo.cpp:431-453)
+	Entry lists[4][PAIR_MAX];
+	int ln[4] = {0, 0, 0, 0};
+	for (int i = 0; i < l.n; i++) {
+		Entry e = l.e[i];
+		if (e.rec < 0) continue;
+		e.loc5 = pool[e.rec].loc5;
+		e.loc3 = pool[e.rec].loc3;
+		const int id = ((e.mask & MMINUS) ? 0 : 2) + ((e.mask & MR) ? 0 : 1);
+		lists[id][ln[id]++] = e;
+	}
+	for (int id = 0; id < 4; id++) {
+		stable_sort(lists[id], ln[id], [pool](const Entry &x, const Entry &y) { return info_less(x, y, pool); });
+		int o = 0;
+		for (int i = 0; i < ln[id]; i++)
+			if (o == 0 || lists[id][o - 1].loc5 != lists[id][i].loc5 || lists[id][o - 1].loc3 != lists[id][i].loc3)
+				lists[id][o++] = lists[id][i];
+		ln[id] = o;
+	}
+
+	if (A.kind == 2) { // hybrid(), probe_search.cpp:67-230
+		for (int pass = 0; pass < 2; pass++) {
+			const int id = pass == 0 ? 1 : 3;
+			for (int i = 0; i < ln[id]; i++) {
+				const Entry &e = lists[id][i];
+				const BoundRec &b = pool[e.rec];
+				Hit *out = alloc_hit(a);
+				if (!out) return;
+				init_hit(*out, A, seq_index);
+				out->probe_tm = b.tm, out->probe_dH = b.dH, out->probe_dS = b.dS;
+				out->probe_mm = b.mm, out->probe_gap = b.gap;
+				out->probe_start = e.loc5, out->probe_stop = e.loc3;
+				out->probe_strand = pass == 0 ? 1 : 0;
+				copy_text(out->probe_align, b.text);
+			}
+		}
+		return;
+	}
+
+	// padlock(), padlock_search.cpp:62-361: upstream = reverse oligo, downstream = forward oligo
+	const int max_len = (a.assay_format == 3 /* MIPS */) ? a.max_len : 0; // tntblast_local.cpp:592,606
+	for (int pass = 0; pass < 2; pass++) {
+		const bool minus = pass == 0;
+		const int up = minus ? 0 : 2, down = up + 1;
+		for (int u = 0; u < ln[up]; u++)
+			for (int d = 0; d < ln[down]; d++) {
+				const Entry &U = lists[up][u], &D = lists[down][d];
+				const int len = minus ? (U.loc5 - D.loc3 - 1) : (D.loc5 - U.loc3 - 1);
+				if (len < 0 || len > max_len) continue;
+				const BoundRec &bu = pool[U.rec], &bd = pool[D.rec];
+				Hit *out = alloc_hit(a);
+				if (!out) return;
+				init_hit(*out, A, seq_index);
+				out->primer_strand = minus ? 1 : 0;
+				out->amplicon_start = minus ? D.loc5 : U.loc5;
+				out->amplicon_stop = minus ? U.loc3 : D.loc3;
+				out->forward_tm = bd.tm, out->reverse_tm = bu.tm;
+				out->forward_dH = bd.dH, out->reverse_dH = bu.dH;
+				out->forward_dS = bd.dS, out->reverse_dS = bu.dS;
+				out->forward_mm = bd.mm, out->reverse_mm = bu.mm;
+				out->forward_gap = bd.gap, out->reverse_gap = bu.gap;
+				out->forward_primer_clamp = bd.a3;
+				out->reverse_primer_clamp = bu.a5;
+				copy_text(out->forward_align, bd.text);
+				copy_text(out->reverse_align, bu.text);
+			}
+	}
+}
+
+} // namespace tnt
+#endif

@@ -1,0 +1,201 @@
+"""Python host mirror of the hot path's C ABI (include/tnt_mi355x.h) over libtnt_mi355x.so.
+
+The reference's entry points for this path are the per-(target, assay) C++ functions
+`amplicon()`, `padlock()`, `hybrid()` (tntblast.h:409-472) called from the OpenMP loop body of
+tntblast_local.cpp:388-793.  `Engine.search()` is the batch-granular replacement of that loop
+body: the whole (expanded) assay set against a device-resident batch of targets, returning the
+`hybrid_sig` payload of every hit.  Errors surface as `TntError` carrying the library's message
+(the reference throws `const char*`, throw.h:17-18).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtnt_mi355x.so")
+
+_lib = None
+
+
+class TntError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libtnt_mi355x.so (built in-tree by __graft_entry__.build()).  Never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TntError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.tnt_abi_version.restype = C.c_int
+    lib.tnt_options_default.argtypes = [P(abi.tnt_options)]
+    lib.tnt_last_error.restype = C.c_char_p
+    lib.tnt_last_error.argtypes = [C.c_void_p]
+    lib.tnt_ctx_create.argtypes = [P(abi.tnt_options), P(abi.tnt_assay), C.c_size_t, C.c_int, P(C.c_void_p)]
+    lib.tnt_ctx_destroy.argtypes = [C.c_void_p]
+    lib.tnt_ctx_num_oligos.argtypes = [C.c_void_p]
+    lib.tnt_ctx_oligo.argtypes = [C.c_void_p, C.c_int]
+    lib.tnt_ctx_oligo.restype = C.c_char_p
+    lib.tnt_ctx_delta_g.argtypes = [C.c_void_p, P(C.c_int32)]
+    lib.tnt_db_create.argtypes = [C.c_void_p, P(C.c_uint8), P(C.c_uint64), C.c_size_t, C.c_uint32, P(C.c_void_p)]
+    lib.tnt_db_destroy.argtypes = [C.c_void_p]
+    lib.tnt_db_num_targets.argtypes = [C.c_void_p]
+    lib.tnt_db_num_targets.restype = C.c_size_t
+    lib.tnt_db_num_bases.argtypes = [C.c_void_p]
+    lib.tnt_db_num_bases.restype = C.c_uint64
+    lib.tnt_search.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_hit)), P(C.c_size_t)]
+    lib.tnt_search_enqueue.argtypes = [C.c_void_p, C.c_void_p]
+    lib.tnt_search_collect.argtypes = [C.c_void_p, P(P(abi.tnt_hit)), P(C.c_size_t)]
+    lib.tnt_last_timing.argtypes = [C.c_void_p, P(abi.tnt_timing)]
+    lib.tnt_seeds.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_seed)), P(C.c_size_t)]
+    lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
+    lib.tnt_hit_sequence.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_hit), C.c_char_p, C.c_size_t]
+    if lib.tnt_abi_version() != 1:
+        raise TntError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+# every symbol include/tnt_mi355x.h declares (checked by the CPU test-suite)
+EXPORTED_SYMBOLS = [
+    "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
+    "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
+    "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect",
+    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_hit_sequence",
+]
+
+
+def _c_assays(expanded):
+    arr = (abi.tnt_assay * max(1, len(expanded)))()
+    keep = []
+    for i, e in enumerate(expanded):
+        arr[i].id, arr[i].degen_id = e.id, e.degen_id
+        for nm in ("forward", "reverse", "probe"):
+            v = getattr(e, nm)
+            b = v.encode() if v else None
+            keep.append(b)
+            setattr(arr[i], nm, b)
+        arr[i].forward_degen, arr[i].reverse_degen, arr[i].probe_degen = e.forward_degen, e.reverse_degen, e.probe_degen
+    arr._keep = keep
+    return arr
+
+
+class TargetBatch:
+    """Device-resident packed targets (replaces read_bio_seq + DNAHash::hash, tntblast_local.cpp:510,534)."""
+
+    def __init__(self, engine, codes, offsets, first_seq_index=0):
+        self.engine = engine
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if offsets.ndim != 1 or len(offsets) < 1 or int(offsets[-1]) > codes.size:
+            raise TntError("bad offsets")
+        self._h = C.c_void_p()
+        rc = engine.lib.tnt_db_create(engine._h, codes.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                      offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets) - 1,
+                                      first_seq_index, C.byref(self._h))
+        engine._check(rc)
+        self.n_targets = len(offsets) - 1
+        self.n_bases = int(offsets[-1])
+
+    def close(self):
+        if self._h:
+            self.engine.lib.tnt_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One context per GPU: options + expanded assay set + thermodynamic tables on `device`."""
+
+    def __init__(self, options, expanded_assays, device=0):
+        self.lib = load_library()
+        self.options = options
+        self.expanded = list(expanded_assays)
+        self._h = C.c_void_p()
+        arr = _c_assays(self.expanded)
+        rc = self.lib.tnt_ctx_create(C.byref(options), arr, len(self.expanded), device, C.byref(self._h))
+        if rc != 0:
+            raise TntError("tnt_ctx_create: %s (code %d)" % (self.lib.tnt_last_error(None).decode(), rc))
+        self.oligos = [self.lib.tnt_ctx_oligo(self._h, i).decode() for i in range(self.lib.tnt_ctx_num_oligos(self._h))]
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TntError("%s (code %d)" % (self.lib.tnt_last_error(self._h).decode(), rc))
+
+    def close(self):
+        if self._h:
+            self.lib.tnt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pack(self, codes, offsets, first_seq_index=0):
+        return TargetBatch(self, codes, offsets, first_seq_index)
+
+    def delta_g(self):
+        out = (C.c_int32 * 2401)()
+        self._check(self.lib.tnt_ctx_delta_g(self._h, out))
+        return np.frombuffer(out, dtype=np.int32).copy()
+
+    def search(self, batch):
+        """seeds -> cull -> bind -> pair for every (target, assay); returns a ctypes array of tnt_hit."""
+        hits = C.POINTER(abi.tnt_hit)()
+        n = C.c_size_t()
+        self._check(self.lib.tnt_search(self._h, batch._h, C.byref(hits), C.byref(n)))
+        out = (abi.tnt_hit * n.value)()
+        if n.value:
+            C.memmove(out, hits, C.sizeof(abi.tnt_hit) * n.value)
+        return out
+
+    def enqueue(self, batch):
+        self._check(self.lib.tnt_search_enqueue(self._h, batch._h))
+
+    def collect(self):
+        hits = C.POINTER(abi.tnt_hit)()
+        n = C.c_size_t()
+        self._check(self.lib.tnt_search_collect(self._h, C.byref(hits), C.byref(n)))
+        out = (abi.tnt_hit * n.value)()
+        if n.value:
+            C.memmove(out, hits, C.sizeof(abi.tnt_hit) * n.value)
+        return out
+
+    def timing(self):
+        t = abi.tnt_timing()
+        self._check(self.lib.tnt_last_timing(self._h, C.byref(t)))
+        return t
+
+    def seeds(self, batch):
+        s = C.POINTER(abi.tnt_seed)()
+        n = C.c_size_t()
+        self._check(self.lib.tnt_seeds(self._h, batch._h, C.byref(s), C.byref(n)))
+        return [(s[i].seq_index, self.oligos[s[i].oligo], s[i].strand, s[i].query_loc, s[i].target_loc) for i in range(n.value)]
+
+    def bind_batch(self, batch, reqs):
+        out = (abi.tnt_bind * len(reqs))()
+        self._check(self.lib.tnt_bind_batch(self._h, batch._h, reqs, len(reqs), out))
+        return out
+
+    def hit_sequence(self, batch, hit):
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.tnt_hit_sequence(self._h, batch._h, C.byref(hit), buf, len(buf))
+        if n < 0:
+            raise TntError("tnt_hit_sequence failed (%d)" % n)
+        return buf.value.decode()
