@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library cross-compiles for gfx950, loads, and exports every symbol the header declares.
+No compute call is made (there is no GPU here and no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import tntcheck as tc
+from thermonucleotideblast_amd import abi, engine
+
+ROOT = tc.ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "tnt_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tnt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol(hip_lib):
+    syms = header_symbols()
+    assert syms, "no symbols parsed from the header"
+    assert sorted(engine.EXPORTED_SYMBOLS) == syms
+    for s in syms:
+        assert hasattr(hip_lib, s), s
+    assert hip_lib.tnt_abi_version() == 1
+
+
+def test_struct_layouts_match_header(hip_lib):
+    # tnt_options_default fills the ctypes mirror with the reference defaults (options.h:85-170)
+    o = abi.tnt_options()
+    hip_lib.tnt_options_default(C.byref(o))
+    d = abi.options_default()
+    for n, _ in abi.tnt_options._fields_:
+        assert getattr(o, n) == getattr(d, n), n
+    assert C.sizeof(abi.tnt_hit) == 30 * 4 + 3 * abi.TNT_ALIGN_TEXT
+    assert C.sizeof(abi.tnt_bind) == 21 * 4 + abi.TNT_ALIGN_TEXT
+    assert C.sizeof(abi.tnt_bind_req) == 28 and C.sizeof(abi.tnt_seed) == 20
+
+
+def test_no_gpu_means_loud_failure(hip_lib):
+    """Without a HIP device context creation must fail with TNT_E_DEVICE, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    o = abi.options_default()
+    rc = hip_lib.tnt_ctx_create(C.byref(o), None, 0, 0, C.byref(h))
+    assert rc == -2
+    assert b"no CPU fallback" in hip_lib.tnt_last_error(None)
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "thermonucleotideblast_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc", ".cpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                for needle in ("tnt_oracle", "libtntoracle", "libtntref", "tntcheck"):
+                    assert needle not in text, (f, needle)
+                assert not re.search(r"#include\s*[<\"].*oracle/", text), f

@@ -1,0 +1,82 @@
+"""CPU, world_size 2 on gloo: the sharding + hit-gather layer used by the multi-GPU runs.
+Each rank searches its shard with the ORACLE (there is no GPU here) and the gathered result must equal
+the single-process result: same partitioning / seq_index / collective code path as on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import tntcheck as tc
+from thermonucleotideblast_amd import shard, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        wl = synth.make_workload(3, n_targets=240, n_assays=16)
+        # ragged lengths so that the balance-by-bases cut is not the midpoint
+        lens = np.diff(wl.offsets.astype(np.int64))
+        keep = np.ones(len(wl.codes), dtype=bool)
+        for t in range(0, 60):
+            keep[int(wl.offsets[t]) + 500:int(wl.offsets[t + 1])] = False
+            lens[t] = 500
+        codes = wl.codes[keep]
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        ranges = shard.shard_ranges(offsets, world)
+        b, e = ranges[rank]
+        c, o = shard.take_shard(codes, offsets, ranges[rank])
+        ora = tc.OracleImpl()
+        local = ora.search(wl.options, wl.expanded, c, o, first=b, threads=1)
+        allhits, counts = shard.gather_hits(local)
+        keys = tc.sorted_hit_keys(allhits)
+        if rank == 0:
+            whole = tc.sorted_hit_keys(ora.search(wl.options, wl.expanded, codes, offsets, threads=2))
+            q.put((ranges, counts, keys == whole, len(whole)))
+        else:
+            q.put((rank, len(keys)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather(checkers):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = [r for r in results if isinstance(r[0], list)][0]
+    ranges, counts, same, n = r0
+    assert same and n > 0
+    assert sum(counts) == n
+    assert ranges[0][1] == ranges[1][0] and ranges[0][0] == 0 and ranges[1][1] == 240
+    assert ranges[0][1] != 120  # balanced by bases, not by count
+
+
+def test_shard_ranges_cover_and_balance():
+    offs = np.concatenate([[0], np.cumsum(np.random.default_rng(0).integers(10, 3000, 1000))]).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        r = shard.shard_ranges(offs, world)
+        assert r[0][0] == 0 and r[-1][1] == 1000
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        sizes = [int(offs[e] - offs[b]) for b, e in r]
+        assert max(sizes) - min(sizes) <= 2 * 3000
+    assert shard.shard_ranges(np.array([0], dtype=np.uint64), 4) == [(0, 0)] * 4

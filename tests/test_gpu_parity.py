@@ -1,0 +1,229 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle, the committed golden
+vectors and (where oracle/_ref travelled) the reference itself.  Integer / index / text results must
+be identical; Tm, dH, dS, dG are compared as float32 BIT PATTERNS (tolerance 0; the north-star bar is
+1e-6 C / 1e-6 kcal/mol)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import tntcheck as tc
+from thermonucleotideblast_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    import __graft_entry__ as g
+    g.build_hip()
+    from thermonucleotideblast_amd.engine import Engine as E
+    return E
+
+
+def _oligo_set(expanded):
+    return sorted({o for e in expanded for o in (e.forward, e.reverse, e.probe) if o})
+
+
+def test_native_library_is_loaded(Engine):
+    from thermonucleotideblast_amd import engine
+    lib = engine.load_library()
+    assert lib.tnt_abi_version() == 1
+    assert any("libtnt_mi355x.so" in line for line in open("/proc/self/maps"))
+
+
+def test_g1_delta_g(Engine):
+    fx = gu.load("g1_tables.json")
+    for key, dg in fx["delta_g"].items():
+        T, na = (float(x) for x in key.split("_"))
+        e = Engine(abi.options_default(target_t=T, salt=na), synth.expand_assays([synth.Assay("a", "ACGTACGTACGTACGTAC", "TGCATGCATGCATGCATG")]))
+        assert np.array_equal(e.delta_g(), np.array(dg, dtype=np.int32)), key
+        e.close()
+
+
+def test_g2_binds_golden(Engine):
+    """4.5k reference NucCruc evaluations: mismatches, bulges, loops, IUPAC, inosine, clipped windows, ties."""
+    fx = gu.load("g2_binds.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
+    for case in fx["cases"]:
+        e = Engine(gu.options_from(case["options"]), ex)
+        om = {o: i for i, o in enumerate(e.oligos)}
+        reqs = tc.make_reqs((r[0], om[fx["oligos"][r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in fx["requests"])
+        db = e.pack(codes, offsets)
+        out = e.bind_batch(db, reqs)
+        bad = [(i, gu.compare_bind(x, gu.bind_record(out[i]))) for i, x in enumerate(case["expected"])]
+        bad = [b for b in bad if b[1]]
+        assert not bad, "%s: %d of %d differ, first %r" % (case["name"], len(bad), len(case["expected"]), bad[:2])
+        db.close()
+        e.close()
+
+
+def test_g4_seeds_golden(Engine):
+    fx = gu.load("g4_seeds.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
+    for k, expected in fx["seeds"].items():
+        n_t = 100 if k == "7" else 12
+        e = Engine(abi.options_default(hash_word_size=int(k)), ex)
+        db = e.pack(codes[:int(offsets[n_t])], offsets[:n_t + 1])
+        got = sorted(e.seeds(db))
+        want = sorted((s[0], fx["oligos"][s[1]], s[2], s[3], s[4]) for s in expected)
+        assert got == want, "word size %s" % k
+        db.close()
+        e.close()
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_g5_search_golden(Engine, cfg):
+    fx = gu.load("g5_search_cfg%d.json.gz" % cfg)
+    wl = synth.make_workload(cfg, n_targets=fx["n_targets"], n_assays=fx["n_assays"])
+    e = Engine(gu.options_from(fx["options"]), wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    hits = e.search(db)
+    assert gu.hits_as_keys(hits) == fx["hits"]
+    db.close()
+    e.close()
+
+
+def test_g5_readme_example(Engine):
+    fx = gu.load("g5_readme.json.gz")
+    ex = synth.expand_assays([synth.Assay("gibb-marburg", *fx["assay"])])
+    t = fx["target"]
+    e = Engine(gu.options_from(fx["options"]), ex)
+    db = e.pack(synth.encode(t), np.array([0, len(t)], dtype=np.uint64))
+    hits = e.search(db)
+    assert gu.hits_as_keys(hits) == fx["hits"]
+    assert e.hit_sequence(db, hits[0]) == t[8:155]
+    db.close()
+    e.close()
+
+
+@pytest.mark.parametrize("cfg,nt,na,seed,kw", [
+    (2, 3000, 96, 41, {}),
+    (3, 3000, 96, 42, {}),
+    (4, 800, 120, 43, {}),
+    (5, 1500, 120, 44, {}),
+    (5, 600, 40, 45, {"assay_format": abi.ASSAY_MIPS, "max_len": 30}),
+    (5, 600, 40, 46, {"target_strand": abi.STRAND_MINUS}),
+    (3, 800, 40, 47, {"single_primer_pcr": 0, "primer_clamp": 2, "probe_clamp_5": 1, "min_max_primer_clamp": 4}),
+    (2, 800, 40, 48, {"min_primer_tm": 0.0, "max_primer_dg": -8.0, "max_mismatch": 2, "max_gap": 0}),
+    (2, 800, 40, 49, {"hash_word_size": 6, "max_len": 250}),
+    (2, 800, 40, 50, {"target_t": 330.0, "salt": 0.2, "primer_strand": 2e-7}),
+])
+def test_search_vs_oracle(Engine, oracle, cfg, nt, na, seed, kw):
+    wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
+    for k, v in kw.items():
+        setattr(wl.options, k, v)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets, first_seq_index=1000)
+    got = tc.sorted_hit_keys(e.search(db))
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets, first=1000))
+    assert got == want
+    assert len(want) > 0
+    # the unit-level entries agree too
+    oligos = e.oligos
+    so = sorted((s[0], oligos[s[1]], s[2], s[3], s[4]) for s in oracle.seeds(wl.options, oligos, wl.codes, wl.offsets, first=1000))
+    assert sorted(e.seeds(db)) == so
+    db.close()
+    e.close()
+
+
+def test_search_vs_reference_where_present(Engine, checkers):
+    if not checkers.have_ref():
+        pytest.skip("oracle/_ref did not travel")
+    ref = checkers.RefImpl()
+    for cfg, nt, na in ((3, 1200, 60), (5, 800, 60)):
+        wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=77 + cfg)
+        e = Engine(wl.options, wl.expanded)
+        db = e.pack(wl.codes, wl.offsets)
+        assert tc.sorted_hit_keys(e.search(db)) == tc.sorted_hit_keys(ref.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+        db.close()
+        e.close()
+
+
+def test_edge_cases(Engine, oracle):
+    opt = abi.options_default(min_primer_tm=40.0, min_probe_tm=40.0)
+    F, R = "TTCCCCTTTGGAGGCATC", "GGAGGATCCAACAGCAAGG"
+    ex = synth.expand_assays([synth.Assay("a", F, R, None)])
+    amp = F + "ACGTTGCAAGGCTTAACCGGTTAACC" + synth.revcomp(R)
+    targets = ["", "ACG", "ACGTAC", amp, "N" * 50, amp[:30], "ACGT" * 3 + amp + "TTGA", "A" * 200, amp + "X" + amp]
+    codes, offsets = gu.pack_targets(targets)
+    e = Engine(opt, ex)
+    # empty database
+    db0 = e.pack(np.zeros(0, np.uint8), np.array([0], dtype=np.uint64))
+    assert len(e.search(db0)) == 0
+    db0.close()
+    db = e.pack(codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    want = tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets))
+    assert got == want and len(want) >= 3
+    db.close()
+    e.close()
+    # longest supported oligo (64) works, 65 fails loudly
+    rng = np.random.default_rng(5)
+    long_o = "".join("ACGT"[i] for i in rng.integers(0, 4, 64))
+    ex = [synth.ExpandedAssay(0, 0, None, None, long_o)]
+    t = "ACGTACGTAC" + synth.revcomp(long_o) + "GGATCCAT" + long_o[:40] + "T" + long_o[40:] + "ACGT"
+    codes, offsets = gu.pack_targets([t])
+    e = Engine(abi.options_default(min_probe_tm=40.0), ex)
+    db = e.pack(codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    want = tc.sorted_hit_keys(oracle.search(abi.options_default(min_probe_tm=40.0), ex, codes, offsets))
+    assert got == want and len(want) >= 2
+    db.close()
+    e.close()
+    from thermonucleotideblast_amd.engine import TntError
+    with pytest.raises(TntError):
+        Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, long_o + "A")])
+    with pytest.raises(TntError):
+        Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGTNACGTACGTACGT")])
+
+
+def test_size_independent_properties(Engine):
+    """Full-size-style checks that need no oracle: idempotence, batch-split invariance (targets are
+    independent), and reverse-complement symmetry of the hit coordinates."""
+    wl = synth.make_workload(2, n_targets=60000, n_assays=96, seed=99)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    a = tc.sorted_hit_keys(e.search(db))
+    b = tc.sorted_hit_keys(e.search(db))
+    assert a == b and len(a) > 10
+    # split into three ragged batches with global seq_index preserved
+    cuts = [0, 1234, 40000, wl.n_targets]
+    parts = []
+    for i in range(3):
+        c = wl.codes[int(wl.offsets[cuts[i]]):int(wl.offsets[cuts[i + 1]])]
+        o = wl.offsets[cuts[i]:cuts[i + 1] + 1] - wl.offsets[cuts[i]]
+        d = e.pack(c, o, first_seq_index=cuts[i])
+        parts += list(tc.sorted_hit_keys(e.search(d)))
+        d.close()
+    assert sorted(parts) == a
+    db.close()
+    # reverse-complement every target: each amplicon maps to [len-1-stop, len-1-start] on the other strand
+    hits_fwd = e.search(e.pack(wl.codes[:int(wl.offsets[3000])], wl.offsets[:3001]))
+    comp = np.array([3, 2, 1, 0] + list(range(4, 18)), dtype=np.uint8)
+    rc = np.concatenate([comp[wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])][::-1]] for t in range(3000)])
+    hits_rc = e.search(e.pack(rc, wl.offsets[:3001]))
+    L = 1000
+    fwd = sorted((h.assay_id, h.seq_index, h.amplicon_start, h.amplicon_stop, tc.f32_bits(h.forward_tm), tc.f32_bits(h.reverse_tm), 1 - h.primer_strand) for h in hits_fwd)
+    rcs = sorted((h.assay_id, h.seq_index, L - 1 - h.amplicon_stop, L - 1 - h.amplicon_start, tc.f32_bits(h.forward_tm), tc.f32_bits(h.reverse_tm), h.primer_strand) for h in hits_rc)
+    assert fwd == rcs and len(fwd) > 0
+    e.close()
+
+
+def test_torch_coexists_with_the_library(Engine):
+    """torch (device memory / streams / RCCL plumbing) and the HIP library share one HIP runtime."""
+    import torch
+    assert torch.cuda.is_available()
+    x = torch.arange(1024, device="cuda").sum().item()
+    assert x == 1023 * 512
+    wl = synth.make_workload(1, n_targets=200)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    n1 = len(e.search(db))
+    y = (torch.ones(4096, device="cuda") * 2).sum().item()
+    assert y == 8192 and n1 == len(e.search(db))
+    db.close()
+    e.close()

@@ -1,0 +1,77 @@
+"""CPU: the oracle (oracle/tnt_oracle.cpp) against the committed golden vectors produced by the reference."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import tntcheck as tc
+from thermonucleotideblast_amd import abi, synth
+
+
+def test_g1_tables(oracle):
+    fx = gu.load("g1_tables.json")
+    for key, dg in fx["delta_g"].items():
+        T, na = (float(x) for x in key.split("_"))
+        t = oracle.tables(abi.options_default(target_t=T, salt=na))
+        assert np.array_equal(t["delta_g"], np.array(dg, dtype=np.int32)), key
+    t = oracle.tables(abi.options_default())
+    assert np.array_equal(t["H"], np.array(fx["param_H_bits"], dtype=np.uint32))
+    assert np.array_equal(t["S"], np.array(fx["param_S_bits"], dtype=np.uint32))
+    assert np.array_equal(t["loop_S"], np.array(fx["loop_S_bits"], dtype=np.uint32))
+    assert np.array_equal(t["bulge_S"], np.array(fx["bulge_S_bits"], dtype=np.uint32))
+    assert np.array_equal(t["scalars"], np.array(fx["scalars_bits"], dtype=np.uint32))
+    # spot values, SURVEY appendix B
+    dg = np.array(fx["delta_g"]["310.15_0.05"])
+    AT, CG, GC, TA = 3, 9, 15, 21
+    assert (dg[AT * 49 + AT], dg[AT * 49 + CG], dg[CG * 49 + GC], dg[TA * 49 + AT]) == (-6580, -10980, -18280, -2380)
+    assert ((dg < 0).sum(), (dg > 0).sum(), (dg == 0).sum()) == (97, 2304, 0)
+
+
+def test_g2_binds(oracle):
+    fx = gu.load("g2_binds.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    reqs = tc.make_reqs(fx["requests"])
+    for case in fx["cases"]:
+        out = oracle.bind_batch(gu.options_from(case["options"]), fx["oligos"], codes, offsets, reqs)
+        bad = [(i, gu.compare_bind(e, gu.bind_record(out[i]))) for i, e in enumerate(case["expected"])]
+        bad = [b for b in bad if b[1]]
+        assert not bad, "%s: %d of %d differ, first %r" % (case["name"], len(bad), len(case["expected"]), bad[:2])
+
+
+def test_g4_seeds(oracle):
+    fx = gu.load("g4_seeds.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    for k, expected in fx["seeds"].items():
+        n_t = 100 if k == "7" else 12
+        got = oracle.seeds(abi.options_default(hash_word_size=int(k)), fx["oligos"], codes[:int(offsets[n_t])], offsets[:n_t + 1])
+        assert [list(s) for s in got] == expected, "word size %s" % k
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_g5_search(oracle, cfg):
+    fx = gu.load("g5_search_cfg%d.json.gz" % cfg)
+    wl = synth.make_workload(cfg, n_targets=fx["n_targets"], n_assays=fx["n_assays"])
+    hits = oracle.search(gu.options_from(fx["options"]), wl.expanded, wl.codes, wl.offsets)
+    assert len(hits) == fx["n_hits"] > 0
+    assert gu.hits_as_keys(hits) == fx["hits"]
+
+
+def test_g5_readme_example(oracle):
+    """README.md:130-203 (gibb-marburg): dG/dH/dS of the README still hold, Tm per the current code."""
+    fx = gu.load("g5_readme.json.gz")
+    ex = synth.expand_assays([synth.Assay("gibb-marburg", *fx["assay"])])
+    t = fx["target"]
+    hits = oracle.search(gu.options_from(fx["options"]), ex, synth.encode(t), np.array([0, len(t)], dtype=np.uint64))
+    assert gu.hits_as_keys(hits) == fx["hits"]
+    h = hits[0]
+    assert (h.amplicon_start, h.amplicon_stop, h.probe_start, h.probe_stop) == (8, 154, 30, 52)
+    assert abs(h.forward_dH - -135.5) < 1e-4 and abs(h.forward_dS - -0.382533) < 1e-6
+    assert abs(h.reverse_dH - -146.5) < 1e-4 and abs(h.reverse_dS - -0.414653) < 1e-6
+    assert abs(h.probe_dH - -180.2) < 1e-4 and abs(h.probe_dS - -0.506923) < 1e-6
+    assert abs(h.forward_tm - 57.1794) < 1e-4 and abs(h.reverse_tm - 58.061) < 1e-4 and abs(h.probe_tm - 62.3354) < 1e-4
+
+
+def test_threads_do_not_change_results(oracle):
+    wl = synth.make_workload(3, n_targets=300, n_assays=20)
+    a = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets, threads=1))
+    b = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets, threads=4))
+    assert a == b and len(a) > 0

@@ -292,7 +292,18 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_ITEMS = 0, C_GROUPS, C_POOL, C_HITS, C_ERR, C_SEEDS, C_ACTIVE, C_COUNT = 8 };
+enum { C_ITEMS = 0, C_GROUPS, C_POOL, C_HITS, C_ERR, C_SEEDS, C_ACTIVE, C_PAD, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BOUND, C_COUNT = 16 };
+static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
+
+// per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
+__global__ void accumulate_kernel(uint32_t *cnt)
+{
+	unsigned long long *ti = reinterpret_cast<unsigned long long *>(cnt + C_TOT_ITEMS_LO);
+	unsigned long long *tg = reinterpret_cast<unsigned long long *>(cnt + C_TOT_GROUPS_LO);
+	*ti += cnt[C_ITEMS];
+	*tg += cnt[C_GROUPS];
+	cnt[C_TOT_BOUND] += cnt[C_POOL];
+}
 
 constexpr size_t ITEM_CAP = size_t(96) << 20;  // bind work items per internal batch
 constexpr size_t GROUP_CAP = size_t(64) << 20;
@@ -786,6 +797,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	p.hit_count = cnt + C_HITS;
 	p.err = cnt + C_ERR;
 	hipLaunchKernelGGL(pair_kernel, dim3(256), dim3(PAIR_THREADS), 0, c->stream, p);
+	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt);
 	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
 	HIP_TRY(hipGetLastError(), c->err);
 	return TNT_OK;
@@ -863,8 +875,9 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, ctx->events.front(), ctx->events.back()) == hipSuccess) T.total_ms = ms;
 	}
-	T.n_binds = cnt[C_ITEMS]; // last batch only when several batches ran; see tnt_last_timing
-	T.n_bound = cnt[C_POOL];
+	T.n_binds = (uint64_t(cnt[C_TOT_ITEMS_HI]) << 32) | cnt[C_TOT_ITEMS_LO];
+	T.n_seeds = (uint64_t(cnt[C_TOT_GROUPS_HI]) << 32) | cnt[C_TOT_GROUPS_LO]; // (target, assay) groups that reached the bind stage
+	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n;
 	if (hits) *hits = ctx->h_hits.data();
 	if (n_hits) *n_hits = n;

@@ -183,9 +183,14 @@ def _put(codes, base, pos, s):
 
 
 def make_workload(config: int, scale: float = 1.0, n_targets: Optional[int] = None,
-                  n_assays: Optional[int] = None, seed: Optional[int] = None) -> Workload:
-    """config 1..5 = BASELINE.json `configs`; scale multiplies the number of targets."""
-    rng = np.random.default_rng(config if seed is None else seed)
+                  n_assays: Optional[int] = None, seed: Optional[int] = None, shard: int = 0) -> Workload:
+    """config 1..5 = BASELINE.json `configs`; scale multiplies the number of targets.
+
+    The assay set depends on (config, seed) only; `shard` selects an independent set of targets for
+    the same assays (one shard per GPU in the weak-scaling runs)."""
+    base_seed = config if seed is None else seed
+    rng = np.random.default_rng([base_seed, 7])            # oligos
+    trng = np.random.default_rng([base_seed, 1000 + shard])  # targets and planted sites
     opt = abi.options_default(min_primer_tm=40.0, min_probe_tm=40.0)
 
     if config == 1:    # 1 primer pair x 1k x 1kb
@@ -212,7 +217,7 @@ def make_workload(config: int, scale: float = 1.0, n_targets: Optional[int] = No
     # keep the expected number of planted sites per assay useful on shrunken copies
     plant = max(plant, min(0.5, 4.0 / nt))
 
-    codes, offsets = _targets(rng, nt, tl)
+    codes, offsets = _targets(trng, nt, tl)
     assays = []
 
     for a in range(na):
@@ -230,6 +235,7 @@ def make_workload(config: int, scale: float = 1.0, n_targets: Optional[int] = No
                     Rw = _degenerate(rng, R)
                     R = _first_expansion(Rw)
             assays.append(Assay(name, Fw, Rw, P))
+            rng_save, rng = rng, trng
             n_plant = rng.binomial(nt, plant)
             for t in rng.integers(0, nt, n_plant):
                 amp = int(rng.integers(80, 401))
@@ -249,33 +255,34 @@ def make_workload(config: int, scale: float = 1.0, n_targets: Optional[int] = No
                     seg[pp:pp + len(P)] = ps if rng.random() < 0.5 else revcomp(ps)
                 seg = "".join(seg)
                 _put(codes, base, pos, revcomp(seg) if flip else seg)
+            rng = rng_save
         else:  # padlock_probe
             if a % 2 == 0:
                 # padlock: 5' probe (forward oligo, downstream) and 3' probe (reverse oligo, upstream)
                 # hybridise adjacently: target carries revcomp(reverse + forward)... see padlock_search.cpp:133-137
                 F, R = _rand_oligo(rng, 20, 25), _rand_oligo(rng, 20, 25)
                 assays.append(Assay(name, F, R, None))
-                n_plant = rng.binomial(nt, plant)
-                for t in rng.integers(0, nt, n_plant):
-                    site = _mutate(rng, F, 2) + _mutate(rng, R, 2)
-                    pos = int(rng.integers(1, tl - len(site) - 1))
-                    _put(codes, int(offsets[t]), pos, site if rng.random() < 0.5 else revcomp(site))
+                n_plant = trng.binomial(nt, plant)
+                for t in trng.integers(0, nt, n_plant):
+                    site = _mutate(trng, F, 2) + _mutate(trng, R, 2)
+                    pos = int(trng.integers(1, tl - len(site) - 1))
+                    _put(codes, int(offsets[t]), pos, site if trng.random() < 0.5 else revcomp(site))
             else:
                 P = _rand_oligo(rng, 25, 40)
                 assays.append(Assay(name, None, None, P))
-                n_plant = rng.binomial(nt, plant)
-                for t in rng.integers(0, nt, n_plant):
-                    site = _mutate(rng, P, 3)
-                    pos = int(rng.integers(1, tl - len(site) - 1))
-                    _put(codes, int(offsets[t]), pos, site if rng.random() < 0.5 else revcomp(site))
+                n_plant = trng.binomial(nt, plant)
+                for t in trng.integers(0, nt, n_plant):
+                    site = _mutate(trng, P, 3)
+                    pos = int(trng.integers(1, tl - len(site) - 1))
+                    _put(codes, int(offsets[t]), pos, site if trng.random() < 0.5 else revcomp(site))
 
     if config == 5:
         # on average 5 IUPAC bases per target and an N-run of length 10 in 1 % of the targets
-        n_deg = rng.poisson(5.0 * nt)
-        pos = rng.integers(0, nt * tl, n_deg)
-        codes[pos] = rng.integers(5, 16, n_deg).astype(np.uint8)
-        for t in np.nonzero(rng.random(nt) < 0.01)[0]:
-            p = int(rng.integers(0, tl - 10))
+        n_deg = trng.poisson(5.0 * nt)
+        pos = trng.integers(0, nt * tl, n_deg)
+        codes[pos] = trng.integers(5, 16, n_deg).astype(np.uint8)
+        for t in np.nonzero(trng.random(nt) < 0.01)[0]:
+            p = int(trng.integers(0, tl - 10))
             codes[int(offsets[t]) + p: int(offsets[t]) + p + 10] = abi.DB_CODES.index("N")
 
     wl = Workload("config%d" % config, opt, assays, codes, offsets)
