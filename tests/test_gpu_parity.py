@@ -122,9 +122,16 @@ def test_search_vs_oracle(Engine, oracle, cfg, nt, na, seed, kw):
     want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets, first=1000))
     assert got == want
     assert len(want) > 0
-    # the unit-level entries agree too
+    # the unit-level entries agree too (probe / padlock assays only seed the strands --target-strand allows)
     oligos = e.oligos
-    so = sorted((s[0], oligos[s[1]], s[2], s[3], s[4]) for s in oracle.seeds(wl.options, oligos, wl.codes, wl.offsets, first=1000))
+    allowed = {abi.MINUS, abi.PLUS}
+    if wl.options.assay_format != abi.ASSAY_PCR:
+        if not (wl.options.target_strand & abi.STRAND_MINUS):
+            allowed.discard(abi.MINUS)
+        if not (wl.options.target_strand & abi.STRAND_PLUS):
+            allowed.discard(abi.PLUS)
+    so = sorted((s[0], oligos[s[1]], s[2], s[3], s[4]) for s in oracle.seeds(wl.options, oligos, wl.codes, wl.offsets, first=1000)
+                if s[2] in allowed)
     assert sorted(e.seeds(db)) == so
     db.close()
     e.close()
