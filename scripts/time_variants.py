@@ -1,0 +1,15 @@
+"""Time the stages of one search for the library named by TNT_MI355X_LIB (kernel experiments)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from thermonucleotideblast_amd import synth
+from thermonucleotideblast_amd.engine import Engine
+cfg = int(os.environ.get("CFG", "2")); nt = int(os.environ.get("NT", "100000"))
+wl = synth.make_workload(cfg, n_targets=nt)
+eng = Engine(wl.options, wl.expanded)
+db = eng.pack(wl.codes, wl.offsets)
+for rep in range(3):
+    t = time.perf_counter(); hits = eng.search(db); dt = time.perf_counter() - t
+    tm = eng.timing()
+print("%s cfg %d nt %d: wall %.1f ms seed %.1f bind %.1f pair %.1f | binds %d groups %d bound %d hits %d" % (
+    os.path.basename(os.environ.get("TNT_MI355X_LIB", "default")), cfg, nt, dt * 1e3, tm.seed_ms, tm.bind_ms, tm.pair_ms, tm.n_binds, tm.n_seeds, tm.n_bound, len(hits)))

@@ -28,7 +28,7 @@ struct BindArgs {
 	const Tables *tab;
 	DbView db;
 	const uint8_t *olig_base;  // [n][MAX_OLIGO] BASE codes, 5'->3'
-	const uint32_t *olig_rev;  // [n][MAX_OLIGO/8] reversed (row i-1 = query[L-i]), 4 bits per base
+	const uint32_t *olig_q4;   // [n][MAX_OLIGO/4] reversed (row i-1 = query[L-i]), one byte per row = 4 * base code
 	const int32_t *olig_len;
 	const Slot *slots;
 	const Thresh *thresh;
@@ -44,10 +44,12 @@ struct BindArgs {
 	uint16_t *cols;
 	uint16_t *best;
 	uint32_t *stack;
+	uint16_t *ties;            // [TIE_CAP][lane] further cells with the maximal score
 	uint32_t *err;
 };
 
 constexpr int BIND_THREADS = 256;
+constexpr int TIE_CAP = 256;      // maximal cells of one DP beyond which the kernel reports ERR_TIE_OVERFLOW
 constexpr unsigned long long WC_MASK = // watson_and_crick[], nuc_cruc.cpp:229-238
 	(1ull << P_AT) | (1ull << P_TA) | (1ull << P_CG) | (1ull << P_GC) | (1ull << (bA * NB + bI)) | (1ull << (bI * NB + bA)) |
 	(1ull << (bT * NB + bI)) | (1ull << (bI * NB + bT)) | (1ull << (bG * NB + bI)) | (1ull << (bI * NB + bG)) |
@@ -291,12 +293,14 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	constexpr int NCOLS = LMAX + WMAX + 4;
 
 	__shared__ int32_t s_dg[NBP * NBP];
+	__shared__ uint32_t s_rt[18];
 	__shared__ uint8_t s_lut[18 * 18 + 4];
 	__shared__ uint8_t s_win[WMAX * BIND_THREADS];
 
 	const int tid = threadIdx.x;
 	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) s_dg[i] = a.tab->dg[i];
 	for (int i = tid; i < 18 * 18; i += BIND_THREADS) s_lut[i] = a.tab->bbp[i];
+	if (tid < 18) s_rt[tid] = a.tab->rt[tid];
 	__syncthreads();
 
 	const Tables &T = *a.tab;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	uint16_t *cols = a.cols + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
 	uint16_t *best = a.best + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
 	uint32_t *stack = a.stack + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
+	uint16_t *ties = a.ties + size_t(blockIdx.x) * (size_t(TIE_CAP) * BIND_THREADS) + tid;
 	uint8_t *win = s_win + tid;
 
 	const uint32_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_items;
@@ -359,111 +364,118 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 		}
 
 		// ------------------------------------------------------------------ DP fill (align_dimer, nuc_cruc.cpp:492-696)
-		uint32_t qpk[LMAX / 8];
+		// Column-major sweep, one column per iteration, all LMAX rows unrolled and branch-free: rows
+		// beyond L and columns beyond W compute throw-away values (their trace words land in scratch
+		// cells nobody reads) and are masked out of the running maximum only.
+		//
+		// Index algebra (delta_g is int32[49*49] in LDS, byte address = prev*196 + cur*4):
+		//   rt(x, q)  = resolve_degenerate(x | q), read from the 4-bit-per-partner word s_rt[x]
+		//   cur4      = 4 * bp(t, q)        = rt(t,q)*28 + 4q
+		//   p4_196    = 196 * bp(pt, q)     = rt(pt,q)*1372 + 196q      (== p1_196 of the next row)
+		//   p5_196    = 196 * bp(t, pq)     = 49 * cur4 of the previous row
+		//   p3_196    = 196 * bp(GAP, pq),  ct4 = 4 * bp(GAP, q)
+		uint32_t qpk[(LMAX + 3) / 4];
 #pragma unroll
-		for (int w = 0; w < LMAX / 8; w++) qpk[w] = active ? a.olig_rev[slot.oligo * (MAX_OLIGO / 8) + w] : 0u;
+		for (int w = 0; w < (LMAX + 3) / 4; w++) qpk[w] = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + w] : 0u;
 
 		int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
 		for (int i = 0; i < LMAX; i++) oM[i] = oQ[i] = oT[i] = -1;
 
-		int gmax = -1, nmax = 0, max_i = 0, max_j = 0;
-		int pt = bGAP, pgap = P__;
+		int gmax = -1, nmax = 0, max_ij = 0;
+		uint32_t prtw = s_rt[bGAP];
+		int pgap196 = P__ * 196;
 		// uniform trip count over the wavefront keeps the unrolled body convergent
 		int Wwave = W;
 		for (int o = 32; o > 0; o >>= 1) {
 			const int other = __shfl_xor(Wwave, o);
 			Wwave = other > Wwave ? other : Wwave;
 		}
+		const char *sdg = reinterpret_cast<const char *>(s_dg);
+#define DG(ADDR) (*reinterpret_cast<const int32_t *>(sdg + (ADDR)))
+		uint16_t *tcol = trace;
+#pragma unroll 1
 		for (int j = 1; j <= Wwave; j++) {
 			const bool colok = j <= W;
 			const int t = colok ? int(win[(j - 1) * BIND_THREADS]) : bGAP;
-			const int cq = lut_pair(s_lut, t, bGAP);
-			const int v5 = s_dg[pgap * NBP + cq];
+			const uint32_t rtw = s_rt[t];
+			const int cq4 = int((rtw >> 24) & 15u) * 28 + 24;     // 4 * bp(t, GAP)
+			const int v5 = DG(pgap196 + cq4);
 			int aM = -1, aQ = -1, aT = -1, bM = -1, bT = -1;
+			int pq4 = 24;                     // 4 * GAP
+			int pq196 = bGAP * 196;           // 196 * pq
+			int p1_196 = pgap196;             // row 1: bp(pt, GAP)
+			int p5_196 = cq4 * 49;            // row 1: 196 * bp(t, GAP)
+			// keep the per-row constants from being hoisted out of the column loop (register pressure)
+#pragma unroll
+			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(qpk[w]));
 #pragma unroll
 			for (int i = 1; i <= LMAX; i++) {
-				if (colok && i <= L) {
-					const int q = int((qpk[(i - 1) >> 3] >> (((i - 1) & 7) * 4)) & 15u);
-					const int pq = (i == 1) ? bGAP : int((qpk[(i - 2) >> 3] >> (((i - 2) & 7) * 4)) & 15u);
-					const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
-					const int cur = lut_pair(s_lut, t, q);
-					const int p1 = lut_pair(s_lut, pt, pq);
-					const int p3 = bGAP * NB + pq;
-					const int p4 = lut_pair(s_lut, pt, q);
-					const int p5 = lut_pair(s_lut, t, pq);
-					const int ct = bGAP * NB + q;
+				const int q4 = int((qpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 31u);
+				const int q196 = q4 * 49;
+				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
+				const int rtq = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
+				const int prtq = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
+				const int cur4 = rtq * 28 + q4;
+				const int p4_196 = prtq * 1372 + q196;
+				const int p3_196 = (bGAP * NB) * 196 + pq196;
+				const int ct4 = (bGAP * NB) * 4 + q4;
 
-					const int dg1 = (aM > 0 ? aM : 0) - s_dg[p1 * NBP + cur];
-					const int dg2 = (aQ > 0 ? aQ : 0) - s_dg[pgap * NBP + cur];
-					const int dg3 = (aT > 0 ? aT : 0) - s_dg[p3 * NBP + cur];
-					int M, tw;
-					if (dg1 >= dg2) {
-						if (dg1 >= dg3) {
-							M = dg1;
-							tw = 1 | (dg1 == dg2 ? 4 : 0) | (dg1 == dg3 ? 2 : 0);
-						} else {
-							M = dg3;
-							tw = 2;
-						}
-					} else {
-						if (dg2 >= dg3) {
-							M = dg2;
-							tw = 4 | (dg2 == dg3 ? 2 : 0);
-						} else {
-							M = dg3;
-							tw = 2;
-						}
-					}
-					int ins = (cM > 0 ? cM : 0) - s_dg[p4 * NBP + cq];
-					int ext = (cQ > 0 ? cQ : 0) - v5;
-					int Iq;
-					if (ins >= ext) {
-						Iq = ins;
-						tw |= TW_IQ_FROM_M | (ins == ext ? TW_IQ_FROM_IQ : 0);
-					} else {
-						Iq = ext;
-						tw |= TW_IQ_FROM_IQ;
-					}
-					ins = (bM > 0 ? bM : 0) - s_dg[p5 * NBP + ct];
-					ext = (bT > 0 ? bT : 0) - s_dg[p3 * NBP + ct];
-					int It;
-					if (ins >= ext) {
-						It = ins;
-						tw |= TW_IT_FROM_M | (ins == ext ? TW_IT_FROM_IT : 0);
-					} else {
-						It = ext;
-						tw |= TW_IT_FROM_IT;
-					}
-					tw |= (M < 0 ? TW_M_NEG : 0) | (M == 0 ? TW_M_ZERO : 0) | (Iq < 0 ? TW_IQ_NEG : 0) | (It < 0 ? TW_IT_NEG : 0);
-					// running maximum in visiting (column-major) order; the set of cells equal to the final
-					// maximum is recovered from these flags, its row-major order from the cell coordinates
-					if (M > gmax) {
-						gmax = M;
-						nmax = 1;
-						max_i = i;
-						max_j = j;
-						tw |= TW_NEWMAX;
-					} else if (M == gmax) {
-						if (nmax == 0) {
-							max_i = i;
-							max_j = j;
-						}
-						nmax++;
-						tw |= TW_EQMAX;
-					}
-					trace[((j - 1) * LMAX + (i - 1)) * BIND_THREADS] = uint16_t(tw);
-					aM = cM, aQ = cQ, aT = cT;
-					bM = M, bT = It;
-					oM[i - 1] = M, oQ[i - 1] = Iq, oT[i - 1] = It;
+				const int dg1 = (aM > 0 ? aM : 0) - DG(p1_196 + cur4);
+				const int dg2 = (aQ > 0 ? aQ : 0) - DG(pgap196 + cur4);
+				const int dg3 = (aT > 0 ? aT : 0) - DG(p3_196 + cur4);
+				// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits
+				int M = dg1 > dg2 ? dg1 : dg2;
+				M = M > dg3 ? M : dg3;
+				int tw = (dg1 == M ? 1 : 0) | (dg3 == M ? 2 : 0) | (dg2 == M ? 4 : 0);
+
+				const int iqi = (cM > 0 ? cM : 0) - DG(p4_196 + cq4);
+				const int iqe = (cQ > 0 ? cQ : 0) - v5;
+				const int Iq = iqi > iqe ? iqi : iqe;
+				tw |= (iqi >= iqe ? TW_IQ_FROM_M : 0) | (iqe >= iqi ? TW_IQ_FROM_IQ : 0);
+
+				const int iti = (bM > 0 ? bM : 0) - DG(p5_196 + ct4);
+				const int ite = (bT > 0 ? bT : 0) - DG(p3_196 + ct4);
+				const int It = iti > ite ? iti : ite;
+				tw |= (iti >= ite ? TW_IT_FROM_M : 0) | (ite >= iti ? TW_IT_FROM_IT : 0);
+
+				tw |= (M < 0 ? TW_M_NEG : 0) | (M == 0 ? TW_M_ZERO : 0) | (Iq < 0 ? TW_IQ_NEG : 0) | (It < 0 ? TW_IT_NEG : 0);
+				tcol[(i - 1) * BIND_THREADS] = uint16_t(tw);
+
+				// running maximum (visiting order is column-major; ties are collected and re-ordered later)
+				const bool cell = colok && (i <= L);
+				const bool gt = cell && (M > gmax);
+				const bool eq = cell && (M == gmax);
+				const bool first = gt || (eq && nmax == 0);
+				if (eq) { // rare: another cell with the current maximum (nuc_cruc.cpp:680-684)
+					if (nmax < TIE_CAP) ties[nmax * BIND_THREADS] = uint16_t((i << 8) | j);
+					nmax++;
 				}
+				max_ij = first ? ((i << 8) | j) : max_ij;
+				nmax = gt ? 1 : nmax;
+				gmax = gt ? M : gmax;
+
+				aM = cM, aQ = cQ, aT = cT;
+				bM = M, bT = It;
+				oM[i - 1] = M, oQ[i - 1] = Iq, oT[i - 1] = It;
+				pq4 = q4;
+				pq196 = q196;
+				p1_196 = p4_196;
+				p5_196 = cur4 * 49;
 			}
-			pt = t;
-			pgap = cq;
+			(void)pq4;
+			prtw = rtw;
+			pgap196 = cq4 * 49;
+			tcol += LMAX * BIND_THREADS;
 		}
+#undef DG
 
 		// ------------------------------------------------------------------ serial tail
 		if (!active) continue;
+#ifdef TNT_EXP_NOTAIL
+		a.result[idx] = -(gmax & 1) - 1 - (nmax & 1) - (max_ij & 1);
+		continue;
+#endif
 
 		LaneCtx c;
 		c.tab = a.tab;
@@ -483,31 +495,27 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 #define QUERY(K) int(c.query[(K)])
 #define TARGET(K) int(win[(K) * BIND_THREADS])
 
-		// tm_dimer: every maximal cell in row-major order (nuc_cruc.cpp:2533-2537)
-		const long first_pos = long(max_j) * (LMAX + 1) + max_i; // column-major rank of the first maximal cell
-		int scan_i = 1, scan_j = 0;
-		for (int mc = 0; mc < nmax; mc++) {
-			int ci, cj;
-			if (nmax == 1) {
-				ci = max_i;
-				cj = max_j;
-			} else {
-				// rare: several maximal cells; walk the matrix row-major for the next flagged one
-				while (true) {
-					scan_j++;
-					if (scan_j > W) {
-						scan_j = 1;
-						scan_i++;
-					}
-					if (scan_i > L) break; // cannot happen: nmax flagged cells exist
-					const int tw = TRACE_AT(scan_i, scan_j);
-					const long pos = long(scan_j) * (LMAX + 1) + scan_i;
-					if ((tw & (TW_NEWMAX | TW_EQMAX)) && pos >= first_pos) break;
+		// tm_dimer: every maximal cell in row-major order (nuc_cruc.cpp:2533-2537).  Cell codes (i << 8 | j)
+		// sort row-major numerically; the first maximal cell lives in max_ij, later ties in ties[1..nmax-1].
+		if (nmax > TIE_CAP) {
+			atomicOr(a.err, ERR_TIE_OVERFLOW);
+			nmax = TIE_CAP;
+		}
+		if (nmax > 1) {
+			ties[0] = uint16_t(max_ij);
+			for (int x = 1; x < nmax; x++) { // insertion sort, rare path
+				const uint16_t v = ties[x * BIND_THREADS];
+				int y = x - 1;
+				while (y >= 0 && ties[y * BIND_THREADS] > v) {
+					ties[(y + 1) * BIND_THREADS] = ties[y * BIND_THREADS];
+					y--;
 				}
-				if (scan_i > L) break;
-				ci = scan_i;
-				cj = scan_j;
+				ties[(y + 1) * BIND_THREADS] = v;
 			}
+		}
+		for (int mc = 0; mc < nmax; mc++) {
+			const int code = (nmax == 1) ? max_ij : int(ties[mc * BIND_THREADS]);
+			const int ci = code >> 8, cj = code & 255;
 
 			// ---------------- enumerate_dimer_alignments, nuc_cruc.cpp:973-1170
 			bool first_time = true;

@@ -38,6 +38,7 @@ struct Tables {
 	float bulge_S[513];
 	uint8_t bbp[18 * 18];   // best_base_pair LUT, nuc_cruc.cpp:14-213 (row = first argument)
 	uint8_t pad0[4];
+	uint32_t rt[18];        // rt[x] nibble q = resolve_degenerate(x | q) for partner q in A,C,G,T,I,E,GAP
 	float init_H, init_S, at_H, at_S, salt, asym_S, bulge_at_S;
 	float temperature;      // target_T
 	float log_na;           // logf([Na+]) computed on the host (no device logf: bit-exactness)
@@ -144,7 +145,7 @@ constexpr uint32_t WT_MINUS = 1u << 7;
 
 // status word set by kernels
 constexpr uint32_t ERR_SEED_OVERFLOW = 1, ERR_ITEM_OVERFLOW = 2, ERR_POOL_OVERFLOW = 4, ERR_HIT_OVERFLOW = 8,
-                   ERR_GROUP_OVERFLOW = 16, ERR_LIST_OVERFLOW = 32, ERR_STACK_OVERFLOW = 64;
+                   ERR_GROUP_OVERFLOW = 16, ERR_LIST_OVERFLOW = 32, ERR_STACK_OVERFLOW = 64, ERR_TIE_OVERFLOW = 128;
 
 } // namespace tnt
 #endif

@@ -99,6 +99,10 @@ void fill_tables(Tables &T, const tnt_options &opt)
 	T.word_size = opt.hash_word_size;
 	for (int x = 0; x < 18; x++)
 		for (int y = 0; y < 18; y++) T.bbp[x * 18 + y] = uint8_t(resolve(x, y) * NB + resolve(y, x));
+	for (int x = 0; x < 18; x++) {
+		T.rt[x] = 0;
+		for (int q = 0; q < NB; q++) T.rt[x] |= uint32_t(resolve(x, q)) << (4 * q);
+	}
 
 	// update_dp_param, nuc_cruc.cpp:340-487; supplementary parameters nuc_cruc.cpp:271-300
 	bool wc[NBP];
@@ -254,7 +258,7 @@ struct tnt_ctx {
 	Tables h_tab;
 	DevBuf<Tables> tab;
 	DevBuf<uint8_t> olig_base;
-	DevBuf<uint32_t> olig_rev;
+	DevBuf<uint32_t> olig_q4;
 	DevBuf<int32_t> olig_len;
 	DevBuf<Slot> slots;
 	DevBuf<Thresh> thresh;
@@ -270,7 +274,7 @@ struct tnt_ctx {
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
-	DevBuf<uint16_t> trace, cols, best;
+	DevBuf<uint16_t> trace, cols, best, ties;
 	DevBuf<uint32_t> stack;
 	DevBuf<SeedOut> seeds_out;
 	int bind_blocks = 0;
@@ -352,6 +356,7 @@ int ensure_work_buffers(tnt_ctx *c)
 	HIP_TRY(c->cols.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
 	HIP_TRY(c->best.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
 	HIP_TRY(c->stack.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
+	HIP_TRY(c->ties.alloc(size_t(c->bind_blocks) * TIE_CAP * BIND_THREADS), c->err);
 	return TNT_OK;
 }
 
@@ -362,7 +367,7 @@ BindArgs bind_args(tnt_ctx *c, const DbView &v)
 	a.tab = c->tab.p;
 	a.db = v;
 	a.olig_base = c->olig_base.p;
-	a.olig_rev = c->olig_rev.p;
+	a.olig_q4 = c->olig_q4.p;
 	a.olig_len = c->olig_len.p;
 	a.slots = c->slots.p;
 	a.thresh = c->thresh.p;
@@ -375,6 +380,7 @@ BindArgs bind_args(tnt_ctx *c, const DbView &v)
 	a.cols = c->cols.p;
 	a.best = c->best.p;
 	a.stack = c->stack.p;
+	a.ties = c->ties.p;
 	a.err = c->counters.p + C_ERR;
 	return a;
 }
@@ -388,6 +394,7 @@ const char *err_text(uint32_t e)
 	if (e & ERR_GROUP_OVERFLOW) return "group buffer overflow";
 	if (e & ERR_LIST_OVERFLOW) return "more than 64 seeds for one (target, assay)";
 	if (e & ERR_STACK_OVERFLOW) return "traceback branch stack overflow";
+	if (e & ERR_TIE_OVERFLOW) return "more than 256 maximal DP cells in one window";
 	return "unknown device error";
 }
 
@@ -542,7 +549,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	// ---- tables
 	fill_tables(c->h_tab, *opt);
 	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
-	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 8), 0);
+	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 4), 0);
 	std::vector<int32_t> ol(std::max<size_t>(1, c->oligos.size()), 0);
 	for (size_t i = 0; i < c->oligos.size(); i++) {
 		const std::string &o = c->oligos[i];
@@ -551,7 +558,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		for (int k = 0; k < L; k++) {
 			ob[i * MAX_OLIGO + k] = uint8_t(char_to_base(o[k]));
 			const uint32_t b = uint32_t(char_to_base(o[L - 1 - k])); // row k+1 of the DP uses query[L-(k+1)]
-			orv[i * (MAX_OLIGO / 8) + (k >> 3)] |= b << ((k & 7) * 4);
+			orv[i * (MAX_OLIGO / 4) + (k >> 2)] |= (b * 4u) << ((k & 3) * 8);
 		}
 	}
 
@@ -597,7 +604,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	hipError_t e = hipSuccess;
 	std::vector<Tables> tv(1, c->h_tab);
 	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
-	    (e = c->olig_rev.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
+	    (e = c->olig_q4.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
 	    (e = c->assays.upload(c->h_assays)) != hipSuccess || (e = c->wt_off.upload(wt_off)) != hipSuccess ||
 	    (e = c->wt_ent.upload(wt_ent)) != hipSuccess || (e = c->wl_off.upload(wl_off)) != hipSuccess ||

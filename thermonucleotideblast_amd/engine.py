@@ -17,7 +17,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtnt_mi355x.so")
+# TNT_MI355X_LIB points at an alternative build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("TNT_MI355X_LIB") or os.path.join(_HERE, "libtnt_mi355x.so")
 
 _lib = None
 
