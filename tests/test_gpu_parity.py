@@ -214,10 +214,19 @@ def test_size_independent_properties(Engine):
     rc = np.concatenate([comp[wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])][::-1]] for t in range(3000)])
     hits_rc = e.search(e.pack(rc, wl.offsets[:3001]))
     L = 1000
-    # F/R amplicons flip strand; single-primer amplicons (same oligo on both sides) keep theirs (amplicon_search.cpp:465)
-    flip = lambda h: (1 - h.primer_strand) if h.forward_oligo != h.reverse_oligo else h.primer_strand  # noqa: E731
-    fwd = sorted((h.assay_id, h.seq_index, h.amplicon_start, h.amplicon_stop, tc.f32_bits(h.forward_tm), tc.f32_bits(h.reverse_tm), flip(h)) for h in hits_fwd)
-    rcs = sorted((h.assay_id, h.seq_index, L - 1 - h.amplicon_stop, L - 1 - h.amplicon_start, tc.f32_bits(h.forward_tm), tc.f32_bits(h.reverse_tm), h.primer_strand) for h in hits_rc)
+    # F/R amplicons flip strand; single-primer amplicons (same oligo on both sides, amplicon_search.cpp:453-465)
+    # keep theirs and swap which site is reported in the forward / reverse slot
+    def key(h, rc):
+        single = h.forward_oligo == h.reverse_oligo
+        tms = (tc.f32_bits(h.forward_tm), tc.f32_bits(h.reverse_tm))
+        if single:
+            tms = tuple(sorted(tms))
+        if rc:
+            return (h.assay_id, h.seq_index, L - 1 - h.amplicon_stop, L - 1 - h.amplicon_start) + tms + (h.primer_strand,)
+        strand = h.primer_strand if single else 1 - h.primer_strand
+        return (h.assay_id, h.seq_index, h.amplicon_start, h.amplicon_stop) + tms + (strand,)
+    fwd = sorted(key(h, False) for h in hits_fwd)
+    rcs = sorted(key(h, True) for h in hits_rc)
     assert fwd == rcs and len(fwd) > 0
     e.close()
 

@@ -20,6 +20,7 @@
 #define TNT_BIND_HIP_H
 
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "tnt_dev.h"
 
 namespace tnt {
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 			const int cq4 = int((rtw >> 24) & 15u) * 28 + 24;     // 4 * bp(t, GAP)
 			const int v5 = DG(pgap196 + cq4);
 			int aM = -1, aQ = -1, aT = -1, bM = -1, bT = -1;
+			const int Lcol = colok ? L : 0;   // rows that count in this column
+			int colmax = INT32_MIN;
 			int pq4 = 24;                     // 4 * GAP
 			int pq196 = bGAP * 196;           // 196 * pq
 			int p1_196 = pgap196;             // row 1: bp(pt, GAP)
@@ -439,21 +442,15 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				const int It = iti > ite ? iti : ite;
 				tw |= (iti >= ite ? TW_IT_FROM_M : 0) | (ite >= iti ? TW_IT_FROM_IT : 0);
 
-				tw |= (M < 0 ? TW_M_NEG : 0) | (M == 0 ? TW_M_ZERO : 0) | (Iq < 0 ? TW_IQ_NEG : 0) | (It < 0 ? TW_IT_NEG : 0);
+				// sign class of M (0 negative, 1 zero, 2 positive) and the sign bits of the gap states
+				tw |= ((M < -1 ? -1 : (M > 1 ? 1 : M)) + 1) << TW_MCLASS_SHIFT; // v_med3_i32
+				tw |= int(uint32_t(Iq) >> 31) << TW_IQ_NEG_SHIFT;
+				tw |= int(uint32_t(It) >> 31) << TW_IT_NEG_SHIFT;
 				tcol[(i - 1) * BIND_THREADS] = uint16_t(tw);
 
-				// running maximum (visiting order is column-major; ties are collected and re-ordered later)
-				const bool cell = colok && (i <= L);
-				const bool gt = cell && (M > gmax);
-				const bool eq = cell && (M == gmax);
-				const bool first = gt || (eq && nmax == 0);
-				if (eq) { // rare: another cell with the current maximum (nuc_cruc.cpp:680-684)
-					if (nmax < TIE_CAP) ties[nmax * BIND_THREADS] = uint16_t((i << 8) | j);
-					nmax++;
-				}
-				max_ij = first ? ((i << 8) | j) : max_ij;
-				nmax = gt ? 1 : nmax;
-				gmax = gt ? M : gmax;
+				// column maximum over the valid rows; the running maximum is updated once per column below
+				const int Mv = (i <= Lcol) ? M : INT32_MIN;
+				colmax = colmax > Mv ? colmax : Mv;
 
 				aM = cM, aQ = cQ, aT = cT;
 				bM = M, bT = It;
@@ -464,6 +461,26 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				p5_196 = cur4 * 49;
 			}
 			(void)pq4;
+			// Running maximum, nuc_cruc.cpp:670-691.  The reference visits cells row-major; here the visiting
+			// order is column-major, rows ascending.  The SET of cells holding the final maximum does not depend
+			// on the order; it is collected as (i << 8 | j) codes and sorted row-major before the traceback.
+			if (colmax >= gmax) {
+#pragma unroll
+				for (int i = 1; i <= LMAX; i++) {
+					if (i <= Lcol && oM[i - 1] == colmax) {
+						const int code = (i << 8) | j;
+						if (colmax > gmax) {
+							gmax = colmax;
+							nmax = 1;
+							max_ij = code;
+						} else {
+							if (nmax == 0) max_ij = code;
+							else if (nmax < TIE_CAP) ties[nmax * BIND_THREADS] = uint16_t(code);
+							nmax++;
+						}
+					}
+				}
+			}
 			prtw = rtw;
 			pgap196 = cq4 * 49;
 			tcol += LMAX * BIND_THREADS;
@@ -572,14 +589,15 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 					}
 					// border cells hold M = I_query = I_target = -1 (nuc_cruc.h:531-536)
 					const bool inside = (li >= 1 && lj >= 1);
-					const int tw = inside ? int(TRACE_AT(li, lj)) : (TW_M_NEG | TW_IQ_NEG | TW_IT_NEG);
+					const int tw = inside ? int(TRACE_AT(li, lj)) : (TW_IQ_NEG | TW_IT_NEG); // mclass 0 = negative
 					const int cidx = li * (WMAX + 1) + lj;
 					if (local == 1) { // query_target
 						if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
 							valid = false;
 						} else {
-							if (tw & TW_M_NEG) valid = false;
-							else if (tw & TW_M_ZERO) {
+							const int mclass = (tw >> TW_MCLASS_SHIFT) & 3;
+							if (mclass == 0) valid = false;
+							else if (mclass == 1) {
 								if (count_zeros) zero_count++;
 								else if (--truncate_at_zero == 0) valid = false;
 							}

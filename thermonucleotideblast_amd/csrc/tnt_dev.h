@@ -26,8 +26,9 @@ constexpr int TW_IQ_FROM_M = 8;   // I_query_trace & im1_jm1
 constexpr int TW_IQ_FROM_IQ = 16; // I_query_trace & i_jm1
 constexpr int TW_IT_FROM_M = 32;  // I_target_trace & im1_jm1
 constexpr int TW_IT_FROM_IT = 64; // I_target_trace & im1_j
-constexpr int TW_M_NEG = 128, TW_M_ZERO = 256, TW_IQ_NEG = 512, TW_IT_NEG = 1024;
-constexpr int TW_NEWMAX = 2048, TW_EQMAX = 4096;
+constexpr int TW_MCLASS_SHIFT = 7;                 // bits 7-8: sign class of M (0 negative, 1 zero, 2 positive)
+constexpr int TW_IQ_NEG_SHIFT = 9, TW_IT_NEG_SHIFT = 10;
+constexpr int TW_IQ_NEG = 1 << TW_IQ_NEG_SHIFT, TW_IT_NEG = 1 << TW_IT_NEG_SHIFT;
 
 // Thermodynamic tables resident in HBM (19 KB floats + 9.6 KB ints); delta_g is staged into LDS.
 struct Tables {

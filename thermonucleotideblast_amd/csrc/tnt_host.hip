@@ -252,6 +252,7 @@ struct tnt_ctx {
 	std::vector<Slot> h_slots;
 	std::vector<float> h_slot_ct;
 	int lmax = 24; // template instance of the bind kernel
+	int scratch_lmax = 24; // what the scratch slabs are sized for
 	size_t n_entries = 0;
 	std::vector<uint32_t> chunk_begin; // assay chunks for the seed kernel (+ end)
 
@@ -328,36 +329,60 @@ DbView make_view(const tnt_db *db, size_t t0, size_t t1)
 	return v;
 }
 
-template <bool FULL> void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks)
+// Template instances of the bind kernel: rows kept in registers.  Padding rows cost full work, so the
+// ladder is fine-grained where assay oligos usually sit (18-32) and coarser above.
+#define TNT_LMAX_LADDER(X) X(20) X(22) X(24) X(25) X(26) X(28) X(30) X(32) X(36) X(40) X(48) X(56) X(64)
+
+int pick_lmax(size_t max_len)
 {
+#define X(N) if (max_len <= N) return N;
+	TNT_LMAX_LADDER(X)
+#undef X
+	return 64;
+}
+
+void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, bool full)
+{
+	if (full) { // unit-level API: one instance is enough
+		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a);
+		return;
+	}
 	switch (c->lmax) {
-	case 24: hipLaunchKernelGGL((bind_kernel<24, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
-	case 32: hipLaunchKernelGGL((bind_kernel<32, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
-	case 48: hipLaunchKernelGGL((bind_kernel<48, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
-	default: hipLaunchKernelGGL((bind_kernel<64, FULL>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
+#define X(N) case N: hipLaunchKernelGGL((bind_kernel<N, false>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
+		TNT_LMAX_LADDER(X)
+#undef X
+	default: break;
 	}
 }
 
-int ensure_work_buffers(tnt_ctx *c)
+int ensure_scratch(tnt_ctx *c, int need_lmax)
 {
-	if (c->items.p) return TNT_OK;
-	HIP_TRY(c->items.alloc(ITEM_CAP), c->err);
-	HIP_TRY(c->result.alloc(ITEM_CAP), c->err);
-	HIP_TRY(c->groups.alloc(GROUP_CAP), c->err);
-	HIP_TRY(c->active.alloc(GROUP_CAP), c->err);
-	HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
-	HIP_TRY(c->hits.alloc(HIT_CAP), c->err);
-	HIP_TRY(c->counters.alloc(C_COUNT), c->err);
+	if (c->trace.p && c->scratch_lmax >= need_lmax) return TNT_OK;
+	c->scratch_lmax = std::max(c->scratch_lmax, need_lmax);
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, c->device), c->err);
 	c->bind_blocks = prop.multiProcessorCount * 4;
-	const size_t lm = size_t(c->lmax), wm = lm + 2 * FLANK, nc = lm + wm + 4;
+	const size_t lm = size_t(c->scratch_lmax), wm = lm + 2 * FLANK, nc = lm + wm + 4;
 	HIP_TRY(c->trace.alloc(size_t(c->bind_blocks) * lm * wm * BIND_THREADS), c->err);
 	HIP_TRY(c->cols.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
 	HIP_TRY(c->best.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
 	HIP_TRY(c->stack.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
 	HIP_TRY(c->ties.alloc(size_t(c->bind_blocks) * TIE_CAP * BIND_THREADS), c->err);
 	return TNT_OK;
+}
+
+int ensure_work_buffers(tnt_ctx *c, int need_lmax)
+{
+	if (!c->items.p) {
+		HIP_TRY(c->items.alloc(ITEM_CAP), c->err);
+		HIP_TRY(c->result.alloc(ITEM_CAP), c->err);
+		HIP_TRY(c->groups.alloc(GROUP_CAP), c->err);
+		HIP_TRY(c->active.alloc(GROUP_CAP), c->err);
+		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
+		HIP_TRY(c->hits.alloc(HIT_CAP), c->err);
+		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
+	}
+	return ensure_scratch(c, need_lmax);
 }
 
 BindArgs bind_args(tnt_ctx *c, const DbView &v)
@@ -544,7 +569,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 			if (char_to_base(ch) < 0) FAIL(TNT_E_ARG, "oligos must be expanded to A/C/G/T/I (expand_degenerate_signatures)");
 		max_L = std::max(max_L, o.size());
 	}
-	c->lmax = max_L <= 24 ? 24 : (max_L <= 32 ? 32 : (max_L <= 48 ? 48 : 64));
+	c->lmax = pick_lmax(max_L);
 
 	// ---- tables
 	fill_tables(c->h_tab, *opt);
@@ -773,7 +798,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	BindArgs b = bind_args(c, v);
 	b.n_items = 0; // read from the device counter
 	b.n_items_dev = cnt + C_ITEMS;
-	launch_bind<false>(c, b, c->bind_blocks);
+	launch_bind(c, b, c->bind_blocks, false);
 	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 
 	FilterArgs f;
@@ -837,7 +862,7 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 {
 	if (!ctx || !db || db->ctx != ctx) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx);
+	int rc = ensure_work_buffers(ctx, ctx->lmax);
 	if (rc) return rc;
 	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
 	ctx->events.clear();
@@ -909,7 +934,7 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 {
 	if (!ctx || !db || db->ctx != ctx || !seeds || !n_seeds) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx);
+	int rc = ensure_work_buffers(ctx, ctx->lmax);
 	if (rc) return rc;
 	size_t tpb = 1;
 	plan(ctx, db, tpb);
@@ -974,7 +999,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	if (n == 0) return TNT_OK;
 	if (n > ITEM_CAP) return TNT_E_LIMIT;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx);
+	int rc = ensure_work_buffers(ctx, 64); // the unit-level kernel instance is bind_kernel<64, true>
 	if (rc) return rc;
 	// one temporary slot per request (arbitrary strand concentration)
 	std::vector<Slot> slots(n);
@@ -1007,7 +1032,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	b.n_items = uint32_t(n);
 	b.n_items_dev = nullptr;
 	b.full = dfull.p;
-	launch_bind<true>(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + BIND_THREADS - 1) / BIND_THREADS)));
+	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + BIND_THREADS - 1) / BIND_THREADS)), true);
 	HIP_TRY(hipGetLastError(), ctx->err);
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);

@@ -35,6 +35,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise TntError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; whichever copy is loaded first serves the whole
+    # process.  Load torch's first (when torch is installed) so torch tensors, RCCL and these kernels always
+    # share ONE HIP runtime regardless of import order.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     lib.tnt_abi_version.restype = C.c_int
