@@ -141,7 +141,8 @@ struct AssayDev {
 
 // seed-table entry: one query word of one (assay, role, strand)
 //   bits 0-6 word index, bit 7 strand (1 = minus / DNAHash::find, 0 = plus / find_complement),
-//   bits 8-9 role (0 F, 1 R, 2 P), bits 10-31 expanded assay index
+//   bits 8-9 role (0 F, 1 R, 2 P), bit 10 set for probe / padlock assays (hash-overload lists),
+//   bits 11-31 expanded assay index
 constexpr uint32_t WT_MINUS = 1u << 7;
 
 // status word set by kernels

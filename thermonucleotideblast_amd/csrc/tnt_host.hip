@@ -264,8 +264,11 @@ struct tnt_ctx {
 	DevBuf<Slot> slots;
 	DevBuf<Thresh> thresh;
 	DevBuf<AssayDev> assays;
-	DevBuf<uint32_t> wt_off, wt_ent, wl_off;
-	DevBuf<uint16_t> wlist;
+	DevBuf<uint32_t> wt_ent, wl_off;
+	DevBuf<uint16_t> wt_off, wlist;
+	std::vector<std::vector<std::pair<uint16_t, uint32_t>>> assay_entries; // per assay: (word, entry bits)
+	std::vector<uint32_t> chunk_ent_base;  // first entry of every chunk in wt_ent
+	std::vector<uint32_t> planned_chunks;  // chunk_begin the device tables were built for
 
 	// work buffers
 	DevBuf<Item> items;
@@ -592,8 +595,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	const size_t n_words = size_t(1) << (2 * k);
 	std::vector<uint32_t> wl_off(c->h_assays.size() * 6 + 1, 0);
 	std::vector<uint16_t> wlist;
-	std::vector<std::vector<uint32_t>> buckets(n_words);
-	std::vector<size_t> entries_per_assay(c->h_assays.size(), 0);
+	c->assay_entries.assign(c->h_assays.size(), {});
+	c->n_entries = 0;
 	for (size_t ai = 0; ai < c->h_assays.size(); ai++) {
 		const AssayDev &d = c->h_assays[ai];
 		const int slots3[3] = {d.slot_f, d.slot_r, d.slot_p};
@@ -608,31 +611,25 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				const std::string &o = c->oligos[c->h_slots[slots3[role]].oligo];
 				const std::vector<uint16_t> w = word_list(o, minus == 0, k); // plus strand: find_complement
 				if (w.size() > 127) FAIL(TNT_E_LIMIT, "too many query words");
-				if (ai >= (size_t(1) << 22)) FAIL(TNT_E_LIMIT, "too many assays");
+				if (ai >= (size_t(1) << 21)) FAIL(TNT_E_LIMIT, "too many assays");
 				for (size_t wi = 0; wi < w.size(); wi++) {
-					buckets[w[wi]].push_back(uint32_t(wi) | (minus ? WT_MINUS : 0u) | (uint32_t(role) << 8) | (uint32_t(ai) << 10));
+					c->assay_entries[ai].push_back(std::make_pair(
+						w[wi], uint32_t(wi) | (minus ? WT_MINUS : 0u) | (uint32_t(role) << 8) | (d.kind != 0 ? (1u << 10) : 0u) |
+						           (uint32_t(ai) << 11)));
 					wlist.push_back(w[wi]);
 				}
-				entries_per_assay[ai] += w.size();
+				c->n_entries += w.size();
 			}
 	}
 	wl_off[c->h_assays.size() * 6] = uint32_t(wlist.size());
-	std::vector<uint32_t> wt_off(n_words + 1, 0), wt_ent;
-	for (size_t w = 0; w < n_words; w++) {
-		wt_off[w] = uint32_t(wt_ent.size());
-		wt_ent.insert(wt_ent.end(), buckets[w].begin(), buckets[w].end());
-	}
-	wt_off[n_words] = uint32_t(wt_ent.size());
-	c->n_entries = wt_ent.size();
-	(void)entries_per_assay;
+	(void)n_words; // the per-chunk bucket tables are built by plan() once the target lengths are known
 
 	hipError_t e = hipSuccess;
 	std::vector<Tables> tv(1, c->h_tab);
 	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
 	    (e = c->olig_q4.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
-	    (e = c->assays.upload(c->h_assays)) != hipSuccess || (e = c->wt_off.upload(wt_off)) != hipSuccess ||
-	    (e = c->wt_ent.upload(wt_ent)) != hipSuccess || (e = c->wl_off.upload(wl_off)) != hipSuccess ||
+	    (e = c->assays.upload(c->h_assays)) != hipSuccess || (e = c->wl_off.upload(wl_off)) != hipSuccess ||
 	    (e = c->wlist.upload(wlist)) != hipSuccess)
 		FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
 #undef FAIL
@@ -766,8 +763,6 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	memset(&s, 0, sizeof(s));
 	s.db = v;
 	s.word_size = c->opt.hash_word_size;
-	s.wt_off = c->wt_off.p;
-	s.wt_ent = c->wt_ent.p;
 	s.wlist = c->wlist.p;
 	s.wl_off = c->wl_off.p;
 	s.assays = c->assays.p;
@@ -787,10 +782,16 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	}
 	s.err = cnt + C_ERR;
 	const int seed_blocks = int(std::min<size_t>(t1 - t0, size_t(c->bind_blocks) * 8));
+	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
 		s.assay_begin = c->chunk_begin[ch];
 		s.assay_end = c->chunk_begin[ch + 1];
-		hipLaunchKernelGGL(seed_kernel, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
+		s.wt_off = c->wt_off.p + ch * (n_words + 1);
+		s.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
+		if (c->opt.hash_word_size <= 7)
+			hipLaunchKernelGGL(seed_kernel<true>, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
+		else
+			hipLaunchKernelGGL(seed_kernel<false>, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
 	}
 	HIP_TRY(hipEventRecord(ev[1], c->stream), c->err);
 	if (seeds_only) return TNT_OK;
@@ -836,19 +837,57 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 }
 
 // Assay chunks for the seed kernel and target batches sized so the expected number of seeds fits.
-static void plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
+// Every chunk gets its own bucket table (16-bit offsets, < 65536 entries) so it can sit in LDS.
+static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 {
-	const double words = double(size_t(1) << (2 * c->opt.hash_word_size));
+	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
+	const double words = double(n_words);
 	const double per_base = double(c->n_entries) / words; // expected raw seeds per target base
 	const double maxlen = std::max<double>(1.0, db->max_len);
-	// chunk so that a target of the longest length yields <= SEED_CAP/2 seeds on average
-	size_t n_assays = c->h_assays.size();
-	double ent_per_assay = n_assays ? double(c->n_entries) / double(n_assays) : 1.0;
-	size_t per_chunk = size_t(std::max(1.0, (SEED_CAP / 2) * words / (maxlen * std::max(1.0, ent_per_assay))));
-	per_chunk = std::min<size_t>(per_chunk, SEED_MAX_ASSAYS);
-	c->chunk_begin.clear();
-	for (size_t a = 0; a < n_assays; a += per_chunk) c->chunk_begin.push_back(uint32_t(a));
-	c->chunk_begin.push_back(uint32_t(n_assays));
+	const size_t n_assays = c->h_assays.size();
+	// a target of the longest length should yield <= SEED_CAP/2 seeds on average
+	const double ent_budget = std::max(1.0, (SEED_CAP / 2) * words / maxlen);
+	std::vector<uint32_t> chunk_begin;
+	size_t a0 = 0;
+	while (a0 < n_assays) {
+		size_t a1 = a0, ent = 0;
+		while (a1 < n_assays && a1 - a0 < size_t(SEED_MAX_ASSAYS)) {
+			const size_t e = c->assay_entries[a1].size();
+			if (a1 > a0 && (double(ent + e) > ent_budget || ent + e > 65535)) break;
+			ent += e;
+			a1++;
+		}
+		chunk_begin.push_back(uint32_t(a0));
+		a0 = a1;
+	}
+	chunk_begin.push_back(uint32_t(n_assays));
+	if (chunk_begin != c->planned_chunks) {
+		std::vector<uint16_t> off;
+		std::vector<uint32_t> ent;
+		c->chunk_ent_base.clear();
+		std::vector<std::vector<uint32_t>> buckets(n_words);
+		for (size_t ch = 0; ch + 1 < chunk_begin.size(); ch++) {
+			for (auto &b : buckets) b.clear();
+			for (uint32_t ai = chunk_begin[ch]; ai < chunk_begin[ch + 1]; ai++)
+				for (const auto &we : c->assay_entries[ai]) buckets[we.first].push_back(we.second);
+			c->chunk_ent_base.push_back(uint32_t(ent.size()));
+			const size_t base = ent.size();
+			for (size_t w = 0; w < n_words; w++) {
+				off.push_back(uint16_t(ent.size() - base));
+				ent.insert(ent.end(), buckets[w].begin(), buckets[w].end());
+			}
+			if (ent.size() - base > 65535) {
+				c->err = "one assay has more than 65535 query words";
+				return TNT_E_LIMIT;
+			}
+			off.push_back(uint16_t(ent.size() - base));
+		}
+		HIP_TRY(hipStreamSynchronize(c->stream), c->err);
+		HIP_TRY(c->wt_off.upload(off), c->err);
+		HIP_TRY(c->wt_ent.upload(ent), c->err);
+		c->planned_chunks = chunk_begin;
+	}
+	c->chunk_begin = chunk_begin;
 	// batch of targets: expected kept seeds (<= raw) must stay below ITEM_CAP / 2
 	const double avg_len = db->n_targets ? double(db->n_bases) / double(db->n_targets) : 1.0;
 	const double per_target = std::max(1.0, per_base * avg_len);
@@ -856,6 +895,7 @@ static void plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	const double gb = (double(GROUP_CAP) / 2.0) / std::max<double>(1.0, double(n_assays));
 	tb = std::min(tb, gb);
 	targets_per_batch = size_t(std::max(1.0, std::min(tb, double(std::max<size_t>(1, db->n_targets)))));
+	return TNT_OK;
 }
 
 int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
@@ -868,7 +908,8 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	ctx->events.clear();
 	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 	size_t tpb = 1;
-	plan(ctx, db, tpb);
+	rc = plan(ctx, db, tpb);
+	if (rc) return rc;
 	ctx->n_batches = 0;
 	for (size_t t0 = 0; t0 < db->n_targets; t0 += tpb) {
 		rc = enqueue_batch(ctx, db, t0, std::min(db->n_targets, t0 + tpb), false);
@@ -937,7 +978,8 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 	int rc = ensure_work_buffers(ctx, ctx->lmax);
 	if (rc) return rc;
 	size_t tpb = 1;
-	plan(ctx, db, tpb);
+	rc = plan(ctx, db, tpb);
+	if (rc) return rc;
 	const double words = double(size_t(1) << (2 * ctx->opt.hash_word_size));
 	const size_t cap = size_t(double(db->n_bases) * double(ctx->n_entries) / words * 2.0) + (1u << 20);
 	HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err);
