@@ -36,6 +36,7 @@ struct BindArgs {
 	const Item *items;
 	uint32_t n_items;
 	const uint32_t *n_items_dev; // when set, the item count is read from the device counter
+	const uint32_t *index;       // optional work list: item indices to bind (phase A / phase B queues)
 	int32_t *result;           // per item: pool index (>= 0) or -status
 	BoundRec *pool;
 	uint32_t pool_cap;
@@ -314,8 +315,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 
 	const uint32_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_items;
 	for (uint32_t base = blockIdx.x * BIND_THREADS; base < n_items; base += gridDim.x * BIND_THREADS) {
-		const uint32_t idx = base + tid;
-		const bool active = idx < n_items;
+		const bool active = base + tid < n_items;
+		const uint32_t idx = active ? (a.index ? a.index[base + tid] : base + tid) : 0u;
 
 		// ------------------------------------------------------------------ item decode
 		Item it = active ? a.items[idx] : Item{0, 0, 0, 0};

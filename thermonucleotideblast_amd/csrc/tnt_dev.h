@@ -70,6 +70,7 @@ struct Item {
 	uint32_t info;    // bits 0-7 query_loc (word index), bit 8 strand (0 plus, 1 minus), bits 9-11 role group
 };
 constexpr uint32_t ITEM_MINUS = 1u << 8;
+constexpr uint32_t ITEM_PHASE_B = 1u << 12; // bound only if a phase-A item of its group bound (second strand / probe)
 
 // result of one bind; pool record only exists for bound items
 struct BoundRec {
@@ -141,9 +142,11 @@ struct AssayDev {
 
 // seed-table entry: one query word of one (assay, role, strand)
 //   bits 0-6 word index, bit 7 strand (1 = minus / DNAHash::find, 0 = plus / find_complement),
-//   bits 8-9 role (0 F, 1 R, 2 P), bit 10 set for probe / padlock assays (hash-overload lists),
-//   bits 11-31 expanded assay index
-constexpr uint32_t WT_MINUS = 1u << 7;
+//   bits 8-9 role (0 F, 1 R, 2 P), bit 10 probe / padlock assay (hash-overload lists),
+//   bit 11 the PCR assay has a probe, bit 12 plain A/C/G/T oligo (word index == base offset),
+//   bits 13-31 expanded assay index
+constexpr uint32_t WT_MINUS = 1u << 7, WT_NONPCR = 1u << 10, WT_HASPROBE = 1u << 11, WT_PLAIN = 1u << 12;
+constexpr int WT_ASSAY_SHIFT = 13;
 
 // status word set by kernels
 constexpr uint32_t ERR_SEED_OVERFLOW = 1, ERR_ITEM_OVERFLOW = 2, ERR_POOL_OVERFLOW = 4, ERR_HIT_OVERFLOW = 8,

@@ -250,7 +250,6 @@ struct tnt_ctx {
 	std::vector<std::string> oligos;
 	std::vector<AssayDev> h_assays;
 	std::vector<Slot> h_slots;
-	std::vector<float> h_slot_ct;
 	int lmax = 24; // template instance of the bind kernel
 	int scratch_lmax = 24; // what the scratch slabs are sized for
 	size_t n_entries = 0;
@@ -265,6 +264,7 @@ struct tnt_ctx {
 	DevBuf<Thresh> thresh;
 	DevBuf<AssayDev> assays;
 	DevBuf<uint32_t> wt_ent, wl_off;
+	DevBuf<unsigned long long> wl_seq;
 	DevBuf<uint16_t> wt_off, wlist;
 	std::vector<std::vector<std::pair<uint16_t, uint32_t>>> assay_entries; // per assay: (word, entry bits)
 	std::vector<uint32_t> chunk_ent_base;  // first entry of every chunk in wt_ent
@@ -274,7 +274,7 @@ struct tnt_ctx {
 	DevBuf<Item> items;
 	DevBuf<int32_t> result;
 	DevBuf<Group> groups;
-	DevBuf<uint32_t> active;
+	DevBuf<uint32_t> active, qa, qb;
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
@@ -300,16 +300,18 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_ITEMS = 0, C_GROUPS, C_POOL, C_HITS, C_ERR, C_SEEDS, C_ACTIVE, C_PAD, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BOUND, C_COUNT = 16 };
-static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
+enum { C_ITEMS = 0, C_GROUPS, C_POOL, C_ACTIVE, C_QA, C_QB, C_HITS, C_ERR, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS, C_COUNT = 16 };
+static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
 __global__ void accumulate_kernel(uint32_t *cnt)
 {
 	unsigned long long *ti = reinterpret_cast<unsigned long long *>(cnt + C_TOT_ITEMS_LO);
 	unsigned long long *tg = reinterpret_cast<unsigned long long *>(cnt + C_TOT_GROUPS_LO);
+	unsigned long long *tb = reinterpret_cast<unsigned long long *>(cnt + C_TOT_BINDS_LO);
 	*ti += cnt[C_ITEMS];
 	*tg += cnt[C_GROUPS];
+	*tb += cnt[C_QA] + cnt[C_QB];
 	cnt[C_TOT_BOUND] += cnt[C_POOL];
 }
 
@@ -381,6 +383,8 @@ int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 		HIP_TRY(c->result.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->groups.alloc(GROUP_CAP), c->err);
 		HIP_TRY(c->active.alloc(GROUP_CAP), c->err);
+		HIP_TRY(c->qa.alloc(ITEM_CAP), c->err);
+		HIP_TRY(c->qb.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
 		HIP_TRY(c->hits.alloc(HIT_CAP), c->err);
 		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
@@ -542,26 +546,25 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 			d.kind = 2;
 		}
 		d.has_probe = (primers && A.probe && d.kind == 0) ? 1 : 0;
-		auto add_slot = [&](const char *s, float ct, int thr) -> int {
-			const int o = intern(s);
-			Slot sl;
-			sl.oligo = o;
+		// Slot table is laid out [assay][role] so the kernels address it without an indirection
+		c->h_slots.resize((i + 1) * 3, Slot{-1, 0.0f, 0, int(i)});
+		auto add_slot = [&](int role, const char *s, float ct, int thr) -> int {
+			Slot &sl = c->h_slots[i * 3 + role];
+			sl.oligo = intern(s);
 			sl.log_ct = logf(ct * 1.0f); // nuc_cruc.cpp:2291 with heterodimer_inv_alpha = 1
 			sl.thresh = thr;
 			sl.assay = int(i);
-			c->h_slots.push_back(sl);
-			c->h_slot_ct.push_back(ct);
-			return int(c->h_slots.size()) - 1;
+			return int(i * 3 + role);
 		};
 		if (primers && d.kind >= 0) {
 			// strand(c, 0) = c - 0.5f*0 (nuc_cruc.h:890-910)
 			const float fs = fwd_strand / A.forward_degen - 0.5f * 0.0f, rs = rev_strand / A.reverse_degen - 0.5f * 0.0f;
-			d.slot_f = add_slot(A.forward, fs, d.kind == 0 ? 0 : 3);
-			d.slot_r = add_slot(A.reverse, rs, d.kind == 0 ? 0 : 2);
+			d.slot_f = add_slot(0, A.forward, fs, d.kind == 0 ? 0 : 3);
+			d.slot_r = add_slot(1, A.reverse, rs, d.kind == 0 ? 0 : 2);
 		}
 		if (A.probe && (d.kind == 2 || d.has_probe)) {
 			const float ps = opt->probe_strand / A.probe_degen;
-			d.slot_p = add_slot(A.probe, ps, 1);
+			d.slot_p = add_slot(2, A.probe, ps, 1);
 		}
 		c->h_assays.push_back(d);
 	}
@@ -595,6 +598,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	const size_t n_words = size_t(1) << (2 * k);
 	std::vector<uint32_t> wl_off(c->h_assays.size() * 6 + 1, 0);
 	std::vector<uint16_t> wlist;
+	std::vector<unsigned long long> wl_seq(c->h_assays.size() * 12 + 2, 0ull);
 	c->assay_entries.assign(c->h_assays.size(), {});
 	c->n_entries = 0;
 	for (size_t ai = 0; ai < c->h_assays.size(); ai++) {
@@ -610,12 +614,26 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				if (d.kind != 0 && !(opt->target_strand & (minus ? TNT_STRAND_MINUS : TNT_STRAND_PLUS))) continue;
 				const std::string &o = c->oligos[c->h_slots[slots3[role]].oligo];
 				const std::vector<uint16_t> w = word_list(o, minus == 0, k); // plus strand: find_complement
+				// the strand-specific sequence, 2 bits per base (plain A/C/G/T oligos only: word index == base offset)
+				bool plain = true;
+				for (size_t x = 0; x < o.size(); x++) {
+					const char ch = minus ? o[x] : o[o.size() - 1 - x];
+					int b2 = -1;
+					switch (ch) {
+					case 'A': case 'a': b2 = minus ? 0 : 3; break;
+					case 'C': case 'c': b2 = minus ? 1 : 2; break;
+					case 'G': case 'g': b2 = minus ? 2 : 1; break;
+					case 'T': case 't': b2 = minus ? 3 : 0; break;
+					default: plain = false; break;
+					}
+					if (b2 >= 0) wl_seq[li * 2 + (x >> 5)] |= (unsigned long long)b2 << ((x & 31) * 2);
+				}
 				if (w.size() > 127) FAIL(TNT_E_LIMIT, "too many query words");
-				if (ai >= (size_t(1) << 21)) FAIL(TNT_E_LIMIT, "too many assays");
+				if (ai >= (size_t(1) << (32 - WT_ASSAY_SHIFT))) FAIL(TNT_E_LIMIT, "too many assays");
 				for (size_t wi = 0; wi < w.size(); wi++) {
 					c->assay_entries[ai].push_back(std::make_pair(
-						w[wi], uint32_t(wi) | (minus ? WT_MINUS : 0u) | (uint32_t(role) << 8) | (d.kind != 0 ? (1u << 10) : 0u) |
-						           (uint32_t(ai) << 11)));
+						w[wi], uint32_t(wi) | (minus ? WT_MINUS : 0u) | (uint32_t(role) << 8) | (d.kind != 0 ? WT_NONPCR : 0u) |
+						           (d.has_probe ? WT_HASPROBE : 0u) | (plain ? WT_PLAIN : 0u) | (uint32_t(ai) << WT_ASSAY_SHIFT)));
 					wlist.push_back(w[wi]);
 				}
 				c->n_entries += w.size();
@@ -630,6 +648,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	    (e = c->olig_q4.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
 	    (e = c->assays.upload(c->h_assays)) != hipSuccess || (e = c->wl_off.upload(wl_off)) != hipSuccess ||
+	    (e = c->wl_seq.upload(wl_seq)) != hipSuccess ||
 	    (e = c->wlist.upload(wlist)) != hipSuccess)
 		FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
 #undef FAIL
@@ -749,8 +768,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	const DbView v = make_view(db, t0, t1);
 	uint32_t *cnt = c->counters.p;
 	// hits and the error word accumulate over batches; the rest restarts
-	HIP_TRY(hipMemsetAsync(cnt + C_ITEMS, 0, sizeof(uint32_t) * 3, c->stream), c->err);
-	HIP_TRY(hipMemsetAsync(cnt + C_ACTIVE, 0, sizeof(uint32_t), c->stream), c->err);
+	HIP_TRY(hipMemsetAsync(cnt + C_ITEMS, 0, sizeof(uint32_t) * 6, c->stream), c->err);
 
 	hipEvent_t ev[4];
 	for (int i = 0; i < 4; i++) {
@@ -765,7 +783,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	s.word_size = c->opt.hash_word_size;
 	s.wlist = c->wlist.p;
 	s.wl_off = c->wl_off.p;
-	s.assays = c->assays.p;
+	s.wl_seq = c->wl_seq.p;
 	s.max_len = c->opt.max_len;
 	s.single_primer_pcr = c->opt.single_primer_pcr;
 	if (!seeds_only) {
@@ -775,40 +793,49 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 		s.groups = c->groups.p;
 		s.group_cap = uint32_t(GROUP_CAP);
 		s.group_count = cnt + C_GROUPS;
+		s.qa = c->qa.p;
+		s.qa_count = cnt + C_QA;
 	} else {
 		s.seeds_out = c->seeds_out.p;
 		s.seeds_cap = uint32_t(c->seeds_out.n);
 		s.seeds_count = cnt + C_SEEDS;
 	}
 	s.err = cnt + C_ERR;
-	const int seed_blocks = int(std::min<size_t>(t1 - t0, size_t(c->bind_blocks) * 8));
+	const int seed_blocks = int(std::min<size_t>((t1 - t0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 8));
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
 		s.assay_begin = c->chunk_begin[ch];
 		s.assay_end = c->chunk_begin[ch + 1];
 		s.wt_off = c->wt_off.p + ch * (n_words + 1);
 		s.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
-		if (c->opt.hash_word_size <= 7)
-			hipLaunchKernelGGL(seed_kernel<true>, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
-		else
-			hipLaunchKernelGGL(seed_kernel<false>, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
+		hipLaunchKernelGGL(seed_kernel, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
 	}
 	HIP_TRY(hipEventRecord(ev[1], c->stream), c->err);
 	if (seeds_only) return TNT_OK;
 
+	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
 	b.n_items = 0; // read from the device counter
-	b.n_items_dev = cnt + C_ITEMS;
+	b.n_items_dev = cnt + C_QA;
+	b.index = c->qa.p;
 	launch_bind(c, b, c->bind_blocks, false);
-	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 
 	FilterArgs f;
 	f.groups = c->groups.p;
 	f.n_groups = cnt + C_GROUPS;
+	f.items = c->items.p;
 	f.result = c->result.p;
 	f.active = c->active.p;
 	f.n_active = cnt + C_ACTIVE;
+	f.qb = c->qb.p;
+	f.qb_count = cnt + C_QB;
 	hipLaunchKernelGGL(filter_kernel, dim3(c->bind_blocks * 4), dim3(256), 0, c->stream, f);
+
+	// phase B: the other strand and the probes of the groups that are still alive
+	b.n_items_dev = cnt + C_QB;
+	b.index = c->qb.p;
+	launch_bind(c, b, c->bind_blocks, false);
+	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 
 	PairArgs p;
 	memset(&p, 0, sizeof(p));
@@ -948,7 +975,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, ctx->events.front(), ctx->events.back()) == hipSuccess) T.total_ms = ms;
 	}
-	T.n_binds = (uint64_t(cnt[C_TOT_ITEMS_HI]) << 32) | cnt[C_TOT_ITEMS_LO];
+	T.n_binds = (uint64_t(cnt[C_TOT_BINDS_HI]) << 32) | cnt[C_TOT_BINDS_LO]; // DP evaluations (phase A + phase B)
 	T.n_seeds = (uint64_t(cnt[C_TOT_GROUPS_HI]) << 32) | cnt[C_TOT_GROUPS_LO]; // (target, assay) groups that reached the bind stage
 	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n;
@@ -1004,9 +1031,7 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 	std::vector<tnt_seed> out;
 	out.reserve(raw.size());
 	for (const SeedOut &s : raw) {
-		const AssayDev &d = ctx->h_assays[s.assay_role >> 2];
-		const int role = int(s.assay_role & 3u);
-		const int slot = role == 0 ? d.slot_f : (role == 1 ? d.slot_r : d.slot_p);
+		const int slot = int(s.assay_role >> 2) * 3 + int(s.assay_role & 3u);
 		tnt_seed o;
 		o.seq_index = int(db->first_seq_index + s.target);
 		o.oligo = ctx->h_slots[slot].oligo;

@@ -207,14 +207,19 @@ __device__ Hit *alloc_hit(const PairArgs &a)
 	return a.hits + o;
 }
 
-// Groups whose seeds all failed to bind produce nothing: compact the rest so the (scratch heavy)
-// pairing kernel only runs where there is something to pair.
+// After phase A (first strand of the PCR groups, everything of the probe / padlock groups):
+//  * PCR group with no bound phase-A item: the reference's list is empty after the second cull
+//    (amplicon_search.cpp:151-179 / :238-266) -> dead, its phase-B seeds are never bound;
+//  * otherwise the group goes on the active list and its phase-B items on the phase-B queue.
 struct FilterArgs {
 	const Group *groups;
 	const uint32_t *n_groups; // device counter written by the seed kernel
+	const Item *items;
 	const int32_t *result;
 	uint32_t *active;
 	uint32_t *n_active;
+	uint32_t *qb;
+	uint32_t *qb_count;
 };
 
 __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
@@ -223,8 +228,18 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
 	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
 		const Group G = a.groups[g];
 		bool any = false;
-		for (uint32_t i = 0; i < G.count; i++) any |= a.result[G.first + i] >= 0;
-		if (any) a.active[atomicAdd(a.n_active, 1u)] = g;
+		uint32_t nb = 0;
+		for (uint32_t i = 0; i < G.count; i++) {
+			if (a.items[G.first + i].info & ITEM_PHASE_B) nb++;
+			else any |= a.result[G.first + i] >= 0;
+		}
+		if (!any) continue;
+		a.active[atomicAdd(a.n_active, 1u)] = g;
+		if (nb) {
+			uint32_t o = atomicAdd(a.qb_count, nb);
+			for (uint32_t i = 0; i < G.count; i++)
+				if (a.items[G.first + i].info & ITEM_PHASE_B) a.qb[o++] = G.first + i;
+		}
 	}
 }
 

@@ -1,6 +1,6 @@
 // tnt_seed.hip.h -- gfx950 seed-scan kernel: streams 2-bit packed targets, looks every k-mer up in
-// the inverted query-word table, keeps the first seed of every (oligo, strand, diagonal), sorts the
-// seeds of one target in LDS, runs the first cull per assay and emits bind work items.
+// the inverted query-word table, keeps the first seed of every (oligo, strand, diagonal), groups the
+// seeds of one target per assay in LDS, runs the first cull and emits bind work items.
 //
 // Replaces DNAHash::hash + DNAHash::find/find_complement + iterator (seq_hash.h:524-779),
 // match_oligo_to_{minus,plus}_strand (bind_oligo.cpp:84-122), the early exits of amplicon()
@@ -16,9 +16,9 @@
 //    i.e. the one with the smallest word index (stable sort + unique, bind_oligo.cpp:98-99): a seed
 //    (w, p) is dropped iff some k in 1..min(w,p) has word_list[w-k] == target_word(p-k).
 //
-// One 256-thread workgroup per target: the four wavefronts scan the target's positions, kept seeds
-// go to an LDS array as 64-bit sort keys, a bitonic sort groups them by assay in the order the
-// reference's lists have, and one lane per non-empty assay segment runs the cull and emits items.
+// ONE WAVEFRONT PER TARGET, wave-synchronous (no workgroup barrier): the stage is a chain of short
+// dependent steps per target, so throughput comes from the number of targets in flight (up to 18
+// wavefronts per CU with 8.5 KB of LDS each), not from the width of one target's scan.
 #ifndef TNT_SEED_HIP_H
 #define TNT_SEED_HIP_H
 
@@ -27,11 +27,11 @@
 
 namespace tnt {
 
-constexpr int SEED_THREADS = 256;
-constexpr int SEED_CAP = 2048;        // seeds of one target x one assay chunk held in LDS (power of two)
-constexpr int SEED_MAX_ASSAYS = 1024; // assays per chunk (10-bit local index in the sort key)
+constexpr int SEED_WAVES = 4;         // wavefronts (= targets in flight) per workgroup
+constexpr int SEED_THREADS = 64 * SEED_WAVES;
+constexpr int SEED_CAP = 512;         // seeds of one target x one assay chunk held in LDS
+constexpr int SEED_MAX_ASSAYS = 256;  // assays per chunk (8-bit local index in the key)
 constexpr int LIST_MAX = 64;          // seeds of one (target, assay)
-constexpr int WT_LDS_WORDS = (1 << 14) + 1; // bucket offsets staged in LDS for k <= 7
 
 struct SeedOut { // debug / unit-level output: every kept seed before the cull
 	uint32_t target, assay_role, strand_minus, query_loc, target_loc;
@@ -44,7 +44,7 @@ struct SeedArgs {
 	const uint32_t *wt_ent;    // this chunk's entries (see tnt_dev.h)
 	const uint16_t *wlist;     // concatenated word lists (little-endian 2-bit words)
 	const uint32_t *wl_off;    // [((assay * 3 + role) * 2 + minus)] -> first word
-	const AssayDev *assays;
+	const unsigned long long *wl_seq; // [list][2]: the strand-specific oligo, 2 bits per base, base 0 in the low bits
 	uint32_t assay_begin, assay_end; // chunk of expanded assays handled by this launch
 	int max_len;               // -l
 	int single_primer_pcr;
@@ -54,6 +54,8 @@ struct SeedArgs {
 	Group *groups;
 	uint32_t group_cap;
 	uint32_t *group_count;
+	uint32_t *qa;              // indices of the items bound in phase A
+	uint32_t *qa_count;
 	SeedOut *seeds_out;        // optional
 	uint32_t seeds_cap;
 	uint32_t *seeds_count;
@@ -75,220 +77,312 @@ __device__ __forceinline__ uint32_t group_rank(uint32_t role, bool minus)
 	return (minus ? 0u : 2u) + role;
 }
 
-// 64-bit sort key of one seed.  bits 63-54 local assay; low three bits role (2) | minus (1).
-//  kind 0 (PCR):   bits 53-22 target_loc, 21-19 assembly group, 18-12 word index
+// 64-bit key of one seed.  bits 63-56 local assay; low five bits: has_probe (16) | non-PCR (8) | role (6) | minus (1).
+//  PCR:      bits 55-24 target_loc, 23-21 assembly group, 20-14 word index
 //     = order of the list after the first cull's stable sort by target_loc (amplicon_search.cpp:688)
-//  kind 1/2:       bits 53-52 list id (minus: up, down; plus: up, down), 51-18 query_loc - target_loc + 2^33,
-//                  17-11 word index = per (strand, oligo) list in diagonal order (sort_by_delta, bind_oligo.cpp:157)
-__device__ __forceinline__ unsigned long long seed_key(uint32_t local_assay, bool pcr, uint32_t role, bool minus, uint32_t wi,
-                                                       uint32_t p)
+//  non-PCR:  bits 55-54 list id (minus: up, down; plus: up, down), 53-20 query_loc - target_loc + 2^33,
+//            19-13 word index = per (strand, oligo) list in diagonal order (sort_by_delta, bind_oligo.cpp:157)
+__device__ __forceinline__ unsigned long long seed_key(uint32_t local_assay, uint32_t ent, uint32_t p)
 {
-	unsigned long long k = (unsigned long long)local_assay << 54;
-	if (pcr) {
-		k |= ((unsigned long long)p << 22) | ((unsigned long long)group_rank(role, minus) << 19) | ((unsigned long long)wi << 12);
+	const uint32_t wi = ent & 127u, role = (ent >> 8) & 3u;
+	const bool minus = (ent & WT_MINUS) != 0, nonpcr = (ent & WT_NONPCR) != 0;
+	unsigned long long k = (unsigned long long)local_assay << 56;
+	if (!nonpcr) {
+		k |= ((unsigned long long)p << 24) | ((unsigned long long)group_rank(role, minus) << 21) | ((unsigned long long)wi << 14);
 	} else {
 		const unsigned long long listid = (minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
 		const unsigned long long diag = (unsigned long long)(long(wi) - long(p) + (1l << 33));
-		k |= (listid << 52) | (diag << 18) | ((unsigned long long)wi << 11);
+		k |= (listid << 54) | (diag << 20) | ((unsigned long long)wi << 13);
 	}
-	return k | (role << 1) | (minus ? 1u : 0u);
+	return k | ((ent & WT_HASPROBE) ? 16u : 0u) | (nonpcr ? 8u : 0u) | (role << 1) | (minus ? 1u : 0u);
 }
 
-__device__ __forceinline__ void key_decode(unsigned long long k, bool pcr, uint32_t &wi, uint32_t &p)
+__device__ __forceinline__ void key_decode(unsigned long long k, uint32_t &wi, uint32_t &p)
 {
-	if (pcr) {
-		wi = uint32_t(k >> 12) & 127u;
-		p = uint32_t(k >> 22);
+	if (!(k & 8u)) {
+		wi = uint32_t(k >> 14) & 127u;
+		p = uint32_t(k >> 24);
 	} else {
-		wi = uint32_t(k >> 11) & 127u;
-		const long diag = long((k >> 18) & ((1ull << 34) - 1ull)) - (1l << 33);
+		wi = uint32_t(k >> 13) & 127u;
+		const long diag = long((k >> 20) & ((1ull << 34) - 1ull)) - (1l << 33);
 		p = uint32_t(long(wi) - diag);
 	}
 }
 
-template <bool LDS_TABLE> __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
+__device__ __forceinline__ uint32_t key_role(unsigned long long k) { return uint32_t(k >> 1) & 3u; }
+
+// wave-synchronous LDS hand-off between phases of the same wavefront
+__device__ __forceinline__ void wave_sync()
 {
-	__shared__ unsigned long long s_key[SEED_CAP];
-	__shared__ uint16_t s_wt[LDS_TABLE ? WT_LDS_WORDS + 1 : 2];
-	__shared__ uint32_t s_n;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-	const int tid = threadIdx.x;
+// Is (wi, p) the first seed of its diagonal?  Word-list form (any oligo).
+__device__ __forceinline__ bool first_on_diagonal_words(const uint32_t *pk, const uint16_t *wl, uint32_t wi, uint32_t p, uint32_t wmask)
+{
+	const uint32_t kmax = wi < p ? wi : p;
+	for (uint32_t k = 1; k <= kmax; k++)
+		if (uint32_t(wl[wi - k]) == target_word(pk, p - k, wmask)) return false;
+	return true;
+}
+
+// Same test on packed bases for plain A/C/G/T oligos (word index == base offset) when the compared
+// stretch fits 32 bases: XOR the two 64-bit windows and look for a run of `ws` matching bases that
+// starts before the seed.
+__device__ __forceinline__ bool first_on_diagonal_packed(const uint32_t *pk, const unsigned long long *seq, uint32_t wi, uint32_t p,
+                                                         int ws)
+{
+	const uint32_t kmax = wi < p ? wi : p;
+	if (kmax == 0) return true;
+	const uint32_t t0 = p - kmax, w0 = t0 >> 4, sh = (t0 & 15u) * 2u;
+	const unsigned long long lo = (unsigned long long)pk[w0] | ((unsigned long long)pk[w0 + 1] << 32);
+	const unsigned long long T = sh ? ((lo >> sh) | ((unsigned long long)pk[w0 + 2] << (64u - sh))) : lo;
+	const uint32_t s2 = (wi - kmax) * 2u;
+	const unsigned long long olo = seq[0], ohi = seq[1];
+	const unsigned long long O = s2 == 0 ? olo : (s2 < 64u ? ((olo >> s2) | (ohi << (64u - s2))) : (ohi >> (s2 - 64u)));
+	const unsigned long long X = T ^ O;
+	const unsigned long long Z = ~(X | (X >> 1)) & 0x5555555555555555ull; // one bit per matching base
+	unsigned long long R = Z;
+	for (int i = 1; i < ws; i++) R &= Z >> (2 * i);
+	const unsigned long long before = (kmax >= 32u) ? ~0ull : ((1ull << (2u * kmax)) - 1ull);
+	return (R & before) == 0;
+}
+
+__global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
+{
+	__shared__ unsigned long long s_raw[SEED_WAVES][SEED_CAP];
+	__shared__ unsigned long long s_srt[SEED_WAVES][SEED_CAP];
+	__shared__ uint16_t s_hist[SEED_WAVES][SEED_MAX_ASSAYS];
+	__shared__ uint16_t s_off[SEED_WAVES][SEED_MAX_ASSAYS];
+	__shared__ uint32_t s_cnt[SEED_WAVES];
+
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned long long *raw = s_raw[wv], *srt = s_srt[wv];
+	uint16_t *hist = s_hist[wv], *off = s_off[wv];
 	const uint32_t wmask = (1u << (2 * a.word_size)) - 1u;
-	if (LDS_TABLE) {
-		for (uint32_t i = tid; i <= wmask + 1u; i += SEED_THREADS) s_wt[i] = a.wt_off[i];
-	}
-	const uint16_t *wt = LDS_TABLE ? s_wt : a.wt_off;
-	__syncthreads();
+	const uint32_t n_chunk = a.assay_end - a.assay_begin;
 
-	for (uint32_t t = blockIdx.x; t < a.db.n_targets; t += gridDim.x) {
+	for (uint32_t t = blockIdx.x * SEED_WAVES + wv; t < a.db.n_targets; t += gridDim.x * SEED_WAVES) {
 		const uint32_t len = a.db.len[t];
-		if (tid == 0) s_n = 0;
-		__syncthreads();
+		for (uint32_t i = lane; i < n_chunk; i += 64) hist[i] = 0;
+		if (lane == 0) s_cnt[wv] = 0;
+		wave_sync();
 
+		// ---------------------------------------------------------------- scan + diagonal de-duplication
 		if (len >= uint32_t(a.word_size)) { // tntblast_local.cpp:513
 			const uint32_t *pk = a.db.packed + a.db.word_off[t];
 			const uint32_t npos = len - a.word_size + 1;
-			for (uint32_t p = tid; p < npos; p += SEED_THREADS) {
+			for (uint32_t p = lane; p < npos; p += 64) {
 				const uint32_t w = target_word(pk, p, wmask);
-				const uint32_t e0 = wt[w], e1 = wt[w + 1];
+				const uint32_t e0 = a.wt_off[w], e1 = a.wt_off[w + 1];
 				for (uint32_t e = e0; e < e1; e++) {
 					const uint32_t ent = a.wt_ent[e];
 					const uint32_t wi = ent & 127u;
-					const uint32_t role = (ent >> 8) & 3u;
-					const bool minus = (ent & WT_MINUS) != 0;
-					const uint32_t assay = ent >> 11;
-					// first seed of its diagonal?
-					const uint16_t *wl = a.wlist + a.wl_off[(assay * 3u + role) * 2u + (minus ? 1u : 0u)];
+					const uint32_t assay = ent >> WT_ASSAY_SHIFT;
+					const uint32_t li = (assay * 3u + ((ent >> 8) & 3u)) * 2u + ((ent & WT_MINUS) ? 1u : 0u);
 					const uint32_t kmax = wi < p ? wi : p;
-					bool first = true;
-					for (uint32_t k = 1; k <= kmax; k++)
-						if (uint32_t(wl[wi - k]) == target_word(pk, p - k, wmask)) {
-							first = false;
-							break;
-						}
+#ifndef TNT_EXP_NODEDUPE
+					bool first;
+					if ((ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) first = first_on_diagonal_packed(pk, a.wl_seq + 2 * li, wi, p, a.word_size);
+					else first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, p, wmask);
 					if (!first) continue;
-					const uint32_t slot = atomicAdd(&s_n, 1u);
-					if (slot < SEED_CAP) s_key[slot] = seed_key(assay - a.assay_begin, ((ent >> 10) & 1u) == 0, role, minus, wi, p);
+#endif
+					const uint32_t la = assay - a.assay_begin;
+					const uint32_t slot = atomicAdd(&s_cnt[wv], 1u);
+					if (slot < uint32_t(SEED_CAP)) {
+						raw[slot] = seed_key(la, ent, p);
+						atomicAdd(reinterpret_cast<unsigned int *>(hist) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
+					}
 				}
 			}
 		}
-		__syncthreads();
-		uint32_t n = s_n;
-		if (n > SEED_CAP) {
-			if (tid == 0) atomicOr(a.err, ERR_SEED_OVERFLOW);
+		wave_sync();
+		uint32_t n = s_cnt[wv];
+		if (n > uint32_t(SEED_CAP)) {
+			if (lane == 0) atomicOr(a.err, ERR_SEED_OVERFLOW);
 			n = SEED_CAP;
 		}
 
 		if (a.seeds_out) {
-			for (uint32_t i = tid; i < n; i += SEED_THREADS) {
+			for (uint32_t i = lane; i < n; i += 64) {
 				const uint32_t o = atomicAdd(a.seeds_count, 1u);
 				if (o < a.seeds_cap) {
-					const unsigned long long k = s_key[i];
-					const uint32_t assay = a.assay_begin + uint32_t(k >> 54);
+					const unsigned long long k = raw[i];
 					uint32_t wi, p;
-					key_decode(k, a.assays[assay].kind == 0, wi, p);
-					a.seeds_out[o] = SeedOut{t, assay * 4u + (uint32_t(k >> 1) & 3u), uint32_t(k & 1u), wi, p};
+					key_decode(k, wi, p);
+					a.seeds_out[o] = SeedOut{t, (a.assay_begin + uint32_t(k >> 56)) * 4u + key_role(k), uint32_t(k & 1u), wi, p};
 				}
 			}
 		}
-
+#ifdef TNT_EXP_SCANONLY
+		if (false) {
+#else
 		if (a.items && n > 0) {
-			// ------------------------------------------------------------ bitonic sort of the keys in LDS
-			uint32_t np2 = 1;
-			while (np2 < n) np2 <<= 1;
-			for (uint32_t i = n + tid; i < np2; i += SEED_THREADS) s_key[i] = ~0ull;
-			__syncthreads();
-			for (uint32_t k = 2; k <= np2; k <<= 1) {
-				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					for (uint32_t i = tid; i < np2; i += SEED_THREADS) {
-						const uint32_t l = i ^ j;
-						if (l > i) {
-							const unsigned long long x = s_key[i], y = s_key[l];
-							const bool up = (i & k) == 0;
-							if ((x > y) == up) {
-								s_key[i] = y;
-								s_key[l] = x;
-							}
-						}
-					}
-					__syncthreads();
+#endif
+			// ------------------------------------------------------------ counting sort by assay (wave-wide)
+			// exclusive prefix of hist -> off (4 assays per lane)
+			{
+				uint32_t c[SEED_MAX_ASSAYS / 64], sum = 0;
+#pragma unroll
+				for (int m = 0; m < SEED_MAX_ASSAYS / 64; m++) {
+					const uint32_t la = uint32_t(lane) * (SEED_MAX_ASSAYS / 64) + m;
+					c[m] = la < n_chunk ? hist[la] : 0u;
+					sum += c[m];
+				}
+				uint32_t incl = sum;
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t y = __shfl_up(incl, d);
+					if (lane >= d) incl += y;
+				}
+				uint32_t run = incl - sum;
+#pragma unroll
+				for (int m = 0; m < SEED_MAX_ASSAYS / 64; m++) {
+					const uint32_t la = uint32_t(lane) * (SEED_MAX_ASSAYS / 64) + m;
+					if (la < n_chunk) off[la] = uint16_t(run);
+					run += c[m];
 				}
 			}
+			wave_sync();
+			for (uint32_t i = lane; i < n; i += 64) {
+				const unsigned long long k = raw[i];
+				const uint32_t la = uint32_t(k >> 56);
+				const uint32_t old = atomicAdd(reinterpret_cast<unsigned int *>(off) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
+				srt[(la & 1u) ? (old >> 16) : (old & 0xFFFFu)] = k;
+			}
+			wave_sync();
 
-			// ------------------------------------------------------------ one lane per assay segment
-			for (uint32_t i0 = tid; i0 < n; i0 += SEED_THREADS) {
-				const uint32_t la = uint32_t(s_key[i0] >> 54);
-				if (i0 > 0 && uint32_t(s_key[i0 - 1] >> 54) == la) continue; // not the head of a segment
-				const uint32_t assay = a.assay_begin + la;
-				const AssayDev A = a.assays[assay];
-
-				uint32_t cnt = 0;
-				int n_minus = 0, n_plus = 0, n_probe = 0;
-				while (i0 + cnt < n && uint32_t(s_key[i0 + cnt] >> 54) == la) {
-					const unsigned long long k = s_key[i0 + cnt];
-					if ((uint32_t(k >> 1) & 3u) == 2) n_probe++;
-					else if (k & 1u) n_minus++;
-					else n_plus++;
-					cnt++;
-				}
+			// ------------------------------------------------------------ one lane per assay of the chunk
+			for (uint32_t la0 = 0; la0 < n_chunk; la0 += 64) {
+				const uint32_t la = la0 + lane;
+				uint32_t cnt = la < n_chunk ? hist[la] : 0u;
+				unsigned long long *key = srt + (la < n_chunk ? uint32_t(off[la]) - cnt : 0u); // off now points past the segment
+				unsigned long long valid = 0, phase_b = 0;
+				uint32_t gflags = 0;
+				bool pcr = false;
+#ifdef TNT_EXP_NOSEG
+				cnt = 0;
+#endif
 				if (cnt > uint32_t(LIST_MAX)) {
 					atomicOr(a.err, ERR_LIST_OVERFLOW);
-					continue;
+					cnt = 0;
 				}
-				const unsigned long long *key = s_key + i0;
-
-				unsigned long long valid = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
-				uint32_t gflags = 0;
-				if (A.kind == 0) {
-					// early exits of amplicon(), amplicon_search.cpp:101-126
-					if (n_minus == 0 || n_plus == 0) continue;
-					if (A.has_probe && n_probe == 0) continue;
-					// cull_oligo_match, amplicon_search.cpp:679-765 (every entry is still unbound here)
-					valid = 0;
-					const uint32_t threshold = uint32_t(a.max_len) + 50u;
-					for (uint32_t f = 0; f < cnt; f++) {
-						const uint32_t fr = uint32_t(key[f] >> 1) & 3u;
-						const bool fminus = key[f] & 1u;
-						if (!fminus || fr == 2) continue;
-						const uint32_t floc = uint32_t(key[f] >> 22);
-						for (uint32_t r = f + 1; r < cnt; r++) {
-							const uint32_t rloc = uint32_t(key[r] >> 22);
-							if (rloc - floc > threshold) break;
-							const uint32_t rr = uint32_t(key[r] >> 1) & 3u;
-							const bool rminus = key[r] & 1u;
-							if (rminus || rr == 2) continue;
-							if (!a.single_primer_pcr && fr == rr) continue;
-							if (A.has_probe) {
-								for (uint32_t p = f + 1; p < r; p++)
-									if ((uint32_t(key[p] >> 1) & 3u) == 2) valid |= (1ull << p) | (1ull << f) | (1ull << r);
-							} else {
-								valid |= (1ull << f) | (1ull << r);
+				if (cnt > 0) {
+					// order of the reference's list: insertion sort of the (unique) keys of this assay
+					for (uint32_t i = 1; i < cnt; i++) {
+						const unsigned long long x = key[i];
+						int j = int(i) - 1;
+						while (j >= 0 && key[j] > x) {
+							key[j + 1] = key[j];
+							j--;
+						}
+						key[j + 1] = x;
+					}
+					const unsigned long long k0 = key[0];
+					pcr = !(k0 & 8u);
+					const bool has_probe = (k0 & 16u) != 0;
+					if (!pcr) {
+						valid = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
+					} else {
+						int n_minus = 0, n_plus = 0, n_probe = 0;
+						for (uint32_t i = 0; i < cnt; i++) {
+							const unsigned long long k = key[i];
+							if (key_role(k) == 2) n_probe++;
+							else if (k & 1u) n_minus++;
+							else n_plus++;
+						}
+						if (n_minus != 0 && n_plus != 0 && !(has_probe && n_probe == 0)) { // early exits, amplicon_search.cpp:101-126
+							// cull_oligo_match, amplicon_search.cpp:679-765 (every entry is still unbound here)
+							const uint32_t threshold = uint32_t(a.max_len) + 50u;
+							for (uint32_t f = 0; f < cnt; f++) {
+								const uint32_t fr = key_role(key[f]);
+								const bool fminus = key[f] & 1u;
+								if (!fminus || fr == 2) continue;
+								const uint32_t floc = uint32_t(key[f] >> 24);
+								for (uint32_t r = f + 1; r < cnt; r++) {
+									const uint32_t rloc = uint32_t(key[r] >> 24);
+									if (rloc - floc > threshold) break;
+									const uint32_t rr = key_role(key[r]);
+									const bool rminus = key[r] & 1u;
+									if (rminus || rr == 2) continue;
+									if (!a.single_primer_pcr && fr == rr) continue;
+									if (has_probe) {
+										for (uint32_t p = f + 1; p < r; p++)
+											if (key_role(key[p]) == 2) valid |= (1ull << p) | (1ull << f) | (1ull << r);
+									} else {
+										valid |= (1ull << f) | (1ull << r);
+									}
+								}
 							}
+							// strand counts of the first cull (amplicon_search.cpp:748-755): the reference looks at the
+							// element FOLLOWING each valid one (past-the-end counts nothing here)
+							int cm = 0, cp = 0;
+							for (uint32_t i = 0; i + 1 < cnt; i++)
+								if ((valid >> i) & 1ull) {
+									const bool nminus = key[i + 1] & 1u;
+									cm += nminus ? 1 : 0;
+									cp += nminus ? 0 : 1;
+								}
+							if (cm < cp) gflags |= GROUP_MINUS_FIRST; // amplicon_search.cpp:131
+							// Phase B = what the reference binds only after both primers were tried on the first
+							// strand (amplicon_search.cpp:131-353): the other strand's primers and the probe.
+							for (uint32_t i = 0; i < cnt; i++)
+								if ((valid >> i) & 1ull) {
+									const bool iminus = key[i] & 1u;
+									if (key_role(key[i]) == 2 || iminus != ((gflags & GROUP_MINUS_FIRST) != 0)) phase_b |= 1ull << i;
+								}
 						}
 					}
-					// strand counts of the first cull (amplicon_search.cpp:748-755): the reference looks at the element
-					// FOLLOWING each valid one (past-the-end counts nothing here)
-					int cm = 0, cp = 0;
-					for (uint32_t i = 0; i + 1 < cnt; i++)
-						if ((valid >> i) & 1ull) {
-							const bool nminus = key[i + 1] & 1u;
-							cm += nminus ? 1 : 0;
-							cp += nminus ? 0 : 1;
-						}
-					if (cm < cp) gflags |= GROUP_MINUS_FIRST; // amplicon_search.cpp:131
 				}
-				const int n_valid = __popcll(valid);
-				if (n_valid == 0) continue;
+				const uint32_t n_valid = uint32_t(__popcll(valid));
+				const uint32_t n_a = uint32_t(__popcll(valid & ~phase_b));
 
-				const uint32_t first = atomicAdd(a.item_count, uint32_t(n_valid));
-				const uint32_t g = atomicAdd(a.group_count, 1u);
-				if (first + n_valid > a.item_cap) {
+				// wave-wide exclusive prefix sums of (items, phase-A items, groups): one atomic per counter and wave
+				uint32_t ii = n_valid, ia = n_a, ig = n_valid ? 1u : 0u;
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t yi = __shfl_up(ii, d), ya = __shfl_up(ia, d), yg = __shfl_up(ig, d);
+					if (lane >= d) ii += yi, ia += ya, ig += yg;
+				}
+				uint32_t bi = 0, ba = 0, bg = 0;
+				if (lane == 63) {
+					if (ii) bi = atomicAdd(a.item_count, ii);
+					if (ia) ba = atomicAdd(a.qa_count, ia);
+					if (ig) bg = atomicAdd(a.group_count, ig);
+				}
+				bi = __shfl(bi, 63) + ii - n_valid;
+				ba = __shfl(ba, 63) + ia - n_a;
+				bg = __shfl(bg, 63) + ig - (n_valid ? 1u : 0u);
+				if (n_valid == 0) continue;
+				if (bi + n_valid > a.item_cap) {
 					atomicOr(a.err, ERR_ITEM_OVERFLOW);
 					continue;
 				}
-				if (g >= a.group_cap) {
+				if (bg >= a.group_cap) {
 					atomicOr(a.err, ERR_GROUP_OVERFLOW);
 					continue;
 				}
-				a.groups[g] = Group{t, assay | gflags, first, uint32_t(n_valid)};
-				uint32_t o = first;
+				const uint32_t assay = a.assay_begin + la;
+				a.groups[bg] = Group{t, assay | gflags, bi, n_valid};
+				uint32_t o = bi;
 				for (uint32_t i = 0; i < cnt; i++) {
 					if (!((valid >> i) & 1ull)) continue;
 					const unsigned long long k = key[i];
-					const uint32_t role = uint32_t(k >> 1) & 3u;
-					const bool minus = k & 1u;
 					uint32_t wi, p;
-					key_decode(k, A.kind == 0, wi, p);
+					key_decode(k, wi, p);
+					const bool pb = (phase_b >> i) & 1ull;
 					Item it;
 					it.target = t;
 					it.tloc = p;
-					it.slot = uint32_t(role == 0 ? A.slot_f : (role == 1 ? A.slot_r : A.slot_p));
-					it.info = wi | (minus ? ITEM_MINUS : 0u) | (role << 9);
-					a.items[o++] = it;
+					it.slot = assay * 3u + key_role(k); // Slot table is laid out [assay][role]
+					it.info = wi | ((k & 1u) ? ITEM_MINUS : 0u) | (key_role(k) << 9) | (pb ? ITEM_PHASE_B : 0u);
+					a.items[o] = it;
+					if (!pb) a.qa[ba++] = o;
+					o++;
 				}
 			}
 		}
-		__syncthreads();
+		wave_sync();
 	}
 }
 
