@@ -37,6 +37,8 @@ struct BindArgs {
 	uint32_t n_items;
 	const uint32_t *n_items_dev; // when set, the item count is read from the device counter
 	const uint32_t *index;       // optional work list: item indices to bind (phase A / phase B queues)
+	const uint32_t *shard_counts; // when set, `index` is a sharded array (seed kernel output) of this region size
+	uint32_t shard_region;
 	int32_t *result;           // per item: pool index (>= 0) or -status
 	BoundRec *pool;
 	uint32_t pool_cap;
@@ -313,10 +315,19 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	uint16_t *ties = a.ties + size_t(blockIdx.x) * (size_t(TIE_CAP) * BIND_THREADS) + tid;
 	uint8_t *win = s_win + tid;
 
-	const uint32_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_items;
+	__shared__ uint32_t s_pre[N_SHARD + 1];
+	if (a.shard_counts) {
+		shard_prefix(a.shard_counts, s_pre, tid);
+		__syncthreads();
+	}
+	const uint32_t n_items = a.shard_counts ? s_pre[N_SHARD] : (a.n_items_dev ? *a.n_items_dev : a.n_items);
 	for (uint32_t base = blockIdx.x * BIND_THREADS; base < n_items; base += gridDim.x * BIND_THREADS) {
 		const bool active = base + tid < n_items;
-		const uint32_t idx = active ? (a.index ? a.index[base + tid] : base + tid) : 0u;
+		uint32_t idx = 0;
+		if (active) {
+			if (a.shard_counts) idx = a.index[shard_locate(s_pre, base + tid, a.shard_region)];
+			else idx = a.index ? a.index[base + tid] : base + tid;
+		}
 
 		// ------------------------------------------------------------------ item decode
 		Item it = active ? a.items[idx] : Item{0, 0, 0, 0};

@@ -148,6 +148,35 @@ struct AssayDev {
 constexpr uint32_t WT_MINUS = 1u << 7, WT_NONPCR = 1u << 10, WT_HASPROBE = 1u << 11, WT_PLAIN = 1u << 12;
 constexpr int WT_ASSAY_SHIFT = 13;
 
+// Sharded append-only outputs of the seed kernel: N_SHARD regions per array, one counter per region
+// (SHARD_STRIDE words apart so the counters sit on different cache lines).
+constexpr uint32_t N_SHARD = 32, SHARD_STRIDE = 32;
+
+// linear index -> physical index of a sharded array: `pre` = exclusive prefix sums of the shard counts
+// (N_SHARD + 1 entries), `region` = capacity of one shard
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t shard_locate(const uint32_t *pre, uint32_t lin, uint32_t region)
+{
+	uint32_t r = 0;
+#pragma unroll
+	for (uint32_t step = N_SHARD / 2; step > 0; step >>= 1)
+		if (pre[r + step] <= lin) r += step;
+	return r * region + (lin - pre[r]);
+}
+__device__ __forceinline__ void shard_prefix(const uint32_t *counts, uint32_t *pre, int tid)
+{
+	// called by the first wavefront of a workgroup; pre[N_SHARD] = total
+	if (tid == 0) {
+		uint32_t run = 0;
+		for (uint32_t r = 0; r < N_SHARD; r++) {
+			pre[r] = run;
+			run += counts[r * SHARD_STRIDE];
+		}
+		pre[N_SHARD] = run;
+	}
+}
+#endif
+
 // status word set by kernels
 constexpr uint32_t ERR_SEED_OVERFLOW = 1, ERR_ITEM_OVERFLOW = 2, ERR_POOL_OVERFLOW = 4, ERR_HIT_OVERFLOW = 8,
                    ERR_GROUP_OVERFLOW = 16, ERR_LIST_OVERFLOW = 32, ERR_STACK_OVERFLOW = 64, ERR_TIE_OVERFLOW = 128;

@@ -300,7 +300,10 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_ITEMS = 0, C_GROUPS, C_POOL, C_ACTIVE, C_QA, C_QB, C_HITS, C_ERR, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS, C_COUNT = 16 };
+enum { C_POOL = 0, C_ACTIVE, C_QB, C_PAD3, C_HITS, C_ERR, C_PAD6, C_PAD7, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
+       // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
+       C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
+       C_COUNT = C_GROUPS + N_SHARD * SHARD_STRIDE };
 static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
@@ -309,9 +312,12 @@ __global__ void accumulate_kernel(uint32_t *cnt)
 	unsigned long long *ti = reinterpret_cast<unsigned long long *>(cnt + C_TOT_ITEMS_LO);
 	unsigned long long *tg = reinterpret_cast<unsigned long long *>(cnt + C_TOT_GROUPS_LO);
 	unsigned long long *tb = reinterpret_cast<unsigned long long *>(cnt + C_TOT_BINDS_LO);
-	*ti += cnt[C_ITEMS];
-	*tg += cnt[C_GROUPS];
-	*tb += cnt[C_QA] + cnt[C_QB];
+	for (uint32_t r = 0; r < N_SHARD; r++) {
+		*ti += cnt[C_ITEMS + r * SHARD_STRIDE];
+		*tg += cnt[C_GROUPS + r * SHARD_STRIDE];
+		*tb += cnt[C_QA + r * SHARD_STRIDE];
+	}
+	*tb += cnt[C_QB];
 	cnt[C_TOT_BOUND] += cnt[C_POOL];
 }
 
@@ -768,7 +774,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	const DbView v = make_view(db, t0, t1);
 	uint32_t *cnt = c->counters.p;
 	// hits and the error word accumulate over batches; the rest restarts
-	HIP_TRY(hipMemsetAsync(cnt + C_ITEMS, 0, sizeof(uint32_t) * 6, c->stream), c->err);
+	HIP_TRY(hipMemsetAsync(cnt + C_POOL, 0, sizeof(uint32_t) * 3, c->stream), c->err);
+	HIP_TRY(hipMemsetAsync(cnt + C_ITEMS, 0, sizeof(uint32_t) * 3 * N_SHARD * SHARD_STRIDE, c->stream), c->err);
 
 	hipEvent_t ev[4];
 	for (int i = 0; i < 4; i++) {
@@ -801,7 +808,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 		s.seeds_count = cnt + C_SEEDS;
 	}
 	s.err = cnt + C_ERR;
-	const int seed_blocks = int(std::min<size_t>((t1 - t0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 8));
+	const int seed_blocks = int(std::min<size_t>((t1 - t0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
 		s.assay_begin = c->chunk_begin[ch];
@@ -816,13 +823,15 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
 	b.n_items = 0; // read from the device counter
-	b.n_items_dev = cnt + C_QA;
 	b.index = c->qa.p;
+	b.shard_counts = cnt + C_QA;
+	b.shard_region = uint32_t(ITEM_CAP / N_SHARD);
 	launch_bind(c, b, c->bind_blocks, false);
 
 	FilterArgs f;
 	f.groups = c->groups.p;
-	f.n_groups = cnt + C_GROUPS;
+	f.group_counts = cnt + C_GROUPS;
+	f.group_region = uint32_t(GROUP_CAP / N_SHARD);
 	f.items = c->items.p;
 	f.result = c->result.p;
 	f.active = c->active.p;
@@ -834,6 +843,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	// phase B: the other strand and the probes of the groups that are still alive
 	b.n_items_dev = cnt + C_QB;
 	b.index = c->qb.p;
+	b.shard_counts = nullptr;
 	launch_bind(c, b, c->bind_blocks, false);
 	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 

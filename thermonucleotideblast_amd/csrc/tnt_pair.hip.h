@@ -212,8 +212,9 @@ __device__ Hit *alloc_hit(const PairArgs &a)
 //    (amplicon_search.cpp:151-179 / :238-266) -> dead, its phase-B seeds are never bound;
 //  * otherwise the group goes on the active list and its phase-B items on the phase-B queue.
 struct FilterArgs {
-	const Group *groups;
-	const uint32_t *n_groups; // device counter written by the seed kernel
+	const Group *groups;      // sharded array (seed kernel output)
+	const uint32_t *group_counts; // [N_SHARD * SHARD_STRIDE]
+	uint32_t group_region;
 	const Item *items;
 	const int32_t *result;
 	uint32_t *active;
@@ -224,8 +225,12 @@ struct FilterArgs {
 
 __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
 {
-	const uint32_t n = *a.n_groups;
-	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+	__shared__ uint32_t s_pre[N_SHARD + 1];
+	shard_prefix(a.group_counts, s_pre, threadIdx.x);
+	__syncthreads();
+	const uint32_t n = s_pre[N_SHARD];
+	for (uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x; lin < n; lin += gridDim.x * blockDim.x) {
+		const uint32_t g = shard_locate(s_pre, lin, a.group_region);
 		const Group G = a.groups[g];
 		bool any = false;
 		uint32_t nb = 0;

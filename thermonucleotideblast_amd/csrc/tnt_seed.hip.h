@@ -50,7 +50,7 @@ struct SeedArgs {
 	int single_primer_pcr;
 	Item *items;
 	uint32_t item_cap;
-	uint32_t *item_count;
+	uint32_t *item_count;      // [N_SHARD * SHARD_STRIDE] sharded counters, region r = [r * cap / N_SHARD, ...)
 	Group *groups;
 	uint32_t group_cap;
 	uint32_t *group_count;
@@ -163,6 +163,8 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 	uint16_t *hist = s_hist[wv], *off = s_off[wv];
 	const uint32_t wmask = (1u << (2 * a.word_size)) - 1u;
 	const uint32_t n_chunk = a.assay_end - a.assay_begin;
+
+	const uint32_t shard = (blockIdx.x * SEED_WAVES + wv) & (N_SHARD - 1);
 
 	for (uint32_t t = blockIdx.x * SEED_WAVES + wv; t < a.db.n_targets; t += gridDim.x * SEED_WAVES) {
 		const uint32_t len = a.db.len[t];
@@ -338,7 +340,10 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 				const uint32_t n_valid = uint32_t(__popcll(valid));
 				const uint32_t n_a = uint32_t(__popcll(valid & ~phase_b));
 
-				// wave-wide exclusive prefix sums of (items, phase-A items, groups): one atomic per counter and wave
+				// wave-wide exclusive prefix sums of (items, phase-A items, groups): one atomic per counter and
+				// wavefront.  The counters are sharded (a single hot word sustains only ~88 atomics/us): every
+				// wavefront appends to the output region of its shard; consumers map a linear index back to
+				// (shard, offset) with the shard prefix sums (shard_locate).
 				uint32_t ii = n_valid, ia = n_a, ig = n_valid ? 1u : 0u;
 				for (int d = 1; d < 64; d <<= 1) {
 					const uint32_t yi = __shfl_up(ii, d), ya = __shfl_up(ia, d), yg = __shfl_up(ig, d);
@@ -346,22 +351,27 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 				}
 				uint32_t bi = 0, ba = 0, bg = 0;
 				if (lane == 63) {
-					if (ii) bi = atomicAdd(a.item_count, ii);
-					if (ia) ba = atomicAdd(a.qa_count, ia);
-					if (ig) bg = atomicAdd(a.group_count, ig);
+					if (ii) bi = atomicAdd(a.item_count + shard * SHARD_STRIDE, ii);
+					if (ia) ba = atomicAdd(a.qa_count + shard * SHARD_STRIDE, ia);
+					if (ig) bg = atomicAdd(a.group_count + shard * SHARD_STRIDE, ig);
 				}
-				bi = __shfl(bi, 63) + ii - n_valid;
-				ba = __shfl(ba, 63) + ia - n_a;
-				bg = __shfl(bg, 63) + ig - (n_valid ? 1u : 0u);
+				const uint32_t ti = __shfl(ii, 63), tg = __shfl(ig, 63);
+				bi = __shfl(bi, 63);
+				ba = __shfl(ba, 63);
+				bg = __shfl(bg, 63);
+				if (ti == 0) continue;
+				if (bi + ti > a.item_cap / N_SHARD) {
+					if (lane == 0) atomicOr(a.err, ERR_ITEM_OVERFLOW);
+					continue;
+				}
+				if (bg + tg > a.group_cap / N_SHARD) {
+					if (lane == 0) atomicOr(a.err, ERR_GROUP_OVERFLOW);
+					continue;
+				}
+				bi += shard * (a.item_cap / N_SHARD) + ii - n_valid;
+				ba += shard * (a.item_cap / N_SHARD) + ia - n_a;
+				bg += shard * (a.group_cap / N_SHARD) + ig - (n_valid ? 1u : 0u);
 				if (n_valid == 0) continue;
-				if (bi + n_valid > a.item_cap) {
-					atomicOr(a.err, ERR_ITEM_OVERFLOW);
-					continue;
-				}
-				if (bg >= a.group_cap) {
-					atomicOr(a.err, ERR_GROUP_OVERFLOW);
-					continue;
-				}
 				const uint32_t assay = a.assay_begin + la;
 				a.groups[bg] = Group{t, assay | gflags, bi, n_valid};
 				uint32_t o = bi;
