@@ -284,6 +284,13 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1)
 	return s;
 }
 
+// tw = 2 * tw + (x == y): v_cmp_eq + v_addc_co
+__device__ __forceinline__ uint32_t push_eq(uint32_t tw, int x, int y)
+{
+	asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(tw) : "v"(x), "v"(y) : "vcc");
+	return tw;
+}
+
 struct AlignInfo {
 	int k0, k1;               // column range inside the scratch buffer
 	int fm_q, fm_t, lm_q, lm_t;
@@ -439,25 +446,30 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				const int dg1 = (aM > 0 ? aM : 0) - DG(p1_196 + cur4);
 				const int dg2 = (aQ > 0 ? aQ : 0) - DG(pgap196 + cur4);
 				const int dg3 = (aT > 0 ? aT : 0) - DG(p3_196 + cur4);
-				// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits
+				// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits.
+				// The trace word is built as a shift register: every flag costs one v_alignbit (sign bits)
+				// or a compare + add-with-carry (equalities).  Final layout: see TW_* in tnt_dev.h.
 				int M = dg1 > dg2 ? dg1 : dg2;
 				M = M > dg3 ? M : dg3;
-				int tw = (dg1 == M ? 1 : 0) | (dg3 == M ? 2 : 0) | (dg2 == M ? 4 : 0);
-
 				const int iqi = (cM > 0 ? cM : 0) - DG(p4_196 + cq4);
 				const int iqe = (cQ > 0 ? cQ : 0) - v5;
 				const int Iq = iqi > iqe ? iqi : iqe;
-				tw |= (iqi >= iqe ? TW_IQ_FROM_M : 0) | (iqe >= iqi ? TW_IQ_FROM_IQ : 0);
-
 				const int iti = (bM > 0 ? bM : 0) - DG(p5_196 + ct4);
 				const int ite = (bT > 0 ? bT : 0) - DG(p3_196 + ct4);
 				const int It = iti > ite ? iti : ite;
-				tw |= (iti >= ite ? TW_IT_FROM_M : 0) | (ite >= iti ? TW_IT_FROM_IT : 0);
 
-				// sign class of M (0 negative, 1 zero, 2 positive) and the sign bits of the gap states
-				tw |= ((M < -1 ? -1 : (M > 1 ? 1 : M)) + 1) << TW_MCLASS_SHIFT; // v_med3_i32
-				tw |= int(uint32_t(Iq) >> 31) << TW_IQ_NEG_SHIFT;
-				tw |= int(uint32_t(It) >> 31) << TW_IT_NEG_SHIFT;
+				uint32_t tw = 0;
+				tw = push_eq(tw, dg1, M);                                  // M came from M        (im1_jm1)
+				tw = push_eq(tw, dg3, M);                                  // M came from I_target (im1_j)
+				tw = push_eq(tw, dg2, M);                                  // M came from I_query  (i_jm1)
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - iqe), 31); // insert < extend: I_query only from I_query
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - iqi), 31); // extend < insert: I_query only from M
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - ite), 31);
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - iti), 31);
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(M), 31);       // M < 0
+				tw = push_eq(tw, M, 0);                                    // M == 0
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(Iq), 31);      // I_query < 0
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(It), 31);      // I_target < 0
 				tcol[(i - 1) * BIND_THREADS] = uint16_t(tw);
 
 				// column maximum over the valid rows; the running maximum is updated once per column below
@@ -601,15 +613,14 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 					}
 					// border cells hold M = I_query = I_target = -1 (nuc_cruc.h:531-536)
 					const bool inside = (li >= 1 && lj >= 1);
-					const int tw = inside ? int(TRACE_AT(li, lj)) : (TW_IQ_NEG | TW_IT_NEG); // mclass 0 = negative
+					const int tw = inside ? int(TRACE_AT(li, lj)) : (TW_M_NEG | TW_IQ_NEG | TW_IT_NEG);
 					const int cidx = li * (WMAX + 1) + lj;
 					if (local == 1) { // query_target
 						if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
 							valid = false;
 						} else {
-							const int mclass = (tw >> TW_MCLASS_SHIFT) & 3;
-							if (mclass == 0) valid = false;
-							else if (mclass == 1) {
+							if (tw & TW_M_NEG) valid = false;
+							else if (tw & TW_M_ZERO) {
 								if (count_zeros) zero_count++;
 								else if (--truncate_at_zero == 0) valid = false;
 							}
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 							n++;
 							al.lm_q = L - li;
 							al.lm_t = lj - 1;
-							mask = tw & TW_M_MASK;
+							mask = ((tw & TW_M_FROM_M) ? 1 : 0) | ((tw & TW_M_FROM_IT) ? 2 : 0) | ((tw & TW_M_FROM_IQ) ? 4 : 0);
 							key = cidx * 4 + 0;
 							li--, lj--;
 						}
@@ -630,7 +641,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 							n++;
 							al.lm_q = L - li + 1;
 							al.lm_t = lj - 1;
-							mask = ((tw & TW_IQ_FROM_M) ? 1 : 0) | ((tw & TW_IQ_FROM_IQ) ? 4 : 0);
+							mask = ((tw & TW_IQ_LT) ? 0 : 1) | ((tw & TW_IQ_GT) ? 0 : 4); // insert >= extend: from M; extend >= insert: from I_query
 							key = cidx * 4 + 1;
 							lj--;
 						}
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 							n++;
 							al.lm_q = L - li;
 							al.lm_t = lj;
-							mask = ((tw & TW_IT_FROM_M) ? 1 : 0) | ((tw & TW_IT_FROM_IT) ? 2 : 0);
+							mask = ((tw & TW_IT_LT) ? 0 : 1) | ((tw & TW_IT_GT) ? 0 : 2);
 							key = cidx * 4 + 2;
 							li--;
 						}

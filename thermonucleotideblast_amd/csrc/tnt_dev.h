@@ -20,15 +20,19 @@ constexpr int MAX_WINDOW = MAX_OLIGO + 2 * FLANK;
 constexpr int MAX_COLS = MAX_OLIGO + MAX_WINDOW + 4; // longest traceback path + dangles
 constexpr int ALIGN_TEXT = 448;           // TNT_ALIGN_TEXT
 
-// trace word of one DP cell (16 bits), see bind kernel
-constexpr int TW_M_MASK = 7;      // bits 0-2: M_trace (im1_jm1=1, im1_j=2, i_jm1=4; nuc_cruc.h:62-64)
-constexpr int TW_IQ_FROM_M = 8;   // I_query_trace & im1_jm1
-constexpr int TW_IQ_FROM_IQ = 16; // I_query_trace & i_jm1
-constexpr int TW_IT_FROM_M = 32;  // I_target_trace & im1_jm1
-constexpr int TW_IT_FROM_IT = 64; // I_target_trace & im1_j
-constexpr int TW_MCLASS_SHIFT = 7;                 // bits 7-8: sign class of M (0 negative, 1 zero, 2 positive)
-constexpr int TW_IQ_NEG_SHIFT = 9, TW_IT_NEG_SHIFT = 10;
-constexpr int TW_IQ_NEG = 1 << TW_IQ_NEG_SHIFT, TW_IT_NEG = 1 << TW_IT_NEG_SHIFT;
+// trace word of one DP cell (11 bits used of 16), see the bind kernel.  Predecessor states follow
+// nuc_cruc.h:62-64 (im1_jm1 = came from M, im1_j = from I_target, i_jm1 = from I_query).
+constexpr int TW_IT_NEG = 1 << 0;     // I_target < 0
+constexpr int TW_IQ_NEG = 1 << 1;     // I_query < 0
+constexpr int TW_M_ZERO = 1 << 2;     // M == 0
+constexpr int TW_M_NEG = 1 << 3;      // M < 0
+constexpr int TW_IT_GT = 1 << 4;      // I_target: extend < insert  (trace = from M only)
+constexpr int TW_IT_LT = 1 << 5;      // I_target: insert < extend  (trace = from I_target only)
+constexpr int TW_IQ_GT = 1 << 6;      // I_query:  extend < insert
+constexpr int TW_IQ_LT = 1 << 7;      // I_query:  insert < extend
+constexpr int TW_M_FROM_IQ = 1 << 8;  // M_trace & i_jm1
+constexpr int TW_M_FROM_IT = 1 << 9;  // M_trace & im1_j
+constexpr int TW_M_FROM_M = 1 << 10;  // M_trace & im1_jm1
 
 // Thermodynamic tables resident in HBM (19 KB floats + 9.6 KB ints); delta_g is staged into LDS.
 struct Tables {
