@@ -307,6 +307,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	__shared__ uint32_t s_rt[18];
 	__shared__ uint8_t s_lut[18 * 18 + 4];
 	__shared__ uint8_t s_win[WMAX * BIND_THREADS];
+	__shared__ uint8_t s_qry[LMAX * BIND_THREADS];   // oligo bases of every lane, row order (row i-1 = query[L-i])
+	__shared__ uint16_t s_cols[NCOLS * BIND_THREADS]; // alignment columns of the path being scored
 
 	const int tid = threadIdx.x;
 	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) s_dg[i] = a.tab->dg[i];
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 
 	const Tables &T = *a.tab;
 	uint16_t *trace = a.trace + size_t(blockIdx.x) * (size_t(LMAX) * WMAX * BIND_THREADS) + tid;
-	uint16_t *cols = a.cols + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
+	uint16_t *cols = s_cols + tid;
+	uint8_t *qry = s_qry + tid;
 	uint16_t *best = a.best + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
 	uint32_t *stack = a.stack + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
 	uint16_t *ties = a.ties + size_t(blockIdx.x) * (size_t(TIE_CAP) * BIND_THREADS) + tid;
@@ -397,6 +400,9 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 		uint32_t qpk[(LMAX + 3) / 4];
 #pragma unroll
 		for (int w = 0; w < (LMAX + 3) / 4; w++) qpk[w] = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + w] : 0u;
+
+#pragma unroll
+		for (int i = 0; i < LMAX; i++) qry[i * BIND_THREADS] = uint8_t((qpk[i >> 2] >> ((i & 3) * 8 + 2)) & 7u);
 
 		int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 		AlignInfo bi = {0, 0, 0, 0, 0, 0};
 
 #define TRACE_AT(I, J) trace[(((J)-1) * LMAX + ((I)-1)) * BIND_THREADS]
-#define QUERY(K) int(c.query[(K)])
+#define QUERY(K) int(qry[(L - 1 - (K)) * BIND_THREADS])
 #define TARGET(K) int(win[(K) * BIND_THREADS])
 
 		// tm_dimer: every maximal cell in row-major order (nuc_cruc.cpp:2533-2537).  Cell codes (i << 8 | j)
