@@ -303,15 +303,20 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NCOLS = LMAX + WMAX + 4;
 
-	__shared__ int32_t s_dg[NBP * NBP];
+	__shared__ int2 s_dg2[NBP * NBP];  // {delta_g(prev, cur), term(cur)}
+	__shared__ int32_t s_term[NBP];
+	__shared__ int32_t s_const[4];
 	__shared__ uint32_t s_rt[18];
 	__shared__ uint8_t s_lut[18 * 18 + 4];
 	__shared__ uint8_t s_win[WMAX * BIND_THREADS];
-	__shared__ uint8_t s_qry[LMAX * BIND_THREADS];   // oligo bases of every lane, row order (row i-1 = query[L-i])
+	constexpr bool QRY_LDS = LMAX <= 32;             // larger instances keep the LDS budget for two workgroups per CU
+	__shared__ uint8_t s_qry[QRY_LDS ? LMAX * BIND_THREADS : 1]; // oligo bases of every lane, row order (row i-1 = query[L-i])
 	__shared__ uint16_t s_cols[NCOLS * BIND_THREADS]; // alignment columns of the path being scored
 
 	const int tid = threadIdx.x;
-	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) s_dg[i] = a.tab->dg[i];
+	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) s_dg2[i] = make_int2(a.tab->dg[i], a.tab->term[i % NBP]);
+	if (tid < NBP) s_term[tid] = a.tab->term[tid];
+	if (tid < 4) s_const[tid] = a.tab->dg_const[tid];
 	for (int i = tid; i < 18 * 18; i += BIND_THREADS) s_lut[i] = a.tab->bbp[i];
 	if (tid < 18) s_rt[tid] = a.tab->rt[tid];
 	__syncthreads();
@@ -391,18 +396,23 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 		// beyond L and columns beyond W compute throw-away values (their trace words land in scratch
 		// cells nobody reads) and are masked out of the running maximum only.
 		//
-		// Index algebra (delta_g is int32[49*49] in LDS, byte address = prev*196 + cur*4):
-		//   rt(x, q)  = resolve_degenerate(x | q), read from the 4-bit-per-partner word s_rt[x]
-		//   cur4      = 4 * bp(t, q)        = rt(t,q)*28 + 4q
-		//   p4_196    = 196 * bp(pt, q)     = rt(pt,q)*1372 + 196q      (== p1_196 of the next row)
-		//   p5_196    = 196 * bp(t, pq)     = 49 * cur4 of the previous row
-		//   p3_196    = 196 * bp(GAP, pq),  ct4 = 4 * bp(GAP, q)
+		// delta_g lookups.  Of the seven table reads per cell of the reference (nuc_cruc.cpp:536-646) only
+		// the stack read g(bp(pt,pq), bp(t,q)) needs the full 49x49 table.  update_dp_param (:379-486) gives
+		// every other combination the same value for all members of a class, which the host verifies when it
+		// builds the tables (tnt_host.hip, fill_tables):
+		//   g((x,GAP) or (GAP,x), c) = g(c, (x,GAP) or (GAP,x)) = term(c)       c a real pair: AT-like / GC / mismatch
+		//   g((x,GAP),(y,GAP)) = g((GAP,x),(GAP,y)) = BULGE;   g(__, c) = FORB_M;   g((GAP,x),(y,GAP)) = FORB_XY
+		//   g(__, (x,GAP) or (GAP,x)) = C0
+		// LDS holds int2 {g(prev,cur), term(cur)} per (prev,cur) (byte address prev*392 + cur*8) and term[] per
+		// pair (term[(GAP,x)] = FORB_XY so the first column needs no special case).
+		//   rt(x, q) = resolve_degenerate(x | q) from the 4-bit-per-partner word s_rt[x]
 		uint32_t qpk[(LMAX + 3) / 4];
 #pragma unroll
 		for (int w = 0; w < (LMAX + 3) / 4; w++) qpk[w] = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + w] : 0u;
-
+		if (QRY_LDS) {
 #pragma unroll
-		for (int i = 0; i < LMAX; i++) qry[i * BIND_THREADS] = uint8_t((qpk[i >> 2] >> ((i & 3) * 8 + 2)) & 7u);
+			for (int i = 0; i < LMAX; i++) qry[i * BIND_THREADS] = uint8_t((qpk[i >> 2] >> ((i & 3) * 8 + 2)) & 7u);
+		}
 
 		int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
@@ -410,58 +420,56 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 
 		int gmax = -1, nmax = 0, max_ij = 0;
 		uint32_t prtw = s_rt[bGAP];
-		int pgap196 = P__ * 196;
 		// uniform trip count over the wavefront keeps the unrolled body convergent
 		int Wwave = W;
 		for (int o = 32; o > 0; o >>= 1) {
 			const int other = __shfl_xor(Wwave, o);
 			Wwave = other > Wwave ? other : Wwave;
 		}
-		const char *sdg = reinterpret_cast<const char *>(s_dg);
-#define DG(ADDR) (*reinterpret_cast<const int32_t *>(sdg + (ADDR)))
+		const char *sdg = reinterpret_cast<const char *>(s_dg2);
+		const char *sterm = reinterpret_cast<const char *>(s_term);
+		const int c_bulge = s_const[0], c_zero = s_const[1], c_forb_m = s_const[2], c_forb_xy = s_const[3];
 		uint16_t *tcol = trace;
 #pragma unroll 1
 		for (int j = 1; j <= Wwave; j++) {
 			const bool colok = j <= W;
+			const bool firstcol = j == 1; // wave-uniform
 			const int t = colok ? int(win[(j - 1) * BIND_THREADS]) : bGAP;
 			const uint32_t rtw = s_rt[t];
-			const int cq4 = int((rtw >> 24) & 15u) * 28 + 24;     // 4 * bp(t, GAP)
-			const int v5 = DG(pgap196 + cq4);
+			const int v5 = firstcol ? c_zero : c_bulge;          // g(bp(pt,GAP), bp(t,GAP))
 			int aM = -1, aQ = -1, aT = -1, bM = -1, bT = -1;
 			const int Lcol = colok ? L : 0;   // rows that count in this column
 			int colmax = INT32_MIN;
-			int pq4 = 24;                     // 4 * GAP
-			int pq196 = bGAP * 196;           // 196 * pq
-			int p1_196 = pgap196;             // row 1: bp(pt, GAP)
-			int p5_196 = cq4 * 49;            // row 1: 196 * bp(t, GAP)
+			int p1_392 = (int((prtw >> 24) & 15u) * NB + bGAP) * 392; // row 1: 392 * bp(pt, GAP)
+			int term_up = 0;                                     // term(cur) of the row above
 			// keep the per-row constants from being hoisted out of the column loop (register pressure)
 #pragma unroll
 			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(qpk[w]));
 #pragma unroll
 			for (int i = 1; i <= LMAX; i++) {
 				const int q4 = int((qpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 31u);
-				const int q196 = q4 * 49;
 				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
 				const int rtq = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
 				const int prtq = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
-				const int cur4 = rtq * 28 + q4;
-				const int p4_196 = prtq * 1372 + q196;
-				const int p3_196 = (bGAP * NB) * 196 + pq196;
-				const int ct4 = (bGAP * NB) * 4 + q4;
+				const int cur8 = rtq * 56 + 2 * q4;               // 8 * bp(t, q)
+				const int p4_4 = prtq * 28 + q4;                   // 4 * bp(pt, q)
+				const int2 e = *reinterpret_cast<const int2 *>(sdg + p1_392 + cur8);
+				const int term_p4 = *reinterpret_cast<const int *>(sterm + p4_4);
+				const int termv = e.y;
 
-				const int dg1 = (aM > 0 ? aM : 0) - DG(p1_196 + cur4);
-				const int dg2 = (aQ > 0 ? aQ : 0) - DG(pgap196 + cur4);
-				const int dg3 = (aT > 0 ? aT : 0) - DG(p3_196 + cur4);
+				const int dg1 = (aM > 0 ? aM : 0) - e.x;
+				const int dg2 = (aQ > 0 ? aQ : 0) - (firstcol ? c_forb_m : termv);
+				const int dg3 = (aT > 0 ? aT : 0) - (i == 1 ? c_forb_m : termv);
 				// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits.
 				// The trace word is built as a shift register: every flag costs one v_alignbit (sign bits)
 				// or a compare + add-with-carry (equalities).  Final layout: see TW_* in tnt_dev.h.
 				int M = dg1 > dg2 ? dg1 : dg2;
 				M = M > dg3 ? M : dg3;
-				const int iqi = (cM > 0 ? cM : 0) - DG(p4_196 + cq4);
+				const int iqi = (cM > 0 ? cM : 0) - term_p4;
 				const int iqe = (cQ > 0 ? cQ : 0) - v5;
 				const int Iq = iqi > iqe ? iqi : iqe;
-				const int iti = (bM > 0 ? bM : 0) - DG(p5_196 + ct4);
-				const int ite = (bT > 0 ? bT : 0) - DG(p3_196 + ct4);
+				const int iti = (bM > 0 ? bM : 0) - (i == 1 ? c_forb_xy : term_up);
+				const int ite = (bT > 0 ? bT : 0) - (i == 1 ? c_zero : c_bulge);
 				const int It = iti > ite ? iti : ite;
 
 				uint32_t tw = 0;
@@ -485,12 +493,9 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				aM = cM, aQ = cQ, aT = cT;
 				bM = M, bT = It;
 				oM[i - 1] = M, oQ[i - 1] = Iq, oT[i - 1] = It;
-				pq4 = q4;
-				pq196 = q196;
-				p1_196 = p4_196;
-				p5_196 = cur4 * 49;
+				p1_392 = p4_4 * 98;
+				term_up = termv;
 			}
-			(void)pq4;
 			// Running maximum, nuc_cruc.cpp:670-691.  The reference visits cells row-major; here the visiting
 			// order is column-major, rows ascending.  The SET of cells holding the final maximum does not depend
 			// on the order; it is collected as (i << 8 | j) codes and sorted row-major before the traceback.
@@ -512,10 +517,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				}
 			}
 			prtw = rtw;
-			pgap196 = cq4 * 49;
 			tcol += LMAX * BIND_THREADS;
 		}
-#undef DG
 
 		// ------------------------------------------------------------------ serial tail
 		if (!active) continue;
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 		AlignInfo bi = {0, 0, 0, 0, 0, 0};
 
 #define TRACE_AT(I, J) trace[(((J)-1) * LMAX + ((I)-1)) * BIND_THREADS]
-#define QUERY(K) int(qry[(L - 1 - (K)) * BIND_THREADS])
+#define QUERY(K) (QRY_LDS ? int(qry[(L - 1 - (K)) * BIND_THREADS]) : int(c.query[(K)]))
 #define TARGET(K) int(win[(K) * BIND_THREADS])
 
 		// tm_dimer: every maximal cell in row-major order (nuc_cruc.cpp:2533-2537).  Cell codes (i << 8 | j)

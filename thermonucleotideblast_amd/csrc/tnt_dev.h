@@ -44,6 +44,9 @@ struct Tables {
 	uint8_t bbp[18 * 18];   // best_base_pair LUT, nuc_cruc.cpp:14-213 (row = first argument)
 	uint8_t pad0[4];
 	uint32_t rt[18];        // rt[x] nibble q = resolve_degenerate(x | q) for partner q in A,C,G,T,I,E,GAP
+	int32_t term[NBP];      // class constants of delta_g (see the bind kernel): term[c] = g((x,GAP), c) for real pairs c,
+	                        // term[(GAP,x)] = g((GAP,x),(y,GAP)) (forbidden)
+	int32_t dg_const[4];    // BULGE, g(__,(x,GAP)), g(__, real pair), g((GAP,x),(y,GAP))
 	float init_H, init_S, at_H, at_S, salt, asym_S, bulge_at_S;
 	float temperature;      // target_T
 	float log_na;           // logf([Na+]) computed on the host (no device logf: bit-exactness)

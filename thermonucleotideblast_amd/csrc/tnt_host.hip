@@ -74,7 +74,9 @@ int resolve(int x, int partner) // resolve_degenerate, nuc_cruc.cpp:14-201 (B fa
 	}
 }
 
-void fill_tables(Tables &T, const tnt_options &opt)
+// returns false when delta_g lacks the class structure the bind kernel relies on (cannot happen for tables
+// produced by update_dp_param; checked anyway so a future table change fails loudly instead of silently)
+bool fill_tables(Tables &T, const tnt_options &opt)
 {
 	memset(&T, 0, sizeof(T));
 	for (int k = 0; k < TNT_SL_NN_COUNT; k++) {
@@ -137,6 +139,34 @@ void fill_tables(Tables &T, const tnt_options &opt)
 			T.dg[(i * NB + bGAP) * NBP + (j * NB + bGAP)] = v_bulge;
 			T.dg[(bGAP * NB + i) * NBP + (bGAP * NB + j)] = v_bulge;
 		}
+
+	// ---- class constants used by the bind kernel instead of six of the seven table reads per cell
+	bool ok = true;
+	auto G = [&](int prev, int cur) { return T.dg[prev * NBP + cur]; };
+	const int GG = P__;
+	T.dg_const[0] = G(bA * NB + bGAP, bA * NB + bGAP);       // BULGE
+	T.dg_const[1] = G(GG, bA * NB + bGAP);                   // C0 = g(__, (x,GAP))
+	T.dg_const[2] = G(GG, bA * NB + bA);                     // FORB_M = g(__, real pair)
+	T.dg_const[3] = G(bGAP * NB + bA, bA * NB + bGAP);       // FORB_XY = g((GAP,x),(y,GAP))
+	for (int p = 0; p < NBP; p++) T.term[p] = 0;
+	for (int x = bA; x <= bI; x++)
+		for (int y = bA; y <= bI; y++) {
+			const int c = x * NB + y;
+			const int v = G(bA * NB + bGAP, c);
+			T.term[c] = v;
+			ok &= G(GG, c) == T.dg_const[2];
+			for (int k = bA; k <= bI; k++) {
+				const int p1 = k * NB + bGAP, p2 = bGAP * NB + k;
+				ok &= G(p1, c) == v && G(p2, c) == v && G(c, p1) == v && G(c, p2) == v;
+			}
+			// bulge extensions and the forbidden / gap-opening combinations
+			const int xg = x * NB + bGAP, gx = bGAP * NB + x, yg = y * NB + bGAP, gy = bGAP * NB + y;
+			ok &= G(xg, yg) == T.dg_const[0] && G(gx, gy) == T.dg_const[0];
+			ok &= G(gx, yg) == T.dg_const[3] && G(xg, gy) == T.dg_const[3];
+			ok &= G(GG, xg) == T.dg_const[1] && G(GG, gx) == T.dg_const[1];
+		}
+	for (int x = bA; x <= bI; x++) T.term[bGAP * NB + x] = T.dg_const[3]; // first column: prev = bp(GAP, q)
+	return ok;
 }
 
 int char_to_base(char c) // expanded oligos only: A C G T I (degenerate_na.cpp:81-133 expands the rest)
@@ -584,7 +614,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	c->lmax = pick_lmax(max_L);
 
 	// ---- tables
-	fill_tables(c->h_tab, *opt);
+	if (!fill_tables(c->h_tab, *opt)) FAIL(TNT_E_UNSUPPORTED, "delta_g table lacks the class structure the bind kernel relies on");
 	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
 	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 4), 0);
 	std::vector<int32_t> ol(std::max<size_t>(1, c->oligos.size()), 0);
