@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 
 		int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
-		for (int i = 0; i < LMAX; i++) oM[i] = oQ[i] = oT[i] = -1;
+		for (int i = 0; i < LMAX; i++) oM[i] = -1, oQ[i] = oT[i] = 0;
 
 		int gmax = -1, nmax = 0, max_ij = 0;
 		uint32_t prtw = s_rt[bGAP];
@@ -437,39 +437,55 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 			const int t = colok ? int(win[(j - 1) * BIND_THREADS]) : bGAP;
 			const uint32_t rtw = s_rt[t];
 			const int v5 = firstcol ? c_zero : c_bulge;          // g(bp(pt,GAP), bp(t,GAP))
-			int aM = -1, aQ = -1, aT = -1, bM = -1, bT = -1;
+			int aM = -1, aQ = 0, aT = 0, bM = -1, bT = 0; // border cells hold -1 (nuc_cruc.h:531-536); gap states are kept clamped
 			const int Lcol = colok ? L : 0;   // rows that count in this column
 			int colmax = INT32_MIN;
-			int p1_392 = (int((prtw >> 24) & 15u) * NB + bGAP) * 392; // row 1: 392 * bp(pt, GAP)
 			int term_up = 0;                                     // term(cur) of the row above
 			// keep the per-row constants from being hoisted out of the column loop (register pressure)
 #pragma unroll
 			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(qpk[w]));
-#pragma unroll
-			for (int i = 1; i <= LMAX; i++) {
-				const int q4 = int((qpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 31u);
-				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
+			// The two LDS reads of a row are issued one row ahead (their addresses depend on the bases only),
+			// so their latency overlaps the arithmetic of the previous row.
+			int2 e_n;
+			int tp4_n, p4_4_n;
+			{
+				const int q4 = int(qpk[0] & 31u);
 				const int rtq = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
 				const int prtq = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
-				const int cur8 = rtq * 56 + 2 * q4;               // 8 * bp(t, q)
-				const int p4_4 = prtq * 28 + q4;                   // 4 * bp(pt, q)
-				const int2 e = *reinterpret_cast<const int2 *>(sdg + p1_392 + cur8);
-				const int term_p4 = *reinterpret_cast<const int *>(sterm + p4_4);
+				p4_4_n = prtq * 28 + q4;                           // 4 * bp(pt, q)
+				const int p1_392 = (int((prtw >> 24) & 15u) * NB + bGAP) * 392; // row 1: 392 * bp(pt, GAP)
+				e_n = *reinterpret_cast<const int2 *>(sdg + p1_392 + rtq * 56 + 2 * q4); // {g(prev, bp(t,q)), term}
+				tp4_n = *reinterpret_cast<const int *>(sterm + p4_4_n);
+			}
+#pragma unroll
+			for (int i = 1; i <= LMAX; i++) {
+				const int2 e = e_n;
+				const int term_p4 = tp4_n;
+				const int p4_4 = p4_4_n;
+				if (i < LMAX) {
+					const int q4 = int((qpk[i >> 2] >> ((i & 3) * 8)) & 31u);
+					const int rtq = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
+					const int prtq = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
+					p4_4_n = prtq * 28 + q4;
+					e_n = *reinterpret_cast<const int2 *>(sdg + p4_4 * 98 + rtq * 56 + 2 * q4); // prev = bp(pt, q of this row)
+					tp4_n = *reinterpret_cast<const int *>(sterm + p4_4_n);
+				}
+				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // oQ / oT are stored clamped at zero
 				const int termv = e.y;
 
 				const int dg1 = (aM > 0 ? aM : 0) - e.x;
-				const int dg2 = (aQ > 0 ? aQ : 0) - (firstcol ? c_forb_m : termv);
-				const int dg3 = (aT > 0 ? aT : 0) - (i == 1 ? c_forb_m : termv);
+				const int dg2 = aQ - (firstcol ? c_forb_m : termv);
+				const int dg3 = aT - (i == 1 ? c_forb_m : termv);
 				// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits.
 				// The trace word is built as a shift register: every flag costs one v_alignbit (sign bits)
 				// or a compare + add-with-carry (equalities).  Final layout: see TW_* in tnt_dev.h.
 				int M = dg1 > dg2 ? dg1 : dg2;
 				M = M > dg3 ? M : dg3;
 				const int iqi = (cM > 0 ? cM : 0) - term_p4;
-				const int iqe = (cQ > 0 ? cQ : 0) - v5;
+				const int iqe = cQ - v5;
 				const int Iq = iqi > iqe ? iqi : iqe;
 				const int iti = (bM > 0 ? bM : 0) - (i == 1 ? c_forb_xy : term_up);
-				const int ite = (bT > 0 ? bT : 0) - (i == 1 ? c_zero : c_bulge);
+				const int ite = bT - (i == 1 ? c_zero : c_bulge);
 				const int It = iti > ite ? iti : ite;
 
 				uint32_t tw = 0;
@@ -491,9 +507,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				colmax = colmax > Mv ? colmax : Mv;
 
 				aM = cM, aQ = cQ, aT = cT;
-				bM = M, bT = It;
-				oM[i - 1] = M, oQ[i - 1] = Iq, oT[i - 1] = It;
-				p1_392 = p4_4 * 98;
+				bM = M, bT = It > 0 ? It : 0;
+				oM[i - 1] = M, oQ[i - 1] = Iq > 0 ? Iq : 0, oT[i - 1] = bT;
 				term_up = termv;
 			}
 			// Running maximum, nuc_cruc.cpp:670-691.  The reference visits cells row-major; here the visiting
