@@ -50,6 +50,9 @@ struct BindArgs {
 	uint32_t *stack;
 	uint16_t *ties;            // [TIE_CAP][lane] further cells with the maximal score
 	uint32_t *err;
+	Group *groups;             // a group is put on the active list when its first item binds
+	uint32_t *active;
+	uint32_t *n_active;
 };
 
 constexpr int BIND_THREADS = 256;
@@ -346,10 +349,10 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 
 		// ------------------------------------------------------------------ item decode
 		Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
-		const Slot slot = a.slots[active ? it.slot : 0];
+		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
 		const int L = active ? a.olig_len[slot.oligo] : 0;
 		const bool minus = (it.info & ITEM_MINUS) != 0;
-		const int qloc = int(it.info & 255u);
+		const int qloc = int(it.info & 127u);
 		const uint32_t tlen = a.db.len[it.target];
 		// bind_oligo.cpp:502-505
 		int start = int(it.tloc) - (qloc + FLANK);
@@ -851,6 +854,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				rec->a5 = a5, rec->a3 = a3, rec->mm = mm, rec->gap = gap;
 				text = rec->text;
 				res = int32_t(slotp);
+				if (a.groups && !(atomicOr(&a.groups[it.group].count, GROUP_ALIVE) & GROUP_ALIVE))
+					a.active[atomicAdd(a.n_active, 1u)] = it.group;
 			} else {
 				atomicOr(a.err, ERR_POOL_OVERFLOW);
 				res = -100;

@@ -73,11 +73,12 @@ struct Slot {
 struct Item {
 	uint32_t target;  // target index inside the packed batch
 	uint32_t tloc;    // seed target_loc
-	uint32_t slot;    // Slot index
-	uint32_t info;    // bits 0-7 query_loc (word index), bit 8 strand (0 plus, 1 minus), bits 9-11 role group
+	uint32_t info;    // bits 0-6 query_loc (word index), bit 7 strand (1 = minus), bit 8 phase B, bits 9-31 Slot index
+	uint32_t group;   // physical index of its Group (marked alive when the item binds)
 };
-constexpr uint32_t ITEM_MINUS = 1u << 8;
-constexpr uint32_t ITEM_PHASE_B = 1u << 12; // bound only if a phase-A item of its group bound (second strand / probe)
+constexpr uint32_t ITEM_MINUS = 1u << 7;
+constexpr uint32_t ITEM_PHASE_B = 1u << 8; // bound only if a phase-A item of its group bound (second strand / probe)
+constexpr int ITEM_SLOT_SHIFT = 9;
 
 // result of one bind; pool record only exists for bound items
 struct BoundRec {
@@ -105,8 +106,9 @@ struct Group {
 	uint32_t target;
 	uint32_t assay;   // expanded assay index | GROUP_* flags
 	uint32_t first;   // first item
-	uint32_t count;
+	uint32_t count;   // | GROUP_ALIVE once one of its items bound
 };
+constexpr uint32_t GROUP_ALIVE = 1u << 31;
 constexpr uint32_t GROUP_MINUS_FIRST = 1u << 31; // bind the minus strand first (amplicon_search.cpp:131)
 constexpr uint32_t GROUP_ASSAY_MASK = (1u << 24) - 1u;
 

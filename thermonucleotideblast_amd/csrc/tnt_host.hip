@@ -450,6 +450,9 @@ BindArgs bind_args(tnt_ctx *c, const DbView &v)
 	a.stack = c->stack.p;
 	a.ties = c->ties.p;
 	a.err = c->counters.p + C_ERR;
+	a.groups = c->groups.p;
+	a.active = c->active.p;
+	a.n_active = c->counters.p + C_ACTIVE;
 	return a;
 }
 
@@ -860,15 +863,12 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 
 	FilterArgs f;
 	f.groups = c->groups.p;
-	f.group_counts = cnt + C_GROUPS;
-	f.group_region = uint32_t(GROUP_CAP / N_SHARD);
 	f.items = c->items.p;
-	f.result = c->result.p;
 	f.active = c->active.p;
 	f.n_active = cnt + C_ACTIVE;
 	f.qb = c->qb.p;
 	f.qb_count = cnt + C_QB;
-	hipLaunchKernelGGL(filter_kernel, dim3(c->bind_blocks * 4), dim3(256), 0, c->stream, f);
+	hipLaunchKernelGGL(filter_kernel, dim3(256), dim3(256), 0, c->stream, f);
 
 	// phase B: the other strand and the probes of the groups that are still alive
 	b.n_items_dev = cnt + C_QB;
@@ -1104,7 +1104,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 {
 	if (!ctx || !db || db->ctx != ctx || (!req && n) || (!out && n)) return TNT_E_ARG;
 	if (n == 0) return TNT_OK;
-	if (n > ITEM_CAP) return TNT_E_LIMIT;
+	if (n > ITEM_CAP || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	int rc = ensure_work_buffers(ctx, 64); // the unit-level kernel instance is bind_kernel<64, true>
 	if (rc) return rc;
@@ -1114,7 +1114,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	for (size_t i = 0; i < n; i++) {
 		const tnt_bind_req &r = req[i];
 		const size_t t = size_t(r.seq_index) - db->first_seq_index;
-		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc > 255 ||
+		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc > 127 ||
 		    r.target_loc < 0 || !(r.ct > 0.0f)) {
 			ctx->err = "bad bind request";
 			return TNT_E_ARG;
@@ -1125,8 +1125,8 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 		slots[i].assay = -1;
 		items[i].target = uint32_t(t);
 		items[i].tloc = uint32_t(r.target_loc);
-		items[i].slot = uint32_t(i);
-		items[i].info = uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u);
+		items[i].info = uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT);
+		items[i].group = 0;
 	}
 	DevBuf<Slot> dslots;
 	DevBuf<BindFull> dfull;
@@ -1136,6 +1136,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 	BindArgs b = bind_args(ctx, make_view(db, 0, db->n_targets));
 	b.slots = dslots.p;
+	b.groups = nullptr;
 	b.n_items = uint32_t(n);
 	b.n_items_dev = nullptr;
 	b.full = dfull.p;

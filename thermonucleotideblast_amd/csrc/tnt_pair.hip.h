@@ -207,42 +207,30 @@ __device__ Hit *alloc_hit(const PairArgs &a)
 	return a.hits + o;
 }
 
-// After phase A (first strand of the PCR groups, everything of the probe / padlock groups):
-//  * PCR group with no bound phase-A item: the reference's list is empty after the second cull
-//    (amplicon_search.cpp:151-179 / :238-266) -> dead, its phase-B seeds are never bound;
-//  * otherwise the group goes on the active list and its phase-B items on the phase-B queue.
+// After phase A (first strand of the PCR groups, everything of the probe / padlock groups) the bind
+// kernel has put every group with a bound item on the active list.  A PCR group that is not on it is dead:
+// the reference's list is empty after the second cull (amplicon_search.cpp:151-179 / :238-266) and its
+// phase-B seeds are never bound.  This kernel queues the phase-B items of the groups that are alive.
 struct FilterArgs {
-	const Group *groups;      // sharded array (seed kernel output)
-	const uint32_t *group_counts; // [N_SHARD * SHARD_STRIDE]
-	uint32_t group_region;
+	const Group *groups;
 	const Item *items;
-	const int32_t *result;
-	uint32_t *active;
-	uint32_t *n_active;
+	const uint32_t *active;
+	const uint32_t *n_active;
 	uint32_t *qb;
 	uint32_t *qb_count;
 };
 
 __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
 {
-	__shared__ uint32_t s_pre[N_SHARD + 1];
-	shard_prefix(a.group_counts, s_pre, threadIdx.x);
-	__syncthreads();
-	const uint32_t n = s_pre[N_SHARD];
-	for (uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x; lin < n; lin += gridDim.x * blockDim.x) {
-		const uint32_t g = shard_locate(s_pre, lin, a.group_region);
-		const Group G = a.groups[g];
-		bool any = false;
+	const uint32_t n = *a.n_active;
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+		const Group G = a.groups[a.active[x]];
+		const uint32_t count = G.count & ~GROUP_ALIVE;
 		uint32_t nb = 0;
-		for (uint32_t i = 0; i < G.count; i++) {
-			if (a.items[G.first + i].info & ITEM_PHASE_B) nb++;
-			else any |= a.result[G.first + i] >= 0;
-		}
-		if (!any) continue;
-		a.active[atomicAdd(a.n_active, 1u)] = g;
+		for (uint32_t i = 0; i < count; i++) nb += (a.items[G.first + i].info & ITEM_PHASE_B) ? 1u : 0u;
 		if (nb) {
 			uint32_t o = atomicAdd(a.qb_count, nb);
-			for (uint32_t i = 0; i < G.count; i++)
+			for (uint32_t i = 0; i < count; i++)
 				if (a.items[G.first + i].info & ITEM_PHASE_B) a.qb[o++] = G.first + i;
 		}
 	}
@@ -261,13 +249,14 @@ __device__ void pair_group(const PairArgs &a, const Group G)
 	const int seq_index = int(a.db.first_seq_index + G.target);
 	const BoundRec *pool = a.pool;
 
-	if (G.count > uint32_t(PAIR_MAX)) {
+	const uint32_t g_count = G.count & ~GROUP_ALIVE;
+	if (g_count > uint32_t(PAIR_MAX)) {
 		atomicOr(a.err, ERR_LIST_OVERFLOW);
 		return;
 	}
 
 	List l;
-	l.n = int(G.count);
+	l.n = int(g_count);
 	bool any_bound = false;
 	for (int i = 0; i < l.n; i++) {
 		const Item it = a.items[G.first + i];
@@ -276,7 +265,7 @@ __device__ void pair_group(const PairArgs &a, const Group G)
 		e.tloc = it.tloc;
 		e.rec = res >= 0 ? res : -1;
 		e.loc5 = e.loc3 = 0;
-		const uint32_t role = (it.info >> 9) & 3u;
+		const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u;
 		e.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((it.info & ITEM_MINUS) ? MMINUS : MPLUS));
 		if (res >= 0) any_bound = true;
 	}

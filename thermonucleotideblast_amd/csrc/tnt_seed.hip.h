@@ -384,8 +384,9 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 					Item it;
 					it.target = t;
 					it.tloc = p;
-					it.slot = assay * 3u + key_role(k); // Slot table is laid out [assay][role]
-					it.info = wi | ((k & 1u) ? ITEM_MINUS : 0u) | (key_role(k) << 9) | (pb ? ITEM_PHASE_B : 0u);
+					// Slot table is laid out [assay][role]
+					it.info = wi | ((k & 1u) ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | ((assay * 3u + key_role(k)) << ITEM_SLOT_SHIFT);
+					it.group = bg;
 					a.items[o] = it;
 					if (!pb) a.qa[ba++] = o;
 					o++;
