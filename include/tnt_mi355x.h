@@ -197,6 +197,13 @@ int tnt_last_timing(tnt_ctx *ctx, tnt_timing *out);
 int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds);
 int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out);
 
+/* Oligo self-structure printed with every hit (tntblast_local.cpp:656-686): hairpin and homodimer Tm of oligo
+ * `a` at strand(ct_a, ct_a), and, when `b` is given, the heterodimer Tm of query a / target b at
+ * strand(ct_a, ct_b) (NucCruc::approximate_tm_hairpin / _homodimer / _heterodimer, nuc_cruc.cpp:2397-2616).
+ * Depends on the oligos and options only; computed on the GPU by the unit-level bind kernel instance.   */
+int tnt_oligo_structure(tnt_ctx *ctx, const char *a, const char *b, float ct_a, float ct_b, float *hairpin_a,
+                        float *homodimer_a, float *heterodimer_ab);
+
 /* amplicon / probe text of a hit, copied from the packed targets (amplicon_search.cpp:508-537,
  * probe_search.cpp:138-152): returns length written (without NUL) or <0.                      */
 int tnt_hit_sequence(tnt_ctx *ctx, tnt_db *db, const tnt_hit *hit, char *buf, size_t cap);

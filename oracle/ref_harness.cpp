@@ -132,6 +132,26 @@ int tntref_tables(const tnt_options *opt, int32_t *delta_g, float *param_H, floa
 	}
 }
 
+// special tri/tetra hairpin loops (nuc_cruc.h:571-588, nuc_cruc_santa_lucia.cpp:773-1180)
+int tntref_hairpin_special(float *H, float *S, int *n)
+{
+	try {
+		NucCruc melt(NucCruc::SANTA_LUCIA, 310.15f);
+		*n = NucCruc::NUM_SPECIAL_HAIRPIN_LOOP;
+		memcpy(H, melt.param_hairpin_special_H, sizeof(float) * NucCruc::NUM_SPECIAL_HAIRPIN_LOOP);
+		memcpy(S, melt.param_hairpin_special_S, sizeof(float) * NucCruc::NUM_SPECIAL_HAIRPIN_LOOP);
+		if (memcmp(melt.param_hairpin_terminal_H, melt.param_H, sizeof(melt.param_H)) ||
+		    memcmp(melt.param_hairpin_terminal_S, melt.param_S, sizeof(melt.param_S))) {
+			g_err = "hairpin terminal tables differ from param_H/S";
+			return -1;
+		}
+		return 0;
+	} catch (const char *e) {
+		g_err = e;
+		return -1;
+	}
+}
+
 // G4: seeds of every oligo against every target, both strands, after the
 // per-(oligo,strand) diagonal dedup (bind_oligo.cpp:84-122).
 int tntref_seeds(const tnt_options *opt, const char *const *oligos, int n_oligos, const uint8_t *codes,

@@ -118,7 +118,7 @@ static Base char_to_base(char c) // nuc_cruc.h:190-231
 // Parameters: nuc_cruc_santa_lucia.cpp (values from the generated table) + nuc_cruc.cpp:226-300
 struct Params {
 	float H[2401], S[2401];
-	float loop_S[513], bulge_S[513];
+	float loop_S[513], bulge_S[513], hairpin_S[513];
 	float init_H, init_S, at_H, at_S, sym_S, salt, asym_S, bulge_at_S;
 	bool wc[NBP];
 	Params()
@@ -132,6 +132,7 @@ struct Params {
 		for (int i = 0; i < 513; i++) {
 			loop_S[i] = f32(TOR_LOOP_S[i]);
 			bulge_S[i] = f32(TOR_BULGE_S[i]);
+			hairpin_S[i] = f32(TOR_HAIRPIN_S[i]);
 		}
 		init_H = f32(TOR_INIT_H);
 		init_S = f32(TOR_INIT_S);
@@ -211,6 +212,8 @@ struct Alignment { // nuc_cruc.h:343-484
 	int fm_q = 0, fm_t = 0, lm_q = 0, lm_t = 0; // first_match / last_match (.first=query, .second=target)
 };
 
+enum Mode { HOMO_DIMER = 0, HETERO_DIMER, HAIRPIN }; // NucCruc::mode, nuc_cruc.h:494
+
 struct Cell {
 	int32_t M = -1, Iq = -1, It = -1;
 	uint8_t Mt = TR_INVALID, Iqt = TR_INVALID, Itt = TR_INVALID;
@@ -252,7 +255,23 @@ public:
 	{
 		cur = Alignment();
 		align_dimer();
-		for (int c : max_cells) enumerate(c); // tm_dimer, nuc_cruc.cpp:2533-2537
+		for (int c : max_cells) enumerate(c, HETERO_DIMER); // tm_dimer, nuc_cruc.cpp:2533-2537
+		return cur.tm;
+	}
+	float approximate_tm_homodimer() // nuc_cruc.cpp:2501-2514: the query against itself
+	{
+		cur = Alignment();
+		target = query;
+		align_dimer();
+		for (int c : max_cells) enumerate(c, HOMO_DIMER);
+		return cur.tm;
+	}
+	float approximate_tm_hairpin() // nuc_cruc.cpp:2597-2615
+	{
+		cur = Alignment();
+		target = query; // trace_back(m_q, m_q), nuc_cruc.cpp:1212
+		align_hairpin();
+		for (int c : max_cells) enumerate_hairpin(c);
 		return cur.tm;
 	}
 	float delta_G() const { return cur.dH - Tk * cur.dS; } // nuc_cruc.h:1217
@@ -515,7 +534,7 @@ private:
 	}
 
 	// nuc_cruc.cpp:973-1170
-	void enumerate(int cell)
+	void enumerate(int cell, Mode mode)
 	{
 		const Params &P = params();
 		const int ql = int(query.size()), tl = int(target.size());
@@ -563,7 +582,7 @@ private:
 				else al.t.push_back(target[--al.lm_t]);
 			}
 			if (al.q.size() < 3) continue; // :1148
-			if (evaluate(al)) {
+			if (evaluate(al, mode)) {
 				const float local_dg = al.dH - Tk * al.dS;
 				if (!cur.valid || local_dg < best_dg) { // :1160-1167
 					cur = al;
@@ -571,6 +590,195 @@ private:
 					best_dg = local_dg;
 				}
 			}
+		}
+	}
+
+	// nuc_cruc.cpp:771-971.  Stem rows i = 1..L-4 (reversed query), columns j = 0..L-4-i (forward query);
+	// cell (i, j+1) pairs query[L-i] with query[j].
+	void align_hairpin()
+	{
+		const int L = int(query.size());
+		if (L == 0) throw ":NucCruc::align_hairpin: Empty query sequence";
+		const int max_stem = L - 4; // steric_limit = 3 + 1
+		stride = L + 1;
+		dp.assign(size_t(L + 1) * stride, Cell());
+		max_cells.clear();
+		max_score = -1;
+		for (int i = 1; i <= max_stem; i++) {
+			const Base qb = query[L - i];
+			const Base pq = (i == 1) ? GAP : query[L - (i - 1)];
+			const int upper_j = max_stem - (i - 1);
+			for (int j = 0; j < upper_j; j++) {
+				const Base tb = query[j];
+				const Base pt = (j == 0) ? GAP : query[j - 1];
+				const Cell &Ac = dp[(i - 1) * stride + j], &Bc = dp[(i - 1) * stride + j + 1], &Cc = dp[i * stride + j];
+				Cell &X = dp[i * stride + j + 1];
+				int curp = bbp(tb, qb);
+				const int dg1 = std::max(0, Ac.M) - g(bbp(pt, pq), curp);
+				const int dg2 = std::max(0, Ac.Iq) - g(bbp(pt, GAP), curp);
+				const int dg3 = std::max(0, Ac.It) - g(bbp(GAP, pq), curp);
+				if (dg1 >= dg2) {
+					if (dg1 >= dg3) {
+						X.M = dg1;
+						X.Mt = TR_M;
+						if (dg1 == dg2) X.Mt |= TR_IQ;
+						if (dg1 == dg3) X.Mt |= TR_IT;
+					} else {
+						X.M = dg3;
+						X.Mt = TR_IT;
+					}
+				} else {
+					if (dg2 >= dg3) {
+						X.M = dg2;
+						X.Mt = TR_IQ;
+						if (dg2 == dg3) X.Mt |= TR_IT;
+					} else {
+						X.M = dg3;
+						X.Mt = TR_IT;
+					}
+				}
+				curp = bbp(tb, GAP);
+				int ins = std::max(0, Cc.M) - g(bbp(pt, qb), curp);
+				int ext = std::max(0, Cc.Iq) - g(bbp(pt, GAP), curp);
+				if (ins >= ext) {
+					X.Iq = ins;
+					X.Iqt = TR_M;
+					if (ins == ext) X.Iqt |= TR_IQ;
+				} else {
+					X.Iq = ext;
+					X.Iqt = TR_IQ;
+				}
+				curp = bbp(GAP, qb);
+				ins = std::max(0, Bc.M) - g(bbp(tb, pq), curp);
+				ext = std::max(0, Bc.It) - g(bbp(GAP, pq), curp);
+				if (ins >= ext) {
+					X.It = ins;
+					X.Itt = TR_M;
+					if (ins == ext) X.Itt |= TR_IT;
+				} else {
+					X.It = ext;
+					X.Itt = TR_IT;
+				}
+				if (X.M >= max_score) {
+					if (X.M > max_score) {
+						max_score = X.M;
+						max_cells.clear();
+					}
+					max_cells.push_back(i * stride + j + 1);
+				}
+			}
+		}
+	}
+
+	// find_loop_index, nuc_cruc.cpp:2619-2869: exact match of the 5 (tri-loop) or 6 (tetra-loop) bases starting
+	// at the 5' closing base against the special-loop list; bases print through "ACGTE" (inosine never matches)
+	int find_loop_index(int start, int len) const
+	{
+		char key[8] = {0};
+		for (int k = 0; k < len; k++) {
+			const int b = query[start + k];
+			key[k] = b <= 4 ? "ACGTE"[b] : '?';
+		}
+		for (int i = 0; i < TOR_HAIRPIN_SPECIAL_COUNT; i++)
+			if (!strcmp(TOR_HAIRPIN_SPECIAL[i].seq, key)) return i;
+		return -1;
+	}
+
+	// evaluate_hairpin_alignment, nuc_cruc.cpp:2301-2394
+	bool evaluate_hairpin(Alignment &al) const
+	{
+		const Params &P = params();
+		const int last_3 = al.fm_q, last_5 = al.fm_t;
+		const unsigned loop_len = unsigned(last_3 - last_5 - 1);
+		al.dH = 0.0f;
+		al.dS = 0.0f;
+		al.dS += P.hairpin_S[loop_len];
+		const int last_pair = bbp(query[last_5], query[last_3]);
+		if (loop_len == 3) {
+			const int li = find_loop_index(last_5, 5);
+			if (li >= 0) {
+				al.dH += f32(TOR_HAIRPIN_SPECIAL[li].h);
+				al.dS += f32(TOR_HAIRPIN_SPECIAL[li].s);
+			}
+			if (last_pair == P_AT || last_pair == P_TA) al.dS += P.bulge_at_S;
+		} else {
+			if (loop_len == 4) {
+				const int li = find_loop_index(last_5, 6);
+				if (li >= 0) {
+					al.dH += f32(TOR_HAIRPIN_SPECIAL[li].h);
+					al.dS += f32(TOR_HAIRPIN_SPECIAL[li].s);
+				}
+			}
+			const int curp = bbp(query[last_5 + 1], query[last_3 - 1]);
+			al.dH += P.H[last_pair * NBP + curp]; // param_hairpin_terminal == param (nuc_cruc_santa_lucia.cpp:594-603)
+			al.dS += P.S[last_pair * NBP + curp];
+		}
+		return evaluate(al, HAIRPIN);
+	}
+
+	// enumerate_hairpin_alignments, nuc_cruc.cpp:1172-1407
+	void enumerate_hairpin(int cell)
+	{
+		const Params &P = params();
+		const int ql = int(query.size());
+		bool first_time = true;
+		std::deque<Branch> stack;
+		int zero_count = -1;
+		unsigned trace_count = 0;
+		float best_dg = cur.dH - Tk * cur.dS;
+		auto consider = [&](Alignment &al) {
+			if (evaluate_hairpin(al)) {
+				const float local_dg = al.dH - Tk * al.dS;
+				if (!cur.valid || local_dg < best_dg) {
+					cur = al;
+					cur.valid = true;
+					best_dg = local_dg;
+				}
+			}
+		};
+		while (true) {
+			if (!first_time && stack.empty() && zero_count <= 0) break;
+			if (16 < trace_count) break;
+			trace_count++;
+			first_time = false;
+			Alignment al;
+			trace_back(cell, stack, zero_count, al);
+			while (!al.q.empty() && !P.wc[bbp(al.q.back(), al.t.back())]) {
+				if (!is_virtual(al.q.back())) --al.lm_q;
+				if (!is_virtual(al.t.back())) ++al.lm_t;
+				al.q.pop_back();
+				al.t.pop_back();
+			}
+			while (!al.q.empty() && !P.wc[bbp(al.q.front(), al.t.front())]) {
+				if (!is_virtual(al.q.front())) ++al.fm_q;
+				if (!is_virtual(al.t.front())) --al.fm_t;
+				al.q.pop_front();
+				al.t.pop_front();
+			}
+			if (zero_count == 0 && !stack.empty()) {
+				while (!stack.empty() && !stack.back().next()) stack.pop_back();
+				zero_count = -1;
+			}
+			if (al.q.size() >= 3) consider(al); // :1265
+			// dangling end at the open end of the stem, always attached (:1307-1324)
+			if (al.lm_t != 0 || al.lm_q != ql - 1) {
+				if (al.lm_t == 0) al.t.push_back(E);
+				else al.t.push_back(query[--al.lm_t]);
+				if (al.lm_q == ql - 1) al.q.push_back(E);
+				else al.q.push_back(query[++al.lm_q]);
+			}
+			const size_t align_size = al.q.size();
+			if (align_size < 3) continue;
+			consider(al); // :1333
+			if (align_size <= 3) continue;
+			// try without an A-T closing pair (:1356-1405)
+			const int lp = bbp(query[al.fm_t], query[al.fm_q]);
+			if (lp == P_GC || lp == P_CG) continue;
+			al.fm_q++;
+			al.fm_t--;
+			al.q.pop_front();
+			al.t.pop_front();
+			consider(al);
 		}
 	}
 
@@ -585,14 +793,16 @@ private:
 		return p == P_AT || p == P_TA;
 	}
 
-	// nuc_cruc.cpp:1620-2299, HETERO_DIMER
-	bool evaluate(Alignment &al) const
+	// nuc_cruc.cpp:1620-2299
+	bool evaluate(Alignment &al, Mode mode) const
 	{
 		const Params &P = params();
 		const float *Hh = P.H, *Ss = P.S;
 		int terminal = P__, lastlast = P__, last = P__, curp = P__;
-		al.dH = P.init_H;
-		al.dS = P.init_S + 0.0f;
+		if (mode != HAIRPIN) { // :1627-1633
+			al.dH = P.init_H;
+			al.dS = P.init_S + (mode == HOMO_DIMER ? P.sym_S : 0.0f);
+		}
 		unsigned nqg = 0, ntg = 0, nmm = 0, num_base = 0;
 		bool terminal_5 = false;
 		const int n = int(al.q.size());
@@ -739,7 +949,8 @@ private:
 		}
 		if (al.dH >= 0.0f) return false; // :2253
 		al.dS += P.salt * (0.5f * num_base - 1) * log_na; // :2270
-		const float tm = al.dH / (1.9872e-3f * logf(ct * 1.0f) + al.dS) - 273.15f; // :2291
+		const float tm = (mode == HAIRPIN) ? al.dH / al.dS - 273.15f // :2286-2289, no strand concentration
+		                                   : al.dH / (1.9872e-3f * logf(ct * 1.0f) + al.dS) - 273.15f; // :2291
 		al.tm = std::max(0.0f, tm);
 		return true;
 	}
@@ -1389,6 +1600,38 @@ int tntor_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assay
 	*out = (tnt_hit *)malloc(sizeof(tnt_hit) * std::max<size_t>(1, all.size()));
 	memcpy(*out, all.data(), sizeof(tnt_hit) * all.size());
 	return rc;
+}
+
+// a17: hairpin / homodimer Tm of one oligo and the heterodimer Tm of two (tntblast_local.cpp:656-686)
+int tntor_oligo_structure(const tnt_options *opt, const char *oligo, float ct, float *hairpin_tm, float *homodimer_tm)
+{
+	try {
+		Melt m(opt->target_t, opt->salt, opt->allow_dangle_5 != 0, opt->allow_dangle_3 != 0);
+		m.set_query(oligo);
+		m.ct = ct - 0.5f * ct; // strand(c, c), nuc_cruc.h:890-910
+		*hairpin_tm = m.approximate_tm_hairpin();
+		*homodimer_tm = m.approximate_tm_homodimer();
+		return 0;
+	} catch (const char *e) {
+		g_err = e;
+		return -1;
+	}
+}
+
+int tntor_heterodimer(const tnt_options *opt, const char *a, const char *b, float ct_a, float ct_b, float *tm)
+{
+	try {
+		Melt m(opt->target_t, opt->salt, opt->allow_dangle_5 != 0, opt->allow_dangle_3 != 0);
+		m.set_query(a);
+		m.target.clear();
+		for (const char *p = b; *p; p++) m.target.push_back(char_to_base(*p)); // set_target, nuc_cruc.h:977-990
+		m.ct = (ct_a > ct_b) ? ct_a - 0.5f * ct_b : ct_b - 0.5f * ct_a;
+		*tm = m.approximate_tm_heterodimer();
+		return 0;
+	} catch (const char *e) {
+		g_err = e;
+		return -1;
+	}
 }
 
 void tntor_free(void *p) { free(p); }

@@ -7,6 +7,8 @@ from the sources under /root/reference by oracle/Makefile).  Only runs in the bu
                       inosine in the oligo, every IUPAC target code, windows truncated at sequence ends,
                       low-complexity repeats (multiple maximal cells / path splits), random seeds.
                       tm/dH/dS/dG as float32 bit patterns, anchors, counts, ranges, alignment text.
+  g3_structure.json.gz  G3: hairpin / homodimer / heterodimer Tm of assay oligos (tntblast_local.cpp:656-686): random
+                      oligos, designed stem-loops (incl. the special tri/tetra-loops), palindromes, repeats.
   g4_seeds.json.gz    G4: seed lists, both strands, incl. N-runs / IUPAC targets (pins SURVEY Q1/Q2).
   g5_search_cfgN.json.gz  G5: end-to-end hit sets of miniature copies of BASELINE configs 1-5 and of the
                       README amplicon case (README.md:130-203).
@@ -31,8 +33,8 @@ GOLD = os.path.join(HERE, "golden")
 
 
 def dump(name, obj):
-    with gzip.open(os.path.join(GOLD, name), "wt") as f:
-        json.dump(obj, f, separators=(",", ":"))
+    with open(os.path.join(GOLD, name), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:  # byte-stable
+        f.write(json.dumps(obj, separators=(",", ":")).encode())
     print(name, os.path.getsize(os.path.join(GOLD, name)), "bytes")
 
 
@@ -103,9 +105,35 @@ def bind_cases(rng):
     return oligos, targets, reqs
 
 
+def structure_oligos(rng):
+    """Oligos for G3: random, README, palindromes / repeats, designed hairpins with 3..7-nt loops."""
+    oligos = [synth._rand_oligo(rng, 15, 40) for _ in range(150)]
+    oligos += ["GGAGGATCCAACAGCAAGG", "TTCCCCTTTGGAGGCATC", "CGATGGGCTTTCAGGACAGGTGT", "GCGCGCGCGCGCGCGC", "ATATATATATATATAT",
+               "AAAAAAAATTTTTTTT", "GGGGGAAAACCCCC", "ACGTIACGTTGCAIGGATCCA", "GCGAAGC", "GCGAAAGC", "ACGT", "ACGTA",
+               "CGCGAATTCGCG", "GGGCGAAGCCC", "GGGCGAAAGCCC", "CCCTTTTGGG"]
+    for _ in range(100):
+        stem = synth._rand_oligo(rng, 4, 9)
+        loop = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(3, 8))))
+        head = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 6))))
+        tail = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 5))))
+        oligos.append(head + stem + loop + synth.revcomp(stem) + tail)
+    return oligos
+
+
 def main():
     ref = tc.RefImpl()
     rng = np.random.default_rng(20260227)
+
+    # ---- G3
+    so = structure_oligos(np.random.default_rng(3))
+    cases = []
+    for name, opt in (("default", abi.options_default()), ("dangle", abi.options_default(allow_dangle_5=1, allow_dangle_3=1)),
+                      ("salt", abi.options_default(salt=0.2, target_t=320.0))):
+        exp = [list(ref.structure(opt, o, so[(i * 7 + 3) % len(so)], 9e-7, 4e-7)) for i, o in enumerate(so)]
+        cases.append({"name": name, "options": opt_dict(opt), "expected": exp})
+    dump("g3_structure.json.gz", {"oligos": so, "partner": "oligos[(i * 7 + 3) % n]", "ct_a": 9e-7, "ct_b": 4e-7,
+                                  "fields": ["hairpin_tm", "homodimer_tm", "heterodimer_tm"], "cases": cases})
+    print("G3: %d oligos, %d non-zero Tm at defaults" % (len(so), sum(1 for r in cases[0]["expected"] for v in r if v)))
 
     # ---- G2
     oligos, targets, rows = bind_cases(rng)

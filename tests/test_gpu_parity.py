@@ -60,6 +60,36 @@ def test_g2_binds_golden(Engine):
         e.close()
 
 
+def test_g3_structure_golden(Engine):
+    """Row a17: hairpin / homodimer / heterodimer Tm of oligos through the unit-level bind kernel instance."""
+    g = gu.load("g3_structure.json.gz")
+    so = g["oligos"]
+    for case in g["cases"]:
+        e = Engine(gu.options_from(case["options"]), [synth.ExpandedAssay(0, 0, None, None, "ACGTACGTACGTACGTAC")])
+        for i, o in enumerate(so):
+            got = e.oligo_structure(o, so[(i * 7 + 3) % len(so)], g["ct_a"], g["ct_b"])
+            assert [tc.f32_bits(v) for v in got] == case["expected"][i], (case["name"], o)
+        h, d, x = e.oligo_structure(so[0])
+        assert x is None and [tc.f32_bits(h), tc.f32_bits(d)] == case["expected"][0][:2]
+        e.close()
+
+
+def test_structure_vs_oracle(Engine, oracle):
+    rng = np.random.default_rng(5)
+    oligos = [synth._rand_oligo(rng, 8, 64) for _ in range(200)] + ["A" * 64, "AT" * 32, "GC" * 32, "G" * 20 + "TTTT" + "C" * 20]
+    opt = abi.options_default(allow_dangle_3=1, salt=0.1)
+    e = Engine(opt, [synth.ExpandedAssay(0, 0, None, None, "ACGTACGTACGTACGTAC")])
+    for i, o in enumerate(oligos):
+        p = oligos[(i * 13 + 1) % len(oligos)]
+        got = e.oligo_structure(o, p, 5e-7, 9e-7)
+        assert tuple(tc.f32_bits(v) for v in got) == oracle.structure(opt, o, p, 5e-7, 9e-7), (o, p)
+    with pytest.raises(Exception):
+        e.oligo_structure("A" * 65)
+    with pytest.raises(Exception):
+        e.oligo_structure("ACGTNACGT")
+    e.close()
+
+
 def test_g4_seeds_golden(Engine):
     fx = gu.load("g4_seeds.json.gz")
     codes, offsets = gu.pack_targets(fx["targets"])

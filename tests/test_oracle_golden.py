@@ -37,6 +37,16 @@ def test_g2_binds(oracle):
         assert not bad, "%s: %d of %d differ, first %r" % (case["name"], len(bad), len(case["expected"]), bad[:2])
 
 
+def test_g3_structure(oracle):
+    g = gu.load("g3_structure.json.gz")
+    so = g["oligos"]
+    for case in g["cases"]:
+        opt = gu.options_from(case["options"])
+        for i, o in enumerate(so):
+            got = oracle.structure(opt, o, so[(i * 7 + 3) % len(so)], g["ct_a"], g["ct_b"])
+            assert list(got) == case["expected"][i], (case["name"], o)
+
+
 def test_g4_seeds(oracle):
     fx = gu.load("g4_seeds.json.gz")
     codes, offsets = gu.pack_targets(fx["targets"])

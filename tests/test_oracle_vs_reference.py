@@ -53,6 +53,25 @@ def test_search(ref, oracle, cfg, nt, na, seed, kw):
     assert len(a) > 0
 
 
+@pytest.mark.parametrize("kw", [{}, {"allow_dangle_5": 1, "allow_dangle_3": 1}, {"salt": 1.0, "target_t": 300.0}])
+def test_oligo_structure(ref, oracle, kw):
+    """hairpin / homodimer / heterodimer Tm of oligos (tntblast_local.cpp:656-686) on fresh random + designed oligos."""
+    rng = np.random.default_rng(77)
+    oligos = [synth._rand_oligo(rng, 12, 45) for _ in range(120)]
+    for _ in range(120):
+        stem = synth._rand_oligo(rng, 3, 10)
+        loop = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(3, 9))))
+        oligos.append(synth._rand_oligo(rng, 1, 5)[:int(rng.integers(0, 5))] + stem + loop + synth.revcomp(stem) + synth._rand_oligo(rng, 1, 4)[:int(rng.integers(0, 4))])
+    opt = abi.options_default(**kw)
+    nz = 0
+    for i, o in enumerate(oligos):
+        p = oligos[(i * 11 + 5) % len(oligos)]
+        a = ref.structure(opt, o, p, 9e-7, 2e-7)
+        assert a == oracle.structure(opt, o, p, 9e-7, 2e-7), (o, p)
+        nz += sum(1 for v in a if v)
+    assert nz > 200
+
+
 def test_expand_matches_reference(checkers):
     import ctypes as C
     if not checkers.have_ref():

@@ -205,6 +205,19 @@ class _CpuImpl:
         return hits
 
 
+    def structure(self, opt, a, b=None, ct_a=9.0e-7, ct_b=9.0e-7):
+        """(hairpin, homodimer, heterodimer) Tm of tntblast_local.cpp:656-686 as float32 bit patterns."""
+        h, d, x = C.c_float(), C.c_float(), C.c_float()
+        f = getattr(self.lib, self.prefix + "oligo_structure")
+        rc = f(C.byref(opt), a.encode(), C.c_float(ct_a), C.byref(h), C.byref(d))
+        assert rc == 0, self.error()
+        if b:
+            g = getattr(self.lib, self.prefix + "heterodimer")
+            rc = g(C.byref(opt), a.encode(), b.encode(), C.c_float(ct_a), C.c_float(ct_b), C.byref(x))
+            assert rc == 0, self.error()
+        return f32_bits(h.value), f32_bits(d.value), (f32_bits(x.value) if b else None)
+
+
 class RefImpl(_CpuImpl):
     prefix = "tntref_"
     path = REF_SO

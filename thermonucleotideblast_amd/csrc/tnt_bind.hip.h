@@ -104,8 +104,24 @@ struct Score {
 	bool ok;
 };
 
-// evaluate_alignment (HETERO_DIMER), nuc_cruc.cpp:1620-2299.  Columns k0..k1-1 of c.cols.
-__device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1)
+// tw = 2 * tw + (x == y): v_cmp_eq + v_addc_co
+__device__ __forceinline__ uint32_t push_eq(uint32_t tw, int x, int y)
+{
+	asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(tw) : "v"(x), "v"(y) : "vcc");
+	return tw;
+}
+
+struct AlignInfo {
+	int k0, k1;               // column range inside the scratch buffer
+	int fm_q, fm_t, lm_q, lm_t;
+};
+
+// NucCruc::mode, nuc_cruc.h:494
+enum : int { MODE_HOMO_DIMER = 0, MODE_HETERO_DIMER = 1, MODE_HAIRPIN = 2 };
+
+// evaluate_alignment, nuc_cruc.cpp:1620-2299.  Columns k0..k1-1 of c.cols.  In HAIRPIN mode the sums start
+// from the loop terms computed by the caller (evaluate_hairpin_alignment, :2301-2394).
+__device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode = MODE_HETERO_DIMER, float dH0 = 0.0f, float dS0 = 0.0f)
 {
 	const Tables &T = *c.tab;
 	const float *Hh = T.H, *Ss = T.S;
@@ -113,8 +129,11 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1)
 #define COLQ(k) col_q(c.cols[(k) * BIND_THREADS])
 #define COLT(k) col_t(c.cols[(k) * BIND_THREADS])
 	int terminal = P__, lastlast = P__, last = P__, curp = P__;
-	float dH = T.init_H;
-	float dS = T.init_S + 0.0f;
+	float dH = dH0, dS = dS0;
+	if (mode != MODE_HAIRPIN) { // :1627-1633
+		dH = T.init_H;
+		dS = T.init_S + (mode == MODE_HOMO_DIMER ? T.sym_S : 0.0f);
+	}
 	unsigned nqg = 0, ntg = 0, nmm = 0, num_base = 0;
 	bool terminal_5 = false;
 	const int n = k1 - k0;
@@ -280,24 +299,54 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1)
 	s.ok = false;
 	if (dH >= 0.0f) return s; // :2253
 	dS += T.salt * (0.5f * float(num_base) - 1.0f) * T.log_na; // :2270
-	const float tm = dH / (1.9872e-3f * c.log_ct + dS) - 273.15f; // :2291
+	const float tm = (mode == MODE_HAIRPIN) ? dH / dS - 273.15f // :2286-2289
+	                                        : dH / (1.9872e-3f * c.log_ct + dS) - 273.15f; // :2291
 	s.dS = dS;
 	s.tm = tm > 0.0f ? tm : 0.0f;
 	s.ok = true;
 	return s;
 }
 
-// tw = 2 * tw + (x == y): v_cmp_eq + v_addc_co
-__device__ __forceinline__ uint32_t push_eq(uint32_t tw, int x, int y)
+// evaluate_hairpin_alignment, nuc_cruc.cpp:2301-2394: loop entropy, special tri/tetra-loop bonus
+// (find_loop_index, :2619-2869 = exact match of the 5 / 6 bases starting at the 5' closing base),
+// closing-AT penalty or terminal mismatch, then the stem through evaluate_alignment(HAIRPIN).
+__device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const AlignInfo &al, const uint8_t *gquery, const uint8_t *lds_query,
+                                  int L)
 {
-	asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(tw) : "v"(x), "v"(y) : "vcc");
-	return tw;
+	const Tables &T = *tab;
+#define HQ(K) (gquery ? int(gquery[(K)]) : int(lds_query[(L - 1 - (K)) * BIND_THREADS]))
+	const int last_3 = al.fm_q, last_5 = al.fm_t;
+	const unsigned loop_len = unsigned(last_3 - last_5 - 1);
+	float dH = 0.0f, dS = 0.0f;
+	dS += T.hairpin_S[loop_len < 513u ? loop_len : 512u];
+	const int last_pair = lut_pair(c.lut, HQ(last_5), HQ(last_3));
+	if (loop_len == 3 || loop_len == 4) {
+		const int n = int(loop_len) + 2;
+		uint32_t key = uint32_t(n) << 24; // 3 bits per base, A C G T; anything else cannot match
+		bool plain = true;
+		for (int k = 0; k < n; k++) {
+			const int b = HQ(last_5 + k);
+			plain &= b <= bT;
+			key |= uint32_t(b & 7) << (3 * k);
+		}
+		if (plain)
+			for (int i = 0; i < T.n_special; i++)
+				if (T.special_key[i] == key) {
+					dH += T.special_H[i];
+					dS += T.special_S[i];
+					break;
+				}
+	}
+	if (loop_len == 3) {
+		if (last_pair == P_AT || last_pair == P_TA) dS += T.bulge_at_S;
+	} else {
+		const int curp = lut_pair(c.lut, HQ(last_5 + 1), HQ(last_3 - 1));
+		dH += T.H[last_pair * NBP + curp]; // param_hairpin_terminal == param (nuc_cruc_santa_lucia.cpp:594-603)
+		dS += T.S[last_pair * NBP + curp];
+	}
+#undef HQ
+	return evaluate_alignment(c, al.k0, al.k1, MODE_HAIRPIN, dH, dS);
 }
-
-struct AlignInfo {
-	int k0, k1;               // column range inside the scratch buffer
-	int fm_q, fm_t, lm_q, lm_t;
-};
 
 // The bind kernel proper.  LMAX = rows kept in registers (oligos of this launch have L <= LMAX).
 template <int LMAX, bool FULL>
@@ -353,16 +402,24 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 		const int L = active ? a.olig_len[slot.oligo] : 0;
 		const bool minus = (it.info & ITEM_MINUS) != 0;
 		const int qloc = int(it.info & 127u);
-		const uint32_t tlen = a.db.len[it.target];
+		const uint32_t tlen = (FULL && (!active || (it.target >> 29))) ? 0u : a.db.len[it.target]; // no target set behind self-structure requests
 		// bind_oligo.cpp:502-505
 		int start = int(it.tloc) - (qloc + FLANK);
 		if (start < 0) start = 0;
 		int stop = start + L + 2 * FLANK;
 		if (stop > int(tlen)) stop = int(tlen);
 		int W = 0;
+		// self-structure requests (FULL instance only): bits 29-30 of `target` select the mode, the target is an oligo
+		const int xmode = FULL ? int((it.target >> 29) & 3u) : 0; // 0 window of a packed target, 1 heterodimer, 2 homodimer, 3 hairpin
+		if (FULL && active && xmode) {
+			const int xo = (xmode == 1) ? int(it.target & 0xFFFFFFu) : slot.oligo; // the oligo that plays the target
+			W = a.olig_len[xo];
+			start = 0, stop = W;
+			for (int k = 0; k < W; k++) win[k * BIND_THREADS] = a.olig_base[size_t(xo) * MAX_OLIGO + k]; // set_target / set_duplex
+		}
 
 		// ------------------------------------------------------------------ window load (Q6: codes > 15 are skipped)
-		if (active) {
+		if (active && !(FULL && xmode)) {
 			const uint32_t *pk = a.db.packed + a.db.word_off[it.target];
 			const uint32_t e0 = a.db.exc_off[it.target], e1 = a.db.exc_off[it.target + 1];
 			uint32_t e = e0;
@@ -441,7 +498,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 			const uint32_t rtw = s_rt[t];
 			const int v5 = firstcol ? c_zero : c_bulge;          // g(bp(pt,GAP), bp(t,GAP))
 			int aM = -1, aQ = 0, aT = 0, bM = -1, bT = 0; // border cells hold -1 (nuc_cruc.h:531-536); gap states are kept clamped
-			const int Lcol = colok ? L : 0;   // rows that count in this column
+			int Lcol = colok ? L : 0;         // rows that count in this column
+			if (FULL && xmode == 3) Lcol = (L - 3 - j) > 0 ? (L - 3 - j) : 0; // align_hairpin's triangle, nuc_cruc.cpp:794-810
 			int colmax = INT32_MIN;
 			int term_up = 0;                                     // term(cur) of the row above
 			// keep the per-row constants from being hoisted out of the column loop (register pressure)
@@ -725,6 +783,48 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 					}
 					zero_count = -1;
 				}
+#define CONSIDER(SCORE)                                                                              \
+	do {                                                                                             \
+		const Score s_ = (SCORE);                                                                    \
+		if (s_.ok) {                                                                                 \
+			const float local_dg = s_.dH - T.temperature * s_.dS;                                    \
+			if (!best_valid || local_dg < best_dg) { /* :1160-1167 */                                \
+				best_valid = true;                                                                   \
+				best_dg = local_dg;                                                                  \
+				best_dH = s_.dH, best_dS = s_.dS, best_tm = s_.tm;                                   \
+				bi = al;                                                                             \
+				for (int k = al.k0; k < al.k1; k++) best[k * BIND_THREADS] = cols[k * BIND_THREADS]; \
+			}                                                                                        \
+		}                                                                                            \
+	} while (0)
+
+				if (FULL && xmode == 3) {
+					// ---------------- enumerate_hairpin_alignments, nuc_cruc.cpp:1264-1405
+					if (al.k1 - al.k0 >= 3) CONSIDER(evaluate_hairpin(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+					// the open end of the stem always gets its dangling / frayed bases (:1307-1324)
+					if (al.lm_t != 0 || al.lm_q != L - 1) {
+						int qb, tb;
+						if (al.lm_t == 0) tb = bE;
+						else tb = QUERY(--al.lm_t);
+						if (al.lm_q == L - 1) qb = bE;
+						else qb = QUERY(++al.lm_q);
+						cols[al.k1 * BIND_THREADS] = mk_col(qb, tb);
+						al.k1++;
+					}
+					const int align_size = al.k1 - al.k0;
+					if (align_size < 3) continue;
+					CONSIDER(evaluate_hairpin(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+					if (align_size <= 3) continue;
+					// an A-T closing pair carries a penalty: try without it (:1356-1405)
+					const int lp = lut_pair(s_lut, QUERY(al.fm_t), QUERY(al.fm_q));
+					if (lp == P_GC || lp == P_CG) continue;
+					al.fm_q++;
+					al.fm_t--;
+					al.k0++;
+					CONSIDER(evaluate_hairpin(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+					continue;
+				}
+
 				// dangling ends, :1088-1137 (off by default, tntblast.h:55-56)
 				if (T.dangle5 && (al.fm_q != 0 || al.fm_t != W - 1)) {
 					int qb, tb;
@@ -747,19 +847,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				}
 				if (al.k1 - al.k0 < 3) continue; // :1148
 
-				const Score s = evaluate_alignment(c, al.k0, al.k1);
-				if (s.ok) {
-					const float local_dg = s.dH - T.temperature * s.dS;
-					if (!best_valid || local_dg < best_dg) { // :1160-1167
-						best_valid = true;
-						best_dg = local_dg;
-						best_dH = s.dH;
-						best_dS = s.dS;
-						best_tm = s.tm;
-						bi = al;
-						for (int k = al.k0; k < al.k1; k++) best[k * BIND_THREADS] = cols[k * BIND_THREADS];
-					}
-				}
+				CONSIDER(evaluate_alignment(c, al.k0, al.k1, (FULL && xmode == 2) ? MODE_HOMO_DIMER : MODE_HETERO_DIMER));
+#undef CONSIDER
 			}
 		}
 

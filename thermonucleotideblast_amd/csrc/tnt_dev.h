@@ -41,6 +41,11 @@ struct Tables {
 	float S[NBP * NBP];
 	float loop_S[513];
 	float bulge_S[513];
+	float hairpin_S[513];
+	uint32_t special_key[136]; // special hairpin loops: length << 24 | 3 bits per base (A C G T), 5' closing base first
+	float special_H[136], special_S[136];
+	int32_t n_special;
+	float sym_S;            // param_symmetry_S (homodimers)
 	uint8_t bbp[18 * 18];   // best_base_pair LUT, nuc_cruc.cpp:14-213 (row = first argument)
 	uint8_t pad0[4];
 	uint32_t rt[18];        // rt[x] nibble q = resolve_degenerate(x | q) for partner q in A,C,G,T,I,E,GAP

@@ -56,6 +56,18 @@ inline float f32(unsigned int bits)
 // ---------------------------------------------------------------------------------------------
 // host-side tables
 
+int char_to_base(char c) // expanded oligos only: A C G T I (degenerate_na.cpp:81-133 expands the rest)
+{
+	switch (c) {
+	case 'A': case 'a': return bA;
+	case 'C': case 'c': return bC;
+	case 'G': case 'g': return bG;
+	case 'T': case 't': return bT;
+	case 'I': case 'i': return bI;
+	default: return -1;
+	}
+}
+
 int resolve(int x, int partner) // resolve_degenerate, nuc_cruc.cpp:14-201 (B falls through into N, :163-197)
 {
 	switch (x) {
@@ -86,7 +98,18 @@ bool fill_tables(Tables &T, const tnt_options &opt)
 	for (int i = 0; i < 513; i++) {
 		T.loop_S[i] = f32(TNT_SL_LOOP_S[i]);
 		T.bulge_S[i] = f32(TNT_SL_BULGE_S[i]);
+		T.hairpin_S[i] = f32(TNT_SL_HAIRPIN_S[i]);
 	}
+	T.n_special = TNT_SL_HAIRPIN_SPECIAL_COUNT;
+	for (int i = 0; i < TNT_SL_HAIRPIN_SPECIAL_COUNT && i < 136; i++) {
+		const char *q = TNT_SL_HAIRPIN_SPECIAL[i].seq;
+		uint32_t key = uint32_t(strlen(q)) << 24;
+		for (int k = 0; q[k]; k++) key |= uint32_t(char_to_base(q[k])) << (3 * k);
+		T.special_key[i] = key;
+		T.special_H[i] = f32(TNT_SL_HAIRPIN_SPECIAL[i].h);
+		T.special_S[i] = f32(TNT_SL_HAIRPIN_SPECIAL[i].s);
+	}
+	T.sym_S = f32(TNT_SL_SYMMETRY_S);
 	T.init_H = f32(TNT_SL_INIT_H);
 	T.init_S = f32(TNT_SL_INIT_S);
 	T.at_H = f32(TNT_SL_AT_CLOSING_H);
@@ -167,18 +190,6 @@ bool fill_tables(Tables &T, const tnt_options &opt)
 		}
 	for (int x = bA; x <= bI; x++) T.term[bGAP * NB + x] = T.dg_const[3]; // first column: prev = bp(GAP, q)
 	return ok;
-}
-
-int char_to_base(char c) // expanded oligos only: A C G T I (degenerate_na.cpp:81-133 expands the rest)
-{
-	switch (c) {
-	case 'A': case 'a': return bA;
-	case 'C': case 'c': return bC;
-	case 'G': case 'g': return bG;
-	case 'T': case 't': return bT;
-	case 'I': case 'i': return bI;
-	default: return -1;
-	}
 }
 
 // build_word_list<std::string>, seq_hash.h:287-374, in the packed stream's little-endian word convention
@@ -1164,6 +1175,79 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 		memcpy(o.align, f.text, TNT_ALIGN_TEXT);
 		o.align[TNT_ALIGN_TEXT - 1] = 0;
 	}
+	return TNT_OK;
+}
+
+int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a, float ct_b, float *hairpin_a, float *homodimer_a,
+                        float *heterodimer_ab)
+{
+	if (!ctx || !oa || !hairpin_a || !homodimer_a || (ob && !heterodimer_ab) || !(ct_a > 0.0f) || (ob && !(ct_b > 0.0f))) return TNT_E_ARG;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx, 64);
+	if (rc) return rc;
+	const char *seqs[2] = {oa, ob};
+	const int n_ol = ob ? 2 : 1;
+	std::vector<uint8_t> base(2 * MAX_OLIGO, 0);
+	std::vector<uint32_t> q4(2 * (MAX_OLIGO / 4), 0);
+	std::vector<int32_t> len(2, 0);
+	for (int o = 0; o < n_ol; o++) {
+		const size_t L = strlen(seqs[o]);
+		if (L == 0 || L > size_t(TNT_MAX_OLIGO)) {
+			ctx->err = "oligo length must be 1..64";
+			return TNT_E_LIMIT;
+		}
+		len[o] = int(L);
+		for (size_t k = 0; k < L; k++) {
+			const int b = char_to_base(seqs[o][k]);
+			if (b < 0) {
+				ctx->err = "oligos must be expanded to A/C/G/T/I";
+				return TNT_E_ARG;
+			}
+			base[o * MAX_OLIGO + k] = uint8_t(b);
+			const uint32_t r = uint32_t(char_to_base(seqs[o][L - 1 - k]));
+			q4[o * (MAX_OLIGO / 4) + (k >> 2)] |= (r * 4u) << ((k & 3) * 8);
+		}
+	}
+	// strand(c_a, c_b) = excess - limit / 2 (nuc_cruc.h:890-910)
+	const float ct_self = ct_a - 0.5f * ct_a;
+	const float ct_pair = ob ? ((ct_a > ct_b) ? ct_a - 0.5f * ct_b : ct_b - 0.5f * ct_a) : ct_self;
+	std::vector<Slot> slots(2);
+	slots[0] = Slot{0, logf(ct_self * 1.0f), 0, -1};
+	slots[1] = Slot{0, logf(ct_pair * 1.0f), 0, -1};
+	std::vector<Item> items;
+	items.push_back(Item{3u << 29, 0, 0u << ITEM_SLOT_SHIFT, 0});                  // hairpin of a
+	items.push_back(Item{2u << 29, 0, 0u << ITEM_SLOT_SHIFT, 0});                  // homodimer of a
+	if (ob) items.push_back(Item{(1u << 29) | 1u, 0, 1u << ITEM_SLOT_SHIFT, 0});   // query a, target b
+	DevBuf<uint8_t> dbase;
+	DevBuf<uint32_t> dq4;
+	DevBuf<int32_t> dlen;
+	DevBuf<Slot> dslots;
+	DevBuf<BindFull> dfull;
+	HIP_TRY(dbase.upload(base), ctx->err);
+	HIP_TRY(dq4.upload(q4), ctx->err);
+	HIP_TRY(dlen.upload(len), ctx->err);
+	HIP_TRY(dslots.upload(slots), ctx->err);
+	HIP_TRY(dfull.alloc(items.size()), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+	DbView v;
+	memset(&v, 0, sizeof(v));
+	BindArgs b = bind_args(ctx, v);
+	b.olig_base = dbase.p;
+	b.olig_q4 = dq4.p;
+	b.olig_len = dlen.p;
+	b.slots = dslots.p;
+	b.groups = nullptr;
+	b.n_items = uint32_t(items.size());
+	b.full = dfull.p;
+	launch_bind(ctx, b, 1, true);
+	HIP_TRY(hipGetLastError(), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	std::vector<BindFull> full(items.size());
+	HIP_TRY(hipMemcpy(full.data(), dfull.p, full.size() * sizeof(BindFull), hipMemcpyDeviceToHost), ctx->err);
+	*hairpin_a = full[0].tm;
+	*homodimer_a = full[1].tm;
+	if (ob) *heterodimer_ab = full[2].tm;
 	return TNT_OK;
 }
 

@@ -67,6 +67,7 @@ def load_library():
     lib.tnt_seeds.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_seed)), P(C.c_size_t)]
     lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
     lib.tnt_hit_sequence.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_hit), C.c_char_p, C.c_size_t]
+    lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
     if lib.tnt_abi_version() != 1:
         raise TntError("ABI version mismatch")
     _lib = lib
@@ -78,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect",
-    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_hit_sequence",
+    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_hit_sequence", "tnt_oligo_structure",
 ]
 
 
@@ -200,6 +201,13 @@ class Engine:
         out = (abi.tnt_bind * len(reqs))()
         self._check(self.lib.tnt_bind_batch(self._h, batch._h, reqs, len(reqs), out))
         return out
+
+    def oligo_structure(self, a, b=None, ct_a=9.0e-7, ct_b=9.0e-7):
+        """(hairpin Tm, homodimer Tm, heterodimer Tm or None) as printed with every hit (tntblast_local.cpp:656-686)."""
+        h, d, x = C.c_float(), C.c_float(), C.c_float()
+        self._check(self.lib.tnt_oligo_structure(self._h, a.encode(), b.encode() if b else None, ct_a, ct_b,
+                                                 C.byref(h), C.byref(d), C.byref(x)))
+        return h.value, d.value, (x.value if b else None)
 
     def hit_sequence(self, batch, hit):
         buf = C.create_string_buffer(1 << 16)
