@@ -35,10 +35,8 @@ struct BindArgs {
 	const Thresh *thresh;
 	const Item *items;
 	uint32_t n_items;
-	const uint32_t *n_items_dev; // when set, the item count is read from the device counter
-	const uint32_t *index;       // optional work list: item indices to bind (phase A / phase B queues)
-	const uint32_t *shard_counts; // when set, `index` is a sharded array (seed kernel output) of this region size
-	uint32_t shard_region;
+	const uint32_t *n_items_dev; // when set, the item count is read from the device counter (n_items caps it)
+	const uint32_t *index;       // optional work list: item indices to bind (one length bucket of a phase queue)
 	int32_t *result;           // per item: pool index (>= 0) or -status
 	BoundRec *pool;
 	uint32_t pool_cap;
@@ -382,19 +380,15 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	uint16_t *ties = a.ties + size_t(blockIdx.x) * (size_t(TIE_CAP) * BIND_THREADS) + tid;
 	uint8_t *win = s_win + tid;
 
-	__shared__ uint32_t s_pre[N_SHARD + 1];
-	if (a.shard_counts) {
-		shard_prefix(a.shard_counts, s_pre, tid);
-		__syncthreads();
+	uint32_t n_items = a.n_items;
+	if (a.n_items_dev) {
+		const uint32_t n_dev = *a.n_items_dev;
+		n_items = n_dev < a.n_items ? n_dev : a.n_items;
 	}
-	const uint32_t n_items = a.shard_counts ? s_pre[N_SHARD] : (a.n_items_dev ? *a.n_items_dev : a.n_items);
 	for (uint32_t base = blockIdx.x * BIND_THREADS; base < n_items; base += gridDim.x * BIND_THREADS) {
 		const bool active = base + tid < n_items;
 		uint32_t idx = 0;
-		if (active) {
-			if (a.shard_counts) idx = a.index[shard_locate(s_pre, base + tid, a.shard_region)];
-			else idx = a.index ? a.index[base + tid] : base + tid;
-		}
+		if (active) idx = a.index ? a.index[base + tid] : base + tid;
 
 		// ------------------------------------------------------------------ item decode
 		Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
@@ -1001,6 +995,11 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 #undef TARGET
 	}
 }
+
+// host-side launchers of the throughput instances, defined in tnt_bind_inst.hip
+#define X(N) void launch_bind_##N(const BindArgs &a, int blocks, hipStream_t stream);
+TNT_LMAX_LADDER(X)
+#undef X
 
 } // namespace tnt
 #endif

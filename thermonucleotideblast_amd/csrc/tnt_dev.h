@@ -72,7 +72,16 @@ struct Slot {
 	float log_ct;    // logf(strand concentration), host computed
 	int32_t thresh;  // index into Thresh table
 	int32_t assay;   // expanded assay index (or -1)
+	int32_t bucket;  // length bucket = which bind kernel instance handles this oligo
 };
+
+// Instances of the bind kernel (rows kept in registers): every oligo length up to 32 has its own, so the
+// oligos of one launch all have exactly LMAX rows; coarser above.
+#define TNT_LMAX_LADDER(X) \
+	X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) \
+	X(34) X(36) X(38) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
+constexpr int MAX_BUCKETS = 27;
+constexpr int BUCKET_STRIDE = 32; // words between two bucket counters (one 128-byte line each)
 
 // bind work item (one seed that survived the first cull)
 struct Item {

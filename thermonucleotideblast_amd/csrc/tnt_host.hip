@@ -291,7 +291,8 @@ struct tnt_ctx {
 	std::vector<std::string> oligos;
 	std::vector<AssayDev> h_assays;
 	std::vector<Slot> h_slots;
-	int lmax = 24; // template instance of the bind kernel
+	int lmax = 24; // largest bind kernel instance this context needs
+	std::vector<int> bucket_lmax; // the instances in use, ascending; Slot::bucket indexes this list
 	int scratch_lmax = 24; // what the scratch slabs are sized for
 	size_t n_entries = 0;
 	std::vector<uint32_t> chunk_begin; // assay chunks for the seed kernel (+ end)
@@ -316,6 +317,7 @@ struct tnt_ctx {
 	DevBuf<int32_t> result;
 	DevBuf<Group> groups;
 	DevBuf<uint32_t> active, qa, qb;
+	DevBuf<uint32_t> qbucket; // [bucket][ITEM_CAP]: the phase queue split by oligo length
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
@@ -324,7 +326,8 @@ struct tnt_ctx {
 	DevBuf<SeedOut> seeds_out;
 	int bind_blocks = 0;
 
-	std::vector<tnt_hit> h_hits;
+	tnt_hit *h_hits = nullptr; // pinned host buffer the hit records are copied into (library owned)
+	size_t h_hits_cap = 0;
 	std::vector<tnt_seed> h_seeds;
 	tnt_timing timing;
 	std::vector<hipEvent_t> events;
@@ -335,6 +338,7 @@ struct tnt_ctx {
 	~tnt_ctx()
 	{
 		for (hipEvent_t e : events) (void)hipEventDestroy(e);
+		if (h_hits) (void)hipHostFree(h_hits);
 		if (stream) (void)hipStreamDestroy(stream);
 	}
 };
@@ -344,7 +348,8 @@ namespace {
 enum { C_POOL = 0, C_ACTIVE, C_QB, C_PAD3, C_HITS, C_ERR, C_PAD6, C_PAD7, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
-       C_COUNT = C_GROUPS + N_SHARD * SHARD_STRIDE };
+       // per length bucket: entries of the current phase queue
+       C_BUCKET = C_GROUPS + N_SHARD * SHARD_STRIDE, C_COUNT = C_BUCKET + MAX_BUCKETS * BUCKET_STRIDE };
 static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
@@ -381,10 +386,8 @@ DbView make_view(const tnt_db *db, size_t t0, size_t t1)
 	return v;
 }
 
-// Template instances of the bind kernel: rows kept in registers.  Padding rows cost full work, so the
-// ladder is fine-grained where assay oligos usually sit (18-32) and coarser above.
-#define TNT_LMAX_LADDER(X) X(20) X(22) X(24) X(25) X(26) X(28) X(30) X(32) X(36) X(40) X(48) X(56) X(64)
-
+// Template instances of the bind kernel (TNT_LMAX_LADDER, tnt_dev.h) live in tnt_bind_inst.hip so that groups
+// of them compile in parallel; the unit-level instance bind_kernel<64, true> is compiled here.
 int pick_lmax(size_t max_len)
 {
 #define X(N) if (max_len <= N) return N;
@@ -393,17 +396,45 @@ int pick_lmax(size_t max_len)
 	return 64;
 }
 
-void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, bool full)
+void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax)
 {
-	if (full) { // unit-level API: one instance is enough
+	if (lmax == 0) { // unit-level API: one instance is enough
 		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a);
 		return;
 	}
-	switch (c->lmax) {
-#define X(N) case N: hipLaunchKernelGGL((bind_kernel<N, false>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a); break;
+	switch (lmax) {
+#define X(N) case N: tnt::launch_bind_##N(a, blocks, c->stream); break;
 		TNT_LMAX_LADDER(X)
 #undef X
 	default: break;
+	}
+}
+
+// One phase of binding: split the queue by oligo length, then one launch per length bucket.
+void launch_bind_phase(tnt_ctx *c, BindArgs b, const uint32_t *src, const uint32_t *src_count, const uint32_t *shard_counts)
+{
+	uint32_t *cnt = c->counters.p;
+	(void)hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream);
+	BucketArgs k;
+	memset(&k, 0, sizeof(k));
+	k.src = src;
+	k.src_count = src_count;
+	k.shard_counts = shard_counts;
+	k.shard_region = uint32_t(ITEM_CAP / N_SHARD);
+	k.items = c->items.p;
+	k.slots = c->slots.p;
+	k.dst = c->qbucket.p;
+	k.cap = uint32_t(ITEM_CAP);
+	k.dst_count = cnt + C_BUCKET;
+	k.n_buckets = int(c->bucket_lmax.size());
+	k.merge_below = uint32_t(c->bind_blocks) * BIND_THREADS * 2u;
+	k.err = cnt + C_ERR;
+	hipLaunchKernelGGL(bucket_kernel, dim3(1024), dim3(256), 0, c->stream, k);
+	for (size_t i = 0; i < c->bucket_lmax.size(); i++) {
+		b.index = c->qbucket.p + i * ITEM_CAP;
+		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
+		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
+		launch_bind(c, b, c->bind_blocks, c->bucket_lmax[i]);
 	}
 }
 
@@ -432,6 +463,7 @@ int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 		HIP_TRY(c->active.alloc(GROUP_CAP), c->err);
 		HIP_TRY(c->qa.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->qb.alloc(ITEM_CAP), c->err);
+		HIP_TRY(c->qbucket.alloc(ITEM_CAP * std::max<size_t>(1, c->bucket_lmax.size())), c->err);
 		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
 		HIP_TRY(c->hits.alloc(HIT_CAP), c->err);
 		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
@@ -597,7 +629,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		}
 		d.has_probe = (primers && A.probe && d.kind == 0) ? 1 : 0;
 		// Slot table is laid out [assay][role] so the kernels address it without an indirection
-		c->h_slots.resize((i + 1) * 3, Slot{-1, 0.0f, 0, int(i)});
+		c->h_slots.resize((i + 1) * 3, Slot{-1, 0.0f, 0, int(i), 0});
 		auto add_slot = [&](int role, const char *s, float ct, int thr) -> int {
 			Slot &sl = c->h_slots[i * 3 + role];
 			sl.oligo = intern(s);
@@ -626,6 +658,17 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		max_L = std::max(max_L, o.size());
 	}
 	c->lmax = pick_lmax(max_L);
+	{
+		std::vector<int> used;
+		for (const Slot &sl : c->h_slots)
+			if (sl.oligo >= 0) used.push_back(pick_lmax(c->oligos[sl.oligo].size()));
+		std::sort(used.begin(), used.end());
+		used.erase(std::unique(used.begin(), used.end()), used.end());
+		c->bucket_lmax = used;
+		for (Slot &sl : c->h_slots)
+			if (sl.oligo >= 0)
+				sl.bucket = int32_t(std::lower_bound(used.begin(), used.end(), pick_lmax(c->oligos[sl.oligo].size())) - used.begin());
+	}
 
 	// ---- tables
 	if (!fill_tables(c->h_tab, *opt)) FAIL(TNT_E_UNSUPPORTED, "delta_g table lacks the class structure the bind kernel relies on");
@@ -866,11 +909,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
-	b.n_items = 0; // read from the device counter
-	b.index = c->qa.p;
-	b.shard_counts = cnt + C_QA;
-	b.shard_region = uint32_t(ITEM_CAP / N_SHARD);
-	launch_bind(c, b, c->bind_blocks, false);
+	launch_bind_phase(c, b, c->qa.p, nullptr, cnt + C_QA);
 
 	FilterArgs f;
 	f.groups = c->groups.p;
@@ -882,10 +921,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	hipLaunchKernelGGL(filter_kernel, dim3(256), dim3(256), 0, c->stream, f);
 
 	// phase B: the other strand and the probes of the groups that are still alive
-	b.n_items_dev = cnt + C_QB;
-	b.index = c->qb.p;
-	b.shard_counts = nullptr;
-	launch_bind(c, b, c->bind_blocks, false);
+	launch_bind_phase(c, b, c->qb.p, cnt + C_QB, nullptr);
 	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 
 	PairArgs p;
@@ -1011,8 +1047,15 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		return TNT_E_LIMIT;
 	}
 	const size_t n = std::min<size_t>(cnt[C_HITS], HIT_CAP);
-	ctx->h_hits.resize(n);
-	if (n) HIP_TRY(hipMemcpy(ctx->h_hits.data(), ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
+	if (n > ctx->h_hits_cap) {
+		if (ctx->h_hits) (void)hipHostFree(ctx->h_hits);
+		ctx->h_hits = nullptr;
+		ctx->h_hits_cap = 0;
+		const size_t cap = std::min<size_t>(HIT_CAP, std::max<size_t>(n + n / 2, 4096));
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hits), cap * sizeof(tnt_hit), hipHostMallocDefault), ctx->err);
+		ctx->h_hits_cap = cap;
+	}
+	if (n) HIP_TRY(hipMemcpy(ctx->h_hits, ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
 	// stage timings
 	tnt_timing &T = ctx->timing;
 	memset(&T, 0, sizeof(T));
@@ -1030,7 +1073,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	T.n_seeds = (uint64_t(cnt[C_TOT_GROUPS_HI]) << 32) | cnt[C_TOT_GROUPS_LO]; // (target, assay) groups that reached the bind stage
 	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n;
-	if (hits) *hits = ctx->h_hits.data();
+	if (hits) *hits = ctx->h_hits;
 	if (n_hits) *n_hits = n;
 	return TNT_OK;
 }
@@ -1134,6 +1177,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 		slots[i].log_ct = logf((r.ct - 0.5f * 0.0f) * 1.0f);
 		slots[i].thresh = r.role == 1 ? 1 : 0;
 		slots[i].assay = -1;
+		slots[i].bucket = 0;
 		items[i].target = uint32_t(t);
 		items[i].tloc = uint32_t(r.target_loc);
 		items[i].info = uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT);
@@ -1151,7 +1195,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	b.n_items = uint32_t(n);
 	b.n_items_dev = nullptr;
 	b.full = dfull.p;
-	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + BIND_THREADS - 1) / BIND_THREADS)), true);
+	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + BIND_THREADS - 1) / BIND_THREADS)), 0);
 	HIP_TRY(hipGetLastError(), ctx->err);
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
@@ -1212,8 +1256,8 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	const float ct_self = ct_a - 0.5f * ct_a;
 	const float ct_pair = ob ? ((ct_a > ct_b) ? ct_a - 0.5f * ct_b : ct_b - 0.5f * ct_a) : ct_self;
 	std::vector<Slot> slots(2);
-	slots[0] = Slot{0, logf(ct_self * 1.0f), 0, -1};
-	slots[1] = Slot{0, logf(ct_pair * 1.0f), 0, -1};
+	slots[0] = Slot{0, logf(ct_self * 1.0f), 0, -1, 0};
+	slots[1] = Slot{0, logf(ct_pair * 1.0f), 0, -1, 0};
 	std::vector<Item> items;
 	items.push_back(Item{3u << 29, 0, 0u << ITEM_SLOT_SHIFT, 0});                  // hairpin of a
 	items.push_back(Item{2u << 29, 0, 0u << ITEM_SLOT_SHIFT, 0});                  // homodimer of a
@@ -1240,7 +1284,7 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	b.groups = nullptr;
 	b.n_items = uint32_t(items.size());
 	b.full = dfull.p;
-	launch_bind(ctx, b, 1, true);
+	launch_bind(ctx, b, 1, 0);
 	HIP_TRY(hipGetLastError(), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	std::vector<BindFull> full(items.size());

@@ -236,6 +236,65 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
 	}
 }
 
+// Distribute a queue of item indices over the length buckets of their oligos: every bucket is bound by the
+// kernel instance with exactly that many rows (no padding rows, uniform trip counts inside a wavefront).
+struct BucketArgs {
+	const uint32_t *src;          // item indices
+	const uint32_t *src_count;    // flat source: number of entries
+	const uint32_t *shard_counts; // or: sharded source (seed kernel output) of `shard_region` entries per shard
+	uint32_t shard_region;
+	const Item *items;
+	const Slot *slots;
+	uint32_t *dst;                // [n_buckets][cap]
+	uint32_t cap;
+	uint32_t *dst_count;          // [n_buckets * BUCKET_STRIDE]
+	int n_buckets;
+	uint32_t merge_below;         // a queue shorter than this goes to the last (longest) bucket as a whole: one launch
+	                              // with padding rows beats one under-filled launch per bucket
+	uint32_t *err;
+};
+
+constexpr int BUCKET_PER_THREAD = 4;
+
+__global__ __launch_bounds__(256) void bucket_kernel(BucketArgs a)
+{
+	__shared__ uint32_t s_pre[N_SHARD + 1];
+	__shared__ uint32_t s_cnt[MAX_BUCKETS], s_base[MAX_BUCKETS];
+	const int tid = threadIdx.x;
+	if (a.shard_counts) {
+		shard_prefix(a.shard_counts, s_pre, tid);
+		__syncthreads();
+	}
+	const uint32_t n = a.shard_counts ? s_pre[N_SHARD] : *a.src_count;
+	constexpr uint32_t STEP = 256 * BUCKET_PER_THREAD;
+	for (uint32_t base = blockIdx.x * STEP; base < n; base += gridDim.x * STEP) {
+		if (tid < MAX_BUCKETS) s_cnt[tid] = 0;
+		__syncthreads();
+		uint32_t idx[BUCKET_PER_THREAD], bkt[BUCKET_PER_THREAD], pos[BUCKET_PER_THREAD];
+#pragma unroll
+		for (int m = 0; m < BUCKET_PER_THREAD; m++) {
+			const uint32_t lin = base + uint32_t(m) * 256u + uint32_t(tid);
+			bkt[m] = 0xFFFFFFFFu;
+			if (lin < n) {
+				idx[m] = a.src[a.shard_counts ? shard_locate(s_pre, lin, a.shard_region) : lin];
+				bkt[m] = n < a.merge_below ? uint32_t(a.n_buckets - 1) : uint32_t(a.slots[a.items[idx[m]].info >> ITEM_SLOT_SHIFT].bucket);
+				pos[m] = atomicAdd(&s_cnt[bkt[m]], 1u);
+			}
+		}
+		__syncthreads();
+		if (tid < a.n_buckets && s_cnt[tid]) s_base[tid] = atomicAdd(a.dst_count + tid * BUCKET_STRIDE, s_cnt[tid]);
+		__syncthreads();
+#pragma unroll
+		for (int m = 0; m < BUCKET_PER_THREAD; m++)
+			if (bkt[m] != 0xFFFFFFFFu) {
+				const uint32_t o = s_base[bkt[m]] + pos[m];
+				if (o < a.cap) a.dst[size_t(bkt[m]) * a.cap + o] = idx[m];
+				else atomicOr(a.err, ERR_ITEM_OVERFLOW);
+			}
+		__syncthreads();
+	}
+}
+
 __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(PairArgs a)
 {
 	const uint32_t n_active = *a.n_active;

@@ -177,13 +177,19 @@ class Engine:
     def enqueue(self, batch):
         self._check(self.lib.tnt_search_enqueue(self._h, batch._h))
 
-    def collect(self):
+    def collect(self, copy=True):
+        """Hit records of the enqueued search.  copy=False returns a view of the library-owned (pinned) buffer
+        that stays valid until the next search on this context."""
         hits = C.POINTER(abi.tnt_hit)()
         n = C.c_size_t()
         self._check(self.lib.tnt_search_collect(self._h, C.byref(hits), C.byref(n)))
+        if not n.value:
+            return (abi.tnt_hit * 0)()
+        view = (abi.tnt_hit * n.value).from_address(C.addressof(hits.contents))
+        if not copy:
+            return view
         out = (abi.tnt_hit * n.value)()
-        if n.value:
-            C.memmove(out, hits, C.sizeof(abi.tnt_hit) * n.value)
+        C.memmove(out, view, C.sizeof(abi.tnt_hit) * n.value)
         return out
 
     def timing(self):
