@@ -37,6 +37,7 @@ struct BindArgs {
 	uint32_t n_items;
 	const uint32_t *n_items_dev; // when set, the item count is read from the device counter (n_items caps it)
 	const uint32_t *index;       // optional work list: item indices to bind (one length bucket of a phase queue)
+	const uint32_t *index_base_dev; // when set, the work list starts at index[*index_base_dev]
 	int32_t *result;           // per item: pool index (>= 0) or -status
 	BoundRec *pool;
 	uint32_t pool_cap;
@@ -53,7 +54,6 @@ struct BindArgs {
 	uint32_t *n_active;
 };
 
-constexpr int BIND_THREADS = 256;
 constexpr int TIE_CAP = 256;      // maximal cells of one DP beyond which the kernel reports ERR_TIE_OVERFLOW
 constexpr unsigned long long WC_MASK = // watson_and_crick[], nuc_cruc.cpp:229-238
 	(1ull << P_AT) | (1ull << P_TA) | (1ull << P_CG) | (1ull << P_GC) | (1ull << (bA * NB + bI)) | (1ull << (bI * NB + bA)) |
@@ -119,6 +119,7 @@ enum : int { MODE_HOMO_DIMER = 0, MODE_HETERO_DIMER = 1, MODE_HAIRPIN = 2 };
 
 // evaluate_alignment, nuc_cruc.cpp:1620-2299.  Columns k0..k1-1 of c.cols.  In HAIRPIN mode the sums start
 // from the loop terms computed by the caller (evaluate_hairpin_alignment, :2301-2394).
+template <int BIND_THREADS> // lane stride of the per-lane LDS / scratch slices
 __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode = MODE_HETERO_DIMER, float dH0 = 0.0f, float dS0 = 0.0f)
 {
 	const Tables &T = *c.tab;
@@ -308,6 +309,7 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 // evaluate_hairpin_alignment, nuc_cruc.cpp:2301-2394: loop entropy, special tri/tetra-loop bonus
 // (find_loop_index, :2619-2869 = exact match of the 5 / 6 bases starting at the 5' closing base),
 // closing-AT penalty or terminal mismatch, then the stem through evaluate_alignment(HAIRPIN).
+template <int BIND_THREADS>
 __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const AlignInfo &al, const uint8_t *gquery, const uint8_t *lds_query,
                                   int L)
 {
@@ -343,13 +345,16 @@ __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const Ali
 		dS += T.S[last_pair * NBP + curp];
 	}
 #undef HQ
-	return evaluate_alignment(c, al.k0, al.k1, MODE_HAIRPIN, dH, dS);
+	return evaluate_alignment<BIND_THREADS>(c, al.k0, al.k1, MODE_HAIRPIN, dH, dS);
 }
 
 // The bind kernel proper.  LMAX = rows kept in registers (oligos of this launch have L <= LMAX).
-template <int LMAX, bool FULL>
-__global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
+// EXACT: every item of the launch has L == LMAX (the host buckets the queues by length).
+template <int LMAX, bool FULL, bool EXACT = false>
+__global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a)
 {
+	static_assert(!(FULL && EXACT), "the unit-level instance takes any length");
+	constexpr int BIND_THREADS = bind_threads_for(LMAX);
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NCOLS = LMAX + WMAX + 4;
 
@@ -380,6 +385,8 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	uint16_t *ties = a.ties + size_t(blockIdx.x) * (size_t(TIE_CAP) * BIND_THREADS) + tid;
 	uint8_t *win = s_win + tid;
 
+	const uint32_t *index = a.index;
+	if (index && a.index_base_dev) index += *a.index_base_dev;
 	uint32_t n_items = a.n_items;
 	if (a.n_items_dev) {
 		const uint32_t n_dev = *a.n_items_dev;
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 	for (uint32_t base = blockIdx.x * BIND_THREADS; base < n_items; base += gridDim.x * BIND_THREADS) {
 		const bool active = base + tid < n_items;
 		uint32_t idx = 0;
-		if (active) idx = a.index ? a.index[base + tid] : base + tid;
+		if (active) idx = index ? index[base + tid] : base + tid;
 
 		// ------------------------------------------------------------------ item decode
 		Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 
 		int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
-		for (int i = 0; i < LMAX; i++) oM[i] = -1, oQ[i] = oT[i] = 0;
+		for (int i = 0; i < LMAX; i++) oM[i] = FULL ? -1 : 0, oQ[i] = oT[i] = 0;
 
 		int gmax = -1, nmax = 0, max_ij = 0;
 		uint32_t prtw = s_rt[bGAP];
@@ -491,10 +498,10 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 			const int t = colok ? int(win[(j - 1) * BIND_THREADS]) : bGAP;
 			const uint32_t rtw = s_rt[t];
 			const int v5 = firstcol ? c_zero : c_bulge;          // g(bp(pt,GAP), bp(t,GAP))
-			int aM = -1, aQ = 0, aT = 0, bM = -1, bT = 0; // border cells hold -1 (nuc_cruc.h:531-536); gap states are kept clamped
+			int aM = FULL ? -1 : 0, aQ = 0, aT = 0, bM = FULL ? -1 : 0, bT = 0; // border cells hold -1 (nuc_cruc.h:531-536), kept clamped like the gap states
 			int Lcol = colok ? L : 0;         // rows that count in this column
 			if (FULL && xmode == 3) Lcol = (L - 3 - j) > 0 ? (L - 3 - j) : 0; // align_hairpin's triangle, nuc_cruc.cpp:794-810
-			int colmax = INT32_MIN;
+			int colmax = INT32_MIN, held = INT32_MIN;
 			int term_up = 0;                                     // term(cur) of the row above
 			// keep the per-row constants from being hoisted out of the column loop (register pressure)
 #pragma unroll
@@ -525,54 +532,70 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 					e_n = *reinterpret_cast<const int2 *>(sdg + p4_4 * 98 + rtq * 56 + 2 * q4); // prev = bp(pt, q of this row)
 					tp4_n = *reinterpret_cast<const int *>(sterm + p4_4_n);
 				}
-				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // oQ / oT are stored clamped at zero
+				// oQ / oT are stored clamped at zero; so is oM in the throughput instances (the unit-level instance
+				// keeps M itself: it reports dp_max / n_max also when no cell is positive)
+				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
 				const int termv = e.y;
 
-				const int dg1 = (aM > 0 ? aM : 0) - e.x;
+				const int dg1 = (FULL ? (aM > 0 ? aM : 0) : aM) - e.x;
 				const int dg2 = aQ - (firstcol ? c_forb_m : termv);
 				const int dg3 = aT - (i == 1 ? c_forb_m : termv);
 				// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits.
-				// The trace word is built as a shift register: every flag costs one v_alignbit (sign bits)
-				// or a compare + add-with-carry (equalities).  Final layout: see TW_* in tnt_dev.h.
+				// The trace word is built as a shift register, one v_alignbit (sign bit) per flag; equalities are
+				// taken as "not less than the maximum" (a full-rate subtract feeds the sign).  Layout: TW_* in tnt_dev.h.
 				int M = dg1 > dg2 ? dg1 : dg2;
 				M = M > dg3 ? M : dg3;
-				const int iqi = (cM > 0 ? cM : 0) - term_p4;
+				const int iqi = (FULL ? (cM > 0 ? cM : 0) : cM) - term_p4;
 				const int iqe = cQ - v5;
 				const int Iq = iqi > iqe ? iqi : iqe;
-				const int iti = (bM > 0 ? bM : 0) - (i == 1 ? c_forb_xy : term_up);
+				const int iti = (FULL ? (bM > 0 ? bM : 0) : bM) - (i == 1 ? c_forb_xy : term_up);
 				const int ite = bT - (i == 1 ? c_zero : c_bulge);
 				const int It = iti > ite ? iti : ite;
 
 				uint32_t tw = 0;
-				tw = push_eq(tw, dg1, M);                                  // M came from M        (im1_jm1)
-				tw = push_eq(tw, dg3, M);                                  // M came from I_target (im1_j)
-				tw = push_eq(tw, dg2, M);                                  // M came from I_query  (i_jm1)
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg1 - M), 31);   // set: M did not come from M        (im1_jm1)
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg3 - M), 31);   // set: M did not come from I_target (im1_j)
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg2 - M), 31);   // set: M did not come from I_query  (i_jm1)
 				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - iqe), 31); // insert < extend: I_query only from I_query
 				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - iqi), 31); // extend < insert: I_query only from M
 				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - ite), 31);
 				tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - iti), 31);
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(M), 31);       // M < 0
-				tw = push_eq(tw, M, 0);                                    // M == 0
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(Iq), 31);      // I_query < 0
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(It), 31);      // I_target < 0
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(M), 31);         // M < 0
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(M - 1), 31);     // M <= 0
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(Iq), 31);        // I_query < 0
+				tw = __builtin_amdgcn_alignbit(tw, uint32_t(It), 31);        // I_target < 0
 				tcol[(i - 1) * BIND_THREADS] = uint16_t(tw);
 
 				// column maximum over the valid rows; the running maximum is updated once per column below
-				const int Mv = (i <= Lcol) ? M : INT32_MIN;
-				colmax = colmax > Mv ? colmax : Mv;
+				if (EXACT) {
+					if (i & 1) {
+						if (i == LMAX) colmax = colmax > M ? colmax : M;
+						else held = M;
+					} else {
+						const int m2 = held > M ? held : M; // one v_max3 per two rows
+						colmax = colmax > m2 ? colmax : m2;
+					}
+				} else {
+					const int Mv = (i <= Lcol) ? M : INT32_MIN;
+					colmax = colmax > Mv ? colmax : Mv;
+				}
 
+				const int Mc = FULL ? M : (M > 0 ? M : 0);
 				aM = cM, aQ = cQ, aT = cT;
-				bM = M, bT = It > 0 ? It : 0;
-				oM[i - 1] = M, oQ[i - 1] = Iq > 0 ? Iq : 0, oT[i - 1] = bT;
+				bM = Mc, bT = It > 0 ? It : 0;
+				oM[i - 1] = Mc, oQ[i - 1] = Iq > 0 ? Iq : 0, oT[i - 1] = bT;
 				term_up = termv;
 			}
+			if (EXACT && !colok) colmax = INT32_MIN;
 			// Running maximum, nuc_cruc.cpp:670-691.  The reference visits cells row-major; here the visiting
 			// order is column-major, rows ascending.  The SET of cells holding the final maximum does not depend
 			// on the order; it is collected as (i << 8 | j) codes and sorted row-major before the traceback.
-			if (colmax >= gmax) {
+			// (throughput instances compare the clamped copies: only positive maxima are collected, a window
+			// without a positive cell has no alignment of three columns and is rejected either way)
+			if (colmax >= gmax && (FULL || colmax > 0)) {
 #pragma unroll
 				for (int i = 1; i <= LMAX; i++) {
-					if (i <= Lcol && oM[i - 1] == colmax) {
+					if ((EXACT || i <= Lcol) && oM[i - 1] == colmax) {
 						const int code = (i << 8) | j;
 						if (colmax > gmax) {
 							gmax = colmax;
@@ -692,14 +715,18 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 					}
 					// border cells hold M = I_query = I_target = -1 (nuc_cruc.h:531-536)
 					const bool inside = (li >= 1 && lj >= 1);
+#ifdef TNT_EXP_NOTRACEREAD
+					const int tw = (inside && n < 9) ? int(TW_M_NOT_IT | TW_M_NOT_IQ) : (TW_M_NEG | TW_IQ_NEG | TW_IT_NEG);
+#else
 					const int tw = inside ? int(TRACE_AT(li, lj)) : (TW_M_NEG | TW_IQ_NEG | TW_IT_NEG);
+#endif
 					const int cidx = li * (WMAX + 1) + lj;
 					if (local == 1) { // query_target
 						if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
 							valid = false;
 						} else {
 							if (tw & TW_M_NEG) valid = false;
-							else if (tw & TW_M_ZERO) {
+							else if (tw & TW_M_LE0) {
 								if (count_zeros) zero_count++;
 								else if (--truncate_at_zero == 0) valid = false;
 							}
@@ -707,7 +734,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 							n++;
 							al.lm_q = L - li;
 							al.lm_t = lj - 1;
-							mask = ((tw & TW_M_FROM_M) ? 1 : 0) | ((tw & TW_M_FROM_IT) ? 2 : 0) | ((tw & TW_M_FROM_IQ) ? 4 : 0);
+							mask = ((tw & TW_M_NOT_M) ? 0 : 1) | ((tw & TW_M_NOT_IT) ? 0 : 2) | ((tw & TW_M_NOT_IQ) ? 0 : 4);
 							key = cidx * 4 + 0;
 							li--, lj--;
 						}
@@ -794,7 +821,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 
 				if (FULL && xmode == 3) {
 					// ---------------- enumerate_hairpin_alignments, nuc_cruc.cpp:1264-1405
-					if (al.k1 - al.k0 >= 3) CONSIDER(evaluate_hairpin(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+					if (al.k1 - al.k0 >= 3) CONSIDER(evaluate_hairpin<BIND_THREADS>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
 					// the open end of the stem always gets its dangling / frayed bases (:1307-1324)
 					if (al.lm_t != 0 || al.lm_q != L - 1) {
 						int qb, tb;
@@ -807,7 +834,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 					}
 					const int align_size = al.k1 - al.k0;
 					if (align_size < 3) continue;
-					CONSIDER(evaluate_hairpin(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+					CONSIDER(evaluate_hairpin<BIND_THREADS>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
 					if (align_size <= 3) continue;
 					// an A-T closing pair carries a penalty: try without it (:1356-1405)
 					const int lp = lut_pair(s_lut, QUERY(al.fm_t), QUERY(al.fm_q));
@@ -815,7 +842,7 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 					al.fm_q++;
 					al.fm_t--;
 					al.k0++;
-					CONSIDER(evaluate_hairpin(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+					CONSIDER(evaluate_hairpin<BIND_THREADS>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
 					continue;
 				}
 
@@ -841,7 +868,9 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 				}
 				if (al.k1 - al.k0 < 3) continue; // :1148
 
-				CONSIDER(evaluate_alignment(c, al.k0, al.k1, (FULL && xmode == 2) ? MODE_HOMO_DIMER : MODE_HETERO_DIMER));
+#ifndef TNT_EXP_NOEVAL
+				CONSIDER(evaluate_alignment<BIND_THREADS>(c, al.k0, al.k1, (FULL && xmode == 2) ? MODE_HOMO_DIMER : MODE_HETERO_DIMER));
+#endif
 #undef CONSIDER
 			}
 		}
@@ -999,6 +1028,9 @@ __global__ __launch_bounds__(BIND_THREADS) void bind_kernel(BindArgs a)
 // host-side launchers of the throughput instances, defined in tnt_bind_inst.hip
 #define X(N) void launch_bind_##N(const BindArgs &a, int blocks, hipStream_t stream);
 TNT_LMAX_LADDER(X)
+#undef X
+#define X(N) void launch_bind_exact_##N(const BindArgs &a, int blocks, hipStream_t stream);
+TNT_EXACT_LADDER(X)
 #undef X
 
 } // namespace tnt

@@ -24,15 +24,16 @@ constexpr int ALIGN_TEXT = 448;           // TNT_ALIGN_TEXT
 // nuc_cruc.h:62-64 (im1_jm1 = came from M, im1_j = from I_target, i_jm1 = from I_query).
 constexpr int TW_IT_NEG = 1 << 0;     // I_target < 0
 constexpr int TW_IQ_NEG = 1 << 1;     // I_query < 0
-constexpr int TW_M_ZERO = 1 << 2;     // M == 0
+constexpr int TW_M_LE0 = 1 << 2;      // M <= 0 (with TW_M_NEG clear: M == 0)
 constexpr int TW_M_NEG = 1 << 3;      // M < 0
 constexpr int TW_IT_GT = 1 << 4;      // I_target: extend < insert  (trace = from M only)
 constexpr int TW_IT_LT = 1 << 5;      // I_target: insert < extend  (trace = from I_target only)
 constexpr int TW_IQ_GT = 1 << 6;      // I_query:  extend < insert
 constexpr int TW_IQ_LT = 1 << 7;      // I_query:  insert < extend
-constexpr int TW_M_FROM_IQ = 1 << 8;  // M_trace & i_jm1
-constexpr int TW_M_FROM_IT = 1 << 9;  // M_trace & im1_j
-constexpr int TW_M_FROM_M = 1 << 10;  // M_trace & im1_jm1
+// the three "M came from" bits are stored inverted (bit = candidate < maximum: one subtract + one sign-bit shift)
+constexpr int TW_M_NOT_IQ = 1 << 8;   // clear: M_trace & i_jm1
+constexpr int TW_M_NOT_IT = 1 << 9;   // clear: M_trace & im1_j
+constexpr int TW_M_NOT_M = 1 << 10;   // clear: M_trace & im1_jm1
 
 // Thermodynamic tables resident in HBM (19 KB floats + 9.6 KB ints); delta_g is staged into LDS.
 struct Tables {
@@ -77,10 +78,19 @@ struct Slot {
 
 // Instances of the bind kernel (rows kept in registers): every oligo length up to 32 has its own, so the
 // oligos of one launch all have exactly LMAX rows; coarser above.
-#define TNT_LMAX_LADDER(X) \
-	X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) \
-	X(34) X(36) X(38) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
-constexpr int MAX_BUCKETS = 27;
+// Exact instances (every oligo of the launch has exactly LMAX rows: no per-row length test) ...
+#define TNT_EXACT_LADDER(X) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+// ... and general ones (L <= LMAX) for the other lengths and for short queues that are bound in one launch
+#define TNT_LMAX_LADDER(X) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
+constexpr int MAX_BUCKETS = 30;
+constexpr int BUCKET_EXACT = 0x100; // flag on the instance id kept by the host (lmax | BUCKET_EXACT)
+
+// Workgroup size of the bind kernel instance with LMAX rows.  One lane owns one DP; a lane needs 6 * LMAX + 32
+// bytes of LDS (window, query, alignment columns) next to the 19.4 KB of tables every workgroup holds once.
+// Up to 25 rows three wavefronts per SIMD fit (one 768-thread workgroup per CU, <= 168 VGPRs); above that the
+// row state needs the registers of a two-wave budget (two 256-thread workgroups per CU).
+constexpr int bind_threads_for(int lmax) { return lmax <= 25 ? 768 : 256; }
+constexpr int bind_blocks_per_cu(int lmax) { return lmax <= 25 ? 2 : 4; } // persistent grid: 2x the resident workgroups
 constexpr int BUCKET_STRIDE = 32; // words between two bucket counters (one 128-byte line each)
 
 // bind work item (one seed that survived the first cull)

@@ -317,14 +317,15 @@ struct tnt_ctx {
 	DevBuf<int32_t> result;
 	DevBuf<Group> groups;
 	DevBuf<uint32_t> active, qa, qb;
-	DevBuf<uint32_t> qbucket; // [bucket][ITEM_CAP]: the phase queue split by oligo length
+	DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
 	DevBuf<uint16_t> trace, cols, best, ties;
 	DevBuf<uint32_t> stack;
 	DevBuf<SeedOut> seeds_out;
-	int bind_blocks = 0;
+	int bind_blocks = 0; // grid of the 256-thread instances
+	int n_cu = 0;
 
 	tnt_hit *h_hits = nullptr; // pinned host buffer the hit records are copied into (library owned)
 	size_t h_hits_cap = 0;
@@ -367,8 +368,8 @@ __global__ void accumulate_kernel(uint32_t *cnt)
 	cnt[C_TOT_BOUND] += cnt[C_POOL];
 }
 
-constexpr size_t ITEM_CAP = size_t(96) << 20;  // bind work items per internal batch
-constexpr size_t GROUP_CAP = size_t(64) << 20;
+constexpr size_t ITEM_CAP = size_t(384) << 20;  // bind work items per internal batch
+constexpr size_t GROUP_CAP = size_t(256) << 20;
 constexpr size_t POOL_CAP = size_t(4) << 20;
 constexpr size_t HIT_CAP = size_t(1) << 20;
 
@@ -396,15 +397,30 @@ int pick_lmax(size_t max_len)
 	return 64;
 }
 
+// persistent grid of one bind kernel instance
+int bind_grid(const tnt_ctx *c, int lmax) { return c->n_cu * bind_blocks_per_cu(lmax & 0xFF); }
+
+// instance id for oligos of length L: the exact instance where there is one, else the smallest general one
+int pick_instance(size_t L)
+{
+#define X(N) if (L == N) return N | BUCKET_EXACT;
+	TNT_EXACT_LADDER(X)
+#undef X
+	return pick_lmax(L);
+}
+
 void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax)
 {
 	if (lmax == 0) { // unit-level API: one instance is enough
-		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(BIND_THREADS), 0, c->stream, a);
+		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads_for(64)), 0, c->stream, a);
 		return;
 	}
 	switch (lmax) {
 #define X(N) case N: tnt::launch_bind_##N(a, blocks, c->stream); break;
 		TNT_LMAX_LADDER(X)
+#undef X
+#define X(N) case N | BUCKET_EXACT: tnt::launch_bind_exact_##N(a, blocks, c->stream); break;
+		TNT_EXACT_LADDER(X)
 #undef X
 	default: break;
 	}
@@ -425,16 +441,18 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const uint32_t *src, const uint32
 	k.slots = c->slots.p;
 	k.dst = c->qbucket.p;
 	k.cap = uint32_t(ITEM_CAP);
-	k.dst_count = cnt + C_BUCKET;
+	k.counters = cnt + C_BUCKET;
 	k.n_buckets = int(c->bucket_lmax.size());
-	k.merge_below = uint32_t(c->bind_blocks) * BIND_THREADS * 2u;
+	k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads_for(c->bucket_lmax.back() & 0xFF));
 	k.err = cnt + C_ERR;
-	hipLaunchKernelGGL(bucket_kernel, dim3(1024), dim3(256), 0, c->stream, k);
+	hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
+	hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	for (size_t i = 0; i < c->bucket_lmax.size(); i++) {
-		b.index = c->qbucket.p + i * ITEM_CAP;
+		b.index = c->qbucket.p;
+		b.index_base_dev = cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
-		launch_bind(c, b, c->bind_blocks, c->bucket_lmax[i]);
+		launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i]);
 	}
 }
 
@@ -444,13 +462,25 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 	c->scratch_lmax = std::max(c->scratch_lmax, need_lmax);
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, c->device), c->err);
-	c->bind_blocks = prop.multiProcessorCount * 4;
-	const size_t lm = size_t(c->scratch_lmax), wm = lm + 2 * FLANK, nc = lm + wm + 4;
-	HIP_TRY(c->trace.alloc(size_t(c->bind_blocks) * lm * wm * BIND_THREADS), c->err);
-	HIP_TRY(c->cols.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
-	HIP_TRY(c->best.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
-	HIP_TRY(c->stack.alloc(size_t(c->bind_blocks) * nc * BIND_THREADS), c->err);
-	HIP_TRY(c->ties.alloc(size_t(c->bind_blocks) * TIE_CAP * BIND_THREADS), c->err);
+	c->n_cu = prop.multiProcessorCount;
+	c->bind_blocks = c->n_cu * 4;
+	// per-workgroup slabs, sized for the most demanding instance this context launches
+	std::vector<int> inst = c->bucket_lmax;
+	inst.push_back(c->scratch_lmax);
+	size_t n_trace = 0, n_cols = 0, n_ties = 0;
+	for (int id : inst) {
+		const int l = id & 0xFF;
+		const size_t lanes = size_t(bind_grid(c, l)) * bind_threads_for(l);
+		const size_t lm = size_t(l), wm = lm + 2 * FLANK, nc = lm + wm + 4;
+		n_trace = std::max(n_trace, lanes * lm * wm);
+		n_cols = std::max(n_cols, lanes * nc);
+		n_ties = std::max(n_ties, lanes * TIE_CAP);
+	}
+	HIP_TRY(c->trace.alloc(n_trace), c->err);
+	HIP_TRY(c->cols.alloc(n_cols), c->err);
+	HIP_TRY(c->best.alloc(n_cols), c->err);
+	HIP_TRY(c->stack.alloc(n_cols), c->err);
+	HIP_TRY(c->ties.alloc(n_ties), c->err);
 	return TNT_OK;
 }
 
@@ -463,7 +493,7 @@ int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 		HIP_TRY(c->active.alloc(GROUP_CAP), c->err);
 		HIP_TRY(c->qa.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->qb.alloc(ITEM_CAP), c->err);
-		HIP_TRY(c->qbucket.alloc(ITEM_CAP * std::max<size_t>(1, c->bucket_lmax.size())), c->err);
+		HIP_TRY(c->qbucket.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
 		HIP_TRY(c->hits.alloc(HIT_CAP), c->err);
 		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
@@ -659,15 +689,19 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	}
 	c->lmax = pick_lmax(max_L);
 	{
+		// buckets: one per instance in use, in ascending length; the last one is the general instance that
+		// takes the longest oligo (short queues are bound there as a whole)
+		auto by_len = [](int a, int b) { return (a & 0xFF) != (b & 0xFF) ? (a & 0xFF) < (b & 0xFF) : a > b; };
 		std::vector<int> used;
 		for (const Slot &sl : c->h_slots)
-			if (sl.oligo >= 0) used.push_back(pick_lmax(c->oligos[sl.oligo].size()));
-		std::sort(used.begin(), used.end());
+			if (sl.oligo >= 0) used.push_back(pick_instance(c->oligos[sl.oligo].size()));
+		used.push_back(c->lmax);
+		std::sort(used.begin(), used.end(), by_len);
 		used.erase(std::unique(used.begin(), used.end()), used.end());
 		c->bucket_lmax = used;
 		for (Slot &sl : c->h_slots)
 			if (sl.oligo >= 0)
-				sl.bucket = int32_t(std::lower_bound(used.begin(), used.end(), pick_lmax(c->oligos[sl.oligo].size())) - used.begin());
+				sl.bucket = int32_t(std::lower_bound(used.begin(), used.end(), pick_instance(c->oligos[sl.oligo].size()), by_len) - used.begin());
 	}
 
 	// ---- tables
@@ -1195,7 +1229,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	b.n_items = uint32_t(n);
 	b.n_items_dev = nullptr;
 	b.full = dfull.p;
-	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + BIND_THREADS - 1) / BIND_THREADS)), 0);
+	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + bind_threads_for(64) - 1) / bind_threads_for(64))), 0);
 	HIP_TRY(hipGetLastError(), ctx->err);
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);

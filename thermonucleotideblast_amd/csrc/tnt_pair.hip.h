@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
 
 // Distribute a queue of item indices over the length buckets of their oligos: every bucket is bound by the
 // kernel instance with exactly that many rows (no padding rows, uniform trip counts inside a wavefront).
+// Two passes: count (bucket sizes), scatter (exclusive offsets -> one compact array, bucket after bucket).
 struct BucketArgs {
 	const uint32_t *src;          // item indices
 	const uint32_t *src_count;    // flat source: number of entries
@@ -245,9 +246,9 @@ struct BucketArgs {
 	uint32_t shard_region;
 	const Item *items;
 	const Slot *slots;
-	uint32_t *dst;                // [n_buckets][cap]
+	uint32_t *dst;                // compact output, `cap` entries
 	uint32_t cap;
-	uint32_t *dst_count;          // [n_buckets * BUCKET_STRIDE]
+	uint32_t *counters;           // per bucket BUCKET_STRIDE words: [0] size, [1] scatter cursor, [2] first entry in dst
 	int n_buckets;
 	uint32_t merge_below;         // a queue shorter than this goes to the last (longest) bucket as a whole: one launch
 	                              // with padding rows beats one under-filled launch per bucket
@@ -256,16 +257,24 @@ struct BucketArgs {
 
 constexpr int BUCKET_PER_THREAD = 4;
 
-__global__ __launch_bounds__(256) void bucket_kernel(BucketArgs a)
+template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(BucketArgs a)
 {
 	__shared__ uint32_t s_pre[N_SHARD + 1];
-	__shared__ uint32_t s_cnt[MAX_BUCKETS], s_base[MAX_BUCKETS];
+	__shared__ uint32_t s_cnt[MAX_BUCKETS], s_base[MAX_BUCKETS], s_first[MAX_BUCKETS];
 	const int tid = threadIdx.x;
-	if (a.shard_counts) {
-		shard_prefix(a.shard_counts, s_pre, tid);
-		__syncthreads();
+	if (a.shard_counts) shard_prefix(a.shard_counts, s_pre, tid);
+	if (SCATTER && tid == 0) {
+		uint32_t run = 0;
+		for (int b = 0; b < a.n_buckets; b++) {
+			s_first[b] = run;
+			if (blockIdx.x == 0) a.counters[b * BUCKET_STRIDE + 2] = run;
+			run += a.counters[b * BUCKET_STRIDE];
+		}
 	}
-	const uint32_t n = a.shard_counts ? s_pre[N_SHARD] : *a.src_count;
+	__syncthreads();
+	const uint32_t n_all = a.shard_counts ? s_pre[N_SHARD] : *a.src_count;
+	const uint32_t n = n_all < a.cap ? n_all : a.cap;
+	if (n_all > a.cap && blockIdx.x == 0 && tid == 0) atomicOr(a.err, ERR_ITEM_OVERFLOW);
 	constexpr uint32_t STEP = 256 * BUCKET_PER_THREAD;
 	for (uint32_t base = blockIdx.x * STEP; base < n; base += gridDim.x * STEP) {
 		if (tid < MAX_BUCKETS) s_cnt[tid] = 0;
@@ -282,16 +291,14 @@ __global__ __launch_bounds__(256) void bucket_kernel(BucketArgs a)
 			}
 		}
 		__syncthreads();
-		if (tid < a.n_buckets && s_cnt[tid]) s_base[tid] = atomicAdd(a.dst_count + tid * BUCKET_STRIDE, s_cnt[tid]);
+		if (tid < a.n_buckets && s_cnt[tid]) s_base[tid] = atomicAdd(a.counters + tid * BUCKET_STRIDE + (SCATTER ? 1 : 0), s_cnt[tid]);
 		__syncthreads();
+		if (SCATTER) {
 #pragma unroll
-		for (int m = 0; m < BUCKET_PER_THREAD; m++)
-			if (bkt[m] != 0xFFFFFFFFu) {
-				const uint32_t o = s_base[bkt[m]] + pos[m];
-				if (o < a.cap) a.dst[size_t(bkt[m]) * a.cap + o] = idx[m];
-				else atomicOr(a.err, ERR_ITEM_OVERFLOW);
-			}
-		__syncthreads();
+			for (int m = 0; m < BUCKET_PER_THREAD; m++)
+				if (bkt[m] != 0xFFFFFFFFu) a.dst[s_first[bkt[m]] + s_base[bkt[m]] + pos[m]] = idx[m];
+			__syncthreads();
+		}
 	}
 }
 
