@@ -82,6 +82,8 @@
 #define I_CNDMASK_K(r) "v_cndmask_b32 " r ", %8, %9, vcc\n"
 #define I_NOT(r) "v_not_b32 " r ", " r "\n"
 #define I_BFREV(r) "v_bfrev_b32 " r ", " r "\n"
+#define I_ADDSDWA(r) "v_add_u32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I_ADDSDWA_W(r) "v_add_u32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
 #define I_MAXI_VOP3(r) "v_max_i32_e64 " r ", " r ", %8\n"
 #define I_SUB_VOP3(r) "v_sub_u32_e64 " r ", " r ", %8\n"
 
@@ -93,7 +95,7 @@
 	X(addc, I_ADDC) X(cmpaddc, I_CMPADDC) X(subco, I_SUBCO) X(cndmask, I_CNDMASK) X(pksub, I_PKSUB) X(pkmax, I_PKMAX)      \
 	X(pkaddu, I_PKADDU) X(perm, I_PERM) X(sad, I_SAD) X(subf, I_SUBF) X(addf, I_ADDF) X(mulf, I_MULF) X(minf, I_MINF)       \
 	X(max3f, I_MAX3F) X(cmpgtf, I_CMPGTF) X(cvtif, I_CVTIF) X(subdep, I_SUBDEP) X(maxi16, I_MAXI16) X(subrev, I_SUBREV)    \
-	X(dot4, I_DOT4) X(mullo, I_MULLO) X(addlshl, I_ADDLSHL) X(xad, I_XAD) X(cndmask_s, I_CNDMASK_S) X(cmpcnd, I_CMPCND) X(cndmask_k, I_CNDMASK_K) X(not_, I_NOT) X(bfrev, I_BFREV) X(maxi_vop3, I_MAXI_VOP3) X(sub_vop3, I_SUB_VOP3)
+	X(dot4, I_DOT4) X(mullo, I_MULLO) X(addlshl, I_ADDLSHL) X(xad, I_XAD) X(cndmask_s, I_CNDMASK_S) X(cmpcnd, I_CMPCND) X(cndmask_k, I_CNDMASK_K) X(not_, I_NOT) X(bfrev, I_BFREV) X(add_sdwa_b, I_ADDSDWA) X(add_sdwa_w, I_ADDSDWA_W) X(maxi_vop3, I_MAXI_VOP3) X(sub_vop3, I_SUB_VOP3)
 
 #define X(NAME, I) DEFINE(k_##NAME, I)
 LIST(X)

@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "tnt_dev.h"
 
 namespace tnt {
@@ -44,14 +45,14 @@ struct BindArgs {
 	uint32_t *pool_count;
 	BindFull *full;            // optional (unit-level API): full record per item
 	uint16_t *trace;           // scratch, per block slot
-	uint16_t *cols;
-	uint16_t *best;
+	uint8_t *best;             // scratch for the best alignment's columns (instances that do not keep them in LDS)
 	uint32_t *stack;
 	uint16_t *ties;            // [TIE_CAP][lane] further cells with the maximal score
 	uint32_t *err;
 	Group *groups;             // a group is put on the active list when its first item binds
 	uint32_t *active;
 	uint32_t *n_active;
+	uint32_t *debug;           // experimental builds only (TNT_EXP_STATS)
 };
 
 constexpr int TIE_CAP = 256;      // maximal cells of one DP beyond which the kernel reports ERR_TIE_OVERFLOW
@@ -77,13 +78,23 @@ __device__ __forceinline__ int db_same(int c) { return c < 5 ? c : c + 2; }
 __device__ const uint8_t c_db_comp[16] = {bT, bG, bC, bA, bI, bK, bY, bS, bB, bW, bR, bD, bM, bH, bV, bN};
 __device__ __forceinline__ int db_comp(int c) { return c_db_comp[c]; }
 
+// scoring scalars and the short ends of the loop / bulge entropy tables, staged in LDS for the serial tail
+struct TailConst {
+	float init_H, init_S, sym_S, at_H, at_S, salt, asym_S, bulge_at_S, temperature, log_na;
+	int32_t dangle5, dangle3;
+	float loop_S[64], bulge_S[64];
+};
+
 // per-lane evaluation context for the serial tail
 struct LaneCtx {
 	const Tables *tab;
 	const uint8_t *lut;       // LDS best_base_pair LUT
+	const uint8_t *hs_map;    // LDS: pair-stack index -> entry of hs_val
+	const float2 *hs_val;     // LDS: the distinct (param_H, param_S) pairs
+	const TailConst *k;       // LDS
 	const uint8_t *win;       // LDS window base of this lane: win[k * BIND_THREADS]
 	const uint8_t *query;     // global oligo bases 5'->3'
-	uint16_t *cols;           // scratch alignment columns of this lane, stride BIND_THREADS
+	uint8_t *cols;            // alignment columns of this lane (LDS), stride BIND_THREADS
 	int L, W;
 	float log_ct;
 };
@@ -93,9 +104,10 @@ __device__ __forceinline__ int lut_pair(const uint8_t *lut, int x, int y)
 	return ((x | y) < NB) ? x * NB + y : int(lut[x * 18 + y]);
 }
 
-__device__ __forceinline__ int col_q(uint16_t c) { return c & 31; }
-__device__ __forceinline__ int col_t(uint16_t c) { return (c >> 5) & 31; }
-__device__ __forceinline__ uint16_t mk_col(int q, int t) { return uint16_t(q | (t << 5)); }
+// one alignment column in a byte: query side (A C G T I $ -: 3 bits) | target side (18 codes: 5 bits) << 3
+__device__ __forceinline__ int col_q(uint8_t c) { return c & 7; }
+__device__ __forceinline__ int col_t(uint8_t c) { return c >> 3; }
+__device__ __forceinline__ uint8_t mk_col(int q, int t) { return uint8_t(q | (t << 3)); }
 
 struct Score {
 	float dH, dS, tm;
@@ -107,6 +119,14 @@ __device__ __forceinline__ uint32_t push_eq(uint32_t tw, int x, int y)
 {
 	asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(tw) : "v"(x), "v"(y) : "vcc");
 	return tw;
+}
+
+// x >> 31 as a full-rate shift (kept opaque: the compiler would turn it into a compare + select)
+__device__ __forceinline__ uint32_t sign_bit(int x)
+{
+	uint32_t r;
+	asm("v_lshrrev_b32 %0, 31, %1" : "=v"(r) : "v"(x));
+	return r;
 }
 
 struct AlignInfo {
@@ -123,15 +143,28 @@ template <int BIND_THREADS> // lane stride of the per-lane LDS / scratch slices
 __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode = MODE_HETERO_DIMER, float dH0 = 0.0f, float dS0 = 0.0f)
 {
 	const Tables &T = *c.tab;
-	const float *Hh = T.H, *Ss = T.S;
+	const TailConst &K = *c.k;
+	// param_H / param_S through the LDS copy: 152 distinct (H, S) pairs behind a byte map
+#define HS_ADD(IDX)                                              \
+	do {                                                         \
+		const float2 v_ = c.hs_val[c.hs_map[(IDX)]];             \
+		dH += v_.x;                                              \
+		dS += v_.y;                                              \
+	} while (0)
+#define HS_SUB(IDX)                                              \
+	do {                                                         \
+		const float2 v_ = c.hs_val[c.hs_map[(IDX)]];             \
+		dH -= v_.x;                                              \
+		dS -= v_.y;                                              \
+	} while (0)
 	const uint8_t *lut = c.lut;
 #define COLQ(k) col_q(c.cols[(k) * BIND_THREADS])
 #define COLT(k) col_t(c.cols[(k) * BIND_THREADS])
 	int terminal = P__, lastlast = P__, last = P__, curp = P__;
 	float dH = dH0, dS = dS0;
 	if (mode != MODE_HAIRPIN) { // :1627-1633
-		dH = T.init_H;
-		dS = T.init_S + (mode == MODE_HOMO_DIMER ? T.sym_S : 0.0f);
+		dH = K.init_H;
+		dS = K.init_S + (mode == MODE_HOMO_DIMER ? K.sym_S : 0.0f);
 	}
 	unsigned nqg = 0, ntg = 0, nmm = 0, num_base = 0;
 	bool terminal_5 = false;
@@ -143,8 +176,8 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 		if (is_wc(curp)) {
 			terminal_5 = true;
 			if (curp == P_AT || curp == P_TA) {
-				dH += T.at_H;
-				dS += T.at_S;
+				dH += K.at_H;
+				dS += K.at_S;
 			}
 		}
 		num_base += is_virtual(q0) ? 0 : 1;
@@ -152,7 +185,7 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 	}
 
 	for (int k = 1; k < n; k++) {
-		const uint16_t cw = c.cols[(k0 + k) * BIND_THREADS];
+		const uint8_t cw = c.cols[(k0 + k) * BIND_THREADS];
 		const int qk = col_q(cw), tk = col_t(cw);
 		lastlast = last;
 		last = curp;
@@ -163,21 +196,16 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 		if (!in_loop) {
 			if (align_start && !is_wc(last) && non_virtual_pair(last)) { // frayed start, :1726-1745
 				int tmp = lut_pair(lut, last / NB, bE);
-				dH += Hh[tmp * NBP + curp];
-				dS += Ss[tmp * NBP + curp];
+				HS_ADD(tmp * NBP + curp);
 				tmp = lut_pair(lut, bE, last % NB);
-				dH += Hh[tmp * NBP + curp];
-				dS += Ss[tmp * NBP + curp];
+				HS_ADD(tmp * NBP + curp);
 			} else if (align_stop && !is_wc(curp) && non_virtual_pair(curp)) { // frayed stop, :1747-1763
 				int tmp = lut_pair(lut, qk, bE);
-				dH += Hh[last * NBP + tmp];
-				dS += Ss[last * NBP + tmp];
+				HS_ADD(last * NBP + tmp);
 				tmp = lut_pair(lut, bE, tk);
-				dH += Hh[last * NBP + tmp];
-				dS += Ss[last * NBP + tmp];
+				HS_ADD(last * NBP + tmp);
 			} else {
-				dH += Hh[last * NBP + curp];
-				dS += Ss[last * NBP + curp];
+				HS_ADD(last * NBP + curp);
 			}
 			num_base += is_virtual(qk) ? 0 : 1;
 			num_base += is_virtual(tk) ? 0 : 1;
@@ -188,8 +216,8 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 			if (!terminal_5) {
 				terminal_5 = true;
 				if (curp == P_AT || curp == P_TA) {
-					dH += T.at_H;
-					dS += T.at_S;
+					dH += K.at_H;
+					dS += K.at_S;
 				}
 			}
 			const unsigned max_gap = nqg > ntg ? nqg : ntg;
@@ -197,18 +225,15 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 				const unsigned gap_diff = (nqg > ntg) ? nqg - ntg : ntg - nqg;
 				const unsigned loop_size = nmm * 2 + gap_diff;
 				if (loop_size == 2 && (last == P_GT || last == P_TG) && (lastlast == P_GT || lastlast == P_TG)) {
-					dH += Hh[lastlast * NBP + last];
-					dS += Ss[lastlast * NBP + last];
+					HS_ADD(lastlast * NBP + last);
 					num_base += 2;
 				} else {
-					dS += T.loop_S[loop_size];
-					dS += float(gap_diff) * T.asym_S;
+					dS += loop_size < 64u ? K.loop_S[loop_size] : T.loop_S[loop_size];
+					dS += float(gap_diff) * K.asym_S;
 					int rhs_q = k - 1, rhs_t = k - 1;
-					dH -= Hh[last * NBP + curp];
-					dS -= Ss[last * NBP + curp];
+					HS_SUB(last * NBP + curp);
 					if (!pair_has_gap(last)) { // right terminal mismatch, :1923-1935
-						dH += Hh[last * NBP + curp];
-						dS += Ss[last * NBP + curp];
+						HS_ADD(last * NBP + curp);
 					} else { // :1936-1992
 						int mm = P__;
 						if (last / NB == bGAP) {
@@ -232,8 +257,7 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 								rhs_t--;
 							}
 						}
-						dH += Hh[mm * NBP + curp];
-						dS += Ss[mm * NBP + curp];
+						HS_ADD(mm * NBP + curp);
 					}
 					// left terminal mismatch, :2000-2077
 					int lhs_q = k - 1, lhs_t = k - 1;
@@ -243,16 +267,14 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 							lhs_q++, lhs_t++;
 							if (COLQ(k0 + lhs_q) != bGAP && COLT(k0 + lhs_t) != bGAP) {
 								const int mm = lut_pair(lut, COLQ(k0 + lhs_q), COLT(k0 + lhs_t));
-								dH -= Hh[pm * NBP + mm];
-								dS -= Ss[pm * NBP + mm];
+								HS_SUB(pm * NBP + mm);
 							} else {
 								num_base += 2;
 								while (COLQ(k0 + lhs_q) == bGAP) lhs_q++;
 								while (COLT(k0 + lhs_t) == bGAP) lhs_t++;
 							}
 							const int mm = lut_pair(lut, COLQ(k0 + lhs_q), COLT(k0 + lhs_t));
-							dH += Hh[pm * NBP + mm];
-							dS += Ss[pm * NBP + mm];
+							HS_ADD(pm * NBP + mm);
 							break;
 						}
 						if (lhs_q == 0) break;
@@ -264,18 +286,17 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 			} else if (nqg || ntg) { // bulge, :2105-2185
 				const unsigned bulge = nqg > ntg ? nqg : ntg;
 				if (bulge == 1) {
-					dH += Hh[lastlast * NBP + curp];
-					dS += Ss[lastlast * NBP + curp];
+					HS_ADD(lastlast * NBP + curp);
 				}
-				dS += T.bulge_S[bulge];
-				if (bulge != 1 && (qk == bA || qk == bT)) dS += T.bulge_at_S;
+				dS += bulge < 64u ? K.bulge_S[bulge] : T.bulge_S[bulge];
+				if (bulge != 1 && (qk == bA || qk == bT)) dS += K.bulge_at_S;
 				if (bulge != 1) { // has_AT_initiation, :2888-2905
 					int i = k;
 					do {
 						i--;
 					} while (i != 0 && (COLQ(k0 + i) == bGAP || COLT(k0 + i) == bGAP));
 					const int p = lut_pair(lut, COLQ(k0 + i), COLT(k0 + i));
-					if (p == P_AT || p == P_TA) dS += T.bulge_at_S;
+					if (p == P_AT || p == P_TA) dS += K.bulge_at_S;
 				}
 			}
 			nqg = ntg = nmm = 0;
@@ -288,8 +309,8 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 #undef COLQ
 #undef COLT
 	if (terminal == P_AT || terminal == P_TA) {
-		dH += T.at_H;
-		dS += T.at_S;
+		dH += K.at_H;
+		dS += K.at_S;
 	}
 	Score s;
 	s.dH = dH;
@@ -297,7 +318,7 @@ __device__ Score evaluate_alignment(const LaneCtx &c, int k0, int k1, int mode =
 	s.tm = 0.0f;
 	s.ok = false;
 	if (dH >= 0.0f) return s; // :2253
-	dS += T.salt * (0.5f * float(num_base) - 1.0f) * T.log_na; // :2270
+	dS += K.salt * (0.5f * float(num_base) - 1.0f) * K.log_na; // :2270
 	const float tm = (mode == MODE_HAIRPIN) ? dH / dS - 273.15f // :2286-2289
 	                                        : dH / (1.9872e-3f * c.log_ct + dS) - 273.15f; // :2291
 	s.dS = dS;
@@ -341,8 +362,9 @@ __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const Ali
 		if (last_pair == P_AT || last_pair == P_TA) dS += T.bulge_at_S;
 	} else {
 		const int curp = lut_pair(c.lut, HQ(last_5 + 1), HQ(last_3 - 1));
-		dH += T.H[last_pair * NBP + curp]; // param_hairpin_terminal == param (nuc_cruc_santa_lucia.cpp:594-603)
-		dS += T.S[last_pair * NBP + curp];
+		const float2 v_ = c.hs_val[c.hs_map[last_pair * NBP + curp]]; // param_hairpin_terminal == param (nuc_cruc_santa_lucia.cpp:594-603)
+		dH += v_.x;
+		dS += v_.y;
 	}
 #undef HQ
 	return evaluate_alignment<BIND_THREADS>(c, al.k0, al.k1, MODE_HAIRPIN, dH, dS);
@@ -350,15 +372,18 @@ __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const Ali
 
 // The bind kernel proper.  LMAX = rows kept in registers (oligos of this launch have L <= LMAX).
 // EXACT: every item of the launch has L == LMAX (the host buckets the queues by length).
-template <int LMAX, bool FULL, bool EXACT = false>
-__global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a)
+// PLAIN: no window of the launch holds a degenerate (IUPAC) target base (the bucket kernel routes windows that
+// do to a general instance), so rt(t, q) = t and the table address splits into column and row constants.
+template <int LMAX, bool FULL, bool EXACT = false, bool PLAIN = false>
+__global__ __launch_bounds__(bind_threads_for(LMAX), (LMAX <= 40 ? 2 : 1)) void bind_kernel(BindArgs a)
 {
-	static_assert(!(FULL && EXACT), "the unit-level instance takes any length");
+	static_assert(!(FULL && (EXACT || PLAIN)), "the unit-level instance takes any length and any target base");
 	constexpr int BIND_THREADS = bind_threads_for(LMAX);
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NCOLS = LMAX + WMAX + 4;
 
-	__shared__ int2 s_dg2[NBP * NBP];  // {delta_g(prev, cur), term(cur)}
+	constexpr int DG_PLANE = 38 * 64;  // ints per plane: ds_read2st64_b32 reaches the second plane with one offset
+	__shared__ int32_t s_dgp[2 * DG_PLANE]; // plane 0: delta_g(prev, cur), plane 1: term(cur); index: see the fill loop
 	__shared__ int32_t s_term[NBP];
 	__shared__ int32_t s_const[4];
 	__shared__ uint32_t s_rt[18];
@@ -366,21 +391,41 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 	__shared__ uint8_t s_win[WMAX * BIND_THREADS];
 	constexpr bool QRY_LDS = LMAX <= 32;             // larger instances keep the LDS budget for two workgroups per CU
 	__shared__ uint8_t s_qry[QRY_LDS ? LMAX * BIND_THREADS : 1]; // oligo bases of every lane, row order (row i-1 = query[L-i])
-	__shared__ uint16_t s_cols[NCOLS * BIND_THREADS]; // alignment columns of the path being scored
+	__shared__ uint8_t s_cols[NCOLS * BIND_THREADS]; // alignment columns of the path being scored
+	constexpr bool BEST_LDS = LMAX <= 28;             // columns of the best path so far: LDS while two workgroups per CU still fit
+	__shared__ uint8_t s_best[BEST_LDS ? NCOLS * BIND_THREADS : 1];
+	__shared__ uint8_t s_hs_map[NBP * NBP + 3];
+	__shared__ float2 s_hs_val[256];
+	__shared__ TailConst s_k;
+	constexpr int PF = 8;                            // trace words fetched ahead along the traceback's diagonal
+	__shared__ uint16_t s_pf[PF * BIND_THREADS];
 
 	const int tid = threadIdx.x;
-	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) s_dg2[i] = make_int2(a.tab->dg[i], a.tab->term[i % NBP]);
+	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) {
+		const int p = i / NBP, cpair = i % NBP; // prev pair (x', q'), current pair (x, q)
+		const int at = ((p / NB) * NB + cpair / NB) * NBP + (p % NB) * NB + cpair % NB;
+		s_dgp[at] = a.tab->dg[i];
+		s_dgp[DG_PLANE + at] = a.tab->term[cpair];
+	}
 	if (tid < NBP) s_term[tid] = a.tab->term[tid];
 	if (tid < 4) s_const[tid] = a.tab->dg_const[tid];
 	for (int i = tid; i < 18 * 18; i += BIND_THREADS) s_lut[i] = a.tab->bbp[i];
 	if (tid < 18) s_rt[tid] = a.tab->rt[tid];
+	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) s_hs_map[i] = a.tab->hs_map[i];
+	for (int i = tid; i < 256; i += BIND_THREADS) s_hs_val[i] = make_float2(a.tab->hs_H[i], a.tab->hs_S[i]);
+	if (tid < 64) s_k.loop_S[tid] = a.tab->loop_S[tid], s_k.bulge_S[tid] = a.tab->bulge_S[tid];
+	if (tid == 0) {
+		const Tables &t = *a.tab;
+		s_k.init_H = t.init_H, s_k.init_S = t.init_S, s_k.sym_S = t.sym_S, s_k.at_H = t.at_H, s_k.at_S = t.at_S;
+		s_k.salt = t.salt, s_k.asym_S = t.asym_S, s_k.bulge_at_S = t.bulge_at_S, s_k.temperature = t.temperature, s_k.log_na = t.log_na;
+		s_k.dangle5 = t.dangle5, s_k.dangle3 = t.dangle3;
+	}
 	__syncthreads();
 
-	const Tables &T = *a.tab;
 	uint16_t *trace = a.trace + size_t(blockIdx.x) * (size_t(LMAX) * WMAX * BIND_THREADS) + tid;
-	uint16_t *cols = s_cols + tid;
+	uint8_t *cols = s_cols + tid;
 	uint8_t *qry = s_qry + tid;
-	uint16_t *best = a.best + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
+	uint8_t *best = BEST_LDS ? s_best + tid : a.best + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
 	uint32_t *stack = a.stack + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
 	uint16_t *ties = a.ties + size_t(blockIdx.x) * (size_t(TIE_CAP) * BIND_THREADS) + tid;
 	uint8_t *win = s_win + tid;
@@ -452,6 +497,9 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 			}
 		}
 
+#ifdef TNT_EXP_STATS
+		const long long st_fill0 = __builtin_readcyclecounter();
+#endif
 		// ------------------------------------------------------------------ DP fill (align_dimer, nuc_cruc.cpp:492-696)
 		// Column-major sweep, one column per iteration, all LMAX rows unrolled and branch-free: rows
 		// beyond L and columns beyond W compute throw-away values (their trace words land in scratch
@@ -474,6 +522,18 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 #pragma unroll
 			for (int i = 0; i < LMAX; i++) qry[i * BIND_THREADS] = uint8_t((qpk[i >> 2] >> ((i & 3) * 8 + 2)) & 7u);
 		}
+		// per-row part of the table address: 4 * (7 * q' + q), q' = base of the row above (GAP above row 1)
+		uint32_t Rpk[(LMAX + 3) / 4];
+		{
+			uint32_t qprev4 = 4u * bGAP;
+#pragma unroll
+			for (int i = 0; i < LMAX; i++) {
+				const uint32_t q4 = (qpk[i >> 2] >> ((i & 3) * 8)) & 255u;
+				if ((i & 3) == 0) Rpk[i >> 2] = 0;
+				Rpk[i >> 2] |= (7u * qprev4 + q4) << ((i & 3) * 8);
+				qprev4 = q4;
+			}
+		}
 
 		int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
@@ -481,13 +541,14 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 
 		int gmax = -1, nmax = 0, max_ij = 0;
 		uint32_t prtw = s_rt[bGAP];
+		int pt = bGAP; // target base of the previous column
 		// uniform trip count over the wavefront keeps the unrolled body convergent
 		int Wwave = W;
 		for (int o = 32; o > 0; o >>= 1) {
 			const int other = __shfl_xor(Wwave, o);
 			Wwave = other > Wwave ? other : Wwave;
 		}
-		const char *sdg = reinterpret_cast<const char *>(s_dg2);
+		const char *sdg = reinterpret_cast<const char *>(s_dgp);
 		const char *sterm = reinterpret_cast<const char *>(s_term);
 		const int c_bulge = s_const[0], c_zero = s_const[1], c_forb_m = s_const[2], c_forb_xy = s_const[3];
 		uint16_t *tcol = trace;
@@ -505,86 +566,110 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 			int term_up = 0;                                     // term(cur) of the row above
 			// keep the per-row constants from being hoisted out of the column loop (register pressure)
 #pragma unroll
-			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(qpk[w]));
+			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(qpk[w]), "+v"(Rpk[w]));
 			// The two LDS reads of a row are issued one row ahead (their addresses depend on the bases only),
 			// so their latency overlaps the arithmetic of the previous row.
-			int2 e_n;
-			int tp4_n, p4_4_n;
+			//
+			// Table index (s_dgp): ((x' * 7 + x) * 49 + q' * 7 + q with prev pair (x', q') and current pair (x, q),
+			// x = rt(t, q).  Without degenerate target bases (x = t, x' = pt) the address splits into a per-column
+			// and a per-row constant: one add per read.
 			{
-				const int q4 = int(qpk[0] & 31u);
-				const int rtq = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
-				const int prtq = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
-				p4_4_n = prtq * 28 + q4;                           // 4 * bp(pt, q)
-				const int p1_392 = (int((prtw >> 24) & 15u) * NB + bGAP) * 392; // row 1: 392 * bp(pt, GAP)
-				e_n = *reinterpret_cast<const int2 *>(sdg + p1_392 + rtq * 56 + 2 * q4); // {g(prev, bp(t,q)), term}
-				tp4_n = *reinterpret_cast<const int *>(sterm + p4_4_n);
-			}
-#pragma unroll
-			for (int i = 1; i <= LMAX; i++) {
-				const int2 e = e_n;
-				const int term_p4 = tp4_n;
-				const int p4_4 = p4_4_n;
-				if (i < LMAX) {
-					const int q4 = int((qpk[i >> 2] >> ((i & 3) * 8)) & 31u);
-					const int rtq = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
-					const int prtq = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
-					p4_4_n = prtq * 28 + q4;
-					e_n = *reinterpret_cast<const int2 *>(sdg + p4_4 * 98 + rtq * 56 + 2 * q4); // prev = bp(pt, q of this row)
-					tp4_n = *reinterpret_cast<const int *>(sterm + p4_4_n);
-				}
-				// oQ / oT are stored clamped at zero; so is oM in the throughput instances (the unit-level instance
-				// keeps M itself: it reports dp_max / n_max also when no cell is positive)
-				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
-				const int termv = e.y;
-
-				const int dg1 = (FULL ? (aM > 0 ? aM : 0) : aM) - e.x;
-				const int dg2 = aQ - (firstcol ? c_forb_m : termv);
-				const int dg3 = aT - (i == 1 ? c_forb_m : termv);
-				// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits.
-				// The trace word is built as a shift register, one v_alignbit (sign bit) per flag; equalities are
-				// taken as "not less than the maximum" (a full-rate subtract feeds the sign).  Layout: TW_* in tnt_dev.h.
-				int M = dg1 > dg2 ? dg1 : dg2;
-				M = M > dg3 ? M : dg3;
-				const int iqi = (FULL ? (cM > 0 ? cM : 0) : cM) - term_p4;
-				const int iqe = cQ - v5;
-				const int Iq = iqi > iqe ? iqi : iqe;
-				const int iti = (FULL ? (bM > 0 ? bM : 0) : bM) - (i == 1 ? c_forb_xy : term_up);
-				const int ite = bT - (i == 1 ? c_zero : c_bulge);
-				const int It = iti > ite ? iti : ite;
-
-				uint32_t tw = 0;
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg1 - M), 31);   // set: M did not come from M        (im1_jm1)
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg3 - M), 31);   // set: M did not come from I_target (im1_j)
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg2 - M), 31);   // set: M did not come from I_query  (i_jm1)
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - iqe), 31); // insert < extend: I_query only from I_query
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - iqi), 31); // extend < insert: I_query only from M
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - ite), 31);
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - iti), 31);
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(M), 31);         // M < 0
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(M - 1), 31);     // M <= 0
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(Iq), 31);        // I_query < 0
-				tw = __builtin_amdgcn_alignbit(tw, uint32_t(It), 31);        // I_target < 0
-				tcol[(i - 1) * BIND_THREADS] = uint16_t(tw);
-
-				// column maximum over the valid rows; the running maximum is updated once per column below
-				if (EXACT) {
-					if (i & 1) {
-						if (i == LMAX) colmax = colmax > M ? colmax : M;
-						else held = M;
+				int colbase = PLAIN ? pt * (4 * 343) + t * (4 * 49) : 0;
+				int pt28 = pt * 28;
+				int xp = int((prtw >> 24) & 15u); // rt(pt, GAP): row 0 of the previous column
+				int ea_n, ta_n;                   // byte addresses of the next row's reads
+				int e_x_n, e_y_n, tp4_n;
+				{
+					const int q4 = int(qpk[0] & 255u), r4 = int(Rpk[0] & 255u);
+					if (PLAIN) {
+						ea_n = colbase + r4;
+						ta_n = pt28 + q4;
 					} else {
-						const int m2 = held > M ? held : M; // one v_max3 per two rows
-						colmax = colmax > m2 ? colmax : m2;
+						const int x = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
+						ea_n = xp * (4 * 343) + x * (4 * 49) + r4;
+						xp = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
+						ta_n = xp * 28 + q4;
 					}
-				} else {
-					const int Mv = (i <= Lcol) ? M : INT32_MIN;
-					colmax = colmax > Mv ? colmax : Mv;
+					e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
+					e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
+					tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
 				}
+#pragma unroll
+				for (int i = 1; i <= LMAX; i++) {
+					const int2 e = make_int2(e_x_n, e_y_n);
+					const int term_p4 = tp4_n;
+					// the reads stay one row ahead: without this fence the scheduler hoists every row's (independent)
+					// reads to the top of the column and the results do not fit the register budget
+					if (PLAIN && i > 1) asm volatile("" : "+v"(colbase), "+v"(pt28) : "v"(bM));
+					if (i < LMAX) {
+						const int q4 = int((qpk[i >> 2] >> ((i & 3) * 8)) & 255u), r4 = int((Rpk[i >> 2] >> ((i & 3) * 8)) & 255u);
+						if (PLAIN) {
+							ea_n = colbase + r4;
+							ta_n = pt28 + q4;
+						} else {
+							const int x = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
+							ea_n = xp * (4 * 343) + x * (4 * 49) + r4; // xp = rt(pt, q of the row above)
+							xp = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
+							ta_n = xp * 28 + q4;
+						}
+						e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
+						e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
+						tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
+					}
+					// oQ / oT are stored clamped at zero; so is oM in the throughput instances (the unit-level instance
+					// keeps M itself: it reports dp_max / n_max also when no cell is positive)
+					const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
+					const int termv = e.y;
 
-				const int Mc = FULL ? M : (M > 0 ? M : 0);
-				aM = cM, aQ = cQ, aT = cT;
-				bM = Mc, bT = It > 0 ? It : 0;
-				oM[i - 1] = Mc, oQ[i - 1] = Iq > 0 ? Iq : 0, oT[i - 1] = bT;
-				term_up = termv;
+					const int dg1 = (FULL ? (aM > 0 ? aM : 0) : aM) - e.x;
+					const int dg2 = aQ - (firstcol ? c_forb_m : termv);
+					const int dg3 = aT - (i == 1 ? c_forb_m : termv);
+					// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits.
+					// The trace word is built as a shift register, one v_alignbit (sign bit) per flag; equalities are
+					// taken as "not less than the maximum" (a full-rate subtract feeds the sign).  Layout: TW_* in tnt_dev.h.
+					int M = dg1 > dg2 ? dg1 : dg2;
+					M = M > dg3 ? M : dg3;
+					const int iqi = (FULL ? (cM > 0 ? cM : 0) : cM) - term_p4;
+					const int iqe = cQ - v5;
+					const int Iq = iqi > iqe ? iqi : iqe;
+					const int iti = (FULL ? (bM > 0 ? bM : 0) : bM) - (i == 1 ? c_forb_xy : term_up);
+					const int ite = bT - (i == 1 ? c_zero : c_bulge);
+					const int It = iti > ite ? iti : ite;
+
+					uint32_t tw;
+					tw = sign_bit(dg1 - M);                                      // set: M did not come from M        (im1_jm1)
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg3 - M), 31);   // set: M did not come from I_target (im1_j)
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg2 - M), 31);   // set: M did not come from I_query  (i_jm1)
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - iqe), 31); // insert < extend: I_query only from I_query
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - iqi), 31); // extend < insert: I_query only from M
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - ite), 31);
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - iti), 31);
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(M), 31);         // M < 0
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(M - 1), 31);     // M <= 0
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(Iq), 31);        // I_query < 0
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(It), 31);        // I_target < 0
+					tcol[(i - 1) * BIND_THREADS] = uint16_t(tw);
+
+					// column maximum over the valid rows; the running maximum is updated once per column below
+					if (EXACT) {
+						if (i & 1) {
+							if (i == LMAX) colmax = colmax > M ? colmax : M;
+							else held = M;
+						} else {
+							const int m2 = held > M ? held : M; // one v_max3 per two rows
+							colmax = colmax > m2 ? colmax : m2;
+						}
+					} else {
+						const int Mv = (i <= Lcol) ? M : INT32_MIN;
+						colmax = colmax > Mv ? colmax : Mv;
+					}
+
+					const int Mc = FULL ? M : (M > 0 ? M : 0);
+					aM = cM, aQ = cQ, aT = cT;
+					bM = Mc, bT = It > 0 ? It : 0;
+					oM[i - 1] = Mc, oQ[i - 1] = Iq > 0 ? Iq : 0, oT[i - 1] = bT;
+					term_up = termv;
+				}
 			}
 			if (EXACT && !colok) colmax = INT32_MIN;
 			// Running maximum, nuc_cruc.cpp:670-691.  The reference visits cells row-major; here the visiting
@@ -610,6 +695,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 				}
 			}
 			prtw = rtw;
+			pt = t;
 			tcol += LMAX * BIND_THREADS;
 		}
 
@@ -623,6 +709,9 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 		LaneCtx c;
 		c.tab = a.tab;
 		c.lut = s_lut;
+		c.hs_map = s_hs_map;
+		c.hs_val = s_hs_val;
+		c.k = &s_k;
 		c.win = win;
 		c.query = a.olig_base + size_t(slot.oligo) * MAX_OLIGO;
 		c.cols = cols;
@@ -630,6 +719,10 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 		c.W = W;
 		c.log_ct = slot.log_ct;
 
+#ifdef TNT_EXP_STATS
+		long long st_trace = 0, st_trim = 0, st_eval = 0;
+		const long long st_tail0 = __builtin_readcyclecounter();
+#endif
 		bool best_valid = false;
 		float best_dH = 0.0f, best_dS = 0.0f, best_tm = 0.0f;
 		AlignInfo bi = {0, 0, 0, 0, 0, 0};
@@ -665,13 +758,16 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 			int sp = 0;
 			int zero_count = -1;
 			unsigned trace_count = 0;
-			float best_dg = best_dH - T.temperature * best_dS;
+			float best_dg = best_dH - s_k.temperature * best_dS;
 			while (true) {
 				if (!first_time && sp == 0 && zero_count <= 0) break;
 				if (16u < trace_count) break;
 				trace_count++;
 				first_time = false;
 
+#ifdef TNT_EXP_STATS
+				const long long st_a = __builtin_readcyclecounter();
+#endif
 				// ---------------- trace_back, nuc_cruc.cpp:1409-1618
 				AlignInfo al;
 				al.k0 = 1;
@@ -691,6 +787,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 				}
 				int key = -1;
 				int mask = 1;
+				int pf_i = -1, pf_j = -1; // first cell of the diagonal run held in s_pf (none yet)
 				while (true) {
 					bool valid = true;
 					int local;
@@ -715,11 +812,22 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 					}
 					// border cells hold M = I_query = I_target = -1 (nuc_cruc.h:531-536)
 					const bool inside = (li >= 1 && lj >= 1);
-#ifdef TNT_EXP_NOTRACEREAD
-					const int tw = (inside && n < 9) ? int(TW_M_NOT_IT | TW_M_NOT_IQ) : (TW_M_NEG | TW_IQ_NEG | TW_IT_NEG);
-#else
-					const int tw = inside ? int(TRACE_AT(li, lj)) : (TW_M_NEG | TW_IQ_NEG | TW_IT_NEG);
-#endif
+					// The path mostly runs down a diagonal: PF cells of the current diagonal are fetched at once (one
+					// memory latency instead of one per step) and refilled when the walk leaves the run.
+					int tw = TW_M_NEG | TW_IQ_NEG | TW_IT_NEG;
+					if (inside) {
+						int d = pf_i - li;
+						if (pf_i < 0 || d < 0 || d >= PF || pf_j - lj != d) {
+							uint16_t v[PF];
+#pragma unroll
+							for (int k = 0; k < PF; k++) v[k] = (li - k >= 1 && lj - k >= 1) ? TRACE_AT(li - k, lj - k) : uint16_t(0);
+#pragma unroll
+							for (int k = 0; k < PF; k++) s_pf[k * BIND_THREADS + tid] = v[k];
+							pf_i = li, pf_j = lj;
+							d = 0;
+						}
+						tw = int(s_pf[d * BIND_THREADS + tid]);
+					}
 					const int cidx = li * (WMAX + 1) + lj;
 					if (local == 1) { // query_target
 						if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
@@ -768,17 +876,21 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 					if (!valid) break;
 				}
 				al.k1 = 1 + n;
+#ifdef TNT_EXP_STATS
+				const long long st_b = __builtin_readcyclecounter();
+				st_trace += st_b - st_a;
+#endif
 
 				// trim frayed ends, :1022-1054
 				while (al.k1 > al.k0) {
-					const uint16_t cw = cols[(al.k1 - 1) * BIND_THREADS];
+					const uint8_t cw = cols[(al.k1 - 1) * BIND_THREADS];
 					if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
 					if (!is_virtual(col_q(cw))) --al.lm_q;
 					if (!is_virtual(col_t(cw))) ++al.lm_t;
 					al.k1--;
 				}
 				while (al.k1 > al.k0) {
-					const uint16_t cw = cols[al.k0 * BIND_THREADS];
+					const uint8_t cw = cols[al.k0 * BIND_THREADS];
 					if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
 					if (!is_virtual(col_q(cw))) ++al.fm_q;
 					if (!is_virtual(col_t(cw))) --al.fm_t;
@@ -808,7 +920,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 	do {                                                                                             \
 		const Score s_ = (SCORE);                                                                    \
 		if (s_.ok) {                                                                                 \
-			const float local_dg = s_.dH - T.temperature * s_.dS;                                    \
+			const float local_dg = s_.dH - s_k.temperature * s_.dS;                                    \
 			if (!best_valid || local_dg < best_dg) { /* :1160-1167 */                                \
 				best_valid = true;                                                                   \
 				best_dg = local_dg;                                                                  \
@@ -847,7 +959,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 				}
 
 				// dangling ends, :1088-1137 (off by default, tntblast.h:55-56)
-				if (T.dangle5 && (al.fm_q != 0 || al.fm_t != W - 1)) {
+				if (s_k.dangle5 && (al.fm_q != 0 || al.fm_t != W - 1)) {
 					int qb, tb;
 					if (al.fm_q == 0) qb = bE;
 					else qb = QUERY(--al.fm_q);
@@ -857,7 +969,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 					al.k0--;
 					cols[al.k0 * BIND_THREADS] = mk_col(qb, tb);
 				}
-				if (T.dangle3 && (al.lm_q != L - 1 || al.lm_t != 0)) {
+				if (s_k.dangle3 && (al.lm_q != L - 1 || al.lm_t != 0)) {
 					int qb, tb;
 					if (al.lm_q == L - 1) qb = bE;
 					else qb = QUERY(++al.lm_q);
@@ -867,18 +979,28 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 					al.k1++;
 				}
 				if (al.k1 - al.k0 < 3) continue; // :1148
+#ifdef TNT_EXP_STATS
+				const long long st_c = __builtin_readcyclecounter();
+				st_trim += st_c - st_b;
+#endif
 
 #ifndef TNT_EXP_NOEVAL
 				CONSIDER(evaluate_alignment<BIND_THREADS>(c, al.k0, al.k1, (FULL && xmode == 2) ? MODE_HOMO_DIMER : MODE_HETERO_DIMER));
+#endif
+#ifdef TNT_EXP_STATS
+				st_eval += __builtin_readcyclecounter() - st_c;
 #endif
 #undef CONSIDER
 			}
 		}
 
+#ifdef TNT_EXP_STATS
+		const long long st_thr0 = __builtin_readcyclecounter();
+#endif
 		// ------------------------------------------------------------------ thresholds, bind_oligo.cpp:600-714
 		const Thresh th = a.thresh[slot.thresh];
 		const float tm = best_tm;
-		const float dg = best_dH - T.temperature * best_dS; // delta_G(), nuc_cruc.h:1217
+		const float dg = best_dH - s_k.temperature * best_dS; // delta_G(), nuc_cruc.h:1217
 		int status = 0;
 		if (tm < th.min_tm || tm > th.max_tm) status = 1;
 		else if (dg < th.min_dg || dg > th.max_dg) status = 2;
@@ -912,7 +1034,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 			{ // num_mismatch_by_query / num_gap / max_contiguous_target_degen, nuc_cruc.h:389-483
 				int aligned = 0, run = 0;
 				for (int k = bi.k0; k < bi.k1; k++) {
-					const uint16_t cw = best[k * BIND_THREADS];
+					const uint8_t cw = best[k * BIND_THREADS];
 					const int q = col_q(cw), t = col_t(cw);
 					if (!is_virtual(q)) {
 						if (!is_virtual(t) && !is_complementary(q, t)) mm++;
@@ -953,6 +1075,9 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 			status = 8; // SURVEY Q11 fence: no alignment is never a bind
 		}
 
+#ifdef TNT_EXP_STATS
+		const long long st_out0 = __builtin_readcyclecounter();
+#endif
 		// ------------------------------------------------------------------ output
 		char *text = nullptr;
 		int32_t res = -status;
@@ -1005,7 +1130,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 			for (int i = 0; i < prefix; i++)
 				text[o++] = is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ';
 			for (int k = bi.k0; k < bi.k1; k++) {
-				const uint16_t cw = best[k * BIND_THREADS];
+				const uint8_t cw = best[k * BIND_THREADS];
 				text[o++] = is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ';
 			}
 			for (int i = 0; i < suffix; i++)
@@ -1019,6 +1144,21 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 			text[o] = 0;
 			if (rec) rec->text_len = o;
 		}
+#ifdef TNT_EXP_STATS
+		{ // wave-level cycle breakdown of the tail (s_memtime ticks / 64, lane 0 of every wave; waves re-converge here)
+			const long long st_end = __builtin_readcyclecounter();
+			if ((tid & 63) == 0) {
+				atomicAdd(a.debug + 0, uint32_t((st_tail0 - st_fill0) >> 6));
+				atomicAdd(a.debug + 1, uint32_t(st_trace >> 6));
+				atomicAdd(a.debug + 2, uint32_t(st_trim >> 6));
+				atomicAdd(a.debug + 3, uint32_t(st_eval >> 6));
+				atomicAdd(a.debug + 4, uint32_t((st_thr0 - st_tail0 - st_trace - st_trim - st_eval) >> 6));
+				atomicAdd(a.debug + 5, uint32_t((st_out0 - st_thr0) >> 6));
+				atomicAdd(a.debug + 6, uint32_t((st_end - st_out0) >> 6));
+				atomicAdd(a.debug + 7, 1u);
+			}
+		}
+#endif
 #undef TRACE_AT
 #undef QUERY
 #undef TARGET
@@ -1027,6 +1167,9 @@ __global__ __launch_bounds__(bind_threads_for(LMAX)) void bind_kernel(BindArgs a
 
 // host-side launchers of the throughput instances, defined in tnt_bind_inst.hip
 #define X(N) void launch_bind_##N(const BindArgs &a, int blocks, hipStream_t stream);
+TNT_LMAX_LADDER(X)
+#undef X
+#define X(N) void launch_bind_plain_##N(const BindArgs &a, int blocks, hipStream_t stream);
 TNT_LMAX_LADDER(X)
 #undef X
 #define X(N) void launch_bind_exact_##N(const BindArgs &a, int blocks, hipStream_t stream);

@@ -1,28 +1,27 @@
 // tnt_bind_inst.hip -- the throughput instances of the bind kernel, one per oligo-length bucket.
 //
-// The build compiles this file several times with -DTNT_INST_LIST="G(36) E(22) ..." (a share of TNT_LMAX_LADDER
-// as G(N) and of TNT_EXACT_LADDER as E(N) each) so the instances build in parallel; compiled once without the
-// macro it provides all of them.
+// The build compiles this file several times with -DTNT_INST_LIST="G(36) P(36) E(22) ..." (a share of the
+// instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows) so they build
+// in parallel; compiled once without the macro it provides all of them.
 #include "tnt_bind.hip.h"
 
 #ifndef TNT_INST_LIST
-#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_EXACT_LADDER(E)
+#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_EXACT_LADDER(E)
 #endif
 
 namespace tnt {
 
-#define G(N)                                                                                                        \
-	void launch_bind_##N(const BindArgs &a, int blocks, hipStream_t stream)                                         \
-	{                                                                                                               \
-		hipLaunchKernelGGL((bind_kernel<N, false, false>), dim3(blocks), dim3(bind_threads_for(N)), 0, stream, a);  \
+#define TNT_LAUNCHER(NAME, N, EXACT, PLAIN)                                                                          \
+	void NAME(const BindArgs &a, int blocks, hipStream_t stream)                                                     \
+	{                                                                                                                \
+		hipLaunchKernelGGL((bind_kernel<N, false, EXACT, PLAIN>), dim3(blocks), dim3(bind_threads_for(N)), 0, stream, a); \
 	}
-#define E(N)                                                                                                        \
-	void launch_bind_exact_##N(const BindArgs &a, int blocks, hipStream_t stream)                                   \
-	{                                                                                                               \
-		hipLaunchKernelGGL((bind_kernel<N, false, true>), dim3(blocks), dim3(bind_threads_for(N)), 0, stream, a);   \
-	}
+#define G(N) TNT_LAUNCHER(launch_bind_##N, N, false, false)
+#define P(N) TNT_LAUNCHER(launch_bind_plain_##N, N, false, true)
+#define E(N) TNT_LAUNCHER(launch_bind_exact_##N, N, true, true)
 TNT_INST_LIST
 #undef G
+#undef P
 #undef E
 
 } // namespace tnt

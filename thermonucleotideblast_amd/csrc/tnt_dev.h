@@ -40,6 +40,8 @@ struct Tables {
 	int32_t dg[NBP * NBP];  // update_dp_param, nuc_cruc.cpp:340-487
 	float H[NBP * NBP];     // param_H (== loop terminal H, nuc_cruc_santa_lucia.cpp:591-595)
 	float S[NBP * NBP];
+	uint8_t hs_map[NBP * NBP + 3]; // H[i], S[i] == hs_H[hs_map[i]], hs_S[hs_map[i]]: the pairs are few, the LDS copy is small
+	float hs_H[256], hs_S[256];
 	float loop_S[513];
 	float bulge_S[513];
 	float hairpin_S[513];
@@ -73,24 +75,26 @@ struct Slot {
 	float log_ct;    // logf(strand concentration), host computed
 	int32_t thresh;  // index into Thresh table
 	int32_t assay;   // expanded assay index (or -1)
-	int32_t bucket;  // length bucket = which bind kernel instance handles this oligo
+	int32_t bucket;  // length bucket = which bind kernel instance handles this oligo ...
+	int32_t bucket_general; // ... and the one for windows that hold a degenerate target base
 };
 
 // Instances of the bind kernel (rows kept in registers): every oligo length up to 32 has its own, so the
 // oligos of one launch all have exactly LMAX rows; coarser above.
-// Exact instances (every oligo of the launch has exactly LMAX rows: no per-row length test) ...
+// Exact instances (every oligo of the launch has exactly LMAX rows: no per-row length test; plain windows only) ...
 #define TNT_EXACT_LADDER(X) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
-// ... and general ones (L <= LMAX) for the other lengths and for short queues that are bound in one launch
+// ... and a ladder (L <= LMAX) in two flavours: plain windows (A/C/G/T targets) for the other lengths, and
+// general ones for windows with degenerate target bases and for short queues that are bound in one launch
 #define TNT_LMAX_LADDER(X) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
-constexpr int MAX_BUCKETS = 30;
-constexpr int BUCKET_EXACT = 0x100; // flag on the instance id kept by the host (lmax | BUCKET_EXACT)
+constexpr int MAX_BUCKETS = 48;
+constexpr int BUCKET_EXACT = 0x100, BUCKET_PLAIN = 0x200; // flags on the instance id kept by the host (lmax | flags)
 
-// Workgroup size of the bind kernel instance with LMAX rows.  One lane owns one DP; a lane needs 6 * LMAX + 32
-// bytes of LDS (window, query, alignment columns) next to the 19.4 KB of tables every workgroup holds once.
-// Up to 25 rows three wavefronts per SIMD fit (one 768-thread workgroup per CU, <= 168 VGPRs); above that the
-// row state needs the registers of a two-wave budget (two 256-thread workgroups per CU).
-constexpr int bind_threads_for(int lmax) { return lmax <= 25 ? 768 : 256; }
-constexpr int bind_blocks_per_cu(int lmax) { return lmax <= 25 ? 2 : 4; } // persistent grid: 2x the resident workgroups
+// Workgroup size of the bind kernel instances.  One lane owns one DP; a lane needs 6 * LMAX + 32 bytes of LDS
+// (window, query, alignment columns) next to the 20 KB of tables every workgroup holds once: two workgroups
+// per CU up to 32 rows.  The fill loop is bound by VALU issue, which two wavefronts per SIMD saturate; a third
+// one (768-thread workgroups, <= 168 VGPRs) was measured and gained nothing while forcing spills above 21 rows.
+constexpr int bind_threads_for(int) { return 256; }
+constexpr int bind_blocks_per_cu(int) { return 4; } // persistent grid: 2x the resident workgroups
 constexpr int BUCKET_STRIDE = 32; // words between two bucket counters (one 128-byte line each)
 
 // bind work item (one seed that survived the first cull)

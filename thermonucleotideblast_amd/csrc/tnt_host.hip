@@ -95,6 +95,21 @@ bool fill_tables(Tables &T, const tnt_options &opt)
 		T.H[TNT_SL_NN[k][0]] = f32(TNT_SL_NN[k][1]);
 		T.S[TNT_SL_NN[k][0]] = f32(TNT_SL_NN[k][2]);
 	}
+	{ // distinct (H, S) pairs (bit patterns) -> byte map for the LDS copy of the scoring tables
+		int n = 0;
+		for (int i = 0; i < NBP * NBP; i++) {
+			int k = 0;
+			for (; k < n; k++)
+				if (memcmp(&T.hs_H[k], &T.H[i], 4) == 0 && memcmp(&T.hs_S[k], &T.S[i], 4) == 0) break;
+			if (k == n) {
+				if (n == 256) return false;
+				T.hs_H[n] = T.H[i];
+				T.hs_S[n] = T.S[i];
+				n++;
+			}
+			T.hs_map[i] = uint8_t(k);
+		}
+	}
 	for (int i = 0; i < 513; i++) {
 		T.loop_S[i] = f32(TNT_SL_LOOP_S[i]);
 		T.bulge_S[i] = f32(TNT_SL_BULGE_S[i]);
@@ -321,7 +336,8 @@ struct tnt_ctx {
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
-	DevBuf<uint16_t> trace, cols, best, ties;
+	DevBuf<uint16_t> trace, ties;
+	DevBuf<uint8_t> best;
 	DevBuf<uint32_t> stack;
 	DevBuf<SeedOut> seeds_out;
 	int bind_blocks = 0; // grid of the 256-thread instances
@@ -350,7 +366,7 @@ enum { C_POOL = 0, C_ACTIVE, C_QB, C_PAD3, C_HITS, C_ERR, C_PAD6, C_PAD7, C_TOT_
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
-       C_BUCKET = C_GROUPS + N_SHARD * SHARD_STRIDE, C_COUNT = C_BUCKET + MAX_BUCKETS * BUCKET_STRIDE };
+       C_BUCKET = C_GROUPS + N_SHARD * SHARD_STRIDE, C_DEBUG = C_BUCKET + MAX_BUCKETS * BUCKET_STRIDE, C_COUNT = C_DEBUG + 16 };
 static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
@@ -400,13 +416,13 @@ int pick_lmax(size_t max_len)
 // persistent grid of one bind kernel instance
 int bind_grid(const tnt_ctx *c, int lmax) { return c->n_cu * bind_blocks_per_cu(lmax & 0xFF); }
 
-// instance id for oligos of length L: the exact instance where there is one, else the smallest general one
+// instance id for plain windows of oligos of length L: the exact instance where there is one, else the ladder
 int pick_instance(size_t L)
 {
-#define X(N) if (L == N) return N | BUCKET_EXACT;
+#define X(N) if (L == N) return N | BUCKET_EXACT | BUCKET_PLAIN;
 	TNT_EXACT_LADDER(X)
 #undef X
-	return pick_lmax(L);
+	return pick_lmax(L) | BUCKET_PLAIN;
 }
 
 void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax)
@@ -419,7 +435,10 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax)
 #define X(N) case N: tnt::launch_bind_##N(a, blocks, c->stream); break;
 		TNT_LMAX_LADDER(X)
 #undef X
-#define X(N) case N | BUCKET_EXACT: tnt::launch_bind_exact_##N(a, blocks, c->stream); break;
+#define X(N) case N | BUCKET_PLAIN: tnt::launch_bind_plain_##N(a, blocks, c->stream); break;
+		TNT_LMAX_LADDER(X)
+#undef X
+#define X(N) case N | BUCKET_EXACT | BUCKET_PLAIN: tnt::launch_bind_exact_##N(a, blocks, c->stream); break;
 		TNT_EXACT_LADDER(X)
 #undef X
 	default: break;
@@ -427,7 +446,8 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax)
 }
 
 // One phase of binding: split the queue by oligo length, then one launch per length bucket.
-void launch_bind_phase(tnt_ctx *c, BindArgs b, const uint32_t *src, const uint32_t *src_count, const uint32_t *shard_counts)
+void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_exceptions, const uint32_t *src, const uint32_t *src_count,
+                       const uint32_t *shard_counts)
 {
 	uint32_t *cnt = c->counters.p;
 	(void)hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream);
@@ -439,6 +459,9 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const uint32_t *src, const uint32
 	k.shard_region = uint32_t(ITEM_CAP / N_SHARD);
 	k.items = c->items.p;
 	k.slots = c->slots.p;
+	k.olig_len = c->olig_len.p;
+	k.db = v;
+	k.has_exceptions = has_exceptions ? 1 : 0;
 	k.dst = c->qbucket.p;
 	k.cap = uint32_t(ITEM_CAP);
 	k.counters = cnt + C_BUCKET;
@@ -448,6 +471,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const uint32_t *src, const uint32
 	hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 	hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	for (size_t i = 0; i < c->bucket_lmax.size(); i++) {
+		// general instances other than the last (merge) bucket only see windows with degenerate bases
+		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) continue;
 		b.index = c->qbucket.p;
 		b.index_base_dev = cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
@@ -477,7 +502,6 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 		n_ties = std::max(n_ties, lanes * TIE_CAP);
 	}
 	HIP_TRY(c->trace.alloc(n_trace), c->err);
-	HIP_TRY(c->cols.alloc(n_cols), c->err);
 	HIP_TRY(c->best.alloc(n_cols), c->err);
 	HIP_TRY(c->stack.alloc(n_cols), c->err);
 	HIP_TRY(c->ties.alloc(n_ties), c->err);
@@ -518,7 +542,6 @@ BindArgs bind_args(tnt_ctx *c, const DbView &v)
 	a.pool_cap = uint32_t(POOL_CAP);
 	a.pool_count = c->counters.p + C_POOL;
 	a.trace = c->trace.p;
-	a.cols = c->cols.p;
 	a.best = c->best.p;
 	a.stack = c->stack.p;
 	a.ties = c->ties.p;
@@ -526,6 +549,7 @@ BindArgs bind_args(tnt_ctx *c, const DbView &v)
 	a.groups = c->groups.p;
 	a.active = c->active.p;
 	a.n_active = c->counters.p + C_ACTIVE;
+	a.debug = c->counters.p + C_DEBUG;
 	return a;
 }
 
@@ -659,7 +683,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		}
 		d.has_probe = (primers && A.probe && d.kind == 0) ? 1 : 0;
 		// Slot table is laid out [assay][role] so the kernels address it without an indirection
-		c->h_slots.resize((i + 1) * 3, Slot{-1, 0.0f, 0, int(i), 0});
+		c->h_slots.resize((i + 1) * 3, Slot{-1, 0.0f, 0, int(i), 0, 0});
 		auto add_slot = [&](int role, const char *s, float ct, int thr) -> int {
 			Slot &sl = c->h_slots[i * 3 + role];
 			sl.oligo = intern(s);
@@ -694,14 +718,20 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		auto by_len = [](int a, int b) { return (a & 0xFF) != (b & 0xFF) ? (a & 0xFF) < (b & 0xFF) : a > b; };
 		std::vector<int> used;
 		for (const Slot &sl : c->h_slots)
-			if (sl.oligo >= 0) used.push_back(pick_instance(c->oligos[sl.oligo].size()));
+			if (sl.oligo >= 0) {
+				used.push_back(pick_instance(c->oligos[sl.oligo].size()));
+				used.push_back(pick_lmax(c->oligos[sl.oligo].size()));
+			}
 		used.push_back(c->lmax);
 		std::sort(used.begin(), used.end(), by_len);
 		used.erase(std::unique(used.begin(), used.end()), used.end());
 		c->bucket_lmax = used;
+		auto index_of = [&](int id) { return int32_t(std::lower_bound(used.begin(), used.end(), id, by_len) - used.begin()); };
 		for (Slot &sl : c->h_slots)
-			if (sl.oligo >= 0)
-				sl.bucket = int32_t(std::lower_bound(used.begin(), used.end(), pick_instance(c->oligos[sl.oligo].size()), by_len) - used.begin());
+			if (sl.oligo >= 0) {
+				sl.bucket = index_of(pick_instance(c->oligos[sl.oligo].size()));
+				sl.bucket_general = index_of(pick_lmax(c->oligos[sl.oligo].size()));
+			}
 	}
 
 	// ---- tables
@@ -943,7 +973,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
-	launch_bind_phase(c, b, c->qa.p, nullptr, cnt + C_QA);
+	launch_bind_phase(c, b, v, !db->h_exc_pos.empty(), c->qa.p, nullptr, cnt + C_QA);
 
 	FilterArgs f;
 	f.groups = c->groups.p;
@@ -955,7 +985,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	hipLaunchKernelGGL(filter_kernel, dim3(256), dim3(256), 0, c->stream, f);
 
 	// phase B: the other strand and the probes of the groups that are still alive
-	launch_bind_phase(c, b, c->qb.p, cnt + C_QB, nullptr);
+	launch_bind_phase(c, b, v, !db->h_exc_pos.empty(), c->qb.p, cnt + C_QB, nullptr);
 	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 
 	PairArgs p;
@@ -1076,6 +1106,14 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	ctx->pending = false;
+#ifdef TNT_EXP_STATS
+	{
+		const uint32_t *d = cnt + C_DEBUG;
+		const double w = d[7] ? double(d[7]) : 1.0;
+		fprintf(stderr, "wave-DPs %u; cycles per wave-DP: fill %.0f trace %.0f trim %.0f eval %.0f other-enum %.0f thresholds %.0f output %.0f\n", d[7],
+		        64.0 * d[0] / w, 64.0 * d[1] / w, 64.0 * d[2] / w, 64.0 * d[3] / w, 64.0 * d[4] / w, 64.0 * d[5] / w, 64.0 * d[6] / w);
+	}
+#endif
 	if (cnt[C_ERR]) {
 		ctx->err = err_text(cnt[C_ERR]);
 		return TNT_E_LIMIT;
@@ -1211,7 +1249,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 		slots[i].log_ct = logf((r.ct - 0.5f * 0.0f) * 1.0f);
 		slots[i].thresh = r.role == 1 ? 1 : 0;
 		slots[i].assay = -1;
-		slots[i].bucket = 0;
+		slots[i].bucket = slots[i].bucket_general = 0;
 		items[i].target = uint32_t(t);
 		items[i].tloc = uint32_t(r.target_loc);
 		items[i].info = uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT);
@@ -1290,8 +1328,8 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	const float ct_self = ct_a - 0.5f * ct_a;
 	const float ct_pair = ob ? ((ct_a > ct_b) ? ct_a - 0.5f * ct_b : ct_b - 0.5f * ct_a) : ct_self;
 	std::vector<Slot> slots(2);
-	slots[0] = Slot{0, logf(ct_self * 1.0f), 0, -1, 0};
-	slots[1] = Slot{0, logf(ct_pair * 1.0f), 0, -1, 0};
+	slots[0] = Slot{0, logf(ct_self * 1.0f), 0, -1, 0, 0};
+	slots[1] = Slot{0, logf(ct_pair * 1.0f), 0, -1, 0, 0};
 	std::vector<Item> items;
 	items.push_back(Item{3u << 29, 0, 0u << ITEM_SLOT_SHIFT, 0});                  // hairpin of a
 	items.push_back(Item{2u << 29, 0, 0u << ITEM_SLOT_SHIFT, 0});                  // homodimer of a

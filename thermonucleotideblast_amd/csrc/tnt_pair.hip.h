@@ -246,6 +246,9 @@ struct BucketArgs {
 	uint32_t shard_region;
 	const Item *items;
 	const Slot *slots;
+	const int32_t *olig_len;
+	DbView db;                    // exception lists: windows with a degenerate target base go to Slot::bucket_general
+	int has_exceptions;
 	uint32_t *dst;                // compact output, `cap` entries
 	uint32_t cap;
 	uint32_t *counters;           // per bucket BUCKET_STRIDE words: [0] size, [1] scatter cursor, [2] first entry in dst
@@ -286,7 +289,25 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 			bkt[m] = 0xFFFFFFFFu;
 			if (lin < n) {
 				idx[m] = a.src[a.shard_counts ? shard_locate(s_pre, lin, a.shard_region) : lin];
-				bkt[m] = n < a.merge_below ? uint32_t(a.n_buckets - 1) : uint32_t(a.slots[a.items[idx[m]].info >> ITEM_SLOT_SHIFT].bucket);
+				const Item it = a.items[idx[m]];
+				const Slot sl = a.slots[it.info >> ITEM_SLOT_SHIFT];
+				bool degenerate = false;
+				if (a.has_exceptions) { // same window as the bind kernel, bind_oligo.cpp:502-505
+					const uint32_t e0 = a.db.exc_off[it.target], e1 = a.db.exc_off[it.target + 1];
+					if (e1 > e0) {
+						int start = int(it.tloc) - (int(it.info & 127u) + FLANK);
+						if (start < 0) start = 0;
+						const uint32_t stop = uint32_t(start + a.olig_len[sl.oligo] + 2 * FLANK);
+						uint32_t lo = e0, hi = e1;
+						while (lo < hi) {
+							const uint32_t mid = (lo + hi) >> 1;
+							if (a.db.exc_pos[mid] < uint32_t(start)) lo = mid + 1;
+							else hi = mid;
+						}
+						degenerate = lo < e1 && a.db.exc_pos[lo] < stop;
+					}
+				}
+				bkt[m] = n < a.merge_below ? uint32_t(a.n_buckets - 1) : uint32_t(degenerate ? sl.bucket_general : sl.bucket);
 				pos[m] = atomicAdd(&s_cnt[bkt[m]], 1u);
 			}
 		}
