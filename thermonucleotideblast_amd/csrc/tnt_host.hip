@@ -302,6 +302,13 @@ struct tnt_ctx {
 	int device = 0;
 	tnt_options opt;
 	hipStream_t stream = nullptr;
+	// The length buckets of a phase are independent launches: they run on BIND_LANES side streams (each with its
+	// own scratch slabs) so that the drain of one launch overlaps the ramp-up of the next.
+	static constexpr int BIND_LANES = 4;
+	hipStream_t lane_stream[BIND_LANES] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t lane_done[BIND_LANES] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t phase_ready = nullptr;
+	size_t lane_trace = 0, lane_cols = 0, lane_ties = 0; // scratch elements per lane
 
 	std::vector<std::string> oligos;
 	std::vector<AssayDev> h_assays;
@@ -356,6 +363,11 @@ struct tnt_ctx {
 	{
 		for (hipEvent_t e : events) (void)hipEventDestroy(e);
 		if (h_hits) (void)hipHostFree(h_hits);
+		for (int i = 0; i < BIND_LANES; i++) {
+			if (lane_done[i]) (void)hipEventDestroy(lane_done[i]);
+			if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
+		}
+		if (phase_ready) (void)hipEventDestroy(phase_ready);
 		if (stream) (void)hipStreamDestroy(stream);
 	}
 };
@@ -425,20 +437,21 @@ int pick_instance(size_t L)
 	return pick_lmax(L) | BUCKET_PLAIN;
 }
 
-void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax)
+void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_t stream = nullptr)
 {
+	if (!stream) stream = c->stream;
 	if (lmax == 0) { // unit-level API: one instance is enough
-		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads_for(64)), 0, c->stream, a);
+		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads_for(64)), 0, stream, a);
 		return;
 	}
 	switch (lmax) {
-#define X(N) case N: tnt::launch_bind_##N(a, blocks, c->stream); break;
+#define X(N) case N: tnt::launch_bind_##N(a, blocks, stream); break;
 		TNT_LMAX_LADDER(X)
 #undef X
-#define X(N) case N | BUCKET_PLAIN: tnt::launch_bind_plain_##N(a, blocks, c->stream); break;
+#define X(N) case N | BUCKET_PLAIN: tnt::launch_bind_plain_##N(a, blocks, stream); break;
 		TNT_LMAX_LADDER(X)
 #undef X
-#define X(N) case N | BUCKET_EXACT | BUCKET_PLAIN: tnt::launch_bind_exact_##N(a, blocks, c->stream); break;
+#define X(N) case N | BUCKET_EXACT | BUCKET_PLAIN: tnt::launch_bind_exact_##N(a, blocks, stream); break;
 		TNT_EXACT_LADDER(X)
 #undef X
 	default: break;
@@ -470,14 +483,28 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 	k.err = cnt + C_ERR;
 	hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 	hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
-	for (size_t i = 0; i < c->bucket_lmax.size(); i++) {
+	(void)hipEventRecord(c->phase_ready, c->stream);
+	for (int l = 0; l < tnt_ctx::BIND_LANES; l++) (void)hipStreamWaitEvent(c->lane_stream[l], c->phase_ready, 0);
+	int n_launch = 0;
+	// longest buckets first: they take the longest per item, the short ones fill the gaps
+	for (size_t k = c->bucket_lmax.size(); k-- > 0;) {
+		const size_t i = k;
 		// general instances other than the last (merge) bucket only see windows with degenerate bases
 		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) continue;
+		const int lane = n_launch++ % tnt_ctx::BIND_LANES;
 		b.index = c->qbucket.p;
 		b.index_base_dev = cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
-		launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i]);
+		b.trace = c->trace.p + size_t(lane) * c->lane_trace;
+		b.best = c->best.p + size_t(lane) * c->lane_cols;
+		b.stack = c->stack.p + size_t(lane) * c->lane_cols;
+		b.ties = c->ties.p + size_t(lane) * c->lane_ties;
+		launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
+	}
+	for (int l = 0; l < tnt_ctx::BIND_LANES && l < n_launch; l++) {
+		(void)hipEventRecord(c->lane_done[l], c->lane_stream[l]);
+		(void)hipStreamWaitEvent(c->stream, c->lane_done[l], 0);
 	}
 }
 
@@ -501,10 +528,11 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 		n_cols = std::max(n_cols, lanes * nc);
 		n_ties = std::max(n_ties, lanes * TIE_CAP);
 	}
-	HIP_TRY(c->trace.alloc(n_trace), c->err);
-	HIP_TRY(c->best.alloc(n_cols), c->err);
-	HIP_TRY(c->stack.alloc(n_cols), c->err);
-	HIP_TRY(c->ties.alloc(n_ties), c->err);
+	c->lane_trace = n_trace, c->lane_cols = n_cols, c->lane_ties = n_ties;
+	HIP_TRY(c->trace.alloc(n_trace * tnt_ctx::BIND_LANES), c->err);
+	HIP_TRY(c->best.alloc(n_cols * tnt_ctx::BIND_LANES), c->err);
+	HIP_TRY(c->stack.alloc(n_cols * tnt_ctx::BIND_LANES), c->err);
+	HIP_TRY(c->ties.alloc(n_ties * tnt_ctx::BIND_LANES), c->err);
 	return TNT_OK;
 }
 
@@ -633,6 +661,11 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	} while (0)
 	if (hipSetDevice(device) != hipSuccess) FAIL(TNT_E_DEVICE, "hipSetDevice failed");
 	if (hipStreamCreate(&c->stream) != hipSuccess) FAIL(TNT_E_DEVICE, "hipStreamCreate failed");
+	for (int i = 0; i < tnt_ctx::BIND_LANES; i++)
+		if (hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->lane_done[i], hipEventDisableTiming) != hipSuccess)
+			FAIL(TNT_E_DEVICE, "hipStreamCreate failed");
+	if (hipEventCreateWithFlags(&c->phase_ready, hipEventDisableTiming) != hipSuccess) FAIL(TNT_E_DEVICE, "hipEventCreate failed");
 
 	// ---- unique oligos
 	std::map<std::string, int> index;
