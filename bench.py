@@ -138,7 +138,7 @@ def main():
         bind_ms += tm.bind_ms
         seed_ms += tm.seed_ms
         pair_ms += tm.pair_ms
-        n_binds = tm.n_binds
+        n_binds = tm.n_binds  # DP evaluations of the last step on this rank
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -155,7 +155,7 @@ def main():
         achieved = alg_bytes / (bind_ms_step * 1e-3) / 1e9 if bind_ms_step > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "bind_pmc.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.config == 2 and n_targets == full:  # measured for this workload only
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_step")
             except Exception:
@@ -176,7 +176,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "bind_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once); the bind "
-                                 "kernel is integer-DP/VALU bound, not HBM bound (SURVEY 8(d))"},
+                                 "stage is bound by integer VALU issue, not by HBM (DESIGN.md 4.2); traffic = PMC "
+                                 "2*FETCH_SIZE + WRITE_SIZE per step of the full-size config (profiles/bind_pmc.json)",
+                         "dp_per_s": n_binds * world / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
