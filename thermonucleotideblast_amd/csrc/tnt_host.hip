@@ -992,6 +992,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 		s.seeds_count = cnt + C_SEEDS;
 	}
 	s.err = cnt + C_ERR;
+	s.debug = cnt + C_DEBUG + 8;
 	const int seed_blocks = int(std::min<size_t>((t1 - t0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
@@ -1143,6 +1144,8 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	{
 		const uint32_t *d = cnt + C_DEBUG;
 		const double w = d[7] ? double(d[7]) : 1.0;
+		fprintf(stderr, "seed waves %u; kilo-cycles per wave: scan %.0f sort %.0f cull %.0f phaseB %.0f prefix+groups %.0f emit %.0f\n", d[15], double(d[8]) / (d[15] ? d[15] : 1),
+		        double(d[9]) / (d[15] ? d[15] : 1), double(d[10]) / (d[15] ? d[15] : 1), double(d[11]) / (d[15] ? d[15] : 1), double(d[12]) / (d[15] ? d[15] : 1), double(d[13]) / (d[15] ? d[15] : 1));
 		fprintf(stderr, "wave-DPs %u; cycles per wave-DP: fill %.0f trace %.0f trim %.0f eval %.0f other-enum %.0f thresholds %.0f output %.0f\n", d[7],
 		        64.0 * d[0] / w, 64.0 * d[1] / w, 64.0 * d[2] / w, 64.0 * d[3] / w, 64.0 * d[4] / w, 64.0 * d[5] / w, 64.0 * d[6] / w);
 	}

@@ -342,12 +342,29 @@ __device__ void pair_group(const PairArgs &a, const Group G)
 		return;
 	}
 
+	// The seed kernel emits the items of a group in arbitrary order; the reference's list order (the order of the
+	// seed keys: target_loc, assembly group, word index for amplicon(); list, diagonal, word index for the hash
+	// overload) is restored here, where only the groups that bound something arrive.
 	List l;
 	l.n = int(g_count);
 	bool any_bound = false;
+	unsigned long long order[PAIR_MAX];
 	for (int i = 0; i < l.n; i++) {
 		const Item it = a.items[G.first + i];
 		const int32_t res = a.result[G.first + i];
+		{
+			const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u, wi = it.info & 127u;
+			const bool minus = (it.info & ITEM_MINUS) != 0;
+			unsigned long long key;
+			if (A.kind == 0) {
+				const unsigned long long rank = role == 2 ? (minus ? 4u : 5u) : ((minus ? 0u : 2u) + role); // F-, R-, F+, R+, P-, P+
+				key = ((unsigned long long)it.tloc << 24) | (rank << 21) | ((unsigned long long)wi << 14);
+			} else {
+				const unsigned long long listid = (minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
+				key = (listid << 54) | ((unsigned long long)(long(wi) - long(it.tloc) + (1l << 33)) << 20) | ((unsigned long long)wi << 13);
+			}
+			order[i] = key;
+		}
 		Entry &e = l.e[i];
 		e.tloc = it.tloc;
 		e.rec = res >= 0 ? res : -1;
@@ -357,6 +374,18 @@ __device__ void pair_group(const PairArgs &a, const Group G)
 		if (res >= 0) any_bound = true;
 	}
 	if (!any_bound) return;
+	for (int i = 1; i < l.n; i++) { // insertion sort by key (keys are unique)
+		const Entry x = l.e[i];
+		const unsigned long long kx = order[i];
+		int j = i - 1;
+		while (j >= 0 && order[j] > kx) {
+			l.e[j + 1] = l.e[j];
+			order[j + 1] = order[j];
+			j--;
+		}
+		l.e[j + 1] = x;
+		order[j + 1] = kx;
+	}
 
 	if (A.kind == 0) {
 		// ---------------------------------------------------------------- amplicon(), amplicon_search.cpp:128-674

@@ -60,6 +60,7 @@ struct SeedArgs {
 	uint32_t seeds_cap;
 	uint32_t *seeds_count;
 	uint32_t *err;
+	uint32_t *debug; // experimental builds only (TNT_EXP_STATS)
 };
 
 __device__ __forceinline__ uint32_t target_word(const uint32_t *pk, uint32_t pos, uint32_t wmask)
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 	__shared__ uint16_t s_hist[SEED_WAVES][SEED_MAX_ASSAYS];
 	__shared__ uint16_t s_off[SEED_WAVES][SEED_MAX_ASSAYS];
 	__shared__ uint32_t s_cnt[SEED_WAVES];
+	__shared__ uint32_t s_ncand[SEED_WAVES];
 
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	unsigned long long *raw = s_raw[wv], *srt = s_srt[wv];
@@ -166,41 +168,87 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 
 	const uint32_t shard = (blockIdx.x * SEED_WAVES + wv) & (N_SHARD - 1);
 
+#ifdef TNT_EXP_STATS
+	long long st_t[7] = {0, 0, 0, 0, 0, 0, 0};
+	long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define ST(K) st_t[K] = __builtin_readcyclecounter()
+#endif
 	for (uint32_t t = blockIdx.x * SEED_WAVES + wv; t < a.db.n_targets; t += gridDim.x * SEED_WAVES) {
+#ifdef TNT_EXP_STATS
+		for (int q = 1; q < 7; q++) st_t[q] = 0;
+#endif
 		const uint32_t len = a.db.len[t];
 		for (uint32_t i = lane; i < n_chunk; i += 64) hist[i] = 0;
 		if (lane == 0) s_cnt[wv] = 0;
 		wave_sync();
+#ifdef TNT_EXP_STATS
+		ST(0);
+#endif
 
 		// ---------------------------------------------------------------- scan + diagonal de-duplication
 		if (len >= uint32_t(a.word_size)) { // tntblast_local.cpp:513
 			const uint32_t *pk = a.db.packed + a.db.word_off[t];
 			const uint32_t npos = len - a.word_size + 1;
-			for (uint32_t p = lane; p < npos; p += 64) {
-				const uint32_t w = target_word(pk, p, wmask);
-				const uint32_t e0 = a.wt_off[w], e1 = a.wt_off[w + 1];
-				for (uint32_t e = e0; e < e1; e++) {
-					const uint32_t ent = a.wt_ent[e];
+			// Stage 1: every lane looks its positions up and appends the (position, entry) candidates to a wave-local
+			// list (kept in `srt`, free until the counting sort).  Only ~0.2 candidates fall on a position, so testing
+			// them in place would run the test with a handful of active lanes; stage 2 works through the list with
+			// all lanes busy.
+			// The list holds SEED_CAP candidates; when it fills up (buckets shared by many expanded assays come in
+			// bursts) it is drained and the scan resumes where every lane stopped.
+			uint2 *cand = reinterpret_cast<uint2 *>(srt);
+			uint32_t p = lane, e_done = 0;
+			while (true) {
+			if (lane == 0) s_ncand[wv] = 0;
+			wave_sync();
+			while (true) {
+				bool over = false;
+				if (p < npos) {
+					const uint32_t w = target_word(pk, p, wmask);
+					const uint32_t e0 = uint32_t(a.wt_off[w]) + e_done, e1 = a.wt_off[w + 1];
+					uint32_t fit = 0;
+					if (e1 > e0) {
+						const uint32_t at = atomicAdd(&s_ncand[wv], e1 - e0);
+						fit = at < uint32_t(SEED_CAP) ? (e1 - e0 < uint32_t(SEED_CAP) - at ? e1 - e0 : uint32_t(SEED_CAP) - at) : 0u;
+						for (uint32_t x = 0; x < fit; x++) cand[at + x] = make_uint2(p, a.wt_ent[e0 + x]);
+					}
+					if (fit == e1 - e0) p += 64, e_done = 0;
+					else e_done += fit, over = true;
+				}
+				if (__builtin_amdgcn_ballot_w64(over) != 0 || __builtin_amdgcn_ballot_w64(p < npos) == 0) break;
+			}
+			wave_sync();
+			uint32_t ncand = s_ncand[wv];
+			if (ncand > uint32_t(SEED_CAP)) ncand = SEED_CAP;
+			// Stage 2: diagonal de-duplication of the candidates, kept seeds -> `raw`
+			for (uint32_t c = lane; c < ncand; c += 64) {
+				const uint32_t cp = cand[c].x, ent = cand[c].y;
+				{
 					const uint32_t wi = ent & 127u;
 					const uint32_t assay = ent >> WT_ASSAY_SHIFT;
 					const uint32_t li = (assay * 3u + ((ent >> 8) & 3u)) * 2u + ((ent & WT_MINUS) ? 1u : 0u);
-					const uint32_t kmax = wi < p ? wi : p;
+					const uint32_t kmax = wi < cp ? wi : cp;
 #ifndef TNT_EXP_NODEDUPE
 					bool first;
-					if ((ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) first = first_on_diagonal_packed(pk, a.wl_seq + 2 * li, wi, p, a.word_size);
-					else first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, p, wmask);
+					if ((ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) first = first_on_diagonal_packed(pk, a.wl_seq + 2 * li, wi, cp, a.word_size);
+					else first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
 					if (!first) continue;
 #endif
 					const uint32_t la = assay - a.assay_begin;
 					const uint32_t slot = atomicAdd(&s_cnt[wv], 1u);
 					if (slot < uint32_t(SEED_CAP)) {
-						raw[slot] = seed_key(la, ent, p);
+						raw[slot] = seed_key(la, ent, cp);
 						atomicAdd(reinterpret_cast<unsigned int *>(hist) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
 					}
 				}
 			}
+			wave_sync();
+			if (__builtin_amdgcn_ballot_w64(p < npos) == 0) break;
+			}
 		}
 		wave_sync();
+#ifdef TNT_EXP_STATS
+		ST(1);
+#endif
 		uint32_t n = s_cnt[wv];
 		if (n > uint32_t(SEED_CAP)) {
 			if (lane == 0) atomicOr(a.err, ERR_SEED_OVERFLOW);
@@ -254,102 +302,145 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 				srt[(la & 1u) ? (old >> 16) : (old & 0xFFFFu)] = k;
 			}
 			wave_sync();
-
-			// ------------------------------------------------------------ one lane per assay of the chunk
-			for (uint32_t la0 = 0; la0 < n_chunk; la0 += 64) {
-				const uint32_t la = la0 + lane;
-				uint32_t cnt = la < n_chunk ? hist[la] : 0u;
-				unsigned long long *key = srt + (la < n_chunk ? uint32_t(off[la]) - cnt : 0u); // off now points past the segment
-				unsigned long long valid = 0, phase_b = 0;
-				uint32_t gflags = 0;
-				bool pcr = false;
-#ifdef TNT_EXP_NOSEG
-				cnt = 0;
+#ifdef TNT_EXP_STATS
+		ST(2);
 #endif
+
+			// ------------------------------------------------------------ first cull + emission, one lane per seed
+			// The seeds sit in `srt`, grouped by assay (segment of assay la = [off[la] - hist[la], off[la])).  The
+			// reference sorts each assay's list by target_loc and culls it with nested loops over the sorted list
+			// (cull_oligo_match, amplicon_search.cpp:679-765).  The outcome per seed is a predicate over the other
+			// seeds of its segment that only needs the ORDER RELATION of two keys (keys are unique and their numeric
+			// order is the list order), so every seed evaluates it for itself with one or two passes over its
+			// segment, no sort.  Items are emitted in arbitrary order inside their group; the pair kernel (which
+			// only sees the ~1 % of groups that bound) restores the list order from the item fields.
+			//
+			// `raw` is dead after the counting sort; it holds the per-assay scratch of this phase:
+			uint32_t *cmcp = reinterpret_cast<uint32_t *>(raw);            // [la] cm | cp << 16 (then: item | qa cursor)
+			uint32_t *nvna = cmcp + SEED_MAX_ASSAYS;                        // [la] valid seeds | phase-A seeds << 16
+			uint16_t *ibase = reinterpret_cast<uint16_t *>(nvna + SEED_MAX_ASSAYS); // [la] first item, relative to the wave's
+			uint16_t *abase = ibase + SEED_MAX_ASSAYS;                      // [la] first phase-A queue entry
+			uint16_t *gbase = abase + SEED_MAX_ASSAYS;                      // [la] group index
+			static_assert(SEED_MAX_ASSAYS * (4 + 4 + 2 + 2 + 2) <= SEED_CAP * 8, "per-assay scratch must fit the raw key buffer");
+			for (uint32_t i = lane; i < n_chunk; i += 64) cmcp[i] = 0, nvna[i] = 0;
+			wave_sync();
+
+			constexpr unsigned long long K_VALID = 1ull << 5, K_PHASE_B = 1ull << 6; // free key bits (see seed_key)
+			const uint32_t threshold = uint32_t(a.max_len) + 50u;
+			for (uint32_t i = lane; i < n; i += 64) {
+				unsigned long long k = srt[i];
+				const uint32_t la = uint32_t(k >> 56);
+				const uint32_t cnt = hist[la], s0 = uint32_t(off[la]) - cnt;
+				bool valid = false;
 				if (cnt > uint32_t(LIST_MAX)) {
 					atomicOr(a.err, ERR_LIST_OVERFLOW);
-					cnt = 0;
-				}
-				if (cnt > 0) {
-					// order of the reference's list: insertion sort of the (unique) keys of this assay
-					for (uint32_t i = 1; i < cnt; i++) {
-						const unsigned long long x = key[i];
-						int j = int(i) - 1;
-						while (j >= 0 && key[j] > x) {
-							key[j + 1] = key[j];
-							j--;
+				} else if (k & 8u) {
+					valid = true; // probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454)
+				} else {
+					const bool has_probe = (k & 16u) != 0, single = a.single_primer_pcr != 0;
+					const uint32_t role = key_role(k), loc = uint32_t(k >> 24);
+					const bool minus = k & 1u;
+					// nearest probe on the side where the partner primer must lie (a pair only counts with a probe between)
+					unsigned long long pnear = minus ? ~0ull : 0ull;
+					bool have_p = !has_probe;
+					if (has_probe && role != 2)
+						for (uint32_t x = 0; x < cnt; x++) {
+							const unsigned long long o = srt[s0 + x];
+							if (key_role(o) != 2) continue;
+							if (minus ? (o > k && o < pnear) : (o < k && o > pnear)) pnear = o, have_p = true;
 						}
-						key[j + 1] = x;
+					if (!has_probe) pnear = k; // the partner only has to lie on the right side of this seed
+					// closest partners: f = minus-strand primer before, r = plus-strand primer after (per oligo)
+					uint32_t f_loc[2] = {0, 0}, r_loc[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+					bool f_ok[2] = {false, false}, r_ok[2] = {false, false};
+					for (uint32_t x = 0; x < cnt; x++) {
+						const unsigned long long o = srt[s0 + x];
+						const uint32_t orole = key_role(o);
+						if (orole == 2) continue;
+						const uint32_t oloc = uint32_t(o >> 24);
+						const bool ominus = o & 1u;
+						if (role == 2) { // probe: primers on either side of me
+							if (ominus && o < k && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
+							if (!ominus && o > k && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
+						} else if (minus) { // I am an f: partners r beyond the probe
+							if (!ominus && o > pnear && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
+						} else { // I am an r: partners f before the probe
+							if (ominus && o < pnear && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
+						}
 					}
-					const unsigned long long k0 = key[0];
-					pcr = !(k0 & 8u);
-					const bool has_probe = (k0 & 16u) != 0;
-					if (!pcr) {
-						valid = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
-					} else {
-						int n_minus = 0, n_plus = 0, n_probe = 0;
-						for (uint32_t i = 0; i < cnt; i++) {
-							const unsigned long long k = key[i];
-							if (key_role(k) == 2) n_probe++;
-							else if (k & 1u) n_minus++;
-							else n_plus++;
-						}
-						if (n_minus != 0 && n_plus != 0 && !(has_probe && n_probe == 0)) { // early exits, amplicon_search.cpp:101-126
-							// cull_oligo_match, amplicon_search.cpp:679-765 (every entry is still unbound here)
-							const uint32_t threshold = uint32_t(a.max_len) + 50u;
-							for (uint32_t f = 0; f < cnt; f++) {
-								const uint32_t fr = key_role(key[f]);
-								const bool fminus = key[f] & 1u;
-								if (!fminus || fr == 2) continue;
-								const uint32_t floc = uint32_t(key[f] >> 24);
-								for (uint32_t r = f + 1; r < cnt; r++) {
-									const uint32_t rloc = uint32_t(key[r] >> 24);
-									if (rloc - floc > threshold) break;
-									const uint32_t rr = key_role(key[r]);
-									const bool rminus = key[r] & 1u;
-									if (rminus || rr == 2) continue;
-									if (!a.single_primer_pcr && fr == rr) continue;
-									if (has_probe) {
-										for (uint32_t p = f + 1; p < r; p++)
-											if (key_role(key[p]) == 2) valid |= (1ull << p) | (1ull << f) | (1ull << r);
-									} else {
-										valid |= (1ull << f) | (1ull << r);
-									}
-								}
-							}
-							// strand counts of the first cull (amplicon_search.cpp:748-755): the reference looks at the
-							// element FOLLOWING each valid one (past-the-end counts nothing here)
-							int cm = 0, cp = 0;
-							for (uint32_t i = 0; i + 1 < cnt; i++)
-								if ((valid >> i) & 1ull) {
-									const bool nminus = key[i + 1] & 1u;
-									cm += nminus ? 1 : 0;
-									cp += nminus ? 0 : 1;
-								}
-							if (cm < cp) gflags |= GROUP_MINUS_FIRST; // amplicon_search.cpp:131
-							// Phase B = what the reference binds only after both primers were tried on the first
-							// strand (amplicon_search.cpp:131-353): the other strand's primers and the probe.
-							for (uint32_t i = 0; i < cnt; i++)
-								if ((valid >> i) & 1ull) {
-									const bool iminus = key[i] & 1u;
-									if (key_role(key[i]) == 2 || iminus != ((gflags & GROUP_MINUS_FIRST) != 0)) phase_b |= 1ull << i;
-								}
+					if (role == 2) {
+						for (int rf = 0; rf < 2; rf++)
+							for (int rr = 0; rr < 2; rr++)
+								if ((single || rf != rr) && f_ok[rf] && r_ok[rr] && r_loc[rr] - f_loc[rf] <= threshold) valid = true;
+					} else if (have_p) {
+						for (int ro = 0; ro < 2; ro++) {
+							if (!single && uint32_t(ro) == role) continue;
+							if (minus ? (r_ok[ro] && r_loc[ro] - loc <= threshold) : (f_ok[ro] && loc - f_loc[ro] <= threshold)) valid = true;
 						}
 					}
 				}
-				const uint32_t n_valid = uint32_t(__popcll(valid));
-				const uint32_t n_a = uint32_t(__popcll(valid & ~phase_b));
+				if (valid) {
+					k |= K_VALID;
+					atomicAdd(&nvna[la], 1u);
+					if (!(k & 8u)) {
+						// strand of the list element FOLLOWING a valid one (amplicon_search.cpp:748-755; past-the-end counts
+						// nothing) decides which strand is bound first (:131)
+						unsigned long long next = ~0ull;
+						for (uint32_t x = 0; x < cnt; x++) {
+							const unsigned long long o = srt[s0 + x] & ~(K_VALID | K_PHASE_B);
+							if (o > (k & ~(K_VALID | K_PHASE_B)) && o < next) next = o;
+						}
+						if (next != ~0ull) atomicAdd(&cmcp[la], (next & 1u) ? 1u : 0x10000u);
+					}
+				}
+				srt[i] = k;
+			}
+			wave_sync();
+#ifdef TNT_EXP_STATS
+		ST(3);
+#endif
+			// Phase B = what the reference binds only after both primers were tried on the first strand
+			// (amplicon_search.cpp:131-353): the other strand's primers and the probe.
+			for (uint32_t i = lane; i < n; i += 64) {
+				unsigned long long k = srt[i];
+				if (!(k & K_VALID)) continue;
+				const uint32_t la = uint32_t(k >> 56);
+				bool pb = false;
+				if (!(k & 8u)) {
+					const uint32_t c2 = cmcp[la];
+					const bool minus_first = (c2 & 0xFFFFu) < (c2 >> 16);
+					pb = key_role(k) == 2 || bool(k & 1u) != minus_first;
+				}
+				if (pb) srt[i] = k | K_PHASE_B;
+				else atomicAdd(&nvna[la], 0x10000u);
+			}
+			wave_sync();
+#ifdef TNT_EXP_STATS
+		ST(4);
+#endif
 
-				// wave-wide exclusive prefix sums of (items, phase-A items, groups): one atomic per counter and
-				// wavefront.  The counters are sharded (a single hot word sustains only ~88 atomics/us): every
-				// wavefront appends to the output region of its shard; consumers map a linear index back to
-				// (shard, offset) with the shard prefix sums (shard_locate).
-				uint32_t ii = n_valid, ia = n_a, ig = n_valid ? 1u : 0u;
+			// wave-wide exclusive prefix sums of (items, phase-A items, groups) over the assays: one atomic per counter
+			// and wavefront.  The counters are sharded (a single hot word sustains only ~88 atomics/us): every
+			// wavefront appends to the output region of its shard; consumers map a linear index back to
+			// (shard, offset) with the shard prefix sums (shard_locate).
+			uint32_t bi = 0, ba = 0, bg = 0;
+			{
+				constexpr int PER = SEED_MAX_ASSAYS / 64;
+				uint32_t nv[PER], na[PER], gf[PER];
+				uint32_t ii = 0, ia = 0, ig = 0;
+#pragma unroll
+				for (int m = 0; m < PER; m++) {
+					const uint32_t la = uint32_t(lane) * PER + m;
+					const uint32_t v = la < n_chunk ? nvna[la] : 0u;
+					nv[m] = v & 0xFFFFu, na[m] = v >> 16;
+					gf[m] = la < n_chunk ? (((cmcp[la] & 0xFFFFu) < (cmcp[la] >> 16)) ? GROUP_MINUS_FIRST : 0u) : 0u;
+					ii += nv[m], ia += na[m], ig += nv[m] ? 1u : 0u;
+				}
+				const uint32_t si = ii, sa = ia, sg = ig;
 				for (int d = 1; d < 64; d <<= 1) {
 					const uint32_t yi = __shfl_up(ii, d), ya = __shfl_up(ia, d), yg = __shfl_up(ig, d);
 					if (lane >= d) ii += yi, ia += ya, ig += yg;
 				}
-				uint32_t bi = 0, ba = 0, bg = 0;
 				if (lane == 63) {
 					if (ii) bi = atomicAdd(a.item_count + shard * SHARD_STRIDE, ii);
 					if (ia) ba = atomicAdd(a.qa_count + shard * SHARD_STRIDE, ia);
@@ -359,42 +450,74 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 				bi = __shfl(bi, 63);
 				ba = __shfl(ba, 63);
 				bg = __shfl(bg, 63);
-				if (ti == 0) continue;
+				if (ti == 0) goto next_target; // nothing survives the cull in this chunk
 				if (bi + ti > a.item_cap / N_SHARD) {
 					if (lane == 0) atomicOr(a.err, ERR_ITEM_OVERFLOW);
-					continue;
+					goto next_target;
 				}
 				if (bg + tg > a.group_cap / N_SHARD) {
 					if (lane == 0) atomicOr(a.err, ERR_GROUP_OVERFLOW);
-					continue;
+					goto next_target;
 				}
-				bi += shard * (a.item_cap / N_SHARD) + ii - n_valid;
-				ba += shard * (a.item_cap / N_SHARD) + ia - n_a;
-				bg += shard * (a.group_cap / N_SHARD) + ig - (n_valid ? 1u : 0u);
-				if (n_valid == 0) continue;
-				const uint32_t assay = a.assay_begin + la;
-				a.groups[bg] = Group{t, assay | gflags, bi, n_valid};
-				uint32_t o = bi;
-				for (uint32_t i = 0; i < cnt; i++) {
-					if (!((valid >> i) & 1ull)) continue;
-					const unsigned long long k = key[i];
-					uint32_t wi, p;
-					key_decode(k, wi, p);
-					const bool pb = (phase_b >> i) & 1ull;
-					Item it;
-					it.target = t;
-					it.tloc = p;
-					// Slot table is laid out [assay][role]
-					it.info = wi | ((k & 1u) ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | ((assay * 3u + key_role(k)) << ITEM_SLOT_SHIFT);
-					it.group = bg;
-					a.items[o] = it;
-					if (!pb) a.qa[ba++] = o;
-					o++;
+				bi += shard * (a.item_cap / N_SHARD);
+				ba += shard * (a.item_cap / N_SHARD);
+				bg += shard * (a.group_cap / N_SHARD);
+				uint32_t ri = ii - si, ra = ia - sa, rg = ig - sg; // exclusive prefixes of this lane's first assay
+#pragma unroll
+				for (int m = 0; m < PER; m++) {
+					const uint32_t la = uint32_t(lane) * PER + m;
+					if (la < n_chunk) {
+						ibase[la] = uint16_t(ri), abase[la] = uint16_t(ra), gbase[la] = uint16_t(rg);
+						if (nv[m]) a.groups[bg + rg] = Group{t, (a.assay_begin + la) | gf[m], bi + ri, nv[m]};
+					}
+					ri += nv[m], ra += na[m], rg += nv[m] ? 1u : 0u;
 				}
 			}
+			wave_sync();
+#ifdef TNT_EXP_STATS
+		ST(5);
+#endif
+			for (uint32_t i = lane; i < n_chunk; i += 64) cmcp[i] = 0; // now the (item | phase-A << 16) cursors
+			wave_sync();
+			for (uint32_t i = lane; i < n; i += 64) {
+				const unsigned long long k = srt[i];
+				if (!(k & K_VALID)) continue;
+				const uint32_t la = uint32_t(k >> 56), assay = a.assay_begin + la;
+				const bool pb = (k & K_PHASE_B) != 0;
+				const uint32_t cur = atomicAdd(&cmcp[la], pb ? 1u : 0x10001u);
+				const uint32_t o = bi + ibase[la] + (cur & 0xFFFFu);
+				uint32_t wi, p;
+				key_decode(k, wi, p);
+				Item it;
+				it.target = t;
+				it.tloc = p;
+				// Slot table is laid out [assay][role]
+				it.info = wi | ((k & 1u) ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | ((assay * 3u + key_role(k)) << ITEM_SLOT_SHIFT);
+				it.group = bg + gbase[la];
+				a.items[o] = it;
+				if (!pb) a.qa[ba + abase[la] + (cur >> 16)] = o;
+			}
 		}
+	next_target:
 		wave_sync();
+#ifdef TNT_EXP_STATS
+		ST(6);
+		{
+			long long prev = st_t[0];
+			for (int q = 1; q < 7; q++) {
+				if (st_t[q] == 0) continue; // phase skipped (no seeds)
+				st_acc[q - 1] += st_t[q] - prev;
+				prev = st_t[q];
+			}
+		}
+#endif
 	}
+#ifdef TNT_EXP_STATS
+	if (lane == 0 && a.debug) {
+		for (int q = 0; q < 6; q++) atomicAdd(a.debug + q, uint32_t(st_acc[q] >> 10));
+		atomicAdd(a.debug + 7, 1u);
+	}
+#endif
 }
 
 } // namespace tnt
