@@ -178,6 +178,31 @@ void tnt_db_destroy(tnt_db *db);
 size_t tnt_db_num_targets(const tnt_db *db);
 uint64_t tnt_db_num_bases(const tnt_db *db);
 
+/* Target ingest: FASTA text -> device-resident packed targets, parsed on the GPU.  Replaces
+ * sequence_data::load_fasta + read_bio_seq_fasta_slow (sequence_data_fastx.cpp:13-79,187-382) for a whole file:
+ * a record starts at the first '>' of a line; the defline runs to the first '\n' or '\r' (leading white space
+ * dropped); white space, '*' and '-' are dropped from the sequence, the rest goes through ascii_to_hash_base
+ * (seq.h:148-189: case-insensitive, U -> T, IUPAC kept, anything else DB_UNKNOWN).  Target i of the database is
+ * record i of the text (seq_index = first_seq_index + i).  `text` is borrowed for the call.               */
+int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uint32_t first_seq_index, tnt_db **out);
+/* Same from a file; gzip-compressed files are inflated with zlib like the reference does (gzopen/gzread). */
+int tnt_db_load_fasta(tnt_ctx *ctx, const char *path, uint32_t first_seq_index, tnt_db **out);
+/* Defline of target i (databases made from FASTA text; empty otherwise).  Owned by the database. */
+int tnt_db_defline(const tnt_db *db, size_t i, const char **defline, size_t *len);
+/* 1-byte codes (seq.h:12-35) of target i, rebuilt from the packed rows; returns the length or a TNT_E_* code. */
+int64_t tnt_db_target_codes(tnt_ctx *ctx, tnt_db *db, size_t i, uint8_t *codes, size_t cap);
+/* Where the time of the last ingest went (ms) and what it moved. */
+typedef struct tnt_ingest_timing {
+	float read_ms;    /* file read / inflate (tnt_db_load_fasta only) */
+	float index_ms;   /* host: record boundaries and deflines */
+	float h2d_ms;     /* text -> device */
+	float count_ms;   /* device: bases and exceptions per record */
+	float layout_ms;  /* host: row offsets (device -> host lengths, prefix sums, host -> device) */
+	float pack_ms;    /* device: 2-bit rows + exception lists */
+	uint64_t text_bytes, bases, exceptions;
+} tnt_ingest_timing;
+int tnt_db_ingest_timing(const tnt_db *db, tnt_ingest_timing *out);
+
 /* The hot path: seeds -> cull -> bind -> pair for every (target, assay).  Hits are owned by
  * the context until the next tnt_search / tnt_ctx_destroy.                                  */
 int tnt_search(tnt_ctx *ctx, tnt_db *db, const tnt_hit **hits, size_t *n_hits);

@@ -26,6 +26,7 @@
 #include "seq.h"
 #include "compress.h"
 #include "degenerate_na.h"
+#include "sequence_data.h"
 
 #include <omp.h>
 #include <cstring>
@@ -568,6 +569,43 @@ int tntref_expand(const char *oligo, char *buf, size_t cap, int *n_out, int *deg
 		memcpy(buf, joined.c_str(), joined.size() + 1);
 		*n_out = int(l.size());
 		*degeneracy_out = int(degeneracy(string(oligo)));
+		return 0;
+	} catch (const char *e) {
+		g_err = e;
+		return -1;
+	}
+}
+
+// FASTA ingest through the reference's own reader: sequence_data::open -> load_fasta (sequence_data_fastx.cpp:13-79),
+// read_bio_seq -> read_bio_seq_fasta_slow (:187-382).  Outputs are malloc'ed: 1-byte codes back to back,
+// n + 1 offsets, deflines joined by '\n'.
+int tntref_read_fasta(const char *path, uint8_t **codes, uint64_t **offsets, size_t *n_targets, char **deflines)
+{
+	try {
+		sequence_data sd;
+		sd.open(path, vector<string>(), vector<string>());
+		const size_t n = sd.size();
+		vector<uint8_t> all;
+		vector<uint64_t> off(1, 0);
+		string defs;
+		for (size_t i = 0; i < n; i++) {
+			pair<string, SEQPTR> seq;
+			sd.read_bio_seq(seq, (unsigned int)i);
+			const unsigned int len = SEQ_SIZE(seq.second);
+			const SEQPTR p = SEQ_START(seq.second);
+			all.insert(all.end(), (const uint8_t *)p, (const uint8_t *)p + len);
+			off.push_back(all.size());
+			defs += seq.first;
+			defs += '\n';
+			delete[] seq.second;
+		}
+		*codes = (uint8_t *)malloc(all.size() + 1);
+		memcpy(*codes, all.data(), all.size());
+		*offsets = (uint64_t *)malloc(off.size() * sizeof(uint64_t));
+		memcpy(*offsets, off.data(), off.size() * sizeof(uint64_t));
+		*deflines = (char *)malloc(defs.size() + 1);
+		memcpy(*deflines, defs.c_str(), defs.size() + 1);
+		*n_targets = n;
 		return 0;
 	} catch (const char *e) {
 		g_err = e;

@@ -1634,6 +1634,81 @@ int tntor_heterodimer(const tnt_options *opt, const char *a, const char *b, floa
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// FASTA ingest.  Restates sequence_data::load_fasta (sequence_data_fastx.cpp:13-79) and
+// read_bio_seq_fasta_slow (:187-382) + ascii_to_hash_base (seq.h:148-189) on an in-memory copy of the file.
+static uint8_t ascii_to_code(unsigned char c)
+{
+	switch (toupper(c)) { // seq.h:150-187
+	case 'A': return 0;
+	case 'C': return 1;
+	case 'G': return 2;
+	case 'T':
+	case 'U': return 3;
+	case 'I': return 4;
+	case 'M': return 5;
+	case 'R': return 6;
+	case 'S': return 7;
+	case 'V': return 8;
+	case 'W': return 9;
+	case 'Y': return 10;
+	case 'H': return 11;
+	case 'K': return 12;
+	case 'D': return 13;
+	case 'B': return 14;
+	case 'N': return 15;
+	case '-': return 16;
+	}
+	return 17;
+}
+
+int tntor_parse_fasta(const char *text, size_t n_bytes, uint8_t **codes, uint64_t **offsets, size_t *n_targets, char **deflines)
+{
+	// record index: a '>' opens a record unless one was already seen on this line (:37-52)
+	std::vector<size_t> index;
+	bool read_fasta = false;
+	for (size_t i = 0; i < n_bytes; i++) {
+		if (!read_fasta && text[i] == '>') {
+			read_fasta = true;
+			index.push_back(i);
+		} else if (text[i] == '\n') {
+			read_fasta = false;
+		}
+	}
+	const size_t n = index.size();
+	index.push_back(n_bytes);
+	std::vector<uint8_t> all;
+	std::vector<uint64_t> off(1, 0);
+	std::string defs;
+	for (size_t r = 0; r < n; r++) {
+		const char *ptr = text + index[r] + 1, *last = text + index[r + 1]; // skip the '>' (:245)
+		while (last > ptr && isspace((unsigned char)*ptr)) ptr++;           // :248-250
+		if (ptr == last) {
+			g_err = "Truncated fasta file detected!";
+			return -1;
+		}
+		const char *defline_start = ptr;
+		while (last > ptr && *ptr != '\n' && *ptr != '\r') ++ptr; // :265-267
+		if (ptr == last) {
+			g_err = "Truncated fasta file detected!";
+			return -1;
+		}
+		defs.append(defline_start, ptr - defline_start);
+		defs += '\n';
+		for (; ptr != last; ++ptr) // :366-370
+			if (!isspace((unsigned char)*ptr) && *ptr != '*' && *ptr != '-' && *ptr != '\r') all.push_back(ascii_to_code((unsigned char)*ptr));
+		off.push_back(all.size());
+	}
+	*codes = (uint8_t *)malloc(all.size() + 1);
+	memcpy(*codes, all.data(), all.size());
+	*offsets = (uint64_t *)malloc(off.size() * sizeof(uint64_t));
+	memcpy(*offsets, off.data(), off.size() * sizeof(uint64_t));
+	*deflines = (char *)malloc(defs.size() + 1);
+	memcpy(*deflines, defs.c_str(), defs.size() + 1);
+	*n_targets = n;
+	return 0;
+}
+
 void tntor_free(void *p) { free(p); }
 
 } // extern "C"

@@ -9,6 +9,9 @@ from the sources under /root/reference by oracle/Makefile).  Only runs in the bu
                       tm/dH/dS/dG as float32 bit patterns, anchors, counts, ranges, alignment text.
   g3_structure.json.gz  G3: hairpin / homodimer / heterodimer Tm of assay oligos (tntblast_local.cpp:656-686): random
                       oligos, designed stem-loops (incl. the special tri/tetra-loops), palindromes, repeats.
+  g6_fasta.json.gz    G6: FASTA ingest (sequence_data_fastx.cpp:13-79,187-382): a text exercising every reader rule (CRLF, blank
+                      lines, lower case, U, IUPAC, unknown characters, '*', '-', '>' inside deflines and mid-line) and the
+                      codes / deflines the reference's sequence_data reads from it.
   g4_seeds.json.gz    G4: seed lists, both strands, incl. N-runs / IUPAC targets (pins SURVEY Q1/Q2).
   g5_search_cfgN.json.gz  G5: end-to-end hit sets of miniature copies of BASELINE configs 1-5 and of the
                       README amplicon case (README.md:130-203).
@@ -171,6 +174,13 @@ def main():
     st = [r[0] for r in fixtures[0]["expected"]]
     print("G2: %d cases, %d bound at defaults, %d with >1 maximal cell" % (
         len(st), st.count(0), sum(1 for r in fixtures[0]["expected"] if r[20] > 1)))
+
+    # ---- G6
+    text = synth.quirky_fasta(np.random.default_rng(6), n_records=60)
+    codes, offsets, names = ref.parse_fasta(text)
+    dump("g6_fasta.json.gz", {"text_latin1": text.decode("latin-1"), "deflines": names,
+                              "targets": [synth.decode(codes[int(offsets[t]):int(offsets[t + 1])]) for t in range(len(names))]})
+    print("G6: %d records, %d bases" % (len(names), int(offsets[-1])))
 
     # ---- G4
     wl = synth.make_workload(5, n_targets=100, n_assays=12)

@@ -90,6 +90,56 @@ def test_structure_vs_oracle(Engine, oracle):
     e.close()
 
 
+def test_g6_fasta_ingest_golden(Engine):
+    """FASTA text parsed on the GPU == what the reference's reader returns (codes, deflines)."""
+    g = gu.load("g6_fasta.json.gz")
+    e = Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGTACGTACGTACGTAC")])
+    db = e.pack_fasta(g["text_latin1"].encode("latin-1"), first_seq_index=7)
+    assert db.n_targets == len(g["deflines"])
+    assert db.n_bases == sum(len(t) for t in g["targets"])
+    for t, want in enumerate(g["targets"]):
+        assert db.defline(t) == g["deflines"][t]
+        assert synth.decode(db.target_codes(t)) == want, t
+    tm = db.ingest_timing()
+    assert tm.bases == db.n_bases and tm.text_bytes == len(g["text_latin1"])
+    db.close()
+    empty = e.pack_fasta(b"no record here\n")
+    assert empty.n_targets == 0 and len(e.search(empty)) == 0
+    empty.close()
+    with pytest.raises(Exception):
+        e.pack_fasta(b">truncated defline")
+    e.close()
+
+
+@pytest.mark.parametrize("cfg,nt,na", [(5, 400, 40), (2, 600, 48)])
+def test_fasta_ingest_search_parity(Engine, oracle, cfg, nt, na, tmp_path):
+    """A database ingested from FASTA text (or a gzip file) gives the same hits as one packed from codes."""
+    import gzip
+    wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=61)
+    text = synth.to_fasta(wl.codes, wl.offsets, width=61)
+    e = Engine(wl.options, wl.expanded)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    assert len(want) > 0
+    a = e.pack(wl.codes, wl.offsets)
+    b = e.pack_fasta(text)
+    path = tmp_path / "t.fna.gz"
+    with gzip.open(path, "wb") as f:
+        f.write(text)
+    c = e.load_fasta(str(path))
+    for db in (a, b, c):
+        assert db.n_targets == wl.n_targets and db.n_bases == wl.n_bases
+        hits = e.search(db)
+        assert tc.sorted_hit_keys(hits) == want
+        if len(hits):  # amplicon text comes from the host copy / the rows fetched back from the device
+            assert e.hit_sequence(a, hits[0]) == e.hit_sequence(db, hits[0])
+    for t in (0, nt // 2, nt - 1):
+        assert np.array_equal(b.target_codes(t), wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])])
+        assert c.defline(t) == "seq%d synthetic target" % t
+    for db in (a, b, c):
+        db.close()
+    e.close()
+
+
 def test_g4_seeds_golden(Engine):
     fx = gu.load("g4_seeds.json.gz")
     codes, offsets = gu.pack_targets(fx["targets"])

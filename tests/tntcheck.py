@@ -218,6 +218,44 @@ class _CpuImpl:
         return f32_bits(h.value), f32_bits(d.value), (f32_bits(x.value) if b else None)
 
 
+    def _fasta_out(self, rc, codes, offsets, n, defs):
+        assert rc == 0, self.error()
+        nt = n.value
+        off = np.ctypeslib.as_array(offsets, shape=(nt + 1,)).copy()
+        cod = np.ctypeslib.as_array(codes, shape=(max(1, int(off[-1])),)).copy()[:int(off[-1])]
+        names = C.string_at(defs).decode("latin-1").split("\n")[:nt]
+        for p in (codes, offsets, defs):
+            self._free(p)
+        return cod, off, names
+
+    def parse_fasta(self, text):
+        """FASTA bytes -> (codes, offsets, deflines).  The reference reads files, so RefImpl goes through a temp file."""
+        codes, offsets, n, defs = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)(), C.c_size_t(), C.c_void_p()
+        if self.prefix == "tntor_":
+            f = self.lib.tntor_parse_fasta
+            f.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint64)),
+                          C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+            rc = f(text, len(text), C.byref(codes), C.byref(offsets), C.byref(n), C.byref(defs))
+        else:
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".fna", delete=False) as tmp:
+                tmp.write(text)
+            try:
+                return self.read_fasta(tmp.name)
+            finally:
+                os.unlink(tmp.name)
+        return self._fasta_out(rc, codes, offsets, n, defs)
+
+    def read_fasta(self, path):
+        codes, offsets, n, defs = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)(), C.c_size_t(), C.c_void_p()
+        assert self.prefix == "tntref_"
+        f = self.lib.tntref_read_fasta
+        f.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t),
+                      C.POINTER(C.c_void_p)]
+        rc = f(os.fsencode(path), C.byref(codes), C.byref(offsets), C.byref(n), C.byref(defs))
+        return self._fasta_out(rc, codes, offsets, n, defs)
+
+
 class RefImpl(_CpuImpl):
     prefix = "tntref_"
     path = REF_SO

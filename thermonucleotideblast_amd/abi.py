@@ -125,6 +125,12 @@ class tnt_timing(C.Structure):
                 ("n_bound", C.c_uint64), ("n_hits", C.c_uint64)]
 
 
+class tnt_ingest_timing(C.Structure):
+    _fields_ = [("read_ms", C.c_float), ("index_ms", C.c_float), ("h2d_ms", C.c_float), ("count_ms", C.c_float),
+                ("layout_ms", C.c_float), ("pack_ms", C.c_float), ("text_bytes", C.c_uint64), ("bases", C.c_uint64),
+                ("exceptions", C.c_uint64)]
+
+
 HIT_SCALAR_FIELDS = [n for n, t in tnt_hit._fields_ if not n.endswith("_align")]
 HIT_FLOAT_FIELDS = [n for n, t in tnt_hit._fields_ if t is C.c_float]
 BIND_FLOAT_FIELDS = ["tm", "dH", "dS", "dg"]

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -26,6 +27,9 @@
 #include "tnt_seed.hip.h"
 #include "tnt_bind.hip.h"
 #include "tnt_pair.hip.h"
+#include "tnt_ingest.hip.h"
+#include <zlib.h>
+#include <chrono>
 #include "santalucia_tables.inc"
 
 using namespace tnt;
@@ -255,6 +259,19 @@ template <class F> void parallel_for(size_t n, F f)
 	for (auto &t : th) t.join();
 }
 
+// the same for a few coarse jobs (no minimum count)
+template <class F> void parallel_for_each(size_t n, F f)
+{
+	const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+	std::vector<std::thread> th;
+	std::atomic<size_t> next(0);
+	for (unsigned w = 0; w < hw && w < n; w++)
+		th.emplace_back([&]() {
+			for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+		});
+	for (auto &t : th) t.join();
+}
+
 template <class T> struct DevBuf {
 	T *p = nullptr;
 	size_t n = 0;
@@ -284,10 +301,15 @@ template <class T> struct DevBuf {
 
 struct tnt_db {
 	tnt_ctx *ctx = nullptr;
-	std::vector<uint32_t> h_packed; // host copy (tnt_hit_sequence)
+	std::vector<uint32_t> h_packed; // host copy (tnt_hit_sequence); fetched from the device on first use after a GPU ingest
 	std::vector<uint64_t> h_word_off;
 	std::vector<uint32_t> h_len, h_exc_off, h_exc_pos;
 	std::vector<uint8_t> h_exc_code;
+	bool host_copy = false;         // h_packed / h_exc_pos / h_exc_code are filled
+	uint64_t n_exceptions = 0;
+	std::string deflines;           // FASTA ingest: all deflines back to back
+	std::vector<uint64_t> defline_off;
+	tnt_ingest_timing ingest;
 	DevBuf<uint32_t> packed, len, exc_off, exc_pos;
 	DevBuf<uint64_t> word_off;
 	DevBuf<uint8_t> exc_code;
@@ -914,6 +936,9 @@ int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, s
 		exc_count[t] = ne;
 	});
 	for (size_t t = 0; t < n_targets; t++) db->h_exc_off[t + 1] = db->h_exc_off[t] + exc_count[t];
+	db->n_exceptions = db->h_exc_off[n_targets];
+	db->host_copy = true;
+	memset(&db->ingest, 0, sizeof(db->ingest));
 	db->h_exc_pos.resize(std::max<size_t>(1, db->h_exc_off[n_targets]));
 	db->h_exc_code.resize(std::max<size_t>(1, db->h_exc_off[n_targets]));
 	parallel_for(n_targets, [&](size_t t) {
@@ -951,6 +976,263 @@ void tnt_db_destroy(tnt_db *db)
 
 size_t tnt_db_num_targets(const tnt_db *db) { return db ? db->n_targets : 0; }
 uint64_t tnt_db_num_bases(const tnt_db *db) { return db ? db->n_bases : 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Target ingest: FASTA text -> packed rows, parsed on the device (tnt_ingest.hip.h)
+namespace {
+
+double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ascii_to_hash_base (seq.h:148-189) behind the skip rule of read_bio_seq_fasta_slow (sequence_data_fastx.cpp:366)
+void ingest_lut(uint8_t lut[256])
+{
+	for (int c = 0; c < 256; c++) {
+		uint8_t v = TNT_DB_UNKNOWN;
+		switch (toupper(c)) {
+		case 'A': v = TNT_DB_A; break;
+		case 'C': v = TNT_DB_C; break;
+		case 'G': v = TNT_DB_G; break;
+		case 'T':
+		case 'U': v = TNT_DB_T; break;
+		case 'I': v = TNT_DB_I; break;
+		case 'M': v = TNT_DB_M; break;
+		case 'R': v = TNT_DB_R; break;
+		case 'S': v = TNT_DB_S; break;
+		case 'V': v = TNT_DB_V; break;
+		case 'W': v = TNT_DB_W; break;
+		case 'Y': v = TNT_DB_Y; break;
+		case 'H': v = TNT_DB_H; break;
+		case 'K': v = TNT_DB_K; break;
+		case 'D': v = TNT_DB_D; break;
+		case 'B': v = TNT_DB_B; break;
+		case 'N': v = TNT_DB_N; break;
+		default: break;
+		}
+		// isspace() in the C locale, '*' and '-' never reach ascii_to_hash_base
+		if (c == ' ' || (c >= '\t' && c <= '\r') || c == '*' || c == '-') v = INGEST_SKIP;
+		lut[c] = v;
+	}
+}
+
+} // namespace
+
+int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uint32_t first_seq_index, tnt_db **out)
+{
+	if (!ctx || !out || (!text && n_bytes)) return TNT_E_ARG;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	tnt_db *db = new tnt_db;
+	db->ctx = ctx;
+	db->first_seq_index = first_seq_index;
+	memset(&db->ingest, 0, sizeof(db->ingest));
+	db->ingest.text_bytes = n_bytes;
+	double t0 = now_ms();
+
+	// ---- record boundaries: a record starts at the first '>' of a line (load_fasta, sequence_data_fastx.cpp:37-52)
+	// The text is cut into slices scanned by host threads: every '>' is a candidate; it opens a record unless
+	// another '>' precedes it on its line (looked up backwards, across the slice boundary if need be).
+	std::vector<uint64_t> rec; // offsets of the '>' + end of text
+	{
+		const size_t slice = size_t(16) << 20, n_slices = (n_bytes + slice - 1) / slice;
+		std::vector<std::vector<uint64_t>> found(n_slices);
+		parallel_for_each(n_slices, [&](size_t si) {
+			const size_t b = si * slice, e = std::min(n_bytes, b + slice);
+			for (size_t at = b; at < e;) {
+				const char *gt = static_cast<const char *>(memchr(text + at, '>', e - at));
+				if (!gt) break;
+				const size_t g = size_t(gt - text);
+				const char *nl = g ? static_cast<const char *>(memrchr(text, '\n', g)) : nullptr;
+				const size_t line = nl ? size_t(nl - text) + 1 : 0;
+				if (!memchr(text + line, '>', g - line)) found[si].push_back(g);
+				at = g + 1;
+			}
+		});
+		for (const auto &f : found) rec.insert(rec.end(), f.begin(), f.end());
+	}
+	const size_t n = rec.size();
+	rec.push_back(n_bytes);
+	std::vector<uint64_t> seq_begin(std::max<size_t>(1, n)), seq_end(std::max<size_t>(1, n)), def_begin(std::max<size_t>(1, n));
+	db->defline_off.assign(n + 1, 0);
+	std::vector<uint8_t> truncated(std::max<size_t>(1, n), 0);
+	parallel_for(n, [&](size_t r) { // defline: read_bio_seq_fasta_slow, sequence_data_fastx.cpp:248-276
+		size_t p = rec[r] + 1;
+		const size_t last = rec[r + 1];
+		while (p < last && isspace(static_cast<unsigned char>(text[p]))) p++;
+		size_t q = p;
+		while (q < last && text[q] != '\n' && text[q] != '\r') q++;
+		truncated[r] = (p == last || q == last) ? 1 : 0;
+		def_begin[r] = p;
+		seq_begin[r] = q;
+		seq_end[r] = last;
+	});
+	for (size_t r = 0; r < n; r++) {
+		if (truncated[r]) {
+			ctx->err = "Truncated fasta file detected!";
+			delete db;
+			return TNT_E_ARG;
+		}
+		db->defline_off[r + 1] = db->defline_off[r] + (seq_begin[r] - def_begin[r]);
+	}
+	db->deflines.resize(db->defline_off[n]);
+	parallel_for(n, [&](size_t r) { memcpy(&db->deflines[db->defline_off[r]], text + def_begin[r], seq_begin[r] - def_begin[r]); });
+	db->n_targets = n;
+	db->ingest.index_ms = float(now_ms() - t0);
+
+	// ---- text to the device
+	t0 = now_ms();
+	DevBuf<uint8_t> d_text, d_lut;
+	DevBuf<uint64_t> d_begin, d_end;
+	DevBuf<uint32_t> d_nexc;
+	uint8_t lut[256];
+	ingest_lut(lut);
+	hipError_t e;
+	if ((e = d_text.alloc(n_bytes + 8)) != hipSuccess || (e = d_lut.alloc(256)) != hipSuccess || (e = d_begin.upload(seq_begin)) != hipSuccess ||
+	    (e = d_end.upload(seq_end)) != hipSuccess || (e = db->len.alloc(std::max<size_t>(1, n))) != hipSuccess ||
+	    (e = d_nexc.alloc(std::max<size_t>(1, n))) != hipSuccess ||
+	    (n_bytes && (e = hipMemcpy(d_text.p, text, n_bytes, hipMemcpyHostToDevice)) != hipSuccess) ||
+	    (e = hipMemcpy(d_lut.p, lut, 256, hipMemcpyHostToDevice)) != hipSuccess) {
+		ctx->err = std::string("fasta upload: ") + hipGetErrorString(e);
+		delete db;
+		return TNT_E_DEVICE;
+	}
+	db->ingest.h2d_ms = float(now_ms() - t0);
+
+	IngestArgs a;
+	memset(&a, 0, sizeof(a));
+	a.text = d_text.p;
+	a.seq_begin = d_begin.p;
+	a.seq_end = d_end.p;
+	a.n_records = uint32_t(n);
+	a.lut = d_lut.p;
+	a.len = db->len.p;
+	a.n_exc = d_nexc.p;
+	const int blocks = int(std::min<size_t>(std::max<size_t>(1, (n + INGEST_WAVES - 1) / INGEST_WAVES), size_t(1) << 16));
+	hipEvent_t ev[4];
+	for (auto &x : ev) HIP_TRY(hipEventCreate(&x), ctx->err);
+	HIP_TRY(hipEventRecord(ev[0], ctx->stream), ctx->err);
+	if (n) hipLaunchKernelGGL(ingest_count_kernel, dim3(blocks), dim3(INGEST_THREADS), 0, ctx->stream, a);
+	HIP_TRY(hipEventRecord(ev[1], ctx->stream), ctx->err);
+
+	// ---- layout of the packed rows (same as tnt_db_create)
+	db->h_len.assign(std::max<size_t>(1, n), 0);
+	std::vector<uint32_t> nexc(std::max<size_t>(1, n), 0);
+	HIP_TRY(hipMemcpyAsync(db->h_len.data(), db->len.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpyAsync(nexc.data(), d_nexc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	t0 = now_ms();
+	db->h_word_off.resize(n + 1);
+	db->h_exc_off.assign(n + 1, 0);
+	uint64_t words = 0;
+	for (size_t t = 0; t < n; t++) {
+		const uint64_t len = db->h_len[t];
+		db->h_word_off[t] = words;
+		db->max_len = std::max(db->max_len, uint32_t(len));
+		db->n_bases += len;
+		words += ((len + 15) / 16 + 3) / 4 * 4;
+		db->h_exc_off[t + 1] = db->h_exc_off[t] + nexc[t];
+	}
+	db->h_word_off[n] = words;
+	db->n_exceptions = db->h_exc_off[n];
+	if ((e = db->packed.alloc(words + 4)) != hipSuccess || (e = db->word_off.upload(db->h_word_off)) != hipSuccess ||
+	    (e = db->exc_off.upload(db->h_exc_off)) != hipSuccess || (e = db->exc_pos.alloc(std::max<uint64_t>(1, db->n_exceptions))) != hipSuccess ||
+	    (e = db->exc_code.alloc(std::max<uint64_t>(1, db->n_exceptions))) != hipSuccess ||
+	    (e = hipMemsetAsync(db->packed.p, 0, (words + 4) * sizeof(uint32_t), ctx->stream)) != hipSuccess) {
+		ctx->err = std::string("target allocation: ") + hipGetErrorString(e);
+		delete db;
+		return TNT_E_DEVICE;
+	}
+	db->ingest.layout_ms = float(now_ms() - t0);
+	a.word_off = db->word_off.p;
+	a.exc_off = db->exc_off.p;
+	a.packed = db->packed.p;
+	a.exc_pos = db->exc_pos.p;
+	a.exc_code = db->exc_code.p;
+	HIP_TRY(hipEventRecord(ev[2], ctx->stream), ctx->err);
+	if (n) hipLaunchKernelGGL(ingest_pack_kernel, dim3(blocks), dim3(INGEST_THREADS), 0, ctx->stream, a);
+	HIP_TRY(hipEventRecord(ev[3], ctx->stream), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	HIP_TRY(hipGetLastError(), ctx->err);
+	(void)hipEventElapsedTime(&db->ingest.count_ms, ev[0], ev[1]);
+	(void)hipEventElapsedTime(&db->ingest.pack_ms, ev[2], ev[3]);
+	for (auto &x : ev) (void)hipEventDestroy(x);
+	db->ingest.bases = db->n_bases;
+	db->ingest.exceptions = db->n_exceptions;
+	*out = db;
+	return TNT_OK;
+}
+
+int tnt_db_load_fasta(tnt_ctx *ctx, const char *path, uint32_t first_seq_index, tnt_db **out)
+{
+	if (!ctx || !path || !out) return TNT_E_ARG;
+	const double t0 = now_ms();
+	gzFile in = gzopen(path, "r"); // reads plain files as they are (sequence_data_fastx.cpp:16)
+	if (!in) {
+		ctx->err = "Unable to open fasta sequence file for reading";
+		return TNT_E_ARG;
+	}
+	(void)gzbuffer(in, 1u << 20);
+	std::vector<char> text;
+	size_t used = 0;
+	while (true) {
+		if (text.size() - used < (size_t(1) << 24)) text.resize(std::max<size_t>(size_t(1) << 26, text.size() * 2));
+		const int got = gzread(in, text.data() + used, unsigned(std::min<size_t>(text.size() - used, size_t(1) << 30)));
+		if (got < 0) {
+			gzclose(in);
+			ctx->err = "Error while reading fasta file";
+			return TNT_E_ARG;
+		}
+		if (got == 0) break;
+		used += size_t(got);
+	}
+	gzclose(in);
+	const float read_ms = float(now_ms() - t0);
+	const int rc = tnt_db_create_from_fasta(ctx, text.data(), used, first_seq_index, out);
+	if (rc == TNT_OK) (*out)->ingest.read_ms = read_ms;
+	return rc;
+}
+
+int tnt_db_defline(const tnt_db *db, size_t i, const char **defline, size_t *len)
+{
+	if (!db || !defline || !len || i >= db->n_targets) return TNT_E_ARG;
+	if (db->defline_off.empty()) {
+		*defline = "";
+		*len = 0;
+		return TNT_OK;
+	}
+	*defline = db->deflines.data() + db->defline_off[i];
+	*len = size_t(db->defline_off[i + 1] - db->defline_off[i]);
+	return TNT_OK;
+}
+
+int64_t tnt_db_target_codes(tnt_ctx *ctx, tnt_db *db, size_t i, uint8_t *codes, size_t cap)
+{
+	if (!ctx || !db || db->ctx != ctx || i >= db->n_targets || (!codes && cap)) return TNT_E_ARG;
+	const uint32_t len = db->h_len[i];
+	if (len > cap) return TNT_E_LIMIT;
+	if (!len) return 0;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	DevBuf<uint8_t> d;
+	HIP_TRY(d.alloc(len), ctx->err);
+	UnpackArgs u;
+	u.db = make_view(db, 0, db->n_targets);
+	u.target = uint32_t(i);
+	u.p0 = 0;
+	u.n = len;
+	u.out = d.p;
+	hipLaunchKernelGGL(unpack_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, u);
+	HIP_TRY(hipMemcpyAsync(codes, d.p, len, hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	return int64_t(len);
+}
+
+int tnt_db_ingest_timing(const tnt_db *db, tnt_ingest_timing *out)
+{
+	if (!db || !out) return TNT_E_ARG;
+	*out = db->ingest;
+	return TNT_OK;
+}
 
 // One internal batch: seed -> bind -> filter -> pair, all on the context stream.
 static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seeds_only)
@@ -1007,7 +1289,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
-	launch_bind_phase(c, b, v, !db->h_exc_pos.empty(), c->qa.p, nullptr, cnt + C_QA);
+	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->qa.p, nullptr, cnt + C_QA);
 
 	FilterArgs f;
 	f.groups = c->groups.p;
@@ -1019,7 +1301,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	hipLaunchKernelGGL(filter_kernel, dim3(256), dim3(256), 0, c->stream, f);
 
 	// phase B: the other strand and the probes of the groups that are still alive
-	launch_bind_phase(c, b, v, !db->h_exc_pos.empty(), c->qb.p, cnt + C_QB, nullptr);
+	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->qb.p, cnt + C_QB, nullptr);
 	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 
 	PairArgs p;
@@ -1408,6 +1690,16 @@ int tnt_hit_sequence(tnt_ctx *ctx, tnt_db *db, const tnt_hit *hit, char *buf, si
 	if (!ctx || !db || !hit || !buf) return TNT_E_ARG;
 	const size_t t = size_t(hit->seq_index) - db->first_seq_index;
 	if (t >= db->n_targets) return TNT_E_ARG;
+	if (!db->host_copy) { // database built on the device (FASTA ingest): fetch the rows once
+		HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+		db->h_packed.resize(db->packed.n);
+		db->h_exc_pos.resize(db->exc_pos.n);
+		db->h_exc_code.resize(db->exc_code.n);
+		HIP_TRY(hipMemcpy(db->h_packed.data(), db->packed.p, db->packed.n * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
+		HIP_TRY(hipMemcpy(db->h_exc_pos.data(), db->exc_pos.p, db->exc_pos.n * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
+		HIP_TRY(hipMemcpy(db->h_exc_code.data(), db->exc_code.p, db->exc_code.n, hipMemcpyDeviceToHost), ctx->err);
+		db->host_copy = true;
+	}
 	const uint32_t len = db->h_len[t];
 	const uint32_t *pk = db->h_packed.data() + db->h_word_off[t];
 	auto code_at = [&](int pos) -> int {

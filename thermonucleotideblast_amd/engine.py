@@ -67,6 +67,12 @@ def load_library():
     lib.tnt_seeds.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_seed)), P(C.c_size_t)]
     lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
     lib.tnt_hit_sequence.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_hit), C.c_char_p, C.c_size_t]
+    lib.tnt_db_create_from_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, P(C.c_void_p)]
+    lib.tnt_db_load_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, P(C.c_void_p)]
+    lib.tnt_db_defline.argtypes = [C.c_void_p, C.c_size_t, P(C.c_char_p), P(C.c_size_t)]
+    lib.tnt_db_target_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, P(C.c_uint8), C.c_size_t]
+    lib.tnt_db_target_codes.restype = C.c_int64
+    lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
     lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
     if lib.tnt_abi_version() != 1:
         raise TntError("ABI version mismatch")
@@ -80,6 +86,7 @@ EXPORTED_SYMBOLS = [
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect",
     "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_hit_sequence", "tnt_oligo_structure",
+    "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_codes", "tnt_db_ingest_timing",
 ]
 
 
@@ -101,8 +108,21 @@ def _c_assays(expanded):
 class TargetBatch:
     """Device-resident packed targets (replaces read_bio_seq + DNAHash::hash, tntblast_local.cpp:510,534)."""
 
-    def __init__(self, engine, codes, offsets, first_seq_index=0):
+    def __init__(self, engine, codes=None, offsets=None, first_seq_index=0, fasta_text=None, fasta_path=None):
         self.engine = engine
+        if fasta_text is not None or fasta_path is not None:
+            # FASTA ingest, parsed on the GPU (replaces sequence_data_fastx.cpp:13-79,187-382)
+            self._h = C.c_void_p()
+            if fasta_path is not None:
+                rc = engine.lib.tnt_db_load_fasta(engine._h, os.fsencode(fasta_path), first_seq_index, C.byref(self._h))
+            else:
+                raw = fasta_text if isinstance(fasta_text, (bytes, bytearray)) else fasta_text.encode()
+                self._keep = raw
+                rc = engine.lib.tnt_db_create_from_fasta(engine._h, raw, len(raw), first_seq_index, C.byref(self._h))
+            engine._check(rc)
+            self.n_targets = int(engine.lib.tnt_db_num_targets(self._h))
+            self.n_bases = int(engine.lib.tnt_db_num_bases(self._h))
+            return
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         if offsets.ndim != 1 or len(offsets) < 1 or int(offsets[-1]) > codes.size:
@@ -114,6 +134,24 @@ class TargetBatch:
         engine._check(rc)
         self.n_targets = len(offsets) - 1
         self.n_bases = int(offsets[-1])
+
+    def defline(self, i):
+        s, n = C.c_char_p(), C.c_size_t()
+        self.engine._check(self.engine.lib.tnt_db_defline(self._h, i, C.byref(s), C.byref(n)))
+        return C.string_at(s, n.value).decode() if n.value else ""
+
+    def target_codes(self, i, cap=1 << 24):
+        """1-byte codes (seq.h:12-35) of target i, rebuilt on the device from the packed rows."""
+        buf = (C.c_uint8 * cap)()
+        n = self.engine.lib.tnt_db_target_codes(self.engine._h, self._h, i, buf, cap)
+        if n < 0:
+            self.engine._check(int(n))
+        return np.frombuffer(buf, dtype=np.uint8, count=int(n)).copy()
+
+    def ingest_timing(self):
+        t = abi.tnt_ingest_timing()
+        self.engine._check(self.engine.lib.tnt_db_ingest_timing(self._h, C.byref(t)))
+        return t
 
     def close(self):
         if self._h:
@@ -158,6 +196,14 @@ class Engine:
 
     def pack(self, codes, offsets, first_seq_index=0):
         return TargetBatch(self, codes, offsets, first_seq_index)
+
+    def pack_fasta(self, text, first_seq_index=0):
+        """FASTA text (bytes or str) -> device-resident targets, parsed on the GPU."""
+        return TargetBatch(self, first_seq_index=first_seq_index, fasta_text=text)
+
+    def load_fasta(self, path, first_seq_index=0):
+        """FASTA file (plain or gzip) -> device-resident targets."""
+        return TargetBatch(self, first_seq_index=first_seq_index, fasta_path=path)
 
     def delta_g(self):
         out = (C.c_int32 * 2401)()

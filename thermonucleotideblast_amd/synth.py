@@ -288,3 +288,51 @@ def make_workload(config: int, scale: float = 1.0, n_targets: Optional[int] = No
     wl = Workload("config%d" % config, opt, assays, codes, offsets)
     wl.expanded = expand_assays(assays)
     return wl
+
+
+def to_fasta(codes, offsets, width=70, first=0, name="seq"):
+    """FASTA text (bytes) of a workload's targets: `>name<i>` deflines, `width` bases per line."""
+    alphabet = np.frombuffer(b"ACGTIMRSVWYHKDBN-X", dtype=np.uint8)
+    out = []
+    for t in range(len(offsets) - 1):
+        seq = alphabet[np.asarray(codes[int(offsets[t]):int(offsets[t + 1])], dtype=np.uint8)].tobytes()
+        out.append(b">%s%d synthetic target\n" % (name.encode(), first + t))
+        out.extend(seq[i:i + width] + b"\n" for i in range(0, len(seq), width))
+        if not seq:
+            out.append(b"\n")
+    return b"".join(out)
+
+
+def quirky_fasta(rng, n_records=40):
+    """FASTA text exercising every rule of the reference's reader (sequence_data_fastx.cpp:13-79,187-382):
+    CRLF line ends, blank lines, lower case, U, every IUPAC code, unknown characters, '*' and '-' inside the
+    sequence, white space inside lines, '>' inside a defline, a '>' in the middle of a sequence line (opens a
+    record), leading blanks in the defline, an empty sequence, text before the first record, no final newline."""
+    letters = b"ACGTacgtUuIiMRSVWYHKDBNmrsvwyhkdbn"
+    recs = [b"this line precedes the first record and is ignored\nACGT\n"]
+    for r in range(n_records):
+        eol = b"\r\n" if r % 3 == 1 else b"\n"
+        d = b">" + (b"  \t" if r % 5 == 2 else b"") + b"rec%d some description > with a second bracket" % r + eol
+        n = int(rng.integers(0, 400)) if r % 7 else 0
+        seq = bytes(rng.choice(np.frombuffer(letters, dtype=np.uint8), size=n))
+        body = bytearray()
+        i = 0
+        while i < len(seq):
+            w = int(rng.integers(1, 80))
+            line = bytearray(seq[i:i + w])
+            if r % 4 == 0 and len(line) > 3:
+                line.insert(2, ord("*"))
+                line.insert(1, ord("-"))
+                line.insert(3, ord(" "))
+            if r % 6 == 3 and len(line) > 2:
+                line[1] = ord("X")
+                line.append(ord("?"))
+            body += bytes(line) + eol
+            if r % 9 == 4:
+                body += eol
+            i += w
+        if r % 11 == 5:
+            body += b"ACGT>midline record" + eol + b"GGCC" + eol
+        recs.append(d + bytes(body))
+    recs.append(b">last record without a final newline\nACGTNNNNACGT")
+    return b"".join(recs)
