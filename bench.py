@@ -79,7 +79,7 @@ def main():
     import torch  # first: the HIP runtime torch loads is the one libtnt_mi355x.so binds to
     import torch.distributed as dist
     import numpy as np
-    from thermonucleotideblast_amd import abi, synth
+    from thermonucleotideblast_amd import shard, synth
     from thermonucleotideblast_amd.engine import Engine
 
     if not torch.cuda.is_available():
@@ -103,23 +103,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    hit_bytes = C.sizeof(abi.tnt_hit)
-
     def gather_hits(hits):
-        """hit lists -> rank 0 over RCCL (all_gather of counts, then of the padded records)."""
+        """hit lists -> every rank over RCCL (shard.gather_hits: all_gather of counts, then of the padded records;
+        the same code runs on gloo in tests/test_distributed_cpu.py)."""
         if world == 1:
             return len(hits)
-        n = torch.tensor([len(hits)], dtype=torch.int64, device="cuda")
-        counts = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts, n)
-        nmax = max(1, int(max(c.item() for c in counts)))
-        buf = torch.zeros(nmax * hit_bytes, dtype=torch.uint8, device="cuda")
-        if len(hits):
-            raw = np.frombuffer(hits, dtype=np.uint8)
-            buf[:raw.size] = torch.from_numpy(raw.copy()).cuda()
-        out = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(out, buf)
-        return int(sum(c.item() for c in counts))
+        allhits, counts = shard.gather_hits(hits, device="cuda")
+        return int(sum(counts))
 
     def step():
         eng.enqueue(db)
