@@ -268,6 +268,20 @@ def test_edge_cases(Engine, oracle):
         Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGTNACGTACGTACGT")])
 
 
+def test_hit_buffer_grows(Engine, oracle, monkeypatch):
+    """More hits than the hit buffer holds: the library grows the buffer and repeats the search."""
+    wl = synth.make_workload(5, n_targets=300, n_assays=30, seed=9)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    assert len(want) > 64
+    monkeypatch.setenv("TNT_MI355X_HIT_CAP", "16")
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    assert tc.sorted_hit_keys(e.search(db)) == want
+    assert tc.sorted_hit_keys(e.search(db)) == want
+    db.close()
+    e.close()
+
+
 def test_size_independent_properties(Engine):
     """Full-size-style checks that need no oracle: idempotence, batch-split invariance (targets are
     independent), and reverse-complement symmetry of the hit coordinates."""

@@ -380,6 +380,10 @@ struct tnt_ctx {
 	size_t n_batches = 0;
 	uint64_t acc_items = 0, acc_bound = 0;
 	bool pending = false;
+	tnt_db *pending_db = nullptr;
+	size_t hit_cap = size_t(1) << 20; // initial hit capacity; grown on demand (tnt_search_collect)
+	int retries = 0;
+	double batch_scale = 1.0; // targets per internal batch relative to the planned number (halved after an overflow)
 
 	~tnt_ctx()
 	{
@@ -421,7 +425,6 @@ __global__ void accumulate_kernel(uint32_t *cnt)
 constexpr size_t ITEM_CAP = size_t(384) << 20;  // bind work items per internal batch
 constexpr size_t GROUP_CAP = size_t(256) << 20;
 constexpr size_t POOL_CAP = size_t(4) << 20;
-constexpr size_t HIT_CAP = size_t(1) << 20;
 
 DbView make_view(const tnt_db *db, size_t t0, size_t t1)
 {
@@ -569,7 +572,7 @@ int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 		HIP_TRY(c->qb.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->qbucket.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
-		HIP_TRY(c->hits.alloc(HIT_CAP), c->err);
+		HIP_TRY(c->hits.alloc(c->hit_cap), c->err);
 		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
 	}
 	return ensure_scratch(c, need_lmax);
@@ -683,6 +686,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	} while (0)
 	if (hipSetDevice(device) != hipSuccess) FAIL(TNT_E_DEVICE, "hipSetDevice failed");
 	if (hipStreamCreate(&c->stream) != hipSuccess) FAIL(TNT_E_DEVICE, "hipStreamCreate failed");
+	if (const char *e = getenv("TNT_MI355X_HIT_CAP")) // initial capacity of the hit buffer (it grows on demand)
+		c->hit_cap = std::max<size_t>(16, strtoull(e, nullptr, 10));
 	for (int i = 0; i < tnt_ctx::BIND_LANES; i++)
 		if (hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->lane_done[i], hipEventDisableTiming) != hipSuccess)
@@ -1320,7 +1325,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	p.assay_format = c->opt.assay_format;
 	p.target_strand = c->opt.target_strand;
 	p.hits = c->hits.p;
-	p.hit_cap = uint32_t(HIT_CAP);
+	p.hit_cap = uint32_t(c->hit_cap);
 	p.hit_count = cnt + C_HITS;
 	p.err = cnt + C_ERR;
 	hipLaunchKernelGGL(pair_kernel, dim3(256), dim3(PAIR_THREADS), 0, c->stream, p);
@@ -1404,6 +1409,7 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	size_t tpb = 1;
 	rc = plan(ctx, db, tpb);
 	if (rc) return rc;
+	tpb = std::max<size_t>(1, size_t(double(tpb) * ctx->batch_scale));
 	ctx->n_batches = 0;
 	for (size_t t0 = 0; t0 < db->n_targets; t0 += tpb) {
 		rc = enqueue_batch(ctx, db, t0, std::min(db->n_targets, t0 + tpb), false);
@@ -1411,6 +1417,7 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 		ctx->n_batches++;
 	}
 	ctx->pending = true;
+	ctx->pending_db = db;
 	return TNT_OK;
 }
 
@@ -1432,16 +1439,33 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		        64.0 * d[0] / w, 64.0 * d[1] / w, 64.0 * d[2] / w, 64.0 * d[3] / w, 64.0 * d[4] / w, 64.0 * d[5] / w, 64.0 * d[6] / w);
 	}
 #endif
+	// Capacity overflows are repaired and the search repeated: the hit buffer grows to what the pair kernel counted,
+	// the per-batch lists (work items, groups, bound records) get smaller batches.
+	if (cnt[C_ERR] & (ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW)) {
+		const uint32_t fatal = cnt[C_ERR] & ~(ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW);
+		if (!fatal && ctx->retries < 8 && ctx->pending_db) {
+			ctx->retries++;
+			if (cnt[C_ERR] & ERR_HIT_OVERFLOW) {
+				ctx->hit_cap = std::max<size_t>(ctx->hit_cap * 2, size_t(cnt[C_HITS]) + size_t(cnt[C_HITS]) / 4);
+				HIP_TRY(ctx->hits.alloc(ctx->hit_cap), ctx->err);
+			}
+			if (cnt[C_ERR] & (ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW)) ctx->batch_scale *= 0.5;
+			const int rc = tnt_search_enqueue(ctx, ctx->pending_db);
+			if (rc) return rc;
+			return tnt_search_collect(ctx, hits, n_hits);
+		}
+	}
+	ctx->retries = 0;
 	if (cnt[C_ERR]) {
 		ctx->err = err_text(cnt[C_ERR]);
 		return TNT_E_LIMIT;
 	}
-	const size_t n = std::min<size_t>(cnt[C_HITS], HIT_CAP);
+	const size_t n = std::min<size_t>(cnt[C_HITS], ctx->hit_cap);
 	if (n > ctx->h_hits_cap) {
 		if (ctx->h_hits) (void)hipHostFree(ctx->h_hits);
 		ctx->h_hits = nullptr;
 		ctx->h_hits_cap = 0;
-		const size_t cap = std::min<size_t>(HIT_CAP, std::max<size_t>(n + n / 2, 4096));
+		const size_t cap = std::max<size_t>(n + n / 2, 4096);
 		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hits), cap * sizeof(tnt_hit), hipHostMallocDefault), ctx->err);
 		ctx->h_hits_cap = cap;
 	}
