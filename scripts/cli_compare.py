@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""End-to-end check of the command-line front end on the GPU box: the same assay file + FASTA database through
+the reference binary (oracle/_ref/tntblast, OMP_NUM_THREADS=1) and through tntblast-mi355x; the two output
+files must be byte-identical.   python scripts/cli_compare.py [workdir]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from thermonucleotideblast_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "tntblast")
+CLI = os.path.join(ROOT, "thermonucleotideblast_amd", "tntblast-mi355x")
+
+CASES = [  # (name, config, targets, assays, seed, extra flags)
+    ("pcr", 2, 300, 24, 3, ["-e", "40"]),
+    ("taqman", 3, 300, 24, 4, ["-e", "40", "-E", "40"]),
+    ("degenerate", 4, 120, 20, 5, ["-e", "40"]),
+    ("padlock_probe", 5, 200, 24, 6, ["-A", "PADLOCK", "-E", "40"]),
+    ("pcr_options", 3, 250, 20, 7, ["-e", "35", "-E", "38", "--primer-clamp", "2", "--probe-clamp5", "1", "-s", "0.1", "-t", "5e-7",
+                                    "--single-primer-pcr", "F", "-l", "600", "-L", "T"]),
+    ("no_align", 2, 200, 16, 8, ["-e", "45", "-a", "F", "-M", "F", "--max-mismatch", "3"]),
+]
+
+
+def write_case(d, cfg, nt, na, seed):
+    wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
+    with open(os.path.join(d, "db.fna"), "wb") as f:
+        f.write(synth.to_fasta(wl.codes, wl.offsets))
+    with open(os.path.join(d, "assays.txt"), "w") as f:
+        f.write("# name forward reverse [probe]   (tntblast assay file)\n")
+        for a in wl.assays:
+            cols = [a.name] + [x for x in (a.forward, a.reverse, a.probe) if x]
+            f.write("\t".join(cols) + "\n")
+
+
+def main():
+    work = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "cli")
+    bad = 0
+    for name, cfg, nt, na, seed, flags in CASES:
+        d = os.path.join(work, name)
+        os.makedirs(d, exist_ok=True)
+        write_case(d, cfg, nt, na, seed)
+        common = ["-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna")] + flags
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        r1 = subprocess.run([REF] + common + ["-o", os.path.join(d, "ref.out")], env=env, capture_output=True, text=True)
+        r2 = subprocess.run([CLI] + common + ["-o", os.path.join(d, "hip.out")], capture_output=True, text=True)
+        if r1.returncode or r2.returncode:
+            print(name, "FAILED to run: ref rc", r1.returncode, "hip rc", r2.returncode, r1.stderr[-300:], r2.stderr[-300:])
+            bad += 1
+            continue
+        a = open(os.path.join(d, "ref.out"), "rb").read()
+        b = open(os.path.join(d, "hip.out"), "rb").read()
+        same = a == b
+        print("%-14s %s  ref %d bytes, %d records; hip %d bytes" % (name, "identical" if same else "DIFFERENT", len(a), a.count(b"name = "), len(b)))
+        if not same:
+            bad += 1
+            la, lb = a.decode("latin-1").split("\n"), b.decode("latin-1").split("\n")
+            for i, (x, y) in enumerate(zip(la, lb)):
+                if x != y:
+                    print("  first difference at line %d:\n    ref: %s\n    hip: %s" % (i + 1, x, y))
+                    break
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

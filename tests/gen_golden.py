@@ -12,6 +12,9 @@ from the sources under /root/reference by oracle/Makefile).  Only runs in the bu
   g6_fasta.json.gz    G6: FASTA ingest (sequence_data_fastx.cpp:13-79,187-382): a text exercising every reader rule (CRLF, blank
                       lines, lower case, U, IUPAC, unknown characters, '*', '-', '>' inside deflines and mid-line) and the
                       codes / deflines the reference's sequence_data reads from it.
+  g7_cli.json.gz      G7: end to end -- assay file + FASTA database through the reference BINARY (oracle/_ref/tntblast,
+                      OMP_NUM_THREADS=1) for PCR, TaqMan, degenerate, padlock + probe and option-variant cases; the
+                      expected "-m 0" output files, byte for byte.
   g4_seeds.json.gz    G4: seed lists, both strands, incl. N-runs / IUPAC targets (pins SURVEY Q1/Q2).
   g5_search_cfgN.json.gz  G5: end-to-end hit sets of miniature copies of BASELINE configs 1-5 and of the
                       README amplicon case (README.md:130-203).
@@ -181,6 +184,25 @@ def main():
     dump("g6_fasta.json.gz", {"text_latin1": text.decode("latin-1"), "deflines": names,
                               "targets": [synth.decode(codes[int(offsets[t]):int(offsets[t + 1])]) for t in range(len(names))]})
     print("G6: %d records, %d bases" % (len(names), int(offsets[-1])))
+
+    # ---- G7
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import cli_compare
+    cases = []
+    for name, cfg, nt, na, seed, flags in cli_compare.CASES:
+        nt, na = min(nt, 120), min(na, 12)
+        with tempfile.TemporaryDirectory() as d:
+            cli_compare.write_case(d, cfg, nt, na, seed)
+            out = os.path.join(d, "ref.out")
+            r = subprocess.run([cli_compare.REF, "-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna"), "-o", out] + flags,
+                               env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            cases.append({"name": name, "flags": flags, "assays": open(os.path.join(d, "assays.txt")).read(),
+                          "fasta": open(os.path.join(d, "db.fna")).read(), "expected": open(out).read()})
+            print("G7", name, len(cases[-1]["expected"]), "bytes,", cases[-1]["expected"].count("name = "), "records")
+    dump("g7_cli.json.gz", {"cases": cases})
 
     # ---- G4
     wl = synth.make_workload(5, n_targets=100, n_assays=12)

@@ -60,3 +60,16 @@ def test_product_does_not_reference_the_oracle():
                 for needle in ("tnt_oracle", "libtntoracle", "libtntref", "tntcheck"):
                     assert needle not in text, (f, needle)
                 assert not re.search(r"#include\s*[<\"].*oracle/", text), f
+
+
+def test_cli_front_end_builds_and_validates_arguments(hip_lib):
+    """tntblast-mi355x: built next to the library; argument errors are reported before any GPU call."""
+    import subprocess
+    import __graft_entry__ as g
+    assert os.path.exists(g.CLI)
+    r = subprocess.run([g.CLI], capture_output=True, text=True)
+    assert r.returncode != 0 and "tntblast-mi355x" in r.stderr
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-m", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "-m 0" in r.stderr
+    r = subprocess.run([g.CLI, "-i", "x"], capture_output=True, text=True)
+    assert r.returncode != 0 and "dbase" in r.stderr

@@ -268,6 +268,38 @@ def test_edge_cases(Engine, oracle):
         Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGTNACGTACGTACGT")])
 
 
+def _run_cli(args):
+    import subprocess
+    import __graft_entry__ as g
+    return subprocess.run([g.CLI] + args, capture_output=True, text=True)
+
+
+def test_cli_output_golden(Engine, tmp_path):
+    """assay file + FASTA database through tntblast-mi355x give, byte for byte, the output file
+    the reference binary wrote (PCR, TaqMan, degenerate oligos, padlock + probes, option variants)."""
+    g = gu.load("g7_cli.json.gz")
+    for case in g["cases"]:
+        d = tmp_path / case["name"]
+        d.mkdir()
+        (d / "assays.txt").write_text(case["assays"])
+        (d / "db.fna").write_text(case["fasta"])
+        r = _run_cli(["-i", str(d / "assays.txt"), "-d", str(d / "db.fna"), "-o", str(d / "out.txt")] + case["flags"])
+        assert r.returncode == 0, r.stderr
+        assert (d / "out.txt").read_text() == case["expected"], case["name"]
+
+
+def test_cli_vs_reference_binary_where_present(Engine, checkers, tmp_path):
+    """Fresh, larger inputs through both binaries (the reference binary only travels with oracle/_ref)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "tntblast")):
+        pytest.skip("no oracle/_ref/tntblast")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cli_compare.py"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+
+
 def test_hit_buffer_grows(Engine, oracle, monkeypatch):
     """More hits than the hit buffer holds: the library grows the buffer and repeats the search."""
     wl = synth.make_workload(5, n_targets=300, n_assays=30, seed=9)

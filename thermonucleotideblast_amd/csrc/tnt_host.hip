@@ -1740,14 +1740,30 @@ int tnt_hit_sequence(tnt_ctx *ctx, tnt_db *db, const tnt_hit *hit, char *buf, si
 	if (stop < start) return TNT_E_ARG;
 	const size_t n = size_t(stop - start + 1);
 	if (n + 1 > cap) return TNT_E_LIMIT;
-	// amplicon_search.cpp:508-537, padlock_search.cpp:206-218,339-351, probe_search.cpp:138-152,208-222:
-	// plus orientation copies the target, minus orientation its reverse complement; '-' outside
-	const bool minus = primers ? (hit->primer_strand == TNT_MINUS) : (hit->probe_strand == TNT_MINUS);
-	for (size_t i = 0; i < n; i++) {
-		const int pos = minus ? stop - int(i) : start + int(i);
-		char ch = '-';
-		if (pos >= 0 && pos < int(len)) ch = minus ? comp[code_at(pos)] : same[code_at(pos)];
-		buf[i] = ch;
+	// The text is '-' where nothing is copied.  Which positions are copied when the range sticks out of the target
+	// differs between the three search functions; each is followed to the letter:
+	//   amplicon()  amplicon_search.cpp:508-537   plus: target as is, minus: reverse complement; padded with '-'
+	//   padlock()   padlock_search.cpp:205-218 (its MINUS products: as is, first index max(0, 1 - start)),
+	//               :339-351 (its PLUS products: reverse complement, first index max(0, stop - len - 1))
+	//   hybrid()    probe_search.cpp:138-152,208-222: the copy always starts at index 0 from the clamped end, i.e.
+	//               the window slides into the target instead of being padded
+	const bool padlock = primers && (ctx->opt.assay_format == TNT_ASSAY_PADLOCK || ctx->opt.assay_format == TNT_ASSAY_MIPS);
+	const bool minus = primers ? ((hit->primer_strand == TNT_MINUS) != padlock) : (hit->probe_strand == TNT_MINUS);
+	for (size_t i = 0; i < n; i++) buf[i] = '-';
+	if (!minus) {
+		long ptr = std::max(0, start);
+		const long i0 = !primers ? 0 : (padlock ? std::max(0, 1 - start) : std::max(0, -start));
+		for (long i = i0; i < long(n); i++, ptr++) {
+			if (ptr >= long(len)) break;
+			buf[i] = same[code_at(int(ptr))];
+		}
+	} else {
+		long ptr = std::min<long>(stop, long(len) - 1);
+		const long i0 = !primers ? 0 : (padlock ? std::max<long>(0, long(stop) - long(len) - 1) : std::max<long>(0, long(stop) - long(len) + 1));
+		for (long i = i0; i < long(n); i++, ptr--) {
+			if (ptr < 0) break;
+			buf[i] = comp[code_at(int(ptr))];
+		}
 	}
 	buf[n] = 0;
 	return int(n);

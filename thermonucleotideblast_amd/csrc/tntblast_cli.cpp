@@ -1,0 +1,602 @@
+// tntblast_cli.cpp -- command-line front end over the C ABI: the reference's flags, its
+// assay-file format and its "-m 0" output file, with the per-target inner loop running on the MI355X.
+//
+// What is restated here is host-side only (file:line in the reference):
+//   option names and defaults            options.cpp:77-106,112-470, options.h:85-170, tntblast.h:19-76
+//   threshold rules                      options.cpp:833-916
+//   assay file                           input.cpp:43-168 (white-space columns, '#' comments, 2 / 3 / 4 columns)
+//   degenerate expansion                 degenerate_na.cpp:44-215, tntblast_util.cpp:579-713
+//   per-hit hairpin / dimer Tm           tntblast_local.cpp:656-686 (through tnt_oligo_structure)
+//   result order                         hybrid_sig::operator<, hybrid_sig.h:328-357 (std::list::sort, stable)
+//   output records                       tntblast_local.cpp:910-1280, write_alignment tntblast_util.cpp:1313-1335,
+//                                        gc_content :1274-1295, primer_heuristics :917-925 + primer.cpp:44-328
+// Everything between reading the inputs and formatting the hits is one call: tnt_search().
+// Not supported (exit with a message): BLAST / GenBank / EMBL / FASTQ databases, -D, -m 1..4, -k/-K/-r masking, -n, -S,
+// --plex, --best-match, --query-seg, --dump-query, --max-target-len fragmentation, --dinkelbach.
+#include <getopt.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <list>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/tnt_mi355x.h"
+
+namespace {
+
+struct Fail {
+	std::string msg;
+};
+[[noreturn]] void fail(const std::string &m) { throw Fail{m}; }
+
+bool parse_bool(const char *s) // options.cpp parse_bool: T / F (any case), TRUE / FALSE
+{
+	std::string v(s);
+	for (char &c : v) c = char(toupper(c));
+	if (v == "T" || v == "TRUE") return true;
+	if (v == "F" || v == "FALSE") return false;
+	fail("Unable to parse a boolean option (expected T or F)");
+}
+
+struct Options {
+	std::string input, output, dbase;
+	tnt_options t;
+	bool have_primer_bounds = false, have_probe_bounds = false;
+	bool show_alignments = true, show_sequence = true, append_name = false, ignore_probe = false, rescale_ct = true;
+	bool verbose = true;
+};
+
+struct Assay { // one line of the assay file
+	std::string name, forward, reverse, probe;
+	int id;
+};
+
+struct Expanded { // one non-degenerate assay
+	int parent; // index into the assay list (== hybrid_sig::my_id)
+	std::string forward, reverse, probe;
+	int forward_degen = 1, reverse_degen = 1, probe_degen = 1;
+};
+
+// expand_nucleic_acid, degenerate_na.cpp:69-173: odometer over the IUPAC members, first position fastest
+std::list<std::string> expand_oligo(const std::string &seq)
+{
+	std::vector<std::string> members(seq.size());
+	size_t count = 1;
+	for (size_t i = 0; i < seq.size(); i++) {
+		const char *m = nullptr;
+		switch (toupper(seq[i])) {
+		case 'A': m = "A"; break;
+		case 'T': m = "T"; break;
+		case 'G': m = "G"; break;
+		case 'C': m = "C"; break;
+		case 'I': m = "I"; break;
+		case 'M': m = "AC"; break;
+		case 'R': m = "GA"; break;
+		case 'S': m = "GC"; break;
+		case 'V': m = "GCA"; break;
+		case 'W': m = "AT"; break;
+		case 'Y': m = "TC"; break;
+		case 'H': m = "ACT"; break;
+		case 'K': m = "GT"; break;
+		case 'D': m = "GAT"; break;
+		case 'B': m = "GTC"; break;
+		case 'N': m = "ATGC"; break;
+		default: std::cerr << "Found the unknown letter \"" << seq[i] << "\"" << std::endl; fail("Unknown base!");
+		}
+		members[i] = m;
+		count *= members[i].size();
+	}
+	std::list<std::string> out;
+	std::vector<size_t> at(seq.size(), 0);
+	for (size_t n = 0; n < count; n++) {
+		std::string s(seq.size(), 'A');
+		for (size_t j = 0; j < seq.size(); j++) s[j] = members[j][at[j]];
+		out.push_back(s);
+		for (size_t j = 0; j < seq.size(); j++) {
+			if (++at[j] == members[j].size()) at[j] = 0;
+			else break;
+		}
+	}
+	return out;
+}
+
+int degeneracy(const std::string &oligo) // degenerate_na.cpp:175-215
+{
+	int d = 1;
+	for (char c : oligo) switch (toupper(c)) {
+		case 'A': case 'T': case 'G': case 'C': case 'I': break;
+		case 'M': case 'R': case 'S': case 'W': case 'Y': case 'K': d *= 2; break;
+		case 'V': case 'H': case 'D': case 'B': d *= 3; break;
+		case 'N': d *= 4; break;
+		default: std::cerr << "Found the unknown letter '" << c << "'" << std::endl; fail("Unknown base!");
+		}
+	return d;
+}
+
+std::vector<Assay> read_input_file(const std::string &path, bool ignore_probe) // input.cpp:43-168
+{
+	std::ifstream fin(path.c_str());
+	if (!fin) {
+		std::cerr << "Unable to open " << path << " for reading" << std::endl;
+		fail("read_input_file: I/O Error");
+	}
+	std::vector<Assay> out;
+	std::string line;
+	while (std::getline(fin, line)) {
+		const std::string::size_type pos = line.find('#');
+		if (pos != std::string::npos) line = line.substr(0, pos);
+		std::stringstream ss(line);
+		std::vector<std::string> col;
+		std::string entry;
+		while (ss >> entry) col.push_back(entry);
+		if (col.empty()) continue;
+		Assay a;
+		a.id = int(out.size());
+		a.name = col[0];
+		switch (col.size()) {
+		case 2:
+			if (ignore_probe) fail("ignore_probe is true but only probes have been provided!");
+			a.probe = col[1];
+			break;
+		case 3:
+			a.forward = col[1], a.reverse = col[2];
+			break;
+		case 4:
+			a.forward = col[1], a.reverse = col[2];
+			if (!ignore_probe) a.probe = col[3];
+			break;
+		default: std::cerr << "Error reading " << path << std::endl; fail("Error: Invalid number of arguments input file");
+		}
+		out.push_back(a);
+	}
+	return out;
+}
+
+std::vector<Expanded> expand_assays(const std::vector<Assay> &assays, bool rescale_ct) // tntblast_util.cpp:579-713
+{
+	std::vector<Expanded> out;
+	for (const Assay &a : assays) {
+		std::list<std::pair<std::string, std::string>> primers;
+		if (!a.forward.empty() && !a.reverse.empty())
+			for (const std::string &f : expand_oligo(a.forward))
+				for (const std::string &r : expand_oligo(a.reverse)) primers.push_back(std::make_pair(f, r));
+		std::list<std::string> probes;
+		if (!a.probe.empty()) probes = expand_oligo(a.probe);
+		const size_t n = primers.size() * probes.size();
+		if (n > 1) std::cout << "Expanded degenerate bases in " << a.name << " to make " << n << " non-degenerate assays" << std::endl;
+		Expanded e;
+		e.parent = a.id;
+		e.forward_degen = (rescale_ct && !a.forward.empty()) ? degeneracy(a.forward) : 1;
+		e.reverse_degen = (rescale_ct && !a.reverse.empty()) ? degeneracy(a.reverse) : 1;
+		e.probe_degen = (rescale_ct && !a.probe.empty()) ? degeneracy(a.probe) : 1;
+		if (primers.empty()) {
+			for (const std::string &p : probes) {
+				e.probe = p;
+				out.push_back(e);
+			}
+		} else {
+			for (const auto &pr : primers) {
+				e.forward = pr.first, e.reverse = pr.second;
+				if (probes.empty()) {
+					e.probe.clear();
+					out.push_back(e);
+				} else {
+					for (const std::string &p : probes) {
+						e.probe = p;
+						out.push_back(e);
+					}
+				}
+			}
+		}
+	}
+	return out;
+}
+
+float gc_content(const std::string &s) // tntblast_util.cpp:1274-1295
+{
+	float gc = 0.0f;
+	for (char c : s)
+		if (c == 'G' || c == 'g' || c == 'C' || c == 'c') gc++;
+	return gc / s.size();
+}
+
+// primer_heuristics (tntblast_util.cpp:917-925): PCRPrimer(POLY_3_GC | MULTI_5_GC | NO_POLY_RUNS | NO_3_T), run 5,
+// verbose reporting (primer.cpp:44-328, error text :406-470)
+std::string primer_heuristics(const std::string &p)
+{
+	enum { POLY_3_GC = 1, MULTI_5_GC = 2, NO_POLY_RUNS = 4, NO_3_T = 8 };
+	for (char c : p)
+		if (!strchr("ATGCatgc", c)) return "BAD_BASE";
+	int status = 0;
+	if (toupper(p.back()) == 'T') status |= NO_3_T;
+	unsigned tc = 0, ag = 0, g = 0, cc = 0, max_tc = 0, max_ag = 0, n_gc = 0, index = 0;
+	for (char ch : p) {
+		switch (toupper(ch)) {
+		case 'A': ag++, tc = 0, g = 0, cc = 0; break;
+		case 'T': tc++, ag = 0, g = 0, cc = 0; break;
+		case 'G': ag++, g++, tc = 0, cc = 0, n_gc++; break;
+		case 'C': tc++, cc++, ag = 0, g = 0, n_gc++; break;
+		}
+		max_tc = std::max(max_tc, tc);
+		max_ag = std::max(max_ag, ag);
+		if (index == 4) {
+			if (max_tc >= 2 ? n_gc > 2 : n_gc > 3) status |= MULTI_5_GC;
+		}
+		index++;
+	}
+	if (max_tc >= 5 || max_ag >= 5) status |= NO_POLY_RUNS;
+	if (cc >= 3 || g >= 3) status |= POLY_3_GC;
+	if (!status) return "PCR_VALID";
+	std::string out;
+	auto add = [&](int bit, const char *name) {
+		if (!(status & bit)) return;
+		if (!out.empty()) out += ", ";
+		out += name;
+	};
+	add(POLY_3_GC, "POLY_3_GC");
+	add(MULTI_5_GC, "MULTI_5_GC");
+	add(NO_POLY_RUNS, "NO_POLY_RUNS");
+	add(NO_3_T, "NO_3_T");
+	return out;
+}
+
+void write_alignment(std::ostream &out, const std::string &prefix, const char *alignment) // tntblast_util.cpp:1313-1335
+{
+	if (!alignment[0]) return;
+	out << prefix;
+	for (const char *c = alignment; *c; c++) {
+		out << *c;
+		if (*c == '\n') out << prefix;
+	}
+	out << std::endl;
+}
+
+struct Record { // a hit with what the writer needs beside the tnt_hit payload
+	tnt_hit h;
+	size_t order; // position in the device output (ties keep it: std::list::sort is stable)
+	float min_tm() const { return std::min(h.forward_tm, h.reverse_tm); }
+	float max_tm() const { return std::max(h.forward_tm, h.reverse_tm); }
+};
+
+bool record_less(const Record &a, const Record &b) // hybrid_sig::operator< for equal ids, hybrid_sig.h:328-357
+{
+	if (a.min_tm() != b.min_tm()) return a.min_tm() > b.min_tm();
+	if (a.h.probe_tm != b.h.probe_tm) return a.h.probe_tm > b.h.probe_tm;
+	if (a.max_tm() != b.max_tm()) return a.max_tm() > b.max_tm();
+	return a.h.seq_index < b.h.seq_index;
+}
+
+void usage()
+{
+	std::cerr << "tntblast-mi355x: the tntblast search on an MI355X (FASTA databases, -m 0 output)\n"
+	             "\t-i <assay file> -d <FASTA database, plain or gzip> [-o <output file>] -e <min primer Tm> -E <min probe Tm>\n"
+	             "\t[-x -X -z -Z -g -G -s -t -T -y -l -A <PCR|PROBE|PADLOCK|MIPS> -W -a -M -L -p -v]\n"
+	             "\t[--primer-clamp --min-max-primer-clamp --probe-clamp5 --probe-clamp3 --single-primer-pcr --target-strand\n"
+	             "\t --temperature --dangle5 --dangle3 --max-gap --max-mismatch --max-poly-degen --rescale-ct --hash-size]"
+	          << std::endl;
+}
+
+void parse_args(int argc, char **argv, Options &o)
+{
+	tnt_options_default(&o.t);
+	int flag = 0;
+	const option longs[] = {{"help", no_argument, &flag, 1},
+	                        {"primer-clamp", required_argument, &flag, 3},
+	                        {"probe-clamp5", required_argument, &flag, 4},
+	                        {"probe-clamp3", required_argument, &flag, 5},
+	                        {"plex", required_argument, &flag, 6},
+	                        {"single-primer-pcr", required_argument, &flag, 7},
+	                        {"hash-size", required_argument, &flag, 8},
+	                        {"target-strand", required_argument, &flag, 9},
+	                        {"temperature", required_argument, &flag, 10},
+	                        {"max-target-len", required_argument, &flag, 11},
+	                        {"query-seg", required_argument, &flag, 12},
+	                        {"dump-query", required_argument, &flag, 13},
+	                        {"dangle5", required_argument, &flag, 14},
+	                        {"dangle3", required_argument, &flag, 15},
+	                        {"min-max-primer-clamp", required_argument, &flag, 16},
+	                        {"dinkelbach", required_argument, &flag, 17},
+	                        {"max-gap", required_argument, &flag, 18},
+	                        {"max-mismatch", required_argument, &flag, 19},
+	                        {"rescale-ct", required_argument, &flag, 20},
+	                        {"best-match", no_argument, &flag, 21},
+	                        {"blast-include", required_argument, &flag, 22},
+	                        {"blast-exclude", required_argument, &flag, 23},
+	                        {"max-poly-degen", required_argument, &flag, 24},
+	                        {nullptr, 0, nullptr, 0}};
+	if (argc == 1) {
+		usage();
+		exit(EXIT_FAILURE);
+	}
+	int c, idx = 0;
+	opterr = 0;
+	while ((c = getopt_long(argc, argv, "-i:o:d:D:l:e:E:z:Z:x:X:g:G:s:t:T:y:A:W:m:a:M:k:K:r:v:p:n:L:S:?h", longs, &idx)) != EOF) {
+		switch (c) {
+		case 0:
+			switch (flag) {
+			case 1: usage(); exit(EXIT_SUCCESS);
+			case 3: o.t.primer_clamp = atoi(optarg); break;
+			case 4: o.t.probe_clamp_5 = atoi(optarg); break;
+			case 5: o.t.probe_clamp_3 = atoi(optarg); break;
+			case 7: o.t.single_primer_pcr = parse_bool(optarg) ? 1 : 0; break;
+			case 8: o.t.hash_word_size = atoi(optarg); break;
+			case 9: {
+				std::string v(optarg);
+				for (char &ch : v) ch = char(toupper(ch));
+				if (v == "PLUS" || v == "SENSE" || v == "+") o.t.target_strand = TNT_STRAND_PLUS;
+				else if (v == "MINUS" || v == "ANTISENSE" || v == "-") o.t.target_strand = TNT_STRAND_MINUS;
+				else if (v == "BOTH") o.t.target_strand = TNT_STRAND_BOTH;
+				else fail("Unknown --target-strand value");
+				break;
+			}
+			case 10: o.t.target_t = float(atof(optarg)); break;
+			case 14: o.t.allow_dangle_5 = parse_bool(optarg) ? 1 : 0; break;
+			case 15: o.t.allow_dangle_3 = parse_bool(optarg) ? 1 : 0; break;
+			case 16: o.t.min_max_primer_clamp = atoi(optarg); break;
+			case 17:
+				if (parse_bool(optarg)) fail("--dinkelbach is not supported by the MI355X path");
+				break;
+			case 18: o.t.max_gap = atoi(optarg); break;
+			case 19: o.t.max_mismatch = atoi(optarg); break;
+			case 20: o.rescale_ct = parse_bool(optarg); break;
+			case 24: o.t.max_poly_degen = abs(atoi(optarg)); break;
+			default: fail(std::string("--") + longs[idx].name + " is not supported by the MI355X front end");
+			}
+			break;
+		case 'i': o.input = optarg; break;
+		case 'o': o.output = optarg; break;
+		case 'd': o.dbase = optarg; break;
+		case 'l': o.t.max_len = atoi(optarg); break;
+		case 'e': o.t.min_primer_tm = float(atof(optarg)), o.have_primer_bounds = true; break;
+		case 'E': o.t.min_probe_tm = float(atof(optarg)), o.have_probe_bounds = true; break;
+		case 'z': o.t.min_primer_dg = float(atof(optarg)), o.have_primer_bounds = true; break;
+		case 'Z': o.t.min_probe_dg = float(atof(optarg)), o.have_probe_bounds = true; break;
+		case 'x': o.t.max_primer_tm = float(atof(optarg)), o.have_primer_bounds = true; break;
+		case 'X': o.t.max_probe_tm = float(atof(optarg)), o.have_probe_bounds = true; break;
+		case 'g': o.t.max_primer_dg = float(atof(optarg)), o.have_primer_bounds = true; break;
+		case 'G': o.t.max_probe_dg = float(atof(optarg)), o.have_probe_bounds = true; break;
+		case 's': o.t.salt = float(atof(optarg)); break;
+		case 't': o.t.primer_strand = float(atof(optarg)); break;
+		case 'T': o.t.probe_strand = float(atof(optarg)); break;
+		case 'y': o.t.asymmetric_strand_ratio = float(atof(optarg)); break;
+		case 'A': {
+			std::string v(optarg);
+			for (char &ch : v) ch = char(toupper(ch));
+			if (v == "PCR") o.t.assay_format = TNT_ASSAY_PCR;
+			else if (v == "PROBE") o.t.assay_format = TNT_ASSAY_PROBE;
+			else if (v == "PADLOCK") o.t.assay_format = TNT_ASSAY_PADLOCK;
+			else if (v == "MIPS") o.t.assay_format = TNT_ASSAY_MIPS;
+			else fail("Unknown assay format (-A)");
+			break;
+		}
+		case 'W': o.t.hash_word_size = atoi(optarg); break;
+		case 'm':
+			if (atoi(optarg) != 0) fail("only the verbose output file (-m 0) is supported by the MI355X front end");
+			break;
+		case 'a': o.show_alignments = parse_bool(optarg); break;
+		case 'M': o.show_sequence = parse_bool(optarg); break;
+		case 'v': o.verbose = parse_bool(optarg); break;
+		case 'p': o.ignore_probe = parse_bool(optarg); break;
+		case 'L': o.append_name = parse_bool(optarg); break;
+		case 'k':
+		case 'K':
+		case 'r':
+		case 'n':
+		case 'S':
+			if (parse_bool(optarg)) fail(std::string("-") + char(c) + " T is not supported by the MI355X front end");
+			break;
+		case 'D': fail("-D (local database) is not supported by the MI355X front end");
+		case 'h':
+		case '?': usage(); exit(EXIT_SUCCESS);
+		default: std::cerr << '"' << char(c) << "\" is not a valid option!" << std::endl; break;
+		}
+	}
+	if (o.dbase.empty()) fail("Unable to read either dbase or local_dbase");
+	if (o.input.empty()) fail("Please specify an assay file (-i)");
+	// validate_parameters, options.cpp:529-675 (the checks that concern the supported flags)
+	if (o.ignore_probe && o.t.assay_format != TNT_ASSAY_PCR) fail("Error: Ignore probes (i.e. -p T) can only be used with a PCR-based assay format");
+	if (o.t.salt <= 0.0f) fail("[Na+] (i.e. \"salt\") is less than zero");
+	if (o.t.salt >= 1.0f) fail("[Na+] (i.e. \"salt\") is greater than 1M");
+	if (o.t.primer_strand <= 0.0f) fail("[Ct] (i.e. \"primer_strand\") is less than zero");
+	if (o.t.probe_strand < 0.0f) o.t.probe_strand = o.t.primer_strand;
+	if (o.t.probe_strand <= 0.0f) fail("[Ct] (i.e. \"probe_strand\") is less than zero");
+	if (o.t.asymmetric_strand_ratio <= 0.0f) fail("The ratio of forward to reverse primer [Ct] is <= 0");
+	if (o.t.min_primer_tm > o.t.max_primer_tm) fail("min_primer_tm > max_primer_tm. Please use consistent values!");
+	if (o.t.min_probe_tm > o.t.max_probe_tm) fail("min_probe_tm > max_probe_tm. Please use consistent values!");
+}
+
+void validate_search_threshold(Options &o, const std::vector<Assay> &assays) // options.cpp:833-916
+{
+	switch (o.t.assay_format) {
+	case TNT_ASSAY_PCR:
+		for (const Assay &a : assays) {
+			if (!a.forward.empty() && !o.have_primer_bounds) fail("Please specify primer search bounds in Tm and/or Delta G");
+			if (!a.probe.empty() && !o.have_probe_bounds) fail("Please specify probe search bounds in Tm and/or Delta G");
+		}
+		break;
+	default:
+		if (!o.have_probe_bounds) {
+			if (!o.have_primer_bounds) fail("Please specify probe search bounds in Tm and/or Delta G");
+			o.t.min_probe_dg = o.t.min_primer_dg, o.t.max_probe_dg = o.t.max_primer_dg;
+			o.t.min_probe_tm = o.t.min_primer_tm, o.t.max_probe_tm = o.t.max_primer_tm;
+		}
+		break;
+	}
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+	tnt_ctx *ctx = nullptr;
+	tnt_db *db = nullptr;
+	try {
+		Options opt;
+		parse_args(argc, argv, opt);
+		std::vector<Assay> assays = read_input_file(opt.input, opt.ignore_probe);
+		if (assays.empty()) fail("No assays found in the input file");
+		validate_search_threshold(opt, assays);
+		const std::vector<Expanded> expanded = expand_assays(assays, opt.rescale_ct);
+
+		std::vector<tnt_assay> ta(expanded.size());
+		for (size_t i = 0; i < expanded.size(); i++) {
+			const Expanded &e = expanded[i];
+			ta[i].id = e.parent;
+			ta[i].degen_id = int(i);
+			ta[i].forward = e.forward.empty() ? nullptr : e.forward.c_str();
+			ta[i].reverse = e.reverse.empty() ? nullptr : e.reverse.c_str();
+			ta[i].probe = e.probe.empty() ? nullptr : e.probe.c_str();
+			ta[i].forward_degen = e.forward_degen, ta[i].reverse_degen = e.reverse_degen, ta[i].probe_degen = e.probe_degen;
+		}
+		if (tnt_ctx_create(&opt.t, ta.data(), ta.size(), 0, &ctx) != TNT_OK) fail(tnt_last_error(nullptr));
+		if (opt.verbose) std::cout << "Reading sequence database: " << opt.dbase << std::endl;
+		if (tnt_db_load_fasta(ctx, opt.dbase.c_str(), 0, &db) != TNT_OK) fail(tnt_last_error(ctx));
+		if (opt.verbose) {
+			std::cout << "Found " << tnt_db_num_targets(db) << " database sequences" << std::endl;
+			std::cout << "Found " << assays.size() << " query assays" << std::endl;
+		}
+		const tnt_hit *hits = nullptr;
+		size_t n_hits = 0;
+		if (tnt_search(ctx, db, &hits, &n_hits) != TNT_OK) fail(tnt_last_error(ctx));
+
+		// results per assay id, in hybrid_sig order (tntblast_local.cpp:703-705,931)
+		std::vector<std::vector<Record>> results(assays.size());
+		for (size_t i = 0; i < n_hits; i++) results[size_t(hits[i].assay_id)].push_back(Record{hits[i], i});
+		for (auto &r : results) std::stable_sort(r.begin(), r.end(), record_less);
+
+		std::ofstream fout;
+		std::ostream *out = &std::cout;
+		if (!opt.output.empty()) {
+			fout.open(opt.output.c_str());
+			if (!fout) fail("Unable to open the output file");
+			out = &fout;
+		}
+		// strand concentrations of the self-structure values, tntblast_local.cpp:228-234,656-686
+		const float fwd_strand = opt.t.asymmetric_strand_ratio * opt.t.primer_strand, rev_strand = opt.t.primer_strand;
+		std::map<std::string, std::pair<float, float>> self_cache; // oligo + role -> (hairpin, homodimer)
+		auto self_tm = [&](const std::string &oligo, float ct, char role) {
+			const std::string key = oligo + role;
+			auto it = self_cache.find(key);
+			if (it != self_cache.end()) return it->second;
+			float h = 0, d = 0, x = 0;
+			if (tnt_oligo_structure(ctx, oligo.c_str(), nullptr, ct, ct, &h, &d, &x) != TNT_OK) fail(tnt_last_error(ctx));
+			return self_cache[key] = std::make_pair(h, d);
+		};
+		std::map<std::string, float> dimer_cache;
+		auto hetero_tm = [&](const std::string &f, const std::string &r) {
+			const std::string key = f + "/" + r;
+			auto it = dimer_cache.find(key);
+			if (it != dimer_cache.end()) return it->second;
+			float h = 0, d = 0, x = 0;
+			if (tnt_oligo_structure(ctx, f.c_str(), r.c_str(), fwd_strand, rev_strand, &h, &d, &x) != TNT_OK) fail(tnt_last_error(ctx));
+			return dimer_cache[key] = x;
+		};
+		std::vector<char> amp(1 << 20);
+		size_t total = 0;
+		for (size_t id = 0; id < results.size(); id++) {
+			if (results[id].empty()) continue;
+			*out << "#####################################################################################" << std::endl;
+			for (const Record &rec : results[id]) {
+				const tnt_hit &h = rec.h;
+				const Expanded &e = expanded[size_t(h.degen_id)];
+				total++;
+				*out << "name = " << assays[id].name << std::endl;
+				const int na = tnt_hit_sequence(ctx, db, &h, amp.data(), amp.size());
+				if (na < 0) fail("amplicon longer than the sequence buffer");
+				const std::string amplicon(amp.data(), size_t(na));
+				std::string fp, rp;
+				if (h.has_primers) {
+					const bool pcr = opt.t.assay_format == TNT_ASSAY_PCR;
+					fp = pcr ? "forward primer" : "5' probe";
+					rp = pcr ? "reverse primer" : "3' probe";
+					// single-primer amplicons swap identities (amplicon_search.cpp:453-463)
+					const std::string &fo = h.forward_oligo == 0 ? e.forward : e.reverse;
+					const std::string &ro = h.reverse_oligo == 1 ? e.reverse : e.forward;
+					*out << fp << " = 5' " << fo << " 3'" << std::endl;
+					*out << rp << " = 5' " << ro << " 3'" << std::endl;
+					const float forward_dg = h.forward_dH - opt.t.target_t * h.forward_dS;
+					const float reverse_dg = h.reverse_dH - opt.t.target_t * h.reverse_dS;
+					const std::pair<float, float> fs = self_tm(fo, fwd_strand, 'F'), rs = self_tm(ro, rev_strand, 'R');
+					*out << fp << " tm = " << h.forward_tm << std::endl;
+					*out << rp << " tm = " << h.reverse_tm << std::endl;
+					*out << fp << " hairpin tm = " << fs.first << std::endl;
+					*out << rp << " hairpin tm = " << rs.first << std::endl;
+					*out << fp << " homodimer tm = " << fs.second << std::endl;
+					*out << rp << " homodimer tm = " << rs.second << std::endl;
+					*out << "heterodimer tm = " << hetero_tm(fo, ro) << std::endl;
+					*out << fp << " dG[" << forward_dg << "] = dH[" << h.forward_dH << "] - T*dS[" << h.forward_dS << "]" << std::endl;
+					*out << rp << " dG[" << reverse_dg << "] = dH[" << h.reverse_dH << "] - T*dS[" << h.reverse_dS << "]" << std::endl;
+					*out << fp << " mismatches = " << h.forward_mm << std::endl;
+					*out << rp << " mismatches = " << h.reverse_mm << std::endl;
+					*out << fp << " gaps = " << h.forward_gap << std::endl;
+					*out << rp << " gaps = " << h.reverse_gap << std::endl;
+					if (pcr) {
+						*out << "min 3' clamp = " << std::min(h.forward_primer_clamp, h.reverse_primer_clamp) << std::endl;
+						*out << "max 3' clamp = " << std::max(h.forward_primer_clamp, h.reverse_primer_clamp) << std::endl;
+					} else {
+						*out << "5' probe 3' ligation clamp = " << h.forward_primer_clamp << std::endl;
+						*out << "3' probe 5' ligation clamp = " << h.reverse_primer_clamp << std::endl;
+					}
+					*out << fp << " %GC = " << 100.0f * gc_content(fo) << std::endl;
+					*out << rp << " %GC = " << 100.0f * gc_content(ro) << std::endl;
+					*out << fp << " heuristics = " << primer_heuristics(fo) << std::endl;
+					*out << rp << " heuristics = " << primer_heuristics(ro) << std::endl;
+					if (pcr) {
+						*out << "amplicon range = " << h.amplicon_start << " .. " << h.amplicon_stop << std::endl;
+						*out << "amplicon length = " << amplicon.size() << std::endl;
+					} else {
+						*out << "product range = " << h.amplicon_start << " .. " << h.amplicon_stop << std::endl;
+						*out << "product length = " << amplicon.size() << std::endl;
+					}
+					if (h.primer_strand == TNT_PLUS) *out << "Forward primer is contained in the target plus strand (+)" << std::endl;
+					else *out << "Forward primer is contained in the target minus strand (-)" << std::endl;
+				}
+				if (h.has_probe) {
+					const float probe_dg = h.probe_dH - opt.t.target_t * h.probe_dS;
+					const std::pair<float, float> ps = self_tm(e.probe, opt.t.probe_strand, 'P');
+					*out << "probe = 5' " << e.probe << " 3'" << std::endl;
+					*out << "probe tm = " << h.probe_tm << std::endl;
+					*out << "probe hairpin tm = " << ps.first << std::endl;
+					*out << "probe homodimer tm = " << ps.second << std::endl;
+					*out << "probe dG[" << probe_dg << "] = dH[" << h.probe_dH << "] - T*dS[" << h.probe_dS << "]" << std::endl;
+					*out << "probe mismatches = " << h.probe_mm << std::endl;
+					*out << "probe gaps = " << h.probe_gap << std::endl;
+					*out << "probe %GC = " << 100.0f * gc_content(e.probe) << std::endl;
+					*out << "probe range = " << h.probe_start << " .. " << h.probe_stop << std::endl;
+					if (h.probe_strand != h.primer_strand) *out << "probe contained in forward strand (+)" << std::endl;
+					else *out << "probe contained in reverse strand (-)" << std::endl;
+				}
+				if (opt.show_alignments) {
+					write_alignment(*out, fp + " align ", h.forward_align);
+					write_alignment(*out, rp + " align ", h.reverse_align);
+					write_alignment(*out, "probe align ", h.probe_align);
+				}
+				const char *defline = "";
+				size_t dl = 0;
+				(void)tnt_db_defline(db, size_t(h.seq_index), &defline, &dl);
+				*out << '>' << std::string(defline, dl);
+				if (opt.append_name) *out << ' ' << assays[id].name;
+				*out << std::endl;
+				if (opt.show_sequence) *out << amplicon << std::endl;
+				*out << std::endl;
+			}
+		}
+		if (opt.verbose) std::cout << "Found " << total << " (total) target sequence matches" << std::endl;
+		tnt_db_destroy(db);
+		tnt_ctx_destroy(ctx);
+		return EXIT_SUCCESS;
+	} catch (const Fail &f) {
+		std::cerr << "Caught the error: " << f.msg << std::endl;
+		if (db) tnt_db_destroy(db);
+		if (ctx) tnt_ctx_destroy(ctx);
+		return EXIT_FAILURE;
+	}
+}
