@@ -187,6 +187,13 @@ uint64_t tnt_db_num_bases(const tnt_db *db);
 int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uint32_t first_seq_index, tnt_db **out);
 /* Same from a file; gzip-compressed files are inflated with zlib like the reference does (gzopen/gzread). */
 int tnt_db_load_fasta(tnt_ctx *ctx, const char *path, uint32_t first_seq_index, tnt_db **out);
+/* Streaming form for databases larger than one wants resident: batches of whole records, about `max_bytes` of text
+ * each (at least one record), read and inflated by a background thread while the caller searches the previous batch.
+ * seq_index keeps counting across batches.  *out == NULL at the end of the file.                              */
+typedef struct tnt_fasta_reader tnt_fasta_reader;
+int tnt_fasta_open(const char *path, tnt_fasta_reader **out);
+int tnt_fasta_next(tnt_fasta_reader *reader, tnt_ctx *ctx, size_t max_bytes, tnt_db **out);
+void tnt_fasta_close(tnt_fasta_reader *reader);
 /* Defline of target i (databases made from FASTA text; empty otherwise).  Owned by the database. */
 int tnt_db_defline(const tnt_db *db, size_t i, const char **defline, size_t *len);
 /* 1-byte codes (seq.h:12-35) of target i, rebuilt from the packed rows; returns the length or a TNT_E_* code. */

@@ -288,6 +288,42 @@ def test_cli_output_golden(Engine, tmp_path):
         assert (d / "out.txt").read_text() == case["expected"], case["name"]
 
 
+def test_fasta_streaming_reader(Engine, oracle, tmp_path):
+    """Batches of whole records (tnt_fasta_open / tnt_fasta_next): same hits as one resident database, global seq_index."""
+    import gzip
+    from thermonucleotideblast_amd.engine import FastaReader
+    wl = synth.make_workload(3, n_targets=500, n_assays=32, seed=71)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    assert len(want) > 5
+    path = tmp_path / "db.fna.gz"
+    with gzip.open(path, "wb") as f:
+        f.write(b"text before the first record\n" + synth.to_fasta(wl.codes, wl.offsets))
+    e = Engine(wl.options, wl.expanded)
+    for max_bytes in (1 << 16, 150_000, 1 << 30):
+        got, n_t, n_batches = [], 0, 0
+        for db in FastaReader(e, str(path), max_bytes=max_bytes):
+            assert db.defline(0) == "seq%d synthetic target" % n_t
+            got += [tc.hit_key(h) for h in e.search(db)]
+            n_t += db.n_targets
+            n_batches += 1
+            db.close()
+        assert n_t == wl.n_targets and sorted(got) == want
+        assert (n_batches > 3) == (max_bytes < 200_000)
+    e.close()
+
+
+def test_cli_streams_in_batches(Engine, tmp_path, monkeypatch):
+    """The front end with a tiny batch size writes the same file."""
+    g = gu.load("g7_cli.json.gz")
+    case = g["cases"][1]
+    (tmp_path / "assays.txt").write_text(case["assays"])
+    (tmp_path / "db.fna").write_text(case["fasta"])
+    monkeypatch.setenv("TNT_MI355X_CHUNK_BYTES", "20000")
+    r = _run_cli(["-i", str(tmp_path / "assays.txt"), "-d", str(tmp_path / "db.fna"), "-o", str(tmp_path / "out.txt")] + case["flags"])
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "out.txt").read_text() == case["expected"]
+
+
 def test_cli_vs_reference_binary_where_present(Engine, checkers, tmp_path):
     """Fresh, larger inputs through both binaries (the reference binary only travels with oracle/_ref)."""
     import subprocess

@@ -1198,6 +1198,144 @@ int tnt_db_load_fasta(tnt_ctx *ctx, const char *path, uint32_t first_seq_index, 
 	return rc;
 }
 
+// ---- streaming reader: whole records in batches, the next batch is read while the caller works on the current one
+struct tnt_fasta_reader {
+	gzFile in = nullptr;
+	std::string err;
+	std::vector<char> carry;   // bytes read beyond the last batch (they start at a record boundary, or before the first record)
+	bool eof = false;
+	uint32_t next_index = 0;
+	// prefetched batch
+	std::thread worker;
+	bool have_next = false;
+	std::vector<char> next_text;
+	size_t next_max = 0;
+	bool next_failed = false;
+};
+
+namespace {
+
+// offset of the last record start (first '>' of its line) at a position > 0, or 0 if there is none
+size_t last_record_start(const char *text, size_t n)
+{
+	size_t end = n;
+	while (end > 1) {
+		const char *gt = static_cast<const char *>(memrchr(text + 1, '>', end - 1));
+		if (!gt) return 0;
+		const size_t g = size_t(gt - text);
+		const char *nl = static_cast<const char *>(memrchr(text, '\n', g));
+		const size_t line = nl ? size_t(nl - text) + 1 : 0;
+		if (!memchr(text + line, '>', g - line)) return g;
+		end = g;
+	}
+	return 0;
+}
+
+// offset of the first record start at a position >= from (> 0), or n if there is none
+size_t next_record_start(const char *text, size_t n, size_t from)
+{
+	for (size_t at = std::max<size_t>(from, 1); at < n;) {
+		const char *gt = static_cast<const char *>(memchr(text + at, '>', n - at));
+		if (!gt) return n;
+		const size_t g = size_t(gt - text);
+		const char *nl = static_cast<const char *>(memrchr(text, '\n', g));
+		const size_t line = nl ? size_t(nl - text) + 1 : 0;
+		if (!memchr(text + line, '>', g - line)) return g;
+		at = g + 1;
+	}
+	return n;
+}
+
+// fills `out` with the carried bytes plus whole records up to about max_bytes; the rest goes back to carry
+void read_batch(tnt_fasta_reader *r, size_t max_bytes, std::vector<char> &out)
+{
+	out.swap(r->carry);
+	r->carry.clear();
+	while (true) {
+		// enough text for a cut at a record boundary near max_bytes?
+		if (out.size() > max_bytes) {
+			size_t cut = last_record_start(out.data(), max_bytes);
+			if (!cut) cut = next_record_start(out.data(), out.size(), max_bytes); // one record longer than the batch
+			if (cut < out.size()) {
+				r->carry.assign(out.begin() + cut, out.end());
+				out.resize(cut);
+				return;
+			}
+		}
+		if (r->eof) return; // the tail of the file
+		const size_t want = std::max<size_t>(size_t(1) << 22, max_bytes > out.size() ? max_bytes - out.size() + (size_t(1) << 16) : size_t(1) << 22);
+		const size_t at = out.size();
+		out.resize(at + want);
+		const int got = gzread(r->in, out.data() + at, unsigned(std::min<size_t>(want, size_t(1) << 30)));
+		if (got < 0) {
+			r->next_failed = true;
+			out.resize(at);
+			return;
+		}
+		out.resize(at + size_t(got));
+		if (got == 0) r->eof = true;
+	}
+}
+
+void start_prefetch(tnt_fasta_reader *r, size_t max_bytes)
+{
+	r->next_max = max_bytes;
+	r->have_next = true;
+	r->worker = std::thread([r, max_bytes]() { read_batch(r, max_bytes, r->next_text); });
+}
+
+} // namespace
+
+int tnt_fasta_open(const char *path, tnt_fasta_reader **out)
+{
+	if (!path || !out) return TNT_E_ARG;
+	gzFile in = gzopen(path, "r");
+	if (!in) return TNT_E_ARG;
+	(void)gzbuffer(in, 1u << 20);
+	tnt_fasta_reader *r = new tnt_fasta_reader;
+	r->in = in;
+	*out = r;
+	return TNT_OK;
+}
+
+int tnt_fasta_next(tnt_fasta_reader *r, tnt_ctx *ctx, size_t max_bytes, tnt_db **out)
+{
+	if (!r || !ctx || !out) return TNT_E_ARG;
+	*out = nullptr;
+	max_bytes = std::max<size_t>(max_bytes, 1u << 16);
+	std::vector<char> text;
+	if (r->have_next) {
+		r->worker.join();
+		r->have_next = false;
+		text.swap(r->next_text);
+	} else {
+		read_batch(r, max_bytes, text);
+	}
+	if (r->next_failed) {
+		ctx->err = "Error while reading fasta file";
+		return TNT_E_ARG;
+	}
+	if (text.empty() && r->eof) return TNT_OK;
+	if (!r->eof || !r->carry.empty()) start_prefetch(r, max_bytes); // overlaps with the caller's search of this batch
+	const int rc = tnt_db_create_from_fasta(ctx, text.data(), text.size(), r->next_index, out);
+	if (rc != TNT_OK) return rc;
+	r->next_index += uint32_t((*out)->n_targets);
+	if ((*out)->n_targets == 0 && r->have_next) { // text before the first record only: move on
+		tnt_db_destroy(*out);
+		*out = nullptr;
+		return tnt_fasta_next(r, ctx, max_bytes, out);
+	}
+	return TNT_OK;
+}
+
+void tnt_fasta_close(tnt_fasta_reader *r)
+{
+	if (!r) return;
+	if (r->have_next) r->worker.join();
+	if (r->in) gzclose(r->in);
+	delete r;
+}
+
 int tnt_db_defline(const tnt_db *db, size_t i, const char **defline, size_t *len)
 {
 	if (!db || !defline || !len || i >= db->n_targets) return TNT_E_ARG;

@@ -262,6 +262,7 @@ void write_alignment(std::ostream &out, const std::string &prefix, const char *a
 struct Record { // a hit with what the writer needs beside the tnt_hit payload
 	tnt_hit h;
 	size_t order; // position in the device output (ties keep it: std::list::sort is stable)
+	std::string amplicon, defline; // taken while the batch of targets that produced the hit is still resident
 	float min_tm() const { return std::min(h.forward_tm, h.reverse_tm); }
 	float max_tm() const { return std::max(h.forward_tm, h.reverse_tm); }
 };
@@ -438,6 +439,7 @@ int main(int argc, char **argv)
 {
 	tnt_ctx *ctx = nullptr;
 	tnt_db *db = nullptr;
+	tnt_fasta_reader *reader = nullptr;
 	try {
 		Options opt;
 		parse_args(argc, argv, opt);
@@ -458,18 +460,43 @@ int main(int argc, char **argv)
 		}
 		if (tnt_ctx_create(&opt.t, ta.data(), ta.size(), 0, &ctx) != TNT_OK) fail(tnt_last_error(nullptr));
 		if (opt.verbose) std::cout << "Reading sequence database: " << opt.dbase << std::endl;
-		if (tnt_db_load_fasta(ctx, opt.dbase.c_str(), 0, &db) != TNT_OK) fail(tnt_last_error(ctx));
-		if (opt.verbose) {
-			std::cout << "Found " << tnt_db_num_targets(db) << " database sequences" << std::endl;
-			std::cout << "Found " << assays.size() << " query assays" << std::endl;
-		}
-		const tnt_hit *hits = nullptr;
-		size_t n_hits = 0;
-		if (tnt_search(ctx, db, &hits, &n_hits) != TNT_OK) fail(tnt_last_error(ctx));
-
+		// The database streams through the device in batches of whole records (TNT_MI355X_CHUNK_BYTES of text each,
+		// default 1 GiB): the next batch is read and inflated while this one is searched.
+		if (tnt_fasta_open(opt.dbase.c_str(), &reader) != TNT_OK) fail("Unable to open fasta sequence file for reading");
+		size_t chunk = size_t(1) << 30;
+		if (const char *e = getenv("TNT_MI355X_CHUNK_BYTES")) chunk = std::max<size_t>(1, strtoull(e, nullptr, 10));
 		// results per assay id, in hybrid_sig order (tntblast_local.cpp:703-705,931)
 		std::vector<std::vector<Record>> results(assays.size());
-		for (size_t i = 0; i < n_hits; i++) results[size_t(hits[i].assay_id)].push_back(Record{hits[i], i});
+		std::vector<char> amp(1 << 20);
+		size_t n_targets = 0, n_seen = 0;
+		while (true) {
+			if (tnt_fasta_next(reader, ctx, chunk, &db) != TNT_OK) fail(tnt_last_error(ctx));
+			if (!db) break;
+			const size_t first = n_targets;
+			n_targets += tnt_db_num_targets(db);
+			const tnt_hit *hits = nullptr;
+			size_t n_hits = 0;
+			if (tnt_search(ctx, db, &hits, &n_hits) != TNT_OK) fail(tnt_last_error(ctx));
+			for (size_t i = 0; i < n_hits; i++) {
+				Record rec{hits[i], n_seen++, std::string(), std::string()};
+				const int na = tnt_hit_sequence(ctx, db, &hits[i], amp.data(), amp.size());
+				if (na < 0) fail("amplicon longer than the sequence buffer");
+				rec.amplicon.assign(amp.data(), size_t(na));
+				const char *defline = "";
+				size_t dl = 0;
+				(void)tnt_db_defline(db, size_t(hits[i].seq_index) - first, &defline, &dl);
+				rec.defline.assign(defline, dl);
+				results[size_t(hits[i].assay_id)].push_back(rec);
+			}
+			tnt_db_destroy(db);
+			db = nullptr;
+		}
+		tnt_fasta_close(reader);
+		reader = nullptr;
+		if (opt.verbose) {
+			std::cout << "Found " << n_targets << " database sequences" << std::endl;
+			std::cout << "Found " << assays.size() << " query assays" << std::endl;
+		}
 		for (auto &r : results) std::stable_sort(r.begin(), r.end(), record_less);
 
 		std::ofstream fout;
@@ -499,7 +526,6 @@ int main(int argc, char **argv)
 			if (tnt_oligo_structure(ctx, f.c_str(), r.c_str(), fwd_strand, rev_strand, &h, &d, &x) != TNT_OK) fail(tnt_last_error(ctx));
 			return dimer_cache[key] = x;
 		};
-		std::vector<char> amp(1 << 20);
 		size_t total = 0;
 		for (size_t id = 0; id < results.size(); id++) {
 			if (results[id].empty()) continue;
@@ -509,9 +535,7 @@ int main(int argc, char **argv)
 				const Expanded &e = expanded[size_t(h.degen_id)];
 				total++;
 				*out << "name = " << assays[id].name << std::endl;
-				const int na = tnt_hit_sequence(ctx, db, &h, amp.data(), amp.size());
-				if (na < 0) fail("amplicon longer than the sequence buffer");
-				const std::string amplicon(amp.data(), size_t(na));
+				const std::string &amplicon = rec.amplicon;
 				std::string fp, rp;
 				if (h.has_primers) {
 					const bool pcr = opt.t.assay_format == TNT_ASSAY_PCR;
@@ -579,10 +603,7 @@ int main(int argc, char **argv)
 					write_alignment(*out, rp + " align ", h.reverse_align);
 					write_alignment(*out, "probe align ", h.probe_align);
 				}
-				const char *defline = "";
-				size_t dl = 0;
-				(void)tnt_db_defline(db, size_t(h.seq_index), &defline, &dl);
-				*out << '>' << std::string(defline, dl);
+				*out << '>' << rec.defline;
 				if (opt.append_name) *out << ' ' << assays[id].name;
 				*out << std::endl;
 				if (opt.show_sequence) *out << amplicon << std::endl;
@@ -590,12 +611,12 @@ int main(int argc, char **argv)
 			}
 		}
 		if (opt.verbose) std::cout << "Found " << total << " (total) target sequence matches" << std::endl;
-		tnt_db_destroy(db);
 		tnt_ctx_destroy(ctx);
 		return EXIT_SUCCESS;
 	} catch (const Fail &f) {
 		std::cerr << "Caught the error: " << f.msg << std::endl;
 		if (db) tnt_db_destroy(db);
+		if (reader) tnt_fasta_close(reader);
 		if (ctx) tnt_ctx_destroy(ctx);
 		return EXIT_FAILURE;
 	}

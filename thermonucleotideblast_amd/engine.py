@@ -69,6 +69,10 @@ def load_library():
     lib.tnt_hit_sequence.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_hit), C.c_char_p, C.c_size_t]
     lib.tnt_db_create_from_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, P(C.c_void_p)]
     lib.tnt_db_load_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, P(C.c_void_p)]
+    lib.tnt_fasta_open.argtypes = [C.c_char_p, P(C.c_void_p)]
+    lib.tnt_fasta_next.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, P(C.c_void_p)]
+    lib.tnt_fasta_close.argtypes = [C.c_void_p]
+    lib.tnt_fasta_close.restype = None
     lib.tnt_db_defline.argtypes = [C.c_void_p, C.c_size_t, P(C.c_char_p), P(C.c_size_t)]
     lib.tnt_db_target_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, P(C.c_uint8), C.c_size_t]
     lib.tnt_db_target_codes.restype = C.c_int64
@@ -87,6 +91,7 @@ EXPORTED_SYMBOLS = [
     "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect",
     "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_codes", "tnt_db_ingest_timing",
+    "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
 ]
 
 
@@ -156,6 +161,42 @@ class TargetBatch:
     def close(self):
         if self._h:
             self.engine.lib.tnt_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FastaReader:
+    """Batches of whole FASTA records as device-resident targets; the next batch is read while the current one is
+    searched (tnt_fasta_open / tnt_fasta_next)."""
+
+    def __init__(self, engine, path, max_bytes=1 << 30):
+        self.engine, self.max_bytes = engine, max_bytes
+        self._h = C.c_void_p()
+        if engine.lib.tnt_fasta_open(os.fsencode(path), C.byref(self._h)) != 0:
+            raise TntError("Unable to open fasta sequence file for reading")
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        h = C.c_void_p()
+        self.engine._check(self.engine.lib.tnt_fasta_next(self._h, self.engine._h, self.max_bytes, C.byref(h)))
+        if not h:
+            raise StopIteration
+        b = TargetBatch.__new__(TargetBatch)
+        b.engine, b._h = self.engine, h
+        b.n_targets = int(self.engine.lib.tnt_db_num_targets(h))
+        b.n_bases = int(self.engine.lib.tnt_db_num_bases(h))
+        return b
+
+    def close(self):
+        if self._h:
+            self.engine.lib.tnt_fasta_close(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
