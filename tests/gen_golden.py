@@ -143,8 +143,8 @@ def main():
 
     # ---- G2
     oligos, targets, rows = bind_cases(rng)
-    # plus ~6k random seeds from a synthetic workload (mostly spurious windows)
-    wl = synth.make_workload(3, n_targets=160, n_assays=10)
+    # plus ~9k random seeds from a synthetic workload (mostly spurious windows)
+    wl = synth.make_workload(3, n_targets=420, n_assays=10)
     wo = sorted({o for e in wl.expanded for o in (e.forward, e.reverse, e.probe) if o})
     seeds = ref.seeds(wl.options, wo, wl.codes, wl.offsets)
     base_t = len(targets)
@@ -152,7 +152,7 @@ def main():
         targets.append(synth.decode(wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])]))
     base_o = len(oligos)
     oligos += wo
-    for s in seeds[::2][:6000]:
+    for s in seeds[::2][:9500]:
         rows.append((base_t + s[0], base_o + s[1], s[2], s[3], s[4], 0, 9e-7))
     codes = np.concatenate([synth.encode(t) for t in targets])
     offsets = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
