@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from thermonucleotideblast_amd import synth  # noqa: E402
@@ -21,13 +23,18 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("pcr_options", 3, 250, 20, 7, ["-e", "35", "-E", "38", "--primer-clamp", "2", "--probe-clamp5", "1", "-s", "0.1", "-t", "5e-7",
                                     "--single-primer-pcr", "F", "-l", "600", "-L", "T"]),
     ("no_align", 2, 200, 16, 8, ["-e", "45", "-a", "F", "-M", "F", "--max-mismatch", "3"]),
+    # one 150-kb record next to short ones: searched in overlapping windows here, unfragmented by the reference
+    ("long_target", 3, 200, 16, 9, ["-e", "40", "-E", "40"]),
 ]
 
 
-def write_case(d, cfg, nt, na, seed):
+def write_case(d, cfg, nt, na, seed, long_target=False):
     wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
+    offsets = wl.offsets
+    if long_target:  # the first 150 records become one
+        offsets = np.concatenate([[0], wl.offsets[150:]]).astype(np.uint64)
     with open(os.path.join(d, "db.fna"), "wb") as f:
-        f.write(synth.to_fasta(wl.codes, wl.offsets))
+        f.write(synth.to_fasta(wl.codes, offsets))
     with open(os.path.join(d, "assays.txt"), "w") as f:
         f.write("# name forward reverse [probe]   (tntblast assay file)\n")
         for a in wl.assays:
@@ -41,7 +48,7 @@ def main():
     for name, cfg, nt, na, seed, flags in CASES:
         d = os.path.join(work, name)
         os.makedirs(d, exist_ok=True)
-        write_case(d, cfg, nt, na, seed)
+        write_case(d, cfg, nt, na, seed, long_target=(name == "long_target"))
         common = ["-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna")] + flags
         env = dict(os.environ, OMP_NUM_THREADS="1")
         r1 = subprocess.run([REF] + common + ["-o", os.path.join(d, "ref.out")], env=env, capture_output=True, text=True)

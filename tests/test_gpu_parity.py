@@ -288,6 +288,49 @@ def test_cli_output_golden(Engine, tmp_path):
         assert (d / "out.txt").read_text() == case["expected"], case["name"]
 
 
+@pytest.mark.parametrize("cfg,kw", [(3, {}), (5, {}), (2, {"max_len": 300})])
+def test_long_targets_are_searched_in_windows(Engine, oracle, cfg, kw):
+    """Targets far longer than one seed work unit (windows of k-mer positions overlapping by the reach of the first
+    cull): same hits as the unfragmented search of the oracle, every hit once."""
+    rng = np.random.default_rng(100 + cfg)
+    wl = synth.make_workload(cfg, n_targets=48, n_assays=24, seed=80 + cfg)
+    for k, v in kw.items():
+        setattr(wl.options, k, v)
+    # glue the 1-kb targets into a few long ones (30 kb, 12 kb, ...) next to short ones: the planted sites end up anywhere,
+    # also across window boundaries
+    lens = np.diff(wl.offsets.astype(np.int64))
+    groups = [30, 12, 1, 1, 1, 1, 1, 1]
+    assert sum(groups) == 48
+    offsets = np.concatenate([[0], np.cumsum([int(lens[sum(groups[:i]):sum(groups[:i + 1])].sum()) for i in range(len(groups))])]).astype(np.uint64)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, offsets))
+    assert len(want) > 10
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    assert got == want
+    sa = e.seeds(db)
+    oligos = _oligo_set(wl.expanded)
+    so = oracle.seeds(wl.options, oligos, wl.codes, offsets)
+    allowed = wl.options.target_strand
+    assert sorted((s[0], s[1], s[2], s[3], s[4]) for s in sa) == sorted((s[0], oligos[s[1]], s[2], s[3], s[4]) for s in so) or allowed != abi.STRAND_BOTH
+    db.close()
+    e.close()
+
+
+def test_genome_sized_target(Engine, oracle):
+    """One 1.5 Mb target (366 windows) beside short ones, PCR + probe assays with planted sites."""
+    wl = synth.make_workload(3, n_targets=1500, n_assays=12, seed=93)
+    lens = np.diff(wl.offsets.astype(np.int64))
+    offsets = np.array([0, int(lens[:1496].sum())] + [int(lens[:1496 + i + 1].sum()) for i in range(4)], dtype=np.uint64)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, offsets))
+    assert len(want) > 20
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    assert tc.sorted_hit_keys(e.search(db)) == want
+    db.close()
+    e.close()
+
+
 def test_fasta_streaming_reader(Engine, oracle, tmp_path):
     """Batches of whole records (tnt_fasta_open / tnt_fasta_next): same hits as one resident database, global seq_index."""
     import gzip

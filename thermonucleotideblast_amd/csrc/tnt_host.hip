@@ -306,6 +306,11 @@ struct tnt_db {
 	std::vector<uint32_t> h_len, h_exc_off, h_exc_pos;
 	std::vector<uint8_t> h_exc_code;
 	bool host_copy = false;         // h_packed / h_exc_pos / h_exc_code are filled
+	// seed work units: whole targets, or overlapping windows of long ones (SeedArgs, tnt_seed.hip.h)
+	std::vector<uint32_t> h_unit_target, h_unit_begin, h_unit_end;
+	DevBuf<uint32_t> unit_target, unit_begin, unit_end;
+	uint32_t max_unit_len = 0;
+	bool split = false;             // some target is cut into windows: results may hold identical copies
 	uint64_t n_exceptions = 0;
 	std::string deflines;           // FASTA ingest: all deflines back to back
 	std::vector<uint64_t> defline_off;
@@ -898,6 +903,45 @@ int tnt_ctx_delta_g(const tnt_ctx *ctx, int32_t *out2401)
 	return e == hipSuccess ? TNT_OK : TNT_E_DEVICE;
 }
 
+namespace {
+
+// stride of the windows a long target is cut into; the window itself is stride + overlap long
+constexpr uint32_t UNIT_STRIDE = 4096;
+
+hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
+{
+	const int k = ctx->opt.hash_word_size;
+	// reach of cull_oligo_match (amplicon_search.cpp:688: max_len + 50), so that a kept pair shares a window
+	const uint32_t overlap = uint32_t(std::max(0, ctx->opt.max_len)) + 50u + 64u;
+	const uint32_t stride = std::max(UNIT_STRIDE, overlap);
+	db->h_unit_target.clear(), db->h_unit_begin.clear(), db->h_unit_end.clear();
+	db->max_unit_len = 0;
+	db->split = false;
+	for (size_t t = 0; t < db->n_targets; t++) {
+		const uint32_t len = db->h_len[t];
+		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
+		if (npos <= stride + overlap) {
+			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
+			db->max_unit_len = std::max(db->max_unit_len, len);
+			continue;
+		}
+		db->split = true;
+		for (uint64_t b = 0; b < npos; b += stride) {
+			const uint32_t e = uint32_t(std::min<uint64_t>(npos, b + stride + overlap));
+			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(uint32_t(b)), db->h_unit_end.push_back(e);
+			db->max_unit_len = std::max(db->max_unit_len, e - uint32_t(b) + uint32_t(k));
+			if (e == npos) break;
+		}
+	}
+	hipError_t e;
+	if ((e = db->unit_target.upload(db->h_unit_target)) != hipSuccess || (e = db->unit_begin.upload(db->h_unit_begin)) != hipSuccess ||
+	    (e = db->unit_end.upload(db->h_unit_end)) != hipSuccess)
+		return e;
+	return hipSuccess;
+}
+
+} // namespace
+
 int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, size_t n_targets, uint32_t first_seq_index,
                   tnt_db **out)
 {
@@ -960,7 +1004,8 @@ int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, s
 	hipError_t e;
 	if ((e = db->packed.upload(db->h_packed)) != hipSuccess || (e = db->word_off.upload(db->h_word_off)) != hipSuccess ||
 	    (e = db->len.upload(db->h_len)) != hipSuccess || (e = db->exc_off.upload(db->h_exc_off)) != hipSuccess ||
-	    (e = db->exc_pos.upload(db->h_exc_pos)) != hipSuccess || (e = db->exc_code.upload(db->h_exc_code)) != hipSuccess) {
+	    (e = db->exc_pos.upload(db->h_exc_pos)) != hipSuccess || (e = db->exc_code.upload(db->h_exc_code)) != hipSuccess ||
+	    (e = build_units(ctx, db)) != hipSuccess) {
 		ctx->err = std::string("target upload: ") + hipGetErrorString(e);
 		delete db;
 		return TNT_E_DEVICE;
@@ -1162,6 +1207,7 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	(void)hipEventElapsedTime(&db->ingest.count_ms, ev[0], ev[1]);
 	(void)hipEventElapsedTime(&db->ingest.pack_ms, ev[2], ev[3]);
 	for (auto &x : ev) (void)hipEventDestroy(x);
+	HIP_TRY(build_units(ctx, db), ctx->err);
 	db->ingest.bases = db->n_bases;
 	db->ingest.exceptions = db->n_exceptions;
 	*out = db;
@@ -1378,9 +1424,10 @@ int tnt_db_ingest_timing(const tnt_db *db, tnt_ingest_timing *out)
 }
 
 // One internal batch: seed -> bind -> filter -> pair, all on the context stream.
-static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seeds_only)
+static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seeds_only)
 {
-	const DbView v = make_view(db, t0, t1);
+	// one internal batch = a range of seed work units; target indices stay those of the whole database
+	const DbView v = make_view(db, 0, db->n_targets);
 	uint32_t *cnt = c->counters.p;
 	// hits and the error word accumulate over batches; the rest restarts
 	HIP_TRY(hipMemsetAsync(cnt + C_POOL, 0, sizeof(uint32_t) * 3, c->stream), c->err);
@@ -1396,6 +1443,11 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	SeedArgs s;
 	memset(&s, 0, sizeof(s));
 	s.db = v;
+	s.unit_target = db->unit_target.p;
+	s.unit_begin = db->unit_begin.p;
+	s.unit_end = db->unit_end.p;
+	s.unit0 = uint32_t(u0);
+	s.unit1 = uint32_t(u1);
 	s.word_size = c->opt.hash_word_size;
 	s.wlist = c->wlist.p;
 	s.wl_off = c->wl_off.p;
@@ -1418,7 +1470,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t t0, size_t t1, bool seed
 	}
 	s.err = cnt + C_ERR;
 	s.debug = cnt + C_DEBUG + 8;
-	const int seed_blocks = int(std::min<size_t>((t1 - t0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
+	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
 		s.assay_begin = c->chunk_begin[ch];
@@ -1480,7 +1532,7 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	const double words = double(n_words);
 	const double per_base = double(c->n_entries) / words; // expected raw seeds per target base
-	const double maxlen = std::max<double>(1.0, db->max_len);
+	const double maxlen = std::max<double>(1.0, db->max_unit_len); // longest seed work unit (target or window)
 	const size_t n_assays = c->h_assays.size();
 	// a target of the longest length should yield <= SEED_CAP/2 seeds on average
 	const double ent_budget = std::max(1.0, (SEED_CAP / 2) * words / maxlen);
@@ -1526,12 +1578,20 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	}
 	c->chunk_begin = chunk_begin;
 	// batch of targets: expected kept seeds (<= raw) must stay below ITEM_CAP / 2
-	const double avg_len = db->n_targets ? double(db->n_bases) / double(db->n_targets) : 1.0;
+	// (units = targets, or overlapping windows of long targets: count their positions, not the bases)
+	const size_t n_units = std::max<size_t>(1, db->h_unit_target.size());
+	double unit_positions = 0.0;
+	if (db->split) {
+		for (size_t u = 0; u < db->h_unit_target.size(); u++) unit_positions += double(db->h_unit_end[u] - db->h_unit_begin[u]);
+	} else {
+		unit_positions = double(db->n_bases);
+	}
+	const double avg_len = unit_positions / double(n_units);
 	const double per_target = std::max(1.0, per_base * avg_len);
 	double tb = (double(ITEM_CAP) / 2.0) / per_target;
 	const double gb = (double(GROUP_CAP) / 2.0) / std::max<double>(1.0, double(n_assays));
 	tb = std::min(tb, gb);
-	targets_per_batch = size_t(std::max(1.0, std::min(tb, double(std::max<size_t>(1, db->n_targets)))));
+	targets_per_batch = size_t(std::max(1.0, std::min(tb, double(n_units)))); // in work units
 	return TNT_OK;
 }
 
@@ -1549,8 +1609,9 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	if (rc) return rc;
 	tpb = std::max<size_t>(1, size_t(double(tpb) * ctx->batch_scale));
 	ctx->n_batches = 0;
-	for (size_t t0 = 0; t0 < db->n_targets; t0 += tpb) {
-		rc = enqueue_batch(ctx, db, t0, std::min(db->n_targets, t0 + tpb), false);
+	const size_t n_units = db->h_unit_target.size();
+	for (size_t u0 = 0; u0 < n_units; u0 += tpb) {
+		rc = enqueue_batch(ctx, db, u0, std::min(n_units, u0 + tpb), false);
 		if (rc) return rc;
 		ctx->n_batches++;
 	}
@@ -1608,6 +1669,27 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		ctx->h_hits_cap = cap;
 	}
 	if (n) HIP_TRY(hipMemcpy(ctx->h_hits, ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
+	size_t n_unique = n;
+	if (n > 1 && ctx->pending_db && ctx->pending_db->split) {
+		// overlapping windows of a long target report what lies in their overlap twice, identically: keep one copy
+		std::vector<uint32_t> order(n);
+		for (size_t i = 0; i < n; i++) order[i] = uint32_t(i);
+		const tnt_hit *H = ctx->h_hits;
+		std::sort(order.begin(), order.end(), [H](uint32_t a, uint32_t b) {
+			const int c = memcmp(&H[a], &H[b], offsetof(tnt_hit, forward_align));
+			return c != 0 ? c < 0 : a < b;
+		});
+		std::vector<uint32_t> keep;
+		for (size_t i = 0; i < n; i++)
+			if (i == 0 || memcmp(&H[order[i]], &H[order[i - 1]], offsetof(tnt_hit, forward_align)) != 0 ||
+			    strcmp(H[order[i]].forward_align, H[order[i - 1]].forward_align) != 0 ||
+			    strcmp(H[order[i]].reverse_align, H[order[i - 1]].reverse_align) != 0 || strcmp(H[order[i]].probe_align, H[order[i - 1]].probe_align) != 0)
+				keep.push_back(order[i]);
+		std::sort(keep.begin(), keep.end());
+		for (size_t i = 0; i < keep.size(); i++)
+			if (keep[i] != i) ctx->h_hits[i] = ctx->h_hits[keep[i]];
+		n_unique = keep.size();
+	}
 	// stage timings
 	tnt_timing &T = ctx->timing;
 	memset(&T, 0, sizeof(T));
@@ -1624,9 +1706,9 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	T.n_binds = (uint64_t(cnt[C_TOT_BINDS_HI]) << 32) | cnt[C_TOT_BINDS_LO]; // DP evaluations (phase A + phase B)
 	T.n_seeds = (uint64_t(cnt[C_TOT_GROUPS_HI]) << 32) | cnt[C_TOT_GROUPS_LO]; // (target, assay) groups that reached the bind stage
 	T.n_bound = cnt[C_TOT_BOUND];
-	T.n_hits = n;
+	T.n_hits = n_unique;
 	if (hits) *hits = ctx->h_hits;
-	if (n_hits) *n_hits = n;
+	if (n_hits) *n_hits = n_unique;
 	return TNT_OK;
 }
 
@@ -1657,7 +1739,7 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 	const size_t cap = size_t(double(db->n_bases) * double(ctx->n_entries) / words * 2.0) + (1u << 20);
 	HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err);
 	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
-	rc = enqueue_batch(ctx, db, 0, db->n_targets, true);
+	rc = enqueue_batch(ctx, db, 0, db->h_unit_target.size(), true);
 	if (rc) return rc;
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
@@ -1691,7 +1773,8 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 		if (a.oligo != b.oligo) return a.oligo < b.oligo;
 		if (a.strand != b.strand) return a.strand > b.strand; // minus first
 		const int da = a.query_loc - a.target_loc, dbb = b.query_loc - b.target_loc;
-		return da < dbb;
+		if (da != dbb) return da < dbb;
+		return a.query_loc < b.query_loc; // (windows of a long target report the seeds of their overlap twice)
 	};
 	std::sort(out.begin(), out.end(), key);
 	out.erase(std::unique(out.begin(), out.end(),

@@ -39,6 +39,12 @@ struct SeedOut { // debug / unit-level output: every kept seed before the cull
 
 struct SeedArgs {
 	DbView db;
+	// Work units: a target, or one window of k-mer start positions [begin, end) of a long target.  Windows of one
+	// target overlap by max_len + 50 (rounded up), the reach of the first cull, so every seed pair the reference's
+	// cull keeps lies inside one window; seeds keep their true target_loc, bind windows are never clipped, and what
+	// two overlapping windows both find is found twice, identically (the host drops the copies).
+	const uint32_t *unit_target, *unit_begin, *unit_end;
+	uint32_t unit0, unit1;
 	int word_size;
 	const uint16_t *wt_off;    // this chunk's bucket offsets [4^k + 1], relative to wt_ent (< 65536 entries per chunk)
 	const uint32_t *wt_ent;    // this chunk's entries (see tnt_dev.h)
@@ -173,7 +179,8 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 	long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #define ST(K) st_t[K] = __builtin_readcyclecounter()
 #endif
-	for (uint32_t t = blockIdx.x * SEED_WAVES + wv; t < a.db.n_targets; t += gridDim.x * SEED_WAVES) {
+	for (uint32_t unit = a.unit0 + blockIdx.x * SEED_WAVES + wv; unit < a.unit1; unit += gridDim.x * SEED_WAVES) {
+		const uint32_t t = a.unit_target[unit];
 #ifdef TNT_EXP_STATS
 		for (int q = 1; q < 7; q++) st_t[q] = 0;
 #endif
@@ -188,7 +195,9 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 		// ---------------------------------------------------------------- scan + diagonal de-duplication
 		if (len >= uint32_t(a.word_size)) { // tntblast_local.cpp:513
 			const uint32_t *pk = a.db.packed + a.db.word_off[t];
-			const uint32_t npos = len - a.word_size + 1;
+			const uint32_t npos_all = len - a.word_size + 1;
+			const uint32_t npos = a.unit_end[unit] < npos_all ? a.unit_end[unit] : npos_all;
+			const uint32_t pos0 = a.unit_begin[unit];
 			// Stage 1: every lane looks its positions up and appends the (position, entry) candidates to a wave-local
 			// list (kept in `srt`, free until the counting sort).  Only ~0.2 candidates fall on a position, so testing
 			// them in place would run the test with a handful of active lanes; stage 2 works through the list with
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 			// The list holds SEED_CAP candidates; when it fills up (buckets shared by many expanded assays come in
 			// bursts) it is drained and the scan resumes where every lane stopped.
 			uint2 *cand = reinterpret_cast<uint2 *>(srt);
-			uint32_t p = lane, e_done = 0;
+			uint32_t p = pos0 + lane, e_done = 0;
 			while (true) {
 			if (lane == 0) s_ncand[wv] = 0;
 			wave_sync();
