@@ -43,7 +43,7 @@ def test_g1_delta_g(Engine):
 
 
 def test_g2_binds_golden(Engine):
-    """4.5k reference NucCruc evaluations: mismatches, bulges, loops, IUPAC, inosine, clipped windows, ties."""
+    """10k reference NucCruc evaluations per option set: mismatches, bulges, loops, IUPAC, inosine, clipped windows, ties."""
     fx = gu.load("g2_binds.json.gz")
     codes, offsets = gu.pack_targets(fx["targets"])
     ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
