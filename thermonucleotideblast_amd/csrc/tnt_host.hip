@@ -1518,7 +1518,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	p.hit_cap = uint32_t(c->hit_cap);
 	p.hit_count = cnt + C_HITS;
 	p.err = cnt + C_ERR;
-	hipLaunchKernelGGL(pair_kernel, dim3(256), dim3(PAIR_THREADS), 0, c->stream, p);
+	hipLaunchKernelGGL(pair_kernel, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
 	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt);
 	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
 	HIP_TRY(hipGetLastError(), c->err);
