@@ -375,7 +375,7 @@ __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const Ali
 // PLAIN: no window of the launch holds a degenerate (IUPAC) target base (the bucket kernel routes windows that
 // do to a general instance), so rt(t, q) = t and the table address splits into column and row constants.
 template <int LMAX, bool FULL, bool EXACT = false, bool PLAIN = false>
-__global__ __launch_bounds__(bind_threads_for(LMAX), (LMAX <= 40 ? 2 : 1)) void bind_kernel(BindArgs a)
+__global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 256 ? 1 : (LMAX <= 40 ? 2 : 1))) void bind_kernel(BindArgs a)
 {
 	static_assert(!(FULL && (EXACT || PLAIN)), "the unit-level instance takes any length and any target base");
 	constexpr int BIND_THREADS = bind_threads_for(LMAX);

@@ -89,12 +89,14 @@ struct Slot {
 constexpr int MAX_BUCKETS = 48;
 constexpr int BUCKET_EXACT = 0x100, BUCKET_PLAIN = 0x200; // flags on the instance id kept by the host (lmax | flags)
 
-// Workgroup size of the bind kernel instances.  One lane owns one DP; a lane needs 6 * LMAX + 32 bytes of LDS
-// (window, query, alignment columns) next to the 20 KB of tables every workgroup holds once: two workgroups
-// per CU up to 32 rows.  The fill loop is bound by VALU issue, which two wavefronts per SIMD saturate; a third
-// one (768-thread workgroups, <= 168 VGPRs) was measured and gained nothing while forcing spills above 21 rows.
-constexpr int bind_threads_for(int) { return 256; }
-constexpr int bind_blocks_per_cu(int) { return 4; } // persistent grid: 2x the resident workgroups
+// Workgroup size of the bind kernel instances.  One lane owns one DP; a lane needs 8 * LMAX + 48 bytes of LDS
+// (window, query, alignment columns, best alignment, trace prefetch) next to the 24 KB of tables every workgroup
+// holds once.  Up to 22 rows the instance fits 168 VGPRs and one 768-thread workgroup fits a CU's LDS: three
+// wavefronts per SIMD, the third one fills the issue slots the other two leave while they wait in their serial
+// tails (+4 % on those buckets).  Longer oligos need the registers of a two-wave budget (two 256-thread workgroups
+// per CU); forcing them into 168 VGPRs spills and was measured slower.
+constexpr int bind_threads_for(int lmax) { return lmax <= 22 ? 768 : 256; }
+constexpr int bind_blocks_per_cu(int lmax) { return lmax <= 22 ? 2 : 4; } // persistent grid: 2x the resident workgroups
 constexpr int BUCKET_STRIDE = 32; // words between two bucket counters (one 128-byte line each)
 
 // bind work item (one seed that survived the first cull)
