@@ -388,7 +388,8 @@ struct tnt_ctx {
 	tnt_db *pending_db = nullptr;
 	size_t hit_cap = size_t(1) << 20; // initial hit capacity; grown on demand (tnt_search_collect)
 	int retries = 0;
-	double batch_scale = 1.0; // targets per internal batch relative to the planned number (halved after an overflow)
+	double batch_scale = 1.0;
+	double chunk_scale = 1.0; // assay-chunk size of the seed kernel relative to the planned one (halved after a seed-list overflow) // targets per internal batch relative to the planned number (halved after an overflow)
 
 	~tnt_ctx()
 	{
@@ -1534,16 +1535,27 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	const double per_base = double(c->n_entries) / words; // expected raw seeds per target base
 	const double maxlen = std::max<double>(1.0, db->max_unit_len); // longest seed work unit (target or window)
 	const size_t n_assays = c->h_assays.size();
-	// a target of the longest length should yield <= SEED_CAP/2 seeds on average
-	const double ent_budget = std::max(1.0, (SEED_CAP / 2) * words / maxlen);
+	// Assay chunks: the seeds one work unit of the longest length yields for the chunk must fit the LDS seed list
+	// (SEED_CAP).  For random sequence their number is a sum over the positions of m_w = entries of the position's
+	// word: mean = len * sum(m_w) / 4^k, variance = len * sum(m_w^2) / 4^k (expanded degenerate assays share words, so
+	// their seeds come in bursts).  A chunk grows while mean + 6 sigma stays below the list size; a target that
+	// overflows it anyway makes tnt_search_collect halve chunk_scale and repeat the search.
+	const double cap = double(SEED_CAP) * c->chunk_scale;
 	std::vector<uint32_t> chunk_begin;
+	std::vector<uint32_t> mult(n_words);
 	size_t a0 = 0;
 	while (a0 < n_assays) {
 		size_t a1 = a0, ent = 0;
+		double sum_sq = 0.0;
+		std::fill(mult.begin(), mult.end(), 0u);
 		while (a1 < n_assays && a1 - a0 < size_t(SEED_MAX_ASSAYS)) {
-			const size_t e = c->assay_entries[a1].size();
-			if (a1 > a0 && (double(ent + e) > ent_budget || ent + e > 65535)) break;
-			ent += e;
+			const auto &ae = c->assay_entries[a1];
+			double add_sq = 0.0;
+			for (const auto &we : ae) add_sq += 2.0 * double(mult[we.first]++) + 1.0;
+			const double mean = maxlen * double(ent + ae.size()) / words, sigma = sqrt(maxlen * (sum_sq + add_sq) / words);
+			if (a1 > a0 && (mean + 6.0 * sigma > cap || ent + ae.size() > 65535)) break;
+			ent += ae.size();
+			sum_sq += add_sq;
 			a1++;
 		}
 		chunk_begin.push_back(uint32_t(a0));
@@ -1640,8 +1652,8 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 #endif
 	// Capacity overflows are repaired and the search repeated: the hit buffer grows to what the pair kernel counted,
 	// the per-batch lists (work items, groups, bound records) get smaller batches.
-	if (cnt[C_ERR] & (ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW)) {
-		const uint32_t fatal = cnt[C_ERR] & ~(ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW);
+	if (cnt[C_ERR] & (ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW | ERR_SEED_OVERFLOW)) {
+		const uint32_t fatal = cnt[C_ERR] & ~(ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW | ERR_SEED_OVERFLOW);
 		if (!fatal && ctx->retries < 8 && ctx->pending_db) {
 			ctx->retries++;
 			if (cnt[C_ERR] & ERR_HIT_OVERFLOW) {
@@ -1649,6 +1661,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 				HIP_TRY(ctx->hits.alloc(ctx->hit_cap), ctx->err);
 			}
 			if (cnt[C_ERR] & (ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW)) ctx->batch_scale *= 0.5;
+			if (cnt[C_ERR] & ERR_SEED_OVERFLOW) ctx->chunk_scale *= 0.5; // one assay per chunk is the floor: then the error stands
 			const int rc = tnt_search_enqueue(ctx, ctx->pending_db);
 			if (rc) return rc;
 			return tnt_search_collect(ctx, hits, n_hits);
