@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: HIP path vs the oracle over random option sets, assay mixes and
+target shapes (lengths, IUPAC content, repeats).  Every case compares the complete hit multisets (coordinates, counts,
+float32 bit patterns, alignment text).   python scripts/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tntcheck as tc  # noqa: E402
+from thermonucleotideblast_amd import abi, synth  # noqa: E402
+from thermonucleotideblast_amd.engine import Engine  # noqa: E402
+
+
+def random_case(rng, case):
+    cfg = int(rng.choice([1, 2, 3, 3, 4, 5, 5]))
+    nt = int(rng.integers(40, 260))
+    na = None if cfg == 1 else int(rng.integers(4, 40))
+    wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=int(rng.integers(1, 1 << 30)))
+    o = wl.options
+    pick = lambda *v: v[int(rng.integers(0, len(v)))]  # noqa: E731
+    o.min_primer_tm = float(pick(0.0, 30.0, 40.0, 45.0, 52.0))
+    o.min_probe_tm = float(pick(0.0, 35.0, 40.0, 48.0))
+    o.max_primer_tm = float(pick(9999.0, 9999.0, 65.0))
+    o.max_primer_dg = float(pick(0.0, 0.0, -6.0, -10.0))
+    o.max_probe_dg = float(pick(0.0, -5.0, -9.0))
+    o.salt = float(pick(0.05, 0.05, 0.2, 0.01, 0.9))
+    o.primer_strand = float(pick(9e-7, 9e-7, 2e-7, 5e-6))
+    o.probe_strand = float(pick(2.5e-7, 9e-7, 1e-8))
+    o.asymmetric_strand_ratio = float(pick(1.0, 1.0, 0.2, 5.0))
+    o.target_t = float(pick(310.15, 310.15, 300.0, 330.0))
+    o.primer_clamp = int(pick(0, 0, 1, 3, 6))
+    o.min_max_primer_clamp = int(pick(-1, -1, 2, 8))
+    o.probe_clamp_5 = int(pick(0, 0, 2))
+    o.probe_clamp_3 = int(pick(0, 0, 3))
+    o.max_gap = int(pick(999, 999, 0, 1))
+    o.max_mismatch = int(pick(999, 999, 1, 4))
+    o.max_poly_degen = int(pick(3, 3, 0, 8))
+    o.max_len = int(pick(2000, 2000, 150, 400, 0 if cfg == 5 else 800))
+    o.hash_word_size = int(pick(7, 7, 7, 5, 6, 8))
+    o.single_primer_pcr = int(pick(1, 1, 0))
+    o.allow_dangle_5 = int(pick(0, 0, 1))
+    o.allow_dangle_3 = int(pick(0, 0, 1))
+    o.target_strand = int(pick(abi.STRAND_BOTH, abi.STRAND_BOTH, abi.STRAND_PLUS, abi.STRAND_MINUS))
+    if cfg == 5:
+        o.assay_format = int(pick(abi.ASSAY_PADLOCK, abi.ASSAY_PADLOCK, abi.ASSAY_MIPS))
+    codes, offsets = wl.codes, wl.offsets
+    shape = int(rng.integers(0, 5))
+    if shape == 1:   # ragged lengths incl. empty and shorter-than-word targets
+        lens = rng.integers(0, 1000, nt)
+        lens[rng.integers(0, nt, 3)] = [0, 3, 6]
+        keep = np.zeros(len(codes), dtype=bool)
+        for t in range(nt):
+            keep[int(offsets[t]):int(offsets[t]) + int(lens[t])] = True
+        codes = codes[keep]
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    elif shape == 2:  # a few long targets (seed windows)
+        # (with thresholds so low that every seed binds, the reference's order-dependent cull (Q5) acts on
+        # the list of the whole target, which windows cannot reproduce; the long-target cases keep sane thresholds)
+        o.min_primer_tm = max(o.min_primer_tm, 30.0)
+        o.min_probe_tm = max(o.min_probe_tm, 30.0)
+        k = int(rng.integers(20, nt))
+        offsets = np.concatenate([[0], offsets[k:]]).astype(np.uint64)
+    elif shape == 3:  # IUPAC codes, N-runs, unknown and gap codes sprinkled in
+        codes = codes.copy()
+        n = int(rng.integers(10, 400))
+        codes[rng.integers(0, len(codes), n)] = rng.integers(4, 18, n).astype(np.uint8)
+        p = int(rng.integers(0, len(codes) - 40))
+        codes[p:p + 30] = 15
+    elif shape == 4:  # low complexity: tandem repeats pasted over some targets
+        codes = codes.copy()
+        for _ in range(6):
+            unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
+            p = int(rng.integers(0, len(codes) - 200))
+            codes[p:p + 120] = np.resize(unit, 120)
+    return cfg, wl, codes, offsets
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else None  # replay one case of the sequence
+    rng = np.random.default_rng(seed)
+    ora = tc.OracleImpl()
+    bad = 0
+    t0 = time.time()
+    total_hits = 0
+    for case in range(n_cases):
+        cfg, wl, codes, offsets = random_case(rng, case)
+        if only is not None and case != only:
+            continue
+        try:
+            want = tc.sorted_hit_keys(ora.search(wl.options, wl.expanded, codes, offsets))
+        except AssertionError as e:  # the oracle refuses (e.g. word size vs oligo length): both must refuse
+            want = ("error", str(e)[:60])
+        try:
+            eng = Engine(wl.options, wl.expanded)
+            db = eng.pack(codes, offsets)
+            got = tc.sorted_hit_keys(eng.search(db))
+            db.close()
+            eng.close()
+        except Exception as e:
+            got = ("error", str(e)[:60])
+        ok = got == want or (isinstance(got, tuple) and isinstance(want, tuple))
+        if isinstance(want, list):
+            total_hits += len(want)
+        if not ok:
+            bad += 1
+            print("CASE %d (seed %d) cfg %d DIFFERS: hip %s vs oracle %s; options %s" % (
+                case, seed, cfg, len(got) if isinstance(got, list) else got, len(want) if isinstance(want, list) else want,
+                {n: getattr(wl.options, n) for n, _ in abi.tnt_options._fields_}))
+            if isinstance(got, list) and isinstance(want, list):
+                sg, sw = set(got), set(want)
+                print("   only hip:", list(sg - sw)[:1], "\n   only oracle:", list(sw - sg)[:1])
+                if only is not None:
+                    import pickle
+                    pickle.dump({"options": {n: getattr(wl.options, n) for n, _ in abi.tnt_options._fields_}, "expanded": [(e.id, e.degen_id, e.forward, e.reverse, e.probe, e.forward_degen, e.reverse_degen, e.probe_degen) for e in wl.expanded],
+                                 "codes": codes, "offsets": offsets, "only_hip": list(sg - sw), "only_oracle": list(sw - sg)},
+                                open(os.path.join(ROOT, "gpurun_out", "fuzz_case.pkl"), "wb"))
+    print("%d cases, %d hits compared, %d differ, %.0f s" % (n_cases, total_hits, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -406,7 +406,7 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_POOL = 0, C_ACTIVE, C_QB, C_PAD3, C_HITS, C_ERR, C_PAD6, C_PAD7, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
+enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_PAD6, C_PAD7, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
@@ -619,7 +619,7 @@ const char *err_text(uint32_t e)
 	if (e & ERR_POOL_OVERFLOW) return "bound-oligo pool overflow";
 	if (e & ERR_HIT_OVERFLOW) return "hit buffer overflow";
 	if (e & ERR_GROUP_OVERFLOW) return "group buffer overflow";
-	if (e & ERR_LIST_OVERFLOW) return "more than 64 seeds for one (target, assay)";
+	if (e & ERR_LIST_OVERFLOW) return "more than 512 seeds of one assay inside one seed window";
 	if (e & ERR_STACK_OVERFLOW) return "traceback branch stack overflow";
 	if (e & ERR_TIE_OVERFLOW) return "more than 256 maximal DP cells in one window";
 	return "unknown device error";
@@ -914,14 +914,23 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 	const int k = ctx->opt.hash_word_size;
 	// reach of cull_oligo_match (amplicon_search.cpp:688: max_len + 50), so that a kept pair shares a window
 	const uint32_t overlap = uint32_t(std::max(0, ctx->opt.max_len)) + 50u + 64u;
-	const uint32_t stride = std::max(UNIT_STRIDE, overlap);
+	// window length for which the busiest assay expects about 128 seeds (short hash words seed densely)
+	size_t max_ent = 1;
+	for (const auto &ae : ctx->assay_entries) max_ent = std::max(max_ent, ae.size());
+	const double dense = 128.0 * double(size_t(1) << (2 * k)) / double(max_ent);
+	const uint32_t stride = std::max(overlap, std::min(UNIT_STRIDE, uint32_t(std::max(1.0, dense - double(overlap)))));
 	db->h_unit_target.clear(), db->h_unit_begin.clear(), db->h_unit_end.clear();
 	db->max_unit_len = 0;
 	db->split = false;
 	for (size_t t = 0; t < db->n_targets; t++) {
 		const uint32_t len = db->h_len[t];
 		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
-		if (npos <= stride + overlap) {
+		// A target is searched whole whenever it can be: the reference's culls act on the seed list of the whole
+		// target, and their order-dependent corner cases can only be reproduced on that list.  It is cut
+		// into windows when its seeds would not fit the LDS lists (about 256 expected for the busiest assay) or when
+		// it is genome-sized (> 32 k positions).
+		const double expect = double(npos) * double(max_ent) / double(size_t(1) << (2 * k));
+		if (npos <= stride + overlap || (expect <= 256.0 && npos <= 32768u)) {
 			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
 			db->max_unit_len = std::max(db->max_unit_len, len);
 			continue;
@@ -1464,6 +1473,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		s.group_count = cnt + C_GROUPS;
 		s.qa = c->qa.p;
 		s.qa_count = cnt + C_QA;
+		s.big_count = cnt + C_BIG;
 	} else {
 		s.seeds_out = c->seeds_out.p;
 		s.seeds_cap = uint32_t(c->seeds_out.n);
@@ -1519,7 +1529,9 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	p.hit_cap = uint32_t(c->hit_cap);
 	p.hit_count = cnt + C_HITS;
 	p.err = cnt + C_ERR;
-	hipLaunchKernelGGL(pair_kernel, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
+	p.n_big = cnt + C_BIG;
+	hipLaunchKernelGGL(pair_kernel<PAIR_MAX>, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
+	hipLaunchKernelGGL(pair_kernel<PAIR_BIG>, dim3(64), dim3(PAIR_THREADS), 0, c->stream, p); // crowded groups, if any
 	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt);
 	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
 	HIP_TRY(hipGetLastError(), c->err);

@@ -22,7 +22,8 @@
 namespace tnt {
 
 constexpr int PAIR_THREADS = 64;
-constexpr int PAIR_MAX = 64; // entries of one (target, assay) group (== LIST_MAX of the seed kernel)
+constexpr int PAIR_MAX = 64;  // entries of one (target, assay) group handled by the common instance of the pair kernel
+constexpr int PAIR_BIG = 512; // ... and by the instance for crowded groups (short hash words, repeats); == LIST_MAX of the seed kernel
 
 struct PairArgs {
 	const Group *groups;
@@ -43,6 +44,7 @@ struct PairArgs {
 	uint32_t hit_cap;
 	uint32_t *hit_count;
 	uint32_t *err;
+	const uint32_t *n_big;      // groups of more than PAIR_MAX items seen by the seed kernel
 };
 
 enum : uint8_t { MF = 1, MR = 2, MP = 4, MPLUS = 8, MMINUS = 16, MVALID = 32 }; // oligo_info, tntblast.h:147-154
@@ -107,8 +109,8 @@ __device__ __forceinline__ bool info_less(const Entry &x, const Entry &y, const 
 	return pool[x.rec].tm > pool[y.rec].tm;
 }
 
-struct List {
-	Entry e[PAIR_MAX];
+template <int N> struct ListT {
+	Entry e[N];
 	int n;
 };
 
@@ -126,12 +128,57 @@ template <class Less> __device__ void stable_sort(Entry *e, int n, Less less)
 	}
 }
 
+// std::list::sort as libstdc++ performs it.  sort_by_oligo_loc (amplicon_search.cpp:12-26) compares bound entries by
+// loc_5 / loc_3 and anything else by target_loc: not a strict weak order, so WHICH order comes out depends
+// on the algorithm, and the cull that follows breaks out of its inner loop on that order (:707).  libstdc++'s
+// list::sort is a bottom-up merge sort over a binary counter of runs: the list is cut, in its current order, into
+// blocks following the binary digits of n from the most significant one; every block is merged up from single
+// elements in aligned halves; the blocks are then merged from the last one leftwards.  A merge takes from the right
+// run iff comp(right, left), else from the left one.
+template <class Less> __device__ void merge_runs(Entry *e, Entry *tmp, int lo, int mid, int hi, Less less)
+{
+	int a = lo, b = mid, o = lo;
+	while (a < mid && b < hi) {
+		if (less(e[b], e[a])) tmp[o++] = e[b++];
+		else tmp[o++] = e[a++];
+	}
+	while (a < mid) tmp[o++] = e[a++];
+	while (b < hi) tmp[o++] = e[b++];
+	for (int i = lo; i < hi; i++) e[i] = tmp[i];
+}
+
+template <class Less> __device__ void list_sort(Entry *e, Entry *tmp, int n, Less less)
+{
+	if (n < 2) return;
+	// blocks by the binary digits of n, most significant first; each sorted bottom-up in aligned halves
+	int start = 0;
+	for (int bit = 30; bit >= 0; bit--) {
+		const int size = 1 << bit;
+		if (!(n & size)) continue;
+		for (int width = 1; width < size; width <<= 1)
+			for (int lo = start; lo < start + size; lo += 2 * width) merge_runs(e, tmp, lo, lo + width, lo + 2 * width, less);
+		start += size;
+	}
+	// final merges: the last (smallest) block into its left neighbour, and so on
+	int lo_bit = 0;
+	while (!(n & (1 << lo_bit))) lo_bit++;
+	int right = n - (1 << lo_bit); // start of the merged tail so far
+	for (int bit = lo_bit + 1; bit <= 30; bit++) {
+		const int size = 1 << bit;
+		if (!(n & size)) continue;
+		const int left = right - size;
+		merge_runs(e, tmp, left, right, n, less);
+		right = left;
+	}
+}
+
 // cull_oligo_match, amplicon_search.cpp:679-765; returns the (minus, plus) "strand counts" the way the
 // reference computes them (mask of the element FOLLOWING each valid one, :748-755; end() counts nothing)
-__device__ void cull(List &l, int max_len, bool has_probe, bool single_primer, int &cnt_minus, int &cnt_plus)
+template <int N> __device__ void cull(ListT<N> &l, int max_len, bool has_probe, bool single_primer, int &cnt_minus, int &cnt_plus)
 {
 	const uint32_t threshold = uint32_t(max_len) + 50u;
-	stable_sort(l.e, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); });
+	Entry tmp[N];
+	list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); });
 	for (int i = 0; i < l.n; i++) l.e[i].mask &= uint8_t(~MVALID);
 	for (int f = 0; f < l.n; f++) {
 		if (l.e[f].mask & (MPLUS | MP)) continue;
@@ -168,9 +215,9 @@ __device__ void cull(List &l, int max_len, bool has_probe, bool single_primer, i
 }
 
 // bind_oligo_to_{minus,plus}_strand, mask overload: list surgery of bind_oligo.cpp:476-500,806-826
-__device__ void bind_step(List &l, uint8_t want, const BoundRec *pool)
+template <int N> __device__ void bind_step(ListT<N> &l, uint8_t want, const BoundRec *pool)
 {
-	Entry cur[PAIR_MAX];
+	Entry cur[N];
 	int nc = 0;
 	int o = 0;
 	for (int i = 0; i < l.n; i++) {
@@ -195,7 +242,7 @@ __device__ void bind_step(List &l, uint8_t want, const BoundRec *pool)
 }
 
 struct PairArgs;
-__device__ void pair_group(const PairArgs &a, const Group G);
+template <int N> __device__ void pair_group(const PairArgs &a, const Group G);
 
 __device__ Hit *alloc_hit(const PairArgs &a)
 {
@@ -323,21 +370,28 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 	}
 }
 
-__global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(PairArgs a)
+// N = PAIR_MAX: the groups of up to PAIR_MAX items (all of them in practice); N = PAIR_BIG: the crowded rest.  The
+// per-lane lists live in scratch memory, so the common instance keeps them small.
+template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(PairArgs a)
 {
+	if (N != PAIR_MAX && *a.n_big == 0) return;
 	const uint32_t n_active = *a.n_active;
-	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS)
-		pair_group(a, a.groups[a.active[gi]]);
+	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS) {
+		const Group G = a.groups[a.active[gi]];
+		const uint32_t count = G.count & ~GROUP_ALIVE;
+		if ((N == PAIR_MAX) != (count <= uint32_t(PAIR_MAX))) continue;
+		pair_group<N>(a, G);
+	}
 }
 
-__device__ void pair_group(const PairArgs &a, const Group G)
+template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 {
 	const AssayDev A = a.assays[G.assay & GROUP_ASSAY_MASK];
 	const int seq_index = int(a.db.first_seq_index + G.target);
 	const BoundRec *pool = a.pool;
 
 	const uint32_t g_count = G.count & ~GROUP_ALIVE;
-	if (g_count > uint32_t(PAIR_MAX)) {
+	if (g_count > uint32_t(N)) {
 		atomicOr(a.err, ERR_LIST_OVERFLOW);
 		return;
 	}
@@ -345,10 +399,10 @@ __device__ void pair_group(const PairArgs &a, const Group G)
 	// The seed kernel emits the items of a group in arbitrary order; the reference's list order (the order of the
 	// seed keys: target_loc, assembly group, word index for amplicon(); list, diagonal, word index for the hash
 	// overload) is restored here, where only the groups that bound something arrive.
-	List l;
+	ListT<N> l;
 	l.n = int(g_count);
 	bool any_bound = false;
-	unsigned long long order[PAIR_MAX];
+	unsigned long long order[N];
 	for (int i = 0; i < l.n; i++) {
 		const Item it = a.items[G.first + i];
 		const int32_t res = a.result[G.first + i];
@@ -423,7 +477,10 @@ __device__ void pair_group(const PairArgs &a, const Group G)
 				bind_step(l, want, pool);
 			}
 		}
-		stable_sort(l.e, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }); // :356
+		{
+			Entry tmp[N];
+			list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }); // :356
+		}
 
 		const bool apply_mm = a.min_max_primer_clamp >= 0;
 		const uint32_t min_max_clamp = apply_mm ? uint32_t(a.min_max_primer_clamp) : 0u;
@@ -493,7 +550,7 @@ __device__ void pair_group(const PairArgs &a, const Group G)
 	// items arrive per list (minus-up, minus-down, plus-up, plus-down) in diagonal order; each list keeps
 	// its bound entries, sorted by oligo_info::operator< (stable) and de-duplicated by (loc5, loc3)
 	// (bind_oligo.cpp:431-453)
-	Entry lists[4][PAIR_MAX];
+	Entry lists[4][N];
 	int ln[4] = {0, 0, 0, 0};
 	for (int i = 0; i < l.n; i++) {
 		Entry e = l.e[i];

@@ -31,7 +31,7 @@ constexpr int SEED_WAVES = 4;         // wavefronts (= targets in flight) per wo
 constexpr int SEED_THREADS = 64 * SEED_WAVES;
 constexpr int SEED_CAP = 512;         // seeds of one target x one assay chunk held in LDS
 constexpr int SEED_MAX_ASSAYS = 256;  // assays per chunk (8-bit local index in the key)
-constexpr int LIST_MAX = 64;          // seeds of one (target, assay)
+constexpr int LIST_MAX = 512;         // seeds of one (work unit, assay): bounded by the seed list itself (PAIR_BIG of the pair kernel)
 
 struct SeedOut { // debug / unit-level output: every kept seed before the cull
 	uint32_t target, assay_role, strand_minus, query_loc, target_loc;
@@ -62,6 +62,7 @@ struct SeedArgs {
 	uint32_t *group_count;
 	uint32_t *qa;              // indices of the items bound in phase A
 	uint32_t *qa_count;
+	uint32_t *big_count;       // groups of more than 64 items (the pair kernel's second instance only runs for them)
 	SeedOut *seeds_out;        // optional
 	uint32_t seeds_cap;
 	uint32_t *seeds_count;
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 					if (la < n_chunk) {
 						ibase[la] = uint16_t(ri), abase[la] = uint16_t(ra), gbase[la] = uint16_t(rg);
 						if (nv[m]) a.groups[bg + rg] = Group{t, (a.assay_begin + la) | gf[m], bi + ri, nv[m]};
+						if (nv[m] > 64u) atomicAdd(a.big_count, 1u);
 					}
 					ri += nv[m], ra += na[m], rg += nv[m] ? 1u : 0u;
 				}
