@@ -133,7 +133,7 @@ struct BindFull {
 
 // per (target, assay) group of items emitted by the seed kernel in first-cull order
 struct Group {
-	uint32_t target;
+	uint32_t target;  // seed work unit (a target or one window of it): the pair kernel looks the target up through it
 	uint32_t assay;   // expanded assay index | GROUP_* flags
 	uint32_t first;   // first item
 	uint32_t count;   // | GROUP_ALIVE once one of its items bound

@@ -308,7 +308,9 @@ struct tnt_db {
 	bool host_copy = false;         // h_packed / h_exc_pos / h_exc_code are filled
 	// seed work units: whole targets, or overlapping windows of long ones (SeedArgs, tnt_seed.hip.h)
 	std::vector<uint32_t> h_unit_target, h_unit_begin, h_unit_end;
+	std::vector<int32_t> h_unit_own_lo, h_unit_own_hi; // coordinates whose hits the unit reports
 	DevBuf<uint32_t> unit_target, unit_begin, unit_end;
+	DevBuf<int32_t> unit_own_lo, unit_own_hi;
 	uint32_t max_unit_len = 0;
 	bool split = false;             // some target is cut into windows: results may hold identical copies
 	uint64_t n_exceptions = 0;
@@ -389,6 +391,7 @@ struct tnt_ctx {
 	size_t hit_cap = size_t(1) << 20; // initial hit capacity; grown on demand (tnt_search_collect)
 	int retries = 0;
 	double batch_scale = 1.0;
+	bool force_big = false;   // launch the crowded-group instance of the pair kernel whatever the expected seed density
 	double chunk_scale = 1.0; // assay-chunk size of the seed kernel relative to the planned one (halved after a seed-list overflow) // targets per internal batch relative to the planned number (halved after an overflow)
 
 	~tnt_ctx()
@@ -908,18 +911,21 @@ namespace {
 
 // stride of the windows a long target is cut into; the window itself is stride + overlap long
 constexpr uint32_t UNIT_STRIDE = 4096;
+constexpr uint32_t UNIT_MARGIN = 80; // > longest oligo + flanks: the seeds of a site lie within this of its first coordinate
 
 hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 {
 	const int k = ctx->opt.hash_word_size;
 	// reach of cull_oligo_match (amplicon_search.cpp:688: max_len + 50), so that a kept pair shares a window
-	const uint32_t overlap = uint32_t(std::max(0, ctx->opt.max_len)) + 50u + 64u;
+	// + what a hit's first coordinate may lie before the seeds that made it (UNIT_MARGIN) + the oligos themselves
+	const uint32_t overlap = uint32_t(std::max(0, ctx->opt.max_len)) + 50u + 2u * 64u + 2u * UNIT_MARGIN;
 	// window length for which the busiest assay expects about 128 seeds (short hash words seed densely)
 	size_t max_ent = 1;
 	for (const auto &ae : ctx->assay_entries) max_ent = std::max(max_ent, ae.size());
 	const double dense = 128.0 * double(size_t(1) << (2 * k)) / double(max_ent);
 	const uint32_t stride = std::max(overlap, std::min(UNIT_STRIDE, uint32_t(std::max(1.0, dense - double(overlap)))));
 	db->h_unit_target.clear(), db->h_unit_begin.clear(), db->h_unit_end.clear();
+	db->h_unit_own_lo.clear(), db->h_unit_own_hi.clear();
 	db->max_unit_len = 0;
 	db->split = false;
 	for (size_t t = 0; t < db->n_targets; t++) {
@@ -932,6 +938,7 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 		const double expect = double(npos) * double(max_ent) / double(size_t(1) << (2 * k));
 		if (npos <= stride + overlap || (expect <= 256.0 && npos <= 32768u)) {
 			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
+			db->h_unit_own_lo.push_back(INT32_MIN), db->h_unit_own_hi.push_back(INT32_MAX);
 			db->max_unit_len = std::max(db->max_unit_len, len);
 			continue;
 		}
@@ -939,13 +946,17 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 		for (uint64_t b = 0; b < npos; b += stride) {
 			const uint32_t e = uint32_t(std::min<uint64_t>(npos, b + stride + overlap));
 			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(uint32_t(b)), db->h_unit_end.push_back(e);
+			// ownership: from UNIT_MARGIN behind this window's start to UNIT_MARGIN behind the next one's
+			db->h_unit_own_lo.push_back(b == 0 ? INT32_MIN : int32_t(b + UNIT_MARGIN));
+			db->h_unit_own_hi.push_back(e == npos ? INT32_MAX : int32_t(b + stride + UNIT_MARGIN));
 			db->max_unit_len = std::max(db->max_unit_len, e - uint32_t(b) + uint32_t(k));
 			if (e == npos) break;
 		}
 	}
 	hipError_t e;
 	if ((e = db->unit_target.upload(db->h_unit_target)) != hipSuccess || (e = db->unit_begin.upload(db->h_unit_begin)) != hipSuccess ||
-	    (e = db->unit_end.upload(db->h_unit_end)) != hipSuccess)
+	    (e = db->unit_end.upload(db->h_unit_end)) != hipSuccess || (e = db->unit_own_lo.upload(db->h_unit_own_lo)) != hipSuccess ||
+	    (e = db->unit_own_hi.upload(db->h_unit_own_hi)) != hipSuccess)
 		return e;
 	return hipSuccess;
 }
@@ -1530,8 +1541,19 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	p.hit_count = cnt + C_HITS;
 	p.err = cnt + C_ERR;
 	p.n_big = cnt + C_BIG;
+	p.unit_target = db->unit_target.p;
+	p.unit_own_lo = db->unit_own_lo.p;
+	p.unit_own_hi = db->unit_own_hi.p;
+	// groups of more than PAIR_MAX items need the instance with the large per-lane lists; it is only launched where
+	// they can be expected (dense seeding, windows of long targets) or after a search ran into one
+	{
+		size_t max_ent = 1;
+		for (const auto &ae : c->assay_entries) max_ent = std::max(max_ent, ae.size());
+		const double expect = double(db->max_unit_len) * double(max_ent) / double(size_t(1) << (2 * c->opt.hash_word_size));
+		p.big_enabled = (c->force_big || expect > 16.0) ? 1 : 0;
+	}
 	hipLaunchKernelGGL(pair_kernel<PAIR_MAX>, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
-	hipLaunchKernelGGL(pair_kernel<PAIR_BIG>, dim3(64), dim3(PAIR_THREADS), 0, c->stream, p); // crowded groups, if any
+	if (p.big_enabled) hipLaunchKernelGGL(pair_kernel<PAIR_BIG>, dim3(64), dim3(PAIR_THREADS), 0, c->stream, p);
 	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt);
 	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
 	HIP_TRY(hipGetLastError(), c->err);
@@ -1664,8 +1686,10 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 #endif
 	// Capacity overflows are repaired and the search repeated: the hit buffer grows to what the pair kernel counted,
 	// the per-batch lists (work items, groups, bound records) get smaller batches.
-	if (cnt[C_ERR] & (ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW | ERR_SEED_OVERFLOW)) {
-		const uint32_t fatal = cnt[C_ERR] & ~(ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW | ERR_SEED_OVERFLOW);
+	const uint32_t repairable = ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW | ERR_SEED_OVERFLOW |
+	                            (ctx->force_big ? 0u : ERR_LIST_OVERFLOW);
+	if (cnt[C_ERR] & repairable) {
+		const uint32_t fatal = cnt[C_ERR] & ~repairable;
 		if (!fatal && ctx->retries < 8 && ctx->pending_db) {
 			ctx->retries++;
 			if (cnt[C_ERR] & ERR_HIT_OVERFLOW) {
@@ -1674,6 +1698,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 			}
 			if (cnt[C_ERR] & (ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW)) ctx->batch_scale *= 0.5;
 			if (cnt[C_ERR] & ERR_SEED_OVERFLOW) ctx->chunk_scale *= 0.5; // one assay per chunk is the floor: then the error stands
+			if (cnt[C_ERR] & ERR_LIST_OVERFLOW) ctx->force_big = true;
 			const int rc = tnt_search_enqueue(ctx, ctx->pending_db);
 			if (rc) return rc;
 			return tnt_search_collect(ctx, hits, n_hits);

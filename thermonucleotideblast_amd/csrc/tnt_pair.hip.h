@@ -45,6 +45,11 @@ struct PairArgs {
 	uint32_t *hit_count;
 	uint32_t *err;
 	const uint32_t *n_big;      // groups of more than PAIR_MAX items seen by the seed kernel
+	// seed work units: a hit is reported by the unit that OWNS its first coordinate (windows of a long target overlap;
+	// the owner's window holds every seed within reach of the hit, so its lists are complete there)
+	const uint32_t *unit_target;
+	const int32_t *unit_own_lo, *unit_own_hi;
+	int big_enabled;            // the PAIR_BIG instance is launched as well (else a crowded group is an error the host repairs)
 };
 
 enum : uint8_t { MF = 1, MR = 2, MP = 4, MPLUS = 8, MMINUS = 16, MVALID = 32 }; // oligo_info, tntblast.h:147-154
@@ -379,7 +384,10 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS) {
 		const Group G = a.groups[a.active[gi]];
 		const uint32_t count = G.count & ~GROUP_ALIVE;
-		if ((N == PAIR_MAX) != (count <= uint32_t(PAIR_MAX))) continue;
+		if ((N == PAIR_MAX) != (count <= uint32_t(PAIR_MAX))) {
+			if (N == PAIR_MAX && !a.big_enabled) atomicOr(a.err, ERR_LIST_OVERFLOW);
+			continue;
+		}
 		pair_group<N>(a, G);
 	}
 }
@@ -387,7 +395,8 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 {
 	const AssayDev A = a.assays[G.assay & GROUP_ASSAY_MASK];
-	const int seq_index = int(a.db.first_seq_index + G.target);
+	const int seq_index = int(a.db.first_seq_index + a.unit_target[G.target]);
+	const int own_lo = a.unit_own_lo[G.target], own_hi = a.unit_own_hi[G.target];
 	const BoundRec *pool = a.pool;
 
 	const uint32_t g_count = G.count & ~GROUP_ALIVE;
@@ -495,6 +504,7 @@ template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 				if ((R.loc3 - F.loc5 + 1) > a.max_len) continue;
 				const BoundRec &bf = pool[F.rec], &br = pool[R.rec];
 				if (apply_mm && uint32_t(bf.a3 > br.a3 ? bf.a3 : br.a3) <= min_max_clamp) continue;
+				if (F.loc5 < own_lo || F.loc5 >= own_hi) continue; // reported by the window that owns the amplicon start
 
 				Hit h;
 				init_hit(h, A, seq_index);
@@ -574,6 +584,7 @@ template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 			const int id = pass == 0 ? 1 : 3;
 			for (int i = 0; i < ln[id]; i++) {
 				const Entry &e = lists[id][i];
+				if (e.loc5 < own_lo || e.loc5 >= own_hi) continue;
 				const BoundRec &b = pool[e.rec];
 				Hit *out = alloc_hit(a);
 				if (!out) return;
@@ -598,6 +609,10 @@ template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 				const Entry &U = lists[up][u], &D = lists[down][d];
 				const int len = minus ? (U.loc5 - D.loc3 - 1) : (D.loc5 - U.loc3 - 1);
 				if (len < 0 || len > max_len) continue;
+				{
+					const int first = minus ? D.loc5 : U.loc5;
+					if (first < own_lo || first >= own_hi) continue;
+				}
 				const BoundRec &bu = pool[U.rec], &bd = pool[D.rec];
 				Hit *out = alloc_hit(a);
 				if (!out) return;

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 					const uint32_t la = uint32_t(lane) * PER + m;
 					if (la < n_chunk) {
 						ibase[la] = uint16_t(ri), abase[la] = uint16_t(ra), gbase[la] = uint16_t(rg);
-						if (nv[m]) a.groups[bg + rg] = Group{t, (a.assay_begin + la) | gf[m], bi + ri, nv[m]};
+						if (nv[m]) a.groups[bg + rg] = Group{unit, (a.assay_begin + la) | gf[m], bi + ri, nv[m]};
 						if (nv[m] > 64u) atomicAdd(a.big_count, 1u);
 					}
 					ri += nv[m], ra += na[m], rg += nv[m] ? 1u : 0u;
