@@ -331,6 +331,18 @@ def test_genome_sized_target(Engine, oracle):
     e.close()
 
 
+def test_randomised_options_and_shapes(Engine, checkers):
+    """A slice of scripts/fuzz_parity.py: random option sets (thresholds, clamps, salt, Ct, temperature, word size 5-8,
+    strands, dangles, assay formats) x target shapes (ragged, long, IUPAC-laden, repetitive) against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "40", "11"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-500:]
+    assert " 0 differ" in r.stdout
+
+
 def test_fasta_streaming_reader(Engine, oracle, tmp_path):
     """Batches of whole records (tnt_fasta_open / tnt_fasta_next): same hits as one resident database, global seq_index."""
     import gzip
