@@ -399,6 +399,9 @@ int tntref_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assa
 
 #pragma omp for schedule(dynamic, 16)
 			for (long t = 0; t < (long)n_targets; t++) {
+				// an exception may not leave a work-sharing loop: the reference's own driver dies of the same
+				// throw (tntblast_local.cpp has no handler inside its target loop either); report it instead
+				try {
 				unordered_map<BindCacheKey, BindCacheValue>().swap(plus_cache);
 				unordered_map<BindCacheKey, BindCacheValue>().swap(minus_cache);
 
@@ -450,6 +453,13 @@ int tntref_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assa
 					}
 				}
 				delete[] bio_seq.second;
+				} catch (const char *e) {
+#pragma omp critical
+					{
+						g_err = e;
+						rc = -1;
+					}
+				}
 			}
 
 			const vector<string> local_index = ordered_keys(local_str_table);

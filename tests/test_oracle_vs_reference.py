@@ -83,3 +83,16 @@ def test_expand_matches_reference(checkers):
         assert lib.tntref_expand(s.encode(), buf, len(buf), C.byref(n), C.byref(d)) == 0
         assert buf.value.decode().split("\n")[:-1] == synth.expand_oligo(s)
         assert d.value == synth.degeneracy(s) == n.value
+
+
+def test_random_option_sets(checkers):
+    """A slice of scripts/fuzz_oracle.py (random options x target shapes, the generator of the GPU fuzz)."""
+    import os
+    import subprocess
+    import sys
+    if not checkers.have_ref():
+        pytest.skip("no oracle/_ref")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_oracle.py"), "24", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 differ" in r.stdout
