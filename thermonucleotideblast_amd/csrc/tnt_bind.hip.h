@@ -12,8 +12,8 @@
 //    lives in VGPRs (static unroll over LMAX rows), so the recurrence needs no LDS traffic.
 //  * delta_g (9.6 KB) and the best_base_pair LUT are staged in LDS once per workgroup; the
 //    target window of every lane sits in LDS as bytes [column][lane].
-//  * one 16-bit trace word per cell goes to an HBM scratch slab laid out [cell][lane] so a
-//    wavefront writes 128 contiguous bytes per cell; the traceback reads it back (L2 resident).
+//  * one 8-bit trace word per cell goes to an HBM scratch slab laid out [cell][lane] so a
+//    wavefront writes 64 contiguous bytes per cell; the traceback reads it back (L2 resident).
 //  * float scoring uses no FMA contraction (-ffp-contract=off), IEEE division, and host-computed
 //    logarithms, so Tm/dH/dS are bit-identical to the reference's float32 arithmetic.
 #ifndef TNT_BIND_HIP_H
@@ -44,7 +44,7 @@ struct BindArgs {
 	uint32_t pool_cap;
 	uint32_t *pool_count;
 	BindFull *full;            // optional (unit-level API): full record per item
-	uint16_t *trace;           // scratch, per block slot
+	uint8_t *trace;            // scratch, per block slot
 	uint8_t *best;             // scratch for the best alignment's columns (instances that do not keep them in LDS)
 	uint32_t *stack;
 	uint16_t *ties;            // [TIE_CAP][lane] further cells with the maximal score
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 	__shared__ float2 s_hs_val[256];
 	__shared__ TailConst s_k;
 	constexpr int PF = 8;                            // trace words fetched ahead along the traceback's diagonal
-	__shared__ uint16_t s_pf[PF * BIND_THREADS];
+	__shared__ uint8_t s_pf[PF * BIND_THREADS];
 
 	const int tid = threadIdx.x;
 	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) {
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 	}
 	__syncthreads();
 
-	uint16_t *trace = a.trace + size_t(blockIdx.x) * (size_t(LMAX) * WMAX * BIND_THREADS) + tid;
+	uint8_t *trace = a.trace + size_t(blockIdx.x) * (size_t(LMAX) * WMAX * BIND_THREADS) + tid;
 	uint8_t *cols = s_cols + tid;
 	uint8_t *qry = s_qry + tid;
 	uint8_t *best = BEST_LDS ? s_best + tid : a.best + size_t(blockIdx.x) * (size_t(NCOLS) * BIND_THREADS) + tid;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 		const char *sdg = reinterpret_cast<const char *>(s_dgp);
 		const char *sterm = reinterpret_cast<const char *>(s_term);
 		const int c_bulge = s_const[0], c_zero = s_const[1], c_forb_m = s_const[2], c_forb_xy = s_const[3];
-		uint16_t *tcol = trace;
+		uint8_t *tcol = trace;
 #pragma unroll 1
 		for (int j = 1; j <= Wwave; j++) {
 			const bool colok = j <= W;
@@ -636,19 +636,20 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 					const int ite = bT - (i == 1 ? c_zero : c_bulge);
 					const int It = iti > ite ? iti : ite;
 
+					// Every flag is taken against the value clamped at zero (which the next column needs anyway): a
+					// negative state sets ALL "not from" flags of that state, a combination a maximum cannot produce,
+					// so "state < 0" costs no bit of its own and the word fits one byte.
+					const int Mz = M > 0 ? M : 0, Iqz = Iq > 0 ? Iq : 0, Itz = It > 0 ? It : 0;
 					uint32_t tw;
-					tw = sign_bit(dg1 - M);                                      // set: M did not come from M        (im1_jm1)
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg3 - M), 31);   // set: M did not come from I_target (im1_j)
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg2 - M), 31);   // set: M did not come from I_query  (i_jm1)
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - iqe), 31); // insert < extend: I_query only from I_query
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - iqi), 31); // extend < insert: I_query only from M
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - ite), 31);
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - iti), 31);
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(M), 31);         // M < 0
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(M - 1), 31);     // M <= 0
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(Iq), 31);        // I_query < 0
-					tw = __builtin_amdgcn_alignbit(tw, uint32_t(It), 31);        // I_target < 0
-					tcol[(i - 1) * BIND_THREADS] = uint16_t(tw);
+					tw = sign_bit(dg1 - Mz);                                     // set: M did not come from M        (im1_jm1)
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg3 - Mz), 31);  // set: M did not come from I_target (im1_j)
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg2 - Mz), 31);  // set: M did not come from I_query  (i_jm1)
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - Iqz), 31); // insert < extend: I_query only from I_query
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - Iqz), 31); // extend < insert: I_query only from M
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - Itz), 31);
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - Itz), 31);
+					tw = __builtin_amdgcn_alignbit(tw, uint32_t(Mz - 1), 31);    // M <= 0
+					tcol[(i - 1) * BIND_THREADS] = uint8_t(tw);
 
 					// column maximum over the valid rows; the running maximum is updated once per column below
 					if (EXACT) {
@@ -664,10 +665,10 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 						colmax = colmax > Mv ? colmax : Mv;
 					}
 
-					const int Mc = FULL ? M : (M > 0 ? M : 0);
+					const int Mc = FULL ? M : Mz;
 					aM = cM, aQ = cQ, aT = cT;
-					bM = Mc, bT = It > 0 ? It : 0;
-					oM[i - 1] = Mc, oQ[i - 1] = Iq > 0 ? Iq : 0, oT[i - 1] = bT;
+					bM = Mc, bT = Itz;
+					oM[i - 1] = Mc, oQ[i - 1] = Iqz, oT[i - 1] = bT;
 					term_up = termv;
 				}
 			}
@@ -814,13 +815,13 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 					const bool inside = (li >= 1 && lj >= 1);
 					// The path mostly runs down a diagonal: PF cells of the current diagonal are fetched at once (one
 					// memory latency instead of one per step) and refilled when the walk leaves the run.
-					int tw = TW_M_NEG | TW_IQ_NEG | TW_IT_NEG;
+					int tw = TW_M_NEG | TW_IQ_NEG | TW_IT_NEG; // border cell
 					if (inside) {
 						int d = pf_i - li;
 						if (pf_i < 0 || d < 0 || d >= PF || pf_j - lj != d) {
-							uint16_t v[PF];
+							uint8_t v[PF];
 #pragma unroll
-							for (int k = 0; k < PF; k++) v[k] = (li - k >= 1 && lj - k >= 1) ? TRACE_AT(li - k, lj - k) : uint16_t(0);
+							for (int k = 0; k < PF; k++) v[k] = (li - k >= 1 && lj - k >= 1) ? TRACE_AT(li - k, lj - k) : uint8_t(0);
 #pragma unroll
 							for (int k = 0; k < PF; k++) s_pf[k * BIND_THREADS + tid] = v[k];
 							pf_i = li, pf_j = lj;
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 						if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
 							valid = false;
 						} else {
-							if (tw & TW_M_NEG) valid = false;
+							if ((tw & TW_M_NEG) == TW_M_NEG) valid = false;
 							else if (tw & TW_M_LE0) {
 								if (count_zeros) zero_count++;
 								else if (--truncate_at_zero == 0) valid = false;
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 						if (lj < 1) {
 							valid = false;
 						} else {
-							if (tw & TW_IQ_NEG) valid = false;
+							if ((tw & TW_IQ_NEG) == TW_IQ_NEG) valid = false;
 							cols[(1 + n) * BIND_THREADS] = mk_col(bGAP, TARGET(lj - 1));
 							n++;
 							al.lm_q = L - li + 1;
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 						if (li > L || li < 1 /* Q7 fence */) {
 							valid = false;
 						} else {
-							if (tw & TW_IT_NEG) valid = false;
+							if ((tw & TW_IT_NEG) == TW_IT_NEG) valid = false;
 							cols[(1 + n) * BIND_THREADS] = mk_col(QUERY(L - li), bGAP);
 							n++;
 							al.lm_q = L - li;

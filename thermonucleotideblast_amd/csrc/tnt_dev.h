@@ -20,20 +20,23 @@ constexpr int MAX_WINDOW = MAX_OLIGO + 2 * FLANK;
 constexpr int MAX_COLS = MAX_OLIGO + MAX_WINDOW + 4; // longest traceback path + dangles
 constexpr int ALIGN_TEXT = 448;           // TNT_ALIGN_TEXT
 
-// trace word of one DP cell (11 bits used of 16), see the bind kernel.  Predecessor states follow
-// nuc_cruc.h:62-64 (im1_jm1 = came from M, im1_j = from I_target, i_jm1 = from I_query).
-constexpr int TW_IT_NEG = 1 << 0;     // I_target < 0
-constexpr int TW_IQ_NEG = 1 << 1;     // I_query < 0
-constexpr int TW_M_LE0 = 1 << 2;      // M <= 0 (with TW_M_NEG clear: M == 0)
-constexpr int TW_M_NEG = 1 << 3;      // M < 0
-constexpr int TW_IT_GT = 1 << 4;      // I_target: extend < insert  (trace = from M only)
-constexpr int TW_IT_LT = 1 << 5;      // I_target: insert < extend  (trace = from I_target only)
-constexpr int TW_IQ_GT = 1 << 6;      // I_query:  extend < insert
-constexpr int TW_IQ_LT = 1 << 7;      // I_query:  insert < extend
-// the three "M came from" bits are stored inverted (bit = candidate < maximum: one subtract + one sign-bit shift)
-constexpr int TW_M_NOT_IQ = 1 << 8;   // clear: M_trace & i_jm1
-constexpr int TW_M_NOT_IT = 1 << 9;   // clear: M_trace & im1_j
-constexpr int TW_M_NOT_M = 1 << 10;   // clear: M_trace & im1_jm1
+// trace word of one DP cell: one byte, see the bind kernel.  Predecessor states follow nuc_cruc.h:62-64
+// (im1_jm1 = came from M, im1_j = from I_target, i_jm1 = from I_query).  Every "came from" bit is stored
+// inverted and taken against the state clamped at zero (bit = candidate < max(state, 0): one subtract + one
+// sign-bit shift), so a negative state shows as ALL of its bits set -- which a maximum of the candidates
+// cannot produce -- and needs no bit of its own.
+constexpr int TW_M_LE0 = 1 << 0;      // M <= 0 (with TW_M_NEG not matched: M == 0)
+constexpr int TW_IT_GT = 1 << 1;      // I_target: extend < insert  (trace = from M only)
+constexpr int TW_IT_LT = 1 << 2;      // I_target: insert < extend  (trace = from I_target only)
+constexpr int TW_IQ_GT = 1 << 3;      // I_query:  extend < insert
+constexpr int TW_IQ_LT = 1 << 4;      // I_query:  insert < extend
+constexpr int TW_M_NOT_IQ = 1 << 5;   // clear: M_trace & i_jm1
+constexpr int TW_M_NOT_IT = 1 << 6;   // clear: M_trace & im1_j
+constexpr int TW_M_NOT_M = 1 << 7;    // clear: M_trace & im1_jm1
+// state < 0  <=>  (tw & TW_x_NEG) == TW_x_NEG
+constexpr int TW_IT_NEG = TW_IT_GT | TW_IT_LT;
+constexpr int TW_IQ_NEG = TW_IQ_GT | TW_IQ_LT;
+constexpr int TW_M_NEG = TW_M_NOT_IQ | TW_M_NOT_IT | TW_M_NOT_M;
 
 // Thermodynamic tables resident in HBM (19 KB floats + 9.6 KB ints); delta_g is staged into LDS.
 struct Tables {

@@ -372,7 +372,8 @@ struct tnt_ctx {
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
-	DevBuf<uint16_t> trace, ties;
+	DevBuf<uint8_t> trace;
+	DevBuf<uint16_t> ties;
 	DevBuf<uint8_t> best;
 	DevBuf<uint32_t> stack;
 	DevBuf<SeedOut> seeds_out;
