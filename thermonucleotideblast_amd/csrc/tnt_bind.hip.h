@@ -114,6 +114,24 @@ struct Score {
 	bool ok;
 };
 
+// LDS byte addresses as plain integers: a table base folded into a per-column register leaves one (byte-select)
+// add per read in the fill loop
+typedef __attribute__((address_space(3))) const int lds_cint;
+__device__ __forceinline__ int lds_addr(const void *p)
+{
+	return int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)p)));
+}
+#ifdef TNT_EXP_NOLDS
+__device__ __forceinline__ int lds_load(int addr)
+{
+	int v = addr;
+	asm volatile("v_add_u32 %0, %0, 1" : "+v"(v));
+	return v;
+}
+#else
+__device__ __forceinline__ int lds_load(int addr) { return *(lds_cint *)(uintptr_t(uint32_t(addr))); }
+#endif
+
 // tw = 2 * tw + (x == y): v_cmp_eq + v_addc_co
 __device__ __forceinline__ uint32_t push_eq(uint32_t tw, int x, int y)
 {
@@ -382,9 +400,14 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NCOLS = LMAX + WMAX + 4;
 
-	constexpr int DG_PLANE = 38 * 64;  // ints per plane: ds_read2st64_b32 reaches the second plane with one offset
-	__shared__ int32_t s_dgp[2 * DG_PLANE]; // plane 0: delta_g(prev, cur), plane 1: term(cur); index: see the fill loop
-	__shared__ int32_t s_term[NBP];
+	// delta_g planes.  General instances: plane 0 delta_g(prev, cur), plane 1 term(cur), index ((x'*7 + x)*49 + q'*7 + q),
+	// and term[] by pair.  Plain instances only meet x, x' in ACGT (x' = GAP in the first column): a compact index
+	// ((x'*4 + x)*49 + q'*7 + q) with GAP stored as x' = 4, and a third plane term(x', q) under the same index, so that
+	// the three reads of a cell share one address (immediate offsets reach the planes).
+	constexpr int DG_PLANE = PLAIN ? 16 * 64 : 38 * 64; // ints per plane, a multiple of 64 for ds_read2st64_b32
+	constexpr int DG_PLANES = PLAIN ? 3 : 2;
+	__shared__ int32_t s_dgp[DG_PLANES * DG_PLANE];
+	__shared__ int32_t s_term[PLAIN ? 1 : NBP];
 	__shared__ int32_t s_const[4];
 	__shared__ uint32_t s_rt[18];
 	__shared__ uint8_t s_lut[18 * 18 + 4];
@@ -401,13 +424,24 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 	__shared__ uint8_t s_pf[PF * BIND_THREADS];
 
 	const int tid = threadIdx.x;
-	for (int i = tid; i < NBP * NBP; i += BIND_THREADS) {
-		const int p = i / NBP, cpair = i % NBP; // prev pair (x', q'), current pair (x, q)
-		const int at = ((p / NB) * NB + cpair / NB) * NBP + (p % NB) * NB + cpair % NB;
-		s_dgp[at] = a.tab->dg[i];
-		s_dgp[DG_PLANE + at] = a.tab->term[cpair];
+	if (PLAIN) {
+		for (int at = tid; at < 5 * 4 * NBP; at += BIND_THREADS) {
+			const int xpc = at / (4 * NBP), x = (at / NBP) & 3, qp = (at % NBP) / NB, q = at % NB;
+			const int xp = xpc == 4 ? bGAP : xpc;
+			const int cpair = x * NB + q;
+			s_dgp[at] = a.tab->dg[(xp * NB + qp) * NBP + cpair];
+			s_dgp[DG_PLANE + at] = a.tab->term[cpair];
+			s_dgp[2 * DG_PLANE + at] = a.tab->term[xp * NB + q];
+		}
+	} else {
+		for (int i = tid; i < NBP * NBP; i += BIND_THREADS) {
+			const int p = i / NBP, cpair = i % NBP; // prev pair (x', q'), current pair (x, q)
+			const int at = ((p / NB) * NB + cpair / NB) * NBP + (p % NB) * NB + cpair % NB;
+			s_dgp[at] = a.tab->dg[i];
+			s_dgp[DG_PLANE + at] = a.tab->term[cpair];
+		}
+		if (tid < NBP) s_term[tid] = a.tab->term[tid];
 	}
-	if (tid < NBP) s_term[tid] = a.tab->term[tid];
 	if (tid < 4) s_const[tid] = a.tab->dg_const[tid];
 	for (int i = tid; i < 18 * 18; i += BIND_THREADS) s_lut[i] = a.tab->bbp[i];
 	if (tid < 18) s_rt[tid] = a.tab->rt[tid];
@@ -566,16 +600,19 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 			int term_up = 0;                                     // term(cur) of the row above
 			// keep the per-row constants from being hoisted out of the column loop (register pressure)
 #pragma unroll
-			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(qpk[w]), "+v"(Rpk[w]));
+			for (int w = 0; w < (LMAX + 3) / 4; w++) {
+				if (PLAIN) asm volatile("" : "+v"(Rpk[w]));
+				else asm volatile("" : "+v"(qpk[w]), "+v"(Rpk[w]));
+			}
 			// The two LDS reads of a row are issued one row ahead (their addresses depend on the bases only),
 			// so their latency overlaps the arithmetic of the previous row.
 			//
 			// Table index (s_dgp): ((x' * 7 + x) * 49 + q' * 7 + q with prev pair (x', q') and current pair (x, q),
 			// x = rt(t, q).  Without degenerate target bases (x = t, x' = pt) the address splits into a per-column
-			// and a per-row constant: one add per read.
+			// and a per-row constant, and the compact plain layout puts term(x', q) under the same index: one add
+			// per cell serves all three reads.
 			{
-				int colbase = PLAIN ? pt * (4 * 343) + t * (4 * 49) : 0;
-				int pt28 = pt * 28;
+				int colbase = PLAIN ? lds_addr(s_dgp) + ((pt > 3 ? 4 : pt) * 4 + (t & 3)) * (4 * NBP) : 0; // (t & 3: columns beyond W)
 				int xp = int((prtw >> 24) & 15u); // rt(pt, GAP): row 0 of the previous column
 				int ea_n, ta_n;                   // byte addresses of the next row's reads
 				int e_x_n, e_y_n, tp4_n;
@@ -583,16 +620,20 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 					const int q4 = int(qpk[0] & 255u), r4 = int(Rpk[0] & 255u);
 					if (PLAIN) {
 						ea_n = colbase + r4;
-						ta_n = pt28 + q4;
+						ta_n = 0;
 					} else {
 						const int x = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
 						ea_n = xp * (4 * 343) + x * (4 * 49) + r4;
 						xp = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
 						ta_n = xp * 28 + q4;
 					}
-					e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
-					e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
-					tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
+					if (PLAIN) {
+						e_x_n = lds_load(ea_n), e_y_n = lds_load(ea_n + 4 * DG_PLANE), tp4_n = lds_load(ea_n + 8 * DG_PLANE);
+					} else {
+						e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
+						e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
+						tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
+					}
 				}
 #pragma unroll
 				for (int i = 1; i <= LMAX; i++) {
@@ -600,21 +641,24 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 					const int term_p4 = tp4_n;
 					// the reads stay one row ahead: without this fence the scheduler hoists every row's (independent)
 					// reads to the top of the column and the results do not fit the register budget
-					if (PLAIN && i > 1) asm volatile("" : "+v"(colbase), "+v"(pt28) : "v"(bM));
+					if (PLAIN && i > 1) asm volatile("" : "+v"(colbase) : "v"(bM));
 					if (i < LMAX) {
 						const int q4 = int((qpk[i >> 2] >> ((i & 3) * 8)) & 255u), r4 = int((Rpk[i >> 2] >> ((i & 3) * 8)) & 255u);
 						if (PLAIN) {
 							ea_n = colbase + r4;
-							ta_n = pt28 + q4;
 						} else {
 							const int x = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
 							ea_n = xp * (4 * 343) + x * (4 * 49) + r4; // xp = rt(pt, q of the row above)
 							xp = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
 							ta_n = xp * 28 + q4;
 						}
-						e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
-						e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
-						tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
+						if (PLAIN) {
+							e_x_n = lds_load(ea_n), e_y_n = lds_load(ea_n + 4 * DG_PLANE), tp4_n = lds_load(ea_n + 8 * DG_PLANE);
+						} else {
+							e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
+							e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
+							tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
+						}
 					}
 					// oQ / oT are stored clamped at zero; so is oM in the throughput instances (the unit-level instance
 					// keeps M itself: it reports dp_max / n_max also when no cell is positive)
@@ -645,11 +689,23 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg3 - Mz), 31);  // set: M did not come from I_target (im1_j)
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg2 - Mz), 31);  // set: M did not come from I_query  (i_jm1)
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - Iqz), 31); // insert < extend: I_query only from I_query
+#ifdef TNT_EXP_SPLITCHAIN
+					uint32_t tw2 = sign_bit(iqe - Iqz);
+					tw2 = __builtin_amdgcn_alignbit(tw2, uint32_t(iti - Itz), 31);
+					tw2 = __builtin_amdgcn_alignbit(tw2, uint32_t(ite - Itz), 31);
+					tw2 = __builtin_amdgcn_alignbit(tw2, uint32_t(Mz - 1), 31);
+					tw = (tw << 4) | tw2;
+#else
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - Iqz), 31); // extend < insert: I_query only from M
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - Itz), 31);
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - Itz), 31);
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(Mz - 1), 31);    // M <= 0
+#endif
+#ifdef TNT_EXP_NOSTORE
+					asm volatile("" ::"v"(tw));
+#else
 					tcol[(i - 1) * BIND_THREADS] = uint8_t(tw);
+#endif
 
 					// column maximum over the valid rows; the running maximum is updated once per column below
 					if (EXACT) {
@@ -1006,6 +1062,10 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 		if (tm < th.min_tm || tm > th.max_tm) status = 1;
 		else if (dg < th.min_dg || dg > th.max_dg) status = 2;
 
+#ifdef TNT_EXP_NOOUT
+		a.result[idx] = -1 - (status & 1);
+		continue;
+#endif
 		int a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0, loc5 = 0, loc3 = 0;
 		if (best_valid && (FULL || status == 0)) {
 			const int front_q = col_q(best[bi.k0 * BIND_THREADS]), front_t = col_t(best[bi.k0 * BIND_THREADS]);
