@@ -593,7 +593,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 			const int t = colok ? int(win[(j - 1) * BIND_THREADS]) : bGAP;
 			const uint32_t rtw = s_rt[t];
 			const int v5 = firstcol ? c_zero : c_bulge;          // g(bp(pt,GAP), bp(t,GAP))
-			int aM = FULL ? -1 : 0, aQ = 0, aT = 0, bM = FULL ? -1 : 0, bT = 0; // border cells hold -1 (nuc_cruc.h:531-536), kept clamped like the gap states
+			int bM = FULL ? -1 : 0, bT = 0; // border cells hold -1 (nuc_cruc.h:531-536), kept clamped like the gap states
 			int Lcol = colok ? L : 0;         // rows that count in this column
 			if (FULL && xmode == 3) Lcol = (L - 3 - j) > 0 ? (L - 3 - j) : 0; // align_hairpin's triangle, nuc_cruc.cpp:794-810
 			int colmax = INT32_MIN, held = INT32_MIN;
@@ -604,9 +604,6 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 				if (PLAIN) asm volatile("" : "+v"(Rpk[w]));
 				else asm volatile("" : "+v"(qpk[w]), "+v"(Rpk[w]));
 			}
-			// The two LDS reads of a row are issued one row ahead (their addresses depend on the bases only),
-			// so their latency overlaps the arithmetic of the previous row.
-			//
 			// Table index (s_dgp): ((x' * 7 + x) * 49 + q' * 7 + q with prev pair (x', q') and current pair (x, q),
 			// x = rt(t, q).  Without degenerate target bases (x = t, x' = pt) the address splits into a per-column
 			// and a per-row constant, and the compact plain layout puts term(x', q) under the same index: one add
@@ -614,67 +611,55 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 			{
 				int colbase = PLAIN ? lds_addr(s_dgp) + ((pt > 3 ? 4 : pt) * 4 + (t & 3)) * (4 * NBP) : 0; // (t & 3: columns beyond W)
 				int xp = int((prtw >> 24) & 15u); // rt(pt, GAP): row 0 of the previous column
-				int ea_n, ta_n;                   // byte addresses of the next row's reads
-				int e_x_n, e_y_n, tp4_n;
-				{
-					const int q4 = int(qpk[0] & 255u), r4 = int(Rpk[0] & 255u);
+				// reads of row k (their addresses depend on the bases only)
+				auto issue = [&](const int k, int &ox, int &oy, int &ot) __attribute__((always_inline)) {
+					const int q4 = int((qpk[(k - 1) >> 2] >> (((k - 1) & 3) * 8)) & 255u), r4 = int((Rpk[(k - 1) >> 2] >> (((k - 1) & 3) * 8)) & 255u);
 					if (PLAIN) {
-						ea_n = colbase + r4;
-						ta_n = 0;
+						const int ea = colbase + r4;
+						ox = lds_load(ea), oy = lds_load(ea + 4 * DG_PLANE), ot = lds_load(ea + 8 * DG_PLANE);
 					} else {
 						const int x = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
-						ea_n = xp * (4 * 343) + x * (4 * 49) + r4;
+						const int ea = xp * (4 * 343) + x * (4 * 49) + r4; // xp = rt(pt, q of the row above)
 						xp = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
-						ta_n = xp * 28 + q4;
+						const int ta = xp * 28 + q4;
+						ox = *reinterpret_cast<const int *>(sdg + ea);
+						oy = *reinterpret_cast<const int *>(sdg + ea + 4 * DG_PLANE);
+						ot = *reinterpret_cast<const int *>(sterm + ta);
 					}
-					if (PLAIN) {
-						e_x_n = lds_load(ea_n), e_y_n = lds_load(ea_n + 4 * DG_PLANE), tp4_n = lds_load(ea_n + 8 * DG_PLANE);
-					} else {
-						e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
-						e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
-						tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
-					}
-				}
+				};
+				// The reads run two rows ahead: row i also forms the diagonal candidates of row i + 1 (they need the
+				// old states of row i, which die there -- the new states can take their registers, no copies at the
+				// loop's back edge) and so needs row i + 1's table values.
+				int nx_x, nx_y, nx_t, n2_x = 0, n2_y = 0, n2_t = 0;
+				issue(1, nx_x, nx_y, nx_t);
+				if (LMAX >= 2) issue(2, n2_x, n2_y, n2_t);
+				int dg1 = 0 - nx_x;                             // row 1: the border row above holds max(0, -1) = 0, 0, 0
+				int dg2 = 0 - (firstcol ? c_forb_m : nx_y);
+				int dg3 = 0 - c_forb_m;
 #pragma unroll
 				for (int i = 1; i <= LMAX; i++) {
-					const int2 e = make_int2(e_x_n, e_y_n);
-					const int term_p4 = tp4_n;
-					// the reads stay one row ahead: without this fence the scheduler hoists every row's (independent)
+					const int termv = nx_y, term_p4 = nx_t;
+					nx_x = n2_x, nx_y = n2_y, nx_t = n2_t;
+					// the reads stay in row order: without this fence the scheduler hoists every row's (independent)
 					// reads to the top of the column and the results do not fit the register budget
 					if (PLAIN && i > 1) asm volatile("" : "+v"(colbase) : "v"(bM));
-					if (i < LMAX) {
-						const int q4 = int((qpk[i >> 2] >> ((i & 3) * 8)) & 255u), r4 = int((Rpk[i >> 2] >> ((i & 3) * 8)) & 255u);
-						if (PLAIN) {
-							ea_n = colbase + r4;
-						} else {
-							const int x = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
-							ea_n = xp * (4 * 343) + x * (4 * 49) + r4; // xp = rt(pt, q of the row above)
-							xp = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
-							ta_n = xp * 28 + q4;
-						}
-						if (PLAIN) {
-							e_x_n = lds_load(ea_n), e_y_n = lds_load(ea_n + 4 * DG_PLANE), tp4_n = lds_load(ea_n + 8 * DG_PLANE);
-						} else {
-							e_x_n = *reinterpret_cast<const int *>(sdg + ea_n);
-							e_y_n = *reinterpret_cast<const int *>(sdg + ea_n + 4 * DG_PLANE);
-							tp4_n = *reinterpret_cast<const int *>(sterm + ta_n);
-						}
-					}
+					if (i + 2 <= LMAX) issue(i + 2, n2_x, n2_y, n2_t);
 					// oQ / oT are stored clamped at zero; so is oM in the throughput instances (the unit-level instance
 					// keeps M itself: it reports dp_max / n_max also when no cell is positive)
 					const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
-					const int termv = e.y;
+					const int cMz = FULL ? (cM > 0 ? cM : 0) : cM;
+					int dn1 = 0, dn2 = 0, dn3 = 0;
+					if (i < LMAX) dn1 = cMz - nx_x, dn2 = cQ - (firstcol ? c_forb_m : nx_y), dn3 = cT - nx_y;
+					int iqi = cMz - term_p4;
+					int iqe = cQ - v5;
+					// the old states of this row are dead from here on
+					asm volatile("" : "+v"(dn1), "+v"(dn2), "+v"(dn3), "+v"(iqi), "+v"(iqe), "+v"(dg1));
 
-					const int dg1 = (FULL ? (aM > 0 ? aM : 0) : aM) - e.x;
-					const int dg2 = aQ - (firstcol ? c_forb_m : termv);
-					const int dg3 = aT - (i == 1 ? c_forb_m : termv);
 					// reference if-chain (nuc_cruc.cpp:552-597) == max3 with "equal to the maximum" trace bits.
 					// The trace word is built as a shift register, one v_alignbit (sign bit) per flag; equalities are
 					// taken as "not less than the maximum" (a full-rate subtract feeds the sign).  Layout: TW_* in tnt_dev.h.
 					int M = dg1 > dg2 ? dg1 : dg2;
 					M = M > dg3 ? M : dg3;
-					const int iqi = (FULL ? (cM > 0 ? cM : 0) : cM) - term_p4;
-					const int iqe = cQ - v5;
 					const int Iq = iqi > iqe ? iqi : iqe;
 					const int iti = (FULL ? (bM > 0 ? bM : 0) : bM) - (i == 1 ? c_forb_xy : term_up);
 					const int ite = bT - (i == 1 ? c_zero : c_bulge);
@@ -689,18 +674,10 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg3 - Mz), 31);  // set: M did not come from I_target (im1_j)
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(dg2 - Mz), 31);  // set: M did not come from I_query  (i_jm1)
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqi - Iqz), 31); // insert < extend: I_query only from I_query
-#ifdef TNT_EXP_SPLITCHAIN
-					uint32_t tw2 = sign_bit(iqe - Iqz);
-					tw2 = __builtin_amdgcn_alignbit(tw2, uint32_t(iti - Itz), 31);
-					tw2 = __builtin_amdgcn_alignbit(tw2, uint32_t(ite - Itz), 31);
-					tw2 = __builtin_amdgcn_alignbit(tw2, uint32_t(Mz - 1), 31);
-					tw = (tw << 4) | tw2;
-#else
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iqe - Iqz), 31); // extend < insert: I_query only from M
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(iti - Itz), 31);
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(ite - Itz), 31);
 					tw = __builtin_amdgcn_alignbit(tw, uint32_t(Mz - 1), 31);    // M <= 0
-#endif
 #ifdef TNT_EXP_NOSTORE
 					asm volatile("" ::"v"(tw));
 #else
@@ -722,7 +699,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 					}
 
 					const int Mc = FULL ? M : Mz;
-					aM = cM, aQ = cQ, aT = cT;
+					dg1 = dn1, dg2 = dn2, dg3 = dn3;
 					bM = Mc, bT = Itz;
 					oM[i - 1] = Mc, oQ[i - 1] = Iqz, oT[i - 1] = bT;
 					term_up = termv;
