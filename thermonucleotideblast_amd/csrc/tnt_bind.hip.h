@@ -402,10 +402,11 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 
 	// delta_g planes.  General instances: plane 0 delta_g(prev, cur), plane 1 term(cur), index ((x'*7 + x)*49 + q'*7 + q),
 	// and term[] by pair.  Plain instances only meet x, x' in ACGT (x' = GAP in the first column): a compact index
-	// ((x'*4 + x)*49 + q'*7 + q) with GAP stored as x' = 4, and a third plane term(x', q) under the same index, so that
-	// the three reads of a cell share one address (immediate offsets reach the planes).
+	// ((x'*4 + x)*49 + q'*7 + q) with GAP stored as x' = 4, a third plane term(x', q) and a fourth with the first
+	// column's special case folded in, all under the same index: the four reads of a cell share one address
+	// (immediate offsets reach the planes).
 	constexpr int DG_PLANE = PLAIN ? 16 * 64 : 38 * 64; // ints per plane, a multiple of 64 for ds_read2st64_b32
-	constexpr int DG_PLANES = PLAIN ? 3 : 2;
+	constexpr int DG_PLANES = PLAIN ? 4 : 2;
 	__shared__ int32_t s_dgp[DG_PLANES * DG_PLANE];
 	__shared__ int32_t s_term[PLAIN ? 1 : NBP];
 	__shared__ int32_t s_const[4];
@@ -432,6 +433,8 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 			s_dgp[at] = a.tab->dg[(xp * NB + qp) * NBP + cpair];
 			s_dgp[DG_PLANE + at] = a.tab->term[cpair];
 			s_dgp[2 * DG_PLANE + at] = a.tab->term[xp * NB + q];
+			// what the I_query -> M candidate subtracts: term(cur), but FORB_M in the first column (x' = GAP)
+			s_dgp[3 * DG_PLANE + at] = xpc == 4 ? a.tab->dg_const[2] : a.tab->term[cpair];
 		}
 	} else {
 		for (int i = tid; i < NBP * NBP; i += BIND_THREADS) {
@@ -612,11 +615,11 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 				int colbase = PLAIN ? lds_addr(s_dgp) + ((pt > 3 ? 4 : pt) * 4 + (t & 3)) * (4 * NBP) : 0; // (t & 3: columns beyond W)
 				int xp = int((prtw >> 24) & 15u); // rt(pt, GAP): row 0 of the previous column
 				// reads of row k (their addresses depend on the bases only)
-				auto issue = [&](const int k, int &ox, int &oy, int &ot) __attribute__((always_inline)) {
+				auto issue = [&](const int k, int &ox, int &oy, int &ot, int &o2) __attribute__((always_inline)) {
 					const int q4 = int((qpk[(k - 1) >> 2] >> (((k - 1) & 3) * 8)) & 255u), r4 = int((Rpk[(k - 1) >> 2] >> (((k - 1) & 3) * 8)) & 255u);
 					if (PLAIN) {
 						const int ea = colbase + r4;
-						ox = lds_load(ea), oy = lds_load(ea + 4 * DG_PLANE), ot = lds_load(ea + 8 * DG_PLANE);
+						ox = lds_load(ea), oy = lds_load(ea + 4 * DG_PLANE), ot = lds_load(ea + 8 * DG_PLANE), o2 = lds_load(ea + 12 * DG_PLANE);
 					} else {
 						const int x = int(__builtin_amdgcn_ubfe(rtw, uint32_t(q4), 4u));
 						const int ea = xp * (4 * 343) + x * (4 * 49) + r4; // xp = rt(pt, q of the row above)
@@ -625,31 +628,32 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 						ox = *reinterpret_cast<const int *>(sdg + ea);
 						oy = *reinterpret_cast<const int *>(sdg + ea + 4 * DG_PLANE);
 						ot = *reinterpret_cast<const int *>(sterm + ta);
+						o2 = firstcol ? c_forb_m : oy;
 					}
 				};
 				// The reads run two rows ahead: row i also forms the diagonal candidates of row i + 1 (they need the
 				// old states of row i, which die there -- the new states can take their registers, no copies at the
 				// loop's back edge) and so needs row i + 1's table values.
-				int nx_x, nx_y, nx_t, n2_x = 0, n2_y = 0, n2_t = 0;
-				issue(1, nx_x, nx_y, nx_t);
-				if (LMAX >= 2) issue(2, n2_x, n2_y, n2_t);
+				int nx_x, nx_y, nx_t, nx_2, n2_x = 0, n2_y = 0, n2_t = 0, n2_2 = 0;
+				issue(1, nx_x, nx_y, nx_t, nx_2);
+				if (LMAX >= 2) issue(2, n2_x, n2_y, n2_t, n2_2);
 				int dg1 = 0 - nx_x;                             // row 1: the border row above holds max(0, -1) = 0, 0, 0
-				int dg2 = 0 - (firstcol ? c_forb_m : nx_y);
+				int dg2 = 0 - nx_2;
 				int dg3 = 0 - c_forb_m;
 #pragma unroll
 				for (int i = 1; i <= LMAX; i++) {
 					const int termv = nx_y, term_p4 = nx_t;
-					nx_x = n2_x, nx_y = n2_y, nx_t = n2_t;
+					nx_x = n2_x, nx_y = n2_y, nx_t = n2_t, nx_2 = n2_2;
 					// the reads stay in row order: without this fence the scheduler hoists every row's (independent)
 					// reads to the top of the column and the results do not fit the register budget
 					if (PLAIN && i > 1) asm volatile("" : "+v"(colbase) : "v"(bM));
-					if (i + 2 <= LMAX) issue(i + 2, n2_x, n2_y, n2_t);
+					if (i + 2 <= LMAX) issue(i + 2, n2_x, n2_y, n2_t, n2_2);
 					// oQ / oT are stored clamped at zero; so is oM in the throughput instances (the unit-level instance
 					// keeps M itself: it reports dp_max / n_max also when no cell is positive)
 					const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
 					const int cMz = FULL ? (cM > 0 ? cM : 0) : cM;
 					int dn1 = 0, dn2 = 0, dn3 = 0;
-					if (i < LMAX) dn1 = cMz - nx_x, dn2 = cQ - (firstcol ? c_forb_m : nx_y), dn3 = cT - nx_y;
+					if (i < LMAX) dn1 = cMz - nx_x, dn2 = cQ - nx_2, dn3 = cT - nx_y;
 					int iqi = cMz - term_p4;
 					int iqe = cQ - v5;
 					// the old states of this row are dead from here on
