@@ -25,7 +25,25 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("no_align", 2, 200, 16, 8, ["-e", "45", "-a", "F", "-M", "F", "--max-mismatch", "3"]),
     # one 150-kb record next to short ones: searched in overlapping windows here, unfragmented by the reference
     ("long_target", 3, 200, 16, 9, ["-e", "40", "-E", "40"]),
+    # the other output formats and post-processing options (every file the run writes is compared, and the closing
+    # statistics / assay summary on stdout)
+    ("fasta_m1", 3, 300, 24, 10, ["-e", "40", "-E", "40", "-m", "1", "-L", "T"]),
+    ("network_m2", 2, 300, 24, 11, ["-e", "40", "-m", "2"]),
+    ("inverse_target_m3", 2, 300, 24, 12, ["-e", "40", "-m", "3"]),
+    ("inverse_query_m4", 2, 300, 24, 13, ["-e", "40", "-m", "4"]),
+    ("per_query_n", 3, 300, 12, 14, ["-e", "40", "-E", "40", "-n", "T"]),
+    ("best_match", 2, 300, 24, 15, ["-e", "30", "--best-match", "-S", "T"]),
+    ("summary_degenerate", 4, 120, 20, 16, ["-e", "40", "-S", "T"]),
 ]
+
+
+def closing_lines(stdout):
+    """stdout from the match count to the end, without the timing line (the progress display before it differs)"""
+    lines = stdout.split("\n")
+    for i, l in enumerate(lines):
+        if "target sequence matches" in l or "inverse target matches" in l or l.startswith("*** Assay Summary"):
+            return [x for x in lines[i:] if x and not x.startswith("Search completed")]
+    return []
 
 
 def write_case(d, cfg, nt, na, seed, long_target=False):
@@ -48,6 +66,9 @@ def main():
     for name, cfg, nt, na, seed, flags in CASES:
         d = os.path.join(work, name)
         os.makedirs(d, exist_ok=True)
+        for f in os.listdir(d):
+            if f.startswith("ref.out") or f.startswith("hip.out"):
+                os.remove(os.path.join(d, f))
         write_case(d, cfg, nt, na, seed, long_target=(name == "long_target"))
         common = ["-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna")] + flags
         env = dict(os.environ, OMP_NUM_THREADS="1")
@@ -57,17 +78,34 @@ def main():
             print(name, "FAILED to run: ref rc", r1.returncode, "hip rc", r2.returncode, r1.stderr[-300:], r2.stderr[-300:])
             bad += 1
             continue
-        a = open(os.path.join(d, "ref.out"), "rb").read()
-        b = open(os.path.join(d, "hip.out"), "rb").read()
-        same = a == b
-        print("%-14s %s  ref %d bytes, %d records; hip %d bytes" % (name, "identical" if same else "DIFFERENT", len(a), a.count(b"name = "), len(b)))
+        files_ref = sorted(f[len("ref.out"):] for f in os.listdir(d) if f.startswith("ref.out"))
+        files_hip = sorted(f[len("hip.out"):] for f in os.listdir(d) if f.startswith("hip.out"))
+        same = files_ref == files_hip and bool(files_ref)
+        n_bytes = n_rec = 0
+        first = None
+        for suffix in files_ref if same else []:
+            a = open(os.path.join(d, "ref.out" + suffix), "rb").read()
+            b = open(os.path.join(d, "hip.out" + suffix), "rb").read()
+            n_bytes += len(a)
+            n_rec += a.count(b"name = ")
+            if a != b and first is None:
+                same = False
+                la, lb = a.decode("latin-1").split("\n"), b.decode("latin-1").split("\n")
+                for i, (x, y) in enumerate(zip(la, lb)):
+                    if x != y:
+                        first = "  first difference in out%s at line %d:\n    ref: %s\n    hip: %s" % (suffix, i + 1, x, y)
+                        break
+                else:
+                    first = "  out%s: %d vs %d lines" % (suffix, len(la), len(lb))
+        c1, c2 = closing_lines(r1.stdout), closing_lines(r2.stdout)
+        if c1 != c2:
+            same = False
+            first = first or "  closing stdout differs:\n    ref: %s\n    hip: %s" % (c1[:6], c2[:6])
+        print("%-18s %s  %d file(s) %s, %d bytes, %d records, %d closing stdout lines" % (
+            name, "identical" if same else "DIFFERENT", len(files_ref), files_ref, n_bytes, n_rec, len(c1)))
         if not same:
             bad += 1
-            la, lb = a.decode("latin-1").split("\n"), b.decode("latin-1").split("\n")
-            for i, (x, y) in enumerate(zip(la, lb)):
-                if x != y:
-                    print("  first difference at line %d:\n    ref: %s\n    hip: %s" % (i + 1, x, y))
-                    break
+            print(first or "  file sets differ: %s vs %s" % (files_ref, files_hip))
     sys.exit(1 if bad else 0)
 
 

@@ -201,9 +201,12 @@ def main():
             r = subprocess.run([cli_compare.REF, "-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna"), "-o", out] + flags,
                                env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
+            files = {f[len("ref.out"):]: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.startswith("ref.out")}
             cases.append({"name": name, "flags": flags, "assays": open(os.path.join(d, "assays.txt")).read(),
-                          "fasta": open(os.path.join(d, "db.fna")).read(), "expected": open(out).read()})
-            print("G7", name, len(cases[-1]["expected"]), "bytes,", cases[-1]["expected"].count("name = "), "records")
+                          "fasta": open(os.path.join(d, "db.fna")).read(), "files": files,
+                          "closing": cli_compare.closing_lines(r.stdout)})
+            print("G7", name, {k: len(v) for k, v in files.items()}, "bytes,", sum(v.count("name = ") for v in files.values()), "records,",
+                  len(cases[-1]["closing"]), "closing stdout lines")
     dump("g7_cli.json.gz", {"cases": cases})
 
     # ---- G4

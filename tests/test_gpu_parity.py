@@ -285,7 +285,13 @@ def test_cli_output_golden(Engine, tmp_path):
         (d / "db.fna").write_text(case["fasta"])
         r = _run_cli(["-i", str(d / "assays.txt"), "-d", str(d / "db.fna"), "-o", str(d / "out.txt")] + case["flags"])
         assert r.returncode == 0, r.stderr
-        assert (d / "out.txt").read_text() == case["expected"], case["name"]
+        # every file the run writes (-m 2: .sif / .atr, -n T: one per query) and the closing statistics on stdout
+        got = {f.name[len("out.txt"):]: f.read_text() for f in sorted(d.iterdir()) if f.name.startswith("out.txt")}
+        assert sorted(got) == sorted(case["files"]), case["name"]
+        for suffix, text in case["files"].items():
+            assert got[suffix] == text, (case["name"], suffix)
+        import cli_compare
+        assert cli_compare.closing_lines(r.stdout) == case["closing"], case["name"]
 
 
 @pytest.mark.parametrize("cfg,kw", [(3, {}), (5, {}), (2, {"max_len": 300})])
@@ -376,7 +382,7 @@ def test_cli_streams_in_batches(Engine, tmp_path, monkeypatch):
     monkeypatch.setenv("TNT_MI355X_CHUNK_BYTES", "20000")
     r = _run_cli(["-i", str(tmp_path / "assays.txt"), "-d", str(tmp_path / "db.fna"), "-o", str(tmp_path / "out.txt")] + case["flags"])
     assert r.returncode == 0, r.stderr
-    assert (tmp_path / "out.txt").read_text() == case["expected"]
+    assert (tmp_path / "out.txt").read_text() == case["files"][""]
 
 
 def test_cli_vs_reference_binary_where_present(Engine, checkers, tmp_path):

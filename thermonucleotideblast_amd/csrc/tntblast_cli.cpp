@@ -16,14 +16,17 @@
 #include <getopt.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <list>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -52,6 +55,12 @@ struct Options {
 	bool have_primer_bounds = false, have_probe_bounds = false;
 	bool show_alignments = true, show_sequence = true, append_name = false, ignore_probe = false, rescale_ct = true;
 	bool verbose = true;
+	// -m (options.cpp:672-708): exactly one of the five file formats; -a / -M add to the standard one
+	enum { STANDARD = 1, FASTA = 2, NETWORK = 4, INVERSE_TARGET = 8, INVERSE_QUERY = 16 };
+	int format = STANDARD;
+	bool per_query = false;  // -n: one output file per query
+	bool summary = false;    // -S: assay summary on stdout
+	bool best_match = false; // --best-match
 };
 
 struct Assay { // one line of the assay file
@@ -275,11 +284,49 @@ bool record_less(const Record &a, const Record &b) // hybrid_sig::operator< for 
 	return a.h.seq_index < b.h.seq_index;
 }
 
+// select_best_match, tntblast_util.cpp:1482-1546: of the matches of one assay on one target, keep one.  The list
+// is first sorted (stably) by target; every later match of the same target then either dies or replaces the survivor.
+void select_best_match(std::vector<Record> &m)
+{
+	if (m.empty()) return;
+	std::stable_sort(m.begin(), m.end(), [](const Record &a, const Record &b) { return a.h.seq_index < b.h.seq_index; });
+	auto min_primer_tm = [](const Record &r) { return std::max(0.0f, r.min_tm()); }; // hybrid_sig.h:369-373
+	std::vector<Record> keep;
+	size_t best = 0;
+	std::vector<char> dead(m.size(), 0);
+	for (size_t curr = 1; curr < m.size(); curr++) {
+		if (m[curr].h.seq_index != m[best].h.seq_index) {
+			best = curr;
+			continue;
+		}
+		bool delete_curr = false;
+		if (m[curr].h.has_primers) {
+			if (min_primer_tm(m[curr]) == min_primer_tm(m[best])) {
+				if (m[curr].h.probe_tm < m[best].h.probe_tm) delete_curr = true;
+				if (m[curr].max_tm() < m[best].max_tm()) delete_curr = true;
+			} else if (min_primer_tm(m[curr]) < min_primer_tm(m[best])) {
+				delete_curr = true;
+			}
+		} else if (m[curr].h.probe_tm < m[best].h.probe_tm) {
+			delete_curr = true;
+		}
+		if (delete_curr) {
+			dead[curr] = 1;
+		} else {
+			dead[best] = 1;
+			best = curr;
+		}
+	}
+	for (size_t i = 0; i < m.size(); i++)
+		if (!dead[i]) keep.push_back(m[i]);
+	m.swap(keep);
+}
+
 void usage()
 {
-	std::cerr << "tntblast-mi355x: the tntblast search on an MI355X (FASTA databases, -m 0 output)\n"
+	std::cerr << "tntblast-mi355x: the tntblast search on an MI355X (FASTA databases)\n"
 	             "\t-i <assay file> -d <FASTA database, plain or gzip> [-o <output file>] -e <min primer Tm> -E <min probe Tm>\n"
-	             "\t[-x -X -z -Z -g -G -s -t -T -y -l -A <PCR|PROBE|PADLOCK|MIPS> -W -a -M -L -p -v]\n"
+	             "\t[-x -X -z -Z -g -G -s -t -T -y -l -A <PCR|PROBE|PADLOCK|MIPS> -W -a -M -L -p -v -m <0..4> -n -S --best-match]\n"
 	             "\t[--primer-clamp --min-max-primer-clamp --probe-clamp5 --probe-clamp3 --single-primer-pcr --target-strand\n"
 	             "\t --temperature --dangle5 --dangle3 --max-gap --max-mismatch --max-poly-degen --rescale-ct --hash-size]"
 	          << std::endl;
@@ -348,6 +395,7 @@ void parse_args(int argc, char **argv, Options &o)
 			case 18: o.t.max_gap = atoi(optarg); break;
 			case 19: o.t.max_mismatch = atoi(optarg); break;
 			case 20: o.rescale_ct = parse_bool(optarg); break;
+			case 21: o.best_match = true; break;
 			case 24: o.t.max_poly_degen = abs(atoi(optarg)); break;
 			default: fail(std::string("--") + longs[idx].name + " is not supported by the MI355X front end");
 			}
@@ -380,18 +428,25 @@ void parse_args(int argc, char **argv, Options &o)
 		}
 		case 'W': o.t.hash_word_size = atoi(optarg); break;
 		case 'm':
-			if (atoi(optarg) != 0) fail("only the verbose output file (-m 0) is supported by the MI355X front end");
+			switch (atoi(optarg)) {
+			case 0: o.format = Options::STANDARD; break;
+			case 1: o.format = Options::FASTA; break;
+			case 2: o.format = Options::NETWORK; break;
+			case 3: o.format = Options::INVERSE_TARGET; break;
+			case 4: o.format = Options::INVERSE_QUERY; break;
+			default: fail("Unknown output format. Please specify a number between 0-3");
+			}
 			break;
 		case 'a': o.show_alignments = parse_bool(optarg); break;
 		case 'M': o.show_sequence = parse_bool(optarg); break;
 		case 'v': o.verbose = parse_bool(optarg); break;
 		case 'p': o.ignore_probe = parse_bool(optarg); break;
 		case 'L': o.append_name = parse_bool(optarg); break;
+		case 'n': o.per_query = parse_bool(optarg); break;
+		case 'S': o.summary = parse_bool(optarg); break;
 		case 'k':
 		case 'K':
 		case 'r':
-		case 'n':
-		case 'S':
 			if (parse_bool(optarg)) fail(std::string("-") + char(c) + " T is not supported by the MI355X front end");
 			break;
 		case 'D': fail("-D (local database) is not supported by the MI355X front end");
@@ -469,11 +524,19 @@ int main(int argc, char **argv)
 		std::vector<std::vector<Record>> results(assays.size());
 		std::vector<char> amp(1 << 20);
 		size_t n_targets = 0, n_seen = 0;
+		std::vector<std::string> all_deflines; // -m 3 only
 		while (true) {
 			if (tnt_fasta_next(reader, ctx, chunk, &db) != TNT_OK) fail(tnt_last_error(ctx));
 			if (!db) break;
 			const size_t first = n_targets;
 			n_targets += tnt_db_num_targets(db);
+			if (opt.format & Options::INVERSE_TARGET)
+				for (size_t t = 0; t < tnt_db_num_targets(db); t++) {
+					const char *defline = "";
+					size_t dl = 0;
+					(void)tnt_db_defline(db, t, &defline, &dl);
+					all_deflines.emplace_back(defline, dl);
+				}
 			const tnt_hit *hits = nullptr;
 			size_t n_hits = 0;
 			if (tnt_search(ctx, db, &hits, &n_hits) != TNT_OK) fail(tnt_last_error(ctx));
@@ -497,15 +560,52 @@ int main(int argc, char **argv)
 			std::cout << "Found " << n_targets << " database sequences" << std::endl;
 			std::cout << "Found " << assays.size() << " query assays" << std::endl;
 		}
-		for (auto &r : results) std::stable_sort(r.begin(), r.end(), record_less);
-
-		std::ofstream fout;
+		// ---- output, tntblast_local.cpp:70-130 (files) and :877-1370 (records, summaries)
+		std::ofstream fout, fout_sif, fout_atr;
 		std::ostream *out = &std::cout;
 		if (!opt.output.empty()) {
-			fout.open(opt.output.c_str());
-			if (!fout) fail("Unable to open the output file");
+			if (!opt.per_query) {
+				if (opt.format & (Options::STANDARD | Options::FASTA)) {
+					fout.open(opt.output.c_str());
+					if (!fout) fail("Unable to open output file");
+				}
+				if (opt.format & Options::NETWORK) {
+					fout_sif.open((opt.output + ".sif").c_str());
+					if (!fout_sif) fail("Unable to open " + opt.output + ".sif");
+				}
+			}
+			if (opt.format & Options::NETWORK) { // one attribute file per run
+				fout_atr.open((opt.output + ".atr").c_str());
+				if (!fout_atr) fail("Unable to open " + opt.output + ".atr");
+				fout_atr << "FunctionalCatagory" << std::endl;
+			}
+			if (opt.format & (Options::INVERSE_TARGET | Options::INVERSE_QUERY)) {
+				fout.open(opt.output.c_str());
+				if (!fout) fail("Unable to open output file");
+			}
 			out = &fout;
 		}
+		const bool standard = (opt.format & Options::STANDARD) != 0;
+		auto mask_white_space = [](std::string v) { // tntblast_util.cpp:1298-1311
+			for (char &ch : v)
+				if (isspace(static_cast<unsigned char>(ch))) ch = '_';
+			return v;
+		};
+
+		if (opt.format & Options::INVERSE_QUERY) {
+			// names of the queries without a match.  The reference keeps one flag per assay id but walks the *expanded*
+			// list with the same index (tntblast_local.cpp:877-903); the two agree unless an assay is degenerate.
+			std::set<std::string> query_set, match_set, diff;
+			for (size_t i = 0; i < expanded.size(); i++) {
+				const std::string &name = assays[size_t(expanded[i].parent)].name;
+				query_set.insert(name);
+				if (i < results.size() && !results[i].empty()) match_set.insert(name);
+			}
+			std::set_difference(query_set.begin(), query_set.end(), match_set.begin(), match_set.end(), std::inserter(diff, diff.begin()));
+			for (const std::string &name : diff) *out << name << std::endl;
+			for (auto &r : results) r.clear(); // this format keeps no matches (:701-716)
+		}
+
 		// strand concentrations of the self-structure values, tntblast_local.cpp:228-234,656-686
 		const float fwd_strand = opt.t.asymmetric_strand_ratio * opt.t.primer_strand, rev_strand = opt.t.primer_strand;
 		std::map<std::string, std::pair<float, float>> self_cache; // oligo + role -> (hairpin, homodimer)
@@ -526,91 +626,196 @@ int main(int argc, char **argv)
 			if (tnt_oligo_structure(ctx, f.c_str(), r.c_str(), fwd_strand, rev_strand, &h, &d, &x) != TNT_OK) fail(tnt_last_error(ctx));
 			return dimer_cache[key] = x;
 		};
-		size_t total = 0;
+
+		// statistics of the final summary, tntblast_local.cpp:236-262
+		typedef std::pair<float, float> FRange;
+		typedef std::pair<unsigned int, unsigned int> URange;
+		auto widen = [](FRange &r, float v) { r.first = std::min(r.first, v), r.second = std::max(r.second, v); };
+		auto widen_u = [](URange &r, size_t v) { r.first = std::min(r.first, (unsigned int)v), r.second = std::max(r.second, (unsigned int)v); };
+		FRange forward_tm_range(9999.0f, -1.0f), reverse_tm_range(9999.0f, -1.0f), probe_tm_range(9999.0f, -1.0f);
+		FRange forward_dg_range(9999.0f, -9999.0f), reverse_dg_range(9999.0f, -9999.0f), probe_dg_range(9999.0f, -9999.0f);
+		FRange forward_gc_range(9999.0f, -1.0f), reverse_gc_range(9999.0f, -1.0f), probe_gc_range(9999.0f, -1.0f);
+		URange amplicon_size_range(9999, 0), forward_size_range(9999, 0), reverse_size_range(9999, 0), probe_size_range(9999, 0);
+		float max_primer_hairpin = -1.0f, max_primer_homodimer = -1.0f, max_primer_heterodimer = -1.0f;
+		float max_probe_homodimer = -1.0f, max_probe_hairpin = -1.0f;
+		unsigned int num_primer = 0, num_probe = 0;
+
+		std::set<std::string> total_unique_targets;
+		std::vector<size_t> match_count(results.size(), 0);
 		for (size_t id = 0; id < results.size(); id++) {
-			if (results[id].empty()) continue;
-			*out << "#####################################################################################" << std::endl;
-			for (const Record &rec : results[id]) {
+			std::vector<Record> &list = results[id];
+			if (list.empty()) continue;
+			if (opt.best_match) select_best_match(list);
+			std::stable_sort(list.begin(), list.end(), record_less);
+			if (opt.per_query) { // :933-965
+				const std::string filename = opt.output + "." + assays[id].name;
+				if (opt.format & (Options::STANDARD | Options::FASTA)) {
+					fout.close();
+					fout.open(filename.c_str());
+					if (!fout) fail("Unable to open " + filename);
+				}
+				if (opt.format & Options::NETWORK) {
+					fout_sif.close();
+					fout_sif.open((filename + ".sif").c_str());
+					if (!fout_sif) fail("Unable to open " + filename + ".sif");
+				}
+			}
+			if (standard) *out << "#####################################################################################" << std::endl;
+			std::set<std::string> unique_targets;
+			for (const Record &rec : list) {
 				const tnt_hit &h = rec.h;
 				const Expanded &e = expanded[size_t(h.degen_id)];
-				total++;
-				*out << "name = " << assays[id].name << std::endl;
+				if (standard) *out << "name = " << assays[id].name << std::endl;
 				const std::string &amplicon = rec.amplicon;
 				std::string fp, rp;
 				if (h.has_primers) {
+					num_primer++;
 					const bool pcr = opt.t.assay_format == TNT_ASSAY_PCR;
 					fp = pcr ? "forward primer" : "5' probe";
 					rp = pcr ? "reverse primer" : "3' probe";
 					// single-primer amplicons swap identities (amplicon_search.cpp:453-463)
 					const std::string &fo = h.forward_oligo == 0 ? e.forward : e.reverse;
 					const std::string &ro = h.reverse_oligo == 1 ? e.reverse : e.forward;
-					*out << fp << " = 5' " << fo << " 3'" << std::endl;
-					*out << rp << " = 5' " << ro << " 3'" << std::endl;
 					const float forward_dg = h.forward_dH - opt.t.target_t * h.forward_dS;
 					const float reverse_dg = h.reverse_dH - opt.t.target_t * h.reverse_dS;
 					const std::pair<float, float> fs = self_tm(fo, fwd_strand, 'F'), rs = self_tm(ro, rev_strand, 'R');
-					*out << fp << " tm = " << h.forward_tm << std::endl;
-					*out << rp << " tm = " << h.reverse_tm << std::endl;
-					*out << fp << " hairpin tm = " << fs.first << std::endl;
-					*out << rp << " hairpin tm = " << rs.first << std::endl;
-					*out << fp << " homodimer tm = " << fs.second << std::endl;
-					*out << rp << " homodimer tm = " << rs.second << std::endl;
-					*out << "heterodimer tm = " << hetero_tm(fo, ro) << std::endl;
-					*out << fp << " dG[" << forward_dg << "] = dH[" << h.forward_dH << "] - T*dS[" << h.forward_dS << "]" << std::endl;
-					*out << rp << " dG[" << reverse_dg << "] = dH[" << h.reverse_dH << "] - T*dS[" << h.reverse_dS << "]" << std::endl;
-					*out << fp << " mismatches = " << h.forward_mm << std::endl;
-					*out << rp << " mismatches = " << h.reverse_mm << std::endl;
-					*out << fp << " gaps = " << h.forward_gap << std::endl;
-					*out << rp << " gaps = " << h.reverse_gap << std::endl;
-					if (pcr) {
-						*out << "min 3' clamp = " << std::min(h.forward_primer_clamp, h.reverse_primer_clamp) << std::endl;
-						*out << "max 3' clamp = " << std::max(h.forward_primer_clamp, h.reverse_primer_clamp) << std::endl;
-					} else {
-						*out << "5' probe 3' ligation clamp = " << h.forward_primer_clamp << std::endl;
-						*out << "3' probe 5' ligation clamp = " << h.reverse_primer_clamp << std::endl;
+					const float hetero = hetero_tm(fo, ro);
+					const float fgc = 100.0f * gc_content(fo), rgc = 100.0f * gc_content(ro);
+					max_primer_hairpin = std::max(max_primer_hairpin, std::max(fs.first, rs.first));
+					max_primer_homodimer = std::max(max_primer_homodimer, std::max(fs.second, rs.second));
+					max_primer_heterodimer = std::max(max_primer_heterodimer, hetero);
+					widen_u(forward_size_range, fo.size()), widen_u(reverse_size_range, ro.size());
+					widen(forward_tm_range, h.forward_tm), widen(forward_dg_range, forward_dg);
+					widen(reverse_tm_range, h.reverse_tm), widen(reverse_dg_range, reverse_dg);
+					widen(forward_gc_range, fgc), widen(reverse_gc_range, rgc);
+					widen_u(amplicon_size_range, amplicon.size());
+					if (standard) {
+						*out << fp << " = 5' " << fo << " 3'" << std::endl;
+						*out << rp << " = 5' " << ro << " 3'" << std::endl;
+						*out << fp << " tm = " << h.forward_tm << std::endl;
+						*out << rp << " tm = " << h.reverse_tm << std::endl;
+						*out << fp << " hairpin tm = " << fs.first << std::endl;
+						*out << rp << " hairpin tm = " << rs.first << std::endl;
+						*out << fp << " homodimer tm = " << fs.second << std::endl;
+						*out << rp << " homodimer tm = " << rs.second << std::endl;
+						*out << "heterodimer tm = " << hetero << std::endl;
+						*out << fp << " dG[" << forward_dg << "] = dH[" << h.forward_dH << "] - T*dS[" << h.forward_dS << "]" << std::endl;
+						*out << rp << " dG[" << reverse_dg << "] = dH[" << h.reverse_dH << "] - T*dS[" << h.reverse_dS << "]" << std::endl;
+						*out << fp << " mismatches = " << h.forward_mm << std::endl;
+						*out << rp << " mismatches = " << h.reverse_mm << std::endl;
+						*out << fp << " gaps = " << h.forward_gap << std::endl;
+						*out << rp << " gaps = " << h.reverse_gap << std::endl;
+						if (pcr) {
+							*out << "min 3' clamp = " << std::min(h.forward_primer_clamp, h.reverse_primer_clamp) << std::endl;
+							*out << "max 3' clamp = " << std::max(h.forward_primer_clamp, h.reverse_primer_clamp) << std::endl;
+						} else {
+							*out << "5' probe 3' ligation clamp = " << h.forward_primer_clamp << std::endl;
+							*out << "3' probe 5' ligation clamp = " << h.reverse_primer_clamp << std::endl;
+						}
+						*out << fp << " %GC = " << fgc << std::endl;
+						*out << rp << " %GC = " << rgc << std::endl;
+						*out << fp << " heuristics = " << primer_heuristics(fo) << std::endl;
+						*out << rp << " heuristics = " << primer_heuristics(ro) << std::endl;
+						if (pcr) {
+							*out << "amplicon range = " << h.amplicon_start << " .. " << h.amplicon_stop << std::endl;
+							*out << "amplicon length = " << amplicon.size() << std::endl;
+						} else {
+							*out << "product range = " << h.amplicon_start << " .. " << h.amplicon_stop << std::endl;
+							*out << "product length = " << amplicon.size() << std::endl;
+						}
+						if (h.primer_strand == TNT_PLUS) *out << "Forward primer is contained in the target plus strand (+)" << std::endl;
+						else *out << "Forward primer is contained in the target minus strand (-)" << std::endl;
 					}
-					*out << fp << " %GC = " << 100.0f * gc_content(fo) << std::endl;
-					*out << rp << " %GC = " << 100.0f * gc_content(ro) << std::endl;
-					*out << fp << " heuristics = " << primer_heuristics(fo) << std::endl;
-					*out << rp << " heuristics = " << primer_heuristics(ro) << std::endl;
-					if (pcr) {
-						*out << "amplicon range = " << h.amplicon_start << " .. " << h.amplicon_stop << std::endl;
-						*out << "amplicon length = " << amplicon.size() << std::endl;
-					} else {
-						*out << "product range = " << h.amplicon_start << " .. " << h.amplicon_stop << std::endl;
-						*out << "product length = " << amplicon.size() << std::endl;
-					}
-					if (h.primer_strand == TNT_PLUS) *out << "Forward primer is contained in the target plus strand (+)" << std::endl;
-					else *out << "Forward primer is contained in the target minus strand (-)" << std::endl;
 				}
 				if (h.has_probe) {
+					num_probe++;
 					const float probe_dg = h.probe_dH - opt.t.target_t * h.probe_dS;
 					const std::pair<float, float> ps = self_tm(e.probe, opt.t.probe_strand, 'P');
-					*out << "probe = 5' " << e.probe << " 3'" << std::endl;
-					*out << "probe tm = " << h.probe_tm << std::endl;
-					*out << "probe hairpin tm = " << ps.first << std::endl;
-					*out << "probe homodimer tm = " << ps.second << std::endl;
-					*out << "probe dG[" << probe_dg << "] = dH[" << h.probe_dH << "] - T*dS[" << h.probe_dS << "]" << std::endl;
-					*out << "probe mismatches = " << h.probe_mm << std::endl;
-					*out << "probe gaps = " << h.probe_gap << std::endl;
-					*out << "probe %GC = " << 100.0f * gc_content(e.probe) << std::endl;
-					*out << "probe range = " << h.probe_start << " .. " << h.probe_stop << std::endl;
-					if (h.probe_strand != h.primer_strand) *out << "probe contained in forward strand (+)" << std::endl;
-					else *out << "probe contained in reverse strand (-)" << std::endl;
+					const float pgc = 100.0f * gc_content(e.probe);
+					widen(probe_gc_range, pgc), widen(probe_tm_range, h.probe_tm), widen(probe_dg_range, probe_dg);
+					widen_u(probe_size_range, e.probe.size());
+					max_probe_hairpin = std::max(max_probe_hairpin, ps.first);
+					max_probe_homodimer = std::max(max_probe_homodimer, ps.second);
+					if (standard) {
+						*out << "probe = 5' " << e.probe << " 3'" << std::endl;
+						*out << "probe tm = " << h.probe_tm << std::endl;
+						*out << "probe hairpin tm = " << ps.first << std::endl;
+						*out << "probe homodimer tm = " << ps.second << std::endl;
+						*out << "probe dG[" << probe_dg << "] = dH[" << h.probe_dH << "] - T*dS[" << h.probe_dS << "]" << std::endl;
+						*out << "probe mismatches = " << h.probe_mm << std::endl;
+						*out << "probe gaps = " << h.probe_gap << std::endl;
+						*out << "probe %GC = " << pgc << std::endl;
+						*out << "probe range = " << h.probe_start << " .. " << h.probe_stop << std::endl;
+						if (h.probe_strand != h.primer_strand) *out << "probe contained in forward strand (+)" << std::endl;
+						else *out << "probe contained in reverse strand (-)" << std::endl;
+					}
 				}
-				if (opt.show_alignments) {
+				if (standard && opt.show_alignments) {
 					write_alignment(*out, fp + " align ", h.forward_align);
 					write_alignment(*out, rp + " align ", h.reverse_align);
 					write_alignment(*out, "probe align ", h.probe_align);
 				}
-				*out << '>' << rec.defline;
-				if (opt.append_name) *out << ' ' << assays[id].name;
-				*out << std::endl;
-				if (opt.show_sequence) *out << amplicon << std::endl;
-				*out << std::endl;
+				if (opt.format & (Options::STANDARD | Options::FASTA)) {
+					*out << '>' << rec.defline;
+					if (opt.append_name) *out << ' ' << assays[id].name;
+					*out << std::endl;
+					if (opt.show_sequence) *out << amplicon << std::endl;
+				}
+				if (standard) *out << std::endl;
+				if (opt.format & Options::NETWORK) fout_sif << mask_white_space(assays[id].name) << " binds " << mask_white_space(rec.defline) << std::endl;
+				unique_targets.insert(rec.defline);
+				total_unique_targets.insert(rec.defline);
+			}
+			match_count[id] = unique_targets.size();
+		}
+		if (opt.format & Options::NETWORK) { // :1282-1294
+			for (const Expanded &e : expanded) fout_atr << mask_white_space(assays[size_t(e.parent)].name) << " = parent" << std::endl;
+			for (const std::string &t : total_unique_targets) fout_atr << mask_white_space(t) << " = child" << std::endl;
+		}
+		if (opt.format & Options::INVERSE_TARGET) { // write_inverse_matches, tntblast_util.cpp:1244-1272
+			unsigned int count = 0;
+			for (const std::string &d : all_deflines)
+				if (total_unique_targets.find(d) == total_unique_targets.end()) {
+					*out << d << std::endl;
+					count++;
+				}
+			if (opt.verbose) std::cout << "Wrote " << count << " inverse target matches (that did not match any query!)" << std::endl;
+		}
+		const bool inverse_query = (opt.format & Options::INVERSE_QUERY) != 0;
+		if (opt.verbose && !inverse_query) std::cout << "Found " << total_unique_targets.size() << " (total) target sequence matches" << std::endl;
+		if (opt.verbose && num_primer > 0 && !inverse_query) { // :1312-1333
+			std::cout << "Amplicon:" << std::endl << "\t" << amplicon_size_range.first << " <= Amplicon length <= " << amplicon_size_range.second << std::endl;
+			std::cout << "Forward primer:" << std::endl
+			          << "\t" << forward_tm_range.first << " <= Tm (C) <= " << forward_tm_range.second << std::endl
+			          << "\t" << forward_dg_range.first << " <= Delta G (Kcal/Mol) <= " << forward_dg_range.second << std::endl
+			          << "\t" << forward_gc_range.first << " <= %GC <= " << forward_gc_range.second << std::endl
+			          << "\t" << forward_size_range.first << " <= length <= " << forward_size_range.second << std::endl;
+			std::cout << "Reverse primer:" << std::endl
+			          << "\t" << reverse_tm_range.first << " <= Tm (C) <= " << reverse_tm_range.second << std::endl
+			          << "\t" << reverse_dg_range.first << " <= Delta G (Kcal/Mol) <= " << reverse_dg_range.second << std::endl
+			          << "\t" << reverse_gc_range.first << " <= %GC <= " << reverse_gc_range.second << std::endl
+			          << "\t" << reverse_size_range.first << " <= length <= " << reverse_size_range.second << std::endl;
+			std::cout << "Max primer hairpin Tm = " << max_primer_hairpin << std::endl;
+			std::cout << "Max primer heterodimer Tm = " << max_primer_heterodimer << std::endl;
+			std::cout << "Max primer homodimer Tm = " << max_primer_homodimer << std::endl;
+		}
+		if (opt.verbose && num_probe > 0 && !inverse_query) { // :1335-1345
+			std::cout << "Probe:" << std::endl
+			          << "\t" << probe_tm_range.first << " <= Tm (C) <= " << probe_tm_range.second << std::endl
+			          << "\t" << probe_dg_range.first << " <= Delta G (Kcal/Mol) <= " << probe_dg_range.second << std::endl
+			          << "\t" << probe_gc_range.first << " <= %GC <= " << probe_gc_range.second << std::endl
+			          << "\t" << probe_size_range.first << " <= length <= " << probe_size_range.second << std::endl;
+			std::cout << "Max probe hairpin Tm = " << max_probe_hairpin << std::endl;
+			std::cout << "Max probe homodimer Tm = " << max_probe_homodimer << std::endl;
+		}
+		if (opt.summary && !inverse_query) { // :1347-1366, one entry per expanded assay
+			std::cout << "*** Assay Summary ***" << std::endl;
+			for (const Expanded &e : expanded) {
+				std::cout << assays[size_t(e.parent)].name << " matched " << match_count[size_t(e.parent)] << " sequences" << std::endl;
+				if (!e.forward.empty() && !e.reverse.empty()) std::cout << "\tF::R = " << e.forward << " :: " << e.reverse << std::endl;
+				if (!e.probe.empty()) std::cout << "\tP = " << e.probe << std::endl;
 			}
 		}
-		if (opt.verbose) std::cout << "Found " << total << " (total) target sequence matches" << std::endl;
 		tnt_ctx_destroy(ctx);
 		return EXIT_SUCCESS;
 	} catch (const Fail &f) {
