@@ -30,7 +30,7 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("fasta_m1", 3, 300, 24, 10, ["-e", "40", "-E", "40", "-m", "1", "-L", "T"]),
     ("network_m2", 2, 300, 24, 11, ["-e", "40", "-m", "2"]),
     ("inverse_target_m3", 2, 300, 24, 12, ["-e", "40", "-m", "3"]),
-    ("inverse_query_m4", 2, 300, 24, 13, ["-e", "40", "-m", "4"]),
+    ("inverse_query_m4", 2, 300, 24, 13, ["-e", "58", "-m", "4"]),
     ("per_query_n", 3, 300, 12, 14, ["-e", "40", "-E", "40", "-n", "T"]),
     ("best_match", 2, 300, 24, 15, ["-e", "30", "--best-match", "-S", "T"]),
     ("summary_degenerate", 4, 120, 20, 16, ["-e", "40", "-S", "T"]),

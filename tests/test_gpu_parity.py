@@ -290,6 +290,9 @@ def test_cli_output_golden(Engine, tmp_path):
         assert sorted(got) == sorted(case["files"]), case["name"]
         for suffix, text in case["files"].items():
             assert got[suffix] == text, (case["name"], suffix)
+        import os
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
         import cli_compare
         assert cli_compare.closing_lines(r.stdout) == case["closing"], case["name"]
 
