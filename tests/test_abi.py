@@ -69,7 +69,9 @@ def test_cli_front_end_builds_and_validates_arguments(hip_lib):
     assert os.path.exists(g.CLI)
     r = subprocess.run([g.CLI], capture_output=True, text=True)
     assert r.returncode != 0 and "tntblast-mi355x" in r.stderr
-    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-m", "1"], capture_output=True, text=True)
-    assert r.returncode != 0 and "-m 0" in r.stderr
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-m", "7"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unknown output format" in r.stderr
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-k", "T"], capture_output=True, text=True)
+    assert r.returncode != 0 and "not supported" in r.stderr
     r = subprocess.run([g.CLI, "-i", "x"], capture_output=True, text=True)
     assert r.returncode != 0 and "dbase" in r.stderr
