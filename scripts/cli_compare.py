@@ -34,6 +34,10 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("per_query_n", 3, 300, 12, 14, ["-e", "40", "-E", "40", "-n", "T"]),
     ("best_match", 2, 300, 24, 15, ["-e", "30", "--best-match", "-S", "T"]),
     ("summary_degenerate", 4, 120, 20, 16, ["-e", "40", "-S", "T"]),
+    # assay front end: every primer / probe combination of the input assays; primer pairs turned into single probes
+    ("plex", 3, 150, 5, 17, ["-e", "40", "-E", "40", "--plex", "T", "-S", "T"]),
+    ("plex_padlock", 5, 150, 6, 18, ["-A", "PADLOCK", "-E", "40", "--plex", "T"]),
+    ("force_probe", 3, 150, 8, 19, ["-A", "PROBE", "-E", "45"]),
 ]
 
 

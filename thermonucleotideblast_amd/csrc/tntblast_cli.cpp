@@ -61,11 +61,28 @@ struct Options {
 	bool per_query = false;  // -n: one output file per query
 	bool summary = false;    // -S: assay summary on stdout
 	bool best_match = false; // --best-match
+	bool multiplex = false;  // --plex
+	bool dump_query = false; // --dump-query
 };
 
+constexpr size_t INVALID_INDEX = ~size_t(0); // hybrid_sig.h:25
 struct Assay { // one line of the assay file
 	std::string name, forward, reverse, probe;
 	int id;
+	// position of the oligo strings in the reference's string table (first use, hybrid_sig.h:555-570): --plex sorts on them
+	size_t fi = INVALID_INDEX, ri = INVALID_INDEX, pi = INVALID_INDEX;
+};
+
+struct StringTable { // str_to_index
+	std::map<std::string, size_t> idx;
+	size_t operator()(const std::string &s)
+	{
+		auto it = idx.find(s);
+		if (it != idx.end()) return it->second;
+		const size_t v = idx.size();
+		idx[s] = v;
+		return v;
+	}
 };
 
 struct Expanded { // one non-degenerate assay
@@ -130,7 +147,10 @@ int degeneracy(const std::string &oligo) // degenerate_na.cpp:175-215
 	return d;
 }
 
-std::vector<Assay> read_input_file(const std::string &path, bool ignore_probe) // input.cpp:43-168
+// input.cpp:43-168.  `force_probe` (-A PROBE): primer pairs become single probes named <name>_F / _R / _P.  The string
+// indices follow the reference as built by g++, which evaluates the constructor arguments right to left: probe,
+// reverse, forward, name.
+std::vector<Assay> read_input_file(const std::string &path, bool ignore_probe, bool force_probe, StringTable &st)
 {
 	std::ifstream fin(path.c_str());
 	if (!fin) {
@@ -138,6 +158,14 @@ std::vector<Assay> read_input_file(const std::string &path, bool ignore_probe) /
 		fail("read_input_file: I/O Error");
 	}
 	std::vector<Assay> out;
+	auto probe_only = [&](const std::string &name, const std::string &oligo) {
+		Assay a;
+		a.id = int(out.size());
+		a.probe = oligo, a.pi = st(oligo);
+		a.name = name;
+		(void)st(name);
+		out.push_back(a);
+	};
 	std::string line;
 	while (std::getline(fin, line)) {
 		const std::string::size_type pos = line.find('#');
@@ -147,26 +175,117 @@ std::vector<Assay> read_input_file(const std::string &path, bool ignore_probe) /
 		std::string entry;
 		while (ss >> entry) col.push_back(entry);
 		if (col.empty()) continue;
-		Assay a;
-		a.id = int(out.size());
-		a.name = col[0];
 		switch (col.size()) {
 		case 2:
 			if (ignore_probe) fail("ignore_probe is true but only probes have been provided!");
-			a.probe = col[1];
+			probe_only(col[0], col[1]);
 			break;
 		case 3:
-			a.forward = col[1], a.reverse = col[2];
+		case 4: {
+			const bool with_probe = col.size() == 4 && !ignore_probe;
+			if (force_probe) {
+				probe_only(col[0] + "_F", col[1]);
+				probe_only(col[0] + "_R", col[2]);
+				if (with_probe) probe_only(col[0] + "_P", col[3]);
+				break;
+			}
+			Assay a;
+			a.id = int(out.size());
+			if (with_probe) a.probe = col[3], a.pi = st(col[3]);
+			a.reverse = col[2], a.ri = st(col[2]);
+			a.forward = col[1], a.fi = st(col[1]);
+			a.name = col[0];
+			(void)st(col[0]);
+			out.push_back(a);
 			break;
-		case 4:
-			a.forward = col[1], a.reverse = col[2];
-			if (!ignore_probe) a.probe = col[3];
-			break;
+		}
 		default: std::cerr << "Error reading " << path << std::endl; fail("Error: Invalid number of arguments input file");
 		}
-		out.push_back(a);
 	}
 	return out;
+}
+
+// multiplex_expansion, tntblast_util.cpp:715-915 (--plex T): every combination of the primers (and probes) of the input
+// assays.  Redundant combinations are removed with std::sort + std::unique on the string-table indices, exactly as the
+// reference does: std::sort is not stable, so which of several equal assays survives (its name) is whatever libstdc++'s
+// introsort leaves first -- the same here, because the same algorithm sees the same sequence and comparisons.
+std::vector<Assay> multiplex_expansion(const std::vector<Assay> &sig, int assay_format, StringTable &st)
+{
+	std::vector<Assay> ret;
+	auto make = [&](const std::string &name, const Assay &f_from, bool f_is_forward, const Assay &r_from, bool r_is_forward) {
+		Assay a;
+		a.name = name;
+		(void)st(name);
+		a.forward = f_is_forward ? f_from.forward : f_from.reverse, a.fi = f_is_forward ? f_from.fi : f_from.ri;
+		a.reverse = r_is_forward ? r_from.forward : r_from.reverse, a.ri = r_is_forward ? r_from.fi : r_from.ri;
+		a.id = 0;
+		return a;
+	};
+	if (assay_format == TNT_ASSAY_PADLOCK || assay_format == TNT_ASSAY_MIPS) {
+		for (const Assay &i : sig)
+			for (const Assay &j : sig) ret.push_back(make(&i == &j ? i.name : i.name + "(5')/" + j.name + "(3')", i, true, j, false));
+	}
+	if (assay_format == TNT_ASSAY_PCR) {
+		bool has_probes = false;
+		for (const Assay &i : sig) {
+			if (i.fi == INVALID_INDEX) continue; // a probe-only assay is dropped (:765-769 builds it and moves on)
+			if (i.pi != INVALID_INDEX) has_probes = true;
+			for (const Assay &j : sig) {
+				if (i.fi == j.ri) continue;
+				ret.push_back(make(i.name + "(F)/" + j.name + "(R)", i, true, j, false));
+			}
+		}
+		for (const Assay &i : sig) {
+			if (i.fi == INVALID_INDEX) continue;
+			for (const Assay &j : sig) {
+				if (i.fi == j.fi) continue;
+				ret.push_back(make(i.name + "(F)/" + j.name + "(F)", i, true, j, true));
+			}
+		}
+		for (const Assay &i : sig) {
+			if (i.fi == INVALID_INDEX) continue;
+			for (const Assay &j : sig) {
+				if (i.ri == j.ri) continue;
+				ret.push_back(make(i.name + "(R)/" + j.name + "(R)", i, false, j, false));
+			}
+		}
+		if (has_probes) {
+			std::vector<Assay> with_probe;
+			for (const Assay &i : ret)
+				for (const Assay &j : sig) {
+					if (j.pi == INVALID_INDEX) continue;
+					Assay a = i;
+					a.name = i.name + "+" + j.name + "(P)";
+					(void)st(a.name);
+					a.probe = j.probe, a.pi = j.pi;
+					with_probe.push_back(a);
+				}
+			ret.swap(with_probe);
+		}
+	}
+	if (assay_format == TNT_ASSAY_PROBE) return sig;
+	auto ordered = [](const Assay &a, size_t &F, size_t &R) {
+		F = a.fi, R = a.ri;
+		if (F < R) std::swap(F, R);
+	};
+	std::sort(ret.begin(), ret.end(), [&](const Assay &a, const Assay &b) { // sort_by_seq, tntblast_util.cpp:31-62
+		size_t Fa, Ra, Fb, Rb;
+		ordered(a, Fa, Ra), ordered(b, Fb, Rb);
+		if (Fa == Fb) {
+			if (Ra == Rb) return a.pi < b.pi;
+			return Ra < Rb;
+		}
+		return Fa < Fb;
+	});
+	ret.erase(std::unique(ret.begin(), ret.end(), [&](const Assay &a, const Assay &b) { // compare_by_seq, :64-91
+		size_t Fa, Ra, Fb, Rb;
+		ordered(a, Fa, Ra), ordered(b, Fb, Rb);
+		return Fa == Fb && Ra == Rb && a.pi == b.pi;
+	}), ret.end());
+	int id = 0;
+	for (Assay &a : ret) a.id = id++;
+	std::cerr << "Multiplexing has created " << ret.size() << " assays from " << sig.size() << " input assays" << std::endl;
+	return ret;
 }
 
 std::vector<Expanded> expand_assays(const std::vector<Assay> &assays, bool rescale_ct) // tntblast_util.cpp:579-713
@@ -326,7 +445,7 @@ void usage()
 {
 	std::cerr << "tntblast-mi355x: the tntblast search on an MI355X (FASTA databases)\n"
 	             "\t-i <assay file> -d <FASTA database, plain or gzip> [-o <output file>] -e <min primer Tm> -E <min probe Tm>\n"
-	             "\t[-x -X -z -Z -g -G -s -t -T -y -l -A <PCR|PROBE|PADLOCK|MIPS> -W -a -M -L -p -v -m <0..4> -n -S --best-match]\n"
+	             "\t[-x -X -z -Z -g -G -s -t -T -y -l -A <PCR|PROBE|PADLOCK|MIPS> -W -a -M -L -p -v -m <0..4> -n -S --best-match --plex --dump-query]\n"
 	             "\t[--primer-clamp --min-max-primer-clamp --probe-clamp5 --probe-clamp3 --single-primer-pcr --target-strand\n"
 	             "\t --temperature --dangle5 --dangle3 --max-gap --max-mismatch --max-poly-degen --rescale-ct --hash-size]"
 	          << std::endl;
@@ -374,6 +493,7 @@ void parse_args(int argc, char **argv, Options &o)
 			case 3: o.t.primer_clamp = atoi(optarg); break;
 			case 4: o.t.probe_clamp_5 = atoi(optarg); break;
 			case 5: o.t.probe_clamp_3 = atoi(optarg); break;
+			case 6: o.multiplex = parse_bool(optarg); break;
 			case 7: o.t.single_primer_pcr = parse_bool(optarg) ? 1 : 0; break;
 			case 8: o.t.hash_word_size = atoi(optarg); break;
 			case 9: {
@@ -386,6 +506,7 @@ void parse_args(int argc, char **argv, Options &o)
 				break;
 			}
 			case 10: o.t.target_t = float(atof(optarg)); break;
+			case 13: o.dump_query = parse_bool(optarg); break;
 			case 14: o.t.allow_dangle_5 = parse_bool(optarg) ? 1 : 0; break;
 			case 15: o.t.allow_dangle_3 = parse_bool(optarg) ? 1 : 0; break;
 			case 16: o.t.min_max_primer_clamp = atoi(optarg); break;
@@ -498,10 +619,19 @@ int main(int argc, char **argv)
 	try {
 		Options opt;
 		parse_args(argc, argv, opt);
-		std::vector<Assay> assays = read_input_file(opt.input, opt.ignore_probe);
+		StringTable st;
+		std::vector<Assay> assays = read_input_file(opt.input, opt.ignore_probe, opt.t.assay_format == TNT_ASSAY_PROBE, st);
+		if (opt.multiplex) assays = multiplex_expansion(assays, opt.t.assay_format, st); // tntblast_local.cpp:137-146
+		const std::vector<Expanded> expanded = expand_assays(assays, opt.rescale_ct);
+		if (opt.dump_query) // Options::write_queries, options.cpp:918-941: the expanded list
+			for (const Expanded &e : expanded) {
+				std::cout << assays[size_t(e.parent)].name;
+				if (!e.forward.empty() && !e.reverse.empty()) std::cout << '\t' << e.forward << '\t' << e.reverse;
+				if (!e.probe.empty()) std::cout << '\t' << e.probe;
+				std::cout << std::endl;
+			}
 		if (assays.empty()) fail("No assays found in the input file");
 		validate_search_threshold(opt, assays);
-		const std::vector<Expanded> expanded = expand_assays(assays, opt.rescale_ct);
 
 		std::vector<tnt_assay> ta(expanded.size());
 		for (size_t i = 0; i < expanded.size(); i++) {
