@@ -144,10 +144,20 @@ def main():
         alg_bytes = ALG_BYTES_PER_BASE * wl.n_bases
         achieved = alg_bytes / (bind_ms_step * 1e-3) / 1e9 if bind_ms_step > 0 else 0.0
         traffic = None
+        valu = None
         pmc = os.path.join(ROOT, "profiles", "bind_pmc.json")
         if os.path.exists(pmc) and args.config == 2 and n_targets == full:  # measured for this workload only
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_step")
+                rec = json.load(open(pmc))
+                traffic = rec.get("hbm_bytes_per_step")
+                # What actually bounds the kernel: VALU issue.  Wave-instructions per step from the same
+                # PMC file over this run's bind time, against 1 024 SIMDs x the sustained shader clock / the mean issue
+                # cost of the fill's instruction mix (scripts/microbench/valu_rate.hip: 2.25 / 4.3 cycles by class).
+                n_valu = rec.get("SQ_INSTS_VALU_per_step")
+                if n_valu and bind_ms_step > 0:
+                    peak = 1024 * 1.97e9 / 3.15
+                    ach = n_valu / (bind_ms_step * 1e-3)
+                    valu = {"achieved": ach, "peak": peak, "unit": "VALU wave-instructions/s", "frac": ach / peak}
             except Exception:
                 traffic = None
         line = {
@@ -168,7 +178,8 @@ def main():
                          "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once); the bind "
                                  "stage is bound by integer VALU issue, not by HBM (DESIGN.md 4.2); traffic = PMC "
                                  "2*FETCH_SIZE + WRITE_SIZE per step of the full-size config (profiles/bind_pmc.json)",
-                         "dp_per_s": n_binds * world / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0},
+                         "dp_per_s": n_binds * world / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0,
+                         "valu_issue": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
