@@ -393,10 +393,10 @@ __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const Ali
 // PLAIN: no window of the launch holds a degenerate (IUPAC) target base (the bucket kernel routes windows that
 // do to a general instance), so rt(t, q) = t and the table address splits into column and row constants.
 template <int LMAX, bool FULL, bool EXACT = false, bool PLAIN = false>
-__global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 256 ? 1 : (LMAX <= 40 ? 2 : 1))) void bind_kernel(BindArgs a)
+__global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LMAX, PLAIN) > 256 ? 1 : (LMAX <= 40 ? 2 : 1))) void bind_kernel(BindArgs a)
 {
 	static_assert(!(FULL && (EXACT || PLAIN)), "the unit-level instance takes any length and any target base");
-	constexpr int BIND_THREADS = bind_threads_for(LMAX);
+	constexpr int BIND_THREADS = bind_threads_for(LMAX, PLAIN);
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NCOLS = LMAX + WMAX + 4;
 
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX), (bind_threads_for(LMAX) > 2
 	constexpr bool QRY_LDS = LMAX <= 32;             // larger instances keep the LDS budget for two workgroups per CU
 	__shared__ uint8_t s_qry[QRY_LDS ? LMAX * BIND_THREADS : 1]; // oligo bases of every lane, row order (row i-1 = query[L-i])
 	__shared__ uint8_t s_cols[NCOLS * BIND_THREADS]; // alignment columns of the path being scored
-	constexpr bool BEST_LDS = LMAX <= 28;             // columns of the best path so far: LDS while two workgroups per CU still fit
+	constexpr bool BEST_LDS = BIND_THREADS > 256 ? LMAX <= 22 : LMAX <= 28;             // columns of the best path so far: LDS while two workgroups per CU still fit
 	__shared__ uint8_t s_best[BEST_LDS ? NCOLS * BIND_THREADS : 1];
 	__shared__ uint8_t s_hs_map[NBP * NBP + 3];
 	__shared__ float2 s_hs_val[256];

@@ -14,7 +14,7 @@ namespace tnt {
 #define TNT_LAUNCHER(NAME, N, EXACT, PLAIN)                                                                          \
 	void NAME(const BindArgs &a, int blocks, hipStream_t stream)                                                     \
 	{                                                                                                                \
-		hipLaunchKernelGGL((bind_kernel<N, false, EXACT, PLAIN>), dim3(blocks), dim3(bind_threads_for(N)), 0, stream, a); \
+		hipLaunchKernelGGL((bind_kernel<N, false, EXACT, PLAIN>), dim3(blocks), dim3(bind_threads_for(N, PLAIN)), 0, stream, a); \
 	}
 #define G(N) TNT_LAUNCHER(launch_bind_##N, N, false, false)
 #define P(N) TNT_LAUNCHER(launch_bind_plain_##N, N, false, true)

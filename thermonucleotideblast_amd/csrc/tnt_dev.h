@@ -98,8 +98,11 @@ constexpr int BUCKET_EXACT = 0x100, BUCKET_PLAIN = 0x200; // flags on the instan
 // wavefronts per SIMD, the third one fills the issue slots the other two leave while they wait in their serial
 // tails (+4 % on those buckets).  Longer oligos need the registers of a two-wave budget (two 256-thread workgroups
 // per CU); forcing them into 168 VGPRs spills and was measured slower.
-constexpr int bind_threads_for(int lmax) { return lmax <= 22 ? 768 : 256; }
-constexpr int bind_blocks_per_cu(int lmax) { return lmax <= 22 ? 2 : 4; } // persistent grid: 2x the resident workgroups
+// Workgroup shape of a bind instance: 768 threads (three wavefronts per SIMD, one workgroup per CU) where the fill fits
+// 168 VGPRs without spilling -- up to 22 rows for any instance, up to 28 for the plain ones -- else 256 threads.
+constexpr bool bind_wide(int lmax, bool plain) { return lmax <= 22 || (plain && lmax <= 28); }
+constexpr int bind_threads_for(int lmax, bool plain) { return bind_wide(lmax, plain) ? 768 : 256; }
+constexpr int bind_blocks_per_cu(int lmax, bool plain) { return bind_wide(lmax, plain) ? 2 : 4; } // persistent grid: 2x the resident workgroups
 constexpr int BUCKET_STRIDE = 32; // words between two bucket counters (one 128-byte line each)
 
 // bind work item (one seed that survived the first cull)

@@ -461,7 +461,9 @@ int pick_lmax(size_t max_len)
 }
 
 // persistent grid of one bind kernel instance
-int bind_grid(const tnt_ctx *c, int lmax) { return c->n_cu * bind_blocks_per_cu(lmax & 0xFF); }
+// `id` = rows | BUCKET_* flags of an instance (0: the unit-level instance)
+int bind_threads(int id) { return bind_threads_for(id ? (id & 0xFF) : 64, (id & BUCKET_PLAIN) != 0); }
+int bind_grid(const tnt_ctx *c, int id) { return c->n_cu * bind_blocks_per_cu(id & 0xFF, (id & BUCKET_PLAIN) != 0); }
 
 // instance id for plain windows of oligos of length L: the exact instance where there is one, else the ladder
 int pick_instance(size_t L)
@@ -476,7 +478,7 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 {
 	if (!stream) stream = c->stream;
 	if (lmax == 0) { // unit-level API: one instance is enough
-		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads_for(64)), 0, stream, a);
+		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
 		return;
 	}
 	switch (lmax) {
@@ -514,7 +516,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 	k.cap = uint32_t(ITEM_CAP);
 	k.counters = cnt + C_BUCKET;
 	k.n_buckets = int(c->bucket_lmax.size());
-	k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads_for(c->bucket_lmax.back() & 0xFF));
+	k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads(c->bucket_lmax.back()));
 	k.err = cnt + C_ERR;
 	hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 	hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
@@ -557,7 +559,7 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 	size_t n_trace = 0, n_cols = 0, n_ties = 0;
 	for (int id : inst) {
 		const int l = id & 0xFF;
-		const size_t lanes = size_t(bind_grid(c, l)) * bind_threads_for(l);
+		const size_t lanes = size_t(bind_grid(c, id)) * size_t(bind_threads(id));
 		const size_t lm = size_t(l), wm = lm + 2 * FLANK, nc = lm + wm + 4;
 		n_trace = std::max(n_trace, lanes * lm * wm);
 		n_cols = std::max(n_cols, lanes * nc);
@@ -1881,7 +1883,7 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	b.n_items = uint32_t(n);
 	b.n_items_dev = nullptr;
 	b.full = dfull.p;
-	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + bind_threads_for(64) - 1) / bind_threads_for(64))), 0);
+	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + size_t(bind_threads(0)) - 1) / size_t(bind_threads(0)))), 0);
 	HIP_TRY(hipGetLastError(), ctx->err);
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
