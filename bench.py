@@ -104,11 +104,12 @@ def main():
         torch.cuda.synchronize()
 
     def gather_hits(hits):
-        """hit lists -> every rank over RCCL (shard.gather_hits: all_gather of counts, then of the padded records;
-        the same code runs on gloo in tests/test_distributed_cpu.py)."""
+        """hit lists -> rank 0 over RCCL (shard.gather_hits: all_gather of the counts, one gather of the padded records
+        taken from device memory, page-locked receive buffer on rank 0; the same code runs on gloo in
+        tests/test_distributed_cpu.py)."""
         if world == 1:
             return len(hits)
-        allhits, counts = shard.gather_hits(hits, device="cuda")
+        allhits, counts = shard.gather_hits(hits, device="cuda", device_hits=eng.hits_device())
         return int(sum(counts))
 
     def step():

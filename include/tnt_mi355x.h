@@ -218,6 +218,12 @@ int tnt_search(tnt_ctx *ctx, tnt_db *db, const tnt_hit **hits, size_t *n_hits);
 int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db);
 int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits);
 
+/* The hits of the last collected search where the pair kernel left them, in device memory (same records, same order as
+ * the host copy): what a multi-GPU driver hands to RCCL without a round trip through the host (the reference's master
+ * receives packed hit lists from its MPI workers, tntblast_master.cpp:811-828).  Valid until the next search on this
+ * context.  TNT_E_UNSUPPORTED when the host copy was post-processed (duplicate removal for windowed long targets). */
+int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hits);
+
 /* per-stage device timings of the last search, in ms (HIP events on the context stream) */
 typedef struct tnt_timing {
 	float seed_ms, bind_ms, pair_ms, total_ms;

@@ -471,3 +471,40 @@ def test_torch_coexists_with_the_library(Engine):
     assert y == 8192 and n1 == len(e.search(db))
     db.close()
     e.close()
+
+
+def test_hits_device_view_matches_host_copy(Engine):
+    """tnt_search_hits_device: the records the multi-GPU gather takes from device memory are the host records."""
+    import torch
+    from thermonucleotideblast_amd import shard
+    wl = synth.make_workload(3, n_targets=400, n_assays=24, seed=31)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    e.enqueue(db)
+    hits = e.collect(copy=False)
+    assert len(hits) > 10
+    dev = e.hits_device()
+    assert dev is not None and dev[1] == len(hits)
+    nbytes = len(hits) * C.sizeof(abi.tnt_hit)
+    t = torch.as_tensor(shard._DeviceBytes(dev[0], nbytes), device="cuda")
+    assert t.is_cuda and t.numel() == nbytes
+    assert bytes(t.cpu().numpy().tobytes()) == bytes(np.frombuffer(hits, dtype=np.uint8).tobytes())
+    # single process: gather_hits is the identity
+    same, counts = shard.gather_hits(hits, device="cuda", device_hits=dev)
+    assert counts == [len(hits)] and same is hits
+    # the collective path itself (RCCL, one rank): device records -> gather -> page-locked buffer on the root
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for use_dev in (dev, None):
+            got, counts = shard.gather_hits(hits, device="cuda", device_hits=use_dev, always_collective=True)
+            assert counts == [len(hits)] and len(got) == len(hits)
+            assert bytes(np.frombuffer(got, dtype=np.uint8).tobytes()) == bytes(np.frombuffer(hits, dtype=np.uint8).tobytes())
+    finally:
+        dist.destroy_process_group()
+    db.close()
+    e.close()

@@ -369,6 +369,8 @@ struct tnt_ctx {
 	DevBuf<Group> groups;
 	DevBuf<uint32_t> active, qa, qb;
 	DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
+	bool dev_hits_valid = false; // ctx->hits still equals the host copy of the last collected search
+	size_t dev_hits_n = 0;
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
@@ -1646,6 +1648,7 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 
 int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 {
+	if (ctx) ctx->dev_hits_valid = false;
 	if (!ctx || !db || db->ctx != ctx) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	int rc = ensure_work_buffers(ctx, ctx->lmax);
@@ -1760,8 +1763,26 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	T.n_seeds = (uint64_t(cnt[C_TOT_GROUPS_HI]) << 32) | cnt[C_TOT_GROUPS_LO]; // (target, assay) groups that reached the bind stage
 	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n_unique;
+	ctx->dev_hits_valid = n_unique == n;
+	ctx->dev_hits_n = n;
 	if (hits) *hits = ctx->h_hits;
 	if (n_hits) *n_hits = n_unique;
+	return TNT_OK;
+}
+
+int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hits)
+{
+	if (!ctx || !device_hits || !n_hits) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "tnt_search_hits_device: collect the search first";
+		return TNT_E_ARG;
+	}
+	if (!ctx->dev_hits_valid) {
+		ctx->err = "the device copy of the hits still holds the duplicates of overlapping target windows";
+		return TNT_E_UNSUPPORTED;
+	}
+	*device_hits = ctx->hits.p;
+	*n_hits = ctx->dev_hits_n;
 	return TNT_OK;
 }
 

@@ -63,6 +63,7 @@ def load_library():
     lib.tnt_search.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_hit)), P(C.c_size_t)]
     lib.tnt_search_enqueue.argtypes = [C.c_void_p, C.c_void_p]
     lib.tnt_search_collect.argtypes = [C.c_void_p, P(P(abi.tnt_hit)), P(C.c_size_t)]
+    lib.tnt_search_hits_device.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t)]
     lib.tnt_last_timing.argtypes = [C.c_void_p, P(abi.tnt_timing)]
     lib.tnt_seeds.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_seed)), P(C.c_size_t)]
     lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
@@ -88,7 +89,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
-    "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect",
+    "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device",
     "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
@@ -278,6 +279,17 @@ class Engine:
         out = (abi.tnt_hit * n.value)()
         C.memmove(out, view, C.sizeof(abi.tnt_hit) * n.value)
         return out
+
+    def hits_device(self):
+        """(device pointer, count) of the last collected search's hit records as the pair kernel left them, or None
+        when the host copy was post-processed (windowed long targets): see tnt_search_hits_device."""
+        ptr = C.c_void_p()
+        n = C.c_size_t()
+        rc = self.lib.tnt_search_hits_device(self._h, C.byref(ptr), C.byref(n))
+        if rc == -4:  # TNT_E_UNSUPPORTED
+            return None
+        self._check(rc)
+        return (ptr.value or 0), n.value
 
     def timing(self):
         t = abi.tnt_timing()

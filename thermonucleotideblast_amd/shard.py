@@ -37,31 +37,67 @@ def take_shard(codes, offsets, rng):
     return codes[int(offsets[b]):int(offsets[e])], (offsets[b:e + 1] - offsets[b]).astype(np.uint64)
 
 
-def gather_hits(hits, device="cpu"):
-    """All ranks contribute their tnt_hit arrays; returns (all hits as one ctypes array, counts)."""
+class _DeviceBytes:
+    """A span of device memory for torch.as_tensor (zero copy, __cuda_array_interface__)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+_pinned = {}
+
+
+def _pinned_bytes(nbytes):
+    """A reusable page-locked receive buffer on the root (the D2H of the gathered records runs at link speed)."""
+    import torch
+    buf = _pinned.get("buf")
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        _pinned["buf"] = buf
+    return buf
+
+
+def gather_hits(hits, device="cpu", device_hits=None, root=0, always_collective=False):
+    """The hit records of every rank, collected on `root`: an all-gather of the counts, then ONE gather of the padded
+    record arrays (RCCL on GPUs, gloo in the CPU tests).  Returns (hits, counts); on the root `hits` holds all records in
+    rank order, elsewhere it is the rank's own list.
+
+    device_hits = (device pointer, count) from Engine.hits_device(): the records are taken where the pair kernel left
+    them and go to the collective without a round trip through the host."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (always_collective and dist.is_initialized()):  # always_collective: tests run the collective path on one rank
         return hits, [len(hits)]
+    rank = dist.get_rank()
     hb = C.sizeof(abi.tnt_hit)
-    n = torch.tensor([len(hits)], dtype=torch.int64, device=device)
+    n_mine = len(hits)
+    n = torch.tensor([n_mine], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     nmax = max(1, max(counts))
-    buf = torch.zeros(nmax * hb, dtype=torch.uint8, device=device)
-    if len(hits):
-        raw = np.frombuffer(hits, dtype=np.uint8).copy()
-        buf[:raw.size] = torch.from_numpy(raw).to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
+    buf = torch.empty(nmax * hb, dtype=torch.uint8, device=device)
+    if n_mine:
+        if device_hits is not None and device != "cpu" and device_hits[1] == n_mine:
+            buf[:n_mine * hb].copy_(torch.as_tensor(_DeviceBytes(device_hits[0], n_mine * hb), device=device))
+        else:
+            buf[:n_mine * hb].copy_(torch.from_numpy(np.frombuffer(hits, dtype=np.uint8)))
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == root else None
+    dist.gather(buf, out, dst=root)
+    if rank != root:
+        return hits, counts
     total = sum(counts)
-    res = (abi.tnt_hit * total)()
+    if device == "cpu":
+        host = torch.empty(max(1, total * hb), dtype=torch.uint8)
+    else:
+        host = _pinned_bytes(total * hb)
     o = 0
     for r in range(world):
         if counts[r]:
-            chunk = out[r][:counts[r] * hb].cpu().numpy().tobytes()
-            C.memmove(C.byref(res, o * hb), chunk, len(chunk))
-            o += counts[r]
+            host[o:o + counts[r] * hb].copy_(out[r][:counts[r] * hb], non_blocking=True)
+            o += counts[r] * hb
+    if device != "cpu":
+        torch.cuda.current_stream().synchronize()
+    res = (abi.tnt_hit * total).from_buffer(host.numpy()[:max(total * hb, 0)]) if total else (abi.tnt_hit * 0)()
     return res, counts
