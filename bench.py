@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--assays", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective-selftest", action="store_true",
+                    help="single GPU: run the multi-GPU step (RCCL process group of one rank, staged gather) instead of the plain one")
     return ap.parse_args()
 
 
@@ -85,8 +87,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    selftest = args.collective_selftest and world == 1
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif selftest:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
 
     # ---- workload: same assays everywhere, one shard of targets per rank (resident before timing)
     full = {1: 1000, 2: 1_000_000, 3: 1_000_000, 4: 1_250_000, 5: 625_000}[args.config]
@@ -103,33 +113,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_hits(hits):
-        """hit lists -> rank 0 over RCCL (shard.gather_hits: all_gather of the counts, one gather of the padded records
-        taken from device memory, page-locked receive buffer on rank 0; the same code runs on gloo in
-        tests/test_distributed_cpu.py)."""
-        if world == 1:
-            return len(hits)
-        allhits, counts = shard.gather_hits(hits, device="cuda", device_hits=eng.hits_device())
-        return int(sum(counts))
-
-    def step():
+    def run(n):
+        """n steps.  One step = one search of the resident shard + the gather of its hit records to rank 0
+        (shard.stage_hits / finish_gather: all-gather of the counts, ONE RCCL gather of the padded records taken from
+        device memory, page-locked receive buffer on rank 0; the same code runs on gloo in tests/test_distributed_cpu.py).
+        The gather of step i travels while the search of step i + 1 runs; every search and every gather of the n steps is
+        complete when this returns."""
+        acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_hits": 0}
+        if n <= 0:
+            return acc
         eng.enqueue(db)
-        hits = eng.collect(copy=False)  # view of the library's pinned buffer
-        return gather_hits(hits), eng.timing()
+        for i in range(n):
+            hits = eng.collect(copy=False)  # view of the library's pinned buffer
+            tm = eng.timing()
+            if world == 1 and not selftest:
+                acc["n_hits"] = len(hits)
+                if i + 1 < n:
+                    eng.enqueue(db)
+            else:
+                st = shard.stage_hits(hits, device="cuda", device_hits=eng.hits_device(), always_collective=selftest)
+                if i + 1 < n:
+                    eng.enqueue(db)
+                _, counts = shard.finish_gather(st)
+                acc["n_hits"] = int(sum(counts))
+            acc["seed"] += tm.seed_ms
+            acc["bind"] += tm.bind_ms
+            acc["pair"] += tm.pair_ms
+            acc["n_binds"] = tm.n_binds  # DP evaluations of the last step on this rank
+        return acc
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    bind_ms = seed_ms = pair_ms = 0.0
-    n_binds = 0
-    n_hits = 0
-    for _ in range(args.steps):
-        n_hits, tm = step()
-        bind_ms += tm.bind_ms
-        seed_ms += tm.seed_ms
-        pair_ms += tm.pair_ms
-        n_binds = tm.n_binds  # DP evaluations of the last step on this rank
+    acc = run(args.steps)
+    bind_ms, seed_ms, pair_ms, n_binds, n_hits = acc["bind"], acc["seed"], acc["pair"], acc["n_binds"], acc["n_hits"]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -168,7 +185,7 @@ def main():
             "dtype": "i32 DP + f32 scoring", "data": "synthetic",
             "config": {"workload": "config%d: %d expanded assays (%d oligos) x %d x %d-base synthetic targets per GPU"
                                    % (args.config, len(wl.expanded), wl.n_oligos, wl.n_targets, wl.n_bases // max(1, wl.n_targets)),
-                       "sharding": "targets by sequence, one shard per GPU, hits gathered to rank 0 over RCCL",
+                       "sharding": "targets by sequence, one shard per GPU, hit records gathered to rank 0 over RCCL every step",
                        "thresholds": "-e 40 -E 40, all other options default"},
             "targets_per_s": wl.n_targets * world * args.steps / elapsed,
             "hits_per_step": n_hits,
@@ -189,7 +206,7 @@ def main():
                 cb = {"error": str(e)}
             line["cpu_baseline"] = cb
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or selftest:
         dist.destroy_process_group()
 
 

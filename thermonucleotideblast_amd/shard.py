@@ -57,19 +57,24 @@ def _pinned_bytes(nbytes):
     return buf
 
 
-def gather_hits(hits, device="cpu", device_hits=None, root=0, always_collective=False):
-    """The hit records of every rank, collected on `root`: an all-gather of the counts, then ONE gather of the padded
-    record arrays (RCCL on GPUs, gloo in the CPU tests).  Returns (hits, counts); on the root `hits` holds all records in
-    rank order, elsewhere it is the rank's own list.
+class _Staged:
+    """First half of a gather: counts known everywhere, this rank's records in a private send buffer."""
+
+    def __init__(self, hits, counts, buf, device, root):
+        self.hits, self.counts, self.buf, self.device, self.root = hits, counts, buf, device, root
+
+
+def stage_hits(hits, device="cpu", device_hits=None, root=0, always_collective=False):
+    """All-gather of the per-rank counts and a copy of this rank's records into a send buffer of the common (padded)
+    size.  After it returns the caller may start the next search: the library's hit buffers are no longer needed.
 
     device_hits = (device pointer, count) from Engine.hits_device(): the records are taken where the pair kernel left
-    them and go to the collective without a round trip through the host."""
+    them, without a round trip through the host."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1 and not (always_collective and dist.is_initialized()):  # always_collective: tests run the collective path on one rank
-        return hits, [len(hits)]
-    rank = dist.get_rank()
+        return _Staged(hits, [len(hits)], None, device, root)
     hb = C.sizeof(abi.tnt_hit)
     n_mine = len(hits)
     n = torch.tensor([n_mine], dtype=torch.int64, device=device)
@@ -83,21 +88,40 @@ def gather_hits(hits, device="cpu", device_hits=None, root=0, always_collective=
             buf[:n_mine * hb].copy_(torch.as_tensor(_DeviceBytes(device_hits[0], n_mine * hb), device=device))
         else:
             buf[:n_mine * hb].copy_(torch.from_numpy(np.frombuffer(hits, dtype=np.uint8)))
-    out = [torch.empty_like(buf) for _ in range(world)] if rank == root else None
-    dist.gather(buf, out, dst=root)
-    if rank != root:
-        return hits, counts
-    total = sum(counts)
-    if device == "cpu":
-        host = torch.empty(max(1, total * hb), dtype=torch.uint8)
-    else:
-        host = _pinned_bytes(total * hb)
+    if device != "cpu":
+        torch.cuda.current_stream().synchronize()  # the copy is done before the library reuses its buffers
+    return _Staged(hits, counts, buf, device, root)
+
+
+def finish_gather(st):
+    """ONE gather of the padded record arrays to the root (RCCL on GPUs, gloo in the CPU tests) and, on the root, their
+    copy into a page-locked host buffer.  Returns (hits, counts); on the root `hits` holds all records in rank order,
+    elsewhere it is the rank's own list."""
+    import torch
+    import torch.distributed as dist
+    if st.buf is None:
+        return st.hits, st.counts
+    world, rank = dist.get_world_size(), dist.get_rank()
+    hb = C.sizeof(abi.tnt_hit)
+    out = [torch.empty_like(st.buf) for _ in range(world)] if rank == st.root else None
+    dist.gather(st.buf, out, dst=st.root)
+    if rank != st.root:
+        if st.device != "cpu":
+            torch.cuda.current_stream().synchronize()  # the send buffer is free again
+        return st.hits, st.counts
+    total = sum(st.counts)
+    host = torch.empty(max(1, total * hb), dtype=torch.uint8) if st.device == "cpu" else _pinned_bytes(total * hb)
     o = 0
     for r in range(world):
-        if counts[r]:
-            host[o:o + counts[r] * hb].copy_(out[r][:counts[r] * hb], non_blocking=True)
-            o += counts[r] * hb
-    if device != "cpu":
+        if st.counts[r]:
+            host[o:o + st.counts[r] * hb].copy_(out[r][:st.counts[r] * hb], non_blocking=True)
+            o += st.counts[r] * hb
+    if st.device != "cpu":
         torch.cuda.current_stream().synchronize()
-    res = (abi.tnt_hit * total).from_buffer(host.numpy()[:max(total * hb, 0)]) if total else (abi.tnt_hit * 0)()
-    return res, counts
+    res = (abi.tnt_hit * total).from_buffer(host.numpy()[:total * hb]) if total else (abi.tnt_hit * 0)()
+    return res, st.counts
+
+
+def gather_hits(hits, device="cpu", device_hits=None, root=0, always_collective=False):
+    """The hit records of every rank, collected on `root` (stage_hits + finish_gather in one call)."""
+    return finish_gather(stage_hits(hits, device, device_hits, root, always_collective))
