@@ -205,9 +205,17 @@ def main():
             except Exception as e:  # the baseline is reporting, never the product
                 cb = {"error": str(e)}
             line["cpu_baseline"] = cb
-        print(json.dumps(line))
     if world > 1 or selftest:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C-level stdout, which is flushed at exit: push it out first so that the
+        # JSON line is the last line of this process's output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
