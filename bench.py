@@ -205,16 +205,18 @@ def main():
             except Exception as e:  # the baseline is reporting, never the product
                 cb = {"error": str(e)}
             line["cpu_baseline"] = cb
+    # RCCL writes its version banner to the C-level stdout, which is only flushed at exit: every rank pushes it out now,
+    # so that rank 0's JSON line is the last line of the job's output
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if world > 1 or selftest:
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes its version banner to the C-level stdout, which is flushed at exit: push it out first so that the
-        # JSON line is the last line of this process's output
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
         print(json.dumps(line), flush=True)
 
 
