@@ -183,7 +183,10 @@ uint64_t tnt_db_num_bases(const tnt_db *db);
  * a record starts at the first '>' of a line; the defline runs to the first '\n' or '\r' (leading white space
  * dropped); white space, '*' and '-' are dropped from the sequence, the rest goes through ascii_to_hash_base
  * (seq.h:148-189: case-insensitive, U -> T, IUPAC kept, anything else DB_UNKNOWN).  Target i of the database is
- * record i of the text (seq_index = first_seq_index + i).  `text` is borrowed for the call.               */
+ * record i of the text (seq_index = first_seq_index + i).  `text` is borrowed for the call.
+ * Text whose first non-space character is '@' is FASTQ (file_type, annotation.cpp:296-374) and read like load_fastq +
+ * read_bio_seq_fastq_slow do (sequence_data_fastx.cpp:81-186,384-583): '@' at the start of a line opens a record unless
+ * the previous line was the '+' line; the sequence is the single line after the defline.                  */
 int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uint32_t first_seq_index, tnt_db **out);
 /* Same from a file; gzip-compressed files are inflated with zlib like the reference does (gzopen/gzread). */
 int tnt_db_load_fasta(tnt_ctx *ctx, const char *path, uint32_t first_seq_index, tnt_db **out);

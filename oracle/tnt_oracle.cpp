@@ -1662,10 +1662,81 @@ static uint8_t ascii_to_code(unsigned char c)
 	return 17;
 }
 
+// file_type, annotation.cpp:296-374, as far as FASTA / FASTQ go: the first non-space character of the first 511 bytes
+static bool is_fastq(const char *text, size_t n_bytes)
+{
+	for (size_t i = 0; i < n_bytes && i < 511; i++)
+		if (!isspace((unsigned char)text[i])) return text[i] == '@';
+	return false;
+}
+
+// load_fastq + read_bio_seq_fastq_slow, sequence_data_fastx.cpp:81-186,384-583
+static int parse_fastq(const char *text, size_t n_bytes, std::vector<uint8_t> &all, std::vector<uint64_t> &off, std::string &defs)
+{
+	// record index (:103-158): an '@' that starts a line opens a record unless the line before it was the '+' line
+	// (then it is the first quality value)
+	std::vector<size_t> index;
+	char last_header = '-';
+	bool read_eol = true;
+	for (size_t i = 0; i < n_bytes; i++) {
+		switch (text[i]) {
+		case '@':
+			if (read_eol) {
+				if (last_header != '+') index.push_back(i);
+				last_header = '@';
+			}
+			read_eol = false;
+			break;
+		case '+':
+			if (read_eol) last_header = (last_header == '+') ? '-' : '+';
+			read_eol = false;
+			break;
+		case ' ':
+		case '\t': break;
+		case '\n':
+		case '\r': read_eol = true; break;
+		default:
+			if (read_eol) last_header = '-';
+			read_eol = false;
+			break;
+		}
+	}
+	const size_t n = index.size();
+	index.push_back(n_bytes);
+	for (size_t r = 0; r < n; r++) {
+		const char *ptr = text + index[r] + 1, *last = text + index[r + 1];
+		while (last > ptr && isspace((unsigned char)*ptr)) ptr++; // :452-455
+		if (ptr == last) return -1;
+		const char *defline_start = ptr;
+		while (last > ptr && *ptr != '\n' && *ptr != '\r') ptr++;
+		if (ptr == last) return -1;
+		defs.append(defline_start, ptr - defline_start);
+		defs += '\n';
+		ptr++; // the end-of-line character (one of them: a "\r\n" file has empty sequences, :568-571)
+		if (ptr == last) return -1;
+		for (; ptr != last && *ptr != '\n' && *ptr != '\r'; ++ptr) // the sequence is one line
+			if (!isspace((unsigned char)*ptr) && *ptr != '*' && *ptr != '-') all.push_back(ascii_to_code((unsigned char)*ptr));
+		off.push_back(all.size());
+	}
+	return int(n);
+}
+
 int tntor_parse_fasta(const char *text, size_t n_bytes, uint8_t **codes, uint64_t **offsets, size_t *n_targets, char **deflines)
 {
-	// record index: a '>' opens a record unless one was already seen on this line (:37-52)
+	std::vector<uint8_t> all;
+	std::vector<uint64_t> off(1, 0);
+	std::string defs;
+	size_t n = 0;
 	std::vector<size_t> index;
+	if (is_fastq(text, n_bytes)) {
+		const int rc = parse_fastq(text, n_bytes, all, off, defs);
+		if (rc < 0) {
+			g_err = "Truncated fastq file detected!";
+			return -1;
+		}
+		n = size_t(rc);
+	} else {
+	// record index: a '>' opens a record unless one was already seen on this line (:37-52)
 	bool read_fasta = false;
 	for (size_t i = 0; i < n_bytes; i++) {
 		if (!read_fasta && text[i] == '>') {
@@ -1675,12 +1746,10 @@ int tntor_parse_fasta(const char *text, size_t n_bytes, uint8_t **codes, uint64_
 			read_fasta = false;
 		}
 	}
-	const size_t n = index.size();
+	n = index.size();
 	index.push_back(n_bytes);
-	std::vector<uint8_t> all;
-	std::vector<uint64_t> off(1, 0);
-	std::string defs;
-	for (size_t r = 0; r < n; r++) {
+	}
+	for (size_t r = 0; r < n && !index.empty(); r++) {
 		const char *ptr = text + index[r] + 1, *last = text + index[r + 1]; // skip the '>' (:245)
 		while (last > ptr && isspace((unsigned char)*ptr)) ptr++;           // :248-250
 		if (ptr == last) {

@@ -38,6 +38,8 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("plex", 3, 150, 5, 17, ["-e", "40", "-E", "40", "--plex", "T", "-S", "T"]),
     ("plex_padlock", 5, 150, 6, 18, ["-A", "PADLOCK", "-E", "40", "--plex", "T"]),
     ("force_probe", 3, 150, 8, 19, ["-A", "PROBE", "-E", "45"]),
+    # the same search on a FASTQ database
+    ("fastq", 3, 200, 16, 20, ["-e", "40", "-E", "40"]),
 ]
 
 
@@ -50,13 +52,21 @@ def closing_lines(stdout):
     return []
 
 
-def write_case(d, cfg, nt, na, seed, long_target=False):
+def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False):
     wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
     offsets = wl.offsets
     if long_target:  # the first 150 records become one
         offsets = np.concatenate([[0], wl.offsets[150:]]).astype(np.uint64)
     with open(os.path.join(d, "db.fna"), "wb") as f:
-        f.write(synth.to_fasta(wl.codes, offsets))
+        if fastq:  # one sequence line per record; the quality line starts with '@' or '+' now and then
+            for t in range(len(offsets) - 1):
+                seq = synth.decode(wl.codes[int(offsets[t]):int(offsets[t + 1])]).encode()
+                q = bytearray(b"I" * len(seq))
+                if q and t % 3:
+                    q[0] = ord("@") if t % 3 == 1 else ord("+")
+                f.write(b"@seq%d synthetic read\n" % t + seq + b"\n+\n" + bytes(q) + b"\n")
+        else:
+            f.write(synth.to_fasta(wl.codes, offsets))
     with open(os.path.join(d, "assays.txt"), "w") as f:
         f.write("# name forward reverse [probe]   (tntblast assay file)\n")
         for a in wl.assays:
@@ -73,7 +83,7 @@ def main():
         for f in os.listdir(d):
             if f.startswith("ref.out") or f.startswith("hip.out"):
                 os.remove(os.path.join(d, f))
-        write_case(d, cfg, nt, na, seed, long_target=(name == "long_target"))
+        write_case(d, cfg, nt, na, seed, long_target=(name == "long_target"), fastq=(name == "fastq"))
         common = ["-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna")] + flags
         env = dict(os.environ, OMP_NUM_THREADS="1")
         r1 = subprocess.run([REF] + common + ["-o", os.path.join(d, "ref.out")], env=env, capture_output=True, text=True)

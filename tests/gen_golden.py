@@ -194,7 +194,7 @@ def main():
     for name, cfg, nt, na, seed, flags in cli_compare.CASES:
         nt, na = min(nt, 120), min(na, 12)
         with tempfile.TemporaryDirectory() as d:
-            cli_compare.write_case(d, cfg, nt, na, seed, long_target=False)
+            cli_compare.write_case(d, cfg, nt, na, seed, long_target=False, fastq=(name == "fastq"))
             if name == "long_target":
                 continue  # needs more than 150 records; covered by scripts/cli_compare.py on the GPU box
             out = os.path.join(d, "ref.out")

@@ -508,3 +508,48 @@ def test_hits_device_view_matches_host_copy(Engine):
         dist.destroy_process_group()
     db.close()
     e.close()
+
+
+def test_fastq_ingest_and_streaming(Engine, oracle, tmp_path):
+    """FASTQ databases (detected by their first character): the device parser against the oracle's restatement of
+    load_fastq / read_bio_seq_fastq_slow, whole and in batches cut at record starts."""
+    from thermonucleotideblast_amd.engine import FastaReader
+    e = Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGTACGTACGTACGTAC")])
+    for seed in (1, 2):
+        text = synth.quirky_fastq(np.random.default_rng(seed), n_records=120)
+        codes, offsets, names = oracle.parse_fasta(text)
+        db = e.pack_fasta(text)
+        assert db.n_targets == len(names) and db.n_bases == int(offsets[-1])
+        for t in range(len(names)):
+            assert db.defline(t) == names[t]
+            assert np.array_equal(db.target_codes(t), codes[int(offsets[t]):int(offsets[t + 1])]), t
+        db.close()
+        path = tmp_path / ("reads%d.fastq" % seed)
+        path.write_bytes(text)
+        t = 0
+        n_batches = 0
+        for db in FastaReader(e, str(path), max_bytes=1 << 16):
+            for k in range(db.n_targets):
+                assert db.defline(k) == names[t + k]
+                assert np.array_equal(db.target_codes(k), codes[int(offsets[t + k]):int(offsets[t + k + 1])])
+            t += db.n_targets
+            n_batches += 1
+            db.close()
+        assert t == len(names)
+    # large enough for several batches
+    big = b"".join(synth.quirky_fastq(np.random.default_rng(10 + i), n_records=200) + b"\n" for i in range(12))
+    codes, offsets, names = oracle.parse_fasta(big)
+    path = tmp_path / "big.fastq"
+    path.write_bytes(big)
+    t, n_batches = 0, 0
+    for db in FastaReader(e, str(path), max_bytes=1 << 16):
+        for k in range(0, db.n_targets, 7):
+            assert db.defline(k) == names[t + k]
+            assert np.array_equal(db.target_codes(k), codes[int(offsets[t + k]):int(offsets[t + k + 1])])
+        t += db.n_targets
+        n_batches += 1
+        db.close()
+    assert t == len(names) and n_batches > 2
+    with pytest.raises(Exception):
+        e.pack_fasta(b"@truncated")
+    e.close()

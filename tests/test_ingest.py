@@ -50,3 +50,22 @@ def test_workload_round_trip(ref):
     c, o, n = ref.parse_fasta(synth.to_fasta(wl.codes, wl.offsets))
     assert np.array_equal(c, wl.codes) and np.array_equal(o, wl.offsets)
     assert n[0] == "seq0 synthetic target"
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fastq_oracle_vs_reference(ref, oracle, seed):
+    """FASTQ (detected by its first character, annotation.cpp:296-374): record index with its quality-line rules, one
+    sequence line per record (sequence_data_fastx.cpp:81-186,384-583)."""
+    text = synth.quirky_fastq(np.random.default_rng(seed), n_records=50 + 10 * seed)
+    a, b = ref.parse_fasta(text), oracle.parse_fasta(text)
+    assert a[2] == b[2] and len(a[2]) > 30
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_fastq_rules(oracle):
+    c, o, n = oracle.parse_fasta(b"@r1 x\nAC*G-T n\n+\n@IIIIII\n@ \tr2\nacgu\n+r2\n+III\n@r3\r\nACGT\r\n+\r\nIIII\r\n")
+    assert n == ["r1 x", "r2", "r3"]
+    assert synth.decode(c[int(o[0]):int(o[1])]) == "ACGTN"
+    assert synth.decode(c[int(o[1]):int(o[2])]) == "ACGT"
+    assert int(o[3]) == int(o[2])  # CRLF: only one end-of-line character is skipped, the sequence line is empty

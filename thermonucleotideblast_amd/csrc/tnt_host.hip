@@ -1093,6 +1093,44 @@ void ingest_lut(uint8_t lut[256])
 	}
 }
 
+// file_type (annotation.cpp:296-374) as far as it tells FASTQ from FASTA: the first non-space character of the first
+// 511 bytes is an '@'
+bool text_is_fastq(const char *text, size_t n)
+{
+	for (size_t i = 0; i < n && i < 511; i++)
+		if (!isspace(static_cast<unsigned char>(text[i]))) return text[i] == '@';
+	return false;
+}
+
+// load_fastq's record index (sequence_data_fastx.cpp:103-158): an '@' that opens a line (blanks and tabs before it do
+// not count) starts a record unless the line before it was the '+' line -- then it is the first quality value.  The scan
+// has to start at a record boundary (the top of the file, or where an earlier batch was cut).
+void fastq_record_starts(const char *text, size_t n, std::vector<uint64_t> &rec)
+{
+	char last_header = '-';
+	bool read_eol = true;
+	for (size_t i = 0; i < n; i++) {
+		const char c = text[i];
+		if (c == '\n' || c == '\r') {
+			read_eol = true;
+		} else if (c == ' ' || c == '\t') {
+			continue;
+		} else if (read_eol) {
+			if (c == '@') {
+				if (last_header != '+') rec.push_back(i);
+				last_header = '@';
+			} else if (c == '+') {
+				last_header = (last_header == '+') ? '-' : '+';
+			} else {
+				last_header = '-';
+			}
+			read_eol = false;
+			// nothing else on this line matters
+			while (i + 1 < n && text[i + 1] != '\n' && text[i + 1] != '\r') i++;
+		}
+	}
+}
+
 } // namespace
 
 int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uint32_t first_seq_index, tnt_db **out)
@@ -1110,7 +1148,10 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	// The text is cut into slices scanned by host threads: every '>' is a candidate; it opens a record unless
 	// another '>' precedes it on its line (looked up backwards, across the slice boundary if need be).
 	std::vector<uint64_t> rec; // offsets of the '>' + end of text
-	{
+	const bool fastq = text_is_fastq(text, n_bytes);
+	if (fastq) {
+		fastq_record_starts(text, n_bytes, rec);
+	} else {
 		const size_t slice = size_t(16) << 20, n_slices = (n_bytes + slice - 1) / slice;
 		std::vector<std::vector<uint64_t>> found(n_slices);
 		parallel_for_each(n_slices, [&](size_t si) {
@@ -1132,7 +1173,8 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	std::vector<uint64_t> seq_begin(std::max<size_t>(1, n)), seq_end(std::max<size_t>(1, n)), def_begin(std::max<size_t>(1, n));
 	db->defline_off.assign(n + 1, 0);
 	std::vector<uint8_t> truncated(std::max<size_t>(1, n), 0);
-	parallel_for(n, [&](size_t r) { // defline: read_bio_seq_fasta_slow, sequence_data_fastx.cpp:248-276
+	std::vector<uint64_t> def_end(std::max<size_t>(1, n));
+	parallel_for(n, [&](size_t r) { // defline: read_bio_seq_fasta_slow / _fastq_slow, sequence_data_fastx.cpp:248-276,448-479
 		size_t p = rec[r] + 1;
 		const size_t last = rec[r + 1];
 		while (p < last && isspace(static_cast<unsigned char>(text[p]))) p++;
@@ -1140,19 +1182,29 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 		while (q < last && text[q] != '\n' && text[q] != '\r') q++;
 		truncated[r] = (p == last || q == last) ? 1 : 0;
 		def_begin[r] = p;
+		def_end[r] = q;
 		seq_begin[r] = q;
 		seq_end[r] = last;
+		if (fastq && !truncated[r]) {
+			// ONE end-of-line character is skipped, then the sequence is the rest of that line (:476-479,568-571):
+			// after "\r\n" the line is empty
+			size_t b = q + 1;
+			if (b == last) truncated[r] = 1;
+			size_t e = b;
+			while (e < last && text[e] != '\n' && text[e] != '\r') e++;
+			seq_begin[r] = b, seq_end[r] = e;
+		}
 	});
 	for (size_t r = 0; r < n; r++) {
 		if (truncated[r]) {
-			ctx->err = "Truncated fasta file detected!";
+			ctx->err = fastq ? "Truncated fastq file detected!" : "Truncated fasta file detected!";
 			delete db;
 			return TNT_E_ARG;
 		}
-		db->defline_off[r + 1] = db->defline_off[r] + (seq_begin[r] - def_begin[r]);
+		db->defline_off[r + 1] = db->defline_off[r] + (def_end[r] - def_begin[r]);
 	}
 	db->deflines.resize(db->defline_off[n]);
-	parallel_for(n, [&](size_t r) { memcpy(&db->deflines[db->defline_off[r]], text + def_begin[r], seq_begin[r] - def_begin[r]); });
+	parallel_for(n, [&](size_t r) { memcpy(&db->deflines[db->defline_off[r]], text + def_begin[r], def_end[r] - def_begin[r]); });
 	db->n_targets = n;
 	db->ingest.index_ms = float(now_ms() - t0);
 
@@ -1276,6 +1328,7 @@ struct tnt_fasta_reader {
 	std::string err;
 	std::vector<char> carry;   // bytes read beyond the last batch (they start at a record boundary, or before the first record)
 	bool eof = false;
+	int fastq = -1;            // unknown until the first 511 bytes are seen
 	uint32_t next_index = 0;
 	// prefetched batch
 	std::thread worker;
@@ -1325,9 +1378,26 @@ void read_batch(tnt_fasta_reader *r, size_t max_bytes, std::vector<char> &out)
 	r->carry.clear();
 	while (true) {
 		// enough text for a cut at a record boundary near max_bytes?
+		if (r->fastq < 0 && (out.size() >= 511 || r->eof)) r->fastq = text_is_fastq(out.data(), out.size()) ? 1 : 0;
 		if (out.size() > max_bytes) {
-			size_t cut = last_record_start(out.data(), max_bytes);
-			if (!cut) cut = next_record_start(out.data(), out.size(), max_bytes); // one record longer than the batch
+			size_t cut = 0;
+			if (r->fastq == 1) { // record starts depend on the lines before them: scan from the top of the batch
+				std::vector<uint64_t> starts;
+				fastq_record_starts(out.data(), out.size(), starts);
+				size_t next = out.size();
+				for (const uint64_t st : starts) {
+					if (st == 0) continue;
+					if (st <= max_bytes) cut = size_t(st);
+					else {
+						next = size_t(st);
+						break;
+					}
+				}
+				if (!cut) cut = next;
+			} else {
+				cut = last_record_start(out.data(), max_bytes);
+				if (!cut) cut = next_record_start(out.data(), out.size(), max_bytes); // one record longer than the batch
+			}
 			if (cut < out.size()) {
 				r->carry.assign(out.begin() + cut, out.end());
 				out.resize(cut);

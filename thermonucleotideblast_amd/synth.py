@@ -336,3 +336,36 @@ def quirky_fasta(rng, n_records=40):
         recs.append(d + bytes(body))
     recs.append(b">last record without a final newline\nACGTNNNNACGT")
     return b"".join(recs)
+
+
+def quirky_fastq(rng, n_records=40):
+    """FASTQ text exercising the rules of the reference's reader (sequence_data_fastx.cpp:81-186,384-583): quality
+    lines that start with '@' or '+', '+' lines repeating the name, blanks before the name, lower case / IUPAC /
+    unknown characters, '*', '-' and blanks inside the sequence, an empty sequence, a CRLF record (read as an empty
+    sequence: only one end-of-line character is skipped), blank lines between records, no final newline."""
+    letters = b"ACGTacgtUuNnRYKMSWBDHVIi"
+    out = bytearray()
+    for r in range(n_records):
+        n = int(rng.integers(1, 200)) if r % 7 else 0
+        seq = bytearray(rng.choice(np.frombuffer(letters, dtype=np.uint8), size=n))
+        if r % 4 == 0 and len(seq) > 4:
+            seq.insert(2, ord("*"))
+            seq.insert(1, ord("-"))
+            seq.insert(3, ord(" "))
+        if r % 6 == 3 and len(seq) > 2:
+            seq[1] = ord("X")
+            seq.append(ord("?"))
+        qual = bytearray(rng.integers(35, 74, size=len(seq)).astype(np.uint8))
+        if len(qual):
+            if r % 3 == 1:
+                qual[0] = ord("@")
+            elif r % 3 == 2:
+                qual[0] = ord("+")
+        eol = b"\r\n" if r % 9 == 8 else b"\n"
+        name = b"read%d length=%d" % (r, len(seq))
+        out += b"@" + (b" \t" if r % 5 == 2 else b"") + name + eol + bytes(seq) + eol
+        out += b"+" + (name if r % 2 else b"") + eol + bytes(qual) + eol
+        if r % 10 == 9:
+            out += b"\n"
+    out += b"@last read without a final newline\nACGTNNNNACGT\n+\nIIIIIIIIIIII"
+    return bytes(out)
