@@ -19,9 +19,11 @@
 //        treated as terminal without pushing a column.
 //  * Q11 when no enumerated alignment is valid the reference keeps stale
 //        first/last_match; such windows are reported as "no bind".
-//  * a6  the per-target BindCache (tntblast.h:247-324) is not modelled; it only
-//        changes results when one oligo string is evaluated under two
-//        different threshold sets / strand concentrations on the same target.
+//  * a6  the per-target BindCache (tntblast.h:247-324) is not modelled here (the
+//        product binds repeated (oligo, window) pairs once, with the results of
+//        the uncached computation); it only changes results when one oligo string
+//        is evaluated under two different threshold sets / strand concentrations
+//        on the same target.
 
 #include <algorithm>
 #include <cmath>
