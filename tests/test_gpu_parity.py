@@ -553,3 +553,32 @@ def test_fastq_ingest_and_streaming(Engine, oracle, tmp_path):
     with pytest.raises(Exception):
         e.pack_fasta(b"@truncated")
     e.close()
+
+
+def test_shared_oligos_are_bound_once(Engine, oracle, monkeypatch):
+    """SURVEY a6 (the reference's per-target BindCache): assays that share oligos -- degenerate expansion, multiplex
+    combinations -- bind every (oligo, window) once; the hit set does not change."""
+    wl = synth.make_workload(3, n_targets=300, n_assays=12, seed=41)
+    # multiplex-like list: every forward primer with every reverse primer and every probe of the first four assays
+    base = wl.expanded[:4]
+    combos = []
+    for i, f in enumerate(base):
+        for j, r in enumerate(base):
+            for k, p in enumerate(base):
+                combos.append(synth.ExpandedAssay(len(combos), len(combos), f.forward, r.reverse, p.probe))
+    want = tc.sorted_hit_keys(oracle.search(wl.options, combos, wl.codes, wl.offsets))
+    assert len(want) > 10
+    e = Engine(wl.options, combos)
+    db = e.pack(wl.codes, wl.offsets)
+    assert tc.sorted_hit_keys(e.search(db)) == want
+    shared = e.timing().n_binds
+    db.close()
+    e.close()
+    monkeypatch.setenv("TNT_MI355X_NO_DEDUPE", "1")
+    e = Engine(wl.options, combos)
+    db = e.pack(wl.codes, wl.offsets)
+    assert tc.sorted_hit_keys(e.search(db)) == want
+    every = e.timing().n_binds
+    db.close()
+    e.close()
+    assert shared * 3 < every * 2, (shared, every)

@@ -20,6 +20,7 @@
 #include <map>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/tnt_mi355x.h"
@@ -354,6 +355,12 @@ struct tnt_ctx {
 	DevBuf<uint32_t> olig_q4;
 	DevBuf<int32_t> olig_len;
 	DevBuf<Slot> slots;
+	// shared oligos (degenerate expansion, --plex): slot -> first slot with the same (oligo, log_ct, thresh); items
+	// that repeat an earlier item of their target take its bind result (the reference's per-target BindCache, a6)
+	std::vector<uint32_t> h_slot_canon, h_slot_next;
+	DevBuf<uint32_t> slot_canon, slot_next;
+	DevBuf<uint32_t> item_rep;
+	bool dedupe = false;
 	DevBuf<Thresh> thresh;
 	DevBuf<AssayDev> assays;
 	DevBuf<uint32_t> wt_ent, wl_off;
@@ -412,7 +419,7 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_PAD6, C_PAD7, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
+enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_PAD7, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
@@ -431,6 +438,8 @@ __global__ void accumulate_kernel(uint32_t *cnt)
 		*tb += cnt[C_QA + r * SHARD_STRIDE];
 	}
 	*tb += cnt[C_QB];
+	*tb -= cnt[C_DUPS];
+	cnt[C_DUPS] = 0;
 	cnt[C_TOT_BOUND] += cnt[C_POOL];
 }
 
@@ -520,6 +529,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 	k.n_buckets = int(c->bucket_lmax.size());
 	k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads(c->bucket_lmax.back()));
 	k.err = cnt + C_ERR;
+	k.item_rep = (c->dedupe && shard_counts) ? c->item_rep.p : nullptr; // phase A only: phase-B items are never duplicates
 	hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 	hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	(void)hipEventRecord(c->phase_ready, c->stream);
@@ -585,6 +595,7 @@ int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 		HIP_TRY(c->qa.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->qb.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->qbucket.alloc(ITEM_CAP), c->err);
+		if (c->dedupe) HIP_TRY(c->item_rep.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
 		HIP_TRY(c->hits.alloc(c->hit_cap), c->err);
 		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
@@ -873,11 +884,34 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	wl_off[c->h_assays.size() * 6] = uint32_t(wlist.size());
 	(void)n_words; // the per-chunk bucket tables are built by plan() once the target lengths are known
 
+	{
+		std::map<std::tuple<int32_t, uint32_t, int32_t>, uint32_t> first;
+		std::map<uint32_t, uint32_t> last; // class -> its last slot so far
+		c->h_slot_canon.resize(c->h_slots.size());
+		c->h_slot_next.assign(c->h_slots.size(), ITEM_NO_REP);
+		for (size_t si = 0; si < c->h_slots.size(); si++) {
+			const Slot &sl = c->h_slots[si];
+			c->h_slot_canon[si] = uint32_t(si);
+			if (sl.oligo < 0) continue;
+			uint32_t ct_bits;
+			memcpy(&ct_bits, &sl.log_ct, sizeof(ct_bits));
+			const auto it = first.emplace(std::make_tuple(sl.oligo, ct_bits, sl.thresh), uint32_t(si));
+			const uint32_t canon = it.first->second;
+			c->h_slot_canon[si] = canon;
+			if (!it.second) {
+				c->dedupe = true;
+				c->h_slot_next[last[canon]] = uint32_t(si);
+			}
+			last[canon] = uint32_t(si);
+		}
+		if (getenv("TNT_MI355X_NO_DEDUPE")) c->dedupe = false; // ablation
+	}
 	hipError_t e = hipSuccess;
 	std::vector<Tables> tv(1, c->h_tab);
 	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
 	    (e = c->olig_q4.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
+	    (e = c->slot_canon.upload(c->h_slot_canon)) != hipSuccess || (e = c->slot_next.upload(c->h_slot_next)) != hipSuccess ||
 	    (e = c->assays.upload(c->h_assays)) != hipSuccess || (e = c->wl_off.upload(wl_off)) != hipSuccess ||
 	    (e = c->wl_seq.upload(wl_seq)) != hipSuccess ||
 	    (e = c->wlist.upload(wlist)) != hipSuccess)
@@ -1560,6 +1594,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		s.qa = c->qa.p;
 		s.qa_count = cnt + C_QA;
 		s.big_count = cnt + C_BIG;
+		if (c->dedupe) s.slot_canon = c->slot_canon.p, s.slot_next = c->slot_next.p, s.item_rep = c->item_rep.p;
 	} else {
 		s.seeds_out = c->seeds_out.p;
 		s.seeds_cap = uint32_t(c->seeds_out.n);
@@ -1582,6 +1617,22 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
 	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->qa.p, nullptr, cnt + C_QA);
+	if (c->dedupe) {
+		PropagateArgs pa;
+		memset(&pa, 0, sizeof(pa));
+		pa.src = c->qa.p;
+		pa.shard_counts = cnt + C_QA;
+		pa.shard_region = uint32_t(ITEM_CAP / N_SHARD);
+		pa.cap = uint32_t(ITEM_CAP);
+		pa.items = c->items.p;
+		pa.item_rep = c->item_rep.p;
+		pa.result = c->result.p;
+		pa.groups = c->groups.p;
+		pa.active = c->active.p;
+		pa.n_active = cnt + C_ACTIVE;
+		pa.n_dups = cnt + C_DUPS;
+		hipLaunchKernelGGL(propagate_kernel, dim3(1024), dim3(256), 0, c->stream, pa);
+	}
 
 	FilterArgs f;
 	f.groups = c->groups.p;

@@ -288,6 +288,50 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a)
 	}
 }
 
+// After phase A: the items that repeat another item's bind (shared oligos, see SeedArgs::slot_canon) take its result
+// -- the pool record is shared, nothing downstream writes to it -- and, like a bind of their own would, put their group
+// on the active list.
+struct PropagateArgs {
+	const uint32_t *src;          // the phase-A queue (sharded, as the seed kernel wrote it)
+	const uint32_t *shard_counts;
+	uint32_t shard_region;
+	uint32_t cap;
+	const Item *items;
+	const uint32_t *item_rep;
+	int32_t *result;
+	Group *groups;
+	uint32_t *active;
+	uint32_t *n_active;
+	uint32_t *n_dups; // statistics: binds saved
+};
+
+__global__ __launch_bounds__(256) void propagate_kernel(PropagateArgs a)
+{
+	__shared__ uint32_t s_pre[N_SHARD + 1];
+	__shared__ uint32_t s_dups;
+	shard_prefix(a.shard_counts, s_pre, threadIdx.x);
+	if (threadIdx.x == 0) s_dups = 0;
+	__syncthreads();
+	const uint32_t n_all = s_pre[N_SHARD];
+	const uint32_t n = n_all < a.cap ? n_all : a.cap;
+	uint32_t mine = 0;
+	for (uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x; lin < n; lin += gridDim.x * blockDim.x) {
+		const uint32_t idx = a.src[shard_locate(s_pre, lin, a.shard_region)];
+		const uint32_t rep = a.item_rep[idx];
+		if (rep == 0xFFFFFFFFu) continue;
+		mine++;
+		const int32_t r = a.result[rep];
+		a.result[idx] = r;
+		if (r >= 0) {
+			const uint32_t g = a.items[idx].group;
+			if (!(atomicOr(&a.groups[g].count, GROUP_ALIVE) & GROUP_ALIVE)) a.active[atomicAdd(a.n_active, 1u)] = g;
+		}
+	}
+	if (mine) atomicAdd(&s_dups, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_dups) atomicAdd(a.n_dups, s_dups);
+}
+
 // Distribute a queue of item indices over the length buckets of their oligos: every bucket is bound by the
 // kernel instance with exactly that many rows (no padding rows, uniform trip counts inside a wavefront).
 // Two passes: count (bucket sizes), scatter (exclusive offsets -> one compact array, bucket after bucket).
@@ -308,6 +352,7 @@ struct BucketArgs {
 	uint32_t merge_below;         // a queue shorter than this goes to the last (longest) bucket as a whole: one launch
 	                              // with padding rows beats one under-filled launch per bucket
 	uint32_t *err;
+	const uint32_t *item_rep;     // optional: items that take the result of another item are not queued (see SeedArgs)
 };
 
 constexpr int BUCKET_PER_THREAD = 4;
@@ -341,6 +386,7 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 			bkt[m] = 0xFFFFFFFFu;
 			if (lin < n) {
 				idx[m] = a.src[a.shard_counts ? shard_locate(s_pre, lin, a.shard_region) : lin];
+				if (a.item_rep && a.item_rep[idx[m]] != 0xFFFFFFFFu) continue; // bound through its representative
 				const Item it = a.items[idx[m]];
 				const Slot sl = a.slots[it.info >> ITEM_SLOT_SHIFT];
 				bool degenerate = false;

@@ -31,6 +31,7 @@ constexpr int SEED_WAVES = 4;         // wavefronts (= targets in flight) per wo
 constexpr int SEED_THREADS = 64 * SEED_WAVES;
 constexpr int SEED_CAP = 512;         // seeds of one target x one assay chunk held in LDS
 constexpr int SEED_MAX_ASSAYS = 256;  // assays per chunk (8-bit local index in the key)
+constexpr uint32_t ITEM_NO_REP = 0xFFFFFFFFu;
 constexpr int LIST_MAX = 512;         // seeds of one (work unit, assay): bounded by the seed list itself (PAIR_BIG of the pair kernel)
 
 struct SeedOut { // debug / unit-level output: every kept seed before the cull
@@ -63,6 +64,13 @@ struct SeedArgs {
 	uint32_t *qa;              // indices of the items bound in phase A
 	uint32_t *qa_count;
 	uint32_t *big_count;       // groups of more than 64 items (the pair kernel's second instance only runs for them)
+	// Shared oligos (degenerate expansion, --plex): the reference memoises every (oligo, window) it evaluates on a target
+	// (BindCache, tntblast.h:247-324).  Here the seed kernel, which holds all seeds of a target in LDS, marks the
+	// phase-A items that repeat an earlier one -- same canonical slot (oligo, strand concentration, thresholds), same
+	// seed -- and the bind stage evaluates the first and hands its result to the others.
+	const uint32_t *slot_canon; // [slot] first slot with the same (oligo, log_ct, thresh)
+	const uint32_t *slot_next;  // [slot] next slot of that class (ascending), ITEM_NO_REP at the end
+	uint32_t *item_rep;         // [item] the item whose bind result this one takes, ITEM_NO_REP otherwise
 	SeedOut *seeds_out;        // optional
 	uint32_t seeds_cap;
 	uint32_t *seeds_count;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 		for (int q = 1; q < 7; q++) st_t[q] = 0;
 #endif
 		const uint32_t len = a.db.len[t];
-		for (uint32_t i = lane; i < n_chunk; i += 64) hist[i] = 0;
+		for (uint32_t i = lane; i < uint32_t(SEED_MAX_ASSAYS); i += 64) hist[i] = 0; // all of it: the tail may hold representatives (see below)
 		if (lane == 0) s_cnt[wv] = 0;
 		wave_sync();
 #ifdef TNT_EXP_STATS
@@ -489,16 +497,68 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 		ST(5);
 #endif
 			for (uint32_t i = lane; i < n_chunk; i += 64) cmcp[i] = 0; // now the (item | phase-A << 16) cursors
+			const bool DEDUPE = a.item_rep != nullptr;
+			static_assert(SEED_CAP == 2 * SEED_MAX_ASSAYS, "hist + off hold one representative index per seed");
+			if (DEDUPE) {
+				// Expanded assays that share an oligo see the same seeds of it.  A phase-A seed of such an assay looks for
+				// its twin -- same strand, word and position -- in the segments of the assays before it in its class (the
+				// slots with this oligo, strand concentration and threshold set, ascending); the first twin that is a
+				// phase-A item too is bound for everybody behind it.  The representative's index goes where the segment
+				// bounds were (hist / off are not needed after this).
+				uint32_t reps[SEED_CAP / 64];
+#pragma unroll
+				for (int m = 0; m < SEED_CAP / 64; m++) {
+					const uint32_t i = uint32_t(lane) + 64u * uint32_t(m);
+					reps[m] = i;
+					if (i >= n) continue;
+					const unsigned long long k = srt[i];
+					if (!(k & K_VALID) || (k & K_PHASE_B)) continue;
+					const uint32_t slot = (a.assay_begin + uint32_t(k >> 56)) * 3u + key_role(k);
+					const uint32_t canon = a.slot_canon[slot];
+					if (canon == slot) continue;
+					uint32_t wi, p;
+					key_decode(k, wi, p);
+					// the first usable twin along the class (ascending slots) stands for everybody behind it
+					for (uint32_t cur = canon; cur != slot && cur != ITEM_NO_REP && reps[m] == i; cur = a.slot_next[cur]) {
+						if (cur / 3u < a.assay_begin || cur / 3u >= a.assay_end) continue; // bound in another launch
+						const uint32_t la0 = cur / 3u - a.assay_begin, role0 = cur % 3u;
+						const uint32_t cnt0 = hist[la0], s0 = uint32_t(off[la0]) - cnt0;
+						for (uint32_t x = 0; x < cnt0; x++) {
+							const unsigned long long o = srt[s0 + x];
+							if (!(o & K_VALID) || (o & K_PHASE_B) || key_role(o) != role0 || ((o ^ k) & 9u)) continue; // strand, PCR / non-PCR
+							uint32_t owi, op;
+							key_decode(o, owi, op);
+							if (owi == wi && op == p) {
+								reps[m] = s0 + x;
+								break;
+							}
+						}
+					}
+				}
+				wave_sync();
+#pragma unroll
+				for (int m = 0; m < SEED_CAP / 64; m++) {
+					const uint32_t i = uint32_t(lane) + 64u * uint32_t(m);
+					if (i < n) (i < uint32_t(SEED_MAX_ASSAYS) ? hist[i] : off[i - SEED_MAX_ASSAYS]) = uint16_t(reps[m]);
+				}
+			}
 			wave_sync();
 			for (uint32_t i = lane; i < n; i += 64) {
 				const unsigned long long k = srt[i];
-				if (!(k & K_VALID)) continue;
+				if (!(k & K_VALID)) {
+					if (DEDUPE) srt[i] = ~0ull;
+					continue;
+				}
 				const uint32_t la = uint32_t(k >> 56), assay = a.assay_begin + la;
 				const bool pb = (k & K_PHASE_B) != 0;
 				const uint32_t cur = atomicAdd(&cmcp[la], pb ? 1u : 0x10001u);
 				const uint32_t o = bi + ibase[la] + (cur & 0xFFFFu);
 				uint32_t wi, p;
 				key_decode(k, wi, p);
+				if (DEDUPE) {
+					const uint32_t rep = i < uint32_t(SEED_MAX_ASSAYS) ? hist[i] : off[i - SEED_MAX_ASSAYS];
+					srt[i] = ((unsigned long long)rep << 32) | o; // the key is not needed any more
+				}
 				Item it;
 				it.target = t;
 				it.tloc = p;
@@ -507,6 +567,15 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 				it.group = bg + gbase[la];
 				a.items[o] = it;
 				if (!pb) a.qa[ba + abase[la] + (cur >> 16)] = o;
+			}
+			if (DEDUPE) {
+				wave_sync();
+				for (uint32_t i = lane; i < n; i += 64) {
+					const unsigned long long v = srt[i];
+					if (v == ~0ull) continue;
+					const uint32_t rep = uint32_t(v >> 32);
+					a.item_rep[uint32_t(v)] = rep != i ? uint32_t(srt[rep]) : ITEM_NO_REP;
+				}
 			}
 		}
 	next_target:
