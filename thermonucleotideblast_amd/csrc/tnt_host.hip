@@ -402,6 +402,7 @@ struct tnt_ctx {
 	int retries = 0;
 	double batch_scale = 1.0;
 	bool force_big = false;   // launch the crowded-group instance of the pair kernel whatever the expected seed density
+	double unit_scale = 1.0;  // stride of the seed windows of long targets relative to the planned one (halved when single-assay chunks still overflow)
 	double chunk_scale = 1.0; // assay-chunk size of the seed kernel relative to the planned one (halved after a seed-list overflow) // targets per internal batch relative to the planned number (halved after an overflow)
 
 	~tnt_ctx()
@@ -962,7 +963,9 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 	size_t max_ent = 1;
 	for (const auto &ae : ctx->assay_entries) max_ent = std::max(max_ent, ae.size());
 	const double dense = 128.0 * double(size_t(1) << (2 * k)) / double(max_ent);
-	const uint32_t stride = std::max(overlap, std::min(UNIT_STRIDE, uint32_t(std::max(1.0, dense - double(overlap)))));
+	uint32_t stride = std::max(overlap, std::min(UNIT_STRIDE, uint32_t(std::max(1.0, dense - double(overlap)))));
+	// after a seed-list overflow with single-assay chunks the windows shrink (the overlap cannot: it is the cull's reach)
+	if (ctx->unit_scale < 1.0) stride = std::max<uint32_t>(128u, uint32_t(double(stride) * ctx->unit_scale));
 	db->h_unit_target.clear(), db->h_unit_begin.clear(), db->h_unit_end.clear();
 	db->h_unit_own_lo.clear(), db->h_unit_own_hi.clear();
 	db->max_unit_len = 0;
@@ -975,7 +978,7 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 		// into windows when its seeds would not fit the LDS lists (about 256 expected for the busiest assay) or when
 		// it is genome-sized (> 32 k positions).
 		const double expect = double(npos) * double(max_ent) / double(size_t(1) << (2 * k));
-		if (npos <= stride + overlap || (expect <= 256.0 && npos <= 32768u)) {
+		if (npos <= stride + overlap || (expect <= 256.0 && npos <= 32768u && ctx->unit_scale >= 1.0)) {
 			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
 			db->h_unit_own_lo.push_back(INT32_MIN), db->h_unit_own_hi.push_back(INT32_MAX);
 			db->max_unit_len = std::max(db->max_unit_len, len);
@@ -1817,14 +1820,22 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	                            (ctx->force_big ? 0u : ERR_LIST_OVERFLOW);
 	if (cnt[C_ERR] & repairable) {
 		const uint32_t fatal = cnt[C_ERR] & ~repairable;
-		if (!fatal && ctx->retries < 8 && ctx->pending_db) {
+		if (!fatal && ctx->retries < 16 && ctx->pending_db) {
 			ctx->retries++;
 			if (cnt[C_ERR] & ERR_HIT_OVERFLOW) {
 				ctx->hit_cap = std::max<size_t>(ctx->hit_cap * 2, size_t(cnt[C_HITS]) + size_t(cnt[C_HITS]) / 4);
 				HIP_TRY(ctx->hits.alloc(ctx->hit_cap), ctx->err);
 			}
 			if (cnt[C_ERR] & (ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW)) ctx->batch_scale *= 0.5;
-			if (cnt[C_ERR] & ERR_SEED_OVERFLOW) ctx->chunk_scale *= 0.5; // one assay per chunk is the floor: then the error stands
+			if (cnt[C_ERR] & ERR_SEED_OVERFLOW) {
+				// fewer assays per seed pass; with one assay per pass, shorter windows (the units of this database are rebuilt)
+				if (ctx->chunk_begin.size() < ctx->h_assays.size() + 1) {
+					ctx->chunk_scale *= 0.5;
+				} else {
+					ctx->unit_scale *= 0.5;
+					HIP_TRY(build_units(ctx, ctx->pending_db), ctx->err);
+				}
+			}
 			if (cnt[C_ERR] & ERR_LIST_OVERFLOW) ctx->force_big = true;
 			const int rc = tnt_search_enqueue(ctx, ctx->pending_db);
 			if (rc) return rc;
