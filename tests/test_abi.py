@@ -73,5 +73,9 @@ def test_cli_front_end_builds_and_validates_arguments(hip_lib):
     assert r.returncode != 0 and "Unknown output format" in r.stderr
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-k", "T"], capture_output=True, text=True)
     assert r.returncode != 0 and "not supported" in r.stderr
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--query-seg", "sometimes"], capture_output=True, text=True)
+    assert r.returncode != 0 and "query-seg" in r.stderr
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--query-seg", "adaptive", "--max-target-len", "1000"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unable to open x" in r.stderr  # both accepted: the run gets as far as the assay file
     r = subprocess.run([g.CLI, "-i", "x"], capture_output=True, text=True)
     assert r.returncode != 0 and "dbase" in r.stderr

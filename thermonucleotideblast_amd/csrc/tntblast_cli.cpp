@@ -506,6 +506,16 @@ void parse_args(int argc, char **argv, Options &o)
 				break;
 			}
 			case 10: o.t.target_t = float(atof(optarg)); break;
+			case 11: // --max-target-len: the reference cuts longer targets into overlapping fragments; here every target is
+			         // searched whole (seed windows with true coordinates), which is what a larger value gives there
+				std::cerr << "note: --max-target-len is not needed here, targets of any length are searched unfragmented" << std::endl;
+				break;
+			case 12: { // --query-seg: how the reference deals queries to its workers, no effect on the results
+				std::string v(optarg);
+				for (char &ch : v) ch = char(tolower(ch));
+				if (v != "always" && v != "never" && v != "adaptive") fail("Unknown --query-seg value");
+				break;
+			}
 			case 13: o.dump_query = parse_bool(optarg); break;
 			case 14: o.t.allow_dangle_5 = parse_bool(optarg) ? 1 : 0; break;
 			case 15: o.t.allow_dangle_3 = parse_bool(optarg) ? 1 : 0; break;
