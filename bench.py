@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X: oligo x target-base evaluations / second.
 
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU
-through torch.distributed.run (RCCL).  A step = one pass of the hot path (seed -> cull -> bind ->
-pair) over one batch of synthetic targets that is already packed and resident in HBM.  Targets
-shard by sequence: every rank owns an independent shard of the same size (weak scaling), there is
-no data-path collective, and the hit records are gathered to rank 0 over RCCL after every step.
+`python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no rank environment this process only LAUNCHES:
+it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (it never touches the GPU
+itself), relays the ranks' output and prints rank 0's JSON line last.  Started by torch.distributed.run (the
+driver's form) it is one rank of N.  The reference distributes (target, query-range) work from an MPI master
+to workers and collects their hit lists (tntblast_master.cpp:438-461,811-828); here targets shard by sequence,
+there is no data-path collective, and the hit records of every step are gathered to rank 0 over RCCL.
 
+A step = one pass of the hot path (seed -> cull -> bind -> pair) over targets that are already packed and
+resident in HBM.
+  --scaling weak   (default) every rank owns an independent shard of the per-GPU size of the configuration
+  --scaling strong one database of the configuration's full size (configs 4 / 5 as BASELINE.json words them: 10 M x
+                   2 kb / 5 M x 1 kb), generated in 8 pieces and dealt to the ranks in contiguous runs
 Workload at N = 1: BASELINE.json configs[1], "96 PCR primer pairs vs 1M x 1kb synthetic targets".
 Prints ONE JSON line on rank 0.
 """
@@ -14,6 +20,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,7 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALG_BYTES_PER_BASE = 0.25      # 2-bit packed targets read once (configs 1-3)
+ALG_BYTES_PER_BASE = 0.25      # 2-bit packed targets read once
+VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2.0  # guide: 1 024 SIMDs, one wave-instruction per 2 cycles, 2.4 GHz
+PIECES = 8                     # the strong-scaling database is generated in this many pieces
 
 
 def parse():
@@ -30,18 +40,51 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config 1..5 (default 2)")
-    ap.add_argument("--targets", type=int, default=None, help="override targets per GPU (default: full config size)")
+    ap.add_argument("--targets", type=int, default=None, help="override targets per GPU (weak) / in total (strong)")
     ap.add_argument("--assays", type=int, default=None)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective-selftest", action="store_true",
                     help="single GPU: run the multi-GPU step (RCCL process group of one rank, staged gather) instead of the plain one")
+    ap.add_argument("--launch-only", action="store_true",
+                    help="no GPU: start the ranks (gloo), count them, run the hit gather on made-up records and print the line")
     return ap.parse_args()
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch(args):
+    """Parent of an N-rank run.  Makes no torch.cuda / HIP call: the ranks are fresh child processes."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    line = None
+    for out in proc.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s  # rank 0's result: printed last
+        else:
+            sys.stdout.write(out)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        rc = 1
+    sys.exit(rc)
 
 
 def cpu_baseline(wl, budget_s):
     """Bounded sample of the same workload on the host cores: the reference's own objects
-    (oracle/_ref, kind 'reference') when they are present, else this repo's restatement ('port')."""
+    (oracle/_ref, kind 'reference') when they are present, else this repo's restatement ('port').
+    Returns (record, hits of the sample, number of targets in the sample)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import tntcheck as tc
     cores = os.cpu_count() or 1
@@ -50,37 +93,115 @@ def cpu_baseline(wl, budget_s):
     elif os.path.exists(tc.ORACLE_SO):
         impl, kind = tc.OracleImpl(), "port"
     else:
-        return None
+        return None, [], 0
     n = min(wl.n_targets, 256 * cores)
     total_t, total_n = 0.0, 0
     first = 0
+    hits = []
     while total_t < budget_s and first < wl.n_targets:
         last = min(wl.n_targets, first + n)
         codes = wl.codes[int(wl.offsets[first]):int(wl.offsets[last])]
         offs = wl.offsets[first:last + 1] - wl.offsets[first]
         t0 = time.perf_counter()
-        impl.search(wl.options, wl.expanded, codes, offs, first=first, threads=cores)
+        got = impl.search(wl.options, wl.expanded, codes, offs, first=first, threads=cores)
         total_t += time.perf_counter() - t0
+        hits.extend(tc.hit_key(h) for h in got)
         total_n += last - first
         first = last
         if total_t < budget_s / 4:
             n *= 2
     bases = int(wl.offsets[first])
-    return {"value": wl.n_oligos * bases / total_t, "unit": "evals/s", "cores": cores, "kind": kind,
-            "targets_per_s": total_n / total_t,
-            "sample": "first %d targets of the same workload, %d OpenMP threads, %.1f s" % (total_n, cores, total_t)}
+    rec = {"value": wl.n_oligos * bases / total_t, "unit": "evals/s", "cores": cores, "kind": kind,
+           "targets_per_s": total_n / total_t,
+           "sample": "first %d targets of the same workload, %d OpenMP threads, %.1f s" % (total_n, cores, total_t)}
+    return rec, hits, total_n
+
+
+def parity_sample(gpu_hits, cpu_keys, n_sample, target_t):
+    """the step's hits on the first `n_sample` targets against the CPU checker's: equality of the hit
+    multisets (every field, floats as bit patterns, alignment text) and max |Tm| / |dG| differences over the hits
+    that pair up by their integer fields."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tntcheck as tc
+    from thermonucleotideblast_amd import abi
+    g = sorted(tc.hit_key(h) for h in gpu_hits if h.seq_index < n_sample)
+    c = sorted(cpu_keys)
+    names = [n for n, _ in abi.tnt_hit._fields_]
+    fl = [i for i, (n, t) in enumerate(abi.tnt_hit._fields_) if t is C.c_float]
+    txt = [i for i, n in enumerate(names) if n.endswith("_align")]
+    ints = [i for i in range(len(names)) if i not in fl and i not in txt]
+
+    def split(keys):
+        d = {}
+        for k in keys:
+            d.setdefault(tuple(k[i] for i in ints), []).append(k)
+        return d
+    dg_, dc_ = split(g), split(c)
+    tm_err = dg_err = 0.0
+    paired = 0
+    f32 = lambda bits: float(np.uint32(bits).view(np.float32))  # noqa: E731
+    for ik, gl in dg_.items():
+        for a, b in zip(sorted(gl), sorted(dc_.get(ik, []))):
+            paired += 1
+            for o in ("forward", "reverse", "probe"):
+                tm_a, tm_b = f32(a[names.index(o + "_tm")]), f32(b[names.index(o + "_tm")])
+                tm_err = max(tm_err, abs(tm_a - tm_b))
+                ga = f32(a[names.index(o + "_dH")]) - target_t * f32(a[names.index(o + "_dS")])
+                gb = f32(b[names.index(o + "_dH")]) - target_t * f32(b[names.index(o + "_dS")])
+                dg_err = max(dg_err, abs(ga - gb))
+    return {"targets": n_sample, "hits_gpu": len(g), "hits_cpu": len(c), "paired": paired,
+            "hit_multiset_equal": g == c, "tm_max_abs_err": tm_err, "dg_max_abs_err": dg_err}
+
+
+def launch_only(args, rank, world):
+    """CPU plumbing check of the N-rank path: rendezvous, rank count, the staged gather of hit records (gloo)."""
+    import torch
+    import torch.distributed as dist
+    from thermonucleotideblast_amd import abi, shard
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == world == args.gpus, "ranks started (%d) != --gpus (%d)" % (dist.get_world_size(), args.gpus)
+    one = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(one)
+    mine = (abi.tnt_hit * (rank + 2))()
+    for i, h in enumerate(mine):
+        h.seq_index, h.assay_id = rank * 1000 + i, i
+        h.forward_align = b"5' ACGT 3'"
+    t0 = time.perf_counter()
+    allhits, counts = shard.gather_hits(mine)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank = [torch.zeros_like(el) for _ in range(world)]
+    dist.all_gather(per_rank, el)
+    ok = True
+    if rank == 0:
+        ok = counts == [r + 2 for r in range(world)] and [h.seq_index for h in allhits] == [r * 1000 + i for r in range(world) for i in range(r + 2)]
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launch-only check of the %d-rank path (no GPU work)" % world, "value": 0.0, "unit": "evals/s",
+                          "n_gpus": int(one.item()), "rccl_ranks": world, "backend": "gloo", "launch_only": True,
+                          "gather_ok": bool(ok), "steps": 0, "warmup": 0, "ms_per_step": 0.0,
+                          "ms_per_step_per_rank": [1000.0 * float(x.item()) for x in per_rank]}), flush=True)
+    if not ok:
+        sys.exit(1)
 
 
 def main():
     args = parse()
+    in_rank_env = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_rank_env:
+        launch(args)  # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and in_rank_env and world > 1:
+        raise SystemExit("bench.py: --gpus %d but torch.distributed.run started %d ranks" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.launch_only:
+        return launch_only(args, rank, world)
 
     import torch  # first: the HIP runtime torch loads is the one libtnt_mi355x.so binds to
     import torch.distributed as dist
-    import numpy as np
     from thermonucleotideblast_amd import shard, synth
     from thermonucleotideblast_amd.engine import Engine
 
@@ -91,21 +212,40 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif selftest:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1,
                                 device_id=torch.device("cuda", local_rank))
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
 
-    # ---- workload: same assays everywhere, one shard of targets per rank (resident before timing)
+    # ---- workload: same assays everywhere; the targets of this rank are resident before the timed region
     full = {1: 1000, 2: 1_000_000, 3: 1_000_000, 4: 1_250_000, 5: 625_000}[args.config]
-    n_targets = args.targets or full
-    wl = synth.make_workload(args.config, n_targets=n_targets, n_assays=args.assays, shard=rank)
-    eng = Engine(wl.options, wl.expanded, device=local_rank)
-    t0 = time.perf_counter()
-    db = eng.pack(wl.codes, wl.offsets, first_seq_index=rank * n_targets)
-    pack_s = time.perf_counter() - t0
+    full_total = {1: 1000, 2: 1_000_000, 3: 1_000_000, 4: 10_000_000, 5: 5_000_000}[args.config]
+    if args.scaling == "strong":
+        if PIECES % world:
+            raise SystemExit("strong scaling deals %d pieces: --gpus must divide it" % PIECES)
+        per_piece = max(1, (args.targets or full_total) // PIECES)
+        my_pieces = list(range(rank * PIECES // world, (rank + 1) * PIECES // world))
+    else:
+        per_piece = args.targets or full
+        my_pieces = [rank]
+    eng = None
+    dbs = []
+    pack_s = 0.0
+    wl0 = None
+    n_bases_rank = 0
+    for pc in my_pieces:
+        wl = synth.make_workload(args.config, n_targets=per_piece, n_assays=args.assays, shard=pc)
+        if eng is None:
+            eng = Engine(wl.options, wl.expanded, device=local_rank)
+        t0 = time.perf_counter()
+        dbs.append(eng.pack(wl.codes, wl.offsets, first_seq_index=pc * per_piece))
+        pack_s += time.perf_counter() - t0
+        n_bases_rank += wl.n_bases
+        if wl0 is None and rank == 0:
+            wl0 = wl  # the CPU baseline and the parity sample use rank 0's first piece
+        else:
+            del wl
+    n_oligos = sum((1 if e.forward else 0) + (1 if e.reverse else 0) + (1 if e.probe else 0) for e in eng.expanded)
+    n_targets_rank = per_piece * len(my_pieces)
 
     def barrier():
         torch.cuda.synchronize()
@@ -113,33 +253,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    last = {"hits": None}
+
     def run(n):
-        """n steps.  One step = one search of the resident shard + the gather of its hit records to rank 0
-        (shard.stage_hits / finish_gather: all-gather of the counts, ONE RCCL gather of the padded records taken from
+        """n steps.  One step = one search of every resident piece of this rank + the gather of the hit records to
+        rank 0 (shard.stage_hits / finish_gather: all-gather of the counts, ONE RCCL gather of the records taken from
         device memory, page-locked receive buffer on rank 0; the same code runs on gloo in tests/test_distributed_cpu.py).
-        The gather of step i travels while the search of step i + 1 runs; every search and every gather of the n steps is
+        The gather of one search travels while the next search runs; every search and every gather of the n steps is
         complete when this returns."""
         acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_hits": 0}
         if n <= 0:
             return acc
-        eng.enqueue(db)
-        for i in range(n):
+        todo = [db for _ in range(n) for db in dbs]
+        eng.enqueue(todo[0])
+        step_hits = step_binds = 0
+        for i, db in enumerate(todo):
             hits = eng.collect(copy=False)  # view of the library's pinned buffer
             tm = eng.timing()
             if world == 1 and not selftest:
-                acc["n_hits"] = len(hits)
-                if i + 1 < n:
-                    eng.enqueue(db)
+                nh = len(hits)
+                if i + 1 < len(todo):
+                    eng.enqueue(todo[i + 1])
+                else:
+                    last["hits"] = hits
             else:
                 st = shard.stage_hits(hits, device="cuda", device_hits=eng.hits_device(), always_collective=selftest)
-                if i + 1 < n:
-                    eng.enqueue(db)
-                _, counts = shard.finish_gather(st)
-                acc["n_hits"] = int(sum(counts))
+                if i + 1 < len(todo):
+                    eng.enqueue(todo[i + 1])
+                else:
+                    last["hits"] = hits
+                _, counts = shard.finish_gather(st, copy=False)
+                nh = int(sum(counts))
             acc["seed"] += tm.seed_ms
             acc["bind"] += tm.bind_ms
             acc["pair"] += tm.pair_ms
-            acc["n_binds"] = tm.n_binds  # DP evaluations of the last step on this rank
+            step_hits += nh
+            step_binds += tm.n_binds
+            if (i + 1) % len(dbs) == 0:
+                acc["n_hits"], acc["n_binds"] = step_hits, step_binds  # of the last step
+                step_hits = step_binds = 0
         return acc
 
     run(args.warmup)
@@ -148,68 +300,90 @@ def main():
     acc = run(args.steps)
     bind_ms, seed_ms, pair_ms, n_binds, n_hits = acc["bind"], acc["seed"], acc["pair"], acc["n_binds"], acc["n_hits"]
     barrier()
-    elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed = time.perf_counter() - t0
+    per_rank_ms = [1000.0 * my_elapsed / args.steps]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_ms = [1000.0 * float(x.item()) / args.steps for x in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        tot = torch.tensor([n_bases_rank, n_targets_rank], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        n_bases_all, n_targets_all = int(tot[0].item()), int(tot[1].item())
+    else:
+        n_bases_all, n_targets_all = n_bases_rank, n_targets_rank
 
     if rank == 0:
-        evals_per_step = wl.n_oligos * wl.n_bases * world  # every rank holds a shard of the same size
+        evals_per_step = n_oligos * n_bases_all
         value = evals_per_step * args.steps / elapsed
         ms_per_step = 1000.0 * elapsed / args.steps
-        bind_ms_step = bind_ms / max(1, args.steps)
-        alg_bytes = ALG_BYTES_PER_BASE * wl.n_bases
+        steps = max(1, args.steps)
+        bind_ms_step, seed_ms_step = bind_ms / steps, seed_ms / steps
+        alg_bytes = ALG_BYTES_PER_BASE * n_bases_rank  # this rank's kernels stream this rank's targets
         achieved = alg_bytes / (bind_ms_step * 1e-3) / 1e9 if bind_ms_step > 0 else 0.0
+        seed_achieved = alg_bytes / (seed_ms_step * 1e-3) / 1e9 if seed_ms_step > 0 else 0.0
         traffic = None
         valu = None
         pmc = os.path.join(ROOT, "profiles", "bind_pmc.json")
-        if os.path.exists(pmc) and args.config == 2 and n_targets == full:  # measured for this workload only
+        if os.path.exists(pmc) and args.config == 2 and per_piece == full and args.scaling == "weak":  # measured for this workload only
             try:
                 rec = json.load(open(pmc))
                 traffic = rec.get("hbm_bytes_per_step")
                 # What actually bounds the kernel: VALU issue.  Wave-instructions per step from the same
-                # PMC file over this run's bind time, against 1 024 SIMDs x the sustained shader clock / the mean issue
-                # cost of the fill's instruction mix (scripts/microbench/valu_rate.hip: 2.25 / 4.3 cycles by class).
+                # PMC file over this run's bind time, against (a) the guide's plain rate: 1 024 SIMDs x 2.4 GHz / 2 cycles,
+                # (b) the rate of this instruction mix measured by scripts/microbench/valu_rate.hip (2.25 / 4.3 cycles
+                # by class at the 1.97 GHz the kernel sustains)
                 n_valu = rec.get("SQ_INSTS_VALU_per_step")
                 if n_valu and bind_ms_step > 0:
-                    peak = 1024 * 1.97e9 / 3.15
                     ach = n_valu / (bind_ms_step * 1e-3)
-                    valu = {"achieved": ach, "peak": peak, "unit": "VALU wave-instructions/s", "frac": ach / peak}
+                    peak_mix = 1024 * 1.97e9 / 3.15
+                    valu = {"achieved": ach, "unit": "VALU wave-instructions/s", "peak_guide": VALU_PEAK_GUIDE,
+                            "frac_guide": ach / VALU_PEAK_GUIDE, "peak_mix": peak_mix, "frac_mix": ach / peak_mix}
             except Exception:
                 traffic = None
+        tl = n_bases_rank // max(1, n_targets_rank)
         line = {
             "metric": "oligo x target-base evaluations per second (seed + NN-thermodynamic bind + pairing)",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": value, "unit": "evals/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "ms_per_step_per_rank": per_rank_ms,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "i32 DP + f32 scoring", "data": "synthetic",
-            "config": {"workload": "config%d: %d expanded assays (%d oligos) x %d x %d-base synthetic targets per GPU"
-                                   % (args.config, len(wl.expanded), wl.n_oligos, wl.n_targets, wl.n_bases // max(1, wl.n_targets)),
-                       "sharding": "targets by sequence, one shard per GPU, hit records gathered to rank 0 over RCCL every step",
+            "config": {"workload": "config%d: %d expanded assays (%d oligos) x %d x %d-base synthetic targets %s"
+                                   % (args.config, len(eng.expanded), n_oligos, n_targets_rank if args.scaling == "weak" else n_targets_all,
+                                      tl, "per GPU" if args.scaling == "weak" else "in total, dealt to the GPUs in %d pieces" % PIECES),
+                       "sharding": "targets by sequence, no data-path collective, hit records gathered to rank 0 over RCCL every step",
                        "thresholds": "-e 40 -E 40, all other options default"},
-            "targets_per_s": wl.n_targets * world * args.steps / elapsed,
+            "targets_per_s": n_targets_all * args.steps / elapsed,
             "hits_per_step": n_hits,
             "pack_and_h2d_s": pack_s,
-            "stage_ms_per_step": {"seed": seed_ms / max(1, args.steps), "bind": bind_ms_step, "pair": pair_ms / max(1, args.steps)},
+            "stage_ms_per_step": {"seed": seed_ms_step, "bind": bind_ms_step, "pair": pair_ms / steps},
             "roofline": {"bound": "hbm", "kernel": "bind_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once); the bind "
                                  "stage is bound by integer VALU issue, not by HBM (DESIGN.md 4.2); traffic = PMC "
                                  "2*FETCH_SIZE + WRITE_SIZE per step of the full-size config (profiles/bind_pmc.json)",
-                         "dp_per_s": n_binds * world / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0,
+                         "dp_per_s": n_binds / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0,
                          "valu_issue": valu},
+            # the streaming stage, for which SURVEY 8(d) means the HBM roofline: the seed kernels of a step (scan + cull)
+            "roofline_seed": {"bound": "hbm", "kernel": "seed stage (scan + dedupe + first cull + emission)", "achieved": seed_achieved,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": seed_achieved / HBM_PEAK_GBS},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and wl0 is not None:
             try:
-                cb = cpu_baseline(wl, args.cpu_seconds)
+                cb, cpu_keys, n_sample = cpu_baseline(wl0, args.cpu_seconds)
+                if cb is not None and last["hits"] is not None and len(dbs) == 1:
+                    line["parity_sample"] = parity_sample(last["hits"], cpu_keys, n_sample, float(wl0.options.target_t))
+                    for k in ("tm_max_abs_err", "dg_max_abs_err", "hit_multiset_equal"):
+                        line[k] = line["parity_sample"][k]
             except Exception as e:  # the baseline is reporting, never the product
                 cb = {"error": str(e)}
             line["cpu_baseline"] = cb
     # RCCL writes its version banner to the C-level stdout, which is only flushed at exit: every rank pushes it out now,
     # so that rank 0's JSON line is the last line of the job's output
     try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
+        C.CDLL(None).fflush(None)
     except Exception:
         pass
     sys.stdout.flush()

@@ -80,3 +80,27 @@ def test_shard_ranges_cover_and_balance():
         sizes = [int(offs[e] - offs[b]) for b, e in r]
         assert max(sizes) - min(sizes) <= 2 * 3000
     assert shard.shard_ranges(np.array([0], dtype=np.uint64), 4) == [(0, 0)] * 4
+
+
+def test_bench_launcher_starts_ranks():
+    """`python bench.py --gpus 2` must start two ranks itself (the parent never touches a GPU): the launch-only mode
+    runs the rendezvous, the rank count and the staged hit gather on gloo and prints rank 0's JSON line last."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-only"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["gather_ok"] is True
+    assert len(line["ms_per_step_per_rank"]) == 2
+
+
+def test_gather_returns_owned_records(checkers):
+    """finish_gather(copy=True) hands out records that a later gather cannot overwrite (single process: no collective)."""
+    from thermonucleotideblast_amd import abi
+    a = (abi.tnt_hit * 2)()
+    a[0].seq_index, a[1].seq_index = 5, 6
+    got, counts = shard.gather_hits(a)
+    assert counts == [2] and [h.seq_index for h in got] == [5, 6]

@@ -93,10 +93,13 @@ def stage_hits(hits, device="cpu", device_hits=None, root=0, always_collective=F
     return _Staged(hits, counts, buf, device, root)
 
 
-def finish_gather(st):
+def finish_gather(st, copy=True):
     """ONE gather of the padded record arrays to the root (RCCL on GPUs, gloo in the CPU tests) and, on the root, their
     copy into a page-locked host buffer.  Returns (hits, counts); on the root `hits` holds all records in rank order,
-    elsewhere it is the rank's own list."""
+    elsewhere it is the rank's own list.
+
+    copy=True (default) returns records the caller owns.  copy=False returns a VIEW of the module's reusable page-locked
+    receive buffer: it is overwritten by the next gather on this process (bench.py, which only counts the records)."""
     import torch
     import torch.distributed as dist
     if st.buf is None:
@@ -118,10 +121,13 @@ def finish_gather(st):
             o += st.counts[r] * hb
     if st.device != "cpu":
         torch.cuda.current_stream().synchronize()
-    res = (abi.tnt_hit * total).from_buffer(host.numpy()[:total * hb]) if total else (abi.tnt_hit * 0)()
+    if not total:
+        return (abi.tnt_hit * 0)(), st.counts
+    raw = host.numpy()[:total * hb]
+    res = (abi.tnt_hit * total).from_buffer_copy(raw) if copy else (abi.tnt_hit * total).from_buffer(raw)
     return res, st.counts
 
 
-def gather_hits(hits, device="cpu", device_hits=None, root=0, always_collective=False):
+def gather_hits(hits, device="cpu", device_hits=None, root=0, always_collective=False, copy=True):
     """The hit records of every rank, collected on `root` (stage_hits + finish_gather in one call)."""
-    return finish_gather(stage_hits(hits, device, device_hits, root, always_collective))
+    return finish_gather(stage_hits(hits, device, device_hits, root, always_collective), copy=copy)
