@@ -237,6 +237,14 @@ int tnt_last_timing(tnt_ctx *ctx, tnt_timing *out);
 /* Unit-level entries (parity tests of SURVEY 8a rows a1-a3 and a5-a14). */
 int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds);
 int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out);
+/* The same requests through the kernels tnt_search() runs (bind_oligo.cpp:502-748 for each): TNT_ROUTE_BUCKETS splits
+ * the queue by oligo length like a search phase does, so every request is bound by the throughput instance of its
+ * length (exact / plain ladder; the general ladder for windows with degenerate target bases); TNT_ROUTE_MERGED binds
+ * the whole queue with the longest general instance (what a search does with short queues).  These instances keep a
+ * status for every request and the record + alignment text of bound ones only: status is always set; tm, dH, dS, dg,
+ * anchors, num_mm, num_gap, loc5, loc3, align are set when status == 0; the other fields are -1 (0 for the window). */
+enum { TNT_ROUTE_UNIT = 0, TNT_ROUTE_BUCKETS = 1, TNT_ROUTE_MERGED = 2 };
+int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out, int route);
 
 /* Oligo self-structure printed with every hit (tntblast_local.cpp:656-686): hairpin and homodimer Tm of oligo
  * `a` at strand(ct_a, ct_a), and, when `b` is given, the heterodimer Tm of query a / target b at

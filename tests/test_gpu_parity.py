@@ -60,6 +60,95 @@ def test_g2_binds_golden(Engine):
         e.close()
 
 
+ROUTED_FIELDS = [3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 21]  # tm dH dS dg a5 a3 mm gap loc5 loc3 align: what a throughput instance keeps
+
+
+@pytest.mark.parametrize("route", [1, 2])
+def test_g2_binds_golden_production_instances(Engine, route):
+    """The G2 cases through the kernels tnt_search runs (bucket_kernel + one launch per length bucket: exact / plain
+    ladder / general instances, 256- and 768-thread; route 2: everything through the longest general instance): the
+    status of every request and the record + text of every bound one must equal the reference's."""
+    fx = gu.load("g2_binds.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
+    for case in fx["cases"]:
+        e = Engine(gu.options_from(case["options"]), ex)
+        om = {o: i for i, o in enumerate(e.oligos)}
+        reqs = tc.make_reqs((r[0], om[fx["oligos"][r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in fx["requests"])
+        db = e.pack(codes, offsets)
+        out = e.bind_batch(db, reqs, route=route)
+        bad, n_bound = [], 0
+        for i, x in enumerate(case["expected"]):
+            got = gu.bind_record(out[i])
+            idx = [0] + (ROUTED_FIELDS if x[0] == 0 else [])
+            n_bound += x[0] == 0
+            d = [(k, x[k], got[k]) for k in idx if x[k] != got[k]]
+            if d:
+                bad.append((i, d))
+        assert n_bound > 100
+        assert not bad, "%s route %d: %d of %d differ, first %r" % (case["name"], route, len(bad), len(case["expected"]), bad[:2])
+        db.close()
+        e.close()
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-2.0, max_probe_dg=-2.0)),
+                                     (3, dict(salt=0.9, target_t=300.0, min_primer_tm=20.0, min_probe_tm=20.0)),
+                                     (4, dict(allow_dangle_5=1, allow_dangle_3=1, min_primer_tm=30.0, min_probe_tm=30.0, primer_clamp=2, max_mismatch=4, max_gap=1))])
+def test_random_windows_production_vs_oracle(Engine, oracle, seed, kw):
+    """Random windows -- oligos of 12..64 bases, sites with substitutions, deletions, insertions, IUPAC codes, clipped at
+    the target ends -- through every route of the bind stage against the oracle."""
+    rng = np.random.default_rng([77, seed])
+    oligos = sorted({synth._rand_oligo(rng, 12, 64) for _ in range(60)} | {synth._rand_oligo(rng, 17, 32) for _ in range(60)})
+    targets, rows = [], []
+    for t in range(1500):
+        o = int(rng.integers(0, len(oligos)))
+        q = oligos[o]
+        minus = rng.random() < 0.5  # the minus-strand binding site reads like the oligo, the plus-strand one like its reverse complement
+        site = list(q) if minus else list(synth.revcomp(q))
+        for _ in range(int(rng.integers(0, 5))):
+            k = int(rng.integers(0, len(site)))
+            r = rng.random()
+            if r < 0.6:
+                site[k] = "ACGT"[int(rng.integers(0, 4))]
+            elif r < 0.75:
+                site[k] = "RYKMSWNBDHV"[int(rng.integers(0, 11))]
+            elif r < 0.9 and len(site) > 10:
+                del site[k]
+            else:
+                site.insert(k, "ACGT"[int(rng.integers(0, 4))])
+        left = int(rng.integers(0, 12))
+        right = int(rng.integers(0, 12))
+        seq = "".join("ACGT"[i] for i in rng.integers(0, 4, left)) + "".join(site) + "".join("ACGT"[i] for i in rng.integers(0, 4, right))
+        targets.append(seq)
+        # a seed somewhere on the site's diagonal: query_loc indexes the word list of the strand-specific oligo
+        ql = int(rng.integers(0, max(1, len(q) - 7)))
+        rows.append((t, o, abi.MINUS if minus else abi.PLUS, ql, min(len(seq) - 1, left + ql), int(rng.integers(0, 2)), 9.0e-7 if t % 3 else 2.5e-7))
+    codes, offsets = gu.pack_targets(targets)
+    opt = abi.options_default(**dict(dict(min_primer_tm=40.0, min_probe_tm=40.0), **kw))
+    e = Engine(opt, [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(oligos)])
+    om = {o: i for i, o in enumerate(e.oligos)}
+    reqs = tc.make_reqs((r[0], om[oligos[r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in rows)
+    oreqs = tc.make_reqs(rows)
+    want = oracle.bind_batch(opt, oligos, codes, offsets, oreqs)
+    db = e.pack(codes, offsets)
+    n_bound = sum(1 for w in want if w.status == 0)
+    assert n_bound > 50, n_bound
+    for route in (0, 1, 2):
+        out = e.bind_batch(db, reqs, route=route)
+        bad = []
+        for i, w in enumerate(want):
+            x, got = gu.bind_record(w), gu.bind_record(out[i])
+            if route == 0:
+                d = gu.compare_bind(x, got)
+            else:
+                d = [(k, x[k], got[k]) for k in ([0] + (ROUTED_FIELDS if x[0] == 0 else [])) if x[k] != got[k]]
+            if d:
+                bad.append((i, d))
+        assert not bad, "route %d: %d of %d differ, first %r" % (route, len(bad), len(want), bad[:2])
+    db.close()
+    e.close()
+
+
 def test_g3_structure_golden(Engine):
     """Row a17: hairpin / homodimer / heterodimer Tm of oligos through the unit-level bind kernel instance."""
     g = gu.load("g3_structure.json.gz")

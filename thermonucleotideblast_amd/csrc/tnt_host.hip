@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -398,6 +399,7 @@ struct tnt_ctx {
 	uint64_t acc_items = 0, acc_bound = 0;
 	bool pending = false;
 	tnt_db *pending_db = nullptr;
+	std::vector<tnt_db *> dbs; // live databases of this context: detached (not freed) when the context goes first
 	size_t hit_cap = size_t(1) << 20; // initial hit capacity; grown on demand (tnt_search_collect)
 	int retries = 0;
 	double batch_scale = 1.0;
@@ -509,7 +511,7 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 
 // One phase of binding: split the queue by oligo length, then one launch per length bucket.
 void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_exceptions, const uint32_t *src, const uint32_t *src_count,
-                       const uint32_t *shard_counts)
+                       const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always */)
 {
 	uint32_t *cnt = c->counters.p;
 	(void)hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream);
@@ -520,7 +522,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 	k.shard_counts = shard_counts;
 	k.shard_region = uint32_t(ITEM_CAP / N_SHARD);
 	k.items = c->items.p;
-	k.slots = c->slots.p;
+	k.slots = b.slots;
 	k.olig_len = c->olig_len.p;
 	k.db = v;
 	k.has_exceptions = has_exceptions ? 1 : 0;
@@ -529,6 +531,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 	k.counters = cnt + C_BUCKET;
 	k.n_buckets = int(c->bucket_lmax.size());
 	k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads(c->bucket_lmax.back()));
+	if (merge_mode == 1) k.merge_below = 0;
+	if (merge_mode == 2) k.merge_below = 0xFFFFFFFFu;
 	k.err = cnt + C_ERR;
 	k.item_rep = (c->dedupe && shard_counts) ? c->item_rep.p : nullptr; // phase A only: phase-B items are never duplicates
 	hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
@@ -927,6 +931,7 @@ void tnt_ctx_destroy(tnt_ctx *ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	for (tnt_db *db : ctx->dbs) db->ctx = nullptr; // a database may outlive its context: it can still be destroyed, nothing else
 	delete ctx;
 }
 
@@ -1073,6 +1078,7 @@ int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, s
 		delete db;
 		return TNT_E_DEVICE;
 	}
+	ctx->dbs.push_back(db);
 	*out = db;
 	return TNT_OK;
 }
@@ -1080,9 +1086,11 @@ int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, s
 void tnt_db_destroy(tnt_db *db)
 {
 	if (!db) return;
-	if (db->ctx) {
-		(void)hipSetDevice(db->ctx->device);
-		(void)hipStreamSynchronize(db->ctx->stream);
+	if (tnt_ctx *c = db->ctx) {
+		(void)hipSetDevice(c->device);
+		(void)hipStreamSynchronize(c->stream);
+		c->dbs.erase(std::remove(c->dbs.begin(), c->dbs.end(), db), c->dbs.end());
+		if (c->pending_db == db) c->pending_db = nullptr;
 	}
 	delete db;
 }
@@ -1174,7 +1182,8 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 {
 	if (!ctx || !out || (!text && n_bytes)) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	tnt_db *db = new tnt_db;
+	std::unique_ptr<tnt_db> owner(new tnt_db); // freed on every early return below
+	tnt_db *db = owner.get();
 	db->ctx = ctx;
 	db->first_seq_index = first_seq_index;
 	memset(&db->ingest, 0, sizeof(db->ingest));
@@ -1235,7 +1244,6 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	for (size_t r = 0; r < n; r++) {
 		if (truncated[r]) {
 			ctx->err = fastq ? "Truncated fastq file detected!" : "Truncated fasta file detected!";
-			delete db;
 			return TNT_E_ARG;
 		}
 		db->defline_off[r + 1] = db->defline_off[r] + (def_end[r] - def_begin[r]);
@@ -1259,7 +1267,6 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	    (n_bytes && (e = hipMemcpy(d_text.p, text, n_bytes, hipMemcpyHostToDevice)) != hipSuccess) ||
 	    (e = hipMemcpy(d_lut.p, lut, 256, hipMemcpyHostToDevice)) != hipSuccess) {
 		ctx->err = std::string("fasta upload: ") + hipGetErrorString(e);
-		delete db;
 		return TNT_E_DEVICE;
 	}
 	db->ingest.h2d_ms = float(now_ms() - t0);
@@ -1274,8 +1281,16 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	a.len = db->len.p;
 	a.n_exc = d_nexc.p;
 	const int blocks = int(std::min<size_t>(std::max<size_t>(1, (n + INGEST_WAVES - 1) / INGEST_WAVES), size_t(1) << 16));
-	hipEvent_t ev[4];
-	for (auto &x : ev) HIP_TRY(hipEventCreate(&x), ctx->err);
+	struct Events { // destroyed on every return
+		hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+		~Events()
+		{
+			for (hipEvent_t x : e)
+				if (x) (void)hipEventDestroy(x);
+		}
+	} events;
+	hipEvent_t *ev = events.e;
+	for (int x = 0; x < 4; x++) HIP_TRY(hipEventCreate(&ev[x]), ctx->err);
 	HIP_TRY(hipEventRecord(ev[0], ctx->stream), ctx->err);
 	if (n) hipLaunchKernelGGL(ingest_count_kernel, dim3(blocks), dim3(INGEST_THREADS), 0, ctx->stream, a);
 	HIP_TRY(hipEventRecord(ev[1], ctx->stream), ctx->err);
@@ -1305,7 +1320,6 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	    (e = db->exc_code.alloc(std::max<uint64_t>(1, db->n_exceptions))) != hipSuccess ||
 	    (e = hipMemsetAsync(db->packed.p, 0, (words + 4) * sizeof(uint32_t), ctx->stream)) != hipSuccess) {
 		ctx->err = std::string("target allocation: ") + hipGetErrorString(e);
-		delete db;
 		return TNT_E_DEVICE;
 	}
 	db->ingest.layout_ms = float(now_ms() - t0);
@@ -1321,11 +1335,11 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	HIP_TRY(hipGetLastError(), ctx->err);
 	(void)hipEventElapsedTime(&db->ingest.count_ms, ev[0], ev[1]);
 	(void)hipEventElapsedTime(&db->ingest.pack_ms, ev[2], ev[3]);
-	for (auto &x : ev) (void)hipEventDestroy(x);
 	HIP_TRY(build_units(ctx, db), ctx->err);
 	db->ingest.bases = db->n_bases;
 	db->ingest.exceptions = db->n_exceptions;
-	*out = db;
+	ctx->dbs.push_back(db);
+	*out = owner.release();
 	return TNT_OK;
 }
 
@@ -1997,12 +2011,27 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 
 int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out)
 {
+	return tnt_bind_batch_routed(ctx, db, req, n, out, TNT_ROUTE_UNIT);
+}
+
+int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out, int route)
+{
 	if (!ctx || !db || db->ctx != ctx || (!req && n) || (!out && n)) return TNT_E_ARG;
+	if (route != TNT_ROUTE_UNIT && route != TNT_ROUTE_BUCKETS && route != TNT_ROUTE_MERGED) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "a search is pending on this context: collect it first";
+		return TNT_E_ARG;
+	}
 	if (n == 0) return TNT_OK;
 	if (n > ITEM_CAP || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	int rc = ensure_work_buffers(ctx, 64); // the unit-level kernel instance is bind_kernel<64, true>
 	if (rc) return rc;
+	auto bucket_of = [&](int id) -> int32_t { // position of an instance in the context's bucket list (it holds the instances of every oligo)
+		for (size_t i = 0; i < ctx->bucket_lmax.size(); i++)
+			if (ctx->bucket_lmax[i] == id) return int32_t(i);
+		return int32_t(ctx->bucket_lmax.size()) - 1;
+	};
 	// one temporary slot per request (arbitrary strand concentration)
 	std::vector<Slot> slots(n);
 	std::vector<Item> items(n);
@@ -2018,7 +2047,8 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 		slots[i].log_ct = logf((r.ct - 0.5f * 0.0f) * 1.0f);
 		slots[i].thresh = r.role == 1 ? 1 : 0;
 		slots[i].assay = -1;
-		slots[i].bucket = slots[i].bucket_general = 0;
+		slots[i].bucket = bucket_of(pick_instance(ctx->oligos[r.oligo].size()));
+		slots[i].bucket_general = bucket_of(pick_lmax(ctx->oligos[r.oligo].size()));
 		items[i].target = uint32_t(t);
 		items[i].tloc = uint32_t(r.target_loc);
 		items[i].info = uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT);
@@ -2035,8 +2065,20 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	b.groups = nullptr;
 	b.n_items = uint32_t(n);
 	b.n_items_dev = nullptr;
-	b.full = dfull.p;
-	launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + size_t(bind_threads(0)) - 1) / size_t(bind_threads(0)))), 0);
+	if (route == TNT_ROUTE_UNIT) {
+		b.full = dfull.p;
+		launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + size_t(bind_threads(0)) - 1) / size_t(bind_threads(0)))), 0);
+	} else {
+		// the path tnt_search takes: the queue is split by bucket_kernel and every request is bound by the throughput
+		// instance of its oligo length (exact / plain ladder / general for windows with degenerate bases)
+		std::vector<uint32_t> queue(n);
+		for (size_t i = 0; i < n; i++) queue[i] = uint32_t(i);
+		const uint32_t n32 = uint32_t(n);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err); // the counters were cleared on the stream
+		HIP_TRY(hipMemcpy(ctx->qb.p, queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(hipMemcpy(ctx->counters.p + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		launch_bind_phase(ctx, b, b.db, db->n_exceptions != 0, ctx->qb.p, ctx->counters.p + C_QB, nullptr, route == TNT_ROUTE_BUCKETS ? 1 : 2);
+	}
 	HIP_TRY(hipGetLastError(), ctx->err);
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
@@ -2044,6 +2086,36 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 	if (cnt[C_ERR]) {
 		ctx->err = err_text(cnt[C_ERR]);
 		return TNT_E_LIMIT;
+	}
+	if (route != TNT_ROUTE_UNIT) {
+		// what the throughput instances leave behind: a status per request and, for bound ones, the pool record
+		std::vector<int32_t> res(n);
+		HIP_TRY(hipMemcpy(res.data(), ctx->result.p, n * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
+		const size_t n_pool = std::min<size_t>(cnt[C_POOL], POOL_CAP);
+		std::vector<BoundRec> recs(n_pool);
+		if (n_pool) HIP_TRY(hipMemcpy(recs.data(), ctx->pool.p, n_pool * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		for (size_t i = 0; i < n; i++) {
+			tnt_bind &o = out[i];
+			memset(&o, 0, sizeof(o));
+			o.q_first = o.q_last = o.t_first = o.t_last = o.poly_degen = o.dp_max = o.n_max = -1; // not kept by these instances
+			if (res[i] < 0) {
+				o.status = -res[i];
+				continue;
+			}
+			if (size_t(res[i]) >= n_pool) {
+				ctx->err = "bind result points outside the pool";
+				return TNT_E_LIMIT;
+			}
+			const BoundRec &r = recs[size_t(res[i])];
+			o.status = 0, o.valid = 1;
+			o.tm = r.tm, o.dH = r.dH, o.dS = r.dS;
+			o.dg = r.dH - ctx->opt.target_t * r.dS; // delta_G(), nuc_cruc.h:1217
+			o.anchor5 = r.a5, o.anchor3 = r.a3, o.num_mm = r.mm, o.num_gap = r.gap;
+			o.loc5 = r.loc5, o.loc3 = r.loc3;
+			memcpy(o.align, r.text, TNT_ALIGN_TEXT);
+			o.align[TNT_ALIGN_TEXT - 1] = 0;
+		}
+		return TNT_OK;
 	}
 	std::vector<BindFull> full(n);
 	HIP_TRY(hipMemcpy(full.data(), dfull.p, n * sizeof(BindFull), hipMemcpyDeviceToHost), ctx->err);
@@ -2067,6 +2139,10 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
                         float *heterodimer_ab)
 {
 	if (!ctx || !oa || !hairpin_a || !homodimer_a || (ob && !heterodimer_ab) || !(ct_a > 0.0f) || (ob && !(ct_b > 0.0f))) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "a search is pending on this context: collect it first";
+		return TNT_E_ARG;
+	}
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	int rc = ensure_work_buffers(ctx, 64);
 	if (rc) return rc;

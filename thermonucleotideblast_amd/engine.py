@@ -67,6 +67,7 @@ def load_library():
     lib.tnt_last_timing.argtypes = [C.c_void_p, P(abi.tnt_timing)]
     lib.tnt_seeds.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_seed)), P(C.c_size_t)]
     lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
+    lib.tnt_bind_batch_routed.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind), C.c_int]
     lib.tnt_hit_sequence.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_hit), C.c_char_p, C.c_size_t]
     lib.tnt_db_create_from_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, P(C.c_void_p)]
     lib.tnt_db_load_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, P(C.c_void_p)]
@@ -90,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device",
-    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_hit_sequence", "tnt_oligo_structure",
+    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
 ]
@@ -302,9 +303,11 @@ class Engine:
         self._check(self.lib.tnt_seeds(self._h, batch._h, C.byref(s), C.byref(n)))
         return [(s[i].seq_index, self.oligos[s[i].oligo], s[i].strand, s[i].query_loc, s[i].target_loc) for i in range(n.value)]
 
-    def bind_batch(self, batch, reqs):
+    def bind_batch(self, batch, reqs, route=0):
+        """route 0: the unit-level kernel instance (full record); 1: the throughput instances a search runs, queue split
+        by oligo length; 2: the longest general throughput instance (tnt_bind_batch_routed)."""
         out = (abi.tnt_bind * len(reqs))()
-        self._check(self.lib.tnt_bind_batch(self._h, batch._h, reqs, len(reqs), out))
+        self._check(self.lib.tnt_bind_batch_routed(self._h, batch._h, reqs, len(reqs), out, route))
         return out
 
     def oligo_structure(self, a, b=None, ct_a=9.0e-7, ct_b=9.0e-7):
