@@ -362,6 +362,7 @@ struct tnt_ctx {
 	DevBuf<uint32_t> slot_canon, slot_next;
 	DevBuf<uint32_t> item_rep;
 	bool dedupe = false;
+	bool seed_lds = false; // the seed kernel instance with LDS-resident tables serves this context
 	DevBuf<Thresh> thresh;
 	DevBuf<AssayDev> assays;
 	DevBuf<uint32_t> wt_ent, wl_off;
@@ -1620,13 +1621,20 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	s.err = cnt + C_ERR;
 	s.debug = cnt + C_DEBUG + 8;
 	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
+	// the streaming instance keeps the chunk's tables in LDS: one persistent workgroup per CU
+	const int lds_blocks = int(std::min<size_t>((u1 - u0 + SEED_LDS_WAVES - 1) / SEED_LDS_WAVES, size_t(c->n_cu)));
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
+	const size_t off_stride = (n_words + 1 + 1) & ~size_t(1); // every chunk's offset table starts on a dword
 	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
 		s.assay_begin = c->chunk_begin[ch];
 		s.assay_end = c->chunk_begin[ch + 1];
-		s.wt_off = c->wt_off.p + ch * (n_words + 1);
+		s.wt_off = c->wt_off.p + ch * off_stride;
 		s.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
-		hipLaunchKernelGGL(seed_kernel, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
+		s.n_ent = c->chunk_ent_base[ch + 1] - c->chunk_ent_base[ch];
+		if (c->seed_lds && s.n_ent <= uint32_t(SEED_LDS_ENT))
+			hipLaunchKernelGGL(seed_kernel<true>, dim3(lds_blocks), dim3(64 * SEED_LDS_WAVES), 0, c->stream, s);
+		else
+			hipLaunchKernelGGL(seed_kernel<false>, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
 	}
 	HIP_TRY(hipEventRecord(ev[1], c->stream), c->err);
 	if (seeds_only) return TNT_OK;
@@ -1718,6 +1726,11 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	// their seeds come in bursts).  A chunk grows while mean + 6 sigma stays below the list size; a target that
 	// overflows it anyway makes tnt_search_collect halve chunk_scale and repeat the search.
 	const double cap = double(SEED_CAP) * c->chunk_scale;
+	// the streaming seed kernel keeps a chunk's table in LDS: hash words up to 7 bases, at most SEED_LDS_ENT entries
+	// (measured slower than the instance reading them through L2 at twice the occupancy: opt-in until the stages behind
+	// the scan are split off into their own launch)
+	c->seed_lds = c->opt.hash_word_size <= SEED_LDS_WORD_SIZE && getenv("TNT_MI355X_SEED_LDS_TABLES");
+	const size_t ent_cap = c->seed_lds ? size_t(SEED_LDS_ENT) : size_t(65535);
 	std::vector<uint32_t> chunk_begin;
 	std::vector<uint32_t> mult(n_words);
 	size_t a0 = 0;
@@ -1730,7 +1743,7 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 			double add_sq = 0.0;
 			for (const auto &we : ae) add_sq += 2.0 * double(mult[we.first]++) + 1.0;
 			const double mean = maxlen * double(ent + ae.size()) / words, sigma = sqrt(maxlen * (sum_sq + add_sq) / words);
-			if (a1 > a0 && (mean + 6.0 * sigma > cap || ent + ae.size() > 65535)) break;
+			if (a1 > a0 && (mean + 6.0 * sigma > cap || ent + ae.size() > ent_cap)) break;
 			ent += ae.size();
 			sum_sq += add_sq;
 			a1++;
@@ -1759,7 +1772,10 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 				return TNT_E_LIMIT;
 			}
 			off.push_back(uint16_t(ent.size() - base));
+			if (off.size() & 1) off.push_back(0); // the next chunk's table starts on a dword (the LDS instance copies dwords)
 		}
+		c->chunk_ent_base.push_back(uint32_t(ent.size()));
+		off.push_back(0), off.push_back(0);
 		HIP_TRY(hipStreamSynchronize(c->stream), c->err);
 		HIP_TRY(c->wt_off.upload(off), c->err);
 		HIP_TRY(c->wt_ent.upload(ent), c->err);
@@ -1822,8 +1838,8 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	{
 		const uint32_t *d = cnt + C_DEBUG;
 		const double w = d[7] ? double(d[7]) : 1.0;
-		fprintf(stderr, "seed waves %u; kilo-cycles per wave: scan %.0f sort %.0f cull %.0f phaseB %.0f prefix+groups %.0f emit %.0f\n", d[15], double(d[8]) / (d[15] ? d[15] : 1),
-		        double(d[9]) / (d[15] ? d[15] : 1), double(d[10]) / (d[15] ? d[15] : 1), double(d[11]) / (d[15] ? d[15] : 1), double(d[12]) / (d[15] ? d[15] : 1), double(d[13]) / (d[15] ? d[15] : 1));
+		fprintf(stderr, "seed waves %u; kilo-cycles per wave: scan+dedupe %.0f (dedupe %.0f) sort %.0f cull %.0f phaseB %.0f prefix+groups %.0f emit %.0f\n", d[15], double(d[8]) / (d[15] ? d[15] : 1),
+		        double(d[14]) / (d[15] ? d[15] : 1), double(d[9]) / (d[15] ? d[15] : 1), double(d[10]) / (d[15] ? d[15] : 1), double(d[11]) / (d[15] ? d[15] : 1), double(d[12]) / (d[15] ? d[15] : 1), double(d[13]) / (d[15] ? d[15] : 1));
 		fprintf(stderr, "wave-DPs %u; cycles per wave-DP: fill %.0f trace %.0f trim %.0f eval %.0f other-enum %.0f thresholds %.0f output %.0f\n", d[7],
 		        64.0 * d[0] / w, 64.0 * d[1] / w, 64.0 * d[2] / w, 64.0 * d[3] / w, 64.0 * d[4] / w, 64.0 * d[5] / w, 64.0 * d[6] / w);
 	}

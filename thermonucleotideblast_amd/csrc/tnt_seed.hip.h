@@ -27,8 +27,16 @@
 
 namespace tnt {
 
-constexpr int SEED_WAVES = 4;         // wavefronts (= targets in flight) per workgroup
+constexpr int SEED_WAVES = 4;         // wavefronts (= targets in flight) per workgroup of the instance that reads its tables from HBM / L2
 constexpr int SEED_THREADS = 64 * SEED_WAVES;
+// The streaming instance: the query-word table of the chunk (bucket offsets + entries + the packed oligos) sits in LDS once
+// per workgroup and is shared by SEED_LDS_WAVES wavefronts; every lane walks 16 consecutive positions out of two registers.
+constexpr int SEED_LDS_WAVES = 8;
+constexpr int SEED_LDS_WORD_SIZE = 7;                 // hash words up to 7 bases: 4^7 + 1 16-bit offsets = 32 KB
+constexpr int SEED_LDS_OFF = (1 << (2 * SEED_LDS_WORD_SIZE)) + 2;
+constexpr int SEED_LDS_ENT = 10240;                   // entries of one assay chunk (40 KB)
+constexpr int SEED_LDS_SEQ = 1536;                    // 64-bit words of packed oligos: 128 assays x 6 lists x 2 (12 KB); larger chunks read them from HBM
+constexpr int SEED_SWEEP = 16;                        // positions per lane and sweep
 constexpr int SEED_CAP = 512;         // seeds of one target x one assay chunk held in LDS
 constexpr int SEED_MAX_ASSAYS = 256;  // assays per chunk (8-bit local index in the key)
 constexpr uint32_t ITEM_NO_REP = 0xFFFFFFFFu;
@@ -49,6 +57,7 @@ struct SeedArgs {
 	int word_size;
 	const uint16_t *wt_off;    // this chunk's bucket offsets [4^k + 1], relative to wt_ent (< 65536 entries per chunk)
 	const uint32_t *wt_ent;    // this chunk's entries (see tnt_dev.h)
+	uint32_t n_ent;            // number of entries of the chunk
 	const uint16_t *wlist;     // concatenated word lists (little-endian 2-bit words)
 	const uint32_t *wl_off;    // [((assay * 3 + role) * 2 + minus)] -> first word
 	const unsigned long long *wl_seq; // [list][2]: the strand-specific oligo, 2 bits per base, base 0 in the low bits
@@ -166,14 +175,21 @@ __device__ __forceinline__ bool first_on_diagonal_packed(const uint32_t *pk, con
 	return (R & before) == 0;
 }
 
-__global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
+// LDS_TABLES: the chunk's query-word table is staged in LDS once per workgroup (word size <= SEED_LDS_WORD_SIZE, at most
+// SEED_LDS_ENT entries) and the scan walks SEED_SWEEP positions per lane out of registers; otherwise the tables are read
+// from HBM / L2 position by position (word size 8, over-long chunks).
+template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES), (LDS_TABLES ? 2 : 4)) void seed_kernel(SeedArgs a)
 {
-	__shared__ unsigned long long s_raw[SEED_WAVES][SEED_CAP];
-	__shared__ unsigned long long s_srt[SEED_WAVES][SEED_CAP];
-	__shared__ uint16_t s_hist[SEED_WAVES][SEED_MAX_ASSAYS];
-	__shared__ uint16_t s_off[SEED_WAVES][SEED_MAX_ASSAYS];
-	__shared__ uint32_t s_cnt[SEED_WAVES];
-	__shared__ uint32_t s_ncand[SEED_WAVES];
+	constexpr int WAVES = LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES;
+	__shared__ unsigned long long s_raw[WAVES][SEED_CAP];
+	__shared__ unsigned long long s_srt[WAVES][SEED_CAP];
+	__shared__ uint16_t s_hist[WAVES][SEED_MAX_ASSAYS];
+	__shared__ uint16_t s_off[WAVES][SEED_MAX_ASSAYS];
+	__shared__ uint32_t s_cnt[WAVES];
+	__shared__ uint32_t s_ncand[WAVES];
+	__shared__ uint16_t s_wt_off[LDS_TABLES ? SEED_LDS_OFF : 2];
+	__shared__ uint32_t s_wt_ent[LDS_TABLES ? SEED_LDS_ENT : 1];
+	__shared__ unsigned long long s_seq[LDS_TABLES ? SEED_LDS_SEQ : 1];
 
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	unsigned long long *raw = s_raw[wv], *srt = s_srt[wv];
@@ -181,14 +197,27 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 	const uint32_t wmask = (1u << (2 * a.word_size)) - 1u;
 	const uint32_t n_chunk = a.assay_end - a.assay_begin;
 
-	const uint32_t shard = (blockIdx.x * SEED_WAVES + wv) & (N_SHARD - 1);
+	const uint32_t shard = (blockIdx.x * WAVES + wv) & (N_SHARD - 1);
+	// packed oligos of the chunk's lists: from LDS when they fit
+	const bool seq_lds = LDS_TABLES && n_chunk * 12u <= uint32_t(SEED_LDS_SEQ);
+	if (LDS_TABLES) {
+		const uint32_t n_off = (wmask + 2u + 1u) / 2u; // 4^k + 1 offsets, copied as dwords
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(a.wt_off);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(s_wt_off);
+		for (uint32_t i = threadIdx.x; i < n_off; i += blockDim.x) dst[i] = src[i];
+		for (uint32_t i = threadIdx.x; i < a.n_ent; i += blockDim.x) s_wt_ent[i] = a.wt_ent[i];
+		if (seq_lds)
+			for (uint32_t i = threadIdx.x; i < n_chunk * 12u; i += blockDim.x) s_seq[i] = a.wl_seq[size_t(a.assay_begin) * 12u + i];
+		__syncthreads();
+	}
 
 #ifdef TNT_EXP_STATS
 	long long st_t[7] = {0, 0, 0, 0, 0, 0, 0};
 	long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+	long long st_drain = 0; // part of the scan slot spent in the de-duplication
 #define ST(K) st_t[K] = __builtin_readcyclecounter()
 #endif
-	for (uint32_t unit = a.unit0 + blockIdx.x * SEED_WAVES + wv; unit < a.unit1; unit += gridDim.x * SEED_WAVES) {
+	for (uint32_t unit = a.unit0 + blockIdx.x * WAVES + wv; unit < a.unit1; unit += gridDim.x * WAVES) {
 		const uint32_t t = a.unit_target[unit];
 #ifdef TNT_EXP_STATS
 		for (int q = 1; q < 7; q++) st_t[q] = 0;
@@ -214,41 +243,26 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 			// The list holds SEED_CAP candidates; when it fills up (buckets shared by many expanded assays come in
 			// bursts) it is drained and the scan resumes where every lane stopped.
 			uint2 *cand = reinterpret_cast<uint2 *>(srt);
-			uint32_t p = pos0 + lane, e_done = 0;
-			while (true) {
-			if (lane == 0) s_ncand[wv] = 0;
-			wave_sync();
-			while (true) {
-				bool over = false;
-				if (p < npos) {
-					const uint32_t w = target_word(pk, p, wmask);
-					const uint32_t e0 = uint32_t(a.wt_off[w]) + e_done, e1 = a.wt_off[w + 1];
-					uint32_t fit = 0;
-					if (e1 > e0) {
-						const uint32_t at = atomicAdd(&s_ncand[wv], e1 - e0);
-						fit = at < uint32_t(SEED_CAP) ? (e1 - e0 < uint32_t(SEED_CAP) - at ? e1 - e0 : uint32_t(SEED_CAP) - at) : 0u;
-						for (uint32_t x = 0; x < fit; x++) cand[at + x] = make_uint2(p, a.wt_ent[e0 + x]);
-					}
-					if (fit == e1 - e0) p += 64, e_done = 0;
-					else e_done += fit, over = true;
-				}
-				if (__builtin_amdgcn_ballot_w64(over) != 0 || __builtin_amdgcn_ballot_w64(p < npos) == 0) break;
-			}
-			wave_sync();
-			uint32_t ncand = s_ncand[wv];
-			if (ncand > uint32_t(SEED_CAP)) ncand = SEED_CAP;
 			// Stage 2: diagonal de-duplication of the candidates, kept seeds -> `raw`
-			for (uint32_t c = lane; c < ncand; c += 64) {
-				const uint32_t cp = cand[c].x, ent = cand[c].y;
-				{
+			auto drain = [&](uint32_t ncand) __attribute__((always_inline)) {
+				wave_sync(); // the list was written by other lanes
+#ifdef TNT_EXP_STATS
+				const long long st_d0 = __builtin_readcyclecounter();
+#endif
+				for (uint32_t c = lane; c < ncand; c += 64) {
+					const uint32_t cp = cand[c].x, ent = cand[c].y;
 					const uint32_t wi = ent & 127u;
 					const uint32_t assay = ent >> WT_ASSAY_SHIFT;
 					const uint32_t li = (assay * 3u + ((ent >> 8) & 3u)) * 2u + ((ent & WT_MINUS) ? 1u : 0u);
 					const uint32_t kmax = wi < cp ? wi : cp;
 #ifndef TNT_EXP_NODEDUPE
 					bool first;
-					if ((ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) first = first_on_diagonal_packed(pk, a.wl_seq + 2 * li, wi, cp, a.word_size);
-					else first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
+					if ((ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) {
+						if (seq_lds) first = first_on_diagonal_packed(pk, s_seq + 2 * (li - a.assay_begin * 6u), wi, cp, a.word_size);
+						else first = first_on_diagonal_packed(pk, a.wl_seq + 2 * li, wi, cp, a.word_size);
+					} else {
+						first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
+					}
 					if (!first) continue;
 #endif
 					const uint32_t la = assay - a.assay_begin;
@@ -258,9 +272,94 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 						atomicAdd(reinterpret_cast<unsigned int *>(hist) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
 					}
 				}
-			}
-			wave_sync();
-			if (__builtin_amdgcn_ballot_w64(p < npos) == 0) break;
+				wave_sync();
+#ifdef TNT_EXP_STATS
+				st_drain += __builtin_readcyclecounter() - st_d0;
+#endif
+			};
+			// The position-by-position scan of [p_begin, p_end): every lane looks one position up per step and appends its
+			// (position, entry) candidates through an LDS counter; a full list is drained and the scan resumes where every
+			// lane stopped.  The only scan of the instance without LDS tables; the overflow path of the sweep below.
+			auto scan_slow = [&](uint32_t p_begin, uint32_t p_end) __attribute__((always_inline)) {
+				uint32_t p = p_begin + lane, e_done = 0;
+				while (true) {
+					if (lane == 0) s_ncand[wv] = 0;
+					wave_sync();
+					while (true) {
+						bool over = false;
+						if (p < p_end) {
+							const uint32_t w = target_word(pk, p, wmask);
+							const uint32_t e0 = uint32_t(LDS_TABLES ? s_wt_off[w] : a.wt_off[w]) + e_done, e1 = LDS_TABLES ? s_wt_off[w + 1] : a.wt_off[w + 1];
+							uint32_t fit = 0;
+							if (e1 > e0) {
+								const uint32_t at = atomicAdd(&s_ncand[wv], e1 - e0);
+								fit = at < uint32_t(SEED_CAP) ? (e1 - e0 < uint32_t(SEED_CAP) - at ? e1 - e0 : uint32_t(SEED_CAP) - at) : 0u;
+								for (uint32_t x = 0; x < fit; x++) cand[at + x] = make_uint2(p, LDS_TABLES ? s_wt_ent[e0 + x] : a.wt_ent[e0 + x]);
+							}
+							if (fit == e1 - e0) p += 64, e_done = 0;
+							else e_done += fit, over = true;
+						}
+						if (__builtin_amdgcn_ballot_w64(over) != 0 || __builtin_amdgcn_ballot_w64(p < p_end) == 0) break;
+					}
+					wave_sync();
+					uint32_t ncand = s_ncand[wv];
+					if (ncand > uint32_t(SEED_CAP)) ncand = SEED_CAP;
+					drain(ncand);
+					if (__builtin_amdgcn_ballot_w64(p < p_end) == 0) break;
+				}
+			};
+#ifdef TNT_EXP_OLDSCAN
+			if (!LDS_TABLES) {
+				scan_slow(pos0, npos);
+			} else
+#endif
+			{
+				// Sweeps of 64 x SEED_SWEEP positions: a lane loads the two packed words that hold its 16 positions (and the
+				// k - 1 bases behind them), extracts the 16 k-mers with shifts, reads their bucket bounds (all 32 reads in
+				// flight at once: from LDS, or from L2 in the instance without LDS tables) and counts its candidates; one
+				// wave-wide prefix sum gives every lane its slice of the candidate list.
+				uint32_t ncand = 0; // candidates in the list (wave-uniform)
+				for (uint32_t base = pos0 & ~uint32_t(SEED_SWEEP - 1); base < npos; base += 64 * SEED_SWEEP) {
+					const uint32_t p0 = base + uint32_t(lane) * SEED_SWEEP;
+					unsigned long long v = 0;
+					if (p0 < npos) v = (unsigned long long)pk[p0 >> 4] | ((unsigned long long)pk[(p0 >> 4) + 1] << 32);
+					uint32_t bnd[SEED_SWEEP]; // first entry | count << 16
+					uint32_t mine = 0;
+#pragma unroll
+					for (int q = 0; q < SEED_SWEEP; q++) {
+						const uint32_t w = uint32_t(v >> (2 * q)) & wmask;
+						const uint32_t e0 = LDS_TABLES ? s_wt_off[w] : a.wt_off[w], e1 = LDS_TABLES ? s_wt_off[w + 1] : a.wt_off[w + 1];
+						const uint32_t n = (p0 + q >= pos0 && p0 + q < npos) ? e1 - e0 : 0u;
+						bnd[q] = e0 | (n << 16);
+						mine += n;
+					}
+					uint32_t incl = mine;
+#pragma unroll
+					for (int d = 1; d < 64; d <<= 1) {
+						const uint32_t y = __shfl_up(incl, d);
+						if (lane >= d) incl += y;
+					}
+					const uint32_t total = __shfl(incl, 63);
+					if (total == 0) continue;
+					if (ncand + total > uint32_t(SEED_CAP)) { // make room
+						drain(ncand);
+						ncand = 0;
+					}
+					if (total > uint32_t(SEED_CAP)) { // a burst (buckets shared by many expanded assays): position by position
+						const uint32_t e = base + 64 * SEED_SWEEP;
+						scan_slow(base > pos0 ? base : pos0, e < npos ? e : npos);
+						continue;
+					}
+					uint32_t o = ncand + incl - mine;
+#pragma unroll
+					for (int q = 0; q < SEED_SWEEP; q++) {
+						uint32_t e = bnd[q] & 0xFFFFu;
+						for (uint32_t n = bnd[q] >> 16; n > 0; n--, e++) cand[o++] = make_uint2(p0 + q, LDS_TABLES ? s_wt_ent[e] : a.wt_ent[e]);
+					}
+					ncand += total;
+				}
+				wave_sync();
+				drain(ncand);
 			}
 		}
 		wave_sync();
@@ -358,58 +457,75 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 					const bool has_probe = (k & 16u) != 0, single = a.single_primer_pcr != 0;
 					const uint32_t role = key_role(k), loc = uint32_t(k >> 24);
 					const bool minus = k & 1u;
+					constexpr unsigned long long K_FLAGS = K_VALID | K_PHASE_B; // earlier rounds have flagged their keys already
+					// four keys of the segment per step (a key read twice changes nothing: every use is a minimum, a maximum or an "exists")
+					const uint32_t last = s0 + cnt - 1u;
+#define SEG4(X, O0, O1, O2, O3)                                                              \
+	const unsigned long long O0 = srt[s0 + (X)] & ~K_FLAGS,                                   \
+	                         O1 = srt[(s0 + (X) + 1u < last ? s0 + (X) + 1u : last)] & ~K_FLAGS, \
+	                         O2 = srt[(s0 + (X) + 2u < last ? s0 + (X) + 2u : last)] & ~K_FLAGS, \
+	                         O3 = srt[(s0 + (X) + 3u < last ? s0 + (X) + 3u : last)] & ~K_FLAGS
 					// nearest probe on the side where the partner primer must lie (a pair only counts with a probe between)
 					unsigned long long pnear = minus ? ~0ull : 0ull;
 					bool have_p = !has_probe;
 					if (has_probe && role != 2)
-						for (uint32_t x = 0; x < cnt; x++) {
-							const unsigned long long o = srt[s0 + x];
-							if (key_role(o) != 2) continue;
-							if (minus ? (o > k && o < pnear) : (o < k && o > pnear)) pnear = o, have_p = true;
+						for (uint32_t x = 0; x < cnt; x += 4) {
+							SEG4(x, o0, o1, o2, o3);
+							const unsigned long long os[4] = {o0, o1, o2, o3};
+#pragma unroll
+							for (int j = 0; j < 4; j++) {
+								const unsigned long long o = os[j];
+								if (key_role(o) != 2) continue;
+								if (minus ? (o > k && o < pnear) : (o < k && o > pnear)) pnear = o, have_p = true;
+							}
 						}
 					if (!has_probe) pnear = k; // the partner only has to lie on the right side of this seed
-					// closest partners: f = minus-strand primer before, r = plus-strand primer after (per oligo)
+					// One pass over the segment:
+					//  * the element FOLLOWING this one in list order (amplicon_search.cpp:748-755 counts its strand when this
+					//    seed is valid; past-the-end counts nothing);
+					//  * a primer is valid iff a partner exists: other strand, beyond the probe, allowed oligo, within reach
+					//    (the reference takes the closest partner per oligo; the closest one is within reach iff any is);
+					//  * a probe needs the closest primers on either side (per oligo).
+					unsigned long long next = ~0ull;
 					uint32_t f_loc[2] = {0, 0}, r_loc[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 					bool f_ok[2] = {false, false}, r_ok[2] = {false, false};
-					for (uint32_t x = 0; x < cnt; x++) {
-						const unsigned long long o = srt[s0 + x];
-						const uint32_t orole = key_role(o);
-						if (orole == 2) continue;
-						const uint32_t oloc = uint32_t(o >> 24);
-						const bool ominus = o & 1u;
-						if (role == 2) { // probe: primers on either side of me
-							if (ominus && o < k && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
-							if (!ominus && o > k && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
-						} else if (minus) { // I am an f: partners r beyond the probe
-							if (!ominus && o > pnear && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
-						} else { // I am an r: partners f before the probe
-							if (ominus && o < pnear && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
+					for (uint32_t x = 0; x < cnt; x += 4) {
+						SEG4(x, o0, o1, o2, o3);
+						const unsigned long long os[4] = {o0, o1, o2, o3};
+#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							const unsigned long long o = os[j];
+							if (o > k && o < next) next = o;
+							const uint32_t orole = key_role(o);
+							if (orole == 2) continue;
+							const uint32_t oloc = uint32_t(o >> 24);
+							const bool ominus = o & 1u;
+							if (role == 2) { // probe: primers on either side of me
+								if (ominus && o < k && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
+								if (!ominus && o > k && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
+							} else if (single || orole != role) {
+								if (minus) valid |= !ominus && o > pnear && oloc - loc <= threshold; // I am an f: partners r beyond the probe
+								else valid |= ominus && o < pnear && loc - oloc <= threshold;        // I am an r: partners f before the probe
+							}
 						}
 					}
+#undef SEG4
 					if (role == 2) {
+						valid = false;
 						for (int rf = 0; rf < 2; rf++)
 							for (int rr = 0; rr < 2; rr++)
 								if ((single || rf != rr) && f_ok[rf] && r_ok[rr] && r_loc[rr] - f_loc[rf] <= threshold) valid = true;
-					} else if (have_p) {
-						for (int ro = 0; ro < 2; ro++) {
-							if (!single && uint32_t(ro) == role) continue;
-							if (minus ? (r_ok[ro] && r_loc[ro] - loc <= threshold) : (f_ok[ro] && loc - f_loc[ro] <= threshold)) valid = true;
-						}
+					} else if (!have_p) {
+						valid = false;
+					}
+					if (valid) {
+						// strand of the list element FOLLOWING a valid one decides which strand is bound first (:131)
+						if (next != ~0ull) atomicAdd(&cmcp[la], (next & 1u) ? 1u : 0x10000u);
 					}
 				}
 				if (valid) {
 					k |= K_VALID;
 					atomicAdd(&nvna[la], 1u);
-					if (!(k & 8u)) {
-						// strand of the list element FOLLOWING a valid one (amplicon_search.cpp:748-755; past-the-end counts
-						// nothing) decides which strand is bound first (:131)
-						unsigned long long next = ~0ull;
-						for (uint32_t x = 0; x < cnt; x++) {
-							const unsigned long long o = srt[s0 + x] & ~(K_VALID | K_PHASE_B);
-							if (o > (k & ~(K_VALID | K_PHASE_B)) && o < next) next = o;
-						}
-						if (next != ~0ull) atomicAdd(&cmcp[la], (next & 1u) ? 1u : 0x10000u);
-					}
 				}
 				srt[i] = k;
 			}
@@ -595,6 +711,7 @@ __global__ __launch_bounds__(SEED_THREADS) void seed_kernel(SeedArgs a)
 #ifdef TNT_EXP_STATS
 	if (lane == 0 && a.debug) {
 		for (int q = 0; q < 6; q++) atomicAdd(a.debug + q, uint32_t(st_acc[q] >> 10));
+		atomicAdd(a.debug + 6, uint32_t(st_drain >> 10));
 		atomicAdd(a.debug + 7, 1u);
 	}
 #endif
