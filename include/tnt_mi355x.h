@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNT_ABI_VERSION 1
+#define TNT_ABI_VERSION 2
 
 /* Longest oligo the gfx950 bind kernel accepts: one wavefront lane per query
  * row (reference cap is MAX_SEQUENCE_LENGTH 1024, nuc_cruc.h:80).           */
@@ -231,6 +231,7 @@ int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hit
 typedef struct tnt_timing {
 	float seed_ms, bind_ms, pair_ms, total_ms;
 	uint64_t n_seeds, n_binds, n_bound, n_hits;
+	uint64_t n_filtered; /* of n_binds: windows the pre-filter rejected before the full bind kernel (their Tm cannot reach the minimum) */
 } tnt_timing;
 int tnt_last_timing(tnt_ctx *ctx, tnt_timing *out);
 
@@ -245,6 +246,13 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
  * anchors, num_mm, num_gap, loc5, loc3, align are set when status == 0; the other fields are -1 (0 for the window). */
 enum { TNT_ROUTE_UNIT = 0, TNT_ROUTE_BUCKETS = 1, TNT_ROUTE_MERGED = 2 };
 int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out, int route);
+
+/* Unit-level entry to the bind stage's pre-filter (tnt_filter.hip.h): for every request score[2k] = an upper bound, in
+ * 1e-4 kcal/mol, of -(dH - Tk dS) + constant over all alignments of the window at Tk = minimum Tm of the request's
+ * threshold set, score[2k+1] = the value it must reach for the window to go on to the full bind kernel (INT32_MIN: the
+ * filter is off for this threshold set); -1 / -1 for windows with a degenerate target base, which never meet the filter.
+ * bind_oligo_to_*_strand rejects what stays below on Tm (bind_oligo.cpp:600-606).                              */
+int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, int32_t *score);
 
 /* Oligo self-structure printed with every hit (tntblast_local.cpp:656-686): hairpin and homodimer Tm of oligo
  * `a` at strand(ct_a, ct_a), and, when `b` is given, the heterodimer Tm of query a / target b at

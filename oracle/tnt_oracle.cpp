@@ -1605,6 +1605,128 @@ int tntor_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assay
 }
 
 // a17: hairpin / homodimer Tm of one oligo and the heterodimer Tm of two (tntblast_local.cpp:656-686)
+// ---------------------------------------------------------------------------------------------------------
+// Checker of the product's bind pre-filter (thermonucleotideblast_amd/csrc/tnt_filter.hip.h): the same upper bound of
+// -(dH - Tk dS) over all alignments of a window, restated in the order evaluate_alignment reads an alignment
+// (nuc_cruc.cpp:1620-2299; the kernel sweeps the other way), on plain windows.  score[2k] = bound, score[2k+1] =
+// threshold of request k (INT32_MIN: this class is never rejected), both in 1e-4 kcal/mol; -1 / -1 when the window
+// holds a degenerate base (such windows never meet the filter).  tests/test_filter_bound.py holds it against
+// tntor_bind_batch ("accepted => bound >= threshold") and tests/test_gpu_parity.py against the kernel (equal integers).
+int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_oligos, const uint8_t *codes, const uint64_t *offsets,
+                       size_t n_targets, uint32_t first_seq_index, const tnt_bind_req *req, size_t n, int32_t *score)
+{
+	using namespace tor;
+	const Params &P = params();
+	const int NEG = -(1 << 28);
+	const double log_na = double(logf(opt->salt));
+	bool ok = !opt->allow_dangle_5 && !opt->allow_dangle_3 && !opt->use_dinkelbach && log_na <= 0.0;
+	for (int i = 0; i < 513; i++) ok = ok && P.loop_S[i] <= 0.0f && P.bulge_S[i] <= 0.0f;
+	ok = ok && P.asym_S <= 0.0f && P.bulge_at_S <= 0.0f;
+	for (int x = A; x <= I; x++)
+		for (int c = 0; c < NBP; c++)
+			if (c / NB <= I && c % NB <= I) {
+				const int g1 = x * NB + GAP, g2 = GAP * NB + x;
+				ok = ok && P.H[g1 * NBP + c] == 0.0f && P.S[g1 * NBP + c] == 0.0f && P.H[g2 * NBP + c] == 0.0f && P.S[g2 * NBP + c] == 0.0f;
+			}
+	struct Cls {
+		bool on;
+		float tk, theta0;
+		std::vector<int> fpos, close; // [prev pair * 49 + cur pair] in evaluate order
+	} cls[2];
+	const double min_tm[2] = {double(opt->min_primer_tm), double(opt->min_probe_tm)};
+	for (int k = 0; k < 2; k++) {
+		Cls &C = cls[k];
+		const double Tk = min_tm[k] + 273.15;
+		C.tk = float(Tk);
+		C.on = ok && min_tm[k] > 0.0 && min_tm[k] < 150.0;
+		C.fpos.assign(NBP * NBP, 0);
+		C.close.assign(NBP * NBP, NEG);
+		if (!C.on) continue;
+		const double sc = double(P.salt) * log_na;
+		auto phi = [&](int prev, int cur) { return -(double(P.H[prev * NBP + cur]) - Tk * (double(P.S[prev * NBP + cur]) + sc)); };
+		double pb1 = -Tk * double(P.bulge_S[1]), pb2 = 1.0e30, pl3 = 1.0e30;
+		// bulges up to the longest window, loops up to 2 x 64 mismatches + the window (entry 512 of both tables is 0 in the
+		// reference, nuc_cruc_santa_lucia.cpp:670,720; no 64-mer reaches it)
+		for (int z = 2; z <= TNT_MAX_WINDOW; z++) pb2 = std::min(pb2, -Tk * double(P.bulge_S[z]));
+		for (int z = 3; z <= 2 * TNT_MAX_OLIGO + TNT_MAX_WINDOW; z++) pl3 = std::min(pl3, -Tk * double(P.loop_S[z]));
+		pl3 += -Tk * double(P.asym_S);
+		const double gap_price = std::min(std::min(pb2, pl3), pb1);
+		for (int prev = 0; prev < NBP; prev++)
+			for (int cur = 0; cur < NBP; cur++) {
+				if (prev / NB > I || prev % NB > I || cur / NB > I || cur % NB > I) continue;
+				const double f = phi(prev, cur);
+				C.fpos[prev * NBP + cur] = int(std::ceil(((P.wc[prev] || P.wc[cur]) ? std::max(f, 0.0) : 0.0) * 10000.0));
+				if (!P.wc[cur]) continue; // a loop / bulge closes on a Watson-Crick column
+				double u1 = -1.0e30;
+				for (int pm = 0; pm < NBP; pm++)
+					if (P.wc[pm] && pm / NB <= I && pm % NB <= I) u1 = std::max(u1, phi(pm, cur));
+				u1 += gap_price - pb1;
+				C.close[prev * NBP + cur] = int(std::ceil((std::max(std::max(f, 0.0), u1) - gap_price) * 10000.0));
+			}
+		const double g_init = double(P.init_H) - Tk * double(P.init_S), g_at = double(P.at_H) - Tk * double(P.at_S);
+		C.theta0 = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02);
+	}
+#pragma omp parallel for schedule(dynamic, 256)
+	for (long k = 0; k < long(n); k++) {
+		const tnt_bind_req &r = req[k];
+		score[2 * k] = score[2 * k + 1] = -1;
+		const size_t t = size_t(r.seq_index) - first_seq_index;
+		if (t >= n_targets || r.oligo < 0 || r.oligo >= n_oligos) continue;
+		const std::string q = oligos[r.oligo];
+		const int L = int(q.size());
+		const uint8_t *seq = codes + offsets[t];
+		const unsigned seq_len = unsigned(offsets[t + 1] - offsets[t]);
+		const unsigned start = unsigned(std::max(int(r.target_loc) - int(r.query_loc + TNT_FLANK), 0));
+		const unsigned stop = std::min(start + unsigned(L) + 2 * TNT_FLANK, seq_len);
+		bool plain = true;
+		for (unsigned p = start; p < stop; p++) plain = plain && seq[p] <= 3;
+		if (!plain) continue;
+		// the window as NucCruc sees it (bind_oligo.cpp:524-573 / :1227-1276) ...
+		std::vector<int> tg;
+		for (unsigned p = start; p < stop; p++) tg.push_back(r.strand == TNT_MINUS ? 3 - int(seq[p]) : int(seq[p]));
+		if (r.strand == TNT_MINUS) std::reverse(tg.begin(), tg.end());
+		// ... read in pairing order: query 5'->3' against the target 3'->5'
+		std::reverse(tg.begin(), tg.end());
+		const int W = int(tg.size());
+		std::vector<int> qb(L);
+		for (int a = 0; a < L; a++) qb[a] = int(char_to_base(q[a]));
+		const Cls &C = cls[r.role == 1 ? 1 : 0];
+		// X: best helix value ending in (a, b); LP: best value inside a loop / bulge that left its diagonal, gap price paid
+		std::vector<int> X(size_t(L + 1) * (W + 1), 0), LP(size_t(L + 1) * (W + 1), NEG);
+		const double gp_unused = 0.0;
+		(void)gp_unused;
+		int best = 0;
+		auto at = [&](int a, int b) { return size_t(a) * (W + 1) + b; };
+		// recompute the gap price in integers the way the tables hold it: close[] already carries "- gap_price", so the entry
+		// into LP from a helix cell is free here and the price is paid on the way out
+		for (int a = 1; a <= L; a++)
+			for (int b = 1; b <= W; b++) {
+				const int cur = qb[a - 1] * NB + tg[b - 1];
+				int x = 0, lp = NEG;
+				if (a > 1 && b > 1) {
+					const int prev = qb[a - 2] * NB + tg[b - 2];
+					x = std::max(X[at(a - 1, b - 1)] + C.fpos[prev * NBP + cur], LP[at(a - 1, b - 1)] + C.close[prev * NBP + cur]);
+					lp = LP[at(a - 1, b - 1)];
+				}
+				x = std::max(x, 0);
+				lp = std::max(lp, std::max(LP[at(a - 1, b)], LP[at(a, b - 1)]));
+				lp = std::max(lp, std::max(X[at(a - 1, b)], X[at(a, b - 1)]));
+				X[at(a, b)] = x;
+				LP[at(a, b)] = lp;
+				best = std::max(best, x);
+			}
+		score[2 * k] = best;
+		if (C.on) {
+			const float log_ct = logf((r.ct - 0.5f * 0.0f) * 1.0f);
+			const float th = C.theta0 - C.tk * (1.9872e-3f * log_ct);
+			score[2 * k + 1] = int(floorf(th * 10000.0f)) - 1;
+		} else {
+			score[2 * k + 1] = INT32_MIN;
+		}
+	}
+	return 0;
+}
+
 int tntor_oligo_structure(const tnt_options *opt, const char *oligo, float ct, float *hairpin_tm, float *homodimer_tm)
 {
 	try {

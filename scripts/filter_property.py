@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""The soundness property of the bind pre-filter (tests/test_filter_bound.py) on N windows per option set
+(default 1 000 000): prints one JSON record per option set.  CPU only (oracle)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_filter_bound as T  # noqa: E402
+import tntcheck as tc  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+chunk = 100000
+ora = tc.OracleImpl()
+for k, (name, kw) in enumerate(T.OPTION_SETS):
+    tot = None
+    for part in range((n + chunk - 1) // chunk):
+        r = T.check_option_set(ora, name, kw, min(chunk, n - part * chunk), 1000 * (k + 1) + part)
+        if tot is None:
+            tot = r
+        else:
+            for key in ("windows", "with_alignment", "accepted", "rejected_by_filter"):
+                tot[key] += r[key]
+            tot["min_slack_kcal"] = min(tot["min_slack_kcal"], r["min_slack_kcal"])
+    tot.pop("reject_rate_of_non_accepted", None)
+    tot["violations"] = 0
+    print(json.dumps(tot), flush=True)

@@ -11,5 +11,5 @@ db = eng.pack(wl.codes, wl.offsets)
 for rep in range(3):
     t = time.perf_counter(); hits = eng.search(db); dt = time.perf_counter() - t
     tm = eng.timing()
-print("%s cfg %d nt %d: wall %.1f ms seed %.1f bind %.1f pair %.1f | binds %d groups %d bound %d hits %d" % (
-    os.path.basename(os.environ.get("TNT_MI355X_LIB", "default")), cfg, nt, dt * 1e3, tm.seed_ms, tm.bind_ms, tm.pair_ms, tm.n_binds, tm.n_seeds, tm.n_bound, len(hits)))
+print("%s cfg %d nt %d: wall %.1f ms seed %.1f bind %.1f pair %.1f | binds %d filtered %d groups %d bound %d hits %d" % (
+    os.path.basename(os.environ.get("TNT_MI355X_LIB", "default")), cfg, nt, dt * 1e3, tm.seed_ms, tm.bind_ms, tm.pair_ms, tm.n_binds, tm.n_filtered, tm.n_seeds, tm.n_bound, len(hits)))

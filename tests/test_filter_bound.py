@@ -1,0 +1,120 @@
+"""CPU: soundness of the bind pre-filter (thermonucleotideblast_amd/csrc/tnt_filter.hip.h), checked on its oracle-side
+restatement (tntor_filter_bound; the GPU suite holds the kernel against that restatement integer by integer).
+
+Property: a window the reference's algorithm accepts (valid alignment, Tm >= the minimum) always has bound >= threshold,
+so the filter never rejects it.  Checked in the stronger form "the bound is an upper bound of -(dH - Tk dS) + constant of
+the best alignment of EVERY window that has one", which gives every random window a say, not only the accepted ones.
+Windows: random oligos against sites with substitutions, deletions and insertions (bulges, internal loops), clipped at
+the target ends, both strands; option sets with different minimum Tm, salt, temperature and strand concentrations.
+
+The in-suite size is TNT_FILTER_PROPERTY_N windows per option set (default 40 000); scripts/filter_property.py runs the same
+check on >= 1 000 000 per set and logs it under profiles/."""
+import os
+
+import numpy as np
+import pytest
+
+import tntcheck as tc
+from thermonucleotideblast_amd import abi, synth
+
+OPTION_SETS = [
+    ("default -e 40 -E 40", dict(min_primer_tm=40.0, min_probe_tm=40.0)),
+    ("-e 55 -E 48, 0.2 M salt", dict(min_primer_tm=55.0, min_probe_tm=48.0, salt=0.2)),
+    ("-e 30 -E 35, 0.9 M salt, 300 K", dict(min_primer_tm=30.0, min_probe_tm=35.0, salt=0.9, target_t=300.0)),
+    ("-e 20 -E 62, 10 mM salt, 333 K", dict(min_primer_tm=20.0, min_probe_tm=62.0, salt=0.01, target_t=333.15)),
+    ("-e 45 -E 45, asymmetric Ct", dict(min_primer_tm=45.0, min_probe_tm=45.0, primer_strand=2.0e-6, probe_strand=5.0e-8)),
+]
+
+
+def make_windows(rng, n, lo=12, hi=40):
+    oligos = sorted({synth._rand_oligo(rng, lo, hi) for _ in range(64)})
+    targets, rows = [], []
+    for t in range(n):
+        o = int(rng.integers(0, len(oligos)))
+        q = oligos[o]
+        minus = rng.random() < 0.5
+        site = list(q) if minus else list(synth.revcomp(q))
+        kind = rng.random()
+        n_edit = 0 if kind < 0.15 else int(rng.integers(1, 7))
+        if kind > 0.9:  # unrelated sequence with a short seed of the site
+            keep = int(rng.integers(0, len(site) - 7))
+            site = ["ACGT"[i] for i in rng.integers(0, 4, len(site))]
+            site[keep:keep + 8] = (list(q) if minus else list(synth.revcomp(q)))[keep:keep + 8]
+        for _ in range(n_edit):
+            k = int(rng.integers(0, len(site)))
+            r = rng.random()
+            if r < 0.55:
+                site[k] = "ACGT"[int(rng.integers(0, 4))]
+            elif r < 0.8 and len(site) > 10:
+                del site[k:k + int(rng.integers(1, 4))]
+            else:
+                site[k:k] = ["ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 4)))]
+        left, right = int(rng.integers(0, 10)), int(rng.integers(0, 10))
+        seq = "".join("ACGT"[i] for i in rng.integers(0, 4, left)) + "".join(site) + "".join("ACGT"[i] for i in rng.integers(0, 4, right))
+        targets.append(seq)
+        ql = int(rng.integers(0, max(1, len(q) - 7)))
+        role = int(rng.integers(0, 2))
+        rows.append((t, o, abi.MINUS if minus else abi.PLUS, ql, min(len(seq) - 1, left + ql), role, None))
+    return oligos, targets, rows
+
+
+def check_option_set(oracle, name, kw, n, seed):
+    rng = np.random.default_rng([2024, seed])
+    opt = abi.options_default(**kw)
+    oligos, targets, rows = make_windows(rng, n)
+    rows = [r[:6] + ((opt.probe_strand if r[5] else opt.primer_strand),) for r in rows]
+    codes = np.concatenate([synth.encode(t) for t in targets])
+    offsets = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
+    reqs = tc.make_reqs(rows)
+    out = oracle.bind_batch(opt, oligos, codes, offsets, reqs)
+    fb = oracle.filter_bound(opt, oligos, codes, offsets, reqs)
+    role = np.array([r[5] for r in rows])
+    min_tm = np.where(role == 1, opt.min_probe_tm, opt.min_primer_tm).astype(np.float64)
+    ct = np.where(role == 1, opt.probe_strand, opt.primer_strand).astype(np.float64)
+    valid = np.array([b.valid for b in out]) > 0
+    tm = np.array([b.tm for b in out], dtype=np.float64)
+    dH = np.array([b.dH for b in out], dtype=np.float64)
+    dS = np.array([b.dS for b in out], dtype=np.float64)
+    bound, theta = fb[:, 0].astype(np.int64), fb[:, 1].astype(np.int64)
+    accepted = valid & (tm >= min_tm)
+    rejected = bound < theta
+    assert accepted.sum() > n // 50, (name, int(accepted.sum()))
+    bad = np.nonzero(accepted & rejected)[0]
+    assert len(bad) == 0, "%s: the filter rejects %d accepted windows, e.g. request %r bound %d theta %d tm %.3f" % (
+        name, len(bad), rows[bad[0]], bound[bad[0]], theta[bad[0]], tm[bad[0]])
+    # stronger: bound >= -(dH - Tk dS) + G_init + min(0, 2 G_AT) - margin for every window with an alignment
+    Tk = min_tm + 273.15
+    g_init = 0.2 - Tk * (-5.6746737e-3)
+    g_at = 2.2 - Tk * 6.9321301e-3
+    phi = -(dH - Tk * dS) + g_init + np.minimum(0.0, 2.0 * g_at)
+    slack = bound / 1.0e4 - phi
+    worst = slack[valid].min()
+    assert worst > -0.02, "%s: bound below the scored alignment by %.4f kcal/mol" % (name, -worst)
+    return {"name": name, "windows": n, "with_alignment": int(valid.sum()), "accepted": int(accepted.sum()),
+            "rejected_by_filter": int(rejected.sum()), "min_slack_kcal": float(worst),
+            "reject_rate_of_non_accepted": float(rejected[~accepted].mean())}
+
+
+@pytest.mark.parametrize("k", range(len(OPTION_SETS)))
+def test_filter_never_rejects_an_accepted_window(oracle, k):
+    n = int(os.environ.get("TNT_FILTER_PROPERTY_N", "40000"))
+    name, kw = OPTION_SETS[k]
+    res = check_option_set(oracle, name, kw, n, k)
+    assert res["rejected_by_filter"] > 0  # the filter does something
+
+
+def test_filter_is_off_where_its_premises_fail(oracle):
+    rng = np.random.default_rng(5)
+    oligos, targets, rows = make_windows(rng, 200)
+    codes = np.concatenate([synth.encode(t) for t in targets])
+    offsets = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
+    reqs = tc.make_reqs([r[:6] + (9.0e-7,) for r in rows])
+    for kw in (dict(min_primer_tm=0.0, min_probe_tm=0.0), dict(allow_dangle_5=1, min_primer_tm=40.0, min_probe_tm=40.0),
+               dict(allow_dangle_3=1, min_primer_tm=40.0, min_probe_tm=40.0)):
+        fb = oracle.filter_bound(abi.options_default(**kw), oligos, codes, offsets, reqs)
+        assert (fb[:, 1] == np.iinfo(np.int32).min).all(), kw
+    # a degenerate target base takes the window out of the filter's reach
+    codes2 = codes.copy()
+    codes2[int(offsets[3]) + 12] = abi.DB_CODES.index("N")
+    fb = oracle.filter_bound(abi.options_default(min_primer_tm=40.0, min_probe_tm=40.0), oligos, codes2, offsets, reqs)
+    assert tuple(fb[3]) == (-1, -1)

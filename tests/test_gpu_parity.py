@@ -29,7 +29,7 @@ def _oligo_set(expanded):
 def test_native_library_is_loaded(Engine):
     from thermonucleotideblast_amd import engine
     lib = engine.load_library()
-    assert lib.tnt_abi_version() == 1
+    assert lib.tnt_abi_version() == 2
     assert any("libtnt_mi355x.so" in line for line in open("/proc/self/maps"))
 
 
@@ -147,6 +147,61 @@ def test_random_windows_production_vs_oracle(Engine, oracle, seed, kw):
         assert not bad, "route %d: %d of %d differ, first %r" % (route, len(bad), len(want), bad[:2])
     db.close()
     e.close()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 4])
+def test_filter_kernel_equals_its_checker(Engine, oracle, k):
+    """The pre-filter kernel (every row-count instance the oligo lengths pick) against the oracle-side restatement whose
+    soundness tests/test_filter_bound.py checks: same bound, same threshold, for every window."""
+    import test_filter_bound as fbt
+    name, kw = fbt.OPTION_SETS[k]
+    rng = np.random.default_rng([99, k])
+    opt = abi.options_default(**kw)
+    oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=64)
+    if k == 2:  # some degenerate target bases: those windows are outside the filter
+        targets = [t if i % 7 else t[:5] + "N" + t[6:] for i, t in enumerate(targets)]
+    rows = [r[:6] + ((opt.probe_strand if r[5] else opt.primer_strand),) for r in rows]
+    codes, offsets = gu.pack_targets(targets)
+    e = Engine(opt, [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(oligos)])
+    om = {o: i for i, o in enumerate(e.oligos)}
+    db = e.pack(codes, offsets)
+    got = e.filter_bound(db, tc.make_reqs((r[0], om[oligos[r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in rows))
+    want = oracle.filter_bound(opt, oligos, codes, offsets, tc.make_reqs(rows))
+    assert (want[:, 0] >= 0).sum() > 4000
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, "%s: %d of %d differ, first %r got %r want %r" % (name, len(bad), len(rows), rows[bad[0]], got[bad[0]], want[bad[0]])
+    db.close()
+    e.close()
+
+
+def test_filter_changes_no_result(Engine, oracle, monkeypatch):
+    """The same searches with the pre-filter on, off and in audit mode (everything is bound and the bind kernel raises an
+    error if it accepts a window the filter marked): identical hits, and the filter does reject most windows."""
+    for cfg, nt, na, kw in [(2, 30000, 96, {}), (3, 20000, 96, dict(min_primer_tm=50.0, min_probe_tm=45.0)), (5, 6000, 200, {})]:
+        wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=31)
+        for k_, v_ in kw.items():
+            setattr(wl.options, k_, v_)
+        res = {}
+        for mode in ("on", "off", "audit"):
+            monkeypatch.delenv("TNT_MI355X_NO_FILTER", raising=False)
+            monkeypatch.delenv("TNT_MI355X_FILTER_AUDIT", raising=False)
+            if mode == "off":
+                monkeypatch.setenv("TNT_MI355X_NO_FILTER", "1")
+            if mode == "audit":
+                monkeypatch.setenv("TNT_MI355X_FILTER_AUDIT", "1")
+            e = Engine(wl.options, wl.expanded)
+            db = e.pack(wl.codes, wl.offsets)
+            res[mode] = tc.sorted_hit_keys(e.search(db))
+            tm = e.timing()
+            if mode == "on":
+                assert tm.n_filtered > tm.n_binds // 2, (cfg, tm.n_filtered, tm.n_binds)
+            else:
+                assert tm.n_filtered == 0
+            db.close()
+            e.close()
+        assert res["on"] == res["off"] == res["audit"] and len(res["on"]) > 0
+        if cfg == 2:
+            assert res["on"] == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
 
 
 def test_g3_structure_golden(Engine):

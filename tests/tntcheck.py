@@ -189,6 +189,19 @@ class _CpuImpl:
         assert rc == 0, self.error()
         return out
 
+    def filter_bound(self, opt, oligos, codes, offsets, reqs, first=0):
+        """Checker of the bind pre-filter (oracle only): (n, 2) int32 array of [bound, threshold] per request."""
+        codes, pc = as_u8(codes)
+        offsets, po = as_u64(offsets)
+        out = np.zeros((len(reqs), 2), dtype=np.int32)
+        f = self.lib.tntor_filter_bound
+        f.argtypes = [C.POINTER(abi.tnt_options), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
+                      C.c_size_t, C.c_uint32, C.POINTER(abi.tnt_bind_req), C.c_size_t, C.POINTER(C.c_int32)]
+        rc = f(C.byref(opt), c_strings(oligos), len(oligos), pc, po, len(offsets) - 1, first, reqs, len(reqs),
+               out.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert rc == 0, self.error()
+        return out
+
     def search(self, opt, expanded, codes, offsets, first=0, threads=0):
         codes, pc = as_u8(codes)
         offsets, po = as_u64(offsets)

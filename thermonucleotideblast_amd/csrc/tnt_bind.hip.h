@@ -53,6 +53,7 @@ struct BindArgs {
 	uint32_t *active;
 	uint32_t *n_active;
 	uint32_t *debug;           // experimental builds only (TNT_EXP_STATS)
+	const uint8_t *audit;      // optional (audit mode of the pre-filter): 1 = the filter would have rejected this item
 };
 
 constexpr int TIE_CAP = 256;      // maximal cells of one DP beyond which the kernel reports ERR_TIE_OVERFLOW
@@ -1124,6 +1125,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 		char *text = nullptr;
 		int32_t res = -status;
 		BoundRec *rec = nullptr;
+		if (!FULL && status == 0 && a.audit && a.audit[idx]) atomicOr(a.err, ERR_FILTER_UNSOUND);
 		if (status == 0 && !FULL) {
 			const uint32_t slotp = atomicAdd(a.pool_count, 1u);
 			if (slotp < a.pool_cap) {

@@ -4,9 +4,10 @@
 // instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows) so they build
 // in parallel; compiled once without the macro it provides all of them.
 #include "tnt_bind.hip.h"
+#include "tnt_filter.hip.h"
 
 #ifndef TNT_INST_LIST
-#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_EXACT_LADDER(E)
+#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F)
 #endif
 
 namespace tnt {
@@ -16,6 +17,11 @@ namespace tnt {
 	{                                                                                                                \
 		hipLaunchKernelGGL((bind_kernel<N, false, EXACT, PLAIN>), dim3(blocks), dim3(bind_threads_for(N, PLAIN)), 0, stream, a); \
 	}
+#define F(N)                                                                                                         \
+	void launch_filter_##N(const FilterArgs2 &a, int blocks, hipStream_t stream)                                     \
+	{                                                                                                                \
+		hipLaunchKernelGGL((filter_kernel<N>), dim3(blocks), dim3(256), 0, stream, a);                                \
+	}
 #define G(N) TNT_LAUNCHER(launch_bind_##N, N, false, false)
 #define P(N) TNT_LAUNCHER(launch_bind_plain_##N, N, false, true)
 #define E(N) TNT_LAUNCHER(launch_bind_exact_##N, N, true, true)
@@ -23,5 +29,6 @@ TNT_INST_LIST
 #undef G
 #undef P
 #undef E
+#undef F
 
 } // namespace tnt

@@ -89,6 +89,8 @@ struct Slot {
 // ... and a ladder (L <= LMAX) in two flavours: plain windows (A/C/G/T targets) for the other lengths, and
 // general ones for windows with degenerate target bases and for short queues that are bound in one launch
 #define TNT_LMAX_LADDER(X) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
+// instances of the pre-filter kernel (tnt_filter.hip.h): the row counts of both ladders above
+#define TNT_FILTER_LADDER(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
 constexpr int MAX_BUCKETS = 48;
 constexpr int BUCKET_EXACT = 0x100, BUCKET_PLAIN = 0x200; // flags on the instance id kept by the host (lmax | flags)
 
@@ -224,7 +226,8 @@ __device__ __forceinline__ void shard_prefix(const uint32_t *counts, uint32_t *p
 
 // status word set by kernels
 constexpr uint32_t ERR_SEED_OVERFLOW = 1, ERR_ITEM_OVERFLOW = 2, ERR_POOL_OVERFLOW = 4, ERR_HIT_OVERFLOW = 8,
-                   ERR_GROUP_OVERFLOW = 16, ERR_LIST_OVERFLOW = 32, ERR_STACK_OVERFLOW = 64, ERR_TIE_OVERFLOW = 128;
+                   ERR_GROUP_OVERFLOW = 16, ERR_LIST_OVERFLOW = 32, ERR_STACK_OVERFLOW = 64, ERR_TIE_OVERFLOW = 128,
+                   ERR_FILTER_UNSOUND = 256; // audit mode: the pre-filter would have rejected a window the bind kernel accepts
 
 } // namespace tnt
 #endif

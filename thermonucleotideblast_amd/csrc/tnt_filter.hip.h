@@ -1,0 +1,215 @@
+// tnt_filter.hip.h -- gfx950 pre-filter of the bind stage: a cheap, SOUND upper bound of the stability any alignment
+// of an (oligo, window) pair can reach, used to reject windows that cannot pass the minimum-Tm threshold before the
+// full bind kernel (DP with traces, traceback, enumeration, scoring: tnt_bind.hip.h) looks at them.
+//
+// Why it is sound (DESIGN.md section 4.2a has the derivation term by term against nuc_cruc.cpp:1620-2299):
+// bind_oligo_to_*_strand accepts a window only if Tm >= min_tm (bind_oligo.cpp:600-606).  With dH < 0 required
+// (nuc_cruc.cpp:2253) and Tm = dH / (R ln Ct + dS) - 273.15 (:2291) that means  -(dH - Tk dS) >= -Tk R ln Ct  at
+// Tk = min_tm + 273.15.  evaluate_alignment builds dH, dS from
+//   * a constant (initiation) and at most two terminal-AT terms,
+//   * one nearest-neighbour stack per column that is not inside a loop (plus its share of the salt term),
+//   * per loop / bulge: an entropy penalty, and terminal stacks that are the stacks of the DIAGONALLY adjacent cells.
+// So  Phi = -(dH - Tk dS) + const  is bounded by the best path through a small automaton over the cells of the window:
+//   X(i,j)  best helix value ending in cell (i,j): the stacks along a diagonal, each counted only when favourable
+//           (a negative stack is dropped: that also covers every loop that returns to its diagonal, for which the
+//           reference charges as little as nothing: loop_S[2] = 0)
+//   M2(i,j) best value inside a loop / bulge that has left its diagonal; it is entered from a helix cell at the price of
+//           the cheapest bulge / asymmetric loop and left through a diagonal step that earns the adjacent stack, or the
+//           best stack across a single-base bulge.
+// Everything is integer (1e-4 kcal/mol), table entries rounded towards "more stable", and the threshold carries a margin
+// for the float32 rounding of the reference's sums.  A window whose bound stays below the threshold is rejected with
+// the status the full kernel would have given it (Tm too low); every other window goes on to the full kernel, so the
+// filter can only cost time, never change a result.  tests/test_filter_bound.py checks "accepted => bound >= threshold"
+// on millions of random windows against the oracle.
+#ifndef TNT_FILTER_HIP_H
+#define TNT_FILTER_HIP_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tnt_dev.h"
+
+namespace tnt {
+
+constexpr int FILT_X = 5;                        // target base of a column: A C G T, 4 = none (before the first column / behind the window)
+constexpr int FILT_ENTRIES = FILT_X * FILT_X * NBP; // index ((x' * 5 + x) * 49 + q' * 7 + q): previous column / row = (x', q'), current = (x, q)
+constexpr int FILT_PLANE = 20 * 64;              // ints per plane (>= FILT_ENTRIES, a multiple of 64 for ds_read2st64_b32)
+constexpr int FILT_CLASSES = 2;                  // threshold sets by minimum Tm: primers, probes
+constexpr int32_t FILT_NEG = -(1 << 28);
+
+// host-built tables of one context (tnt_host.hip, fill_filter_tables)
+struct FilterTables {
+	int32_t plane[FILT_CLASSES][2][FILT_PLANE]; // [class][0] stack counted when favourable; [1] entry into a loop through this diagonal step, minus the gap price
+	float tk[FILT_CLASSES];                     // min_tm + 273.15
+	float theta0[FILT_CLASSES];                 // threshold without the strand-concentration term, kcal/mol (margin included)
+	int32_t enabled[FILT_CLASSES];              // 0: windows of this class are never rejected
+};
+
+struct FilterArgs2 {
+	const FilterTables *tab;
+	DbView db;
+	const uint32_t *olig_q4;   // [n][MAX_OLIGO/4] reversed oligo, one byte per row = 4 * base code (as the bind kernel reads it)
+	const int32_t *olig_len;
+	const Slot *slots;
+	const Thresh *thresh;
+	const Item *items;
+	const uint32_t *index;          // work list (one length bucket of a phase queue) ...
+	const uint32_t *index_base_dev; // ... starting at index[*index_base_dev]
+	const uint32_t *n_items_dev;
+	uint32_t n_items;               // cap on the device count
+	uint32_t *survivors;            // out: the indices that go on to the full kernel, written from survivors[*index_base_dev]
+	uint32_t *n_survivors;          // out: their number (device counter, zeroed by the host)
+	int32_t *result;                // rejected windows get their status here (-1: Tm below the minimum)
+	uint32_t *n_rejected;           // statistics: windows rejected here (device counter)
+	uint8_t *audit;                 // optional: audit mode marks what the filter would reject and lets everything through
+	int32_t *score_out;             // optional (unit-level entry): bound and threshold per item, [2 * idx]
+};
+
+// bits 0-1 of Thresh index -> class: 0 primer thresholds, 1..3 probe thresholds (tnt_host.hip builds th[0..3])
+__device__ __forceinline__ int filter_class(int thresh_index) { return thresh_index == 0 ? 0 : 1; }
+
+template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterArgs2 a)
+{
+	constexpr int THREADS = 256;
+	constexpr int WMAX = LMAX + 2 * FLANK;
+	__shared__ int32_t s_tab[FILT_CLASSES * 2 * FILT_PLANE];
+	__shared__ uint8_t s_win[WMAX * THREADS];
+
+	const int tid = threadIdx.x;
+	for (int i = tid; i < FILT_CLASSES * 2 * FILT_PLANE; i += THREADS) s_tab[i] = (&a.tab->plane[0][0][0])[i];
+	__syncthreads();
+
+	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
+	uint32_t *surv = a.survivors ? a.survivors + (a.index_base_dev ? *a.index_base_dev : 0u) : nullptr;
+	uint32_t n_items = a.n_items;
+	if (a.n_items_dev) {
+		const uint32_t n_dev = *a.n_items_dev;
+		n_items = n_dev < n_items ? n_dev : n_items;
+	}
+	uint8_t *win = s_win + tid;
+
+	for (uint32_t base = blockIdx.x * THREADS; base < n_items; base += gridDim.x * THREADS) {
+		const bool active = base + tid < n_items;
+		const uint32_t idx = active ? index[base + tid] : 0u;
+		const Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
+		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
+		const int L = active ? a.olig_len[slot.oligo] : 0;
+		const bool minus = (it.info & ITEM_MINUS) != 0;
+		const int qloc = int(it.info & 127u);
+		const uint32_t tlen = active ? a.db.len[it.target] : 0u;
+		// window, bind_oligo.cpp:502-505; plain windows only (the bucket pass routes windows with degenerate bases elsewhere)
+		int start = int(it.tloc) - (qloc + FLANK);
+		if (start < 0) start = 0;
+		int stop = start + L + 2 * FLANK;
+		if (stop > int(tlen)) stop = int(tlen);
+		const int W = active ? stop - start : 0;
+		if (active) {
+			const uint32_t *pk = a.db.packed + a.db.word_off[it.target];
+			for (int r = 0; r < W; r++) {
+				const int pos = start + r;
+				const int code = int((pk[pos >> 4] >> ((pos & 15) * 2)) & 3u);
+				// minus-strand binding: complement, reversed (bind_oligo.cpp:524-573); plus: as is (:1227-1276)
+				if (minus) win[(W - 1 - r) * THREADS] = uint8_t(3 - code);
+				else win[r * THREADS] = uint8_t(code);
+			}
+		}
+		// per-row part of the table address, 4 * (7 * q' + q): q' = base of the row above (none above row 1), rows behind
+		// the oligo are "none" as well (their entries add nothing and open nothing)
+		uint32_t Rpk[(LMAX + 3) / 4];
+		{
+			uint32_t qprev = bGAP;
+#pragma unroll
+			for (int w = 0; w < (LMAX + 3) / 4; w++) {
+				const uint32_t q4w = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + w] : 0u;
+				uint32_t r = 0;
+#pragma unroll
+				for (int b = 0; b < 4; b++) {
+					const int i = w * 4 + b; // row i + 1
+					uint32_t q = (q4w >> (b * 8 + 2)) & 7u;
+					if (i >= L) q = bGAP;
+					r |= (4u * (7u * qprev + q)) << (b * 8);
+					qprev = q;
+				}
+				Rpk[w] = r;
+			}
+		}
+		const int cls = filter_class(slot.thresh);
+		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * (2 * FILT_PLANE * 4);
+
+		int X[LMAX], M2[LMAX];
+#pragma unroll
+		for (int i = 0; i < LMAX; i++) X[i] = 0, M2[i] = FILT_NEG;
+		int best = 0;
+		int Wwave = W;
+		for (int o = 32; o > 0; o >>= 1) {
+			const int other = __shfl_xor(Wwave, o);
+			Wwave = other > Wwave ? other : Wwave;
+		}
+		int pt = 4; // target base of the previous column (none)
+#pragma unroll 1
+		for (int j = 1; j <= Wwave; j++) {
+			const int t = j <= W ? int(win[(j - 1) * THREADS]) : 4;
+			const int colbase = tab_base + (pt * FILT_X + t) * (NBP * 4);
+#pragma unroll
+			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
+			int dX = 0, dM = FILT_NEG; // the cell above row 1 in the previous column
+			int upM = FILT_NEG;        // M2 of the row above in this column
+			int colmax = 0;
+#pragma unroll
+			for (int i = 1; i <= LMAX; i++) {
+				const int r4 = int((Rpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 255u);
+				const int ea = colbase + r4;
+				typedef __attribute__((address_space(3))) const int lds_cint;
+				const int fp = *(lds_cint *)(uintptr_t(uint32_t(ea)));
+				const int gp = *(lds_cint *)(uintptr_t(uint32_t(ea + 4 * FILT_PLANE)));
+				const int oldX = X[i - 1], oldM = M2[i - 1]; // (i, j-1)
+				const int mUL = upM > oldM ? upM : oldM;
+				const int a1 = dX + fp;
+				const int a2 = dX + gp;
+				const int nX = a1 > mUL ? a1 : mUL;
+				int nM = dM > mUL ? dM : mUL;
+				nM = nM > a2 ? nM : a2;
+				colmax = colmax > nX ? colmax : nX;
+				dX = oldX, dM = oldM;
+				X[i - 1] = nX, M2[i - 1] = nM;
+				upM = nM;
+			}
+			best = best > colmax ? best : colmax;
+			pt = t;
+		}
+
+		// threshold of this item: theta0 of its class - Tk * R * ln(Ct), in 1e-4 kcal/mol, rounded down
+		bool pass = true;
+		int theta = INT32_MIN;
+		if (a.tab->enabled[cls]) {
+			const float th = a.tab->theta0[cls] - a.tab->tk[cls] * (1.9872e-3f * slot.log_ct);
+			theta = int(floorf(th * 10000.0f)) - 1;
+			pass = best >= theta;
+		}
+		if (a.score_out && active) a.score_out[2 * idx] = best, a.score_out[2 * idx + 1] = theta;
+		if (a.audit) {
+			if (active) a.audit[idx] = pass ? 0 : 1;
+			pass = true;
+		}
+		if (active && !pass) a.result[idx] = -1; // bind_oligo.cpp:600-606: Tm below the minimum
+		if (surv) {
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(active && pass);
+			const int lane = tid & 63;
+			if (a.n_rejected) {
+				const unsigned long long r = __builtin_amdgcn_ballot_w64(active && !pass);
+				if (lane == 0 && r) atomicAdd(a.n_rejected, uint32_t(__builtin_popcountll(r)));
+			}
+			uint32_t wbase = 0;
+			if (lane == 0 && m) wbase = atomicAdd(a.n_survivors, uint32_t(__builtin_popcountll(m)));
+			wbase = __shfl(wbase, 0);
+			if (active && pass) surv[wbase + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
+		}
+	}
+}
+
+// host-side launchers, defined in tnt_bind_inst.hip next to the bind kernel instances of the same lengths
+#define X(N) void launch_filter_##N(const FilterArgs2 &a, int blocks, hipStream_t stream);
+TNT_FILTER_LADDER(X)
+#undef X
+
+} // namespace tnt
+#endif

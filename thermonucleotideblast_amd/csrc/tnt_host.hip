@@ -28,6 +28,7 @@
 #include "tnt_dev.h"
 #include "tnt_seed.hip.h"
 #include "tnt_bind.hip.h"
+#include "tnt_filter.hip.h"
 #include "tnt_pair.hip.h"
 #include "tnt_ingest.hip.h"
 #include <zlib.h>
@@ -213,6 +214,72 @@ bool fill_tables(Tables &T, const tnt_options &opt)
 	return ok;
 }
 
+// Tables of the pre-filter (tnt_filter.hip.h): an upper bound, per pair of diagonally adjacent cells, of what
+// evaluate_alignment (nuc_cruc.cpp:1620-2299) can credit to an alignment that uses them, at the temperature of the
+// minimum-Tm threshold.  Returns with enabled[] = 0 wherever the derivation's premises do not hold (then nothing is
+// rejected): dangling-end options, a threshold at or below 0 C, parameter tables with a stabilising loop / bulge term.
+void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt)
+{
+	memset(&F, 0, sizeof(F));
+	bool wc[NBP];
+	memset(wc, 0, sizeof(wc));
+	wc[P_AT] = wc[P_TA] = wc[P_CG] = wc[P_GC] = true;
+	for (int b = bA; b <= bI; b++) wc[b * NB + bI] = wc[bI * NB + b] = true;
+	// premises: every loop / bulge / asymmetry / AT-bulge term is an entropy penalty, the salt term
+	// destabilises, stacks on a gap column carry nothing, no dangling-end columns
+	bool ok = !opt.allow_dangle_5 && !opt.allow_dangle_3 && !opt.use_dinkelbach && T.log_na <= 0.0f && T.salt >= 0.0f;
+	for (int i = 0; i < 513; i++) ok = ok && T.loop_S[i] <= 0.0f && T.bulge_S[i] <= 0.0f;
+	ok = ok && T.asym_S <= 0.0f && T.bulge_at_S <= 0.0f;
+	for (int x = bA; x <= bI; x++)
+		for (int c1 = bA; c1 <= bI; c1++)
+			for (int c2 = bA; c2 <= bI; c2++) {
+				const int c = c1 * NB + c2, g1 = x * NB + bGAP, g2 = bGAP * NB + x;
+				ok = ok && T.H[g1 * NBP + c] == 0.0f && T.S[g1 * NBP + c] == 0.0f && T.H[g2 * NBP + c] == 0.0f && T.S[g2 * NBP + c] == 0.0f;
+			}
+	const double min_tm[FILT_CLASSES] = {double(opt.min_primer_tm), double(opt.min_probe_tm)};
+	for (int cls = 0; cls < FILT_CLASSES; cls++) {
+		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][0][i] = 0, F.plane[cls][1][i] = FILT_NEG;
+		const double Tk = min_tm[cls] + 273.15;
+		F.tk[cls] = float(Tk);
+		if (!ok || !(min_tm[cls] > 0.0) || !(min_tm[cls] < 150.0)) continue;
+		const double sc = double(T.salt) * double(T.log_na); // per counted column (nuc_cruc.cpp:2270: 0.5 per base)
+		auto phi = [&](int prev, int cur) { return -(double(T.H[prev * NBP + cur]) - Tk * (double(T.S[prev * NBP + cur]) + sc)); };
+		double pb1 = -Tk * double(T.bulge_S[1]), pb2 = 1.0e30, pl3 = 1.0e30;
+		// sizes a window of this library can hold (the reference leaves the last entry of both tables at 0,
+		// nuc_cruc_santa_lucia.cpp:670,720: a 512-base loop no 64-mer can form)
+		for (int sz = 2; sz <= MAX_WINDOW; sz++) pb2 = std::min(pb2, -Tk * double(T.bulge_S[sz]));
+		for (int sz = 3; sz <= 2 * MAX_OLIGO + MAX_WINDOW; sz++) pl3 = std::min(pl3, -Tk * double(T.loop_S[sz]));
+		pl3 += -Tk * double(T.asym_S); // a loop that leaves its diagonal is asymmetric by at least one base
+		const double gap_price = std::min(std::min(pb2, pl3), pb1);
+		// best stack across a single-base bulge into pair c (nuc_cruc.cpp:2105-2120: the flanking stack is kept)
+		double u1[NBP];
+		for (int c = 0; c < NBP; c++) {
+			u1[c] = -1.0e30;
+			for (int pm = 0; pm < NBP; pm++)
+				if (wc[pm] && pm / NB <= bI && pm % NB <= bI) u1[c] = std::max(u1[c], phi(pm, c));
+			u1[c] += gap_price - pb1;
+		}
+		for (int xp = 0; xp < 4; xp++)
+			for (int x = 0; x < 4; x++)
+				for (int qp = bA; qp <= bI; qp++)
+					for (int q = bA; q <= bI; q++) {
+						// the sweep runs against the order evaluate_alignment reads the columns in: cell (i, j) = (q, x) comes
+						// first there, its diagonal neighbour (i-1, j-1) = (q', x') second
+						const int first = q * NB + x, second = qp * NB + xp;
+						const int at = (xp * FILT_X + x) * NBP + qp * NB + q;
+						const double f = phi(first, second);
+						const double fpos = (wc[first] || wc[second]) ? std::max(f, 0.0) : 0.0; // a stack inside a loop is never credited
+						F.plane[cls][0][at] = int32_t(std::ceil(fpos * 10000.0));
+						if (wc[second]) // a loop / bulge is closed by a Watson-Crick column
+							F.plane[cls][1][at] = int32_t(std::ceil((std::max(std::max(f, 0.0), u1[second]) - gap_price) * 10000.0));
+					}
+		const double g_init = double(T.init_H) - Tk * double(T.init_S);
+		const double g_at = double(T.at_H) - Tk * double(T.at_S);
+		F.theta0[cls] = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02); // 0.02 kcal/mol: float32 rounding of the reference's sums, generously
+		F.enabled[cls] = 1;
+	}
+}
+
 // build_word_list<std::string>, seq_hash.h:287-374, in the packed stream's little-endian word convention
 // (first base of the k-mer in the lowest two bits)
 std::vector<uint16_t> word_list(const std::string &oligo, bool complement, int k)
@@ -352,6 +419,12 @@ struct tnt_ctx {
 
 	Tables h_tab;
 	DevBuf<Tables> tab;
+	// pre-filter of the bind stage (tnt_filter.hip.h)
+	FilterTables h_ftab;
+	DevBuf<FilterTables> ftab;
+	DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
+	DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
+	bool filter_on = false, filter_audit = false;
 	DevBuf<uint8_t> olig_base;
 	DevBuf<uint32_t> olig_q4;
 	DevBuf<int32_t> olig_len;
@@ -423,7 +496,7 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_PAD7, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
+enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_FILTERED /* windows rejected by the pre-filter (whole search) */, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
@@ -510,6 +583,16 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 	}
 }
 
+void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t stream)
+{
+	switch (rows) {
+#define X(N) case N: tnt::launch_filter_##N(a, blocks, stream); break;
+		TNT_FILTER_LADDER(X)
+#undef X
+	default: break;
+	}
+}
+
 // One phase of binding: split the queue by oligo length, then one launch per length bucket.
 void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_exceptions, const uint32_t *src, const uint32_t *src_count,
                        const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always */)
@@ -551,6 +634,33 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.index_base_dev = cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
+		b.audit = nullptr;
+		if (c->filter_on && (c->bucket_lmax[i] & BUCKET_PLAIN)) {
+			// plain windows first meet the pre-filter: what cannot reach the minimum Tm is rejected there, the rest of the
+			// bucket is compacted into qsurv (same offset) and bound by the full kernel
+			FilterArgs2 f;
+			memset(&f, 0, sizeof(f));
+			f.tab = c->ftab.p;
+			f.db = v;
+			f.olig_q4 = b.olig_q4;
+			f.olig_len = b.olig_len;
+			f.slots = b.slots;
+			f.thresh = b.thresh;
+			f.items = b.items;
+			f.index = c->qbucket.p;
+			f.index_base_dev = b.index_base_dev;
+			f.n_items_dev = b.n_items_dev;
+			f.n_items = uint32_t(ITEM_CAP);
+			f.survivors = c->qsurv.p;
+			f.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 3;
+			f.result = b.result;
+			f.n_rejected = cnt + C_FILTERED;
+			f.audit = c->filter_audit ? c->audit.p : nullptr;
+			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane]);
+			b.index = c->qsurv.p;
+			b.n_items_dev = f.n_survivors;
+			b.audit = f.audit;
+		}
 		b.trace = c->trace.p + size_t(lane) * c->lane_trace;
 		b.best = c->best.p + size_t(lane) * c->lane_cols;
 		b.stack = c->stack.p + size_t(lane) * c->lane_cols;
@@ -601,6 +711,8 @@ int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 		HIP_TRY(c->qa.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->qb.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->qbucket.alloc(ITEM_CAP), c->err);
+		if (c->filter_on) HIP_TRY(c->qsurv.alloc(ITEM_CAP), c->err);
+		if (c->filter_audit) HIP_TRY(c->audit.alloc(ITEM_CAP), c->err);
 		if (c->dedupe) HIP_TRY(c->item_rep.alloc(ITEM_CAP), c->err);
 		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
 		HIP_TRY(c->hits.alloc(c->hit_cap), c->err);
@@ -647,6 +759,7 @@ const char *err_text(uint32_t e)
 	if (e & ERR_LIST_OVERFLOW) return "more than 512 seeds of one assay inside one seed window";
 	if (e & ERR_STACK_OVERFLOW) return "traceback branch stack overflow";
 	if (e & ERR_TIE_OVERFLOW) return "more than 256 maximal DP cells in one window";
+	if (e & ERR_FILTER_UNSOUND) return "pre-filter audit: the filter would have rejected a window the bind kernel accepts";
 	return "unknown device error";
 }
 
@@ -827,6 +940,9 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 
 	// ---- tables
 	if (!fill_tables(c->h_tab, *opt)) FAIL(TNT_E_UNSUPPORTED, "delta_g table lacks the class structure the bind kernel relies on");
+	fill_filter_tables(c->h_ftab, c->h_tab, *opt);
+	c->filter_on = (c->h_ftab.enabled[0] || c->h_ftab.enabled[1]) && !getenv("TNT_MI355X_NO_FILTER");
+	c->filter_audit = c->filter_on && getenv("TNT_MI355X_FILTER_AUDIT");
 	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
 	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 4), 0);
 	std::vector<int32_t> ol(std::max<size_t>(1, c->oligos.size()), 0);
@@ -914,7 +1030,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	}
 	hipError_t e = hipSuccess;
 	std::vector<Tables> tv(1, c->h_tab);
-	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
+	std::vector<FilterTables> fv(1, c->h_ftab);
+	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->ftab.upload(fv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
 	    (e = c->olig_q4.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
 	    (e = c->slot_canon.upload(c->h_slot_canon)) != hipSuccess || (e = c->slot_next.upload(c->h_slot_next)) != hipSuccess ||
@@ -1925,6 +2042,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	T.n_seeds = (uint64_t(cnt[C_TOT_GROUPS_HI]) << 32) | cnt[C_TOT_GROUPS_LO]; // (target, assay) groups that reached the bind stage
 	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n_unique;
+	T.n_filtered = cnt[C_FILTERED];
 	ctx->dev_hits_valid = n_unique == n;
 	ctx->dev_hits_n = n;
 	if (hits) *hits = ctx->h_hits;
@@ -2148,6 +2266,80 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		memcpy(o.align, f.text, TNT_ALIGN_TEXT);
 		o.align[TNT_ALIGN_TEXT - 1] = 0;
 	}
+	return TNT_OK;
+}
+
+int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, int32_t *score)
+{
+	if (!ctx || !db || db->ctx != ctx || (!req && n) || (!score && n)) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "a search is pending on this context: collect it first";
+		return TNT_E_ARG;
+	}
+	if (n == 0) return TNT_OK;
+	if (n > ITEM_CAP || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx, 64);
+	if (rc) return rc;
+	if (!db->host_copy) {
+		ctx->err = "tnt_filter_bound needs a database packed from codes (tnt_db_create)";
+		return TNT_E_UNSUPPORTED;
+	}
+	std::vector<Slot> slots(n);
+	std::vector<Item> items(n);
+	std::map<int, std::vector<uint32_t>> by_rows; // kernel instance (rows) -> requests
+	std::vector<uint8_t> plain(n, 1);
+	for (size_t i = 0; i < n; i++) {
+		const tnt_bind_req &r = req[i];
+		const size_t t = size_t(r.seq_index) - db->first_seq_index;
+		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc > 127 ||
+		    r.target_loc < 0 || !(r.ct > 0.0f)) {
+			ctx->err = "bad bind request";
+			return TNT_E_ARG;
+		}
+		const int L = int(ctx->oligos[r.oligo].size());
+		slots[i] = Slot{r.oligo, logf((r.ct - 0.5f * 0.0f) * 1.0f), r.role == 1 ? 1 : 0, -1, 0, 0};
+		items[i] = Item{uint32_t(t), uint32_t(r.target_loc), uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT), 0};
+		// windows with a degenerate base never meet the filter (the bucket pass routes them to the general bind instances)
+		const int start = std::max(0, r.target_loc - (r.query_loc + FLANK));
+		const uint32_t stop = std::min<uint32_t>(uint32_t(start + L + 2 * FLANK), db->h_len[t]);
+		const uint32_t *eb = db->h_exc_pos.data() + db->h_exc_off[t], *ee = db->h_exc_pos.data() + db->h_exc_off[t + 1];
+		const uint32_t *it = std::lower_bound(eb, ee, uint32_t(start));
+		if (it != ee && *it < stop) plain[i] = 0;
+		else by_rows[pick_instance(size_t(L)) & 0xFF].push_back(uint32_t(i));
+	}
+	DevBuf<Slot> dslots;
+	DevBuf<int32_t> dscore;
+	DevBuf<uint32_t> dindex;
+	HIP_TRY(dslots.upload(slots), ctx->err);
+	HIP_TRY(dscore.alloc(2 * n), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+	HIP_TRY(hipMemset(dscore.p, 0xFF, 2 * n * sizeof(int32_t)), ctx->err);
+	std::vector<uint32_t> order;
+	for (const auto &kv : by_rows) order.insert(order.end(), kv.second.begin(), kv.second.end());
+	HIP_TRY(dindex.upload(order), ctx->err);
+	FilterArgs2 f;
+	memset(&f, 0, sizeof(f));
+	f.tab = ctx->ftab.p;
+	f.db = make_view(db, 0, db->n_targets);
+	f.olig_q4 = ctx->olig_q4.p;
+	f.olig_len = ctx->olig_len.p;
+	f.slots = dslots.p;
+	f.thresh = ctx->thresh.p;
+	f.items = ctx->items.p;
+	f.result = ctx->result.p;
+	f.score_out = dscore.p;
+	size_t at = 0;
+	for (const auto &kv : by_rows) {
+		f.index = dindex.p + at;
+		f.n_items = uint32_t(kv.second.size());
+		launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), kv.first, ctx->stream);
+		at += kv.second.size();
+	}
+	HIP_TRY(hipGetLastError(), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpy(score, dscore.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
 	return TNT_OK;
 }
 

@@ -68,6 +68,7 @@ def load_library():
     lib.tnt_seeds.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_seed)), P(C.c_size_t)]
     lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
     lib.tnt_bind_batch_routed.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind), C.c_int]
+    lib.tnt_filter_bound.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(C.c_int32)]
     lib.tnt_hit_sequence.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_hit), C.c_char_p, C.c_size_t]
     lib.tnt_db_create_from_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, P(C.c_void_p)]
     lib.tnt_db_load_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, P(C.c_void_p)]
@@ -80,7 +81,7 @@ def load_library():
     lib.tnt_db_target_codes.restype = C.c_int64
     lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
     lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
-    if lib.tnt_abi_version() != 1:
+    if lib.tnt_abi_version() != 2:
         raise TntError("ABI version mismatch")
     _lib = lib
     return lib
@@ -91,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device",
-    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_hit_sequence", "tnt_oligo_structure",
+    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
 ]
@@ -308,6 +309,12 @@ class Engine:
         by oligo length; 2: the longest general throughput instance (tnt_bind_batch_routed)."""
         out = (abi.tnt_bind * len(reqs))()
         self._check(self.lib.tnt_bind_batch_routed(self._h, batch._h, reqs, len(reqs), out, route))
+        return out
+
+    def filter_bound(self, batch, reqs):
+        """(n, 2) int32 array [bound, threshold] of the bind stage's pre-filter for every request (tnt_filter_bound)."""
+        out = np.zeros((len(reqs), 2), dtype=np.int32)
+        self._check(self.lib.tnt_filter_bound(self._h, batch._h, reqs, len(reqs), out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
     def oligo_structure(self, a, b=None, ct_a=9.0e-7, ct_b=9.0e-7):
