@@ -32,13 +32,15 @@ namespace tnt {
 
 constexpr int FILT_X = 5;                        // target base of a column: A C G T, 4 = none (before the first column / behind the window)
 constexpr int FILT_ENTRIES = FILT_X * FILT_X * NBP; // index ((x' * 5 + x) * 49 + q' * 7 + q): previous column / row = (x', q'), current = (x, q)
-constexpr int FILT_PLANE = 20 * 64;              // ints per plane (>= FILT_ENTRIES, a multiple of 64 for ds_read2st64_b32)
+constexpr int FILT_PLANE = 20 * 64;              // entries per class (>= FILT_ENTRIES)
 constexpr int FILT_CLASSES = 2;                  // threshold sets by minimum Tm: primers, probes
 constexpr int32_t FILT_NEG = -(1 << 28);
 
 // host-built tables of one context (tnt_host.hip, fill_filter_tables)
 struct FilterTables {
-	int32_t plane[FILT_CLASSES][2][FILT_PLANE]; // [class][0] stack counted when favourable; [1] entry into a loop through this diagonal step, minus the gap price
+	// per class and entry two ints side by side (one ds_read_b64 per cell): [0] the stack, counted when favourable;
+	// [1] entry into a loop through this diagonal step, minus the gap price
+	int32_t plane[FILT_CLASSES][FILT_PLANE][2];
 	float tk[FILT_CLASSES];                     // min_tm + 273.15
 	float theta0[FILT_CLASSES];                 // threshold without the strand-concentration term, kcal/mol (margin included)
 	int32_t enabled[FILT_CLASSES];              // 0: windows of this class are never rejected
@@ -72,10 +74,10 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 	constexpr int THREADS = 256;
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	__shared__ int32_t s_tab[FILT_CLASSES * 2 * FILT_PLANE];
-	__shared__ uint8_t s_win[WMAX * THREADS];
 
 	const int tid = threadIdx.x;
 	for (int i = tid; i < FILT_CLASSES * 2 * FILT_PLANE; i += THREADS) s_tab[i] = (&a.tab->plane[0][0][0])[i];
+	static_assert(sizeof(a.tab->plane) == sizeof(int32_t) * FILT_CLASSES * 2 * FILT_PLANE, "table size");
 	__syncthreads();
 
 	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
@@ -85,7 +87,6 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 		const uint32_t n_dev = *a.n_items_dev;
 		n_items = n_dev < n_items ? n_dev : n_items;
 	}
-	uint8_t *win = s_win + tid;
 
 	for (uint32_t base = blockIdx.x * THREADS; base < n_items; base += gridDim.x * THREADS) {
 		const bool active = base + tid < n_items;
@@ -102,38 +103,53 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 		int stop = start + L + 2 * FLANK;
 		if (stop > int(tlen)) stop = int(tlen);
 		const int W = active ? stop - start : 0;
-		if (active) {
-			const uint32_t *pk = a.db.packed + a.db.word_off[it.target];
-			for (int r = 0; r < W; r++) {
-				const int pos = start + r;
-				const int code = int((pk[pos >> 4] >> ((pos & 15) * 2)) & 3u);
-				// minus-strand binding: complement, reversed (bind_oligo.cpp:524-573); plus: as is (:1227-1276)
-				if (minus) win[(W - 1 - r) * THREADS] = uint8_t(3 - code);
-				else win[r * THREADS] = uint8_t(code);
-			}
+		// The window stays in registers: the packed words that hold [start, stop), shifted so that base `start` sits in the
+		// low bits.  Column j reads base start + j - 1 as it is (plus-strand binding, bind_oligo.cpp:1227-1276) or the
+		// complement of base stop - j (minus strand: complement, reversed, :524-573).
+		constexpr int NW = (WMAX + 15) / 16; // words of the shifted stream
+		uint32_t wv[NW];
+		{
+			const uint32_t *pk = a.db.packed + (active ? a.db.word_off[it.target] : 0ull) + uint32_t(start >> 4);
+			uint32_t raw[NW + 1];
+#pragma unroll
+			for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u; // rows are padded and the array has slack behind its end
+			const uint32_t sh = uint32_t(start & 15) * 2u;
+#pragma unroll
+			for (int k = 0; k < NW; k++) wv[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
 		}
-		// per-row part of the table address, 4 * (7 * q' + q): q' = base of the row above (none above row 1), rows behind
-		// the oligo are "none" as well (their entries add nothing and open nothing)
-		uint32_t Rpk[(LMAX + 3) / 4];
+		auto base_at = [&](int r) __attribute__((always_inline)) { // base r of the window, r in [0, W)
+			uint32_t w = wv[0];
+#pragma unroll
+			for (int k = 1; k < NW; k++) w = (r >> 4) == k ? wv[k] : w;
+			return int((w >> ((r & 15) * 2)) & 3u);
+		};
+		auto column_base = [&](int j) __attribute__((always_inline)) { // target base of column j in 1..W
+			return minus ? 3 - base_at(W - j) : base_at(j - 1);
+		};
+		// per-row part of the table address, 8 * (7 * q' + q), two rows per register: q' = base of the row above (none above
+		// row 1), rows behind the oligo are "none" as well (their entries add nothing and open nothing)
+		uint32_t Rpk[(LMAX + 1) / 2];
 		{
 			uint32_t qprev = bGAP;
 #pragma unroll
 			for (int w = 0; w < (LMAX + 3) / 4; w++) {
 				const uint32_t q4w = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + w] : 0u;
-				uint32_t r = 0;
 #pragma unroll
 				for (int b = 0; b < 4; b++) {
 					const int i = w * 4 + b; // row i + 1
+					if (i >= LMAX) continue;
 					uint32_t q = (q4w >> (b * 8 + 2)) & 7u;
 					if (i >= L) q = bGAP;
-					r |= (4u * (7u * qprev + q)) << (b * 8);
+					const uint32_t r = 8u * (7u * qprev + q);
+					if ((i & 1) == 0) Rpk[i >> 1] = r;
+					else Rpk[i >> 1] |= r << 16;
 					qprev = q;
 				}
-				Rpk[w] = r;
 			}
 		}
 		const int cls = filter_class(slot.thresh);
 		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * (2 * FILT_PLANE * 4);
+		typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
 
 		int X[LMAX], M2[LMAX];
 #pragma unroll
@@ -144,23 +160,32 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 			const int other = __shfl_xor(Wwave, o);
 			Wwave = other > Wwave ? other : Wwave;
 		}
-		int pt = 4; // target base of the previous column (none)
+		// The table values of a column are fetched one column ahead (every row's read for column j + 1 is issued right after
+		// that row of column j is done): the LDS latency of a read is covered by a whole column of arithmetic.
+		auto row_addr = [&](int i) __attribute__((always_inline)) { return int((Rpk[(i - 1) >> 1] >> (((i - 1) & 1) * 16)) & 0xFFFFu); };
+		int t = W >= 1 ? column_base(1) : 4; // target base of the current column
+		int colbase = tab_base + (4 * FILT_X + t) * (NBP * 8); // no column before the first
+		// (instances of more than 32 rows do not have the registers for it: they read each value where it is used)
+		constexpr bool AHEAD = LMAX <= 32;
+		unsigned long long e[AHEAD ? LMAX : 1];
+		if (AHEAD) {
+#pragma unroll
+			for (int i = 1; i <= LMAX; i++) e[AHEAD ? i - 1 : 0] = *(lds_cu64 *)(uintptr_t(uint32_t(colbase + row_addr(i))));
+		}
 #pragma unroll 1
 		for (int j = 1; j <= Wwave; j++) {
-			const int t = j <= W ? int(win[(j - 1) * THREADS]) : 4;
-			const int colbase = tab_base + (pt * FILT_X + t) * (NBP * 4);
+			const int tn = j < W ? column_base(j + 1) : 4; // column j + 1
+			const int nextbase = tab_base + (t * FILT_X + tn) * (NBP * 8);
 #pragma unroll
-			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
+			for (int w = 0; w < (LMAX + 1) / 2; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
 			int dX = 0, dM = FILT_NEG; // the cell above row 1 in the previous column
 			int upM = FILT_NEG;        // M2 of the row above in this column
 			int colmax = 0;
 #pragma unroll
 			for (int i = 1; i <= LMAX; i++) {
-				const int r4 = int((Rpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 255u);
-				const int ea = colbase + r4;
-				typedef __attribute__((address_space(3))) const int lds_cint;
-				const int fp = *(lds_cint *)(uintptr_t(uint32_t(ea)));
-				const int gp = *(lds_cint *)(uintptr_t(uint32_t(ea + 4 * FILT_PLANE)));
+				const unsigned long long ev = AHEAD ? e[AHEAD ? i - 1 : 0] : *(lds_cu64 *)(uintptr_t(uint32_t(colbase + row_addr(i))));
+				const int fp = int(uint32_t(ev)), gp = int(uint32_t(ev >> 32));
+				if (AHEAD) e[AHEAD ? i - 1 : 0] = *(lds_cu64 *)(uintptr_t(uint32_t(nextbase + row_addr(i))));
 				const int oldX = X[i - 1], oldM = M2[i - 1]; // (i, j-1)
 				const int mUL = upM > oldM ? upM : oldM;
 				const int a1 = dX + fp;
@@ -174,7 +199,8 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 				upM = nM;
 			}
 			best = best > colmax ? best : colmax;
-			pt = t;
+			t = tn;
+			colbase = nextbase;
 		}
 
 		// threshold of this item: theta0 of its class - Tk * R * ln(Ct), in 1e-4 kcal/mol, rounded down

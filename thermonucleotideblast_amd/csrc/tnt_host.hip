@@ -238,7 +238,7 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 			}
 	const double min_tm[FILT_CLASSES] = {double(opt.min_primer_tm), double(opt.min_probe_tm)};
 	for (int cls = 0; cls < FILT_CLASSES; cls++) {
-		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][0][i] = 0, F.plane[cls][1][i] = FILT_NEG;
+		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i][0] = 0, F.plane[cls][i][1] = FILT_NEG;
 		const double Tk = min_tm[cls] + 273.15;
 		F.tk[cls] = float(Tk);
 		if (!ok || !(min_tm[cls] > 0.0) || !(min_tm[cls] < 150.0)) continue;
@@ -269,9 +269,9 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 						const int at = (xp * FILT_X + x) * NBP + qp * NB + q;
 						const double f = phi(first, second);
 						const double fpos = (wc[first] || wc[second]) ? std::max(f, 0.0) : 0.0; // a stack inside a loop is never credited
-						F.plane[cls][0][at] = int32_t(std::ceil(fpos * 10000.0));
+						F.plane[cls][at][0] = int32_t(std::ceil(fpos * 10000.0));
 						if (wc[second]) // a loop / bulge is closed by a Watson-Crick column
-							F.plane[cls][1][at] = int32_t(std::ceil((std::max(std::max(f, 0.0), u1[second]) - gap_price) * 10000.0));
+							F.plane[cls][at][1] = int32_t(std::ceil((std::max(std::max(f, 0.0), u1[second]) - gap_price) * 10000.0));
 					}
 		const double g_init = double(T.init_H) - Tk * double(T.init_S);
 		const double g_at = double(T.at_H) - Tk * double(T.at_S);
@@ -425,6 +425,7 @@ struct tnt_ctx {
 	DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
 	DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
 	bool filter_on = false, filter_audit = false;
+	bool serial_bind = false; // profiling: every launch of the bind stage on one side stream (per-kernel durations add up to the stage time)
 	DevBuf<uint8_t> olig_base;
 	DevBuf<uint32_t> olig_q4;
 	DevBuf<int32_t> olig_len;
@@ -629,7 +630,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		const size_t i = k;
 		// general instances other than the last (merge) bucket only see windows with degenerate bases
 		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) continue;
-		const int lane = n_launch++ % tnt_ctx::BIND_LANES;
+		const int lane = c->serial_bind ? 0 : n_launch++ % tnt_ctx::BIND_LANES;
+		if (c->serial_bind) n_launch = 1;
 		b.index = c->qbucket.p;
 		b.index_base_dev = cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
@@ -943,6 +945,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	fill_filter_tables(c->h_ftab, c->h_tab, *opt);
 	c->filter_on = (c->h_ftab.enabled[0] || c->h_ftab.enabled[1]) && !getenv("TNT_MI355X_NO_FILTER");
 	c->filter_audit = c->filter_on && getenv("TNT_MI355X_FILTER_AUDIT");
+	c->serial_bind = getenv("TNT_MI355X_SERIAL_BIND") != nullptr;
 	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
 	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 4), 0);
 	std::vector<int32_t> ol(std::max<size_t>(1, c->oligos.size()), 0);
@@ -1910,7 +1913,9 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	}
 	const double avg_len = unit_positions / double(n_units);
 	const double per_target = std::max(1.0, per_base * avg_len);
-	double tb = (double(ITEM_CAP) / 2.0) / per_target;
+	// (per_target counts raw seeds; the first cull keeps a small part of them for PCR assays, all of them for probes:
+	// a batch is sized for every raw seed becoming an item, an overflow of a shard region is repaired by halving it)
+	double tb = (double(ITEM_CAP) * 0.75) / per_target;
 	const double gb = (double(GROUP_CAP) / 2.0) / std::max<double>(1.0, double(n_assays));
 	tb = std::min(tb, gb);
 	targets_per_batch = size_t(std::max(1.0, std::min(tb, double(n_units)))); // in work units
