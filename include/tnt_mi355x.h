@@ -227,6 +227,15 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits);
  * context.  TNT_E_UNSUPPORTED when the host copy was post-processed (duplicate removal for windowed long targets). */
 int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hits);
 
+/* The same hits in compact form, packed on the device: what the gather of a multi-GPU run sends (about 350 bytes per hit
+ * instead of sizeof(tnt_hit) = 1464; the reference's workers send packed hit lists too, tntblast_master.cpp:811-828).
+ *   blob   = { uint32 n_hits, uint32 n_bytes } record*
+ *   record = the 120 bytes of tnt_hit before its texts | uint16 length[3] | uint16 0 | the three texts | pad to 4 bytes
+ * Valid until the next search on this context.  tnt_hits_unpack() is the host-side inverse (no GPU involved): with
+ * out == NULL it only reports the count.                                                                           */
+int tnt_search_hits_compact(tnt_ctx *ctx, const void **device_blob, size_t *n_bytes, size_t *n_hits);
+int tnt_hits_unpack(const void *blob, size_t n_bytes, tnt_hit *out, size_t cap, size_t *n_hits);
+
 /* per-stage device timings of the last search, in ms (HIP events on the context stream) */
 typedef struct tnt_timing {
 	float seed_ms, bind_ms, pair_ms, total_ms;

@@ -42,6 +42,12 @@ def _worker(rank, world, port, q):
         local = ora.search(wl.options, wl.expanded, c, o, first=b, threads=1)
         allhits, counts = shard.gather_hits(local)
         keys = tc.sorted_hit_keys(allhits)
+        # the compact form (what bench.py sends): exact byte counts per rank, unpacked on the root by the library
+        blobs, counts2 = shard.finish_compact(shard.stage_compact(shard.pack_hits(local), len(local)))
+        if rank == 0:
+            assert counts2 == counts
+            assert tc.sorted_hit_keys(shard.unpack_all(blobs)) == keys
+            assert sum(len(b) for b in blobs) < sum(counts) * 1464 // 3
         if rank == 0:
             whole = tc.sorted_hit_keys(ora.search(wl.options, wl.expanded, codes, offsets, threads=2))
             q.put((ranges, counts, keys == whole, len(whole)))

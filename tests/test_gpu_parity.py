@@ -643,11 +643,21 @@ def test_hits_device_view_matches_host_copy(Engine):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    # the compact records the benchmark gathers: packed on the device == packed on the host, and unpacking gives the hits back
+    comp = e.hits_compact()
+    assert comp is not None and comp[2] == len(hits)
+    blob = bytes(torch.as_tensor(shard._DeviceBytes(comp[0], comp[1]), device="cuda").cpu().numpy().tobytes())
+    assert blob == shard.pack_hits(hits)
+    assert len(blob) < nbytes // 3
+    back = shard.unpack_all([np.frombuffer(blob, dtype=np.uint8)])
+    assert tc.sorted_hit_keys(back) == tc.sorted_hit_keys(hits) and [h.seq_index for h in back] == [h.seq_index for h in hits]
     try:
         for use_dev in (dev, None):
             got, counts = shard.gather_hits(hits, device="cuda", device_hits=use_dev, always_collective=True)
             assert counts == [len(hits)] and len(got) == len(hits)
             assert bytes(np.frombuffer(got, dtype=np.uint8).tobytes()) == bytes(np.frombuffer(hits, dtype=np.uint8).tobytes())
+        blobs, counts = shard.finish_compact(shard.stage_compact((comp[0], comp[1]), comp[2], device="cuda", always_collective=True))
+        assert counts == [len(hits)] and bytes(blobs[0].tobytes()) == blob
     finally:
         dist.destroy_process_group()
     db.close()

@@ -454,6 +454,8 @@ struct tnt_ctx {
 	DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
 	bool dev_hits_valid = false; // ctx->hits still equals the host copy of the last collected search
 	size_t dev_hits_n = 0;
+	DevBuf<uint8_t> hit_blob;   // compact form of the hits (tnt_search_hits_compact)
+	DevBuf<uint32_t> hit_sizes;
 	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
 	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
@@ -2068,6 +2070,75 @@ int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hit
 	}
 	*device_hits = ctx->hits.p;
 	*n_hits = ctx->dev_hits_n;
+	return TNT_OK;
+}
+
+int tnt_search_hits_compact(tnt_ctx *ctx, const void **device_blob, size_t *n_bytes, size_t *n_hits)
+{
+	if (!ctx || !device_blob || !n_bytes || !n_hits) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "tnt_search_hits_compact: collect the search first";
+		return TNT_E_ARG;
+	}
+	if (!ctx->dev_hits_valid) {
+		ctx->err = "the device copy of the hits still holds the duplicates of overlapping target windows";
+		return TNT_E_UNSUPPORTED;
+	}
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	const size_t n = ctx->dev_hits_n;
+	const size_t worst = 8 + n * (size_t(HIT_POD_BYTES) + 8 + 3 * size_t(ALIGN_TEXT));
+	if (ctx->hit_blob.n < worst) HIP_TRY(ctx->hit_blob.alloc(worst + worst / 4 + 4096), ctx->err);
+	if (ctx->hit_sizes.n < n + 1) HIP_TRY(ctx->hit_sizes.alloc(n + n / 4 + 1024), ctx->err);
+	HitPackArgs a;
+	a.hits = ctx->hits.p;
+	a.n = uint32_t(n);
+	a.sizes = ctx->hit_sizes.p;
+	a.blob = ctx->hit_blob.p;
+	a.total = ctx->counters.p + C_DEBUG; // scratch word, read back below
+	const int blocks = int(std::min<size_t>(1024, (n + 255) / 256 + 1));
+	hipLaunchKernelGGL(hit_size_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+	hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+	hipLaunchKernelGGL(hit_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+	uint32_t total = 0;
+	HIP_TRY(hipMemcpyAsync(&total, a.total, sizeof(total), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	HIP_TRY(hipGetLastError(), ctx->err);
+	*device_blob = ctx->hit_blob.p;
+	*n_bytes = total;
+	*n_hits = n;
+	return TNT_OK;
+}
+
+int tnt_hits_unpack(const void *blob, size_t n_bytes, tnt_hit *out, size_t cap, size_t *n_hits)
+{
+	if (!blob || n_bytes < 8 || !n_hits) return TNT_E_ARG;
+	const uint8_t *p = static_cast<const uint8_t *>(blob);
+	uint32_t n = 0, total = 0;
+	memcpy(&n, p, 4);
+	memcpy(&total, p + 4, 4);
+	*n_hits = n;
+	if (total > n_bytes) return TNT_E_ARG;
+	if (!out) return TNT_OK; // a query for the count
+	if (cap < n) return TNT_E_LIMIT;
+	size_t at = 8;
+	for (uint32_t i = 0; i < n; i++) {
+		if (at + HIT_POD_BYTES + 8 > total) return TNT_E_ARG;
+		tnt_hit &h = out[i];
+		memcpy(&h, p + at, HIT_POD_BYTES);
+		uint32_t l01 = 0, l2 = 0;
+		memcpy(&l01, p + at + HIT_POD_BYTES, 4);
+		memcpy(&l2, p + at + HIT_POD_BYTES + 4, 4);
+		const uint32_t len[3] = {l01 & 0xFFFFu, l01 >> 16, l2 & 0xFFFFu};
+		char *dst[3] = {h.forward_align, h.reverse_align, h.probe_align};
+		size_t t = at + HIT_POD_BYTES + 8;
+		for (int k = 0; k < 3; k++) {
+			if (len[k] >= TNT_ALIGN_TEXT || t + len[k] > total) return TNT_E_ARG;
+			memcpy(dst[k], p + t, len[k]);
+			memset(dst[k] + len[k], 0, TNT_ALIGN_TEXT - len[k]);
+			t += len[k];
+		}
+		at = (t + 3) & ~size_t(3);
+	}
 	return TNT_OK;
 }
 

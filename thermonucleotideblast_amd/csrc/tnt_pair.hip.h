@@ -679,5 +679,86 @@ template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Compact form of the hit records for the gather of a multi-GPU run (the reference's workers send packed hit lists to
+// the master, tntblast_master.cpp:811-828): per hit the 120 bytes of numbers, three 16-bit text lengths and the text
+// bytes themselves instead of three fixed 448-byte fields -- about 350 bytes instead of 1 464 for 20-mers.
+//   blob = { uint32 n_hits, uint32 n_bytes } { record }*      record = 120 B numbers | u16 len[3] | u16 0 | texts | pad to 4
+constexpr int HIT_POD_BYTES = 120;
+static_assert(HIT_POD_BYTES == int(sizeof(Hit)) - 3 * ALIGN_TEXT, "the numbers of a hit come first, the three texts last");
+
+struct HitPackArgs {
+	const Hit *hits;
+	uint32_t n;
+	uint32_t *sizes;   // [n] record sizes, then (in place) exclusive offsets
+	uint8_t *blob;     // output
+	uint32_t *total;   // [0] bytes of the blob (header included)
+};
+
+__device__ __forceinline__ uint32_t text_len(const char *t)
+{
+	uint32_t n = 0;
+	while (n < uint32_t(ALIGN_TEXT - 1) && t[n]) n++;
+	return n;
+}
+
+__global__ __launch_bounds__(256) void hit_size_kernel(HitPackArgs a)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+		const Hit &h = a.hits[i];
+		const uint32_t bytes = uint32_t(HIT_POD_BYTES) + 8u + text_len(h.forward_align) + text_len(h.reverse_align) + text_len(h.probe_align);
+		a.sizes[i] = (bytes + 3u) & ~3u;
+	}
+}
+
+// exclusive prefix sum of sizes[] by one workgroup (hit lists are short: tens of thousands of records per search)
+__global__ __launch_bounds__(1024) void hit_scan_kernel(HitPackArgs a)
+{
+	__shared__ uint32_t s_part[1024];
+	const uint32_t per = (a.n + 1023u) / 1024u, b = threadIdx.x * per, e = b + per < a.n ? b + per : a.n;
+	uint32_t sum = 0;
+	for (uint32_t i = b; i < e; i++) sum += a.sizes[i];
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = 8; // header
+		for (int t = 0; t < 1024; t++) {
+			const uint32_t v = s_part[t];
+			s_part[t] = run;
+			run += v;
+		}
+		a.total[0] = run;
+		reinterpret_cast<uint32_t *>(a.blob)[0] = a.n;
+		reinterpret_cast<uint32_t *>(a.blob)[1] = run;
+	}
+	__syncthreads();
+	uint32_t run = s_part[threadIdx.x];
+	for (uint32_t i = b; i < e; i++) {
+		const uint32_t v = a.sizes[i];
+		a.sizes[i] = run;
+		run += v;
+	}
+}
+
+__global__ __launch_bounds__(256) void hit_pack_kernel(HitPackArgs a)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+		const Hit &h = a.hits[i];
+		uint8_t *o = a.blob + a.sizes[i];
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(&h);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(o);
+		for (int k = 0; k < HIT_POD_BYTES / 4; k++) dst[k] = src[k];
+		const char *txt[3] = {h.forward_align, h.reverse_align, h.probe_align};
+		uint32_t len[3];
+		for (int k = 0; k < 3; k++) len[k] = text_len(txt[k]);
+		dst[HIT_POD_BYTES / 4] = len[0] | (len[1] << 16);
+		dst[HIT_POD_BYTES / 4 + 1] = len[2];
+		uint8_t *w = o + HIT_POD_BYTES + 8;
+		for (int k = 0; k < 3; k++)
+			for (uint32_t c = 0; c < len[k]; c++) *w++ = uint8_t(txt[k][c]);
+		while ((w - o) & 3) *w++ = 0;
+	}
+}
+
 } // namespace tnt
 #endif

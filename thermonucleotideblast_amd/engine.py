@@ -27,6 +27,19 @@ class TntError(RuntimeError):
     pass
 
 
+def unpack_hits(blob):
+    """Compact hit records (bytes-like, tnt_search_hits_compact's layout) -> ctypes array of tnt_hit (host only)."""
+    lib = load_library()
+    raw = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    n = C.c_size_t()
+    if lib.tnt_hits_unpack(raw, len(blob), None, 0, C.byref(n)) != 0:
+        raise TntError("malformed hit blob")
+    out = (abi.tnt_hit * n.value)()
+    if lib.tnt_hits_unpack(raw, len(blob), out, n.value, C.byref(n)) != 0:
+        raise TntError("malformed hit blob")
+    return out
+
+
 def load_library():
     """Load libtnt_mi355x.so (built in-tree by __graft_entry__.build()).  Never falls back."""
     global _lib
@@ -64,6 +77,8 @@ def load_library():
     lib.tnt_search_enqueue.argtypes = [C.c_void_p, C.c_void_p]
     lib.tnt_search_collect.argtypes = [C.c_void_p, P(P(abi.tnt_hit)), P(C.c_size_t)]
     lib.tnt_search_hits_device.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t)]
+    lib.tnt_search_hits_compact.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t), P(C.c_size_t)]
+    lib.tnt_hits_unpack.argtypes = [C.c_void_p, C.c_size_t, P(abi.tnt_hit), C.c_size_t, P(C.c_size_t)]
     lib.tnt_last_timing.argtypes = [C.c_void_p, P(abi.tnt_timing)]
     lib.tnt_seeds.argtypes = [C.c_void_p, C.c_void_p, P(P(abi.tnt_seed)), P(C.c_size_t)]
     lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
@@ -91,7 +106,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
-    "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device",
+    "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device", "tnt_search_hits_compact", "tnt_hits_unpack",
     "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
@@ -292,6 +307,16 @@ class Engine:
             return None
         self._check(rc)
         return (ptr.value or 0), n.value
+
+    def hits_compact(self):
+        """(device pointer, bytes, count) of the last collected search's hits in compact form (tnt_search_hits_compact),
+        or None when the host copy was post-processed (windowed long targets)."""
+        ptr, nb, n = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        rc = self.lib.tnt_search_hits_compact(self._h, C.byref(ptr), C.byref(nb), C.byref(n))
+        if rc == -4:  # TNT_E_UNSUPPORTED
+            return None
+        self._check(rc)
+        return (ptr.value or 0), nb.value, n.value
 
     def timing(self):
         t = abi.tnt_timing()

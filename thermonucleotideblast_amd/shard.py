@@ -1,12 +1,16 @@
-"""Multi-GPU layer: targets shard by sequence, hit records are gathered to every rank.
+"""Multi-GPU layer: targets shard by sequence, hit records are gathered to rank 0.
 
 The reference distributes (target, query-range) work items from an MPI master to workers and
 collects packed hit lists per chunk of assays (tntblast_master.cpp:438-461,811-828,
 tntblast_worker.cpp:173-186,602).  Targets are independent, so here the database is cut into
 contiguous index ranges balanced by base count (global `seq_index` is preserved), the assay
 tables are replicated, and there is exactly one collective after the search: an all-gather of the
-per-rank hit counts followed by an all-gather of the padded POD records (RCCL over xGMI with the
-"nccl" backend on GPUs; the same code runs on "gloo" for the CPU tests).
+per-rank hit counts followed by the transfer of the records to rank 0 (RCCL over xGMI with the "nccl"
+backend on GPUs; the same code runs on "gloo" for the CPU tests).  Two forms of the transfer:
+  * stage_hits / finish_gather: ONE gather of the full tnt_hit arrays, padded to the largest rank (1 464 bytes per hit);
+  * stage_compact / finish_compact: the compact records of tnt_search_hits_compact (numbers + text lengths + text bytes,
+    about 350 bytes per hit for 20-mers), every rank sending exactly its bytes to rank 0 (send / recv sized from the
+    all-gathered byte counts, nothing padded).  bench.py uses this one.
 """
 import ctypes as C
 
@@ -131,3 +135,108 @@ def finish_gather(st, copy=True):
 def gather_hits(hits, device="cpu", device_hits=None, root=0, always_collective=False, copy=True):
     """The hit records of every rank, collected on `root` (stage_hits + finish_gather in one call)."""
     return finish_gather(stage_hits(hits, device, device_hits, root, always_collective), copy=copy)
+
+
+# ------------------------------------------------------------------------------------------------ compact records
+HIT_POD_BYTES = 120  # the numbers of a tnt_hit (everything before its three texts)
+
+
+def pack_hits(hits):
+    """Host-side packer of the compact layout (include/tnt_mi355x.h, tnt_search_hits_compact): for ranks whose hits come
+    from the CPU checkers (tests) and for checking the device packer."""
+    out = [b""]
+    total = 8
+    for h in hits:
+        raw = bytes(C.string_at(C.addressof(h), HIT_POD_BYTES))
+        texts = [bytes(h.forward_align), bytes(h.reverse_align), bytes(h.probe_align)]
+        rec = raw + np.array([len(t) for t in texts] + [0], dtype="<u2").tobytes() + b"".join(texts)
+        rec += b"\0" * (-len(rec) % 4)
+        out.append(rec)
+        total += len(rec)
+    out[0] = np.array([len(hits), total], dtype="<u4").tobytes()
+    return b"".join(out)
+
+
+class _StagedCompact:
+    def __init__(self, mine, sizes, counts, device, root, reqs, recv):
+        self.mine, self.sizes, self.counts, self.device, self.root, self.reqs, self.recv = mine, sizes, counts, device, root, reqs, recv
+
+
+def stage_compact(blob, n_hits, device="cpu", root=0, always_collective=False):
+    """`blob` = this rank's compact records: bytes (CPU) or (device pointer, n_bytes) from Engine.hits_compact().
+    All-gather of (hit count, byte count); then every other rank posts the send of exactly its bytes and the root the
+    matching receives.  The caller may start the next search right away: the blob is only rewritten by the next
+    hits_compact() call."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if isinstance(blob, tuple):
+        nbytes = int(blob[1])
+        mine = torch.as_tensor(_DeviceBytes(blob[0], max(1, nbytes)), device=device)[:nbytes]
+    else:
+        nbytes = len(blob)
+        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8) if nbytes else torch.empty(0, dtype=torch.uint8)
+        if device != "cpu":
+            mine = mine.to(device)
+    if world == 1 and not (always_collective and dist.is_initialized()):
+        return _StagedCompact(mine, [nbytes], [int(n_hits)], device, root, [], [])
+    me = torch.tensor([int(n_hits), nbytes], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(me) for _ in range(world)]
+    dist.all_gather(every, me)
+    counts = [int(e[0].item()) for e in every]
+    sizes = [int(e[1].item()) for e in every]
+    rank = dist.get_rank()
+    reqs, recv = [], []
+    if rank == root:
+        for r in range(world):
+            if r == root or sizes[r] == 0:
+                recv.append(None)
+                continue
+            buf = torch.empty(sizes[r], dtype=torch.uint8, device=device)
+            recv.append(buf)
+            reqs.append(dist.irecv(buf, src=r))
+    elif nbytes:
+        reqs.append(dist.isend(mine, dst=root))
+    return _StagedCompact(mine, sizes, counts, device, root, reqs, recv)
+
+
+def finish_compact(st):
+    """Completes the transfers.  On the root returns (list of per-rank blobs as bytes-like host arrays, counts): the
+    device buffers are copied into page-locked host memory.  Elsewhere returns ([own blob], counts)."""
+    import torch
+    import torch.distributed as dist
+    for r in st.reqs:
+        r.wait()
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank != st.root:
+        if st.device != "cpu":
+            torch.cuda.current_stream().synchronize()
+        return [st.mine], st.counts
+    parts = [st.mine if r == st.root else st.recv[r] for r in range(len(st.sizes))] if st.recv else [st.mine]
+    total = sum(st.sizes)
+    host = torch.empty(max(1, total), dtype=torch.uint8) if st.device == "cpu" else _pinned_bytes(total)
+    out, o = [], 0
+    for r, p in enumerate(parts):
+        n = st.sizes[r]
+        if n and p is not None:
+            host[o:o + n].copy_(p[:n], non_blocking=True)
+        out.append((o, n))
+        o += n
+    if st.device != "cpu":
+        torch.cuda.current_stream().synchronize()
+    raw = host.numpy()
+    return [raw[o:o + n] for o, n in out], st.counts
+
+
+def unpack_all(blobs):
+    """Per-rank compact blobs -> one ctypes array of tnt_hit in rank order (host only)."""
+    from .engine import unpack_hits
+    parts = [unpack_hits(bytes(b)) for b in blobs if len(b) >= 8]
+    total = sum(len(p) for p in parts)
+    out = (abi.tnt_hit * total)()
+    o = 0
+    for p in parts:
+        if len(p):
+            C.memmove(C.addressof(out) + o * C.sizeof(abi.tnt_hit), p, len(p) * C.sizeof(abi.tnt_hit))
+            o += len(p)
+    return out
