@@ -61,19 +61,8 @@ def random_case(rng, case, max_code=18, dangle=True):
             keep[int(offsets[t]):int(offsets[t]) + int(lens[t])] = True
         codes = codes[keep]
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
-    elif shape == 2:  # a few long targets (seed windows)
-        # (with thresholds so low that every seed binds, the reference's order-dependent cull (Q5) acts on
-        # the list of the whole target, which windows cannot reproduce; the long-target cases keep sane thresholds)
-        o.min_primer_tm = max(o.min_primer_tm, 30.0)
-        o.min_probe_tm = max(o.min_probe_tm, 30.0)
-        # ... and sane conditions: at 0.9 M salt / 300 K nearly every seed of a 400-kb target binds at Tm >= 40 too
-        # (seed 36, case 75: one amplicon of 1 014 exists only in the context of the whole target's list)
-        o.salt = min(o.salt, 0.2)
-        o.target_t = max(o.target_t, 310.15)
-        # ... and the default word size or longer: 5- and 6-mers seed (and so bind) many more weak sites (three of 960
-        # cases at word size 5-6: HIP reports the amplicon once more, exactly like the reference run on the 6 kb around
-        # it does, while the reference on the whole 140-240 kb target reports one copy less)
-        o.hash_word_size = max(o.hash_word_size, 7)
+    elif shape == 2:  # a few long targets: seeded in windows, culled and paired whole (no guards on the options: the lists
+        # of a windowed target are the whole target's lists)
         k = int(rng.integers(20, nt))
         offsets = np.concatenate([[0], offsets[k:]]).astype(np.uint64)
     elif shape == 3:  # IUPAC codes, N-runs, unknown and gap codes sprinkled in

@@ -32,6 +32,7 @@
 #include "tnt_pair.hip.h"
 #include "tnt_ingest.hip.h"
 #include <zlib.h>
+#include <pthread.h>
 #include <chrono>
 #include "santalucia_tables.inc"
 
@@ -381,7 +382,9 @@ struct tnt_db {
 	DevBuf<uint32_t> unit_target, unit_begin, unit_end;
 	DevBuf<int32_t> unit_own_lo, unit_own_hi;
 	uint32_t max_unit_len = 0;
-	bool split = false;             // some target is cut into windows: results may hold identical copies
+	size_t n_short_units = 0;       // units [0, n_short_units) are whole targets, the rest windows of long targets
+	std::vector<uint32_t> h_long_targets; // targets that are seeded in windows and paired on the host
+	bool split = false;             // some target is cut into windows
 	uint64_t n_exceptions = 0;
 	std::string deflines;           // FASTA ingest: all deflines back to back
 	std::vector<uint64_t> defline_off;
@@ -1077,50 +1080,57 @@ int tnt_ctx_delta_g(const tnt_ctx *ctx, int32_t *out2401)
 
 namespace {
 
-// stride of the windows a long target is cut into; the window itself is stride + overlap long
+// stride of the windows a long target is seeded in
 constexpr uint32_t UNIT_STRIDE = 4096;
-constexpr uint32_t UNIT_MARGIN = 80; // > longest oligo + flanks: the seeds of a site lie within this of its first coordinate
 
 hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 {
 	const int k = ctx->opt.hash_word_size;
-	// reach of cull_oligo_match (amplicon_search.cpp:688: max_len + 50), so that a kept pair shares a window
-	// + what a hit's first coordinate may lie before the seeds that made it (UNIT_MARGIN) + the oligos themselves
-	const uint32_t overlap = uint32_t(std::max(0, ctx->opt.max_len)) + 50u + 2u * 64u + 2u * UNIT_MARGIN;
 	// window length for which the busiest assay expects about 128 seeds (short hash words seed densely)
 	size_t max_ent = 1;
 	for (const auto &ae : ctx->assay_entries) max_ent = std::max(max_ent, ae.size());
 	const double dense = 128.0 * double(size_t(1) << (2 * k)) / double(max_ent);
-	uint32_t stride = std::max(overlap, std::min(UNIT_STRIDE, uint32_t(std::max(1.0, dense - double(overlap)))));
-	// after a seed-list overflow with single-assay chunks the windows shrink (the overlap cannot: it is the cull's reach)
-	if (ctx->unit_scale < 1.0) stride = std::max<uint32_t>(128u, uint32_t(double(stride) * ctx->unit_scale));
+	uint32_t stride = uint32_t(std::max(128.0, std::min(double(UNIT_STRIDE), dense)));
+	// after a seed-list overflow with single-assay chunks the windows shrink
+	if (ctx->unit_scale < 1.0) stride = std::max<uint32_t>(64u, uint32_t(double(stride) * ctx->unit_scale));
 	db->h_unit_target.clear(), db->h_unit_begin.clear(), db->h_unit_end.clear();
 	db->h_unit_own_lo.clear(), db->h_unit_own_hi.clear();
+	db->h_long_targets.clear();
 	db->max_unit_len = 0;
 	db->split = false;
-	for (size_t t = 0; t < db->n_targets; t++) {
+	// Whole targets first: they go through the device pipeline (seed -> bind -> pair per work unit).  A target is searched
+	// whole whenever it can be: the reference's culls and pairing act on the lists of the whole target.  It is cut into
+	// windows of k-mer positions when its seeds would not fit the LDS lists of one work unit (about 256 expected for the
+	// busiest assay) or when it is genome-sized (> 32 k positions); the windows are only SEEDED and BOUND on the device,
+	// their lists are merged per (target, assay) and culled / paired whole on the host (search_long_targets).
+	auto is_long = [&](size_t t) {
 		const uint32_t len = db->h_len[t];
 		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
-		// A target is searched whole whenever it can be: the reference's culls act on the seed list of the whole
-		// target, and their order-dependent corner cases can only be reproduced on that list.  It is cut
-		// into windows when its seeds would not fit the LDS lists (about 256 expected for the busiest assay) or when
-		// it is genome-sized (> 32 k positions).
 		const double expect = double(npos) * double(max_ent) / double(size_t(1) << (2 * k));
-		if (npos <= stride + overlap || (expect <= 256.0 && npos <= 32768u && ctx->unit_scale >= 1.0)) {
-			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
-			db->h_unit_own_lo.push_back(INT32_MIN), db->h_unit_own_hi.push_back(INT32_MAX);
-			db->max_unit_len = std::max(db->max_unit_len, len);
-			continue;
-		}
+		return !(expect <= 256.0 && npos <= 32768u && ctx->unit_scale >= 1.0);
+	};
+	for (size_t t = 0; t < db->n_targets; t++) {
+		if (is_long(t)) continue;
+		const uint32_t len = db->h_len[t];
+		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
+		db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
+		db->h_unit_own_lo.push_back(INT32_MIN), db->h_unit_own_hi.push_back(INT32_MAX);
+		db->max_unit_len = std::max(db->max_unit_len, len);
+	}
+	db->n_short_units = db->h_unit_target.size();
+	for (size_t t = 0; t < db->n_targets; t++) {
+		if (!is_long(t)) continue;
+		const uint32_t len = db->h_len[t];
+		const uint32_t npos = len - uint32_t(k) + 1u;
 		db->split = true;
+		db->h_long_targets.push_back(uint32_t(t));
+		// windows overlap by the k-mer itself only: every position is seeded once (the diagonal de-duplication looks at the
+		// packed target, not at the window's list)
 		for (uint64_t b = 0; b < npos; b += stride) {
-			const uint32_t e = uint32_t(std::min<uint64_t>(npos, b + stride + overlap));
+			const uint32_t e = uint32_t(std::min<uint64_t>(npos, b + stride));
 			db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(uint32_t(b)), db->h_unit_end.push_back(e);
-			// ownership: from UNIT_MARGIN behind this window's start to UNIT_MARGIN behind the next one's
-			db->h_unit_own_lo.push_back(b == 0 ? INT32_MIN : int32_t(b + UNIT_MARGIN));
-			db->h_unit_own_hi.push_back(e == npos ? INT32_MAX : int32_t(b + stride + UNIT_MARGIN));
+			db->h_unit_own_lo.push_back(INT32_MIN), db->h_unit_own_hi.push_back(INT32_MAX);
 			db->max_unit_len = std::max(db->max_unit_len, e - uint32_t(b) + uint32_t(k));
-			if (e == npos) break;
 		}
 	}
 	hipError_t e;
@@ -1759,7 +1769,11 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 			hipLaunchKernelGGL(seed_kernel<false>, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
 	}
 	HIP_TRY(hipEventRecord(ev[1], c->stream), c->err);
-	if (seeds_only) return TNT_OK;
+	if (seeds_only) { // (every event of the set is recorded: the stage timings walk over all of them)
+		HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
+		HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
+		return TNT_OK;
+	}
 
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
@@ -1924,6 +1938,296 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	return TNT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Targets that do not fit one seed work unit (genomes; dense seeding with short hash words).  The reference's culls, its
+// choice of the strand that is bound first and its pairing loops act on the lists of the WHOLE target
+// (amplicon_search.cpp:96-674, padlock_search.cpp, probe_search.cpp), and the first cull's outcome is not local
+// (cull_oligo_match counts the strands of list successors, sort_by_oligo_loc is not a strict weak order: SURVEY Q4, Q5).
+// So such a target is only SEEDED (windows of k-mer positions, every position once) and BOUND (every seed the first cull
+// keeps, through the same bucket -> pre-filter -> bind kernels as everything else) on the device; its seed lists are
+// merged per (target, assay) on the host, where the first cull, the bind / cull sequence and the pairing loops run on the
+// complete lists with the code the pair kernel runs (tnt_pair.hip.h is compiled for both sides).
+static void run_with_stack(size_t bytes, void *(*fn)(void *), void *arg)
+{
+	pthread_attr_t attr;
+	pthread_attr_init(&attr);
+	pthread_attr_setstacksize(&attr, bytes);
+	pthread_t th;
+	if (pthread_create(&th, &attr, fn, arg) == 0) pthread_join(th, nullptr);
+	else fn(arg); // (falls back to the caller's stack; lists that need more than it has are rare)
+	pthread_attr_destroy(&attr);
+}
+
+struct LongJob {
+	PairArgs args;
+	const std::vector<Group> *groups;
+	// first cull
+	std::vector<ListT<PAIR_HOST> *> lists; // one scratch list
+	int mode; // 0: first culls, 1: pairing
+	// first-cull input / output
+	const std::vector<Item> *all_items;
+	const std::vector<uint32_t> *seg_begin; // [n_groups + 1] segments of all_items (sorted in list order)
+	const std::vector<uint32_t> *seg_assay;
+	const tnt_ctx *ctx;
+	std::vector<uint8_t> *valid;            // per item of all_items
+	std::vector<uint8_t> *minus_first;      // per segment
+	bool overflow;
+};
+
+static void *long_job_main(void *p)
+{
+	LongJob &J = *static_cast<LongJob *>(p);
+	if (J.mode == 0) {
+		ListT<PAIR_HOST> *l = new ListT<PAIR_HOST>;
+		const std::vector<Item> &items = *J.all_items;
+		for (size_t g = 0; g + 1 < J.seg_begin->size(); g++) {
+			const uint32_t b = (*J.seg_begin)[g], e = (*J.seg_begin)[g + 1];
+			const AssayDev &A = J.ctx->h_assays[(*J.seg_assay)[g]];
+			if (e - b > uint32_t(PAIR_HOST)) {
+				J.overflow = true;
+				continue;
+			}
+			if (A.kind != 0) { // probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454)
+				for (uint32_t i = b; i < e; i++) (*J.valid)[i] = 1;
+				continue;
+			}
+			// amplicon(): the assembled match list (already in the order the cull's stable sort by target_loc leaves it in)
+			l->n = int(e - b);
+			for (uint32_t i = b; i < e; i++) {
+				Entry &en = l->e[i - b];
+				const uint32_t role = (items[i].info >> ITEM_SLOT_SHIFT) % 3u;
+				en.loc5 = en.loc3 = 0;
+				en.tloc = items[i].tloc;
+				en.rec = int32_t(i); // remember which item this is
+				en.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((items[i].info & ITEM_MINUS) ? MMINUS : MPLUS));
+			}
+			int cm = 0, cp = 0;
+			cull(*l, J.ctx->opt.max_len, A.has_probe != 0, J.ctx->opt.single_primer_pcr != 0, cm, cp); // amplicon_search.cpp:128
+			for (int i = 0; i < l->n; i++) (*J.valid)[size_t(l->e[i].rec)] = 1;
+			(*J.minus_first)[g] = cm < cp ? 1 : 0; // :131
+		}
+		delete l;
+	} else {
+		for (const Group &G : *J.groups) pair_group<PAIR_HOST>(J.args, G);
+	}
+	return nullptr;
+}
+
+static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &out)
+{
+	const size_t u0 = db->n_short_units, u1 = db->h_unit_target.size();
+	if (u0 >= u1) return TNT_OK;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	if (hipError_t stale = hipGetLastError()) { // nothing before this point may have failed
+		ctx->err = std::string("before the long-target path: ") + hipGetErrorString(stale);
+		return TNT_E_DEVICE;
+	}
+	uint32_t *cnt = ctx->counters.p;
+	// ---- seeds of every window (the seed kernel's unit-level output: kept seeds before the cull)
+	std::vector<SeedOut> raw;
+	for (int attempt = 0;; attempt++) {
+		size_t tpb = 1;
+		int rc = plan(ctx, db, tpb);
+		if (rc) return rc;
+		double positions = 0.0;
+		for (size_t u = u0; u < u1; u++) positions += double(db->h_unit_end[u] - db->h_unit_begin[u]);
+		const double words = double(size_t(1) << (2 * ctx->opt.hash_word_size));
+		const size_t cap = size_t(positions * double(ctx->n_entries) / words * 1.5) + (size_t(1) << 20);
+		if (cap > (size_t(1) << 31)) {
+			ctx->err = "too many seeds on the long targets of this batch";
+			return TNT_E_LIMIT;
+		}
+		HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err);
+		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+		rc = enqueue_batch(ctx, db, u0, u1, true);
+		if (rc) return rc;
+		uint32_t h[C_COUNT];
+		HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		if (hipError_t bad = hipGetLastError()) {
+			ctx->err = std::string("seeding the windows of long targets: ") + hipGetErrorString(bad);
+			return TNT_E_DEVICE;
+		}
+		if ((h[C_ERR] & ERR_SEED_OVERFLOW) && attempt < 16) { // a window's list overflowed: fewer assays per pass, then shorter windows
+			if (ctx->chunk_begin.size() < ctx->h_assays.size() + 1) {
+				ctx->chunk_scale *= 0.5;
+			} else {
+				ctx->unit_scale *= 0.5;
+				HIP_TRY(build_units(ctx, db), ctx->err);
+				return search_long_targets(ctx, db, out); // the unit ranges changed
+			}
+			continue;
+		}
+		if (h[C_ERR]) {
+			ctx->err = err_text(h[C_ERR]);
+			return TNT_E_LIMIT;
+		}
+		if (h[C_SEEDS] > cap) {
+			ctx->err = "seed output overflow on a long target";
+			return TNT_E_LIMIT;
+		}
+		raw.resize(h[C_SEEDS]);
+		if (!raw.empty()) HIP_TRY(hipMemcpy(raw.data(), ctx->seeds_out.p, raw.size() * sizeof(SeedOut), hipMemcpyDeviceToHost), ctx->err);
+		ctx->seeds_out.release();
+		break;
+	}
+	if (raw.empty()) return TNT_OK;
+
+	// ---- per (target, assay) lists in the reference's list order
+	std::vector<Item> items(raw.size());
+	std::vector<unsigned long long> key(raw.size());
+	std::vector<uint32_t> order(raw.size());
+	for (size_t i = 0; i < raw.size(); i++) {
+		const SeedOut &sd = raw[i];
+		const uint32_t assay = sd.assay_role >> 2, role = sd.assay_role & 3u;
+		const AssayDev &A = ctx->h_assays[assay];
+		items[i] = Item{sd.target, sd.target_loc, sd.query_loc | (sd.strand_minus ? ITEM_MINUS : 0u) | ((assay * 3u + role) << ITEM_SLOT_SHIFT), 0};
+		// the order of seed_key (tnt_seed.hip.h): PCR lists by (target_loc, assembly group F- R- F+ R+ P- P+, word);
+		// hash-overload lists by (list, diagonal, word)
+		unsigned long long k;
+		if (A.kind == 0) {
+			const unsigned long long rank = role == 2 ? (sd.strand_minus ? 4u : 5u) : ((sd.strand_minus ? 0u : 2u) + role);
+			k = ((unsigned long long)sd.target_loc << 24) | (rank << 21) | ((unsigned long long)sd.query_loc << 14);
+		} else {
+			const unsigned long long listid = (sd.strand_minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
+			k = (listid << 54) | ((unsigned long long)(long(sd.query_loc) - long(sd.target_loc) + (1l << 33)) << 20) | ((unsigned long long)sd.query_loc << 13);
+		}
+		key[i] = k;
+		order[i] = uint32_t(i);
+	}
+	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+		if (items[x].target != items[y].target) return items[x].target < items[y].target;
+		const uint32_t ax = (items[x].info >> ITEM_SLOT_SHIFT) / 3u, ay = (items[y].info >> ITEM_SLOT_SHIFT) / 3u;
+		if (ax != ay) return ax < ay;
+		return key[x] < key[y];
+	});
+	std::vector<Item> sorted(raw.size());
+	std::vector<uint32_t> seg_begin, seg_assay;
+	for (size_t i = 0; i < order.size(); i++) {
+		sorted[i] = items[order[i]];
+		const uint32_t assay = (sorted[i].info >> ITEM_SLOT_SHIFT) / 3u;
+		if (i == 0 || sorted[i].target != sorted[i - 1].target || assay != seg_assay.back()) {
+			seg_begin.push_back(uint32_t(i));
+			seg_assay.push_back(assay);
+		}
+	}
+	seg_begin.push_back(uint32_t(sorted.size()));
+
+	// ---- first cull of every list (amplicon_search.cpp:128-131) on the host
+	std::vector<uint8_t> valid(sorted.size(), 0), minus_first(seg_assay.size(), 0);
+	LongJob job;
+	memset(&job.args, 0, sizeof(job.args));
+	job.mode = 0;
+	job.all_items = &sorted;
+	job.seg_begin = &seg_begin;
+	job.seg_assay = &seg_assay;
+	job.ctx = ctx;
+	job.valid = &valid;
+	job.minus_first = &minus_first;
+	job.overflow = false;
+	job.groups = nullptr;
+	run_with_stack(size_t(64) << 20, long_job_main, &job);
+	if (job.overflow) {
+		ctx->err = "more than 32768 seeds of one assay on one target";
+		return TNT_E_LIMIT;
+	}
+
+	// ---- the kept seeds become bind work items, grouped per (target, assay)
+	std::vector<Item> bind_items;
+	std::vector<Group> groups;
+	std::vector<uint32_t> unit_target;
+	std::vector<int32_t> own_lo, own_hi;
+	for (size_t g = 0; g + 1 < seg_begin.size(); g++) {
+		const uint32_t first = uint32_t(bind_items.size());
+		for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++)
+			if (valid[i]) bind_items.push_back(sorted[i]);
+		const uint32_t count = uint32_t(bind_items.size()) - first;
+		if (!count) continue;
+		const uint32_t t = sorted[seg_begin[g]].target;
+		if (unit_target.empty() || unit_target.back() != t) unit_target.push_back(t), own_lo.push_back(INT32_MIN), own_hi.push_back(INT32_MAX);
+		groups.push_back(Group{uint32_t(unit_target.size() - 1), seg_assay[g] | (minus_first[g] ? GROUP_MINUS_FIRST : 0u), first, count});
+	}
+	if (bind_items.empty()) return TNT_OK;
+
+	// ---- bind them on the device, a million at a time: bucket -> pre-filter -> bind, as a search phase does
+	const DbView v = make_view(db, 0, db->n_targets);
+	std::vector<int32_t> result(bind_items.size(), -1);
+	std::vector<BoundRec> pool;
+	const size_t CHUNK = size_t(1) << 20;
+	for (size_t c0 = 0; c0 < bind_items.size(); c0 += CHUNK) {
+		const size_t nc = std::min(CHUNK, bind_items.size() - c0);
+		std::vector<uint32_t> queue(nc);
+		for (size_t i = 0; i < nc; i++) queue[i] = uint32_t(i);
+		const uint32_t n32 = uint32_t(nc);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		HIP_TRY(hipMemcpy(ctx->items.p, bind_items.data() + c0, nc * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(hipMemcpy(ctx->qb.p, queue.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(hipMemcpy(cnt + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		BindArgs b = bind_args(ctx, v);
+		b.groups = nullptr;
+		launch_bind_phase(ctx, b, v, db->n_exceptions != 0, ctx->qb.p, cnt + C_QB, nullptr);
+		uint32_t h[C_COUNT];
+		HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		HIP_TRY(hipGetLastError(), ctx->err);
+		if (h[C_ERR]) {
+			ctx->err = err_text(h[C_ERR]);
+			return TNT_E_LIMIT;
+		}
+		std::vector<int32_t> res(nc);
+		HIP_TRY(hipMemcpy(res.data(), ctx->result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
+		const size_t np = std::min<size_t>(h[C_POOL], POOL_CAP), base = pool.size();
+		pool.resize(base + np);
+		if (np) HIP_TRY(hipMemcpy(pool.data() + base, ctx->pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		for (size_t i = 0; i < nc; i++) result[c0 + i] = res[i] >= 0 ? int32_t(base + size_t(res[i])) : res[i];
+		ctx->acc_items += nc;
+	}
+
+	// ---- the bind / cull sequence and the pairing loops on the whole lists (pair_group, compiled for the host)
+	std::vector<Hit> hits(std::max<size_t>(1024, pool.size() * 2));
+	for (;;) {
+		uint32_t n_hits = 0, err = 0, zero = 0;
+		PairArgs &p = job.args;
+		memset(&p, 0, sizeof(p));
+		p.groups = groups.data();
+		p.items = bind_items.data();
+		p.result = result.data();
+		p.pool = pool.data();
+		p.assays = ctx->h_assays.data();
+		p.db.first_seq_index = db->first_seq_index;
+		p.max_len = ctx->opt.max_len;
+		p.single_primer_pcr = ctx->opt.single_primer_pcr;
+		p.min_max_primer_clamp = ctx->opt.min_max_primer_clamp;
+		p.assay_format = ctx->opt.assay_format;
+		p.target_strand = ctx->opt.target_strand;
+		p.hits = hits.data();
+		p.hit_cap = uint32_t(hits.size());
+		p.hit_count = &n_hits;
+		p.err = &err;
+		p.n_big = &zero;
+		p.unit_target = unit_target.data();
+		p.unit_own_lo = own_lo.data();
+		p.unit_own_hi = own_hi.data();
+		job.mode = 1;
+		job.groups = &groups;
+		run_with_stack(size_t(64) << 20, long_job_main, &job);
+		if (err & ERR_HIT_OVERFLOW) {
+			hits.resize(hits.size() * 4);
+			continue;
+		}
+		if (err) {
+			ctx->err = err_text(err);
+			return TNT_E_LIMIT;
+		}
+		out.resize(n_hits);
+		if (n_hits) memcpy(out.data(), hits.data(), size_t(n_hits) * sizeof(tnt_hit));
+		break;
+	}
+	return TNT_OK;
+}
+
 int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 {
 	if (ctx) ctx->dev_hits_valid = false;
@@ -1939,7 +2243,7 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	if (rc) return rc;
 	tpb = std::max<size_t>(1, size_t(double(tpb) * ctx->batch_scale));
 	ctx->n_batches = 0;
-	const size_t n_units = db->h_unit_target.size();
+	const size_t n_units = db->n_short_units; // the windows of long targets are handled by search_long_targets
 	for (size_t u0 = 0; u0 < n_units; u0 += tpb) {
 		rc = enqueue_batch(ctx, db, u0, std::min(n_units, u0 + tpb), false);
 		if (rc) return rc;
@@ -2012,25 +2316,25 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	}
 	if (n) HIP_TRY(hipMemcpy(ctx->h_hits, ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
 	size_t n_unique = n;
-	if (n > 1 && ctx->pending_db && ctx->pending_db->split) {
-		// overlapping windows of a long target report what lies in their overlap twice, identically: keep one copy
-		std::vector<uint32_t> order(n);
-		for (size_t i = 0; i < n; i++) order[i] = uint32_t(i);
-		const tnt_hit *H = ctx->h_hits;
-		std::sort(order.begin(), order.end(), [H](uint32_t a, uint32_t b) {
-			const int c = memcmp(&H[a], &H[b], offsetof(tnt_hit, forward_align));
-			return c != 0 ? c < 0 : a < b;
-		});
-		std::vector<uint32_t> keep;
-		for (size_t i = 0; i < n; i++)
-			if (i == 0 || memcmp(&H[order[i]], &H[order[i - 1]], offsetof(tnt_hit, forward_align)) != 0 ||
-			    strcmp(H[order[i]].forward_align, H[order[i - 1]].forward_align) != 0 ||
-			    strcmp(H[order[i]].reverse_align, H[order[i - 1]].reverse_align) != 0 || strcmp(H[order[i]].probe_align, H[order[i - 1]].probe_align) != 0)
-				keep.push_back(order[i]);
-		std::sort(keep.begin(), keep.end());
-		for (size_t i = 0; i < keep.size(); i++)
-			if (keep[i] != i) ctx->h_hits[i] = ctx->h_hits[keep[i]];
-		n_unique = keep.size();
+	if (ctx->pending_db && !ctx->pending_db->h_long_targets.empty()) {
+		// targets seeded in windows: lists merged per (target, assay), culled and paired whole on the host
+		std::vector<tnt_hit> extra;
+		const int rc = search_long_targets(ctx, ctx->pending_db, extra);
+		if (rc) return rc;
+		if (!extra.empty()) {
+			const size_t total = n + extra.size();
+			if (total > ctx->h_hits_cap) {
+				tnt_hit *bigger = nullptr;
+				const size_t cap = total + total / 2;
+				HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bigger), cap * sizeof(tnt_hit), hipHostMallocDefault), ctx->err);
+				if (n) memcpy(bigger, ctx->h_hits, n * sizeof(tnt_hit));
+				if (ctx->h_hits) (void)hipHostFree(ctx->h_hits);
+				ctx->h_hits = bigger;
+				ctx->h_hits_cap = cap;
+			}
+			memcpy(ctx->h_hits + n, extra.data(), extra.size() * sizeof(tnt_hit));
+			n_unique = total;
+		}
 	}
 	// stage timings
 	tnt_timing &T = ctx->timing;
@@ -2050,7 +2354,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n_unique;
 	T.n_filtered = cnt[C_FILTERED];
-	ctx->dev_hits_valid = n_unique == n;
+	ctx->dev_hits_valid = n_unique == n; // hits of long targets only exist on the host
 	ctx->dev_hits_n = n;
 	if (hits) *hits = ctx->h_hits;
 	if (n_hits) *n_hits = n_unique;
@@ -2065,7 +2369,7 @@ int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hit
 		return TNT_E_ARG;
 	}
 	if (!ctx->dev_hits_valid) {
-		ctx->err = "the device copy of the hits still holds the duplicates of overlapping target windows";
+		ctx->err = "the hits of targets that were seeded in windows only exist in the host copy";
 		return TNT_E_UNSUPPORTED;
 	}
 	*device_hits = ctx->hits.p;
@@ -2081,7 +2385,7 @@ int tnt_search_hits_compact(tnt_ctx *ctx, const void **device_blob, size_t *n_by
 		return TNT_E_ARG;
 	}
 	if (!ctx->dev_hits_valid) {
-		ctx->err = "the device copy of the hits still holds the duplicates of overlapping target windows";
+		ctx->err = "the hits of targets that were seeded in windows only exist in the host copy";
 		return TNT_E_UNSUPPORTED;
 	}
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);

@@ -18,10 +18,23 @@
 
 #include <hip/hip_runtime.h>
 #include "tnt_dev.h"
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <algorithm>
+#endif
 
 namespace tnt {
 
+// The list surgery below (sorts, culls, pairing loops) also runs on the host, for targets too long for one seed work
+// unit: their (target, assay) lists are assembled from all windows and replayed whole (tnt_host.hip, search_long_targets).
+#define TNT_HD __host__ __device__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TNT_SET_ERR(PTR, CODE) atomicOr((PTR), (CODE))
+#else
+#define TNT_SET_ERR(PTR, CODE) (*(PTR) |= (CODE))
+#endif
+
 constexpr int PAIR_THREADS = 64;
+constexpr int PAIR_HOST = 1 << 15; // entries of one (target, assay) list in the host replay
 constexpr int PAIR_MAX = 64;  // entries of one (target, assay) group handled by the common instance of the pair kernel
 constexpr int PAIR_BIG = 512; // ... and by the instance for crowded groups (short hash words, repeats); == LIST_MAX of the seed kernel
 
@@ -61,14 +74,14 @@ struct Entry {
 	uint8_t mask;
 };
 
-__device__ __forceinline__ void copy_text(char *dst, const char *src)
+TNT_HD inline void copy_text(char *dst, const char *src)
 {
 	int i = 0;
 	for (; i < ALIGN_TEXT - 1 && src[i]; i++) dst[i] = src[i];
 	dst[i] = 0;
 }
 
-__device__ void init_hit(Hit &h, const AssayDev &A, int seq_index)
+TNT_HD inline void init_hit(Hit &h, const AssayDev &A, int seq_index)
 {
 	// hybrid_sig::init(), hybrid_sig.h:54-110
 	h.assay_id = A.id, h.degen_id = A.degen_id, h.seq_index = seq_index;
@@ -86,7 +99,7 @@ __device__ void init_hit(Hit &h, const AssayDev &A, int seq_index)
 }
 
 // sort_by_oligo_loc, amplicon_search.cpp:12-26 (mixed keys)
-__device__ __forceinline__ bool oligo_loc_less(const Entry &x, const Entry &y)
+TNT_HD inline bool oligo_loc_less(const Entry &x, const Entry &y)
 {
 	if (!(x.loc5 + x.loc3) || !(y.loc5 + y.loc3)) return x.tloc < y.tloc;
 	if (x.loc5 == y.loc5) return x.loc3 < y.loc3;
@@ -94,7 +107,7 @@ __device__ __forceinline__ bool oligo_loc_less(const Entry &x, const Entry &y)
 }
 
 // sort_by_bound_match, bind_oligo.cpp:49-82 (alignment.size() is 3 * columns + constant)
-__device__ __forceinline__ bool bound_less(const Entry &x, const Entry &y, const BoundRec *pool)
+TNT_HD inline bool bound_less(const Entry &x, const Entry &y, const BoundRec *pool)
 {
 	if (x.loc5 != y.loc5) return x.loc5 < y.loc5;
 	if (x.loc3 != y.loc3) return x.loc3 < y.loc3;
@@ -107,7 +120,7 @@ __device__ __forceinline__ bool bound_less(const Entry &x, const Entry &y, const
 }
 
 // oligo_info::operator<, tntblast.h:230-242
-__device__ __forceinline__ bool info_less(const Entry &x, const Entry &y, const BoundRec *pool)
+TNT_HD inline bool info_less(const Entry &x, const Entry &y, const BoundRec *pool)
 {
 	if (x.loc5 != y.loc5) return x.loc5 < y.loc5;
 	if (x.loc3 != y.loc3) return x.loc3 < y.loc3;
@@ -120,8 +133,14 @@ template <int N> struct ListT {
 };
 
 // stable insertion sort == std::list::sort for a strict weak order
-template <class Less> __device__ void stable_sort(Entry *e, int n, Less less)
+template <class Less> TNT_HD void stable_sort(Entry *e, int n, Less less)
 {
+#if !defined(__HIP_DEVICE_COMPILE__)
+	if (n > 64) { // host replay of long lists
+		std::stable_sort(e, e + n, less);
+		return;
+	}
+#endif
 	for (int i = 1; i < n; i++) {
 		const Entry x = e[i];
 		int j = i - 1;
@@ -140,7 +159,7 @@ template <class Less> __device__ void stable_sort(Entry *e, int n, Less less)
 // blocks following the binary digits of n from the most significant one; every block is merged up from single
 // elements in aligned halves; the blocks are then merged from the last one leftwards.  A merge takes from the right
 // run iff comp(right, left), else from the left one.
-template <class Less> __device__ void merge_runs(Entry *e, Entry *tmp, int lo, int mid, int hi, Less less)
+template <class Less> TNT_HD void merge_runs(Entry *e, Entry *tmp, int lo, int mid, int hi, Less less)
 {
 	int a = lo, b = mid, o = lo;
 	while (a < mid && b < hi) {
@@ -152,7 +171,7 @@ template <class Less> __device__ void merge_runs(Entry *e, Entry *tmp, int lo, i
 	for (int i = lo; i < hi; i++) e[i] = tmp[i];
 }
 
-template <class Less> __device__ void list_sort(Entry *e, Entry *tmp, int n, Less less)
+template <class Less> TNT_HD void list_sort(Entry *e, Entry *tmp, int n, Less less)
 {
 	if (n < 2) return;
 	// blocks by the binary digits of n, most significant first; each sorted bottom-up in aligned halves
@@ -179,7 +198,7 @@ template <class Less> __device__ void list_sort(Entry *e, Entry *tmp, int n, Les
 
 // cull_oligo_match, amplicon_search.cpp:679-765; returns the (minus, plus) "strand counts" the way the
 // reference computes them (mask of the element FOLLOWING each valid one, :748-755; end() counts nothing)
-template <int N> __device__ void cull(ListT<N> &l, int max_len, bool has_probe, bool single_primer, int &cnt_minus, int &cnt_plus)
+template <int N> TNT_HD void cull(ListT<N> &l, int max_len, bool has_probe, bool single_primer, int &cnt_minus, int &cnt_plus)
 {
 	const uint32_t threshold = uint32_t(max_len) + 50u;
 	Entry tmp[N];
@@ -220,7 +239,7 @@ template <int N> __device__ void cull(ListT<N> &l, int max_len, bool has_probe, 
 }
 
 // bind_oligo_to_{minus,plus}_strand, mask overload: list surgery of bind_oligo.cpp:476-500,806-826
-template <int N> __device__ void bind_step(ListT<N> &l, uint8_t want, const BoundRec *pool)
+template <int N> TNT_HD void bind_step(ListT<N> &l, uint8_t want, const BoundRec *pool)
 {
 	Entry cur[N];
 	int nc = 0;
@@ -247,13 +266,17 @@ template <int N> __device__ void bind_step(ListT<N> &l, uint8_t want, const Boun
 }
 
 struct PairArgs;
-template <int N> __device__ void pair_group(const PairArgs &a, const Group G);
+template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G);
 
-__device__ Hit *alloc_hit(const PairArgs &a)
+TNT_HD inline Hit *alloc_hit(const PairArgs &a)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
 	const uint32_t o = atomicAdd(a.hit_count, 1u);
+#else
+	const uint32_t o = (*a.hit_count)++;
+#endif
 	if (o >= a.hit_cap) {
-		atomicOr(a.err, ERR_HIT_OVERFLOW);
+		TNT_SET_ERR(a.err, ERR_HIT_OVERFLOW);
 		return nullptr;
 	}
 	return a.hits + o;
@@ -438,7 +461,7 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 	}
 }
 
-template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
+template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 {
 	const AssayDev A = a.assays[G.assay & GROUP_ASSAY_MASK];
 	const int seq_index = int(a.db.first_seq_index + a.unit_target[G.target]);
@@ -447,7 +470,7 @@ template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 
 	const uint32_t g_count = G.count & ~GROUP_ALIVE;
 	if (g_count > uint32_t(N)) {
-		atomicOr(a.err, ERR_LIST_OVERFLOW);
+		TNT_SET_ERR(a.err, ERR_LIST_OVERFLOW);
 		return;
 	}
 
@@ -483,6 +506,17 @@ template <int N> __device__ void pair_group(const PairArgs &a, const Group G)
 		if (res >= 0) any_bound = true;
 	}
 	if (!any_bound) return;
+#if !defined(__HIP_DEVICE_COMPILE__)
+	if (l.n > 64) { // host replay of long lists: the same order (keys are unique), not quadratic
+		unsigned long long *idx = new unsigned long long[size_t(l.n)];
+		Entry *cp = new Entry[size_t(l.n)];
+		for (int i = 0; i < l.n; i++) idx[i] = uint32_t(i), cp[i] = l.e[i];
+		std::sort(idx, idx + l.n, [&](unsigned long long x, unsigned long long y) { return order[x] < order[y]; });
+		for (int i = 0; i < l.n; i++) l.e[i] = cp[idx[i]];
+		delete[] idx;
+		delete[] cp;
+	} else
+#endif
 	for (int i = 1; i < l.n; i++) { // insertion sort by key (keys are unique)
 		const Entry x = l.e[i];
 		const unsigned long long kx = order[i];
