@@ -199,6 +199,10 @@ int tnt_fasta_next(tnt_fasta_reader *reader, tnt_ctx *ctx, size_t max_bytes, tnt
 void tnt_fasta_close(tnt_fasta_reader *reader);
 /* Defline of target i (databases made from FASTA text; empty otherwise).  Owned by the database. */
 int tnt_db_defline(const tnt_db *db, size_t i, const char **defline, size_t *len);
+/* Length of target i in bases and the size of its record in the file (defline, line ends and all): the "approximate
+ * length" the reference cuts long targets by (sequence_data_fastx.cpp:63-76, tntblast_local.cpp:282-289); equal to the
+ * number of bases for databases packed from codes.                                                                     */
+int tnt_db_target_info(const tnt_db *db, size_t i, uint32_t *n_bases, uint64_t *record_bytes);
 /* 1-byte codes (seq.h:12-35) of target i, rebuilt from the packed rows; returns the length or a TNT_E_* code. */
 int64_t tnt_db_target_codes(tnt_ctx *ctx, tnt_db *db, size_t i, uint8_t *codes, size_t cap);
 /* Where the time of the last ingest went (ms) and what it moved. */

@@ -40,7 +40,20 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("force_probe", 3, 150, 8, 19, ["-A", "PROBE", "-E", "45"]),
     # the same search on a FASTQ database
     ("fastq", 3, 200, 16, 20, ["-e", "40", "-E", "40"]),
+    # primer / probe masking of the amplicon text (mask_binding_sites, tntblast_util.cpp:97-576)
+    ("mask_primers_k", 3, 200, 16, 23, ["-e", "40", "-E", "40", "-k", "T"]),
+    ("mask_probe_K", 3, 200, 16, 24, ["-e", "40", "-E", "40", "-K", "T"]),
+    ("replace_primers_r", 2, 200, 16, 25, ["-e", "40", "-r", "T"]),
+    ("mask_all_krK_m1", 3, 200, 16, 26, ["-e", "38", "-E", "38", "-k", "T", "-r", "T", "-K", "T", "-m", "1"]),
+    # targets longer than --max-target-len are searched in overlapping fragments (tntblast_local.cpp:282-289,438-468):
+    # matches cut off by a fragment's edge are dropped, matches found by two fragments are made unique
+    # (uniquify_results).  One 620-kb record at the default threshold (500 000); one 64-kb record cut into six.
+    ("fragment_default", 2, 660, 12, 21, ["-e", "40"]),
+    ("fragment_small", 3, 104, 12, 22, ["-e", "40", "-E", "40", "--max-target-len", "12000", "-l", "500"]),
 ]
+
+LONG_RECORDS = {"long_target": 150, "fragment_default": 620, "fragment_small": 64}
+MAX_TARGET_LEN = {"fragment_default": 500000, "fragment_small": 12000}
 
 
 def closing_lines(stdout):
@@ -52,11 +65,32 @@ def closing_lines(stdout):
     return []
 
 
-def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False):
+def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False, name=None):
     wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
     offsets = wl.offsets
-    if long_target:  # the first 150 records become one
-        offsets = np.concatenate([[0], wl.offsets[150:]]).astype(np.uint64)
+    if long_target or name in LONG_RECORDS:  # the first records become one
+        k = LONG_RECORDS.get(name, 150)
+        offsets = np.concatenate([[0], wl.offsets[k:]]).astype(np.uint64)
+    if name in MAX_TARGET_LEN:
+        # copies of planted sites around the first cut of the long record: one amplicon across the cut, one inside the
+        # stretch both fragments read, one at the very start of the second fragment
+        nb = int(offsets[1])
+        approx = len(b">seq0 synthetic target\n") + nb + (nb + 69) // 70  # bytes of the record, as the reference counts
+        n = 2
+        while approx > n * MAX_TARGET_LEN[name]:
+            n += 1
+        cut = approx // n + (1 if approx % n else 0)  # last base of the first fragment's own part
+        rng = np.random.default_rng(seed)
+        codes = wl.codes.copy()
+        for a, at in zip(wl.assays[:3], (cut - 120, cut + 300, cut + 1)):
+            amp = 260
+            seg = list("ACGT"[i] for i in rng.integers(0, 4, amp))
+            seg[:len(a.forward)] = a.forward
+            seg[amp - len(a.reverse):] = synth.revcomp(a.reverse)
+            if a.probe:
+                seg[100:100 + len(a.probe)] = a.probe
+            codes[at:at + amp] = synth.encode("".join(seg))
+        wl.codes = codes
     with open(os.path.join(d, "db.fna"), "wb") as f:
         if fastq:  # one sequence line per record; the quality line starts with '@' or '+' now and then
             for t in range(len(offsets) - 1):
@@ -83,7 +117,7 @@ def main():
         for f in os.listdir(d):
             if f.startswith("ref.out") or f.startswith("hip.out"):
                 os.remove(os.path.join(d, f))
-        write_case(d, cfg, nt, na, seed, long_target=(name == "long_target"), fastq=(name == "fastq"))
+        write_case(d, cfg, nt, na, seed, fastq=(name == "fastq"), name=name)
         common = ["-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna")] + flags
         env = dict(os.environ, OMP_NUM_THREADS="1")
         r1 = subprocess.run([REF] + common + ["-o", os.path.join(d, "ref.out")], env=env, capture_output=True, text=True)

@@ -126,7 +126,39 @@ def structure_oligos(rng):
     return oligos
 
 
+def g7_case(cli_compare, name, cfg, nt, na, seed, flags):
+    """One end-to-end case through the reference binary: inputs + every output file + the closing stdout lines."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        cli_compare.write_case(d, cfg, nt, na, seed, fastq=(name == "fastq"), name=name)
+        out = os.path.join(d, "ref.out")
+        r = subprocess.run([cli_compare.REF, "-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna"), "-o", out] + flags,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        files = {f[len("ref.out"):]: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.startswith("ref.out")}
+        case = {"name": name, "flags": flags, "assays": open(os.path.join(d, "assays.txt")).read(),
+                "fasta": open(os.path.join(d, "db.fna")).read(), "files": files, "closing": cli_compare.closing_lines(r.stdout)}
+    print("G7", name, {k: len(v) for k, v in files.items()}, "bytes,", sum(v.count("name = ") for v in files.values()), "records,",
+          len(case["closing"]), "closing stdout lines")
+    return case
+
+
+def add_g7_cases(names):
+    """`python tests/gen_golden.py g7 <case> ...`: (re)generates only the named G7 cases, the others stay as they are."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import cli_compare
+    import golden_util as gu
+    have = gu.load("g7_cli.json.gz")["cases"]
+    for name, cfg, nt, na, seed, flags in cli_compare.CASES:
+        if name in names:
+            have = [c for c in have if c["name"] != name] + [g7_case(cli_compare, name, cfg, nt, na, seed, flags)]
+    dump("g7_cli.json.gz", {"cases": have})
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "g7":
+        return add_g7_cases(sys.argv[2:])
     ref = tc.RefImpl()
     rng = np.random.default_rng(20260227)
 
@@ -192,11 +224,12 @@ def main():
     import cli_compare
     cases = []
     for name, cfg, nt, na, seed, flags in cli_compare.CASES:
-        nt, na = min(nt, 120), min(na, 12)
+        if name not in cli_compare.LONG_RECORDS:
+            nt, na = min(nt, 120), min(na, 12)
         with tempfile.TemporaryDirectory() as d:
-            cli_compare.write_case(d, cfg, nt, na, seed, long_target=False, fastq=(name == "fastq"))
             if name == "long_target":
-                continue  # needs more than 150 records; covered by scripts/cli_compare.py on the GPU box
+                continue  # covered by scripts/cli_compare.py on the GPU box (the fragment cases hold long records)
+            cli_compare.write_case(d, cfg, nt, na, seed, fastq=(name == "fastq"), name=name)
             out = os.path.join(d, "ref.out")
             r = subprocess.run([cli_compare.REF, "-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna"), "-o", out] + flags,
                                env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True)

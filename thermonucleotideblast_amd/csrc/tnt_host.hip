@@ -388,6 +388,7 @@ struct tnt_db {
 	uint64_t n_exceptions = 0;
 	std::string deflines;           // FASTA ingest: all deflines back to back
 	std::vector<uint64_t> defline_off;
+	std::vector<uint64_t> record_bytes; // FASTA / FASTQ ingest: bytes of every record, defline and line ends included
 	tnt_ingest_timing ingest;
 	DevBuf<uint32_t> packed, len, exc_off, exc_pos;
 	DevBuf<uint64_t> word_off;
@@ -1381,6 +1382,8 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 		}
 		db->defline_off[r + 1] = db->defline_off[r] + (def_end[r] - def_begin[r]);
 	}
+	db->record_bytes.resize(n);
+	for (size_t r = 0; r < n; r++) db->record_bytes[r] = rec[r + 1] - rec[r];
 	db->deflines.resize(db->defline_off[n]);
 	parallel_for(n, [&](size_t r) { memcpy(&db->deflines[db->defline_off[r]], text + def_begin[r], def_end[r] - def_begin[r]); });
 	db->n_targets = n;
@@ -1672,6 +1675,14 @@ int tnt_db_defline(const tnt_db *db, size_t i, const char **defline, size_t *len
 	}
 	*defline = db->deflines.data() + db->defline_off[i];
 	*len = size_t(db->defline_off[i + 1] - db->defline_off[i]);
+	return TNT_OK;
+}
+
+int tnt_db_target_info(const tnt_db *db, size_t i, uint32_t *n_bases, uint64_t *record_bytes)
+{
+	if (!db || i >= db->n_targets) return TNT_E_ARG;
+	if (n_bases) *n_bases = db->h_len[i];
+	if (record_bytes) *record_bytes = db->record_bytes.empty() ? uint64_t(db->h_len[i]) : db->record_bytes[i];
 	return TNT_OK;
 }
 

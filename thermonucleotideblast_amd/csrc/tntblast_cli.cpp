@@ -10,9 +10,11 @@
 //   result order                         hybrid_sig::operator<, hybrid_sig.h:328-357 (std::list::sort, stable)
 //   output records                       tntblast_local.cpp:910-1280, write_alignment tntblast_util.cpp:1313-1335,
 //                                        gc_content :1274-1295, primer_heuristics :917-925 + primer.cpp:44-328
-// Everything between reading the inputs and formatting the hits is one call: tnt_search().
-// Not supported (exit with a message): BLAST / GenBank / EMBL / FASTQ databases, -D, -m 1..4, -k/-K/-r masking, -n, -S,
-// --plex, --best-match, --query-seg, --dump-query, --max-target-len fragmentation, --dinkelbach.
+//   primer / probe masking -k -K -r      mask_binding_sites, tntblast_util.cpp:97-576 (NucCruc evaluations = tnt_bind_batch)
+//   --max-target-len fragmentation       tntblast_local.cpp:282-289,438-468,638-648, seq_len_increment sequence_data.cpp:739-754,
+//                                        uniquify_results tntblast_util.cpp:1555-1755
+// Between reading the inputs and formatting the hits there is one call per batch of targets: tnt_search().
+// Not supported (exit with a message): BLAST / GenBank / EMBL databases, -D, --dinkelbach.
 #include <getopt.h>
 
 #include <algorithm>
@@ -63,6 +65,9 @@ struct Options {
 	bool best_match = false; // --best-match
 	bool multiplex = false;  // --plex
 	bool dump_query = false; // --dump-query
+	long max_target_len = 500000; // --max-target-len, DEFAULT_FRAGMENT_TARGET_LENGTH (tntblast.h:61)
+	enum { MASK_PRIMERS = 1, MASK_PROBE = 2, REPLACE_PRIMERS = 4 }; // tntblast.h:115-117
+	int mask = 0;                 // -k / -K / -r
 };
 
 constexpr size_t INVALID_INDEX = ~size_t(0); // hybrid_sig.h:25
@@ -441,6 +446,272 @@ void select_best_match(std::vector<Record> &m)
 	m.swap(keep);
 }
 
+
+// seq_len_increment, sequence_data.cpp:739-754: length of the pieces a target of (approximate) length `len` is cut into
+std::pair<unsigned int, unsigned int> seq_len_increment(unsigned int len, unsigned int max_len)
+{
+	if (len <= max_len) return std::make_pair(len - 1, 1u);
+	unsigned int n = 2;
+	while (len > n * max_len) n++;
+	return std::make_pair(len / n + ((len % n != 0) ? 1u : 0u), n);
+}
+
+// top_strand, tntblast_util.cpp:1758-1780
+std::string top_strand(const std::string &align)
+{
+	const std::string::size_type start = align.find("5' ");
+	if (start == std::string::npos) fail("top_strand: Unable to parse alignment");
+	const std::string::size_type stop = align.find(" 3'");
+	if (stop == std::string::npos) fail("top_strand: Unable to parse alignment");
+	return align.substr(start + 3, stop - (start + 3));
+}
+
+// uniquify_results, tntblast_util.cpp:1555-1755: fragments of a long target overlap, so a match can be found twice
+// (sometimes once complete and once clipped); of matches that contain one another the larger survives.
+// `oligo_len(r, slot)` = length of the oligo in the forward (0) / reverse (1) slot of record r.
+template <class LEN> void uniquify_results(std::vector<Record> &m, LEN oligo_len)
+{
+	if (m.size() < 2) return;
+	auto range = [](const Record &r) {
+		return r.h.has_primers ? std::make_pair(r.h.amplicon_start, r.h.amplicon_stop) : std::make_pair(r.h.probe_start, r.h.probe_stop);
+	};
+	std::stable_sort(m.begin(), m.end(), [&](const Record &a, const Record &b) { // sort_by_loc, hybrid_sig.h:468-497 (equal ids here)
+		if (a.h.seq_index != b.h.seq_index) return a.h.seq_index < b.h.seq_index;
+		return range(a) < range(b);
+	});
+	std::vector<char> keep(m.size(), 0);
+	size_t start = 0;
+	while (start < m.size()) {
+		size_t stop = start;
+		while (stop < m.size() && m[stop].h.degen_id == m[start].h.degen_id && m[stop].h.seq_index == m[start].h.seq_index) stop++;
+		std::list<size_t> valid;
+		for (size_t it = start; it < stop; it++) {
+			if (valid.empty()) {
+				valid.push_back(it);
+				continue;
+			}
+			const Record &A = m[it];
+			const int fl = oligo_len(A, 0) / 2, rl = oligo_len(A, 1) / 2;
+			int status = 0; // 0 NO_MATCH, 1 A_CONTAINS_B, 2 B_CONTAINS_A
+			for (auto v = valid.begin(); v != valid.end(); ++v) {
+				const Record &B = m[*v];
+				int same = 0;
+				if (A.h.has_primers) {
+					const bool primers_overlap = std::abs(A.h.amplicon_start - B.h.amplicon_start) < fl && std::abs(A.h.amplicon_stop - B.h.amplicon_stop) < rl;
+					if (primers_overlap) {
+						if (A.h.amplicon_start <= B.h.amplicon_start && A.h.amplicon_stop >= B.h.amplicon_stop &&
+						    top_strand(A.h.forward_align).find(top_strand(B.h.forward_align)) != std::string::npos &&
+						    top_strand(A.h.reverse_align).find(top_strand(B.h.reverse_align)) != std::string::npos)
+							same = 1;
+						else if (B.h.amplicon_start <= A.h.amplicon_start && B.h.amplicon_stop >= A.h.amplicon_stop &&
+						         top_strand(B.h.forward_align).find(top_strand(A.h.forward_align)) != std::string::npos &&
+						         top_strand(B.h.reverse_align).find(top_strand(A.h.reverse_align)) != std::string::npos)
+							same = 2;
+						if (A.h.has_probe && B.h.has_probe && (A.h.probe_start != B.h.probe_start || A.h.probe_stop != B.h.probe_stop)) same = 0;
+					}
+				} else {
+					if (A.h.probe_start <= B.h.probe_start && A.h.probe_stop >= B.h.probe_stop &&
+					    top_strand(A.h.probe_align).find(top_strand(B.h.probe_align)) != std::string::npos)
+						same = 1;
+					else if (B.h.probe_start <= A.h.probe_start && B.h.probe_stop >= A.h.probe_stop &&
+					         top_strand(B.h.probe_align).find(top_strand(A.h.probe_align)) != std::string::npos)
+						same = 2;
+				}
+				if (same == 0) continue;
+				if (same == 1) {
+					*v = it; // overwrite B with A and keep searching
+					status = 1;
+				} else {
+					status = 2; // A is not valid
+					break;
+				}
+			}
+			if (status == 0) valid.push_front(it); // valid.splice(valid.begin(), valid_update)
+		}
+		for (size_t v : valid) keep[v] = 1;
+		start = stop;
+	}
+	std::vector<Record> out;
+	for (size_t i = 0; i < m.size(); i++)
+		if (keep[i]) out.push_back(m[i]);
+	m.swap(out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mask_binding_sites, tntblast_util.cpp:97-576 (called from amplicon(), amplicon_search.cpp:539,663): the primer binding
+// sites of an amplicon are lower-cased (-k) or replaced by the primers themselves (-r), the probe's sites lower-cased
+// (-K).  Where a site lies is decided by NucCruc on pieces of the amplicon text; those evaluations are bind requests
+// (tnt_bind_batch, the unit-level kernel instance) against a scratch database whose targets are the pieces.
+struct MaskJob {
+	size_t record;     // index into the batch's records
+	int kind;          // 0 forward primer (5' end, minus strand), 1 reverse primer (3' end, plus), 2 probe plus, 3 probe minus
+	size_t pos;        // probe: position i of the sliding window
+	unsigned int gap_offset, target_len;
+};
+
+// the base NucCruc is given for a character of the amplicon: `complement` for push_front(complement) loads; the "as is"
+// loads of mask_primer_3 / mask_probe pass degenerate letters through the SAME table as the complementing ones
+// (tntblast_util.cpp:300-331,409-441), so for them a degenerate letter stands for its complement
+int mask_code(char ch, bool as_is)
+{
+	static const char *letters = "ACGTIMRSVWYHKDBN"; // seq.h:12-35 codes 0..15
+	static const char *degen_swap = "ACGTIKYSBWRDMHVN";
+	const char u = char(toupper(static_cast<unsigned char>(ch)));
+	const char *p = strchr(letters, u);
+	if (!p || !u) return -1;
+	int code = int(p - letters);
+	if (as_is) code = int(strchr(letters, degen_swap[code]) - letters);
+	return code;
+}
+
+char base_complement_char(char c) // seq.h / tntblast_util: complement of an oligo letter, upper case
+{
+	static const char *from = "ACGTIMRSVWYHKDBN", *to = "TGCAIKYSBWRDMHVN";
+	const char *p = strchr(from, char(toupper(static_cast<unsigned char>(c))));
+	return p ? to[p - from] : c;
+}
+
+template <class OLIGO> void apply_masks_round(tnt_ctx *ctx, const Options &opt, std::vector<Record> &recs, size_t first, OLIGO oligo_of, bool probe_round);
+
+// the probe's windows are cut from the amplicon as the primer pass left it (-r changes its text and its length)
+template <class OLIGO> void apply_masks(tnt_ctx *ctx, const Options &opt, std::vector<Record> &recs, size_t first, OLIGO oligo_of)
+{
+	if (!opt.mask) return;
+	apply_masks_round(ctx, opt, recs, first, oligo_of, false);
+	apply_masks_round(ctx, opt, recs, first, oligo_of, true);
+}
+
+template <class OLIGO> void apply_masks_round(tnt_ctx *ctx, const Options &opt, std::vector<Record> &recs, size_t first, OLIGO oligo_of, bool probe_round)
+{
+	std::map<std::string, int> oligo_index;
+	for (int i = 0; i < tnt_ctx_num_oligos(ctx); i++) oligo_index[tnt_ctx_oligo(ctx, i)] = i;
+	std::vector<uint8_t> codes;
+	std::vector<uint64_t> offs(1, 0);
+	std::vector<tnt_bind_req> reqs;
+	std::vector<MaskJob> jobs;
+	auto add = [&](const std::vector<int> &piece, const std::string &oligo, bool minus, float ct, MaskJob job) {
+		job.target_len = (unsigned int)piece.size();
+		for (int c : piece) codes.push_back(uint8_t(c));
+		offs.push_back(codes.size());
+		tnt_bind_req r;
+		r.seq_index = int(offs.size() - 2);
+		r.oligo = oligo_index.at(oligo);
+		r.strand = minus ? TNT_MINUS : TNT_PLUS;
+		r.query_loc = 0, r.target_loc = 0; // the window is the whole piece (it is never longer than the oligo + 2)
+		r.role = job.kind >= 2 ? 1 : 0;
+		r.ct = ct;
+		reqs.push_back(r);
+		jobs.push_back(job);
+	};
+	const float fwd_ct = opt.t.asymmetric_strand_ratio * opt.t.primer_strand, rev_ct = opt.t.primer_strand;
+	for (size_t ri = first; ri < recs.size(); ri++) {
+		const Record &R = recs[ri];
+		if (!R.h.has_primers) continue; // only amplicon() masks
+		const std::string &amp = R.amplicon;
+		const std::string fo = oligo_of(R, 0), ro = oligo_of(R, 1), po = oligo_of(R, 2);
+		if (!probe_round && (opt.mask & (Options::MASK_PRIMERS | Options::REPLACE_PRIMERS))) {
+			{ // mask_primer_5, :141-243: the first |oligo| characters, complemented and reversed, until a bad character
+				std::vector<int> piece;
+				unsigned int gaps = 0;
+				for (size_t i = 0; i < fo.size() && i < amp.size(); i++) {
+					if (amp[i] == '-') {
+						gaps++;
+						continue;
+					}
+					const int c = mask_code(amp[i], false);
+					if (c < 0) break;
+					piece.push_back(c);
+				}
+				add(piece, fo, true, fwd_ct, MaskJob{ri, 0, 0, gaps, 0});
+			}
+			{ // mask_primer_3, :245-384: the last |oligo| characters as they are; a bad character restarts the piece
+				std::vector<int> piece;
+				unsigned int gaps = 0;
+				for (size_t i = amp.size() >= ro.size() ? amp.size() - ro.size() : 0; i < amp.size(); i++) {
+					if (amp[i] == '-') {
+						gaps++;
+						continue;
+					}
+					const int c = mask_code(amp[i], true);
+					if (c < 0) {
+						piece.clear();
+						continue;
+					}
+					piece.push_back(c);
+				}
+				add(piece, ro, false, rev_ct, MaskJob{ri, 1, 0, gaps, 0});
+			}
+		}
+		if (probe_round && (opt.mask & Options::MASK_PROBE) && R.h.has_probe) { // mask_probe, :387-576: a window of |oligo| + 2 slides over both strands
+			for (int minus = 0; minus < 2; minus++) {
+				std::vector<int> window; // oldest base first, in amplicon order
+				for (size_t i = 0; i < amp.size(); i++) {
+					const int c = mask_code(amp[i], minus == 0);
+					if (c < 0) window.clear();
+					else window.push_back(c);
+					add(window, po, minus != 0, opt.t.probe_strand, MaskJob{ri, 2 + minus, i, 0, 0});
+					if (window.size() == po.size() + 2) window.erase(window.begin());
+				}
+			}
+		}
+	}
+	if (reqs.empty()) return;
+	tnt_db *mdb = nullptr;
+	if (tnt_db_create(ctx, codes.data(), offs.data(), offs.size() - 1, 0, &mdb) != TNT_OK) fail(tnt_last_error(ctx));
+	std::vector<tnt_bind> out(reqs.size());
+	if (tnt_bind_batch(ctx, mdb, reqs.data(), reqs.size(), out.data()) != TNT_OK) fail(tnt_last_error(ctx));
+	tnt_db_destroy(mdb);
+	const bool do_mask = (opt.mask & Options::MASK_PRIMERS) != 0, do_replace = (opt.mask & Options::REPLACE_PRIMERS) != 0;
+	// the primers first (5', then 3'), then the probe passes, per record in the order the reference applies them
+	for (size_t k = 0; k < jobs.size(); k++) {
+		const MaskJob &J = jobs[k];
+		const tnt_bind &b = out[k];
+		std::string &amp = recs[J.record].amplicon;
+		const Record &R = recs[J.record];
+		if (J.kind == 0) {
+			const std::string oligo = oligo_of(R, 0);
+			const size_t len = amp.size(), oligo_len = oligo.size();
+			// alignment_range_target() = (t_first, t_last); in amplicon coordinates (:224-227)
+			const long r1 = long(J.gap_offset) + long(J.target_len) - long(b.t_first) - 1, r2 = long(J.gap_offset) + long(J.target_len) - long(b.t_last) - 1;
+			if (do_replace) {
+				amp = oligo + (size_t(r1 + 1) <= len ? amp.substr(size_t(r1 + 1), len - size_t(r1) - 1) : std::string());
+				if (do_mask)
+					for (size_t j = 0; j < oligo_len && j < amp.size(); j++) amp[j] = char(tolower(static_cast<unsigned char>(amp[j])));
+			} else if (do_mask) {
+				for (long j = r2; j <= r1; j++)
+					if (j >= 0 && size_t(j) < amp.size()) amp[size_t(j)] = char(tolower(static_cast<unsigned char>(amp[size_t(j)])));
+			}
+		} else if (J.kind == 1) {
+			const std::string oligo = oligo_of(R, 1);
+			const size_t len = amp.size(), oligo_len = oligo.size();
+			const long r1 = long(b.t_first) - long(J.gap_offset), r2 = long(b.t_last) - long(J.gap_offset);
+			if (do_replace) {
+				std::string comp(oligo_len, 'A');
+				for (size_t i = 0; i < oligo_len; i++) comp[i] = base_complement_char(oligo[oligo_len - 1 - i]);
+				const long keep = long(len) - long(J.target_len) + r1;
+				amp = amp.substr(0, size_t(std::max(0l, std::min(keep, long(len))))) + comp;
+				if (do_mask)
+					for (size_t j = amp.size() - oligo_len; j < amp.size(); j++) amp[j] = char(tolower(static_cast<unsigned char>(amp[j])));
+			} else if (do_mask) {
+				const long stop = long(len) + r2 + 1 - long(J.target_len);
+				for (long j = long(len) - long(J.target_len) + r1; j < stop; j++)
+					if (j >= 0 && size_t(j) < amp.size()) amp[size_t(j)] = char(tolower(static_cast<unsigned char>(amp[size_t(j)])));
+			}
+		} else if (b.valid && b.tm >= opt.t.min_probe_tm) {
+			long lo, hi;
+			if (J.kind == 2) { // plus strand, :466-482
+				lo = long(b.t_first) + long(J.pos) - (long(J.target_len) - 1);
+				hi = long(b.t_last) + long(J.pos) - (long(J.target_len) - 1);
+			} else { // minus strand, :556-570
+				hi = long(J.pos) - long(b.t_first);
+				lo = long(J.pos) - long(b.t_last);
+			}
+			for (long j = lo; j <= hi; j++)
+				if (j >= 0 && size_t(j) < amp.size()) amp[size_t(j)] = char(tolower(static_cast<unsigned char>(amp[size_t(j)])));
+		}
+	}
+}
+
 void usage()
 {
 	std::cerr << "tntblast-mi355x: the tntblast search on an MI355X (FASTA databases)\n"
@@ -506,9 +777,10 @@ void parse_args(int argc, char **argv, Options &o)
 				break;
 			}
 			case 10: o.t.target_t = float(atof(optarg)); break;
-			case 11: // --max-target-len: the reference cuts longer targets into overlapping fragments; here every target is
-			         // searched whole (seed windows with true coordinates), which is what a larger value gives there
-				std::cerr << "note: --max-target-len is not needed here, targets of any length are searched unfragmented" << std::endl;
+			case 11: // --max-target-len: longer targets are searched in overlapping fragments like the reference does
+			         // (options.cpp:177-184), so that its results come out -- edge effects included
+				o.max_target_len = atol(optarg);
+				if (o.max_target_len <= 1) fail("Please specify a --max-target-len > 1");
 				break;
 			case 12: { // --query-seg: how the reference deals queries to its workers, no effect on the results
 				std::string v(optarg);
@@ -575,10 +847,14 @@ void parse_args(int argc, char **argv, Options &o)
 		case 'L': o.append_name = parse_bool(optarg); break;
 		case 'n': o.per_query = parse_bool(optarg); break;
 		case 'S': o.summary = parse_bool(optarg); break;
-		case 'k':
+		case 'k': // options.cpp:371-394
+			o.mask = parse_bool(optarg) ? (o.mask | Options::MASK_PRIMERS) : (o.mask & ~Options::MASK_PRIMERS);
+			break;
 		case 'K':
+			o.mask = parse_bool(optarg) ? (o.mask | Options::MASK_PROBE) : (o.mask & ~Options::MASK_PROBE);
+			break;
 		case 'r':
-			if (parse_bool(optarg)) fail(std::string("-") + char(c) + " T is not supported by the MI355X front end");
+			o.mask = parse_bool(optarg) ? (o.mask | Options::REPLACE_PRIMERS) : (o.mask & ~Options::REPLACE_PRIMERS);
 			break;
 		case 'D': fail("-D (local database) is not supported by the MI355X front end");
 		case 'h':
@@ -663,6 +939,23 @@ int main(int argc, char **argv)
 		// results per assay id, in hybrid_sig order (tntblast_local.cpp:703-705,931)
 		std::vector<std::vector<Record>> results(assays.size());
 		std::vector<char> amp(1 << 20);
+		bool fragmented = false; // some target was searched in pieces: the results are made unique at the end
+		// Options::max_product_length + 2 (options.cpp:790-830, tntblast_local.cpp:174): how far a fragment reaches beyond its cut
+		uint64_t max_product_length = 0;
+		if (opt.t.assay_format == TNT_ASSAY_PCR) {
+			for (const Expanded &e : expanded) {
+				if (!e.forward.empty() && !e.reverse.empty()) {
+					max_product_length = uint64_t(std::max(0, opt.t.max_len));
+					break;
+				}
+				max_product_length = std::max<uint64_t>(max_product_length, e.probe.size());
+			}
+		} else if (opt.t.assay_format == TNT_ASSAY_PADLOCK) {
+			for (const Expanded &e : expanded) max_product_length = std::max<uint64_t>(max_product_length, e.forward.size() + e.reverse.size());
+		} else {
+			for (const Expanded &e : expanded) max_product_length = std::max<uint64_t>(max_product_length, e.probe.size());
+		}
+		max_product_length += 2;
 		size_t n_targets = 0, n_seen = 0;
 		std::vector<std::string> all_deflines; // -m 3 only
 		while (true) {
@@ -677,10 +970,21 @@ int main(int argc, char **argv)
 					(void)tnt_db_defline(db, t, &defline, &dl);
 					all_deflines.emplace_back(defline, dl);
 				}
+			// targets whose record is longer than --max-target-len are searched in fragments (tntblast_local.cpp:282-289,
+			// 438-468): the record's size in the file -- defline and line ends included -- is what the reference goes by
+			std::vector<char> is_long(tnt_db_num_targets(db), 0);
+			std::vector<size_t> long_targets;
+			for (size_t t = 0; t < tnt_db_num_targets(db); t++) {
+				uint64_t approx = 0;
+				if (tnt_db_target_info(db, t, nullptr, &approx) != TNT_OK) fail("tnt_db_target_info failed");
+				if (approx > uint64_t(opt.max_target_len)) is_long[t] = 1, long_targets.push_back(t);
+			}
 			const tnt_hit *hits = nullptr;
 			size_t n_hits = 0;
+			std::vector<Record> batch; // this batch's records: masked (if asked for), then filed under their assays
 			if (tnt_search(ctx, db, &hits, &n_hits) != TNT_OK) fail(tnt_last_error(ctx));
 			for (size_t i = 0; i < n_hits; i++) {
+				if (is_long[size_t(hits[i].seq_index) - first]) continue; // reported by its fragments below
 				Record rec{hits[i], n_seen++, std::string(), std::string()};
 				const int na = tnt_hit_sequence(ctx, db, &hits[i], amp.data(), amp.size());
 				if (na < 0) fail("amplicon longer than the sequence buffer");
@@ -689,8 +993,79 @@ int main(int argc, char **argv)
 				size_t dl = 0;
 				(void)tnt_db_defline(db, size_t(hits[i].seq_index) - first, &defline, &dl);
 				rec.defline.assign(defline, dl);
-				results[size_t(hits[i].assay_id)].push_back(rec);
+				batch.push_back(rec);
 			}
+			if (!long_targets.empty()) {
+				// the fragments become the targets of a database of their own
+				struct Frag {
+					size_t target;
+					unsigned int start, stop, max_stop, len; // [start, stop] of the cut, bases actually read
+				};
+				std::vector<Frag> frags;
+				std::vector<uint8_t> codes;
+				std::vector<uint64_t> offs(1, 0);
+				std::vector<uint8_t> whole;
+				for (size_t t : long_targets) {
+					uint32_t n_bases = 0;
+					uint64_t approx = 0;
+					(void)tnt_db_target_info(db, t, &n_bases, &approx);
+					whole.resize(std::max<size_t>(1, n_bases));
+					if (tnt_db_target_codes(ctx, db, t, whole.data(), whole.size()) < 0) fail(tnt_last_error(ctx));
+					const unsigned int max_stop = (unsigned int)(approx - 1);
+					const unsigned int delta = seq_len_increment((unsigned int)approx, (unsigned int)opt.max_target_len).first;
+					unsigned int start = 0, stop = delta;
+					while (true) {
+						// read_bio_seq(target, start, stop + max_product_length), sequence_data_fastx.cpp:296-372
+						const uint64_t want_stop = uint64_t(stop) + max_product_length;
+						const uint64_t last = std::min<uint64_t>(want_stop, n_bases ? n_bases - 1 : 0);
+						const unsigned int len = (n_bases && start <= last) ? (unsigned int)(last - start + 1) : 0u;
+						if (len >= (unsigned int)opt.t.hash_word_size) { // shorter pieces are skipped (tntblast_local.cpp:513-531)
+							frags.push_back(Frag{t, start, stop, max_stop, len});
+							codes.insert(codes.end(), whole.begin() + start, whole.begin() + start + len);
+							offs.push_back(codes.size());
+						}
+						if (stop == max_stop) break;
+						start = stop + 1;
+						stop = std::min(stop + delta, max_stop);
+						fragmented = true;
+					}
+				}
+				if (!frags.empty()) {
+					tnt_db *fdb = nullptr;
+					if (tnt_db_create(ctx, codes.data(), offs.data(), frags.size(), 0, &fdb) != TNT_OK) fail(tnt_last_error(ctx));
+					const tnt_hit *fh = nullptr;
+					size_t nf = 0;
+					if (tnt_search(ctx, fdb, &fh, &nf) != TNT_OK) fail(tnt_last_error(ctx));
+					for (size_t i = 0; i < nf; i++) {
+						const Frag &F = frags[size_t(fh[i].seq_index)];
+						const int lo = fh[i].has_primers ? fh[i].amplicon_start : fh[i].probe_start;
+						const int hi = fh[i].has_primers ? fh[i].amplicon_stop : fh[i].probe_stop;
+						// matches cut off by the fragment's edges are dropped (tntblast_local.cpp:638-648)
+						if (F.start != 0 && lo <= 0) continue;
+						if (F.stop != F.max_stop && hi >= int(F.len) - 1) continue;
+						Record rec{fh[i], n_seen++, std::string(), std::string()};
+						const int na = tnt_hit_sequence(ctx, fdb, &fh[i], amp.data(), amp.size());
+						if (na < 0) fail("amplicon longer than the sequence buffer");
+						rec.amplicon.assign(amp.data(), size_t(na));
+						rec.h.seq_index = int(first + F.target);
+						if (rec.h.has_primers) rec.h.amplicon_start += int(F.start), rec.h.amplicon_stop += int(F.start); // offset_ranges
+						if (rec.h.has_probe) rec.h.probe_start += int(F.start), rec.h.probe_stop += int(F.start);
+						const char *defline = "";
+						size_t dl = 0;
+						(void)tnt_db_defline(db, F.target, &defline, &dl);
+						rec.defline.assign(defline, dl);
+						batch.push_back(rec);
+					}
+					tnt_db_destroy(fdb);
+				}
+			}
+			apply_masks(ctx, opt, batch, 0, [&](const Record &r, int slot) { // tntblast_util.cpp:97-137
+				const Expanded &e = expanded[size_t(r.h.degen_id)];
+				if (slot == 2) return e.probe;
+				const int which = slot == 0 ? r.h.forward_oligo : r.h.reverse_oligo; // single-primer amplicons swap identities
+				return which == 0 ? e.forward : e.reverse;
+			});
+			for (Record &rec : batch) results[size_t(rec.h.assay_id)].push_back(rec);
 			tnt_db_destroy(db);
 			db = nullptr;
 		}
@@ -786,6 +1161,12 @@ int main(int argc, char **argv)
 			std::vector<Record> &list = results[id];
 			if (list.empty()) continue;
 			if (opt.best_match) select_best_match(list);
+			if (fragmented) // tntblast_local.cpp:923-928
+				uniquify_results(list, [&](const Record &r, int slot) {
+					const Expanded &e = expanded[size_t(r.h.degen_id)];
+					const int which = slot == 0 ? r.h.forward_oligo : r.h.reverse_oligo; // single-primer amplicons swap identities
+					return int((which == 0 ? e.forward : e.reverse).size());
+				});
 			std::stable_sort(list.begin(), list.end(), record_less);
 			if (opt.per_query) { // :933-965
 				const std::string filename = opt.output + "." + assays[id].name;

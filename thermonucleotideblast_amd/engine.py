@@ -92,6 +92,7 @@ def load_library():
     lib.tnt_fasta_close.argtypes = [C.c_void_p]
     lib.tnt_fasta_close.restype = None
     lib.tnt_db_defline.argtypes = [C.c_void_p, C.c_size_t, P(C.c_char_p), P(C.c_size_t)]
+    lib.tnt_db_target_info.argtypes = [C.c_void_p, C.c_size_t, P(C.c_uint32), P(C.c_uint64)]
     lib.tnt_db_target_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, P(C.c_uint8), C.c_size_t]
     lib.tnt_db_target_codes.restype = C.c_int64
     lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
@@ -108,7 +109,7 @@ EXPORTED_SYMBOLS = [
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device", "tnt_search_hits_compact", "tnt_hits_unpack",
     "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
-    "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_codes", "tnt_db_ingest_timing",
+    "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_info", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
 ]
 
