@@ -156,9 +156,58 @@ def add_g7_cases(names):
     dump("g7_cli.json.gz", {"cases": have})
 
 
+def gen_g8():
+    """G8: the reference's per-target BindCache hands the FIRST evaluation of an (oligo string, window) to every later
+    caller, whatever its strand concentration and thresholds (tntblast.h:247-270, bind_oligo.cpp:600-612,750-803).  An
+    assay set in which one oligo is a primer (-e 50) of one assay and the TaqMan probe (-E 25) of another: the reference's
+    hits (probe Tm at the primer's Ct, records missing where the first cascade stopped early) next to the inputs."""
+    ref = tc.RefImpl()
+    rng = np.random.default_rng(8)
+    X, Y, F2, R2 = (synth._rand_oligo(rng, n, n) for n in (22, 20, 20, 20))
+    assays = [synth.Assay("pcr", X, Y, None), synth.Assay("taqman", F2, R2, X)]
+    opt = abi.options_default(min_primer_tm=50.0, min_probe_tm=25.0)
+    targets = []
+    for t in range(80):
+        site = synth._mutate(rng, X, 4)
+        amp = list("ACGT"[i] for i in rng.integers(0, 4, 300))
+        amp[:len(F2)] = F2
+        amp[40:40 + len(X)] = site
+        amp[150:150 + len(Y)] = synth.revcomp(synth._mutate(rng, Y, 1))
+        amp[300 - len(R2):] = synth.revcomp(R2)
+        seq = "".join("ACGT"[i] for i in rng.integers(0, 4, 50)) + "".join(amp) + "".join("ACGT"[i] for i in rng.integers(0, 4, 50))
+        targets.append(seq if t % 2 else synth.revcomp(seq))
+    codes = np.concatenate([synth.encode(t) for t in targets])
+    offsets = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
+    hits = ref.search(opt, synth.expand_assays(assays), codes, offsets, threads=1)
+    dump("g8_bindcache.json.gz", {"assays": [[a.name, a.forward, a.reverse, a.probe] for a in assays], "options": opt_dict(opt),
+                                  "targets": targets, "hits": [list(k) for k in tc.sorted_hit_keys(hits)]})
+    print("G8: %d reference hits" % len(hits))
+
+
+def add_g5_inputs():
+    """`python tests/gen_golden.py g5-inputs`: stores the inputs of the G5 cases (targets, assay rows) inside their fixtures
+    -- they used to be regenerated from numpy seeds by the tests -- after checking that they still reproduce the stored hits."""
+    import golden_util as gu
+    ref = tc.RefImpl()
+    for cfg in (1, 2, 3, 4, 5):
+        name = "g5_search_cfg%d.json.gz" % cfg
+        fx = gu.load(name)
+        wl = synth.make_workload(cfg, n_targets=fx["n_targets"], n_assays=fx["n_assays"])
+        hits = [list(k) for k in tc.sorted_hit_keys(ref.search(wl.options, wl.expanded, wl.codes, wl.offsets))]
+        assert hits == fx["hits"], "config %d: the regenerated inputs no longer give the stored hits" % cfg
+        fx["assays"] = [[a.name, a.forward, a.reverse, a.probe] for a in wl.assays]
+        fx["targets"] = [synth.decode(wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])]) for t in range(wl.n_targets)]
+        dump(name, fx)
+        print("G5 cfg", cfg, "inputs stored:", len(fx["targets"]), "targets,", len(fx["assays"]), "assays")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g5-inputs":
+        return add_g5_inputs()
     if len(sys.argv) > 2 and sys.argv[1] == "g7":
         return add_g7_cases(sys.argv[2:])
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        return gen_g8()
     ref = tc.RefImpl()
     rng = np.random.default_rng(20260227)
 
@@ -261,6 +310,8 @@ def main():
         wl = synth.make_workload(cfg, n_targets=nt, n_assays=na)
         hits = ref.search(wl.options, wl.expanded, wl.codes, wl.offsets)
         dump("g5_search_cfg%d.json.gz" % cfg, {"config": cfg, "n_targets": nt, "n_assays": na, "options": opt_dict(wl.options),
+                                               "assays": [[a.name, a.forward, a.reverse, a.probe] for a in wl.assays],
+                                               "targets": [synth.decode(wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])]) for t in range(wl.n_targets)],
                                                "n_hits": len(hits), "hits": [list(k) for k in tc.sorted_hit_keys(hits)]})
         print("G5 cfg", cfg, "hits", len(hits))
     # README example (README.md:130-203): the printed 147-nt amplicon as target

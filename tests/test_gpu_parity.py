@@ -302,12 +302,38 @@ def test_g4_seeds_golden(Engine):
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
 def test_g5_search_golden(Engine, cfg):
     fx = gu.load("g5_search_cfg%d.json.gz" % cfg)
-    wl = synth.make_workload(cfg, n_targets=fx["n_targets"], n_assays=fx["n_assays"])
-    e = Engine(gu.options_from(fx["options"]), wl.expanded)
-    db = e.pack(wl.codes, wl.offsets)
+    expanded, codes, offsets = gu.g5_inputs(fx)  # stored in the fixture, not regenerated from RNG seeds
+    e = Engine(gu.options_from(fx["options"]), expanded)
+    db = e.pack(codes, offsets)
     hits = e.search(db)
     assert gu.hits_as_keys(hits) == fx["hits"]
     db.close()
+    e.close()
+
+
+def test_g8_bind_cache_conflict_is_refused(Engine, oracle, monkeypatch):
+    """An assay set in which the reference's per-target BindCache would hand one caller's evaluation to another with a
+    different strand concentration / threshold set (G8) is refused with a message, never searched silently differently;
+    with TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 every use is bound on its own (the oracle's semantics)."""
+    from thermonucleotideblast_amd.engine import TntError
+    g = gu.load("g8_bindcache.json.gz")
+    ex = synth.expand_assays([synth.Assay(a[0], a[1], a[2], a[3]) for a in g["assays"]])
+    opt = gu.options_from(g["options"])
+    monkeypatch.delenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", raising=False)
+    with pytest.raises(TntError, match="bind cache"):
+        Engine(opt, ex)
+    monkeypatch.setenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", "1")
+    codes, offsets = gu.pack_targets(g["targets"])
+    e = Engine(opt, ex)
+    db = e.pack(codes, offsets)
+    assert tc.sorted_hit_keys(e.search(db)) == tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets))
+    db.close()
+    e.close()
+    # the same oligo as a primer and as a stand-alone probe is fine: hybrid() binds with a cache of its own
+    monkeypatch.delenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", raising=False)
+    a = g["assays"]
+    ok = synth.expand_assays([synth.Assay(a[0][0], a[0][1], a[0][2], None), synth.Assay("probe", None, None, a[0][1])])
+    e = Engine(opt, ok)
     e.close()
 
 

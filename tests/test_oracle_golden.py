@@ -59,8 +59,8 @@ def test_g4_seeds(oracle):
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
 def test_g5_search(oracle, cfg):
     fx = gu.load("g5_search_cfg%d.json.gz" % cfg)
-    wl = synth.make_workload(cfg, n_targets=fx["n_targets"], n_assays=fx["n_assays"])
-    hits = oracle.search(gu.options_from(fx["options"]), wl.expanded, wl.codes, wl.offsets)
+    expanded, codes, offsets = gu.g5_inputs(fx)  # stored in the fixture, not regenerated from RNG seeds
+    hits = oracle.search(gu.options_from(fx["options"]), expanded, codes, offsets)
     assert len(hits) == fx["n_hits"] > 0
     assert gu.hits_as_keys(hits) == fx["hits"]
 
@@ -85,3 +85,30 @@ def test_threads_do_not_change_results(oracle):
     a = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets, threads=1))
     b = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets, threads=4))
     assert a == b and len(a) > 0
+
+
+def test_g8_reference_bind_cache_quirk_is_pinned(oracle):
+    """G8 (reference-generated): one oligo as a primer of one assay and as the TaqMan probe of another.  The reference's
+    per-target BindCache gives the probe the primer's evaluation (its Tm at the primer's strand concentration; nothing
+    where the primer's threshold cascade had stopped early), so its hits differ from the uncached computation -- which is
+    what the oracle and the library compute; the library refuses such an assay set (tests/test_gpu_parity.py)."""
+    g = gu.load("g8_bindcache.json.gz")
+    assays = [synth.Assay(a[0], a[1], a[2], a[3]) for a in g["assays"]]
+    opt = gu.options_from(g["options"])
+    codes, offsets = gu.pack_targets(g["targets"])
+    got = [list(k) for k in tc.sorted_hit_keys(oracle.search(opt, synth.expand_assays(assays), codes, offsets))]
+    ref = g["hits"]
+    both = [h for h in got if h in ref]
+    assert len(ref) == 113 and len(got) == 135 and len(both) == 57
+    # the PCR assay (its oligos are evaluated first on every target) is not affected
+    assert sorted(h for h in got if h[0] == 0) == sorted(h for h in ref if h[0] == 0)
+    # where both report the same TaqMan amplicon, only the probe's Tm differs (it was computed at the primer's Ct)
+    names = [n for n, _ in abi.tnt_hit._fields_]
+    ints = [i for i, (n, t) in enumerate(abi.tnt_hit._fields_) if t is not __import__("ctypes").c_float and not n.endswith("_align")]
+    key = lambda h: tuple(h[i] for i in ints)  # noqa: E731
+    refmap = {key(h): h for h in ref if h[0] == 1}
+    differing = [(h, refmap[key(h)]) for h in got if h[0] == 1 and key(h) in refmap and h != refmap[key(h)]]
+    assert differing
+    for a, b in differing:
+        diff = [names[i] for i in range(len(names)) if a[i] != b[i]]
+        assert diff == ["probe_tm"], diff

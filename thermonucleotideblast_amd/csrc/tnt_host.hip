@@ -1036,6 +1036,23 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 			last[canon] = uint32_t(si);
 		}
 		if (getenv("TNT_MI355X_NO_DEDUPE")) c->dedupe = false; // ablation
+		// The reference memoises every evaluated (oligo string, window) per target and hands the memo out again whatever
+		// strand concentration or threshold set asks for it (BindCacheKey holds neither, tntblast.h:247-270; on a hit the
+		// caller's thresholds are applied to the first caller's Tm, and to zeros where that caller's cascade had stopped
+		// early, bind_oligo.cpp:600-612,750-803).  Which evaluation comes first depends on the whole bind / cull history of
+		// the target; that is not reproduced here, so an assay set in which it could matter is refused, loudly.
+		std::map<int32_t, std::string> cls; // oligo -> (strand concentration, thresholds) as bytes
+		for (const Slot &sl : c->h_slots) {
+			if (sl.oligo < 0) continue;
+			if (c->h_assays[size_t(sl.assay)].kind == 2) continue; // hybrid() binds with a cache of its own (probe_search.cpp:96,166)
+			std::string key(reinterpret_cast<const char *>(&sl.log_ct), sizeof(sl.log_ct));
+			key.append(reinterpret_cast<const char *>(&th[size_t(sl.thresh)]), sizeof(Thresh));
+			const auto it = cls.emplace(sl.oligo, key);
+			if (!it.second && it.first->second != key && !getenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS"))
+				FAIL(TNT_E_UNSUPPORTED, "oligo " + c->oligos[size_t(sl.oligo)] + " is used under two strand concentrations or threshold sets: the reference's "
+				                        "per-target bind cache would reuse the first evaluation for the second (tntblast.h:247-270), which this "
+				                        "library does not reproduce (TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 binds every use on its own)");
+		}
 	}
 	hipError_t e = hipSuccess;
 	std::vector<Tables> tv(1, c->h_tab);
