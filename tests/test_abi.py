@@ -71,8 +71,12 @@ def test_cli_front_end_builds_and_validates_arguments(hip_lib):
     assert r.returncode != 0 and "tntblast-mi355x" in r.stderr
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-m", "7"], capture_output=True, text=True)
     assert r.returncode != 0 and "Unknown output format" in r.stderr
-    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-k", "T"], capture_output=True, text=True)
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-k", "T", "-K", "T", "-r", "T"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unable to open x" in r.stderr  # masking flags are accepted (G7 holds their output)
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--dinkelbach", "T"], capture_output=True, text=True)
     assert r.returncode != 0 and "not supported" in r.stderr
+    r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--max-target-len", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "max-target-len" in r.stderr
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--query-seg", "sometimes"], capture_output=True, text=True)
     assert r.returncode != 0 and "query-seg" in r.stderr
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--query-seg", "adaptive", "--max-target-len", "1000"], capture_output=True, text=True)
