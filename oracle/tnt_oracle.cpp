@@ -236,6 +236,7 @@ class Melt {
 public:
 	float Tk, na, log_na, ct; // Tk: do not name this `T` (would shadow Base::T)
 	bool dangle5, dangle3;
+	bool dinkelbach = false; // --dinkelbach: Tm by iterating the alignment at its own melting temperature
 	int32_t dg[2401];
 	std::vector<Base> query, target;
 	Alignment cur;
@@ -253,28 +254,57 @@ public:
 		for (char c : s) query.push_back(char_to_base(c));
 	}
 
-	float approximate_tm_heterodimer() // nuc_cruc.cpp:2441-2454 (non-Dinkelbach branch)
+	void temperature(float t) // NucCruc::temperature -> update_dp_param, nuc_cruc.cpp:340-487
 	{
-		cur = Alignment();
-		align_dimer();
-		for (int c : max_cells) enumerate(c, HETERO_DIMER); // tm_dimer, nuc_cruc.cpp:2533-2537
-		return cur.tm;
+		Tk = t;
+		make_delta_g(Tk, na, dg);
 	}
-	float approximate_tm_homodimer() // nuc_cruc.cpp:2501-2514: the query against itself
+	// the Dinkelbach loop shared by the three approximate_tm_* (nuc_cruc.cpp:2399-2432,2459-2498,2548-2593): align at
+	// 0 C, then again and again at the Tm the last alignment gave, while its free energy at that temperature is negative
+	// and still rising; the last pass stands.  The initial temperature (and its DP parameters) come back afterwards.
+	template <class PASS> float iterate(PASS one_pass)
 	{
-		cur = Alignment();
+		if (!dinkelbach) return one_pass();
+		const float init_T = Tk;
+		float q = -999999.9f, last_q = q, local_tm = 0.0f;
+		temperature(273.15f); // NC_ZERO_C
+		do {
+			local_tm = one_pass();
+			last_q = q;
+			q = delta_G();
+			temperature(273.15f + local_tm);
+		} while ((q < 0.0) && (q > last_q));
+		temperature(init_T);
+		return local_tm;
+	}
+	float approximate_tm_heterodimer() // nuc_cruc.cpp:2397-2455
+	{
+		return iterate([this]() {
+			cur = Alignment();
+			align_dimer();
+			for (int c : max_cells) enumerate(c, HETERO_DIMER); // tm_dimer, nuc_cruc.cpp:2533-2537
+			return cur.tm;
+		});
+	}
+	float approximate_tm_homodimer() // nuc_cruc.cpp:2457-2515: the query against itself
+	{
 		target = query;
-		align_dimer();
-		for (int c : max_cells) enumerate(c, HOMO_DIMER);
-		return cur.tm;
+		return iterate([this]() {
+			cur = Alignment();
+			align_dimer();
+			for (int c : max_cells) enumerate(c, HOMO_DIMER);
+			return cur.tm;
+		});
 	}
-	float approximate_tm_hairpin() // nuc_cruc.cpp:2597-2615
+	float approximate_tm_hairpin() // nuc_cruc.cpp:2542-2616
 	{
-		cur = Alignment();
 		target = query; // trace_back(m_q, m_q), nuc_cruc.cpp:1212
-		align_hairpin();
-		for (int c : max_cells) enumerate_hairpin(c);
-		return cur.tm;
+		return iterate([this]() {
+			cur = Alignment();
+			align_hairpin();
+			for (int c : max_cells) enumerate_hairpin(c);
+			return cur.tm;
+		});
 	}
 	float delta_G() const { return cur.dH - Tk * cur.dS; } // nuc_cruc.h:1217
 
@@ -1522,6 +1552,7 @@ int tntor_bind_batch(const tnt_options *opt, const char *const *oligos, int n_ol
 	{
 		try {
 			Melt m(opt->target_t, opt->salt, opt->allow_dangle_5 != 0, opt->allow_dangle_3 != 0);
+			m.dinkelbach = opt->use_dinkelbach != 0;
 #pragma omp for schedule(dynamic, 64)
 			for (long k = 0; k < long(n); k++) {
 				const tnt_bind_req &r = req[k];
@@ -1569,6 +1600,7 @@ int tntor_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assay
 		try {
 			Seeder h(opt->hash_word_size);
 			Melt m(opt->target_t, opt->salt, opt->allow_dangle_5 != 0, opt->allow_dangle_3 != 0);
+			m.dinkelbach = opt->use_dinkelbach != 0;
 			std::vector<tnt_hit> local;
 #pragma omp for schedule(dynamic, 16)
 			for (long t = 0; t < long(n_targets); t++) {
@@ -1731,6 +1763,7 @@ int tntor_oligo_structure(const tnt_options *opt, const char *oligo, float ct, f
 {
 	try {
 		Melt m(opt->target_t, opt->salt, opt->allow_dangle_5 != 0, opt->allow_dangle_3 != 0);
+			m.dinkelbach = opt->use_dinkelbach != 0;
 		m.set_query(oligo);
 		m.ct = ct - 0.5f * ct; // strand(c, c), nuc_cruc.h:890-910
 		*hairpin_tm = m.approximate_tm_hairpin();
@@ -1746,6 +1779,7 @@ int tntor_heterodimer(const tnt_options *opt, const char *a, const char *b, floa
 {
 	try {
 		Melt m(opt->target_t, opt->salt, opt->allow_dangle_5 != 0, opt->allow_dangle_3 != 0);
+			m.dinkelbach = opt->use_dinkelbach != 0;
 		m.set_query(a);
 		m.target.clear();
 		for (const char *p = b; *p; p++) m.target.push_back(char_to_base(*p)); // set_target, nuc_cruc.h:977-990

@@ -45,6 +45,8 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("mask_probe_K", 3, 200, 16, 24, ["-e", "40", "-E", "40", "-K", "T"]),
     ("replace_primers_r", 2, 200, 16, 25, ["-e", "40", "-r", "T"]),
     ("mask_all_krK_m1", 3, 200, 16, 26, ["-e", "38", "-E", "38", "-k", "T", "-r", "T", "-K", "T", "-m", "1"]),
+    # Tm by Dinkelbach iteration (binds and the hairpin / dimer values of every record)
+    ("dinkelbach", 3, 200, 16, 27, ["-e", "40", "-E", "40", "--dinkelbach", "T"]),
     # targets longer than --max-target-len are searched in overlapping fragments (tntblast_local.cpp:282-289,438-468):
     # matches cut off by a fragment's edge are dropped, matches found by two fragments are made unique
     # (uniquify_results).  One 620-kb record at the default threshold (500 000); one 64-kb record cut into six.

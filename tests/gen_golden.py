@@ -201,7 +201,35 @@ def add_g5_inputs():
         print("G5 cfg", cfg, "inputs stored:", len(fx["targets"]), "targets,", len(fx["assays"]), "assays")
 
 
+def gen_g9():
+    """G9: --dinkelbach (NucCruc::approximate_tm_heterodimer's iteration, nuc_cruc.cpp:2399-2432).  Every third request of
+    G2 (its oligos, targets and requests stay in g2_binds.json.gz) through the reference with use_dinkelbach, two option
+    sets, the same record fields as G2; plus hairpin / homodimer / heterodimer Tm of the G3 oligos."""
+    import golden_util as gu
+    ref = tc.RefImpl()
+    fx = gu.load("g2_binds.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    idx = list(range(0, len(fx["requests"]), 3))
+    reqs = tc.make_reqs([tuple(fx["requests"][i]) for i in idx])
+    cases = []
+    so = gu.load("g3_structure.json.gz")["oligos"]
+    for name, opt in (("dinkelbach", abi.options_default(use_dinkelbach=1, min_primer_tm=40.0, min_probe_tm=40.0)),
+                      ("dinkelbach_salt", abi.options_default(use_dinkelbach=1, salt=0.2, target_t=320.0, min_primer_tm=30.0, min_probe_tm=30.0,
+                                                              primer_clamp=2, max_mismatch=4))):
+        out = ref.bind_batch(opt, fx["oligos"], codes, offsets, reqs)
+        recs = [[b.status, b.target_start, b.target_stop, tc.f32_bits(b.tm), tc.f32_bits(b.dH), tc.f32_bits(b.dS), tc.f32_bits(b.dg),
+                 b.anchor5, b.anchor3, b.num_mm, b.num_gap, b.poly_degen, b.loc5, b.loc3, b.q_first, b.q_last, b.t_first, b.t_last,
+                 b.valid, b.dp_max, b.n_max, b.align.decode()] for b in out]
+        st = [list(ref.structure(opt, o, so[(i * 7 + 3) % len(so)], 9e-7, 4e-7)) for i, o in enumerate(so)]
+        cases.append({"name": name, "options": opt_dict(opt), "expected": recs, "structure": st})
+        print("G9", name, len(recs), "binds,", sum(1 for r in recs if r[0] == 0), "bound")
+    dump("g9_dinkelbach.json.gz", {"g2_request_indices": idx, "cases": cases, "structure_partner": "oligos[(i * 7 + 3) % n]",
+                                   "ct_a": 9e-7, "ct_b": 4e-7})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        return gen_g9()
     if len(sys.argv) > 1 and sys.argv[1] == "g5-inputs":
         return add_g5_inputs()
     if len(sys.argv) > 2 and sys.argv[1] == "g7":

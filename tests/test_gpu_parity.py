@@ -204,6 +204,49 @@ def test_filter_changes_no_result(Engine, oracle, monkeypatch):
             assert res["on"] == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
 
 
+@pytest.mark.parametrize("route", [0, 2])
+def test_g9_dinkelbach_golden(Engine, route):
+    """--dinkelbach: the bind kernel's temperature iteration (unit-level instance and the throughput instance a search
+    runs) against the reference's NucCruc, and the self-structure Tm printed with every hit."""
+    fx, g = gu.load("g2_binds.json.gz"), gu.load("g9_dinkelbach.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
+    so = gu.load("g3_structure.json.gz")["oligos"]
+    for case in g["cases"]:
+        e = Engine(gu.options_from(case["options"]), ex)
+        om = {o: i for i, o in enumerate(e.oligos)}
+        rows = [fx["requests"][i] for i in g["g2_request_indices"]]
+        reqs = tc.make_reqs((r[0], om[fx["oligos"][r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in rows)
+        db = e.pack(codes, offsets)
+        out = e.bind_batch(db, reqs, route=route)
+        bad = []
+        for i, x in enumerate(case["expected"]):
+            got = gu.bind_record(out[i])
+            d = gu.compare_bind(x, got) if route == 0 else [(k, x[k], got[k]) for k in ([0] + (ROUTED_FIELDS if x[0] == 0 else [])) if x[k] != got[k]]
+            if d:
+                bad.append((i, d))
+        assert not bad, "%s route %d: %d of %d differ, first %r" % (case["name"], route, len(bad), len(case["expected"]), bad[:2])
+        if route == 0:
+            for i, o in enumerate(so[:120]):
+                got = e.oligo_structure(o, so[(i * 7 + 3) % len(so)], g["ct_a"], g["ct_b"])
+                assert [tc.f32_bits(v) for v in got] == case["structure"][i], (case["name"], o)
+        db.close()
+        e.close()
+
+
+def test_dinkelbach_search_vs_oracle(Engine, oracle):
+    for cfg, nt, na in [(3, 500, 32), (5, 400, 40), (4, 300, 30)]:
+        wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=77)
+        wl.options.use_dinkelbach = 1
+        e = Engine(wl.options, wl.expanded)
+        db = e.pack(wl.codes, wl.offsets)
+        got = tc.sorted_hit_keys(e.search(db))
+        want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+        assert len(want) > 0 and got == want, (cfg, len(got), len(want))
+        db.close()
+        e.close()
+
+
 def test_g3_structure_golden(Engine):
     """Row a17: hairpin / homodimer / heterodimer Tm of oligos through the unit-level bind kernel instance."""
     g = gu.load("g3_structure.json.gz")

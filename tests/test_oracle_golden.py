@@ -112,3 +112,19 @@ def test_g8_reference_bind_cache_quirk_is_pinned(oracle):
     for a, b in differing:
         diff = [names[i] for i in range(len(names)) if a[i] != b[i]]
         assert diff == ["probe_tm"], diff
+
+
+def test_g9_dinkelbach(oracle):
+    """G9: the oracle's Dinkelbach iteration against the reference's (binds of every third G2 request, self-structure Tm)."""
+    fx, g = gu.load("g2_binds.json.gz"), gu.load("g9_dinkelbach.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    reqs = tc.make_reqs([tuple(fx["requests"][i]) for i in g["g2_request_indices"]])
+    so = gu.load("g3_structure.json.gz")["oligos"]
+    for case in g["cases"]:
+        opt = gu.options_from(case["options"])
+        out = oracle.bind_batch(opt, fx["oligos"], codes, offsets, reqs)
+        bad = [(i, gu.compare_bind(x, gu.bind_record(out[i]))) for i, x in enumerate(case["expected"])]
+        bad = [b for b in bad if b[1]]
+        assert not bad, (case["name"], len(bad), bad[:2])
+        for i, o in enumerate(so):
+            assert list(oracle.structure(opt, o, so[(i * 7 + 3) % len(so)], g["ct_a"], g["ct_b"])) == case["structure"][i], (case["name"], o)

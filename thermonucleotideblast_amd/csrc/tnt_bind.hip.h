@@ -393,10 +393,15 @@ __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const Ali
 // EXACT: every item of the launch has L == LMAX (the host buckets the queues by length).
 // PLAIN: no window of the launch holds a degenerate (IUPAC) target base (the bucket kernel routes windows that
 // do to a general instance), so rt(t, q) = t and the table address splits into column and row constants.
-template <int LMAX, bool FULL, bool EXACT = false, bool PLAIN = false>
-__global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LMAX, PLAIN) > 256 ? 1 : (LMAX <= 40 ? 2 : 1))) void bind_kernel(BindArgs a)
+// DINK: --dinkelbach (NucCruc::approximate_tm_*, nuc_cruc.cpp:2399-2432,2459-2498,2548-2593): the alignment is computed
+// at 0 C, then again and again at the Tm the last pass gave while its free energy there is negative and still rising;
+// every pass has its own delta_g (update_dp_param at that temperature), which a lane derives on the fly from the
+// (H, S, floor) triples of the entries (Tables::dk_*).  General instances only.
+template <int LMAX, bool FULL, bool EXACT = false, bool PLAIN = false, bool DINK = false>
+__global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LMAX, PLAIN) > 256 ? 1 : ((LMAX <= 40 && !DINK) ? 2 : 1))) void bind_kernel(BindArgs a)
 {
 	static_assert(!(FULL && (EXACT || PLAIN)), "the unit-level instance takes any length and any target base");
+	static_assert(!(DINK && (EXACT || PLAIN)), "the Dinkelbach passes run on the general instances");
 	constexpr int BIND_THREADS = bind_threads_for(LMAX, PLAIN);
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NCOLS = LMAX + WMAX + 4;
@@ -411,6 +416,10 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 	__shared__ int32_t s_dgp[DG_PLANES * DG_PLANE];
 	__shared__ int32_t s_term[PLAIN ? 1 : NBP];
 	__shared__ int32_t s_const[4];
+	// DINK: the same planes as triples (value = max(int((H - T * S) * 10000), F)); [plane][entry], then term[49], const[4]
+	constexpr int DK_N = DINK ? 2 * DG_PLANE + NBP + 4 : 1;
+	__shared__ float s_dkH[DK_N], s_dkS[DK_N];
+	__shared__ int32_t s_dkF[DK_N];
 	__shared__ uint32_t s_rt[18];
 	__shared__ uint8_t s_lut[18 * 18 + 4];
 	__shared__ uint8_t s_win[WMAX * BIND_THREADS];
@@ -445,6 +454,21 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 			s_dgp[DG_PLANE + at] = a.tab->term[cpair];
 		}
 		if (tid < NBP) s_term[tid] = a.tab->term[tid];
+		if (DINK) {
+			auto triple = [&](int at, int src) {
+				s_dkH[DINK ? at : 0] = src >= 0 ? a.tab->dk_H[src] : 0.0f;
+				s_dkS[DINK ? at : 0] = src >= 0 ? a.tab->dk_S[src] : 0.0f;
+				s_dkF[DINK ? at : 0] = src >= 0 ? a.tab->dk_F[src] : 0;
+			};
+			for (int i = tid; i < NBP * NBP; i += BIND_THREADS) {
+				const int p = i / NBP, cpair = i % NBP;
+				const int at = ((p / NB) * NB + cpair / NB) * NBP + (p % NB) * NB + cpair % NB;
+				triple(at, i);
+				triple(DG_PLANE + at, a.tab->term_src[cpair]);
+			}
+			if (tid < NBP) triple(2 * DG_PLANE + tid, a.tab->term_src[tid]);
+			if (tid < 4) triple(2 * DG_PLANE + NBP + tid, a.tab->const_src[tid]);
+		}
 	}
 	if (tid < 4) s_const[tid] = a.tab->dg_const[tid];
 	for (int i = tid; i < 18 * 18; i += BIND_THREADS) s_lut[i] = a.tab->bbp[i];
@@ -573,6 +597,21 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 			}
 		}
 
+		// uniform trip count over the wavefront keeps the unrolled body convergent
+		int Wwave = W;
+		for (int o = 32; o > 0; o >>= 1) {
+			const int other = __shfl_xor(Wwave, o);
+			Wwave = other > Wwave ? other : Wwave;
+		}
+		// temperature of this pass: the target temperature, or the Dinkelbach sequence 0 C, Tm_1, Tm_2, ...
+		float Tcur = DINK ? 273.15f : s_k.temperature;
+		float dk_q = -999999.9f;
+		auto dkv = [&](int at) __attribute__((always_inline)) { // delta_g entry `at` of the triple planes at Tcur
+			const int v = int((s_dkH[DINK ? at : 0] - Tcur * s_dkS[DINK ? at : 0]) * 10000.0f);
+			const int f = s_dkF[DINK ? at : 0];
+			return v > f ? v : f;
+		};
+	dinkelbach_pass:
 		int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
 		for (int i = 0; i < LMAX; i++) oM[i] = FULL ? -1 : 0, oQ[i] = oT[i] = 0;
@@ -580,15 +619,10 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 		int gmax = -1, nmax = 0, max_ij = 0;
 		uint32_t prtw = s_rt[bGAP];
 		int pt = bGAP; // target base of the previous column
-		// uniform trip count over the wavefront keeps the unrolled body convergent
-		int Wwave = W;
-		for (int o = 32; o > 0; o >>= 1) {
-			const int other = __shfl_xor(Wwave, o);
-			Wwave = other > Wwave ? other : Wwave;
-		}
 		const char *sdg = reinterpret_cast<const char *>(s_dgp);
 		const char *sterm = reinterpret_cast<const char *>(s_term);
-		const int c_bulge = s_const[0], c_zero = s_const[1], c_forb_m = s_const[2], c_forb_xy = s_const[3];
+		const int c_bulge = DINK ? dkv(2 * DG_PLANE + NBP + 0) : s_const[0], c_zero = DINK ? dkv(2 * DG_PLANE + NBP + 1) : s_const[1],
+		          c_forb_m = DINK ? dkv(2 * DG_PLANE + NBP + 2) : s_const[2], c_forb_xy = DINK ? dkv(2 * DG_PLANE + NBP + 3) : s_const[3];
 		uint8_t *tcol = trace;
 #pragma unroll 1
 		for (int j = 1; j <= Wwave; j++) {
@@ -626,9 +660,13 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 						const int ea = xp * (4 * 343) + x * (4 * 49) + r4; // xp = rt(pt, q of the row above)
 						xp = int(__builtin_amdgcn_ubfe(prtw, uint32_t(q4), 4u));
 						const int ta = xp * 28 + q4;
-						ox = *reinterpret_cast<const int *>(sdg + ea);
-						oy = *reinterpret_cast<const int *>(sdg + ea + 4 * DG_PLANE);
-						ot = *reinterpret_cast<const int *>(sterm + ta);
+						if (DINK) {
+							ox = dkv(ea >> 2), oy = dkv(DG_PLANE + (ea >> 2)), ot = dkv(2 * DG_PLANE + (ta >> 2));
+						} else {
+							ox = *reinterpret_cast<const int *>(sdg + ea);
+							oy = *reinterpret_cast<const int *>(sdg + ea + 4 * DG_PLANE);
+							ot = *reinterpret_cast<const int *>(sterm + ta);
+						}
 						o2 = firstcol ? c_forb_m : oy;
 					}
 				};
@@ -797,7 +835,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 			int sp = 0;
 			int zero_count = -1;
 			unsigned trace_count = 0;
-			float best_dg = best_dH - s_k.temperature * best_dS;
+			float best_dg = best_dH - Tcur * best_dS;
 			while (true) {
 				if (!first_time && sp == 0 && zero_count <= 0) break;
 				if (16u < trace_count) break;
@@ -959,7 +997,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 	do {                                                                                             \
 		const Score s_ = (SCORE);                                                                    \
 		if (s_.ok) {                                                                                 \
-			const float local_dg = s_.dH - s_k.temperature * s_.dS;                                    \
+			const float local_dg = s_.dH - Tcur * s_.dS;                                               \
 			if (!best_valid || local_dg < best_dg) { /* :1160-1167 */                                \
 				best_valid = true;                                                                   \
 				best_dg = local_dg;                                                                  \
@@ -1033,6 +1071,14 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 			}
 		}
 
+		if (DINK) { // the while condition of the Dinkelbach loop, nuc_cruc.cpp:2414-2432
+			const float last_q = dk_q;
+			dk_q = best_dH - Tcur * best_dS; // delta_G() at this pass's temperature (0 when nothing aligned: curr_align.clear())
+			if (dk_q < 0.0f && dk_q > last_q) {
+				Tcur = 273.15f + best_tm; // temperature(NC_ZERO_C + local_tm)
+				goto dinkelbach_pass;
+			}
+		}
 #ifdef TNT_EXP_STATS
 		const long long st_thr0 = __builtin_readcyclecounter();
 #endif

@@ -58,6 +58,13 @@ struct Tables {
 	int32_t term[NBP];      // class constants of delta_g (see the bind kernel): term[c] = g((x,GAP), c) for real pairs c,
 	                        // term[(GAP,x)] = g((GAP,x),(y,GAP)) (forbidden)
 	int32_t dg_const[4];    // BULGE, g(__,(x,GAP)), g(__, real pair), g((GAP,x),(y,GAP))
+	// --dinkelbach re-derives delta_g at another temperature per window and pass: every entry as the triple it was made
+	// from, dg = max(int((dk_H - T * dk_S) * 10000), dk_F)  (update_dp_param, nuc_cruc.cpp:357-486; dk_S holds S + the
+	// entry's salt term, dk_F = 0 for the clamped classes and INT32_MIN otherwise)
+	float dk_H[NBP * NBP], dk_S[NBP * NBP];
+	int32_t dk_F[NBP * NBP];
+	int32_t term_src[NBP];  // term[c] == dg[term_src[c]], dg_const[k] == dg[const_src[k]]
+	int32_t const_src[4];
 	float init_H, init_S, at_H, at_S, salt, asym_S, bulge_at_S;
 	float temperature;      // target_T
 	float log_na;           // logf([Na+]) computed on the host (no device logf: bit-exactness)

@@ -162,44 +162,61 @@ bool fill_tables(Tables &T, const tnt_options &opt)
 	const float loop_sc = salt_correction * 3.08f, bulge_sc = salt_correction * 0.69f;
 	const float tmatch_sc = salt_correction * 0.56f, tmis_sc = salt_correction * 1.31f;
 	auto scale = [](float x) { return int32_t(x * 10000.0f); };
-	for (int i = 0; i < NBP * NBP; i++) T.dg[i] = scale(T.H[i] - Tk * (T.S[i] + salt_correction));
-	const int32_t v_at = std::max(0, scale(-4.474f - Tk * (-2.091e-2f + tmatch_sc)));
-	const int32_t v_gc = std::max(0, scale(-3.000f - Tk * (-1.318e-2f + tmatch_sc)));
-	const int32_t v_mm = std::max(0, scale(-2.421f - Tk * (-1.180e-2f + tmis_sc)));
-	const int32_t v_loop = std::max(0, scale(-5.779f - Tk * (-2.330e-2f + loop_sc)));
-	const int32_t v_bulge = std::max(0, scale(5.247e-1f - Tk * (3.318e-4f + bulge_sc)));
+	for (int i = 0; i < NBP * NBP; i++) {
+		T.dk_H[i] = T.H[i], T.dk_S[i] = T.S[i] + salt_correction, T.dk_F[i] = INT32_MIN;
+		T.dg[i] = scale(T.H[i] - Tk * (T.S[i] + salt_correction));
+	}
+	// the supplementary classes as (H, S + salt term) pairs: their value at any temperature is max(0, scale(H - T * S))
+	struct Cls {
+		float H, S;
+	};
+	const Cls k_at = {-4.474f, -2.091e-2f + tmatch_sc}, k_gc = {-3.000f, -1.318e-2f + tmatch_sc}, k_mm = {-2.421f, -1.180e-2f + tmis_sc},
+	          k_loop = {-5.779f, -2.330e-2f + loop_sc}, k_bulge = {5.247e-1f, 3.318e-4f + bulge_sc};
+	auto put = [&](int idx, const Cls &k) {
+		T.dk_H[idx] = k.H, T.dk_S[idx] = k.S, T.dk_F[idx] = 0;
+		T.dg[idx] = std::max(0, scale(k.H - Tk * k.S));
+	};
+	const int32_t v_at = std::max(0, scale(k_at.H - Tk * k_at.S));
+	const int32_t v_gc = std::max(0, scale(k_gc.H - Tk * k_gc.S));
+	const int32_t v_mm = std::max(0, scale(k_mm.H - Tk * k_mm.S));
+	const int32_t v_loop = std::max(0, scale(k_loop.H - Tk * k_loop.S));
+	const int32_t v_bulge = std::max(0, scale(k_bulge.H - Tk * k_bulge.S));
+	(void)v_loop, (void)v_bulge;
 	for (int i = bA; i <= bI; i++)
 		for (int j = bA; j <= bI; j++) {
 			const int cur = i * NB + j;
-			const int32_t v = !wc[cur] ? v_mm : ((cur == P_GC || cur == P_CG) ? v_gc : v_at); // inosine pairs == AT (:289-290)
+			const Cls &kv = !wc[cur] ? k_mm : ((cur == P_GC || cur == P_CG) ? k_gc : k_at); // inosine pairs == AT (:289-290)
 			for (int k = bA; k <= bI; k++) {
 				const int p1 = k * NB + bGAP, p2 = bGAP * NB + k;
-				T.dg[cur * NBP + p1] = T.dg[p1 * NBP + cur] = T.dg[cur * NBP + p2] = T.dg[p2 * NBP + cur] = v;
+				put(cur * NBP + p1, kv), put(p1 * NBP + cur, kv), put(cur * NBP + p2, kv), put(p2 * NBP + cur, kv);
 			}
 			for (int k = bA; k <= bI; k++)
 				for (int l = bA; l <= bI; l++)
-					if (!wc[cur] && !wc[k * NB + l]) T.dg[cur * NBP + k * NB + l] = v_loop;
+					if (!wc[cur] && !wc[k * NB + l]) put(cur * NBP + k * NB + l, k_loop);
 		}
 	for (int i = bA; i <= bI; i++)
 		for (int j = bA; j <= bI; j++) {
-			T.dg[(i * NB + bGAP) * NBP + (j * NB + bGAP)] = v_bulge;
-			T.dg[(bGAP * NB + i) * NBP + (bGAP * NB + j)] = v_bulge;
+			put((i * NB + bGAP) * NBP + (j * NB + bGAP), k_bulge);
+			put((bGAP * NB + i) * NBP + (bGAP * NB + j), k_bulge);
 		}
+	(void)v_at, (void)v_gc, (void)v_mm;
 
 	// ---- class constants used by the bind kernel instead of six of the seven table reads per cell
 	bool ok = true;
 	auto G = [&](int prev, int cur) { return T.dg[prev * NBP + cur]; };
 	const int GG = P__;
-	T.dg_const[0] = G(bA * NB + bGAP, bA * NB + bGAP);       // BULGE
-	T.dg_const[1] = G(GG, bA * NB + bGAP);                   // C0 = g(__, (x,GAP))
-	T.dg_const[2] = G(GG, bA * NB + bA);                     // FORB_M = g(__, real pair)
-	T.dg_const[3] = G(bGAP * NB + bA, bA * NB + bGAP);       // FORB_XY = g((GAP,x),(y,GAP))
-	for (int p = 0; p < NBP; p++) T.term[p] = 0;
+	T.const_src[0] = (bA * NB + bGAP) * NBP + bA * NB + bGAP; // BULGE
+	T.const_src[1] = GG * NBP + bA * NB + bGAP;              // C0 = g(__, (x,GAP))
+	T.const_src[2] = GG * NBP + bA * NB + bA;                // FORB_M = g(__, real pair)
+	T.const_src[3] = (bGAP * NB + bA) * NBP + bA * NB + bGAP; // FORB_XY = g((GAP,x),(y,GAP))
+	for (int k = 0; k < 4; k++) T.dg_const[k] = T.dg[T.const_src[k]];
+	for (int p = 0; p < NBP; p++) T.term[p] = 0, T.term_src[p] = -1;
 	for (int x = bA; x <= bI; x++)
 		for (int y = bA; y <= bI; y++) {
 			const int c = x * NB + y;
 			const int v = G(bA * NB + bGAP, c);
 			T.term[c] = v;
+			T.term_src[c] = (bA * NB + bGAP) * NBP + c;
 			ok &= G(GG, c) == T.dg_const[2];
 			for (int k = bA; k <= bI; k++) {
 				const int p1 = k * NB + bGAP, p2 = bGAP * NB + k;
@@ -211,7 +228,9 @@ bool fill_tables(Tables &T, const tnt_options &opt)
 			ok &= G(gx, yg) == T.dg_const[3] && G(xg, gy) == T.dg_const[3];
 			ok &= G(GG, xg) == T.dg_const[1] && G(GG, gx) == T.dg_const[1];
 		}
-	for (int x = bA; x <= bI; x++) T.term[bGAP * NB + x] = T.dg_const[3]; // first column: prev = bp(GAP, q)
+	for (int x = bA; x <= bI; x++) T.term[bGAP * NB + x] = T.dg_const[3], T.term_src[bGAP * NB + x] = T.const_src[3]; // first column: prev = bp(GAP, q)
+	// the triples reproduce the table at the target temperature (what --dinkelbach recomputes per pass)
+	for (int i = 0; i < NBP * NBP; i++) ok &= std::max(scale(T.dk_H[i] - Tk * T.dk_S[i]), T.dk_F[i]) == T.dg[i];
 	return ok;
 }
 
@@ -572,6 +591,11 @@ int pick_instance(size_t L)
 void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_t stream = nullptr)
 {
 	if (!stream) stream = c->stream;
+	if (c->opt.use_dinkelbach) { // every bind through the 64-row general instances that iterate the temperature
+		if (lmax == 0) hipLaunchKernelGGL((bind_kernel<64, true, false, false, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
+		else hipLaunchKernelGGL((bind_kernel<64, false, false, false, true>), dim3(blocks), dim3(bind_threads(64)), 0, stream, a);
+		return;
+	}
 	if (lmax == 0) { // unit-level API: one instance is enough
 		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
 		return;
@@ -604,6 +628,7 @@ void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t strea
 void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_exceptions, const uint32_t *src, const uint32_t *src_count,
                        const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always */)
 {
+	if (c->opt.use_dinkelbach) merge_mode = 2; // the Dinkelbach passes only exist in the longest general instance
 	uint32_t *cnt = c->counters.p;
 	(void)hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream);
 	BucketArgs k;
@@ -812,10 +837,6 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		g_create_error = "hash word size must be 3..8 (options.cpp -W)";
 		return TNT_E_ARG;
 	}
-	if (opt->use_dinkelbach) {
-		g_create_error = "--dinkelbach is not implemented on the GPU path";
-		return TNT_E_UNSUPPORTED;
-	}
 	if (!(opt->salt >= 1.0e-6f && opt->salt <= 1.0f)) { // NucCruc::salt, nuc_cruc.h:852-867
 		g_create_error = "[Na+] out of range";
 		return TNT_E_ARG;
@@ -923,7 +944,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 			if (char_to_base(ch) < 0) FAIL(TNT_E_ARG, "oligos must be expanded to A/C/G/T/I (expand_degenerate_signatures)");
 		max_L = std::max(max_L, o.size());
 	}
-	c->lmax = pick_lmax(max_L);
+	c->lmax = opt->use_dinkelbach ? 64 : pick_lmax(max_L); // --dinkelbach: one 64-row instance binds everything
 	{
 		// buckets: one per instance in use, in ascending length; the last one is the general instance that
 		// takes the longest oligo (short queues are bound there as a whole)

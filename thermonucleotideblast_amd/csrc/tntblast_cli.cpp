@@ -14,7 +14,7 @@
 //   --max-target-len fragmentation       tntblast_local.cpp:282-289,438-468,638-648, seq_len_increment sequence_data.cpp:739-754,
 //                                        uniquify_results tntblast_util.cpp:1555-1755
 // Between reading the inputs and formatting the hits there is one call per batch of targets: tnt_search().
-// Not supported (exit with a message): BLAST / GenBank / EMBL databases, -D, --dinkelbach.
+// Not supported (exit with a message): BLAST / GenBank / EMBL databases, -D.
 #include <getopt.h>
 
 #include <algorithm>
@@ -792,9 +792,7 @@ void parse_args(int argc, char **argv, Options &o)
 			case 14: o.t.allow_dangle_5 = parse_bool(optarg) ? 1 : 0; break;
 			case 15: o.t.allow_dangle_3 = parse_bool(optarg) ? 1 : 0; break;
 			case 16: o.t.min_max_primer_clamp = atoi(optarg); break;
-			case 17:
-				if (parse_bool(optarg)) fail("--dinkelbach is not supported by the MI355X path");
-				break;
+			case 17: o.t.use_dinkelbach = parse_bool(optarg) ? 1 : 0; break; // options.cpp --dinkelbach
 			case 18: o.t.max_gap = atoi(optarg); break;
 			case 19: o.t.max_mismatch = atoi(optarg); break;
 			case 20: o.rescale_ct = parse_bool(optarg); break;
