@@ -353,16 +353,14 @@ def main():
             try:
                 rec = json.load(open(pmc))
                 traffic = rec.get("hbm_bytes_per_step")
-                # What actually bounds the kernel: VALU issue.  Wave-instructions per step from the same
-                # PMC file over this run's bind time, against (a) the guide's plain rate: 1 024 SIMDs x 2.4 GHz / 2 cycles,
-                # (b) the rate of this instruction mix measured by scripts/microbench/valu_rate.hip (2.25 / 4.3 cycles
-                # by class at the 1.97 GHz the kernel sustains)
+                # What bounds these kernels is instruction issue and LDS bank conflicts, not HBM:
+                # VALU wave-instructions per step from the same PMC file over this run's bind time, against the guide's plain
+                # rate: 1 024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction
                 n_valu = rec.get("SQ_INSTS_VALU_per_step")
                 if n_valu and bind_ms_step > 0:
                     ach = n_valu / (bind_ms_step * 1e-3)
-                    peak_mix = 1024 * 1.97e9 / 3.15
                     valu = {"achieved": ach, "unit": "VALU wave-instructions/s", "peak_guide": VALU_PEAK_GUIDE,
-                            "frac_guide": ach / VALU_PEAK_GUIDE, "peak_mix": peak_mix, "frac_mix": ach / peak_mix}
+                            "frac_guide": ach / VALU_PEAK_GUIDE, "wave_instructions_per_step": n_valu}
             except Exception:
                 traffic = None
         tl = n_bases_rank // max(1, n_targets_rank)
@@ -382,11 +380,13 @@ def main():
             "gather_bytes_per_search": acc["gather_bytes"],
             "pack_and_h2d_s": pack_s,
             "stage_ms_per_step": {"seed": seed_ms_step, "bind": bind_ms_step, "pair": pair_ms / steps},
-            "roofline": {"bound": "hbm", "kernel": "bind_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "bind stage: bucket_kernel + filter_kernel<L> (pre-filter) + bind_kernel<L> on the survivors",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once); the bind "
-                                 "stage is bound by integer VALU issue, not by HBM (DESIGN.md 4.2); traffic = PMC "
-                                 "2*FETCH_SIZE + WRITE_SIZE per step of the full-size config (profiles/bind_pmc.json)",
+                         "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once) over the stage time "
+                                 "(HIP events on the library's stream); the stage is bound by VALU issue and LDS bank "
+                                 "conflicts, not by HBM (DESIGN.md 4.2, 4.2a); traffic = PMC 2*FETCH_SIZE + WRITE_SIZE per step "
+                                 "of the full-size config (profiles/bind_pmc.json; round 1: 56.5 GB)",
                          "dp_per_s": n_binds / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0,
                          "valu_issue": valu},
             # the streaming stage, for which SURVEY 8(d) means the HBM roofline: the seed kernels of a step (scan + cull)

@@ -15,9 +15,11 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"\[clone.*", "", name).strip()
-    m = re.search(r"(bind_kernel)<(\d+), *(true|false)>", name)
+    m = re.search(r"(bind_kernel)<(\d+), *(true|false)", name)
     if m:
         return "bind_kernel<%s>" % ("unit" if m.group(3) == "true" else "L")
+    if "filter_kernel<" in name:
+        return "filter_kernel<L>"
     m = re.search(r"(\w+_kernel)\b", name)
     return m.group(1) if m else name.split("(")[0]
 
@@ -34,13 +36,17 @@ def main():
             disp[k].add((os.path.basename(f), r["Dispatch_Id"]))
     dur = defaultdict(list)
     per_inst = defaultdict(list)
+    per_filt = defaultdict(list)
     for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
             dur[short(r["Kernel_Name"])].append(d)
-            m = re.search(r"bind_kernel<(\d+), *false>", r["Kernel_Name"])
+            m = re.search(r"bind_kernel<(\d+), *false", r["Kernel_Name"])
             if m:
                 per_inst[int(m.group(1))].append(d)
+            m = re.search(r"filter_kernel<(\d+)>", r["Kernel_Name"])
+            if m:
+                per_filt[int(m.group(1))].append(d)
     out = {"searches": searches, "kernels": {}}
     for k in sorted(set(counters) | set(dur)):
         e = {c: v / searches for c, v in sorted(counters[k].items())}
@@ -51,6 +57,8 @@ def main():
         out["kernels"][k] = e
     if per_inst:
         out["bind_instances_ms_per_search"] = {str(l): sum(v) / searches for l, v in sorted(per_inst.items())}
+    if per_filt:
+        out["filter_instances_ms_per_search"] = {str(l): sum(v) / searches for l, v in sorted(per_filt.items())}
     json.dump(out, open(dst, "w"), indent=1)
     for k, e in out["kernels"].items():
         print(k, {c: (round(v, 3) if v < 1e4 else "%.4g" % v) for c, v in e.items()})
