@@ -133,7 +133,11 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 			uint32_t qprev = bGAP;
 #pragma unroll
 			for (int w = 0; w < (LMAX + 3) / 4; w++) {
+#ifdef TNT_EXP_UNIFORM_SLOT
+				const uint32_t q4w = a.olig_q4[uint32_t(__builtin_amdgcn_readfirstlane(int(slot.oligo))) * (MAX_OLIGO / 4) + w]; // timing experiment only
+#else
 				const uint32_t q4w = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + w] : 0u;
+#endif
 #pragma unroll
 				for (int b = 0; b < 4; b++) {
 					const int i = w * 4 + b; // row i + 1

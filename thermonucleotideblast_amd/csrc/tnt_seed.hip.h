@@ -36,7 +36,13 @@ constexpr int SEED_LDS_WORD_SIZE = 7;                 // hash words up to 7 base
 constexpr int SEED_LDS_OFF = (1 << (2 * SEED_LDS_WORD_SIZE)) + 2;
 constexpr int SEED_LDS_ENT = 10240;                   // entries of one assay chunk (40 KB)
 constexpr int SEED_LDS_SEQ = 1536;                    // 64-bit words of packed oligos: 128 assays x 6 lists x 2 (12 KB); larger chunks read them from HBM
-constexpr int SEED_SWEEP = 16;                        // positions per lane and sweep
+#ifndef TNT_SEED_SWEEP
+#define TNT_SEED_SWEEP 16
+#endif
+#ifndef TNT_SEED_MINBLOCKS
+#define TNT_SEED_MINBLOCKS 4
+#endif
+constexpr int SEED_SWEEP = TNT_SEED_SWEEP;               // positions per lane and sweep
 constexpr int SEED_CAP = 512;         // seeds of one target x one assay chunk held in LDS
 constexpr int SEED_MAX_ASSAYS = 256;  // assays per chunk (8-bit local index in the key)
 constexpr uint32_t ITEM_NO_REP = 0xFFFFFFFFu;
@@ -178,7 +184,7 @@ __device__ __forceinline__ bool first_on_diagonal_packed(const uint32_t *pk, con
 // LDS_TABLES: the chunk's query-word table is staged in LDS once per workgroup (word size <= SEED_LDS_WORD_SIZE, at most
 // SEED_LDS_ENT entries) and the scan walks SEED_SWEEP positions per lane out of registers; otherwise the tables are read
 // from HBM / L2 position by position (word size 8, over-long chunks).
-template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES), (LDS_TABLES ? 2 : 4)) void seed_kernel(SeedArgs a)
+template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES), (LDS_TABLES ? 2 : TNT_SEED_MINBLOCKS)) void seed_kernel(SeedArgs a)
 {
 	constexpr int WAVES = LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES;
 	__shared__ unsigned long long s_raw[WAVES][SEED_CAP];
@@ -322,7 +328,7 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 				for (uint32_t base = pos0 & ~uint32_t(SEED_SWEEP - 1); base < npos; base += 64 * SEED_SWEEP) {
 					const uint32_t p0 = base + uint32_t(lane) * SEED_SWEEP;
 					unsigned long long v = 0;
-					if (p0 < npos) v = (unsigned long long)pk[p0 >> 4] | ((unsigned long long)pk[(p0 >> 4) + 1] << 32);
+					if (p0 < npos) v = ((unsigned long long)pk[p0 >> 4] | ((unsigned long long)pk[(p0 >> 4) + 1] << 32)) >> ((p0 & 15u) * 2u);
 					uint32_t bnd[SEED_SWEEP]; // first entry | count << 16
 					uint32_t mine = 0;
 #pragma unroll
