@@ -1641,8 +1641,8 @@ int tntor_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assay
 // Checker of the product's bind pre-filter (thermonucleotideblast_amd/csrc/tnt_filter.hip.h): the same upper bound of
 // -(dH - Tk dS) over all alignments of a window, restated in the order evaluate_alignment reads an alignment
 // (nuc_cruc.cpp:1620-2299; the kernel sweeps the other way), on plain windows.  score[2k] = bound, score[2k+1] =
-// threshold of request k (INT32_MIN: this class is never rejected), both in 1e-4 kcal/mol; -1 / -1 when the window
-// holds a degenerate base (such windows never meet the filter).  tests/test_filter_bound.py holds it against
+// threshold of request k (INT32_MIN: this class is never rejected), both in 1e-4 kcal/mol; INT32_MAX / INT32_MIN when the
+// window holds inosine or a skipped code (such windows are never rejected).  tests/test_filter_bound.py holds it against
 // tntor_bind_batch ("accepted => bound >= threshold") and tests/test_gpu_parity.py against the kernel (equal integers).
 int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_oligos, const uint8_t *codes, const uint64_t *offsets,
                        size_t n_targets, uint32_t first_seq_index, const tnt_bind_req *req, size_t n, int32_t *score)
@@ -1710,12 +1710,20 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		const unsigned seq_len = unsigned(offsets[t + 1] - offsets[t]);
 		const unsigned start = unsigned(std::max(int(r.target_loc) - int(r.query_loc + TNT_FLANK), 0));
 		const unsigned stop = std::min(start + unsigned(L) + 2 * TNT_FLANK, seq_len);
-		bool plain = true;
-		for (unsigned p = start; p < stop; p++) plain = plain && seq[p] <= 3;
-		if (!plain) continue;
+		// IUPAC codes (5..15 = M R S V W Y H K D B N) become "any of A C G T": resolve_degenerate (nuc_cruc.cpp:14-201) turns
+		// them into one of the four per aligned pair, so the maximum over the four bounds whatever it picks.  Inosine in the
+		// target and the codes the window loader skips (> 15) are not modelled: bound = INT32_MAX, the window is never rejected.
+		const int ANY = -1;
+		bool modelled = true;
+		for (unsigned p = start; p < stop; p++) modelled = modelled && (seq[p] <= 3 || (seq[p] >= 5 && seq[p] <= 15));
+		if (!modelled) {
+			score[2 * k] = INT32_MAX;
+			score[2 * k + 1] = INT32_MIN;
+			continue;
+		}
 		// the window as NucCruc sees it (bind_oligo.cpp:524-573 / :1227-1276) ...
 		std::vector<int> tg;
-		for (unsigned p = start; p < stop; p++) tg.push_back(r.strand == TNT_MINUS ? 3 - int(seq[p]) : int(seq[p]));
+		for (unsigned p = start; p < stop; p++) tg.push_back(seq[p] > 3 ? ANY : (r.strand == TNT_MINUS ? 3 - int(seq[p]) : int(seq[p])));
 		if (r.strand == TNT_MINUS) std::reverse(tg.begin(), tg.end());
 		// ... read in pairing order: query 5'->3' against the target 3'->5'
 		std::reverse(tg.begin(), tg.end());
@@ -1731,13 +1739,19 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		auto at = [&](int a, int b) { return size_t(a) * (W + 1) + b; };
 		// recompute the gap price in integers the way the tables hold it: close[] already carries "- gap_price", so the entry
 		// into LP from a helix cell is free here and the price is paid on the way out
+		// table value of (previous pair, current pair), maximised over the bases an ANY column can stand for
+		auto entry = [&](const std::vector<int> &tab, int qp, int tp, int qc, int tc) {
+			int m = INT32_MIN;
+			for (int x = (tp == ANY ? 0 : tp); x <= (tp == ANY ? 3 : tp); x++)
+				for (int y = (tc == ANY ? 0 : tc); y <= (tc == ANY ? 3 : tc); y++) m = std::max(m, tab[(qp * NB + x) * NBP + qc * NB + y]);
+			return m;
+		};
 		for (int a = 1; a <= L; a++)
 			for (int b = 1; b <= W; b++) {
-				const int cur = qb[a - 1] * NB + tg[b - 1];
 				int x = 0, lp = NEG;
 				if (a > 1 && b > 1) {
-					const int prev = qb[a - 2] * NB + tg[b - 2];
-					x = std::max(X[at(a - 1, b - 1)] + C.fpos[prev * NBP + cur], LP[at(a - 1, b - 1)] + C.close[prev * NBP + cur]);
+					x = std::max(X[at(a - 1, b - 1)] + entry(C.fpos, qb[a - 2], tg[b - 2], qb[a - 1], tg[b - 1]),
+					             LP[at(a - 1, b - 1)] + entry(C.close, qb[a - 2], tg[b - 2], qb[a - 1], tg[b - 1]));
 					lp = LP[at(a - 1, b - 1)];
 				}
 				x = std::max(x, 0);

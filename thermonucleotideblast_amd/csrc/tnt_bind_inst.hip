@@ -1,13 +1,13 @@
 // tnt_bind_inst.hip -- the throughput instances of the bind kernel, one per oligo-length bucket.
 //
 // The build compiles this file several times with -DTNT_INST_LIST="G(36) P(36) E(22) ..." (a share of the
-// instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows) so they build
+// instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows, F / D = pre-filter for plain / any windows) so they build
 // in parallel; compiled once without the macro it provides all of them.
 #include "tnt_bind.hip.h"
 #include "tnt_filter.hip.h"
 
 #ifndef TNT_INST_LIST
-#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F)
+#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F) TNT_LMAX_LADDER(D)
 #endif
 
 namespace tnt {
@@ -20,7 +20,12 @@ namespace tnt {
 #define F(N)                                                                                                         \
 	void launch_filter_##N(const FilterArgs2 &a, int blocks, hipStream_t stream)                                     \
 	{                                                                                                                \
-		hipLaunchKernelGGL((filter_kernel<N>), dim3(blocks), dim3(256), 0, stream, a);                                \
+		hipLaunchKernelGGL((filter_kernel<N, false>), dim3(blocks), dim3(256), 0, stream, a);                         \
+	}
+#define D(N)                                                                                                         \
+	void launch_filter_degen_##N(const FilterArgs2 &a, int blocks, hipStream_t stream)                               \
+	{                                                                                                                \
+		hipLaunchKernelGGL((filter_kernel<N, true>), dim3(blocks), dim3(256), 0, stream, a);                          \
 	}
 #define G(N) TNT_LAUNCHER(launch_bind_##N, N, false, false)
 #define P(N) TNT_LAUNCHER(launch_bind_plain_##N, N, false, true)
@@ -30,5 +35,6 @@ TNT_INST_LIST
 #undef P
 #undef E
 #undef F
+#undef D
 
 } // namespace tnt

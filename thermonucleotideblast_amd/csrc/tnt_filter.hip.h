@@ -30,9 +30,10 @@
 
 namespace tnt {
 
-constexpr int FILT_X = 5;                        // target base of a column: A C G T, 4 = none (before the first column / behind the window)
-constexpr int FILT_ENTRIES = FILT_X * FILT_X * NBP; // index ((x' * 5 + x) * 49 + q' * 7 + q): previous column / row = (x', q'), current = (x, q)
-constexpr int FILT_PLANE = 20 * 64;              // entries per class (>= FILT_ENTRIES)
+constexpr int FILT_X = 6;                        // target base of a column: A C G T, 4 = none (before the first column / behind the window),
+constexpr int FILT_NONE = 4, FILT_ANY = 5;       // 5 = an IUPAC code: whatever resolve_degenerate (nuc_cruc.cpp:14-201) makes of it is one of A C G T
+constexpr int FILT_ENTRIES = FILT_X * FILT_X * NBP; // index ((x' * 6 + x) * 49 + q' * 7 + q): previous column / row = (x', q'), current = (x, q)
+constexpr int FILT_PLANE = 28 * 64;              // entries per class (>= FILT_ENTRIES)
 constexpr int FILT_CLASSES = 2;                  // threshold sets by minimum Tm: primers, probes
 constexpr int32_t FILT_NEG = -(1 << 28);
 
@@ -69,8 +70,13 @@ struct FilterArgs2 {
 // bits 0-1 of Thresh index -> class: 0 primer thresholds, 1..3 probe thresholds (tnt_host.hip builds th[0..3])
 __device__ __forceinline__ int filter_class(int thresh_index) { return thresh_index == 0 ? 0 : 1; }
 
-template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterArgs2 a)
+// DEGEN: the instance for windows that may hold non-ACGT target codes (the general buckets).  An IUPAC code (M R S V W Y H K
+// D B N) is resolved per aligned pair to one of A C G T (resolve_degenerate), so its column takes, entry by entry, the
+// maximum over the four bases (the ANY rows of the table): still an upper bound.  Inosine in the target and codes the
+// window loader skips (gap, unknown: bind_oligo.cpp, Q6) are not modelled: such a window passes unfiltered.
+template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_kernel(FilterArgs2 a)
 {
+	static_assert(FILT_ENTRIES <= FILT_PLANE, "table size");
 	constexpr int THREADS = 256;
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	__shared__ int32_t s_tab[FILT_CLASSES * 2 * FILT_PLANE];
@@ -117,14 +123,46 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 #pragma unroll
 			for (int k = 0; k < NW; k++) wv[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
 		}
+		// DEGEN: the window's non-ACGT codes from the target's exception list: IUPAC codes mark their position in `am` (bit
+		// 2 * (r & 15) of word r >> 4, the layout of `wv`); anything else makes the window pass unfiltered
+		uint32_t am[DEGEN ? NW : 1];
+		bool unfilterable = false;
+		if (DEGEN) {
+#pragma unroll
+			for (int k = 0; k < NW; k++) am[DEGEN ? k : 0] = 0u;
+			if (active) {
+				const uint32_t e0 = a.db.exc_off[it.target], e1 = a.db.exc_off[it.target + 1];
+				uint32_t lo = e0, hi = e1;
+				while (lo < hi) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (a.db.exc_pos[mid] < uint32_t(start)) lo = mid + 1;
+					else hi = mid;
+				}
+				for (uint32_t x = lo; x < e1 && a.db.exc_pos[x] < uint32_t(stop); x++) {
+					const int code = a.db.exc_code[x];
+					if (code < 5 || code > 15) unfilterable = true; // inosine; skipped codes (the window shrinks)
+					const int r = int(a.db.exc_pos[x]) - start;
+#pragma unroll
+					for (int k = 0; k < NW; k++)
+						if ((r >> 4) == k) am[DEGEN ? k : 0] |= 1u << ((r & 15) * 2);
+				}
+			}
+		}
 		auto base_at = [&](int r) __attribute__((always_inline)) { // base r of the window, r in [0, W)
 			uint32_t w = wv[0];
 #pragma unroll
 			for (int k = 1; k < NW; k++) w = (r >> 4) == k ? wv[k] : w;
-			return int((w >> ((r & 15) * 2)) & 3u);
+			const int b = int((w >> ((r & 15) * 2)) & 3u);
+			if (!DEGEN) return b;
+			uint32_t m = am[0];
+#pragma unroll
+			for (int k = 1; k < NW; k++) m = (r >> 4) == k ? am[DEGEN ? k : 0] : m;
+			return ((m >> ((r & 15) * 2)) & 1u) ? -1 : b;
 		};
 		auto column_base = [&](int j) __attribute__((always_inline)) { // target base of column j in 1..W
-			return minus ? 3 - base_at(W - j) : base_at(j - 1);
+			const int b = minus ? base_at(W - j) : base_at(j - 1);
+			if (DEGEN && b < 0) return FILT_ANY; // (the complement of an IUPAC code is an IUPAC code)
+			return minus ? 3 - b : b;
 		};
 		// per-row part of the table address, 8 * (7 * q' + q), two rows per register: q' = base of the row above (none above
 		// row 1), rows behind the oligo are "none" as well (their entries add nothing and open nothing)
@@ -215,6 +253,7 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 			theta = int(floorf(th * 10000.0f)) - 1;
 			pass = best >= theta;
 		}
+		if (DEGEN && unfilterable) pass = true, best = INT32_MAX, theta = INT32_MIN;
 		if (a.score_out && active) a.score_out[2 * idx] = best, a.score_out[2 * idx + 1] = theta;
 		if (a.audit) {
 			if (active) a.audit[idx] = pass ? 0 : 1;
@@ -239,6 +278,9 @@ template <int LMAX> __global__ __launch_bounds__(256) void filter_kernel(FilterA
 // host-side launchers, defined in tnt_bind_inst.hip next to the bind kernel instances of the same lengths
 #define X(N) void launch_filter_##N(const FilterArgs2 &a, int blocks, hipStream_t stream);
 TNT_FILTER_LADDER(X)
+#undef X
+#define X(N) void launch_filter_degen_##N(const FilterArgs2 &a, int blocks, hipStream_t stream);
+TNT_LMAX_LADDER(X)
 #undef X
 
 } // namespace tnt

@@ -293,6 +293,24 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 						if (wc[second]) // a loop / bulge is closed by a Watson-Crick column
 							F.plane[cls][at][1] = int32_t(std::ceil((std::max(std::max(f, 0.0), u1[second]) - gap_price) * 10000.0));
 					}
+		// columns that hold an IUPAC code (FILT_ANY): resolve_degenerate turns the code into one of A C G T per aligned pair
+		// (nuc_cruc.cpp:14-201), so the maximum over the four bases bounds whatever it picks -- in either role of the column
+		for (int qq = 0; qq < NBP; qq++) {
+			auto at = [&](int xp, int x) { return (xp * FILT_X + x) * NBP + qq; };
+			for (int k = 0; k < 2; k++) {
+				for (int xp = 0; xp < 4; xp++) { // (x', ANY)
+					int32_t m = F.plane[cls][at(xp, 0)][k];
+					for (int x = 1; x < 4; x++) m = std::max(m, F.plane[cls][at(xp, x)][k]);
+					F.plane[cls][at(xp, FILT_ANY)][k] = m;
+				}
+				for (int x = 0; x < FILT_X; x++) { // (ANY, x), x = ANY included (its column of the table was filled above)
+					if (x == FILT_NONE) continue;
+					int32_t m = F.plane[cls][at(0, x)][k];
+					for (int xp = 1; xp < 4; xp++) m = std::max(m, F.plane[cls][at(xp, x)][k]);
+					F.plane[cls][at(FILT_ANY, x)][k] = m;
+				}
+			}
+		}
 		const double g_init = double(T.init_H) - Tk * double(T.init_S);
 		const double g_at = double(T.at_H) - Tk * double(T.at_S);
 		F.theta0[cls] = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02); // 0.02 kcal/mol: float32 rounding of the reference's sums, generously
@@ -459,6 +477,7 @@ struct tnt_ctx {
 	DevBuf<uint32_t> slot_canon, slot_next;
 	DevBuf<uint32_t> item_rep;
 	bool dedupe = false;
+	bool filter_general = false; // the general buckets (degenerate windows, merged short queues) meet the pre-filter too
 	bool seed_lds = false; // the seed kernel instance with LDS-resident tables serves this context
 	DevBuf<Thresh> thresh;
 	DevBuf<AssayDev> assays;
@@ -546,8 +565,14 @@ __global__ void accumulate_kernel(uint32_t *cnt)
 	cnt[C_TOT_BOUND] += cnt[C_POOL];
 }
 
-constexpr size_t ITEM_CAP = size_t(384) << 20;  // bind work items per internal batch
-constexpr size_t GROUP_CAP = size_t(256) << 20;
+static size_t cap_from_env(const char *name, size_t dflt_m)
+{
+	const char *e = getenv(name);
+	const long v = e ? atol(e) : 0;
+	return size_t(v >= 16 && v <= 2048 ? size_t(v) : dflt_m) << 20;
+}
+static const size_t ITEM_CAP = cap_from_env("TNT_MI355X_ITEM_CAP_M", 768);  // bind work items per internal batch
+static const size_t GROUP_CAP = cap_from_env("TNT_MI355X_GROUP_CAP_M", 256);
 constexpr size_t POOL_CAP = size_t(4) << 20;
 
 DbView make_view(const tnt_db *db, size_t t0, size_t t1)
@@ -614,8 +639,17 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 	}
 }
 
-void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t stream)
+void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t stream, bool degen = false /* windows with any target code */)
 {
+	if (degen) {
+		switch (rows) {
+#define X(N) case N: tnt::launch_filter_degen_##N(a, blocks, stream); break;
+			TNT_LMAX_LADDER(X)
+#undef X
+		default: break;
+		}
+		return;
+	}
 	switch (rows) {
 #define X(N) case N: tnt::launch_filter_##N(a, blocks, stream); break;
 		TNT_FILTER_LADDER(X)
@@ -668,9 +702,10 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
 		b.audit = nullptr;
-		if (c->filter_on && (c->bucket_lmax[i] & BUCKET_PLAIN)) {
-			// plain windows first meet the pre-filter: what cannot reach the minimum Tm is rejected there, the rest of the
-			// bucket is compacted into qsurv (same offset) and bound by the full kernel
+		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general)) {
+			// every window first meets the pre-filter: what cannot reach the minimum Tm is rejected there, the rest of the
+			// bucket is compacted into qsurv (same offset) and bound by the full kernel.  (The general buckets -- windows
+			// with degenerate target bases, merged short queues -- go through the instance that reads the exception lists.)
 			FilterArgs2 f;
 			memset(&f, 0, sizeof(f));
 			f.tab = c->ftab.p;
@@ -689,7 +724,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.result = b.result;
 			f.n_rejected = cnt + C_FILTERED;
 			f.audit = c->filter_audit ? c->audit.p : nullptr;
-			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane]);
+			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
 			b.index = c->qsurv.p;
 			b.n_items_dev = f.n_survivors;
 			b.audit = f.audit;
@@ -972,6 +1007,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	fill_filter_tables(c->h_ftab, c->h_tab, *opt);
 	c->filter_on = (c->h_ftab.enabled[0] || c->h_ftab.enabled[1]) && !getenv("TNT_MI355X_NO_FILTER");
 	c->filter_audit = c->filter_on && getenv("TNT_MI355X_FILTER_AUDIT");
+	c->filter_general = c->filter_on && !getenv("TNT_MI355X_NO_FILTER_GENERAL");
 	c->serial_bind = getenv("TNT_MI355X_SERIAL_BIND") != nullptr;
 	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
 	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 4), 0);
@@ -2729,12 +2765,12 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 		const int L = int(ctx->oligos[r.oligo].size());
 		slots[i] = Slot{r.oligo, logf((r.ct - 0.5f * 0.0f) * 1.0f), r.role == 1 ? 1 : 0, -1, 0, 0};
 		items[i] = Item{uint32_t(t), uint32_t(r.target_loc), uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT), 0};
-		// windows with a degenerate base never meet the filter (the bucket pass routes them to the general bind instances)
+		// windows with a non-ACGT code meet the filter instance of the general buckets
 		const int start = std::max(0, r.target_loc - (r.query_loc + FLANK));
 		const uint32_t stop = std::min<uint32_t>(uint32_t(start + L + 2 * FLANK), db->h_len[t]);
 		const uint32_t *eb = db->h_exc_pos.data() + db->h_exc_off[t], *ee = db->h_exc_pos.data() + db->h_exc_off[t + 1];
 		const uint32_t *it = std::lower_bound(eb, ee, uint32_t(start));
-		if (it != ee && *it < stop) plain[i] = 0;
+		if (it != ee && *it < stop) plain[i] = 0, by_rows[1000 + (pick_lmax(size_t(L)) & 0xFF)].push_back(uint32_t(i)); // the instance of the general buckets
 		else by_rows[pick_instance(size_t(L)) & 0xFF].push_back(uint32_t(i));
 	}
 	DevBuf<Slot> dslots;
@@ -2763,7 +2799,7 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 	for (const auto &kv : by_rows) {
 		f.index = dindex.p + at;
 		f.n_items = uint32_t(kv.second.size());
-		launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), kv.first, ctx->stream);
+		launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), kv.first % 1000, ctx->stream, kv.first >= 1000);
 		at += kv.second.size();
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);

@@ -30,14 +30,14 @@ namespace tnt {
 constexpr int SEED_WAVES = 4;         // wavefronts (= targets in flight) per workgroup of the instance that reads its tables from HBM / L2
 constexpr int SEED_THREADS = 64 * SEED_WAVES;
 // The streaming instance: the query-word table of the chunk (bucket offsets + entries + the packed oligos) sits in LDS once
-// per workgroup and is shared by SEED_LDS_WAVES wavefronts; every lane walks 16 consecutive positions out of two registers.
+// per workgroup and is shared by SEED_LDS_WAVES wavefronts; every lane walks SEED_SWEEP consecutive positions out of two registers.
 constexpr int SEED_LDS_WAVES = 8;
 constexpr int SEED_LDS_WORD_SIZE = 7;                 // hash words up to 7 bases: 4^7 + 1 16-bit offsets = 32 KB
 constexpr int SEED_LDS_OFF = (1 << (2 * SEED_LDS_WORD_SIZE)) + 2;
 constexpr int SEED_LDS_ENT = 10240;                   // entries of one assay chunk (40 KB)
 constexpr int SEED_LDS_SEQ = 1536;                    // 64-bit words of packed oligos: 128 assays x 6 lists x 2 (12 KB); larger chunks read them from HBM
 #ifndef TNT_SEED_SWEEP
-#define TNT_SEED_SWEEP 16
+#define TNT_SEED_SWEEP 8
 #endif
 #ifndef TNT_SEED_MINBLOCKS
 #define TNT_SEED_MINBLOCKS 4
@@ -320,7 +320,7 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 			} else
 #endif
 			{
-				// Sweeps of 64 x SEED_SWEEP positions: a lane loads the two packed words that hold its 16 positions (and the
+				// Sweeps of 64 x SEED_SWEEP positions: a lane loads the two packed words that hold its positions (and the
 				// k - 1 bases behind them), extracts the 16 k-mers with shifts, reads their bucket bounds (all 32 reads in
 				// flight at once: from LDS, or from L2 in the instance without LDS tables) and counts its candidates; one
 				// wave-wide prefix sum gives every lane its slice of the candidate list.
