@@ -471,28 +471,17 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 	                         O1 = srt[(s0 + (X) + 1u < last ? s0 + (X) + 1u : last)] & ~K_FLAGS, \
 	                         O2 = srt[(s0 + (X) + 2u < last ? s0 + (X) + 2u : last)] & ~K_FLAGS, \
 	                         O3 = srt[(s0 + (X) + 3u < last ? s0 + (X) + 3u : last)] & ~K_FLAGS
-					// nearest probe on the side where the partner primer must lie (a pair only counts with a probe between)
-					unsigned long long pnear = minus ? ~0ull : 0ull;
-					bool have_p = !has_probe;
-					if (has_probe && role != 2)
-						for (uint32_t x = 0; x < cnt; x += 4) {
-							SEG4(x, o0, o1, o2, o3);
-							const unsigned long long os[4] = {o0, o1, o2, o3};
-#pragma unroll
-							for (int j = 0; j < 4; j++) {
-								const unsigned long long o = os[j];
-								if (key_role(o) != 2) continue;
-								if (minus ? (o > k && o < pnear) : (o < k && o > pnear)) pnear = o, have_p = true;
-							}
-						}
-					if (!has_probe) pnear = k; // the partner only has to lie on the right side of this seed
 					// One pass over the segment:
 					//  * the element FOLLOWING this one in list order (amplicon_search.cpp:748-755 counts its strand when this
 					//    seed is valid; past-the-end counts nothing);
-					//  * a primer is valid iff a partner exists: other strand, beyond the probe, allowed oligo, within reach
-					//    (the reference takes the closest partner per oligo; the closest one is within reach iff any is);
+					//  * a primer is valid iff a partner exists: other strand, allowed oligo, within reach (the reference takes
+					//    the closest partner per oligo; the closest one is within reach iff any is) and, with a probe in the
+					//    assay, beyond the nearest probe on that side (a pair only counts with a probe between).  The pass
+					//    keeps the nearest probe (`pnear`) and the partner within reach that lies farthest out (`far`): some
+					//    partner lies beyond the probe iff that one does;
 					//  * a probe needs the closest primers on either side (per oligo).
 					unsigned long long next = ~0ull;
+					unsigned long long pnear = minus ? ~0ull : 0ull, far = minus ? 0ull : ~0ull;
 					uint32_t f_loc[2] = {0, 0}, r_loc[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 					bool f_ok[2] = {false, false}, r_ok[2] = {false, false};
 					for (uint32_t x = 0; x < cnt; x += 4) {
@@ -503,17 +492,27 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 							const unsigned long long o = os[j];
 							if (o > k && o < next) next = o;
 							const uint32_t orole = key_role(o);
-							if (orole == 2) continue;
+							if (orole == 2) {
+								if (minus ? (o > k && o < pnear) : (o < k && o > pnear)) pnear = o;
+								continue;
+							}
 							const uint32_t oloc = uint32_t(o >> 24);
 							const bool ominus = o & 1u;
 							if (role == 2) { // probe: primers on either side of me
 								if (ominus && o < k && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
 								if (!ominus && o > k && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
 							} else if (single || orole != role) {
-								if (minus) valid |= !ominus && o > pnear && oloc - loc <= threshold; // I am an f: partners r beyond the probe
-								else valid |= ominus && o < pnear && loc - oloc <= threshold;        // I am an r: partners f before the probe
+								if (minus) { // I am an f: partners r to my right
+									if (!ominus && o > k && oloc - loc <= threshold && o > far) far = o;
+								} else {     // I am an r: partners f to my left
+									if (ominus && o < k && loc - oloc <= threshold && o < far) far = o;
+								}
 							}
 						}
+					}
+					if (role != 2) {
+						if (!has_probe) valid = minus ? far != 0ull : far != ~0ull;
+						else valid = minus ? (pnear != ~0ull && far > pnear) : (pnear != 0ull && far < pnear);
 					}
 #undef SEG4
 					if (role == 2) {
@@ -521,8 +520,6 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 						for (int rf = 0; rf < 2; rf++)
 							for (int rr = 0; rr < 2; rr++)
 								if ((single || rf != rr) && f_ok[rf] && r_ok[rr] && r_loc[rr] - f_loc[rf] <= threshold) valid = true;
-					} else if (!have_p) {
-						valid = false;
 					}
 					if (valid) {
 						// strand of the list element FOLLOWING a valid one decides which strand is bound first (:131)
