@@ -16,8 +16,8 @@
 //   M2(i,j) best value inside a loop / bulge that has left its diagonal; it is entered from a helix cell at the price of
 //           the cheapest bulge / asymmetric loop and left through a diagonal step that earns the adjacent stack, or the
 //           best stack across a single-base bulge.
-// Everything is integer (1e-4 kcal/mol), table entries rounded towards "more stable", and the threshold carries a margin
-// for the float32 rounding of the reference's sums.  A window whose bound stays below the threshold is rejected with
+// Everything is integer -- 16-bit, in units of 1e-3 kcal/mol, saturating (a bound that saturates passes) -- with the table
+// entries rounded towards "more stable", and the threshold carries a margin for the float32 rounding of the reference's sums.  A window whose bound stays below the threshold is rejected with
 // the status the full kernel would have given it (Tm too low); every other window goes on to the full kernel, so the
 // filter can only cost time, never change a result.  tests/test_filter_bound.py checks "accepted => bound >= threshold"
 // on millions of random windows against the oracle.
@@ -35,13 +35,15 @@ constexpr int FILT_NONE = 4, FILT_ANY = 5;       // 5 = an IUPAC code: whatever 
 constexpr int FILT_ENTRIES = FILT_X * FILT_X * NBP; // index ((x' * 6 + x) * 49 + q' * 7 + q): previous column / row = (x', q'), current = (x, q)
 constexpr int FILT_PLANE = 28 * 64;              // entries per class (>= FILT_ENTRIES)
 constexpr int FILT_CLASSES = 2;                  // threshold sets by minimum Tm: primers, probes
-constexpr int32_t FILT_NEG = -(1 << 28);
+constexpr int FILT_UNITS = 1000;                 // table units per kcal/mol
+constexpr int FILT_NEG = -16384;                 // "not possible": -16.4 kcal/mol (a price no path that matters can pay) ...
+constexpr int FILT_SAT = 32767;                  // ... and the value sums saturate at: 32.8 kcal/mol, above every threshold
 
 // host-built tables of one context (tnt_host.hip, fill_filter_tables)
 struct FilterTables {
-	// per class and entry two ints side by side (one ds_read_b64 per cell): [0] the stack, counted when favourable;
-	// [1] entry into a loop through this diagonal step, minus the gap price
-	int32_t plane[FILT_CLASSES][FILT_PLANE][2];
+	// per class and entry two 16-bit values in one word (one ds_read_b32 per cell): low half the stack, counted when
+	// favourable; high half the entry into a loop through this diagonal step, minus the gap price
+	uint32_t plane[FILT_CLASSES][FILT_PLANE];
 	float tk[FILT_CLASSES];                     // min_tm + 273.15
 	float theta0[FILT_CLASSES];                 // threshold without the strand-concentration term, kcal/mol (margin included)
 	int32_t enabled[FILT_CLASSES];              // 0: windows of this class are never rejected
@@ -79,13 +81,16 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 	static_assert(FILT_ENTRIES <= FILT_PLANE, "table size");
 	constexpr int THREADS = 256;
 	constexpr int WMAX = LMAX + 2 * FLANK;
-	__shared__ int32_t s_tab[FILT_CLASSES * 2 * FILT_PLANE];
+	__shared__ uint32_t s_tab[FILT_CLASSES * FILT_PLANE];
+	typedef short s2 __attribute__((ext_vector_type(2))); // (X, M2) of a cell, or (stack, loop entry) of a table entry: one register
 
 	const int tid = threadIdx.x;
-	for (int i = tid; i < FILT_CLASSES * 2 * FILT_PLANE; i += THREADS) s_tab[i] = (&a.tab->plane[0][0][0])[i];
-	static_assert(sizeof(a.tab->plane) == sizeof(int32_t) * FILT_CLASSES * 2 * FILT_PLANE, "table size");
+	for (int i = tid; i < FILT_CLASSES * FILT_PLANE; i += THREADS) s_tab[i] = (&a.tab->plane[0][0])[i];
+	static_assert(sizeof(a.tab->plane) == sizeof(uint32_t) * FILT_CLASSES * FILT_PLANE, "table size");
 	__syncthreads();
 
+	__shared__ uint32_t s_wcount[THREADS / 64], s_wbase;
+	uint32_t n_rej = 0; // windows this wavefront rejected (wave-uniform)
 	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
 	uint32_t *surv = a.survivors ? a.survivors + (a.index_base_dev ? *a.index_base_dev : 0u) : nullptr;
 	uint32_t n_items = a.n_items;
@@ -164,94 +169,94 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 			if (DEGEN && b < 0) return FILT_ANY; // (the complement of an IUPAC code is an IUPAC code)
 			return minus ? 3 - b : b;
 		};
-		// per-row part of the table address, 8 * (7 * q' + q), two rows per register: q' = base of the row above (none above
-		// row 1), rows behind the oligo are "none" as well (their entries add nothing and open nothing)
-		uint32_t Rpk[(LMAX + 1) / 2];
+		// per-row part of the table address, 4 * (7 * q' + q) (one byte, four rows per register): q' = base of the row above
+		// (none above row 1), rows behind the oligo are "none" as well (their entries add nothing and open nothing)
+		uint32_t Rpk[(LMAX + 3) / 4];
 		{
 			uint32_t qprev = bGAP;
 #pragma unroll
 			for (int w = 0; w < (LMAX + 3) / 4; w++) {
-#ifdef TNT_EXP_UNIFORM_SLOT
-				const uint32_t q4w = a.olig_q4[uint32_t(__builtin_amdgcn_readfirstlane(int(slot.oligo))) * (MAX_OLIGO / 4) + w]; // timing experiment only
-#else
 				const uint32_t q4w = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + w] : 0u;
-#endif
+				Rpk[w] = 0;
 #pragma unroll
 				for (int b = 0; b < 4; b++) {
 					const int i = w * 4 + b; // row i + 1
 					if (i >= LMAX) continue;
 					uint32_t q = (q4w >> (b * 8 + 2)) & 7u;
 					if (i >= L) q = bGAP;
-					const uint32_t r = 8u * (7u * qprev + q);
-					if ((i & 1) == 0) Rpk[i >> 1] = r;
-					else Rpk[i >> 1] |= r << 16;
+					Rpk[w] |= (4u * (7u * qprev + q)) << (8 * b);
 					qprev = q;
 				}
 			}
 		}
+		static_assert(4 * (NBP - 1) < 256, "row constants are bytes");
 		const int cls = filter_class(slot.thresh);
-		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * (2 * FILT_PLANE * 4);
-		typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * (FILT_PLANE * 4);
+		typedef __attribute__((address_space(3))) const s2 lds_cs2;
 
-		int X[LMAX], M2[LMAX];
-#pragma unroll
-		for (int i = 0; i < LMAX; i++) X[i] = 0, M2[i] = FILT_NEG;
-		int best = 0;
 		int Wwave = W;
+#ifdef TNT_EXP_FILT_NOSWEEP
+		Wwave = 0; // timing experiment: everything but the sweep
+#endif
 		for (int o = 32; o > 0; o >>= 1) {
 			const int other = __shfl_xor(Wwave, o);
 			Wwave = other > Wwave ? other : Wwave;
 		}
-		// The table values of a column are fetched one column ahead (every row's read for column j + 1 is issued right after
-		// that row of column j is done): the LDS latency of a read is covered by a whole column of arithmetic.
-		auto row_addr = [&](int i) __attribute__((always_inline)) { return int((Rpk[(i - 1) >> 1] >> (((i - 1) & 1) * 16)) & 0xFFFFu); };
-		int t = W >= 1 ? column_base(1) : 4; // target base of the current column
-		int colbase = tab_base + (4 * FILT_X + t) * (NBP * 8); // no column before the first
-		// (instances of more than 32 rows do not have the registers for it: they read each value where it is used)
-		constexpr bool AHEAD = LMAX <= 32;
-		unsigned long long e[AHEAD ? LMAX : 1];
-		if (AHEAD) {
+		// The sweep, two columns per trip: the cells of a column live in one register each, (X, M2) as two 16-bit halves,
+		// and the two columns of a trip write alternate register sets (no copies at the back edge).  Per cell: one
+		// ds_read_b32 and four packed instructions --
+		//   a  = entry + (dX, dX)            v_pk_add_i16, saturating    (dX + stack, dX + loop entry)
+		//   m  = max(up, old)                v_pk_max_i16                high half: max(M2 above, M2 to the left)
+		//   n  = max(a, (m.hi, m.hi))        v_pk_max_i16                (X, M2) but for the diagonal's M2 ...
+		//   n  = max(n, diag)                v_pk_max_i16                ... which this adds (X >= dX anyway: stacks are >= 0)
+		// The maximum of X over the window needs no instruction per cell: X never decreases along a diagonal (the stack
+		// term is >= 0, also through the padding rows and columns), so it is reached in the last row or the last column.
+		const s2 EDGE = {0, short(FILT_NEG)}; // a cell outside the matrix: X = 0, M2 = none
+		s2 PA[LMAX], PB[LMAX];
 #pragma unroll
-			for (int i = 1; i <= LMAX; i++) e[AHEAD ? i - 1 : 0] = *(lds_cu64 *)(uintptr_t(uint32_t(colbase + row_addr(i))));
-		}
-#pragma unroll 1
-		for (int j = 1; j <= Wwave; j++) {
-			const int tn = j < W ? column_base(j + 1) : 4; // column j + 1
-			const int nextbase = tab_base + (t * FILT_X + tn) * (NBP * 8);
+		for (int i = 0; i < LMAX; i++) PA[i] = EDGE;
+		s2 bestpk = EDGE;
+		auto row_addr = [&](int i) __attribute__((always_inline)) { return int((Rpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 0xFFu); };
+		auto column = [&](const s2 *Pin, s2 *Pout, const int colbase) __attribute__((always_inline)) {
+			s2 e[LMAX];
 #pragma unroll
-			for (int w = 0; w < (LMAX + 1) / 2; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
-			int dX = 0, dM = FILT_NEG; // the cell above row 1 in the previous column
-			int upM = FILT_NEG;        // M2 of the row above in this column
-			int colmax = 0;
+			for (int i = 1; i <= LMAX; i++) e[i - 1] = *(lds_cs2 *)(uintptr_t(uint32_t(colbase + row_addr(i))));
+			s2 D = EDGE, U = EDGE; // (1, j) sees the edge above it and diagonally
 #pragma unroll
 			for (int i = 1; i <= LMAX; i++) {
-				const unsigned long long ev = AHEAD ? e[AHEAD ? i - 1 : 0] : *(lds_cu64 *)(uintptr_t(uint32_t(colbase + row_addr(i))));
-				const int fp = int(uint32_t(ev)), gp = int(uint32_t(ev >> 32));
-				if (AHEAD) e[AHEAD ? i - 1 : 0] = *(lds_cu64 *)(uintptr_t(uint32_t(nextbase + row_addr(i))));
-				const int oldX = X[i - 1], oldM = M2[i - 1]; // (i, j-1)
-				const int mUL = upM > oldM ? upM : oldM;
-				const int a1 = dX + fp;
-				const int a2 = dX + gp;
-				const int nX = a1 > mUL ? a1 : mUL;
-				int nM = dM > mUL ? dM : mUL;
-				nM = nM > a2 ? nM : a2;
-				colmax = colmax > nX ? colmax : nX;
-				dX = oldX, dM = oldM;
-				X[i - 1] = nX, M2[i - 1] = nM;
-				upM = nM;
+				const s2 O = Pin[i - 1]; // (i, j-1)
+				const s2 sum = __builtin_elementwise_add_sat(e[i - 1], (s2){D.x, D.x});
+				const s2 m = __builtin_elementwise_max(U, O);
+				s2 n = __builtin_elementwise_max(sum, (s2){m.y, m.y});
+				n = __builtin_elementwise_max(n, D);
+				Pout[i - 1] = n;
+				D = O, U = n;
 			}
-			best = best > colmax ? best : colmax;
-			t = tn;
-			colbase = nextbase;
+			bestpk = __builtin_elementwise_max(bestpk, U); // the last row of this column
+		};
+		int t = W >= 1 ? column_base(1) : FILT_NONE; // target base of the current column
+		int tp = FILT_NONE;                          // no column before the first
+#pragma unroll 1
+		for (int j = 1; j <= Wwave; j += 2) {
+#pragma unroll
+			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
+			const int t1 = j < W ? column_base(j + 1) : FILT_NONE;     // column j + 1 (none: behind the window, or padding of an odd width)
+			const int t2 = j + 1 < W ? column_base(j + 2) : FILT_NONE; // column j + 2
+			column(PA, PB, tab_base + (tp * FILT_X + t) * (NBP * 4));
+			column(PB, PA, tab_base + (t * FILT_X + t1) * (NBP * 4));
+			tp = t1, t = t2;
 		}
+#pragma unroll
+		for (int i = 0; i < LMAX; i++) bestpk = __builtin_elementwise_max(bestpk, PA[i]); // the last column
+		int best = int(bestpk.x);
 
-		// threshold of this item: theta0 of its class - Tk * R * ln(Ct), in 1e-4 kcal/mol, rounded down
+		// threshold of this item: theta0 of its class - Tk * R * ln(Ct), in table units, rounded down; a saturated bound passes
 		bool pass = true;
 		int theta = INT32_MIN;
 		if (a.tab->enabled[cls]) {
 			const float th = a.tab->theta0[cls] - a.tab->tk[cls] * (1.9872e-3f * slot.log_ct);
-			theta = int(floorf(th * 10000.0f)) - 1;
-			pass = best >= theta;
+			theta = int(floorf(th * float(FILT_UNITS))) - 1;
+			pass = best >= theta || best >= FILT_SAT;
 		}
 		if (DEGEN && unfilterable) pass = true, best = INT32_MAX, theta = INT32_MIN;
 		if (a.score_out && active) a.score_out[2 * idx] = best, a.score_out[2 * idx + 1] = theta;
@@ -261,18 +266,28 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 		}
 		if (active && !pass) a.result[idx] = -1; // bind_oligo.cpp:600-606: Tm below the minimum
 		if (surv) {
+			// survivors are compacted with one atomic per workgroup and trip (a hot counter sustains ~88 atomics per
+			// microsecond: one per wavefront, as the statistics counter once had, cost more than the sweep)
 			const unsigned long long m = __builtin_amdgcn_ballot_w64(active && pass);
-			const int lane = tid & 63;
-			if (a.n_rejected) {
-				const unsigned long long r = __builtin_amdgcn_ballot_w64(active && !pass);
-				if (lane == 0 && r) atomicAdd(a.n_rejected, uint32_t(__builtin_popcountll(r)));
+			const int lane = tid & 63, wv = tid >> 6;
+			n_rej += uint32_t(__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && !pass)));
+			if (lane == 0) s_wcount[wv] = uint32_t(__builtin_popcountll(m));
+			__syncthreads();
+			if (tid == 0) {
+				uint32_t run = 0;
+				for (int w = 0; w < THREADS / 64; w++) {
+					const uint32_t c = s_wcount[w];
+					s_wcount[w] = run;
+					run += c;
+				}
+				s_wbase = run ? atomicAdd(a.n_survivors, run) : 0u;
 			}
-			uint32_t wbase = 0;
-			if (lane == 0 && m) wbase = atomicAdd(a.n_survivors, uint32_t(__builtin_popcountll(m)));
-			wbase = __shfl(wbase, 0);
-			if (active && pass) surv[wbase + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
+			__syncthreads();
+			if (active && pass) surv[s_wbase + s_wcount[wv] + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
+			__syncthreads(); // the next trip reuses the counters
 		}
 	}
+	if (a.n_rejected && (tid & 63) == 0 && n_rej) atomicAdd(a.n_rejected, n_rej); // statistics: once per wavefront
 }
 
 // host-side launchers, defined in tnt_bind_inst.hip next to the bind kernel instances of the same lengths

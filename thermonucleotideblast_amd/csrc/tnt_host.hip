@@ -257,10 +257,15 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 				ok = ok && T.H[g1 * NBP + c] == 0.0f && T.S[g1 * NBP + c] == 0.0f && T.H[g2 * NBP + c] == 0.0f && T.S[g2 * NBP + c] == 0.0f;
 			}
 	const double min_tm[FILT_CLASSES] = {double(opt.min_primer_tm), double(opt.min_probe_tm)};
+	// table units: FILT_UNITS per kcal/mol, rounded up, 16 bits ("not possible" = FILT_NEG: a price of 16 kcal/mol)
+	auto units = [](double kcal) { return int(std::min(double(FILT_SAT), std::max(double(FILT_NEG), std::ceil(kcal * double(FILT_UNITS))))); };
+	auto pack = [](int stack, int entry) { return uint32_t(uint16_t(int16_t(stack))) | (uint32_t(uint16_t(int16_t(entry))) << 16); };
 	for (int cls = 0; cls < FILT_CLASSES; cls++) {
-		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i][0] = 0, F.plane[cls][i][1] = FILT_NEG;
+		int v[FILT_PLANE][2];
+		for (int i = 0; i < FILT_PLANE; i++) v[i][0] = 0, v[i][1] = FILT_NEG;
 		const double Tk = min_tm[cls] + 273.15;
 		F.tk[cls] = float(Tk);
+		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i] = pack(0, FILT_NEG);
 		if (!ok || !(min_tm[cls] > 0.0) || !(min_tm[cls] < 150.0)) continue;
 		const double sc = double(T.salt) * double(T.log_na); // per counted column (nuc_cruc.cpp:2270: 0.5 per base)
 		auto phi = [&](int prev, int cur) { return -(double(T.H[prev * NBP + cur]) - Tk * (double(T.S[prev * NBP + cur]) + sc)); };
@@ -289,9 +294,9 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 						const int at = (xp * FILT_X + x) * NBP + qp * NB + q;
 						const double f = phi(first, second);
 						const double fpos = (wc[first] || wc[second]) ? std::max(f, 0.0) : 0.0; // a stack inside a loop is never credited
-						F.plane[cls][at][0] = int32_t(std::ceil(fpos * 10000.0));
+						v[at][0] = units(fpos);
 						if (wc[second]) // a loop / bulge is closed by a Watson-Crick column
-							F.plane[cls][at][1] = int32_t(std::ceil((std::max(std::max(f, 0.0), u1[second]) - gap_price) * 10000.0));
+							v[at][1] = units(std::max(std::max(f, 0.0), u1[second]) - gap_price);
 					}
 		// columns that hold an IUPAC code (FILT_ANY): resolve_degenerate turns the code into one of A C G T per aligned pair
 		// (nuc_cruc.cpp:14-201), so the maximum over the four bases bounds whatever it picks -- in either role of the column
@@ -299,18 +304,19 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 			auto at = [&](int xp, int x) { return (xp * FILT_X + x) * NBP + qq; };
 			for (int k = 0; k < 2; k++) {
 				for (int xp = 0; xp < 4; xp++) { // (x', ANY)
-					int32_t m = F.plane[cls][at(xp, 0)][k];
-					for (int x = 1; x < 4; x++) m = std::max(m, F.plane[cls][at(xp, x)][k]);
-					F.plane[cls][at(xp, FILT_ANY)][k] = m;
+					int m = v[at(xp, 0)][k];
+					for (int x = 1; x < 4; x++) m = std::max(m, v[at(xp, x)][k]);
+					v[at(xp, FILT_ANY)][k] = m;
 				}
 				for (int x = 0; x < FILT_X; x++) { // (ANY, x), x = ANY included (its column of the table was filled above)
 					if (x == FILT_NONE) continue;
-					int32_t m = F.plane[cls][at(0, x)][k];
-					for (int xp = 1; xp < 4; xp++) m = std::max(m, F.plane[cls][at(xp, x)][k]);
-					F.plane[cls][at(FILT_ANY, x)][k] = m;
+					int m = v[at(0, x)][k];
+					for (int xp = 1; xp < 4; xp++) m = std::max(m, v[at(xp, x)][k]);
+					v[at(FILT_ANY, x)][k] = m;
 				}
 			}
 		}
+		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i] = pack(v[i][0], v[i][1]);
 		const double g_init = double(T.init_H) - Tk * double(T.init_S);
 		const double g_at = double(T.at_H) - Tk * double(T.at_S);
 		F.theta0[cls] = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02); // 0.02 kcal/mol: float32 rounding of the reference's sums, generously
