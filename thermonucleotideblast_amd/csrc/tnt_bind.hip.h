@@ -67,17 +67,44 @@ __device__ __forceinline__ bool is_virtual(int b) { return b == bE || b == bGAP;
 __device__ __forceinline__ bool non_virtual_pair(int p) { return (p % NB < bE) && (p / NB < bE); }
 __device__ __forceinline__ bool pair_has_gap(int p) { return (p % NB == bGAP) || (p / NB >= bGAP); }
 
-// is_complemetary_base, nuc_cruc_anchor.cpp:8-139 (bit0 A, bit1 T, bit2 G, bit3 C); BASE codes 0..17
-__device__ const uint8_t c_query_mask[18] = {1, 8, 4, 2, 15, 0, 0, 1 | 8, 4 | 1, 4 | 8, 4 | 8 | 1, 1 | 2, 2 | 8, 1 | 8 | 2, 4 | 2, 4 | 1 | 2, 4 | 2 | 8, 15};
+// is_complemetary_base, nuc_cruc_anchor.cpp:8-139 (bit0 A, bit1 T, bit2 G, bit3 C); BASE codes 0..17.  The masks are
+// 4-bit fields of compile-time words (the serial tail asks per alignment column: no memory behind it).
+constexpr unsigned long long pack_nibbles(const int (&v)[18], int from)
+{
+	unsigned long long w = 0;
+	for (int i = 0; i < 16 && from + i < 18; i++) w |= (unsigned long long)(v[from + i] & 15) << (4 * i);
+	return w;
+}
+constexpr int QUERY_MASK[18] = {1, 8, 4, 2, 15, 0, 0, 1 | 8, 4 | 1, 4 | 8, 4 | 8 | 1, 1 | 2, 2 | 8, 1 | 8 | 2, 4 | 2, 4 | 1 | 2, 4 | 2 | 8, 15};
 // the target base is mapped to its complement first
-__device__ const uint8_t c_target_mask[18] = {2, 4, 8, 1, 15, 0, 0, 2 | 4, 8 | 2, 8 | 4, 8 | 4 | 2, 2 | 1, 1 | 4, 2 | 4 | 1, 8 | 1, 8 | 2 | 1, 8 | 1 | 4, 15};
-__device__ __forceinline__ bool is_complementary(int q, int t) { return (c_query_mask[q] & c_target_mask[t]) != 0; }
+constexpr int TARGET_MASK[18] = {2, 4, 8, 1, 15, 0, 0, 2 | 4, 8 | 2, 8 | 4, 8 | 4 | 2, 2 | 1, 1 | 4, 2 | 4 | 1, 8 | 1, 8 | 2 | 1, 8 | 1 | 4, 15};
+constexpr unsigned long long QM_LO = pack_nibbles(QUERY_MASK, 0), QM_HI = pack_nibbles(QUERY_MASK, 16);
+constexpr unsigned long long TM_LO = pack_nibbles(TARGET_MASK, 0), TM_HI = pack_nibbles(TARGET_MASK, 16);
+__device__ __forceinline__ uint32_t nibble(unsigned long long lo, unsigned long long hi, int i)
+{
+	return uint32_t((i < 16 ? lo : hi) >> ((i & 15) * 4)) & 15u;
+}
+__device__ __forceinline__ bool is_complementary(int q, int t) { return (nibble(QM_LO, QM_HI, q) & nibble(TM_LO, TM_HI, t)) != 0; }
+// the letter NucCruc prints for a BASE code (nuc_cruc_output.cpp): "ACGTI$-MRSVWYHKDBN"
+__device__ __forceinline__ char base_letter(int b)
+{
+	constexpr unsigned long long L0 = 0x4D2D244954474341ull;         // "ACGTI$-M", first letter in the low byte
+	constexpr unsigned long long L1 = 0x444B485957565352ull;         // "RSVWYHKD"
+	constexpr unsigned long long L2 = 0x4E42ull;                     // "BN"
+	const unsigned long long w = b < 8 ? L0 : (b < 16 ? L1 : L2);
+	return char(uint32_t(w >> ((b & 7) * 8)) & 255u);
+}
 
 // seq.h code (0..15) -> BASE code of the base itself (bind_oligo.cpp:1227-1276) ...
 __device__ __forceinline__ int db_same(int c) { return c < 5 ? c : c + 2; }
 // ... and of its complement (bind_oligo.cpp:524-573): A C G T I M R S V W Y H K D B N -> T G C A I K Y S B W R D M H V N
-__device__ const uint8_t c_db_comp[16] = {bT, bG, bC, bA, bI, bK, bY, bS, bB, bW, bR, bD, bM, bH, bV, bN};
-__device__ __forceinline__ int db_comp(int c) { return c_db_comp[c]; }
+constexpr unsigned long long pack_bytes(int a, int b, int c, int d, int e, int f, int g, int h)
+{
+	return (unsigned long long)a | ((unsigned long long)b << 8) | ((unsigned long long)c << 16) | ((unsigned long long)d << 24) |
+	       ((unsigned long long)e << 32) | ((unsigned long long)f << 40) | ((unsigned long long)g << 48) | ((unsigned long long)h << 56);
+}
+constexpr unsigned long long DB_COMP_LO = pack_bytes(bT, bG, bC, bA, bI, bK, bY, bS), DB_COMP_HI = pack_bytes(bB, bW, bR, bD, bM, bH, bV, bN);
+__device__ __forceinline__ int db_comp(int c) { return int(uint32_t((c < 8 ? DB_COMP_LO : DB_COMP_HI) >> ((c & 7) * 8)) & 255u); }
 
 // scoring scalars and the short ends of the loop / bulge entropy tables, staged in LDS for the serial tail
 struct TailConst {
@@ -1205,16 +1232,15 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 		}
 
 		if (text) { // operator<<(ostream&, NucCruc), nuc_cruc_output.cpp:74-205
-			const char *bm = "ACGTI$-MRSVWYHKDBN";
 			int prefix = bi.fm_q < (W - 1 - bi.fm_t) ? bi.fm_q : (W - 1 - bi.fm_t);
 			if (prefix < 0) prefix = 0;
 			int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
 			if (suffix < 0) suffix = 0;
 			int o = 0;
 			text[o++] = '5', text[o++] = '\'', text[o++] = ' ';
-			for (int i = 0; i < prefix; i++) text[o++] = bm[QUERY(bi.fm_q - prefix + i)];
-			for (int k = bi.k0; k < bi.k1; k++) text[o++] = bm[col_q(best[k * BIND_THREADS])];
-			for (int i = 0; i < suffix; i++) text[o++] = bm[QUERY(bi.lm_q + 1 + i)];
+			for (int i = 0; i < prefix; i++) text[o++] = base_letter(QUERY(bi.fm_q - prefix + i));
+			for (int k = bi.k0; k < bi.k1; k++) text[o++] = base_letter(col_q(best[k * BIND_THREADS]));
+			for (int i = 0; i < suffix; i++) text[o++] = base_letter(QUERY(bi.lm_q + 1 + i));
 			text[o++] = ' ', text[o++] = '3', text[o++] = '\'', text[o++] = '\n';
 			text[o++] = ' ', text[o++] = ' ', text[o++] = ' ';
 			for (int i = 0; i < prefix; i++)
@@ -1227,9 +1253,9 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 				text[o++] = is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ';
 			text[o++] = '\n';
 			text[o++] = '3', text[o++] = '\'', text[o++] = ' ';
-			for (int i = prefix; i > 0; i--) text[o++] = bm[TARGET(bi.fm_t + i)];
-			for (int k = bi.k0; k < bi.k1; k++) text[o++] = bm[col_t(best[k * BIND_THREADS])];
-			for (int i = 1; i <= suffix; i++) text[o++] = bm[TARGET(bi.lm_t - i)];
+			for (int i = prefix; i > 0; i--) text[o++] = base_letter(TARGET(bi.fm_t + i));
+			for (int k = bi.k0; k < bi.k1; k++) text[o++] = base_letter(col_t(best[k * BIND_THREADS]));
+			for (int i = 1; i <= suffix; i++) text[o++] = base_letter(TARGET(bi.lm_t - i));
 			text[o++] = ' ', text[o++] = '5', text[o++] = '\'';
 			text[o] = 0;
 			if (rec) rec->text_len = o;
