@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""profiles/bind_pmc.json (what bench.py reads for roofline.traffic / valu_issue) from a PMC summary of
+scripts/pmc_summarize.py:   python scripts/make_bind_pmc.py profiles/r02n_pmc_config2_1M_serial.json"""
+import json
+import os
+import sys
+
+src = sys.argv[1]
+d = json.load(open(src))["kernels"]
+stage = ["bucket_kernel", "filter_kernel<L>", "bind_kernel<L>"]
+fetch = sum(float(d[k]["FETCH_SIZE"]) for k in stage)   # KB per search (= per step of the full-size config)
+write = sum(float(d[k]["WRITE_SIZE"]) for k in stage)
+old = {}
+dst = os.path.join(os.path.dirname(os.path.abspath(src)), "bind_pmc.json")
+if os.path.exists(dst):
+    old = json.load(open(dst))
+out = {
+    "source": "%s (rocprofv3 --pmc, separate passes, scripts/pmc_collect.sh 2 1000000, bind launches serialised on one stream)" % src,
+    "kernel": "bind stage of one step (config 2, 1 000 000 x 1 kb targets): bucket_kernel + filter_kernel<L> + bind_kernel<L> on the survivors",
+    "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+    "per_kernel_KB": {k: {"FETCH_SIZE": float(v["FETCH_SIZE"]), "WRITE_SIZE": float(v["WRITE_SIZE"])}
+                      for k, v in d.items() if k in stage + ["seed_kernel", "pair_kernel"]},
+    "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE taken as is",
+    "hbm_bytes_per_step": int((2.0 * fetch + write) * 1024),
+    "SQ_INSTS_VALU_per_step": sum(float(d[k]["SQ_INSTS_VALU"]) for k in stage),
+    "history": (old.get("history") or ([{"hbm_bytes_per_step": old["round1"]["hbm_bytes_per_step"], "SQ_INSTS_VALU_per_step": old["round1"]["SQ_INSTS_VALU_per_step"], "state": "round 1 (r01k)"}] if "round1" in old else []))
+               + ([{"hbm_bytes_per_step": old["hbm_bytes_per_step"], "SQ_INSTS_VALU_per_step": old["SQ_INSTS_VALU_per_step"], "state": old.get("source", "")[:40]}] if "hbm_bytes_per_step" in old and old.get("source") != None and src not in old.get("source", "") else []),
+}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("hbm_bytes_per_step", "SQ_INSTS_VALU_per_step")}))

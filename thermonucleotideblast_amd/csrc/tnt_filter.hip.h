@@ -76,6 +76,14 @@ __device__ __forceinline__ int filter_class(int thresh_index) { return thresh_in
 // D B N) is resolved per aligned pair to one of A C G T (resolve_degenerate), so its column takes, entry by entry, the
 // maximum over the four bases (the ANY rows of the table): still an upper bound.  Inosine in the target and codes the
 // window loader skips (gap, unknown: bind_oligo.cpp, Q6) are not modelled: such a window passes unfiltered.
+// wave-synchronous LDS hand-off inside one wavefront
+__device__ __forceinline__ void filt_wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_kernel(FilterArgs2 a)
 {
 	static_assert(FILT_ENTRIES <= FILT_PLANE, "table size");
@@ -90,7 +98,9 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 	__syncthreads();
 
 	__shared__ uint32_t s_wcount[THREADS / 64], s_wbase;
-	uint32_t n_rej = 0; // windows this wavefront rejected (wave-uniform)
+	__shared__ uint32_t s_keep[THREADS / 64][128]; // survivors of a wavefront on their way to the list
+	uint32_t n_rej = 0, n_keep = 0; // windows this wavefront rejected / holds in s_keep (wave-uniform)
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
 	uint32_t *surv = a.survivors ? a.survivors + (a.index_base_dev ? *a.index_base_dev : 0u) : nullptr;
 	uint32_t n_items = a.n_items;
@@ -266,26 +276,42 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 		}
 		if (active && !pass) a.result[idx] = -1; // bind_oligo.cpp:600-606: Tm below the minimum
 		if (surv) {
-			// survivors are compacted with one atomic per workgroup and trip (a hot counter sustains ~88 atomics per
-			// microsecond: one per wavefront, as the statistics counter once had, cost more than the sweep)
+			// Survivors collect in a per-wavefront LDS buffer and leave for the list 64 at a time: one global atomic per 64
+			// survivors (a hot counter sustains only ~88 atomics per microsecond -- one per wavefront and trip, as a first
+			// version had it, cost more than the sweep -- and nothing waits for a round trip every trip).
 			const unsigned long long m = __builtin_amdgcn_ballot_w64(active && pass);
-			const int lane = tid & 63, wv = tid >> 6;
 			n_rej += uint32_t(__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && !pass)));
-			if (lane == 0) s_wcount[wv] = uint32_t(__builtin_popcountll(m));
-			__syncthreads();
-			if (tid == 0) {
-				uint32_t run = 0;
-				for (int w = 0; w < THREADS / 64; w++) {
-					const uint32_t c = s_wcount[w];
-					s_wcount[w] = run;
-					run += c;
-				}
-				s_wbase = run ? atomicAdd(a.n_survivors, run) : 0u;
+			if (active && pass) s_keep[wave][n_keep + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
+			n_keep += uint32_t(__builtin_popcountll(m));
+			if (n_keep >= 64u) {
+				filt_wave_sync();
+				uint32_t at = 0;
+				if (lane == 0) at = atomicAdd(a.n_survivors, 64u);
+				at = uint32_t(__builtin_amdgcn_readfirstlane(int(at)));
+				surv[at + lane] = s_keep[wave][lane];
+				const uint32_t rest = n_keep - 64u; // < 64
+				const uint32_t moved = uint32_t(lane) < rest ? s_keep[wave][64 + lane] : 0u;
+				filt_wave_sync();
+				if (uint32_t(lane) < rest) s_keep[wave][lane] = moved;
+				n_keep = rest;
 			}
-			__syncthreads();
-			if (active && pass) surv[s_wbase + s_wcount[wv] + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
-			__syncthreads(); // the next trip reuses the counters
+			filt_wave_sync();
 		}
+	}
+	if (surv) { // what is left in the buffers: one atomic per workgroup
+		if (lane == 0) s_wcount[wave] = n_keep;
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t run = 0;
+			for (int w = 0; w < THREADS / 64; w++) {
+				const uint32_t c = s_wcount[w];
+				s_wcount[w] = run;
+				run += c;
+			}
+			s_wbase = run ? atomicAdd(a.n_survivors, run) : 0u;
+		}
+		__syncthreads();
+		if (uint32_t(lane) < n_keep) surv[s_wbase + s_wcount[wave] + lane] = s_keep[wave][lane];
 	}
 	if (a.n_rejected && (tid & 63) == 0 && n_rej) atomicAdd(a.n_rejected, n_rej); // statistics: once per wavefront
 }
