@@ -791,10 +791,18 @@ def test_shared_oligos_are_bound_once(Engine, oracle, monkeypatch):
                 combos.append(synth.ExpandedAssay(len(combos), len(combos), f.forward, r.reverse, p.probe))
     want = tc.sorted_hit_keys(oracle.search(wl.options, combos, wl.codes, wl.offsets))
     assert len(want) > 10
+    # (behind the pre-filter the marking is off by default -- a repeated window costs one cheap sweep there --: ask for it)
+    monkeypatch.setenv("TNT_MI355X_DEDUPE", "1")
     e = Engine(wl.options, combos)
     db = e.pack(wl.codes, wl.offsets)
     assert tc.sorted_hit_keys(e.search(db)) == want
     shared = e.timing().n_binds
+    db.close()
+    e.close()
+    monkeypatch.delenv("TNT_MI355X_DEDUPE")
+    e = Engine(wl.options, combos)  # the default
+    db = e.pack(wl.codes, wl.offsets)
+    assert tc.sorted_hit_keys(e.search(db)) == want
     db.close()
     e.close()
     monkeypatch.setenv("TNT_MI355X_NO_DEDUPE", "1")

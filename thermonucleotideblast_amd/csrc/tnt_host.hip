@@ -1098,6 +1098,11 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 			}
 			last[canon] = uint32_t(si);
 		}
+		// Marking the repeats costs the seed kernel a walk along the class per phase-A seed; it pays when a bind is the full
+		// kernel.  Behind the pre-filter a repeated window costs one cheap sweep, and the marking loses (config 4, 400 k
+		// targets: seed 336 -> 261 ms, bind stage 216 -> 247 ms without it): it is used when the filter is off (dangling-end
+		// options, thresholds at or below 0 C, --dinkelbach) or asked for.
+		if (c->filter_on && !getenv("TNT_MI355X_DEDUPE")) c->dedupe = false;
 		if (getenv("TNT_MI355X_NO_DEDUPE")) c->dedupe = false; // ablation
 		// The reference memoises every evaluated (oligo string, window) per target and hands the memo out again whatever
 		// strand concentration or threshold set asks for it (BindCacheKey holds neither, tntblast.h:247-270; on a hit the
