@@ -28,16 +28,19 @@
 extern "C" {
 #endif
 
-#define TNT_ABI_VERSION 2
+#define TNT_ABI_VERSION 3
 
-/* Longest oligo the gfx950 bind kernel accepts: one wavefront lane per query
- * row (reference cap is MAX_SEQUENCE_LENGTH 1024, nuc_cruc.h:80).           */
-#define TNT_MAX_OLIGO 64
+/* Longest oligo the gfx950 bind kernels accept (reference cap: MAX_SEQUENCE_LENGTH
+ * 1024, nuc_cruc.h:80).  Up to 64 bases the rows of the alignment live in
+ * registers; 65..128 run through an instance that keeps them in scratch memory. */
+#define TNT_MAX_OLIGO 128
 /* NUM_FLANK_BASE, tntblast.h:76 */
 #define TNT_FLANK 4
 /* window = oligo + 2*flank (bind_oligo.cpp:139-142) */
 #define TNT_MAX_WINDOW (TNT_MAX_OLIGO + 2 * TNT_FLANK)
-/* alignment text: 3 lines of "5' " + <=(L+W) columns + " 3'" (nuc_cruc_output.cpp:8-213) */
+/* alignment text: 3 lines of "5' " + <=(L+W) columns + " 3'" (nuc_cruc_output.cpp:8-213).  Sized for
+ * every alignment of a 64-mer; an alignment of a longer oligo whose text does not fit (more than ~14 gap
+ * columns at 128 bases) fails the call with TNT_E_LIMIT instead of being cut. */
 #define TNT_ALIGN_TEXT 448
 
 /* error codes */

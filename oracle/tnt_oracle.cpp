@@ -1682,7 +1682,7 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		auto phi = [&](int prev, int cur) { return -(double(P.H[prev * NBP + cur]) - Tk * (double(P.S[prev * NBP + cur]) + sc)); };
 		double pb1 = -Tk * double(P.bulge_S[1]), pb2 = 1.0e30, pl3 = 1.0e30;
 		// bulges up to the longest window, loops up to 2 x 64 mismatches + the window (entry 512 of both tables is 0 in the
-		// reference, nuc_cruc_santa_lucia.cpp:670,720; no 64-mer reaches it)
+		// reference, nuc_cruc_santa_lucia.cpp:670,720; no 128-mer reaches it)
 		for (int z = 2; z <= TNT_MAX_WINDOW; z++) pb2 = std::min(pb2, -Tk * double(P.bulge_S[z]));
 		for (int z = 3; z <= 2 * TNT_MAX_OLIGO + TNT_MAX_WINDOW; z++) pl3 = std::min(pl3, -Tk * double(P.loop_S[z]));
 		pl3 += -Tk * double(P.asym_S);

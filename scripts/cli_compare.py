@@ -10,6 +10,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import longwl  # noqa: E402
 from thermonucleotideblast_amd import synth  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "tntblast")
@@ -52,6 +54,10 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     # (uniquify_results).  One 620-kb record at the default threshold (500 000); one 64-kb record cut into six.
     ("fragment_default", 2, 660, 12, 21, ["-e", "40"]),
     ("fragment_small", 3, 104, 12, 22, ["-e", "40", "-E", "40", "--max-target-len", "12000", "-l", "500"]),
+    # oligos of 65..128 bases (tests/longwl.py; the "config" names its kind): hybridisation probes, padlock arms, a long primer
+    ("long_probes", "probe", 60, 6, 31, ["-E", "45"]),
+    ("long_padlock_arms", "padlock", 60, 6, 33, ["-A", "PADLOCK", "-E", "45"]),
+    ("long_primer", "pcr", 60, 6, 34, ["-e", "45"]),
 ]
 
 LONG_RECORDS = {"long_target": 150, "fragment_default": 620, "fragment_small": 64}
@@ -68,7 +74,7 @@ def closing_lines(stdout):
 
 
 def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False, name=None):
-    wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
+    wl = longwl.make(cfg, seed, n_targets=nt) if isinstance(cfg, str) else synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
     offsets = wl.offsets
     if long_target or name in LONG_RECORDS:  # the first records become one
         k = LONG_RECORDS.get(name, 150)

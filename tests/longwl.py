@@ -1,0 +1,59 @@
+"""Workloads with oligos of 65..128 bases (long hybridisation probes, padlock arms, one long primer): planted sites with
+substitutions and small indels on random targets.  Used by the CPU test that pins the oracle against the reference for
+such oligos and by the GPU test that holds the HIP path against the oracle."""
+import numpy as np
+
+from thermonucleotideblast_amd import abi, synth
+
+
+def _edit(rng, s, n_sub, n_indel):
+    s = list(synth._mutate(rng, s, n_sub))
+    for _ in range(int(rng.integers(0, n_indel + 1))):
+        k = int(rng.integers(5, len(s) - 5))
+        if rng.random() < 0.5:
+            del s[k]
+        else:
+            s.insert(k, "ACGT"[int(rng.integers(0, 4))])
+    return "".join(s)
+
+
+def make(kind, seed, n_targets=60, tl=700):
+    """kind: 'probe' (hybridisation probes 65..128), 'padlock' (arms 65..100), 'pcr' (primer pairs, one primer 65..90)."""
+    rng = np.random.default_rng([4242, seed])
+    codes, offsets = synth._targets(rng, n_targets, tl)
+    opt = abi.options_default(min_primer_tm=45.0, min_probe_tm=45.0)
+    assays = []
+    for a in range(6):
+        if kind == "probe":
+            P = synth._rand_oligo(rng, 65, 128)
+            if a == 0:
+                P = synth._rand_oligo(rng, 128, 128)
+            assays.append(synth.Assay("long%d" % a, None, None, P))
+            sites = [P]
+        elif kind == "padlock":
+            opt.assay_format = abi.ASSAY_PADLOCK
+            F, R = synth._rand_oligo(rng, 65, 100), synth._rand_oligo(rng, 20, 100)
+            assays.append(synth.Assay("long%d" % a, F, R, None))
+            sites = [F + R]  # the two arms side by side (padlock_search.cpp:133-137), either strand below
+        else:
+            F, R = synth._rand_oligo(rng, 65, 90), synth._rand_oligo(rng, 18, 25)
+            if a % 2:
+                F, R = R, F
+            assays.append(synth.Assay("long%d" % a, F, R, None))
+            amp = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(20, 120))))
+            sites = [F + amp + synth.revcomp(R)]
+        for _ in range(int(rng.integers(6, 12))):
+            t = int(rng.integers(0, n_targets))
+            s = _edit(rng, sites[0], 5, 2)
+            if rng.random() < 0.5:
+                s = synth.revcomp(s)
+            if len(s) + 2 >= tl:
+                continue
+            pos = int(rng.integers(1, tl - len(s) - 1))
+            synth._put(codes, int(offsets[t]), pos, s)
+    # a few IUPAC letters
+    pos = rng.integers(0, n_targets * tl, 40)
+    codes[pos] = rng.integers(5, 16, 40).astype(np.uint8)
+    wl = synth.Workload("long-%s" % kind, opt, assays, codes, offsets)
+    wl.expanded = synth.expand_assays(assays)
+    return wl

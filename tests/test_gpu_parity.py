@@ -29,7 +29,7 @@ def _oligo_set(expanded):
 def test_native_library_is_loaded(Engine):
     from thermonucleotideblast_amd import engine
     lib = engine.load_library()
-    assert lib.tnt_abi_version() == 2
+    assert lib.tnt_abi_version() == 3
     assert any("libtnt_mi355x.so" in line for line in open("/proc/self/maps"))
 
 
@@ -270,11 +270,51 @@ def test_structure_vs_oracle(Engine, oracle):
         p = oligos[(i * 13 + 1) % len(oligos)]
         got = e.oligo_structure(o, p, 5e-7, 9e-7)
         assert tuple(tc.f32_bits(v) for v in got) == oracle.structure(opt, o, p, 5e-7, 9e-7), (o, p)
+    for o in ("A" * 65, "AT" * 64, synth._rand_oligo(rng, 100, 128)):  # the long unit-level instance
+        got = e.oligo_structure(o, oligos[3], 5e-7, 9e-7)
+        assert tuple(tc.f32_bits(v) for v in got) == oracle.structure(opt, o, oligos[3], 5e-7, 9e-7), o
     with pytest.raises(Exception):
-        e.oligo_structure("A" * 65)
+        e.oligo_structure("A" * 129)
     with pytest.raises(Exception):
         e.oligo_structure("ACGTNACGT")
     e.close()
+
+
+@pytest.mark.parametrize("kind,seed", [("probe", 1), ("probe", 2), ("padlock", 3), ("pcr", 4), ("pcr", 5)])
+def test_long_oligos_vs_oracle(Engine, oracle, kind, seed):
+    """Oligos of 65..128 bases run through the 128-row instances (rows in scratch memory, no pre-filter): binds through all
+    three routes and complete searches against the oracle (itself held against the reference on the same workloads,
+    tests/test_oracle_vs_reference.py::test_long_oligos); 129 bases are refused."""
+    import longwl
+    wl = longwl.make(kind, seed)
+    oligos = sorted({o for x in wl.expanded for o in (x.forward, x.reverse, x.probe) if o})
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    assert tc.sorted_hit_keys(e.search(db)) == want and len(want) > 10
+    sa = oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    rows = [(s[0], s[1], s[2], s[3], s[4], i % 2, 9e-7 if i % 3 else 2.5e-7) for i, s in enumerate(sa[:5000])]
+    ow = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, tc.make_reqs(rows))
+    om = {o: i for i, o in enumerate(e.oligos)}
+    reqs = tc.make_reqs((r[0], om[oligos[r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in rows)
+    assert sum(1 for w in ow if w.status == 0) > 5
+    for route in (0, 1, 2):
+        out = e.bind_batch(db, reqs, route=route)
+        bad = []
+        for i, w in enumerate(ow):
+            x, got = gu.bind_record(w), gu.bind_record(out[i])
+            if route == 0:
+                d = gu.compare_bind(x, got)
+            else:
+                d = [(k, x[k], got[k]) for k in ([0] + (ROUTED_FIELDS if x[0] == 0 else [])) if x[k] != got[k]]
+            if d:
+                bad.append((i, rows[i], d))
+        assert not bad, (route, len(bad), bad[:3])
+    db.close()
+    e.close()
+    too_long = [synth.ExpandedAssay(0, 0, None, None, "ACGT" * 32 + "A")]
+    with pytest.raises(Exception):
+        Engine(wl.options, too_long)
 
 
 def test_g6_fasta_ingest_golden(Engine):
@@ -461,22 +501,25 @@ def test_edge_cases(Engine, oracle):
     assert got == want and len(want) >= 3
     db.close()
     e.close()
-    # longest supported oligo (64) works, 65 fails loudly
+    # the longest oligos of the register-resident instances (64) and of the long ones (128) work, 129 fail loudly
     rng = np.random.default_rng(5)
-    long_o = "".join("ACGT"[i] for i in rng.integers(0, 4, 64))
-    ex = [synth.ExpandedAssay(0, 0, None, None, long_o)]
-    t = "ACGTACGTAC" + synth.revcomp(long_o) + "GGATCCAT" + long_o[:40] + "T" + long_o[40:] + "ACGT"
-    codes, offsets = gu.pack_targets([t])
-    e = Engine(abi.options_default(min_probe_tm=40.0), ex)
-    db = e.pack(codes, offsets)
-    got = tc.sorted_hit_keys(e.search(db))
-    want = tc.sorted_hit_keys(oracle.search(abi.options_default(min_probe_tm=40.0), ex, codes, offsets))
-    assert got == want and len(want) >= 2
-    db.close()
-    e.close()
+    for n_long in (64, 128):
+        long_o = "".join("ACGT"[i] for i in rng.integers(0, 4, n_long))
+        ex = [synth.ExpandedAssay(0, 0, None, None, long_o)]
+        t = "ACGTACGTAC" + synth.revcomp(long_o) + "GGATCCAT" + long_o[:40] + "T" + long_o[40:] + "ACGT"
+        codes, offsets = gu.pack_targets([t])
+        e = Engine(abi.options_default(min_probe_tm=40.0), ex)
+        db = e.pack(codes, offsets)
+        got = tc.sorted_hit_keys(e.search(db))
+        want = tc.sorted_hit_keys(oracle.search(abi.options_default(min_probe_tm=40.0), ex, codes, offsets))
+        assert got == want and len(want) >= 2
+        db.close()
+        e.close()
     from thermonucleotideblast_amd.engine import TntError
     with pytest.raises(TntError):
         Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, long_o + "A")])
+    with pytest.raises(TntError):
+        Engine(abi.options_default(use_dinkelbach=1), [synth.ExpandedAssay(0, 0, None, None, long_o[:65])])
     with pytest.raises(TntError):
         Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGTNACGTACGTACGT")])
 

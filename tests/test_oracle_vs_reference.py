@@ -53,6 +53,28 @@ def test_search(ref, oracle, cfg, nt, na, seed, kw):
     assert len(a) > 0
 
 
+@pytest.mark.parametrize("kind,seed", [("probe", 1), ("probe", 2), ("padlock", 3), ("pcr", 4), ("pcr", 5)])
+def test_long_oligos(ref, oracle, kind, seed):
+    """Oligos of 65..128 bases (the library's long instances): seeds, binds, hits and self-structure of the oracle against
+    the reference."""
+    import longwl
+    wl = longwl.make(kind, seed)
+    oligos = sorted({o for e in wl.expanded for o in (e.forward, e.reverse, e.probe) if o})
+    assert max(len(o) for o in oligos) > 64
+    sa = ref.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    assert sa == oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    reqs = tc.make_reqs((s[0], s[1], s[2], s[3], s[4], i % 2, 9e-7 if i % 3 else 2.5e-7) for i, s in enumerate(sa[:6000]))
+    ra = ref.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    rb = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    bad = [b for b in ((i, tc.bind_compare_fields(ra[i], rb[i])) for i in range(len(reqs))) if b[1]]
+    assert not bad, bad[:3]
+    assert sum(1 for r in ra if r.status == 0) > 5
+    a = tc.sorted_hit_keys(ref.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    assert a == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets)) and len(a) > 10
+    for o in oligos[:4]:
+        assert ref.structure(wl.options, o, oligos[0]) == oracle.structure(wl.options, o, oligos[0])
+
+
 @pytest.mark.parametrize("kw", [{}, {"allow_dangle_5": 1, "allow_dangle_3": 1}, {"salt": 1.0, "target_t": 300.0}])
 def test_oligo_structure(ref, oracle, kw):
     """hairpin / homodimer / heterodimer Tm of oligos (tntblast_local.cpp:656-686) on fresh random + designed oligos."""

@@ -1236,6 +1236,12 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 			if (prefix < 0) prefix = 0;
 			int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
 			if (suffix < 0) suffix = 0;
+			// three lines of prefix + columns + suffix and 18 characters of decoration: the field holds every alignment of
+			// a 64-mer; one of a longer oligo that does not fit fails the call (never a cut text)
+			if (LMAX > 64 && 3 * (prefix + (bi.k1 - bi.k0) + suffix) + 18 >= ALIGN_TEXT) {
+				atomicOr(a.err, ERR_TEXT_OVERFLOW);
+				prefix = suffix = 0, bi.k1 = bi.k0;
+			}
 			int o = 0;
 			text[o++] = '5', text[o++] = '\'', text[o++] = ' ';
 			for (int i = 0; i < prefix; i++) text[o++] = base_letter(QUERY(bi.fm_q - prefix + i));
@@ -1284,9 +1290,11 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 // host-side launchers of the throughput instances, defined in tnt_bind_inst.hip
 #define X(N) void launch_bind_##N(const BindArgs &a, int blocks, hipStream_t stream);
 TNT_LMAX_LADDER(X)
+TNT_LONG_LADDER(X)
 #undef X
 #define X(N) void launch_bind_plain_##N(const BindArgs &a, int blocks, hipStream_t stream);
 TNT_LMAX_LADDER(X)
+TNT_LONG_LADDER(X)
 #undef X
 #define X(N) void launch_bind_exact_##N(const BindArgs &a, int blocks, hipStream_t stream);
 TNT_EXACT_LADDER(X)

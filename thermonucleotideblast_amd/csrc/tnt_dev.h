@@ -14,7 +14,7 @@ constexpr int NBP = 49;  // NUM_BASE_PAIR
 constexpr int P_AT = bA * NB + bT, P_TA = bT * NB + bA, P_CG = bC * NB + bG, P_GC = bG * NB + bC;
 constexpr int P_GT = bG * NB + bT, P_TG = bT * NB + bG, P_EE = bE * NB + bE, P__ = bGAP * NB + bGAP;
 
-constexpr int MAX_OLIGO = 64;             // TNT_MAX_OLIGO
+constexpr int MAX_OLIGO = 128;            // TNT_MAX_OLIGO
 constexpr int FLANK = 4;                  // NUM_FLANK_BASE, tntblast.h:76
 constexpr int MAX_WINDOW = MAX_OLIGO + 2 * FLANK;
 constexpr int MAX_COLS = MAX_OLIGO + MAX_WINDOW + 4; // longest traceback path + dangles
@@ -96,6 +96,9 @@ struct Slot {
 // ... and a ladder (L <= LMAX) in two flavours: plain windows (A/C/G/T targets) for the other lengths, and
 // general ones for windows with degenerate target bases and for short queues that are bound in one launch
 #define TNT_LMAX_LADDER(X) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
+// oligos of 65 to 128 bases (long hybridisation probes, MIPS arms): the same two flavours, rows mostly in scratch memory;
+// they do not meet the pre-filter
+#define TNT_LONG_LADDER(X) X(128)
 // instances of the pre-filter kernel (tnt_filter.hip.h): the row counts of both ladders above
 #define TNT_FILTER_LADDER(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
 constexpr int MAX_BUCKETS = 48;
@@ -111,7 +114,7 @@ constexpr int BUCKET_EXACT = 0x100, BUCKET_PLAIN = 0x200; // flags on the instan
 // 168 VGPRs without spilling -- up to 22 rows for any instance, up to 28 for the plain ones -- else 256 threads.
 constexpr bool bind_wide(int lmax, bool plain) { return lmax <= 22 || (plain && lmax <= 28); }
 constexpr int bind_threads_for(int lmax, bool plain) { return bind_wide(lmax, plain) ? 768 : 256; }
-constexpr int bind_blocks_per_cu(int lmax, bool plain) { return bind_wide(lmax, plain) ? 2 : 4; } // persistent grid: 2x the resident workgroups
+constexpr int bind_blocks_per_cu(int lmax, bool plain) { return (bind_wide(lmax, plain) || lmax > 64) ? 2 : 4; } // persistent grid: 2x the resident workgroups
 constexpr int BUCKET_STRIDE = 32; // words between two bucket counters (one 128-byte line each)
 
 // bind work item (one seed that survived the first cull)
@@ -234,7 +237,8 @@ __device__ __forceinline__ void shard_prefix(const uint32_t *counts, uint32_t *p
 // status word set by kernels
 constexpr uint32_t ERR_SEED_OVERFLOW = 1, ERR_ITEM_OVERFLOW = 2, ERR_POOL_OVERFLOW = 4, ERR_HIT_OVERFLOW = 8,
                    ERR_GROUP_OVERFLOW = 16, ERR_LIST_OVERFLOW = 32, ERR_STACK_OVERFLOW = 64, ERR_TIE_OVERFLOW = 128,
-                   ERR_FILTER_UNSOUND = 256; // audit mode: the pre-filter would have rejected a window the bind kernel accepts
+                   ERR_FILTER_UNSOUND = 256, // audit mode: the pre-filter would have rejected a window the bind kernel accepts
+                   ERR_TEXT_OVERFLOW = 512;  // the alignment text of an oligo longer than 64 bases does not fit TNT_ALIGN_TEXT
 
 } // namespace tnt
 #endif

@@ -271,7 +271,7 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 		auto phi = [&](int prev, int cur) { return -(double(T.H[prev * NBP + cur]) - Tk * (double(T.S[prev * NBP + cur]) + sc)); };
 		double pb1 = -Tk * double(T.bulge_S[1]), pb2 = 1.0e30, pl3 = 1.0e30;
 		// sizes a window of this library can hold (the reference leaves the last entry of both tables at 0,
-		// nuc_cruc_santa_lucia.cpp:670,720: a 512-base loop no 64-mer can form)
+		// nuc_cruc_santa_lucia.cpp:670,720: a 512-base loop no 128-mer can form)
 		for (int sz = 2; sz <= MAX_WINDOW; sz++) pb2 = std::min(pb2, -Tk * double(T.bulge_S[sz]));
 		for (int sz = 3; sz <= 2 * MAX_OLIGO + MAX_WINDOW; sz++) pl3 = std::min(pl3, -Tk * double(T.loop_S[sz]));
 		pl3 += -Tk * double(T.asym_S); // a loop that leaves its diagonal is asymmetric by at least one base
@@ -483,6 +483,7 @@ struct tnt_ctx {
 	DevBuf<uint32_t> slot_canon, slot_next;
 	DevBuf<uint32_t> item_rep;
 	bool dedupe = false;
+	int unit_rows = 64; // rows of the unit-level kernel instance this context's oligos need (64 or MAX_OLIGO)
 	bool filter_general = false; // the general buckets (degenerate windows, merged short queues) meet the pre-filter too
 	bool seed_lds = false; // the seed kernel instance with LDS-resident tables serves this context
 	DevBuf<Thresh> thresh;
@@ -601,8 +602,9 @@ int pick_lmax(size_t max_len)
 {
 #define X(N) if (max_len <= N) return N;
 	TNT_LMAX_LADDER(X)
+	TNT_LONG_LADDER(X)
 #undef X
-	return 64;
+	return MAX_OLIGO;
 }
 
 // persistent grid of one bind kernel instance
@@ -619,7 +621,7 @@ int pick_instance(size_t L)
 	return pick_lmax(L) | BUCKET_PLAIN;
 }
 
-void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_t stream = nullptr)
+void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_t stream = nullptr, int unit_rows = 0 /* 0: the context's */)
 {
 	if (!stream) stream = c->stream;
 	if (c->opt.use_dinkelbach) { // every bind through the 64-row general instances that iterate the temperature
@@ -627,16 +629,19 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 		else hipLaunchKernelGGL((bind_kernel<64, false, false, false, true>), dim3(blocks), dim3(bind_threads(64)), 0, stream, a);
 		return;
 	}
-	if (lmax == 0) { // unit-level API: one instance is enough
-		hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
+	if (lmax == 0) { // unit-level API: the 64-row instance, or the long one when an oligo needs it
+		if ((unit_rows ? unit_rows : c->unit_rows) > 64) hipLaunchKernelGGL((bind_kernel<MAX_OLIGO, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
+		else hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
 		return;
 	}
 	switch (lmax) {
 #define X(N) case N: tnt::launch_bind_##N(a, blocks, stream); break;
 		TNT_LMAX_LADDER(X)
+		TNT_LONG_LADDER(X)
 #undef X
 #define X(N) case N | BUCKET_PLAIN: tnt::launch_bind_plain_##N(a, blocks, stream); break;
 		TNT_LMAX_LADDER(X)
+		TNT_LONG_LADDER(X)
 #undef X
 #define X(N) case N | BUCKET_EXACT | BUCKET_PLAIN: tnt::launch_bind_exact_##N(a, blocks, stream); break;
 		TNT_EXACT_LADDER(X)
@@ -708,7 +713,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
 		b.audit = nullptr;
-		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general)) {
+		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) && (c->bucket_lmax[i] & 0xFF) <= 64) { // (no filter instance beyond 64 rows)
 			// every window first meets the pre-filter: what cannot reach the minimum Tm is rejected there, the rest of the
 			// bucket is compacted into qsurv (same offset) and bound by the full kernel.  (The general buckets -- windows
 			// with degenerate target bases, merged short queues -- go through the instance that reads the exception lists.)
@@ -834,6 +839,7 @@ const char *err_text(uint32_t e)
 	if (e & ERR_STACK_OVERFLOW) return "traceback branch stack overflow";
 	if (e & ERR_TIE_OVERFLOW) return "more than 256 maximal DP cells in one window";
 	if (e & ERR_FILTER_UNSOUND) return "pre-filter audit: the filter would have rejected a window the bind kernel accepts";
+	if (e & ERR_TEXT_OVERFLOW) return "the alignment text of an oligo longer than 64 bases does not fit TNT_ALIGN_TEXT";
 	return "unknown device error";
 }
 
@@ -979,13 +985,15 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		c->h_assays.push_back(d);
 	}
 	for (const std::string &o : c->oligos) {
-		if (o.size() > size_t(TNT_MAX_OLIGO)) FAIL(TNT_E_LIMIT, "oligo longer than TNT_MAX_OLIGO (64) bases");
+		if (o.size() > size_t(TNT_MAX_OLIGO)) FAIL(TNT_E_LIMIT, "oligo longer than TNT_MAX_OLIGO (128) bases");
 		if (o.empty()) FAIL(TNT_E_ARG, "empty oligo");
 		for (char ch : o)
 			if (char_to_base(ch) < 0) FAIL(TNT_E_ARG, "oligos must be expanded to A/C/G/T/I (expand_degenerate_signatures)");
 		max_L = std::max(max_L, o.size());
 	}
+	if (opt->use_dinkelbach && max_L > 64) FAIL(TNT_E_LIMIT, "--dinkelbach with an oligo longer than 64 bases");
 	c->lmax = opt->use_dinkelbach ? 64 : pick_lmax(max_L); // --dinkelbach: one 64-row instance binds everything
+	c->unit_rows = max_L > 64 ? MAX_OLIGO : 64;
 	{
 		// buckets: one per instance in use, in ascending length; the last one is the general instance that
 		// takes the longest oligo (short queues are bound there as a whole)
@@ -1051,8 +1059,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				const std::string &o = c->oligos[c->h_slots[slots3[role]].oligo];
 				const std::vector<uint16_t> w = word_list(o, minus == 0, k); // plus strand: find_complement
 				// the strand-specific sequence, 2 bits per base (plain A/C/G/T oligos only: word index == base offset)
-				bool plain = true;
-				for (size_t x = 0; x < o.size(); x++) {
+				bool plain = o.size() <= 64; // (the packed form holds 64 bases; longer oligos take the word-list test)
+				for (size_t x = 0; x < o.size() && plain; x++) {
 					const char ch = minus ? o[x] : o[o.size() - 1 - x];
 					int b2 = -1;
 					switch (ch) {
@@ -2635,7 +2643,7 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 	if (n == 0) return TNT_OK;
 	if (n > ITEM_CAP || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, 64); // the unit-level kernel instance is bind_kernel<64, true>
+	int rc = ensure_work_buffers(ctx, ctx->unit_rows); // the unit-level kernel instance is bind_kernel<64 or 128, true>
 	if (rc) return rc;
 	auto bucket_of = [&](int id) -> int32_t { // position of an instance in the context's bucket list (it holds the instances of every oligo)
 		for (size_t i = 0; i < ctx->bucket_lmax.size(); i++)
@@ -2828,7 +2836,8 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 		return TNT_E_ARG;
 	}
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, 64);
+	const int struct_rows = (strlen(oa) > 64 || (ob && strlen(ob) > 64)) ? MAX_OLIGO : 64; // which unit-level instance
+	int rc = ensure_work_buffers(ctx, struct_rows);
 	if (rc) return rc;
 	const char *seqs[2] = {oa, ob};
 	const int n_ol = ob ? 2 : 1;
@@ -2838,7 +2847,7 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	for (int o = 0; o < n_ol; o++) {
 		const size_t L = strlen(seqs[o]);
 		if (L == 0 || L > size_t(TNT_MAX_OLIGO)) {
-			ctx->err = "oligo length must be 1..64";
+			ctx->err = "oligo length must be 1..128";
 			return TNT_E_LIMIT;
 		}
 		len[o] = int(L);
@@ -2885,7 +2894,7 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	b.groups = nullptr;
 	b.n_items = uint32_t(items.size());
 	b.full = dfull.p;
-	launch_bind(ctx, b, 1, 0);
+	launch_bind(ctx, b, 1, 0, nullptr, struct_rows);
 	HIP_TRY(hipGetLastError(), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	std::vector<BindFull> full(items.size());

@@ -48,6 +48,8 @@ constexpr int SEED_MAX_ASSAYS = 256;  // assays per chunk (8-bit local index in 
 constexpr uint32_t ITEM_NO_REP = 0xFFFFFFFFu;
 constexpr int LIST_MAX = 512;         // seeds of one (work unit, assay): bounded by the seed list itself (PAIR_BIG of the pair kernel)
 
+typedef uint32_t __attribute__((aligned(2))) u32_a2; // a dword at a 2-byte aligned address (two neighbouring 16-bit bucket offsets)
+
 struct SeedOut { // debug / unit-level output: every kept seed before the cull
 	uint32_t target, assay_role, strand_minus, query_loc, target_loc;
 };
@@ -334,7 +336,15 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 #pragma unroll
 					for (int q = 0; q < SEED_SWEEP; q++) {
 						const uint32_t w = uint32_t(v >> (2 * q)) & wmask;
-						const uint32_t e0 = LDS_TABLES ? s_wt_off[w] : a.wt_off[w], e1 = LDS_TABLES ? s_wt_off[w + 1] : a.wt_off[w + 1];
+						// both bounds of the bucket with one (2-byte aligned) dword read: the gathers of this scan are bound by
+						// the number of scattered requests, not by bytes
+						uint32_t e0, e1;
+						if (LDS_TABLES) {
+							e0 = s_wt_off[w], e1 = s_wt_off[w + 1];
+						} else {
+							const uint32_t two = *reinterpret_cast<const u32_a2 *>(a.wt_off + w);
+							e0 = two & 0xFFFFu, e1 = two >> 16;
+						}
 						const uint32_t n = (p0 + q >= pos0 && p0 + q < npos) ? e1 - e0 : 0u;
 						bnd[q] = e0 | (n << 16);
 						mine += n;

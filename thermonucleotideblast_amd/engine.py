@@ -97,7 +97,7 @@ def load_library():
     lib.tnt_db_target_codes.restype = C.c_int64
     lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
     lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
-    if lib.tnt_abi_version() != 2:
+    if lib.tnt_abi_version() != 3:
         raise TntError("ABI version mismatch")
     _lib = lib
     return lib
