@@ -11,8 +11,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import longwl  # noqa: E402
 import tntcheck as tc  # noqa: E402
 from thermonucleotideblast_amd import abi, synth  # noqa: E402
+
+LONG_FRACTION = float(os.environ.get("FUZZ_LONG", "0"))  # share of the cases that use oligos of 65..128 bases (tests/longwl.py)
 
 
 def random_case(rng, case, max_code=18, dangle=True):
@@ -22,6 +25,13 @@ def random_case(rng, case, max_code=18, dangle=True):
     nt = int(rng.integers(40, 260))
     na = None if cfg == 1 else int(rng.integers(4, 40))
     wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=int(rng.integers(1, 1 << 30)))
+    if LONG_FRACTION > 0.0:  # (its own stream: the sequence of ordinary cases does not depend on the share)
+        lrng = np.random.default_rng([case, 977])
+        if lrng.random() < LONG_FRACTION:
+            kind = ("pcr", "probe", "padlock")[int(lrng.integers(0, 3))]
+            cfg = 2 if kind == "pcr" else 5
+            wl = longwl.make(kind, int(lrng.integers(1, 1 << 30)), n_targets=min(nt, 120))
+            nt = wl.n_targets
     o = wl.options
     pick = lambda *v: v[int(rng.integers(0, len(v)))]  # noqa: E731
     o.min_primer_tm = float(pick(0.0, 30.0, 40.0, 45.0, 52.0))
@@ -54,7 +64,7 @@ def random_case(rng, case, max_code=18, dangle=True):
     codes, offsets = wl.codes, wl.offsets
     shape = int(rng.integers(0, 5))
     if shape == 1:   # ragged lengths incl. empty and shorter-than-word targets
-        lens = rng.integers(0, 1000, nt)
+        lens = np.minimum(rng.integers(0, 1000, nt), np.diff(offsets).astype(np.int64))
         lens[rng.integers(0, nt, 3)] = [0, 3, 6]
         keep = np.zeros(len(codes), dtype=bool)
         for t in range(nt):

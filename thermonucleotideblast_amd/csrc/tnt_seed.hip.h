@@ -471,16 +471,22 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 					valid = true; // probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454)
 				} else {
 					const bool has_probe = (k & 16u) != 0, single = a.single_primer_pcr != 0;
-					const uint32_t role = key_role(k), loc = uint32_t(k >> 24);
+					const uint32_t role = key_role(k);
 					const bool minus = k & 1u;
-					constexpr unsigned long long K_FLAGS = K_VALID | K_PHASE_B; // earlier rounds have flagged their keys already
+					// The order relation of two keys of a segment is the order of bits 14..55 (target_loc, assembly group, word
+					// index).  A work unit that is culled here is a whole target of at most 32 768 positions (build_units), so
+					// the 32 bits from bit 14 up hold all of it: 32-bit comparisons (the 64-bit ones were most of this phase).
+					auto order_of = [](unsigned long long key) __attribute__((always_inline)) {
+						return __builtin_amdgcn_alignbit(uint32_t(key >> 32), uint32_t(key), 14); // wi | group << 7 | loc << 10
+					};
+					const uint32_t ko = order_of(k), loc = ko >> 10;
 					// four keys of the segment per step (a key read twice changes nothing: every use is a minimum, a maximum or an "exists")
 					const uint32_t last = s0 + cnt - 1u;
-#define SEG4(X, O0, O1, O2, O3)                                                              \
-	const unsigned long long O0 = srt[s0 + (X)] & ~K_FLAGS,                                   \
-	                         O1 = srt[(s0 + (X) + 1u < last ? s0 + (X) + 1u : last)] & ~K_FLAGS, \
-	                         O2 = srt[(s0 + (X) + 2u < last ? s0 + (X) + 2u : last)] & ~K_FLAGS, \
-	                         O3 = srt[(s0 + (X) + 3u < last ? s0 + (X) + 3u : last)] & ~K_FLAGS
+#define SEG4(X, O0, O1, O2, O3)                                                    \
+	const unsigned long long O0 = srt[s0 + (X)],                                    \
+	                         O1 = srt[(s0 + (X) + 1u < last ? s0 + (X) + 1u : last)], \
+	                         O2 = srt[(s0 + (X) + 2u < last ? s0 + (X) + 2u : last)], \
+	                         O3 = srt[(s0 + (X) + 3u < last ? s0 + (X) + 3u : last)]
 					// One pass over the segment:
 					//  * the element FOLLOWING this one in list order (amplicon_search.cpp:748-755 counts its strand when this
 					//    seed is valid; past-the-end counts nothing);
@@ -490,39 +496,42 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 					//    keeps the nearest probe (`pnear`) and the partner within reach that lies farthest out (`far`): some
 					//    partner lies beyond the probe iff that one does;
 					//  * a probe needs the closest primers on either side (per oligo).
-					unsigned long long next = ~0ull;
-					unsigned long long pnear = minus ? ~0ull : 0ull, far = minus ? 0ull : ~0ull;
+					// (An order word is never 0 for a primer on the plus strand or a probe -- their groups are 2..5 -- and never
+					// all ones, so both serve as "none".)
+					uint32_t next = ~0u;
+					uint32_t pnear = minus ? ~0u : 0u, far = minus ? 0u : ~0u;
 					uint32_t f_loc[2] = {0, 0}, r_loc[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 					bool f_ok[2] = {false, false}, r_ok[2] = {false, false};
+					// (as it stands, with branches: the same body written with selects only was measured 6 % slower)
 					for (uint32_t x = 0; x < cnt; x += 4) {
 						SEG4(x, o0, o1, o2, o3);
 						const unsigned long long os[4] = {o0, o1, o2, o3};
 #pragma unroll
 						for (int j = 0; j < 4; j++) {
-							const unsigned long long o = os[j];
-							if (o > k && o < next) next = o;
-							const uint32_t orole = key_role(o);
+							const uint32_t oo = order_of(os[j]), olow = uint32_t(os[j]);
+							if (oo > ko && oo < next) next = oo;
+							const uint32_t orole = (olow >> 1) & 3u;
 							if (orole == 2) {
-								if (minus ? (o > k && o < pnear) : (o < k && o > pnear)) pnear = o;
+								if (minus ? (oo > ko && oo < pnear) : (oo < ko && oo > pnear)) pnear = oo;
 								continue;
 							}
-							const uint32_t oloc = uint32_t(o >> 24);
-							const bool ominus = o & 1u;
+							const uint32_t oloc = oo >> 10;
+							const bool ominus = olow & 1u;
 							if (role == 2) { // probe: primers on either side of me
-								if (ominus && o < k && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
-								if (!ominus && o > k && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
+								if (ominus && oo < ko && (!f_ok[orole] || oloc > f_loc[orole])) f_ok[orole] = true, f_loc[orole] = oloc;
+								if (!ominus && oo > ko && (!r_ok[orole] || oloc < r_loc[orole])) r_ok[orole] = true, r_loc[orole] = oloc;
 							} else if (single || orole != role) {
 								if (minus) { // I am an f: partners r to my right
-									if (!ominus && o > k && oloc - loc <= threshold && o > far) far = o;
+									if (!ominus && oo > ko && oloc - loc <= threshold && oo > far) far = oo;
 								} else {     // I am an r: partners f to my left
-									if (ominus && o < k && loc - oloc <= threshold && o < far) far = o;
+									if (ominus && oo < ko && loc - oloc <= threshold && oo < far) far = oo;
 								}
 							}
 						}
 					}
 					if (role != 2) {
-						if (!has_probe) valid = minus ? far != 0ull : far != ~0ull;
-						else valid = minus ? (pnear != ~0ull && far > pnear) : (pnear != 0ull && far < pnear);
+						if (!has_probe) valid = minus ? far != 0u : far != ~0u;
+						else valid = minus ? (pnear != ~0u && far > pnear) : (pnear != 0u && far < pnear);
 					}
 #undef SEG4
 					if (role == 2) {
@@ -532,8 +541,9 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 								if ((single || rf != rr) && f_ok[rf] && r_ok[rr] && r_loc[rr] - f_loc[rf] <= threshold) valid = true;
 					}
 					if (valid) {
-						// strand of the list element FOLLOWING a valid one decides which strand is bound first (:131)
-						if (next != ~0ull) atomicAdd(&cmcp[la], (next & 1u) ? 1u : 0x10000u);
+						// strand of the list element FOLLOWING a valid one decides which strand is bound first (:131); its
+						// assembly group tells the strand: F-, R-, F+, R+, P-, P+
+						if (next != ~0u) atomicAdd(&cmcp[la], ((0x13u >> ((next >> 7) & 7u)) & 1u) ? 1u : 0x10000u);
 					}
 				}
 				if (valid) {
