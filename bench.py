@@ -348,6 +348,7 @@ def main():
         seed_achieved = alg_bytes / (seed_ms_step * 1e-3) / 1e9 if seed_ms_step > 0 else 0.0
         traffic = None
         valu = None
+        seed_issue = None
         pmc = os.path.join(ROOT, "profiles", "bind_pmc.json")
         if os.path.exists(pmc) and args.config == 2 and per_piece == full and args.scaling == "weak":  # measured for this workload only
             try:
@@ -356,6 +357,13 @@ def main():
                 # What bounds these kernels is instruction issue and LDS bank conflicts, not HBM:
                 # VALU wave-instructions per step from the same PMC file over this run's bind time, against the guide's plain
                 # rate: 1 024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction
+                si = rec.get("seed_kernel_insts_per_step")
+                if si and seed_ms_step > 0:
+                    # the seed stage is a chain of short dependent per-target steps: ~5 700 wave-instructions per target
+                    n_all, n_v = sum(si.values()), si["SQ_INSTS_VALU"]
+                    seed_issue = {"wave_instructions_per_step": n_all, "valu_wave_instructions_per_step": n_v, "unit": "wave-instructions/s",
+                                  "achieved_all": n_all / (seed_ms_step * 1e-3), "achieved_valu": n_v / (seed_ms_step * 1e-3),
+                                  "peak_guide": VALU_PEAK_GUIDE, "frac_guide_valu": n_v / (seed_ms_step * 1e-3) / VALU_PEAK_GUIDE}
                 n_valu = rec.get("SQ_INSTS_VALU_per_step")
                 if n_valu and bind_ms_step > 0:
                     ach = n_valu / (bind_ms_step * 1e-3)
@@ -391,7 +399,11 @@ def main():
                          "valu_issue": valu},
             # the streaming stage, for which SURVEY 8(d) means the HBM roofline: the seed kernels of a step (scan + cull)
             "roofline_seed": {"bound": "hbm", "kernel": "seed stage (scan + dedupe + first cull + emission)", "achieved": seed_achieved,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": seed_achieved / HBM_PEAK_GBS},
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": seed_achieved / HBM_PEAK_GBS,
+                              "note": "a chain of short dependent per-target steps (scan, de-duplication, counting sort, first cull, "
+                                      "emission), bound by instruction issue and LDS round trips, not by the 0.25 B/base it streams "
+                                      "(DESIGN.md 4.1); issue = PMC instruction counts of the stage (profiles/bind_pmc.json) over its time",
+                              "issue": seed_issue},
         }
         if world == 1 and not args.no_cpu_baseline and wl0 is not None:
             try:

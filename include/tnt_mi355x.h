@@ -264,10 +264,11 @@ enum { TNT_ROUTE_UNIT = 0, TNT_ROUTE_BUCKETS = 1, TNT_ROUTE_MERGED = 2 };
 int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out, int route);
 
 /* Unit-level entry to the bind stage's pre-filter (tnt_filter.hip.h): for every request score[2k] = an upper bound, in
- * 1e-4 kcal/mol, of -(dH - Tk dS) + constant over all alignments of the window at Tk = minimum Tm of the request's
- * threshold set, score[2k+1] = the value it must reach for the window to go on to the full bind kernel (INT32_MIN: the
- * filter is off for this threshold set); -1 / -1 for windows with a degenerate target base, which never meet the filter.
- * bind_oligo_to_*_strand rejects what stays below on Tm (bind_oligo.cpp:600-606).                              */
+ * 1e-3 kcal/mol (saturating at 32 767), of -(dH - Tk dS) + constant over all alignments of the window at Tk = minimum Tm
+ * of the request's threshold set, score[2k+1] = the value it must reach for the window to go on to the full bind kernel
+ * (INT32_MIN: the filter is off for this threshold set).  IUPAC codes in the window count as "any of A C G T"; a window
+ * with inosine or a skipped code gives INT32_MAX / INT32_MIN (never rejected); oligos beyond 64 bases have no filter
+ * instance: -1 / -1.  bind_oligo_to_*_strand rejects what stays below on Tm (bind_oligo.cpp:600-606).           */
 int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, int32_t *score);
 
 /* Oligo self-structure printed with every hit (tntblast_local.cpp:656-686): hairpin and homodimer Tm of oligo

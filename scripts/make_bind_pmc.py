@@ -23,6 +23,8 @@ out = {
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_step": int((2.0 * fetch + write) * 1024),
     "SQ_INSTS_VALU_per_step": sum(float(d[k]["SQ_INSTS_VALU"]) for k in stage),
+    # the seed stage's instruction counts (wave-instructions per step): what bounds it is issue, not the 250 MB it streams
+    "seed_kernel_insts_per_step": {k: float(d["seed_kernel"][k]) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")},
     "history": (old.get("history") or ([{"hbm_bytes_per_step": old["round1"]["hbm_bytes_per_step"], "SQ_INSTS_VALU_per_step": old["round1"]["SQ_INSTS_VALU_per_step"], "state": "round 1 (r01k)"}] if "round1" in old else []))
                + ([{"hbm_bytes_per_step": old["hbm_bytes_per_step"], "SQ_INSTS_VALU_per_step": old["SQ_INSTS_VALU_per_step"], "state": old.get("source", "")[:40]}] if "hbm_bytes_per_step" in old and old.get("source") != None and src not in old.get("source", "") else []),
 }

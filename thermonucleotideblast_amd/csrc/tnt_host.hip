@@ -650,6 +650,25 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 	}
 }
 
+// is there a pre-filter instance of this many rows (degen: for windows with any target code)?
+bool has_filter_instance(int rows, bool degen)
+{
+	if (degen) {
+		switch (rows) {
+#define X(N) case N: return true;
+			TNT_LMAX_LADDER(X)
+#undef X
+		default: return false;
+		}
+	}
+	switch (rows) {
+#define X(N) case N: return true;
+		TNT_FILTER_LADDER(X)
+#undef X
+	default: return false;
+	}
+}
+
 void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t stream, bool degen = false /* windows with any target code */)
 {
 	if (degen) {
@@ -713,7 +732,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
 		b.audit = nullptr;
-		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) && (c->bucket_lmax[i] & 0xFF) <= 64) { // (no filter instance beyond 64 rows)
+		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) &&
+		    has_filter_instance(c->bucket_lmax[i] & 0xFF, !(c->bucket_lmax[i] & BUCKET_PLAIN))) { // (none beyond 64 rows: such a bucket goes to the bind kernel as it is)
 			// every window first meets the pre-filter: what cannot reach the minimum Tm is rejected there, the rest of the
 			// bucket is compacted into qsurv (same offset) and bound by the full kernel.  (The general buckets -- windows
 			// with degenerate target bases, merged short queues -- go through the instance that reads the exception lists.)
