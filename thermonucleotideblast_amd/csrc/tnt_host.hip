@@ -688,6 +688,13 @@ void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t strea
 	}
 }
 
+template <bool LDS_TABLES> void launch_seed(const SeedArgs &s, int mode, int blocks, int threads, hipStream_t stream)
+{
+	if (mode == SEED_LIST) hipLaunchKernelGGL((seed_kernel<LDS_TABLES, SEED_LIST>), dim3(blocks), dim3(threads), 0, stream, s);
+	else if (mode == SEED_SEARCH_SHARED) hipLaunchKernelGGL((seed_kernel<LDS_TABLES, SEED_SEARCH_SHARED>), dim3(blocks), dim3(threads), 0, stream, s);
+	else hipLaunchKernelGGL((seed_kernel<LDS_TABLES, SEED_SEARCH>), dim3(blocks), dim3(threads), 0, stream, s);
+}
+
 // One phase of binding: split the queue by oligo length, then one launch per length bucket.
 void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_exceptions, const uint32_t *src, const uint32_t *src_count,
                        const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always */)
@@ -1888,9 +1895,9 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		s.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
 		s.n_ent = c->chunk_ent_base[ch + 1] - c->chunk_ent_base[ch];
 		if (c->seed_lds && s.n_ent <= uint32_t(SEED_LDS_ENT))
-			hipLaunchKernelGGL(seed_kernel<true>, dim3(lds_blocks), dim3(64 * SEED_LDS_WAVES), 0, c->stream, s);
+			launch_seed<true>(s, seeds_only ? SEED_LIST : (s.item_rep ? SEED_SEARCH_SHARED : SEED_SEARCH), lds_blocks, 64 * SEED_LDS_WAVES, c->stream);
 		else
-			hipLaunchKernelGGL(seed_kernel<false>, dim3(seed_blocks), dim3(SEED_THREADS), 0, c->stream, s);
+			launch_seed<false>(s, seeds_only ? SEED_LIST : (s.item_rep ? SEED_SEARCH_SHARED : SEED_SEARCH), seed_blocks, SEED_THREADS, c->stream);
 	}
 	HIP_TRY(hipEventRecord(ev[1], c->stream), c->err);
 	if (seeds_only) { // (every event of the set is recorded: the stage timings walk over all of them)

@@ -186,7 +186,12 @@ __device__ __forceinline__ bool first_on_diagonal_packed(const uint32_t *pk, con
 // LDS_TABLES: the chunk's query-word table is staged in LDS once per workgroup (word size <= SEED_LDS_WORD_SIZE, at most
 // SEED_LDS_ENT entries) and the scan walks SEED_SWEEP positions per lane out of registers; otherwise the tables are read
 // from HBM / L2 position by position (word size 8, over-long chunks).
-template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES), (LDS_TABLES ? 2 : TNT_SEED_MINBLOCKS)) void seed_kernel(SeedArgs a)
+// MODE: what a launch is for -- SEED_SEARCH: culls and emits bind work items; SEED_SEARCH_SHARED: the same plus the marking of
+// repeated (oligo, window) items of assays that share oligos; SEED_LIST: the seeds themselves (unit-level API, windows of long
+// targets).  Separate instances: the common one does not carry the other two's code and pointers (this kernel spills scalar
+// registers as it is).
+enum { SEED_SEARCH = 0, SEED_SEARCH_SHARED = 1, SEED_LIST = 2 };
+template <bool LDS_TABLES, int MODE> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES), (LDS_TABLES ? 2 : TNT_SEED_MINBLOCKS)) void seed_kernel(SeedArgs a)
 {
 	constexpr int WAVES = LDS_TABLES ? SEED_LDS_WAVES : SEED_WAVES;
 	__shared__ unsigned long long s_raw[WAVES][SEED_CAP];
@@ -388,7 +393,7 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 			n = SEED_CAP;
 		}
 
-		if (a.seeds_out) {
+		if (MODE == SEED_LIST && a.seeds_out) {
 			for (uint32_t i = lane; i < n; i += 64) {
 				const uint32_t o = atomicAdd(a.seeds_count, 1u);
 				if (o < a.seeds_cap) {
@@ -402,7 +407,7 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 #ifdef TNT_EXP_SCANONLY
 		if (false) {
 #else
-		if (a.items && n > 0) {
+		if (MODE != SEED_LIST && a.items && n > 0) {
 #endif
 			// ------------------------------------------------------------ counting sort by assay (wave-wide)
 			// exclusive prefix of hist -> off (4 assays per lane)
@@ -636,7 +641,7 @@ template <bool LDS_TABLES> __global__ __launch_bounds__(64 * (LDS_TABLES ? SEED_
 		ST(5);
 #endif
 			for (uint32_t i = lane; i < n_chunk; i += 64) cmcp[i] = 0; // now the (item | phase-A << 16) cursors
-			const bool DEDUPE = a.item_rep != nullptr;
+			constexpr bool DEDUPE = MODE == SEED_SEARCH_SHARED;
 			static_assert(SEED_CAP == 2 * SEED_MAX_ASSAYS, "hist + off hold one representative index per seed");
 			if (DEDUPE) {
 				// Expanded assays that share an oligo see the same seeds of it.  A phase-A seed of such an assay looks for
