@@ -37,7 +37,7 @@ constexpr int SEED_LDS_OFF = (1 << (2 * SEED_LDS_WORD_SIZE)) + 2;
 constexpr int SEED_LDS_ENT = 10240;                   // entries of one assay chunk (40 KB)
 constexpr int SEED_LDS_SEQ = 1536;                    // 64-bit words of packed oligos: 128 assays x 6 lists x 2 (12 KB); larger chunks read them from HBM
 #ifndef TNT_SEED_SWEEP
-#define TNT_SEED_SWEEP 8
+#define TNT_SEED_SWEEP 16
 #endif
 #ifndef TNT_SEED_MINBLOCKS
 #define TNT_SEED_MINBLOCKS 4
