@@ -91,6 +91,10 @@ void load_window(NucCruc &melt, const unsigned char *seq, unsigned int start, un
 
 } // namespace
 
+// defined in the reference's amplicon_search.cpp (external linkage, declared there only)
+pair<unsigned int, unsigned int> cull_oligo_match(list<oligo_info> &m_match_list, const unsigned int &m_max_amplicon_len,
+	const bool &m_has_probe, const bool &m_single_primer_pcr);
+
 extern "C" {
 
 const char *tntref_last_error(void) { return g_err.c_str(); }
@@ -344,6 +348,58 @@ int tntref_bind_batch(const tnt_options *opt, const char *const *oligos, int n_o
 		}
 	}
 	return rc;
+}
+
+// a4 at unit level: the head of amplicon() (amplicon_search.cpp:96-129) with the reference's own functions -- match list in
+// assembly order, early exits, cull_oligo_match -- and what is left of the list.  Same records as tntor_first_cull; the
+// seventh field (strand bound first) comes from counts that read one node past the list and is not compared.
+int tntref_first_cull(const tnt_options *opt, const tnt_assay *assays, size_t n_assays, const uint8_t *codes, const uint64_t *offsets,
+                      size_t n_targets, uint32_t first_seq_index, int32_t **out, size_t *n_out)
+{
+	try {
+		vector<int32_t> all;
+		DNAHash dbase(opt->hash_word_size);
+		for (size_t t = 0; t < n_targets; t++) {
+			SEQPTR seq = make_seqptr(codes, offsets[t], offsets[t + 1]);
+			if (SEQ_SIZE(seq) >= dbase.min_sequence_size()) {
+				dbase.hash(seq, SEQ_SIZE(seq), 0, SEQ_SIZE(seq));
+				for (size_t a = 0; a < n_assays; a++) {
+					const tnt_assay &A = assays[a];
+					if (!(A.forward && A.reverse) || opt->assay_format != TNT_ASSAY_PCR) continue;
+					list<oligo_info> ml;
+					match_oligo_to_minus_strand(ml, dbase, A.forward, oligo_info::F);
+					match_oligo_to_minus_strand(ml, dbase, A.reverse, oligo_info::R);
+					const size_t n_minus = ml.size();
+					if (n_minus == 0) continue;
+					match_oligo_to_plus_strand(ml, dbase, A.forward, oligo_info::F);
+					match_oligo_to_plus_strand(ml, dbase, A.reverse, oligo_info::R);
+					const size_t n_plus = ml.size();
+					if (n_plus == n_minus) continue;
+					if (A.probe) {
+						match_oligo_to_minus_strand(ml, dbase, A.probe, oligo_info::P);
+						match_oligo_to_plus_strand(ml, dbase, A.probe, oligo_info::P);
+						if (ml.size() == n_plus) continue;
+					}
+					const pair<unsigned int, unsigned int> sc = cull_oligo_match(ml, (unsigned int)opt->max_len, A.probe != NULL, opt->single_primer_pcr != 0);
+					for (list<oligo_info>::const_iterator i = ml.begin(); i != ml.end(); ++i) {
+						const int32_t rec[7] = {int32_t(first_seq_index + t), int32_t(a),
+						                        (i->mask & oligo_info::F) ? 0 : ((i->mask & oligo_info::R) ? 1 : 2),
+						                        (i->mask & oligo_info::PLUS_STRAND) ? TNT_PLUS : TNT_MINUS, int32_t(i->query_loc),
+						                        int32_t(i->target_loc), sc.first < sc.second ? 1 : 0};
+						all.insert(all.end(), rec, rec + 7);
+					}
+				}
+			}
+			delete[] seq;
+		}
+		*n_out = all.size() / 7;
+		*out = (int32_t *)malloc(sizeof(int32_t) * max<size_t>(1, all.size()));
+		memcpy(*out, all.data(), sizeof(int32_t) * all.size());
+		return 0;
+	} catch (const char *e) {
+		g_err = e;
+		return -1;
+	}
 }
 
 // G5: the whole path.  Mirrors the loop body of tntblast_local.cpp:491-706 (without the

@@ -1309,6 +1309,29 @@ static tnt_hit blank_hit(const tnt_assay &A, int seq_index)
 	return h;
 }
 
+// The head of amplicon() (amplicon_search.cpp:96-128): the match list in its assembly order, the early exits, the first cull.
+// Returns false where amplicon() returns before binding anything; `sc` = the strand counts that pick the strand bound first.
+static bool first_cull(const tnt_options &o, const tnt_assay &A, const Seeder &h, std::list<Info> &ml, std::pair<unsigned, unsigned> &sc)
+{
+	const bool has_probe = A.probe != nullptr;
+	const std::string F = A.forward, R = A.reverse, Pp = has_probe ? A.probe : "";
+	match_oligo(ml, h, F, MF, false);
+	match_oligo(ml, h, R, MR, false);
+	const size_t n_minus = ml.size();
+	if (n_minus == 0) return false;
+	match_oligo(ml, h, F, MF, true);
+	match_oligo(ml, h, R, MR, true);
+	const size_t n_plus = ml.size();
+	if (n_plus == n_minus) return false;
+	if (has_probe) {
+		match_oligo(ml, h, Pp, MP, false);
+		match_oligo(ml, h, Pp, MP, true);
+		if (ml.size() == n_plus) return false;
+	}
+	sc = cull(ml, o.max_len, has_probe, o.single_primer_pcr != 0);
+	return true;
+}
+
 // amplicon(), amplicon_search.cpp:58-677
 static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const uint8_t *seq, unsigned seq_len,
                      int seq_index, Melt &m, std::vector<tnt_hit> &out)
@@ -1323,20 +1346,8 @@ static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const u
 	const std::string F = A.forward, R = A.reverse, Pp = has_probe ? A.probe : "";
 
 	std::list<Info> ml;
-	match_oligo(ml, h, F, MF, false);
-	match_oligo(ml, h, R, MR, false);
-	const size_t n_minus = ml.size();
-	if (n_minus == 0) return;
-	match_oligo(ml, h, F, MF, true);
-	match_oligo(ml, h, R, MR, true);
-	const size_t n_plus = ml.size();
-	if (n_plus == n_minus) return;
-	if (has_probe) {
-		match_oligo(ml, h, Pp, MP, false);
-		match_oligo(ml, h, Pp, MP, true);
-		if (ml.size() == n_plus) return;
-	}
-	const std::pair<unsigned, unsigned> sc = cull(ml, o.max_len, has_probe, single);
+	std::pair<unsigned, unsigned> sc;
+	if (!first_cull(o, A, h, ml, sc)) return;
 
 	const Thresh pt = {o.min_primer_tm, o.max_primer_tm, o.min_primer_dg, o.max_primer_dg, 0u, unsigned(o.primer_clamp),
 	                   unsigned(o.max_gap), unsigned(o.max_mismatch), unsigned(o.max_poly_degen)};
@@ -1634,6 +1645,44 @@ int tntor_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assay
 	*out = (tnt_hit *)malloc(sizeof(tnt_hit) * std::max<size_t>(1, all.size()));
 	memcpy(*out, all.data(), sizeof(tnt_hit) * all.size());
 	return rc;
+}
+
+// a4 at unit level: the seeds of every (target, PCR assay) that survive amplicon()'s early exits and the first
+// cull_oligo_match, and the strand that is bound first (amplicon_search.cpp:96-131).  Records of six ints:
+// seq_index, assay (position in `assays`), role (0 forward, 1 reverse, 2 probe), strand, query_loc, target_loc, and a
+// seventh: 1 when the minus strand is bound first.
+int tntor_first_cull(const tnt_options *opt, const tnt_assay *assays, size_t n_assays, const uint8_t *codes, const uint64_t *offsets,
+                     size_t n_targets, uint32_t first_seq_index, int32_t **out, size_t *n_out)
+{
+	std::vector<int32_t> all;
+	try {
+		Seeder h(opt->hash_word_size);
+		for (size_t t = 0; t < n_targets; t++) {
+			const uint8_t *seq = codes + offsets[t];
+			const unsigned len = unsigned(offsets[t + 1] - offsets[t]);
+			if (len < unsigned(opt->hash_word_size)) continue;
+			h.hash(seq, len);
+			for (size_t a = 0; a < n_assays; a++) {
+				const tnt_assay &A = assays[a];
+				if (!(A.forward && A.reverse) || opt->assay_format != TNT_ASSAY_PCR) continue;
+				std::list<Info> ml;
+				std::pair<unsigned, unsigned> sc;
+				if (!first_cull(*opt, A, h, ml, sc)) continue;
+				for (const Info &i : ml) {
+					const int32_t rec[7] = {int32_t(first_seq_index + t), int32_t(a), (i.mask & MF) ? 0 : ((i.mask & MR) ? 1 : 2),
+					                        (i.mask & MPLUS) ? TNT_PLUS : TNT_MINUS, int32_t(i.qloc), int32_t(i.tloc), sc.first < sc.second ? 1 : 0};
+					all.insert(all.end(), rec, rec + 7);
+				}
+			}
+		}
+	} catch (const char *e) {
+		g_err = e;
+		return -1;
+	}
+	*n_out = all.size() / 7;
+	*out = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, all.size()));
+	memcpy(*out, all.data(), sizeof(int32_t) * all.size());
+	return 0;
 }
 
 // a17: hairpin / homodimer Tm of one oligo and the heterodimer Tm of two (tntblast_local.cpp:656-686)

@@ -280,6 +280,26 @@ def test_structure_vs_oracle(Engine, oracle):
     e.close()
 
 
+@pytest.mark.parametrize("cfg,nt,na,seed,kw", [(2, 2000, 48, 31, {}), (3, 2000, 48, 32, {}), (4, 600, 60, 33, {}),
+                                                (3, 1500, 24, 34, {"max_len": 150, "single_primer_pcr": 0}),
+                                                (2, 800, 24, 35, {"hash_word_size": 5, "max_len": 400}),
+                                                (1, 1000, None, 36, {})])
+def test_first_cull_vs_oracle(Engine, oracle, cfg, nt, na, seed, kw):
+    """Row a4 at unit level: the seeds the seed kernel hands to the bind stage (amplicon()'s early exits + the first
+    cull_oligo_match, decided per seed without sorting) and the strand it binds first, against the oracle's list-based
+    restatement (which tests/test_oracle_vs_reference.py::test_first_cull holds against the reference's own functions)."""
+    wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
+    for k, v in kw.items():
+        setattr(wl.options, k, v)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    got = e.first_cull(db)
+    want = oracle.first_cull(wl.options, wl.expanded, wl.codes, wl.offsets)
+    assert sorted(map(tuple, got)) == sorted(map(tuple, want)) and len(want) > 100
+    db.close()
+    e.close()
+
+
 @pytest.mark.parametrize("kind,seed", [("probe", 1), ("probe", 2), ("padlock", 3), ("pcr", 4), ("pcr", 5)])
 def test_long_oligos_vs_oracle(Engine, oracle, kind, seed):
     """Oligos of 65..128 bases run through the 128-row instances (rows in scratch memory, no pre-filter): binds through all

@@ -218,6 +218,23 @@ class _CpuImpl:
         return hits
 
 
+    def first_cull(self, opt, expanded, codes, offsets, first=0):
+        """Rows (seq_index, assay, role, strand, query_loc, target_loc, minus_first) of the seeds that survive amplicon()'s
+        early exits and the first cull (PCR assays)."""
+        codes, pc = as_u8(codes)
+        offsets, po = as_u64(offsets)
+        arr = c_assays(expanded)
+        f = getattr(self.lib, self.prefix + "first_cull")
+        f.argtypes = [C.POINTER(abi.tnt_options), C.POINTER(abi.tnt_assay), C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
+                      C.c_size_t, C.c_uint32, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_size_t)]
+        out = C.POINTER(C.c_int32)()
+        n = C.c_size_t()
+        rc = f(C.byref(opt), arr, len(expanded), pc, po, len(offsets) - 1, first, C.byref(out), C.byref(n))
+        assert rc == 0, self.error()
+        rows = np.ctypeslib.as_array(out, shape=(max(1, n.value), 7))[:n.value].copy()
+        self._free(out)
+        return rows
+
     def structure(self, opt, a, b=None, ct_a=9.0e-7, ct_b=9.0e-7):
         """(hairpin, homodimer, heterodimer) Tm of tntblast_local.cpp:656-686 as float32 bit patterns."""
         h, d, x = C.c_float(), C.c_float(), C.c_float()

@@ -519,6 +519,7 @@ struct tnt_ctx {
 	tnt_hit *h_hits = nullptr; // pinned host buffer the hit records are copied into (library owned)
 	size_t h_hits_cap = 0;
 	std::vector<tnt_seed> h_seeds;
+	std::vector<int32_t> h_cull_rows; // tnt_first_cull
 	tnt_timing timing;
 	std::vector<hipEvent_t> events;
 	size_t n_batches = 0;
@@ -2651,6 +2652,65 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 	ctx->h_seeds.swap(out);
 	*seeds = ctx->h_seeds.data();
 	*n_seeds = ctx->h_seeds.size();
+	return TNT_OK;
+}
+
+int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_rows)
+{
+	if (!ctx || !db || db->ctx != ctx || !rows || !n_rows) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "a search is pending on this context: collect it first";
+		return TNT_E_ARG;
+	}
+	if (!db->h_long_targets.empty()) {
+		ctx->err = "tnt_first_cull: the lists of targets seeded in windows are culled on the host (search_long_targets)";
+		return TNT_E_UNSUPPORTED;
+	}
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx, ctx->lmax);
+	if (rc) return rc;
+	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+	ctx->events.clear();
+	ctx->dev_hits_valid = false;
+	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	size_t tpb = 1;
+	rc = plan(ctx, db, tpb);
+	if (rc) return rc;
+	ctx->h_cull_rows.clear();
+	std::vector<Item> items;
+	std::vector<Group> groups;
+	const size_t n_units = db->n_short_units, item_region = ITEM_CAP / N_SHARD, group_region = GROUP_CAP / N_SHARD;
+	for (size_t u0 = 0; u0 < n_units; u0 += tpb) {
+		// a whole batch of the search (the stages behind the seed kernel run too; their results are not looked at)
+		rc = enqueue_batch(ctx, db, u0, std::min(n_units, u0 + tpb), false);
+		if (rc) return rc;
+		uint32_t cnt[C_COUNT];
+		HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		if (cnt[C_ERR]) {
+			ctx->err = err_text(cnt[C_ERR]);
+			return TNT_E_LIMIT;
+		}
+		for (uint32_t r = 0; r < N_SHARD; r++) {
+			const uint32_t ni = cnt[C_ITEMS + r * SHARD_STRIDE], ng = cnt[C_GROUPS + r * SHARD_STRIDE];
+			if (!ni) continue;
+			items.resize(ni);
+			groups.resize(ng);
+			HIP_TRY(hipMemcpy(items.data(), ctx->items.p + r * item_region, ni * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
+			HIP_TRY(hipMemcpy(groups.data(), ctx->groups.p + r * group_region, ng * sizeof(Group), hipMemcpyDeviceToHost), ctx->err);
+			for (const Item &it : items) {
+				const uint32_t slot = it.info >> ITEM_SLOT_SHIFT, assay = slot / 3u;
+				if (ctx->h_assays[assay].kind != 0) continue; // probe / padlock lists are not culled (every seed is an item)
+				const Group &g = groups[it.group - r * group_region];
+				const int32_t row[7] = {int32_t(db->first_seq_index + it.target), int32_t(assay), int32_t(slot % 3u),
+				                        (it.info & ITEM_MINUS) ? TNT_MINUS : TNT_PLUS, int32_t(it.info & 127u), int32_t(it.tloc),
+				                        (g.assay & GROUP_MINUS_FIRST) ? 1 : 0};
+				ctx->h_cull_rows.insert(ctx->h_cull_rows.end(), row, row + 7);
+			}
+		}
+	}
+	*rows = ctx->h_cull_rows.data();
+	*n_rows = ctx->h_cull_rows.size() / 7;
 	return TNT_OK;
 }
 

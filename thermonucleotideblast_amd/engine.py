@@ -108,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device", "tnt_search_hits_compact", "tnt_hits_unpack",
-    "tnt_last_timing", "tnt_seeds", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
+    "tnt_last_timing", "tnt_seeds", "tnt_first_cull", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_info", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
 ]
@@ -329,6 +329,17 @@ class Engine:
         n = C.c_size_t()
         self._check(self.lib.tnt_seeds(self._h, batch._h, C.byref(s), C.byref(n)))
         return [(s[i].seq_index, self.oligos[s[i].oligo], s[i].strand, s[i].query_loc, s[i].target_loc) for i in range(n.value)]
+
+    def first_cull(self, batch):
+        """(n, 7) int32 rows (seq_index, assay, role, strand, query_loc, target_loc, minus_first): the seeds of the PCR assays
+        that survive amplicon()'s early exits and the first cull (tnt_first_cull)."""
+        import numpy as np
+        rows = C.POINTER(C.c_int32)()
+        n = C.c_size_t()
+        self._check(self.lib.tnt_first_cull(self._h, batch._h, C.byref(rows), C.byref(n)))
+        if not n.value:
+            return np.zeros((0, 7), dtype=np.int32)
+        return np.ctypeslib.as_array(rows, shape=(n.value, 7)).copy()
 
     def bind_batch(self, batch, reqs, route=0):
         """route 0: the unit-level kernel instance (full record); 1: the throughput instances a search runs, queue split
