@@ -20,6 +20,7 @@
 #define TNT_BIND_HIP_H
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <stdint.h>
 #include <type_traits>
 #include "tnt_dev.h"
@@ -1242,28 +1243,36 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 				atomicOr(a.err, ERR_TEXT_OVERFLOW);
 				prefix = suffix = 0, bi.k1 = bi.k0;
 			}
+			// (written a dword at a time: every lane writes into a record of its own, so a byte store is a memory request)
 			int o = 0;
-			text[o++] = '5', text[o++] = '\'', text[o++] = ' ';
-			for (int i = 0; i < prefix; i++) text[o++] = base_letter(QUERY(bi.fm_q - prefix + i));
-			for (int k = bi.k0; k < bi.k1; k++) text[o++] = base_letter(col_q(best[k * BIND_THREADS]));
-			for (int i = 0; i < suffix; i++) text[o++] = base_letter(QUERY(bi.lm_q + 1 + i));
-			text[o++] = ' ', text[o++] = '3', text[o++] = '\'', text[o++] = '\n';
-			text[o++] = ' ', text[o++] = ' ', text[o++] = ' ';
-			for (int i = 0; i < prefix; i++)
-				text[o++] = is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ';
+			uint32_t acc = 0;
+			static_assert(offsetof(BoundRec, text) % 4 == 0 && offsetof(BindFull, text) % 4 == 0 && sizeof(BoundRec) % 4 == 0 && sizeof(BindFull) % 4 == 0 && ALIGN_TEXT % 4 == 0,
+			              "text fields on 4-byte boundaries");
+			uint32_t *text32 = reinterpret_cast<uint32_t *>(text);
+			auto put = [&](char ch) __attribute__((always_inline)) {
+				acc |= uint32_t(uint8_t(ch)) << ((o & 3) * 8);
+				o++;
+				if ((o & 3) == 0) text32[(o >> 2) - 1] = acc, acc = 0;
+			};
+			put('5'), put('\''), put(' ');
+			for (int i = 0; i < prefix; i++) put(base_letter(QUERY(bi.fm_q - prefix + i)));
+			for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_q(best[k * BIND_THREADS])));
+			for (int i = 0; i < suffix; i++) put(base_letter(QUERY(bi.lm_q + 1 + i)));
+			put(' '), put('3'), put('\''), put('\n');
+			put(' '), put(' '), put(' ');
+			for (int i = 0; i < prefix; i++) put(is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ');
 			for (int k = bi.k0; k < bi.k1; k++) {
 				const uint8_t cw = best[k * BIND_THREADS];
-				text[o++] = is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ';
+				put(is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ');
 			}
-			for (int i = 0; i < suffix; i++)
-				text[o++] = is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ';
-			text[o++] = '\n';
-			text[o++] = '3', text[o++] = '\'', text[o++] = ' ';
-			for (int i = prefix; i > 0; i--) text[o++] = base_letter(TARGET(bi.fm_t + i));
-			for (int k = bi.k0; k < bi.k1; k++) text[o++] = base_letter(col_t(best[k * BIND_THREADS]));
-			for (int i = 1; i <= suffix; i++) text[o++] = base_letter(TARGET(bi.lm_t - i));
-			text[o++] = ' ', text[o++] = '5', text[o++] = '\'';
-			text[o] = 0;
+			for (int i = 0; i < suffix; i++) put(is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ');
+			put('\n');
+			put('3'), put('\''), put(' ');
+			for (int i = prefix; i > 0; i--) put(base_letter(TARGET(bi.fm_t + i)));
+			for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_t(best[k * BIND_THREADS])));
+			for (int i = 1; i <= suffix; i++) put(base_letter(TARGET(bi.lm_t - i)));
+			put(' '), put('5'), put('\'');
+			text32[o >> 2] = acc; // the rest and the terminating zero (acc holds zeros above the characters written)
 			if (rec) rec->text_len = o;
 		}
 #ifdef TNT_EXP_STATS
