@@ -2687,8 +2687,9 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 		uint32_t cnt[C_COUNT];
 		HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
-		if (cnt[C_ERR]) {
-			ctx->err = err_text(cnt[C_ERR]);
+		const uint32_t err = cnt[C_ERR] & ~(ERR_HIT_OVERFLOW | ERR_POOL_OVERFLOW); // (the stages behind the seed kernel are not looked at)
+		if (err) {
+			ctx->err = err_text(err);
 			return TNT_E_LIMIT;
 		}
 		for (uint32_t r = 0; r < N_SHARD; r++) {
