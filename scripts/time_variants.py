@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 from thermonucleotideblast_amd import synth
 from thermonucleotideblast_amd.engine import Engine
 cfg = int(os.environ.get("CFG", "2")); nt = int(os.environ.get("NT", "100000"))
-wl = synth.make_workload(cfg, n_targets=nt)
+na = os.environ.get("NA")
+wl = synth.make_workload(cfg, n_targets=nt, n_assays=int(na) if na else None)
 eng = Engine(wl.options, wl.expanded)
 db = eng.pack(wl.codes, wl.offsets)
 for rep in range(3):
