@@ -76,7 +76,9 @@ def test_cli_front_end_builds_and_validates_arguments(hip_lib):
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--dinkelbach", "T"], capture_output=True, text=True)
     assert r.returncode != 0 and "Unable to open x" in r.stderr  # accepted
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "-D", "z"], capture_output=True, text=True)
-    assert r.returncode != 0 and "not supported" in r.stderr
+    assert r.returncode != 0 and "but not both" in r.stderr  # options.cpp:535
+    r = subprocess.run([g.CLI, "-i", "x", "-D", "z"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unable to open x" in r.stderr  # -D alone names the database like -d
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--max-target-len", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "max-target-len" in r.stderr
     r = subprocess.run([g.CLI, "-i", "x", "-d", "y", "--query-seg", "sometimes"], capture_output=True, text=True)

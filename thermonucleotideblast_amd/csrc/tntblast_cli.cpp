@@ -52,7 +52,7 @@ bool parse_bool(const char *s) // options.cpp parse_bool: T / F (any case), TRUE
 }
 
 struct Options {
-	std::string input, output, dbase;
+	std::string input, output, dbase, local_dbase;
 	tnt_options t;
 	bool have_primer_bounds = false, have_probe_bounds = false;
 	bool show_alignments = true, show_sequence = true, append_name = false, ignore_probe = false, rescale_ct = true;
@@ -854,13 +854,15 @@ void parse_args(int argc, char **argv, Options &o)
 		case 'r':
 			o.mask = parse_bool(optarg) ? (o.mask | Options::REPLACE_PRIMERS) : (o.mask & ~Options::REPLACE_PRIMERS);
 			break;
-		case 'D': fail("-D (local database) is not supported by the MI355X front end");
+		case 'D': o.local_dbase = optarg; break; // a database only the master node sees (options.cpp:288, tntblast_local.cpp:186-193): read like -d here
 		case 'h':
 		case '?': usage(); exit(EXIT_SUCCESS);
 		default: std::cerr << '"' << char(c) << "\" is not a valid option!" << std::endl; break;
 		}
 	}
-	if (o.dbase.empty()) fail("Unable to read either dbase or local_dbase");
+	if (o.dbase.empty() && o.local_dbase.empty()) fail("Unable to read either dbase or local_dbase"); // options.cpp:531-537
+	if (!o.dbase.empty() && !o.local_dbase.empty()) fail("Please specify either dbase or local_dbase (but not both)");
+	if (o.dbase.empty()) o.dbase = o.local_dbase;
 	if (o.input.empty()) fail("Please specify an assay file (-i)");
 	// validate_parameters, options.cpp:529-675 (the checks that concern the supported flags)
 	if (o.ignore_probe && o.t.assay_format != TNT_ASSAY_PCR) fail("Error: Ignore probes (i.e. -p T) can only be used with a PCR-based assay format");
