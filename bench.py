@@ -359,7 +359,7 @@ def main():
                 # rate: 1 024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction
                 si = rec.get("seed_kernel_insts_per_step")
                 if si and seed_ms_step > 0:
-                    # the seed stage is a chain of short dependent per-target steps: ~5 700 wave-instructions per target
+                    # the seed stage is a chain of short dependent per-target steps: ~5 200 wave-instructions per target
                     n_all, n_v = sum(si.values()), si["SQ_INSTS_VALU"]
                     seed_issue = {"wave_instructions_per_step": n_all, "valu_wave_instructions_per_step": n_v, "unit": "wave-instructions/s",
                                   "achieved_all": n_all / (seed_ms_step * 1e-3), "achieved_valu": n_v / (seed_ms_step * 1e-3),
