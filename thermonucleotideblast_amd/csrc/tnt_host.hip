@@ -2079,14 +2079,20 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 // keeps, through the same bucket -> pre-filter -> bind kernels as everything else) on the device; its seed lists are
 // merged per (target, assay) on the host, where the first cull, the bind / cull sequence and the pairing loops run on the
 // complete lists with the code the pair kernel runs (tnt_pair.hip.h is compiled for both sides).
-static void run_with_stack(size_t bytes, void *(*fn)(void *), void *arg)
+// `n` workers with stacks of `bytes` (the host lists are large): fn gets its argument n times, the workers share a work
+// counter inside it
+static void run_threads_with_stack(unsigned n, size_t bytes, void *(*fn)(void *), void *arg)
 {
 	pthread_attr_t attr;
 	pthread_attr_init(&attr);
 	pthread_attr_setstacksize(&attr, bytes);
-	pthread_t th;
-	if (pthread_create(&th, &attr, fn, arg) == 0) pthread_join(th, nullptr);
-	else fn(arg); // (falls back to the caller's stack; lists that need more than it has are rare)
+	std::vector<pthread_t> th;
+	for (unsigned w = 0; w < n; w++) {
+		pthread_t t;
+		if (pthread_create(&t, &attr, fn, arg) == 0) th.push_back(t);
+	}
+	if (th.empty()) fn(arg); // (falls back to the caller's thread and stack)
+	for (pthread_t t : th) pthread_join(t, nullptr);
 	pthread_attr_destroy(&attr);
 }
 
@@ -2104,6 +2110,7 @@ struct LongJob {
 	std::vector<uint8_t> *valid;            // per item of all_items
 	std::vector<uint8_t> *minus_first;      // per segment
 	bool overflow;
+	std::atomic<size_t> next{0};            // the workers take the lists / groups one at a time
 };
 
 static void *long_job_main(void *p)
@@ -2112,7 +2119,8 @@ static void *long_job_main(void *p)
 	if (J.mode == 0) {
 		ListT<PAIR_HOST> *l = new ListT<PAIR_HOST>;
 		const std::vector<Item> &items = *J.all_items;
-		for (size_t g = 0; g + 1 < J.seg_begin->size(); g++) {
+		const size_t n_seg = J.seg_begin->size() - 1;
+		for (size_t g = J.next.fetch_add(1); g < n_seg; g = J.next.fetch_add(1)) {
 			const uint32_t b = (*J.seg_begin)[g], e = (*J.seg_begin)[g + 1];
 			const AssayDev &A = J.ctx->h_assays[(*J.seg_assay)[g]];
 			if (e - b > uint32_t(PAIR_HOST)) {
@@ -2140,7 +2148,8 @@ static void *long_job_main(void *p)
 		}
 		delete l;
 	} else {
-		for (const Group &G : *J.groups) pair_group<PAIR_HOST>(J.args, G);
+		const size_t n_grp = J.groups->size();
+		for (size_t g = J.next.fetch_add(1); g < n_grp; g = J.next.fetch_add(1)) pair_group<PAIR_HOST>(J.args, (*J.groups)[g]);
 	}
 	return nullptr;
 }
@@ -2149,6 +2158,14 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 {
 	const size_t u0 = db->n_short_units, u1 = db->h_unit_target.size();
 	if (u0 >= u1) return TNT_OK;
+	const bool timing = getenv("TNT_MI355X_LONG_TIMING") != nullptr; // phase times of this path on stderr
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "long targets: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	if (hipError_t stale = hipGetLastError()) { // nothing before this point may have failed
 		ctx->err = std::string("before the long-target path: ") + hipGetErrorString(stale);
@@ -2204,46 +2221,63 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		break;
 	}
 	if (raw.empty()) return TNT_OK;
+	lap("seed windows + copy");
 
-	// ---- per (target, assay) lists in the reference's list order
-	std::vector<Item> items(raw.size());
-	std::vector<unsigned long long> key(raw.size());
-	std::vector<uint32_t> order(raw.size());
-	for (size_t i = 0; i < raw.size(); i++) {
-		const SeedOut &sd = raw[i];
-		const uint32_t assay = sd.assay_role >> 2, role = sd.assay_role & 3u;
-		const AssayDev &A = ctx->h_assays[assay];
-		items[i] = Item{sd.target, sd.target_loc, sd.query_loc | (sd.strand_minus ? ITEM_MINUS : 0u) | ((assay * 3u + role) << ITEM_SLOT_SHIFT), 0};
-		// the order of seed_key (tnt_seed.hip.h): PCR lists by (target_loc, assembly group F- R- F+ R+ P- P+, word);
-		// hash-overload lists by (list, diagonal, word)
-		unsigned long long k;
-		if (A.kind == 0) {
-			const unsigned long long rank = role == 2 ? (sd.strand_minus ? 4u : 5u) : ((sd.strand_minus ? 0u : 2u) + role);
-			k = ((unsigned long long)sd.target_loc << 24) | (rank << 21) | ((unsigned long long)sd.query_loc << 14);
-		} else {
-			const unsigned long long listid = (sd.strand_minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
-			k = (listid << 54) | ((unsigned long long)(long(sd.query_loc) - long(sd.target_loc) + (1l << 33)) << 20) | ((unsigned long long)sd.query_loc << 13);
+	// ---- per (target, assay) lists in the reference's list order: a counting sort into (target, assay) buckets, then
+	// every bucket by its keys (the buckets on several threads)
+	struct Keyed {
+		unsigned long long key;
+		Item item;
+	};
+	const size_t n_assays_all = ctx->h_assays.size();
+	std::vector<uint32_t> long_targets; // the targets these windows belong to, ascending
+	for (size_t u = u0; u < u1; u++)
+		if (long_targets.empty() || long_targets.back() != db->h_unit_target[u]) long_targets.push_back(db->h_unit_target[u]);
+	std::sort(long_targets.begin(), long_targets.end());
+	long_targets.erase(std::unique(long_targets.begin(), long_targets.end()), long_targets.end());
+	auto bucket_of_seed = [&](const SeedOut &sd) {
+		const size_t tr = size_t(std::lower_bound(long_targets.begin(), long_targets.end(), sd.target) - long_targets.begin());
+		return tr * n_assays_all + size_t(sd.assay_role >> 2);
+	};
+	const size_t n_buckets = long_targets.size() * n_assays_all;
+	std::vector<uint32_t> bucket_first(n_buckets + 1, 0);
+	for (const SeedOut &sd : raw) bucket_first[bucket_of_seed(sd) + 1]++;
+	for (size_t b = 0; b < n_buckets; b++) bucket_first[b + 1] += bucket_first[b];
+	std::vector<Keyed> keyed(raw.size());
+	{
+		std::vector<uint32_t> cursor(bucket_first.begin(), bucket_first.end() - 1);
+		for (const SeedOut &sd : raw) {
+			const uint32_t assay = sd.assay_role >> 2, role = sd.assay_role & 3u;
+			const AssayDev &A = ctx->h_assays[assay];
+			// the order of seed_key (tnt_seed.hip.h): PCR lists by (target_loc, assembly group F- R- F+ R+ P- P+, word);
+			// hash-overload lists by (list, diagonal, word)
+			unsigned long long k;
+			if (A.kind == 0) {
+				const unsigned long long rank = role == 2 ? (sd.strand_minus ? 4u : 5u) : ((sd.strand_minus ? 0u : 2u) + role);
+				k = ((unsigned long long)sd.target_loc << 24) | (rank << 21) | ((unsigned long long)sd.query_loc << 14);
+			} else {
+				const unsigned long long listid = (sd.strand_minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
+				k = (listid << 54) | ((unsigned long long)(long(sd.query_loc) - long(sd.target_loc) + (1l << 33)) << 20) | ((unsigned long long)sd.query_loc << 13);
+			}
+			Keyed &o = keyed[cursor[bucket_of_seed(sd)]++];
+			o.key = k;
+			o.item = Item{sd.target, sd.target_loc, sd.query_loc | (sd.strand_minus ? ITEM_MINUS : 0u) | ((assay * 3u + role) << ITEM_SLOT_SHIFT), 0};
 		}
-		key[i] = k;
-		order[i] = uint32_t(i);
 	}
-	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-		if (items[x].target != items[y].target) return items[x].target < items[y].target;
-		const uint32_t ax = (items[x].info >> ITEM_SLOT_SHIFT) / 3u, ay = (items[y].info >> ITEM_SLOT_SHIFT) / 3u;
-		if (ax != ay) return ax < ay;
-		return key[x] < key[y];
+	parallel_for_each(n_buckets, [&](size_t b) {
+		std::sort(keyed.begin() + bucket_first[b], keyed.begin() + bucket_first[b + 1], [](const Keyed &x, const Keyed &y) { return x.key < y.key; });
 	});
 	std::vector<Item> sorted(raw.size());
 	std::vector<uint32_t> seg_begin, seg_assay;
-	for (size_t i = 0; i < order.size(); i++) {
-		sorted[i] = items[order[i]];
-		const uint32_t assay = (sorted[i].info >> ITEM_SLOT_SHIFT) / 3u;
-		if (i == 0 || sorted[i].target != sorted[i - 1].target || assay != seg_assay.back()) {
-			seg_begin.push_back(uint32_t(i));
-			seg_assay.push_back(assay);
-		}
+	for (size_t b = 0; b < n_buckets; b++) {
+		if (bucket_first[b] == bucket_first[b + 1]) continue;
+		seg_begin.push_back(bucket_first[b]);
+		seg_assay.push_back(uint32_t(b % n_assays_all));
+		for (uint32_t i = bucket_first[b]; i < bucket_first[b + 1]; i++) sorted[i] = keyed[i].item;
 	}
 	seg_begin.push_back(uint32_t(sorted.size()));
+	std::vector<Keyed>().swap(keyed);
+	lap("keys + sort");
 
 	// ---- first cull of every list (amplicon_search.cpp:128-131) on the host
 	std::vector<uint8_t> valid(sorted.size(), 0), minus_first(seg_assay.size(), 0);
@@ -2258,12 +2292,15 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	job.minus_first = &minus_first;
 	job.overflow = false;
 	job.groups = nullptr;
-	run_with_stack(size_t(64) << 20, long_job_main, &job);
+	const unsigned workers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	job.next = 0;
+	run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job);
 	if (job.overflow) {
 		ctx->err = "more than 32768 seeds of one assay on one target";
 		return TNT_E_LIMIT;
 	}
 
+	lap("first cull");
 	// ---- the kept seeds become bind work items, grouped per (target, assay)
 	std::vector<Item> bind_items;
 	std::vector<Group> groups;
@@ -2281,6 +2318,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	}
 	if (bind_items.empty()) return TNT_OK;
 
+	lap("work items");
 	// ---- bind them on the device, a million at a time: bucket -> pre-filter -> bind, as a search phase does
 	const DbView v = make_view(db, 0, db->n_targets);
 	std::vector<int32_t> result(bind_items.size(), -1);
@@ -2317,6 +2355,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		ctx->acc_items += nc;
 	}
 
+	lap("bind on the device");
 	// ---- the bind / cull sequence and the pairing loops on the whole lists (pair_group, compiled for the host)
 	std::vector<Hit> hits(std::max<size_t>(1024, pool.size() * 2));
 	for (;;) {
@@ -2344,7 +2383,8 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		p.unit_own_hi = own_hi.data();
 		job.mode = 1;
 		job.groups = &groups;
-		run_with_stack(size_t(64) << 20, long_job_main, &job);
+		job.next = 0;
+		run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job);
 		if (err & ERR_HIT_OVERFLOW) {
 			hits.resize(hits.size() * 4);
 			continue;
@@ -2357,6 +2397,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		if (n_hits) memcpy(out.data(), hits.data(), size_t(n_hits) * sizeof(tnt_hit));
 		break;
 	}
+	lap("pairing");
 	return TNT_OK;
 }
 

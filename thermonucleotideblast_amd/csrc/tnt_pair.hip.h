@@ -30,7 +30,7 @@ namespace tnt {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TNT_SET_ERR(PTR, CODE) atomicOr((PTR), (CODE))
 #else
-#define TNT_SET_ERR(PTR, CODE) (*(PTR) |= (CODE))
+#define TNT_SET_ERR(PTR, CODE) ((void)__atomic_fetch_or((PTR), (CODE), __ATOMIC_RELAXED)) // (the host replay runs on several threads)
 #endif
 
 constexpr int PAIR_THREADS = 64;
@@ -273,7 +273,7 @@ TNT_HD inline Hit *alloc_hit(const PairArgs &a)
 #if defined(__HIP_DEVICE_COMPILE__)
 	const uint32_t o = atomicAdd(a.hit_count, 1u);
 #else
-	const uint32_t o = (*a.hit_count)++;
+	const uint32_t o = __atomic_fetch_add(a.hit_count, 1u, __ATOMIC_RELAXED); // (the host replay runs on several threads)
 #endif
 	if (o >= a.hit_cap) {
 		TNT_SET_ERR(a.err, ERR_HIT_OVERFLOW);
