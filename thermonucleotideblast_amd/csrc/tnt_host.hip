@@ -2395,6 +2395,15 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		}
 		out.resize(n_hits);
 		if (n_hits) memcpy(out.data(), hits.data(), size_t(n_hits) * sizeof(tnt_hit));
+		// The workers took the groups as they came: put the hits back into the order one thread produces -- groups by
+		// (target, assay position), the hits of a group in the order its worker wrote them (a worker's slots ascend) --, so
+		// that the output does not depend on the scheduling.
+		std::map<std::pair<int32_t, int32_t>, uint32_t> position; // (assay id, degen id) -> first position in the assay list
+		for (size_t ai = ctx->h_assays.size(); ai-- > 0;) position[{ctx->h_assays[ai].id, ctx->h_assays[ai].degen_id}] = uint32_t(ai);
+		std::stable_sort(out.begin(), out.end(), [&](const tnt_hit &x, const tnt_hit &y) {
+			if (x.seq_index != y.seq_index) return x.seq_index < y.seq_index;
+			return position[{x.assay_id, x.degen_id}] < position[{y.assay_id, y.degen_id}];
+		});
 		break;
 	}
 	lap("pairing");
