@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNT_ABI_VERSION 3
+#define TNT_ABI_VERSION 4
 
 /* Longest oligo the gfx950 bind kernels accept (reference cap: MAX_SEQUENCE_LENGTH
  * 1024, nuc_cruc.h:80).  Up to 64 bases the rows of the alignment live in
@@ -178,6 +178,10 @@ int tnt_ctx_delta_g(const tnt_ctx *ctx, int32_t *out2401);
 int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, size_t n_targets,
                   uint32_t first_seq_index, tnt_db **out);
 void tnt_db_destroy(tnt_db *db);
+/* Leave targets out of every later search of this database (skip[i] != 0; targets from n on are searched): the reference
+ * never searches a record longer than --max-target-len whole, only its fragments (tntblast_local.cpp:282-289,438-468),
+ * so a front end marks such records here and searches their fragments as a database of their own.               */
+int tnt_db_skip_targets(tnt_ctx *ctx, tnt_db *db, const uint8_t *skip, size_t n);
 size_t tnt_db_num_targets(const tnt_db *db);
 uint64_t tnt_db_num_bases(const tnt_db *db);
 

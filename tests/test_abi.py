@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol(hip_lib):
     assert sorted(engine.EXPORTED_SYMBOLS) == syms
     for s in syms:
         assert hasattr(hip_lib, s), s
-    assert hip_lib.tnt_abi_version() == 3
+    assert hip_lib.tnt_abi_version() == 4
 
 
 def test_struct_layouts_match_header(hip_lib):
@@ -87,3 +87,18 @@ def test_cli_front_end_builds_and_validates_arguments(hip_lib):
     assert r.returncode != 0 and "Unable to open x" in r.stderr  # both accepted: the run gets as far as the assay file
     r = subprocess.run([g.CLI, "-i", "x"], capture_output=True, text=True)
     assert r.returncode != 0 and "dbase" in r.stderr
+
+
+def test_hits_unpack_rejects_corrupt_blobs(hip_lib):
+    """tnt_hits_unpack is host code: a truncated or corrupt blob from a peer rank is refused before its count is
+    handed out (a count the blob cannot hold would make the caller allocate for it)."""
+    import struct
+    n = C.c_size_t(123)
+    blob = struct.pack("<II", 4_000_000_000, 16) + b"\0" * 8          # count far beyond what 16 bytes hold
+    assert hip_lib.tnt_hits_unpack(blob, len(blob), None, 0, C.byref(n)) == -1 and n.value == 0
+    blob = struct.pack("<II", 0, 4)                                    # total below the header size
+    assert hip_lib.tnt_hits_unpack(blob, len(blob), None, 0, C.byref(n)) == -1
+    blob = struct.pack("<II", 0, 64)                                   # total beyond the bytes handed over
+    assert hip_lib.tnt_hits_unpack(blob, len(blob), None, 0, C.byref(n)) == -1
+    blob = struct.pack("<II", 0, 8)                                    # the empty blob
+    assert hip_lib.tnt_hits_unpack(blob, len(blob), None, 0, C.byref(n)) == 0 and n.value == 0

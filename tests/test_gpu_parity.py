@@ -29,7 +29,7 @@ def _oligo_set(expanded):
 def test_native_library_is_loaded(Engine):
     from thermonucleotideblast_amd import engine
     lib = engine.load_library()
-    assert lib.tnt_abi_version() == 3
+    assert lib.tnt_abi_version() == 4
     assert any("libtnt_mi355x.so" in line for line in open("/proc/self/maps"))
 
 

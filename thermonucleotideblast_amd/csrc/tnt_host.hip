@@ -428,6 +428,8 @@ struct tnt_db {
 	size_t n_short_units = 0;       // units [0, n_short_units) are whole targets, the rest windows of long targets
 	std::vector<uint32_t> h_long_targets; // targets that are seeded in windows and paired on the host
 	bool split = false;             // some target is cut into windows
+	bool all_long = false;          // a whole-target work unit overflowed its seed list with one assay per pass: every target is seeded in windows
+	std::vector<uint8_t> h_skip;    // per target: 1 = not searched (tnt_db_skip_targets)
 	uint64_t n_exceptions = 0;
 	std::string deflines;           // FASTA ingest: all deflines back to back
 	std::vector<uint64_t> defline_off;
@@ -1213,7 +1215,9 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 	for (const auto &ae : ctx->assay_entries) max_ent = std::max(max_ent, ae.size());
 	const double dense = 128.0 * double(size_t(1) << (2 * k)) / double(max_ent);
 	uint32_t stride = uint32_t(std::max(128.0, std::min(double(UNIT_STRIDE), dense)));
-	// after a seed-list overflow with single-assay chunks the windows shrink
+	// after a seed-list overflow with single-assay chunks the windows shrink.  The split into whole targets and windowed
+	// ones does NOT depend on unit_scale: search_long_targets halves it and rebuilds the units after the whole targets' hits
+	// were collected, so a target must not change sides then (it would be reported twice).
 	if (ctx->unit_scale < 1.0) stride = std::max<uint32_t>(64u, uint32_t(double(stride) * ctx->unit_scale));
 	db->h_unit_target.clear(), db->h_unit_begin.clear(), db->h_unit_end.clear();
 	db->h_unit_own_lo.clear(), db->h_unit_own_hi.clear();
@@ -1229,10 +1233,11 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 		const uint32_t len = db->h_len[t];
 		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
 		const double expect = double(npos) * double(max_ent) / double(size_t(1) << (2 * k));
-		return !(expect <= 256.0 && npos <= 32768u && ctx->unit_scale >= 1.0);
+		return !(expect <= 256.0 && npos <= 32768u) || db->all_long;
 	};
+	auto skipped = [&](size_t t) { return t < db->h_skip.size() && db->h_skip[t] != 0; };
 	for (size_t t = 0; t < db->n_targets; t++) {
-		if (is_long(t)) continue;
+		if (is_long(t) || skipped(t)) continue;
 		const uint32_t len = db->h_len[t];
 		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
 		db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
@@ -1241,8 +1246,9 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 	}
 	db->n_short_units = db->h_unit_target.size();
 	for (size_t t = 0; t < db->n_targets; t++) {
-		if (!is_long(t)) continue;
+		if (!is_long(t) || skipped(t)) continue;
 		const uint32_t len = db->h_len[t];
+		if (len < uint32_t(k)) continue; // (only reachable with all_long: nothing to seed, tntblast_local.cpp:513)
 		const uint32_t npos = len - uint32_t(k) + 1u;
 		db->split = true;
 		db->h_long_targets.push_back(uint32_t(t));
@@ -1292,7 +1298,7 @@ int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, s
 		words += ((len + 15) / 16 + 3) / 4 * 4; // 16-byte aligned rows: a wavefront reads whole dwordx4 lines
 	}
 	db->h_word_off[n_targets] = words;
-	db->h_packed.assign(words + 4, 0u);
+	db->h_packed.assign(words + 8, 0u); // slack: the window loaders read up to six words from a window's first word
 	// exceptions: count first (codes > 3 keep their low two bits in the stream)
 	std::vector<uint32_t> exc_count(n_targets + 1, 0);
 	parallel_for(n_targets, [&](size_t t) {
@@ -1348,6 +1354,17 @@ void tnt_db_destroy(tnt_db *db)
 		if (c->pending_db == db) c->pending_db = nullptr;
 	}
 	delete db;
+}
+
+int tnt_db_skip_targets(tnt_ctx *ctx, tnt_db *db, const uint8_t *skip, size_t n)
+{
+	if (!ctx || !db || db->ctx != ctx || (!skip && n) || n > db->n_targets) return TNT_E_ARG;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	db->h_skip.assign(db->n_targets, 0);
+	for (size_t t = 0; t < n; t++) db->h_skip[t] = skip[t] ? 1 : 0;
+	HIP_TRY(build_units(ctx, db), ctx->err);
+	return TNT_OK;
 }
 
 size_t tnt_db_num_targets(const tnt_db *db) { return db ? db->n_targets : 0; }
@@ -1572,10 +1589,10 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	}
 	db->h_word_off[n] = words;
 	db->n_exceptions = db->h_exc_off[n];
-	if ((e = db->packed.alloc(words + 4)) != hipSuccess || (e = db->word_off.upload(db->h_word_off)) != hipSuccess ||
+	if ((e = db->packed.alloc(words + 8)) != hipSuccess || (e = db->word_off.upload(db->h_word_off)) != hipSuccess ||
 	    (e = db->exc_off.upload(db->h_exc_off)) != hipSuccess || (e = db->exc_pos.alloc(std::max<uint64_t>(1, db->n_exceptions))) != hipSuccess ||
 	    (e = db->exc_code.alloc(std::max<uint64_t>(1, db->n_exceptions))) != hipSuccess ||
-	    (e = hipMemsetAsync(db->packed.p, 0, (words + 4) * sizeof(uint32_t), ctx->stream)) != hipSuccess) {
+	    (e = hipMemsetAsync(db->packed.p, 0, (words + 8) * sizeof(uint32_t), ctx->stream)) != hipSuccess) {
 		ctx->err = std::string("target allocation: ") + hipGetErrorString(e);
 		return TNT_E_DEVICE;
 	}
@@ -2081,7 +2098,7 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 // complete lists with the code the pair kernel runs (tnt_pair.hip.h is compiled for both sides).
 // `n` workers with stacks of `bytes` (the host lists are large): fn gets its argument n times, the workers share a work
 // counter inside it
-static void run_threads_with_stack(unsigned n, size_t bytes, void *(*fn)(void *), void *arg)
+static bool run_threads_with_stack(unsigned n, size_t bytes, void *(*fn)(void *), void *arg)
 {
 	pthread_attr_t attr;
 	pthread_attr_init(&attr);
@@ -2091,9 +2108,9 @@ static void run_threads_with_stack(unsigned n, size_t bytes, void *(*fn)(void *)
 		pthread_t t;
 		if (pthread_create(&t, &attr, fn, arg) == 0) th.push_back(t);
 	}
-	if (th.empty()) fn(arg); // (falls back to the caller's thread and stack)
 	for (pthread_t t : th) pthread_join(t, nullptr);
 	pthread_attr_destroy(&attr);
+	return !th.empty(); // no worker at all: the caller fails (fn needs the large stack, it must not run on the caller's)
 }
 
 struct LongJob {
@@ -2109,7 +2126,7 @@ struct LongJob {
 	const tnt_ctx *ctx;
 	std::vector<uint8_t> *valid;            // per item of all_items
 	std::vector<uint8_t> *minus_first;      // per segment
-	bool overflow;
+	std::atomic<bool> overflow{false};
 	std::atomic<size_t> next{0};            // the workers take the lists / groups one at a time
 };
 
@@ -2201,6 +2218,12 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 			if (ctx->chunk_begin.size() < ctx->h_assays.size() + 1) {
 				ctx->chunk_scale *= 0.5;
 			} else {
+				if (ctx->unit_scale < 1.0 / 64.0) { // the windows are at their shortest already
+					ctx->err = err_text(ERR_SEED_OVERFLOW);
+					return TNT_E_LIMIT;
+				}
+				// shorter windows for the targets that are seeded in windows; the whole targets (units below u0, already
+				// searched and collected) stay what they are: build_units does not look at unit_scale for the split
 				ctx->unit_scale *= 0.5;
 				HIP_TRY(build_units(ctx, db), ctx->err);
 				return search_long_targets(ctx, db, out); // the unit ranges changed
@@ -2294,7 +2317,10 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	job.groups = nullptr;
 	const unsigned workers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 	job.next = 0;
-	run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job);
+	if (!run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job)) {
+		ctx->err = "could not start a host thread for the lists of long targets";
+		return TNT_E_DEVICE;
+	}
 	if (job.overflow) {
 		ctx->err = "more than 32768 seeds of one assay on one target";
 		return TNT_E_LIMIT;
@@ -2384,7 +2410,10 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		job.mode = 1;
 		job.groups = &groups;
 		job.next = 0;
-		run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job);
+		if (!run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job)) {
+			ctx->err = "could not start a host thread for the lists of long targets";
+			return TNT_E_DEVICE;
+		}
 		if (err & ERR_HIT_OVERFLOW) {
 			hits.resize(hits.size() * 4);
 			continue;
@@ -2472,7 +2501,10 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 				if (ctx->chunk_begin.size() < ctx->h_assays.size() + 1) {
 					ctx->chunk_scale *= 0.5;
 				} else {
-					ctx->unit_scale *= 0.5;
+					// a whole target overflowed with one assay per pass: this database is seeded in windows throughout (the
+					// search restarts from scratch below, so no hit is reported twice)
+					if (ctx->pending_db->all_long) ctx->unit_scale *= 0.5;
+					ctx->pending_db->all_long = true;
 					HIP_TRY(build_units(ctx, ctx->pending_db), ctx->err);
 				}
 			}
@@ -2602,8 +2634,10 @@ int tnt_hits_unpack(const void *blob, size_t n_bytes, tnt_hit *out, size_t cap, 
 	uint32_t n = 0, total = 0;
 	memcpy(&n, p, 4);
 	memcpy(&total, p + 4, 4);
+	*n_hits = 0;
+	// a truncated or corrupt blob (a peer rank's bytes) must not make the caller allocate for a count it cannot hold
+	if (total < 8 || total > n_bytes || 8 + uint64_t(n) * (uint64_t(HIT_POD_BYTES) + 8) > uint64_t(total)) return TNT_E_ARG;
 	*n_hits = n;
-	if (total > n_bytes) return TNT_E_ARG;
 	if (!out) return TNT_OK; // a query for the count
 	if (cap < n) return TNT_E_LIMIT;
 	size_t at = 8;

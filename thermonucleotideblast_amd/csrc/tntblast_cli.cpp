@@ -982,9 +982,12 @@ int main(int argc, char **argv)
 			const tnt_hit *hits = nullptr;
 			size_t n_hits = 0;
 			std::vector<Record> batch; // this batch's records: masked (if asked for), then filed under their assays
+			// (records beyond --max-target-len are not searched whole: only their fragments are, below)
+			if (!long_targets.empty() && tnt_db_skip_targets(ctx, db, reinterpret_cast<const uint8_t *>(is_long.data()), is_long.size()) != TNT_OK)
+				fail(tnt_last_error(ctx));
 			if (tnt_search(ctx, db, &hits, &n_hits) != TNT_OK) fail(tnt_last_error(ctx));
 			for (size_t i = 0; i < n_hits; i++) {
-				if (is_long[size_t(hits[i].seq_index) - first]) continue; // reported by its fragments below
+				if (is_long[size_t(hits[i].seq_index) - first]) continue; // (none: skipped above)
 				Record rec{hits[i], n_seen++, std::string(), std::string()};
 				const int na = tnt_hit_sequence(ctx, db, &hits[i], amp.data(), amp.size());
 				if (na < 0) fail("amplicon longer than the sequence buffer");

@@ -97,7 +97,8 @@ def load_library():
     lib.tnt_db_target_codes.restype = C.c_int64
     lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
     lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
-    if lib.tnt_abi_version() != 3:
+    lib.tnt_db_skip_targets.argtypes = [C.c_void_p, C.c_void_p, P(C.c_uint8), C.c_size_t]
+    if lib.tnt_abi_version() != abi.TNT_ABI_VERSION:
         raise TntError("ABI version mismatch")
     _lib = lib
     return lib
@@ -107,7 +108,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
-    "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device", "tnt_search_hits_compact", "tnt_hits_unpack",
+    "tnt_db_skip_targets", "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device", "tnt_search_hits_compact", "tnt_hits_unpack",
     "tnt_last_timing", "tnt_seeds", "tnt_first_cull", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_info", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
@@ -158,6 +159,11 @@ class TargetBatch:
         engine._check(rc)
         self.n_targets = len(offsets) - 1
         self.n_bases = int(offsets[-1])
+
+    def skip_targets(self, mask):
+        """Leave the targets with mask[i] != 0 out of every later search (tnt_db_skip_targets)."""
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.engine._check(self.engine.lib.tnt_db_skip_targets(self.engine._h, self._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), m.size))
 
     def defline(self, i):
         s, n = C.c_char_p(), C.c_size_t()
