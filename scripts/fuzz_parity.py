@@ -52,7 +52,7 @@ def random_case(rng, case, max_code=18, dangle=True):
     o.max_mismatch = int(pick(999, 999, 1, 4))
     o.max_poly_degen = int(pick(3, 3, 0, 8))
     o.max_len = int(pick(2000, 2000, 150, 400, 0 if cfg == 5 else 800))
-    o.hash_word_size = int(pick(7, 7, 7, 5, 6, 8))
+    o.hash_word_size = int(pick(7, 7, 7, 5, 6, 8, 7, 7, 4, 3))  # (3 and 4: every target is seeded in windows, the seed-list repairs run)
     o.single_primer_pcr = int(pick(1, 1, 0))
     o.allow_dangle_5 = int(pick(0, 0, 1))
     o.allow_dangle_3 = int(pick(0, 0, 1))

@@ -283,7 +283,12 @@ def test_structure_vs_oracle(Engine, oracle):
 @pytest.mark.parametrize("cfg,nt,na,seed,kw", [(2, 2000, 48, 31, {}), (3, 2000, 48, 32, {}), (4, 600, 60, 33, {}),
                                                 (3, 1500, 24, 34, {"max_len": 150, "single_primer_pcr": 0}),
                                                 (2, 800, 24, 35, {"hash_word_size": 5, "max_len": 400}),
-                                                (1, 1000, None, 36, {})])
+                                                (1, 1000, None, 36, {}),
+                                                # targets beyond the reach of the cull (max_len + 50 < target length): the general loop
+                                                (2, 600, 24, 37, {"max_len": 300}),
+                                                (3, 600, 24, 38, {"max_len": 400}),
+                                                (2, 1000, 48, 39, {"single_primer_pcr": 0}),
+                                                (3, 1000, 48, 40, {"single_primer_pcr": 0})])
 def test_first_cull_vs_oracle(Engine, oracle, cfg, nt, na, seed, kw):
     """Row a4 at unit level: the seeds the seed kernel hands to the bind stage (amplicon()'s early exits + the first
     cull_oligo_match, decided per seed without sorting) and the strand it binds first, against the oracle's list-based
@@ -402,6 +407,28 @@ def test_g4_seeds_golden(Engine):
         e.close()
 
 
+def test_g4_g5_short_hash_words_golden(Engine):
+    """-W 3 and -W 4: reference-generated seed lists and hit sets (tests/gen_golden_w34.py)."""
+    fx = gu.load("g4_seeds_w34.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
+    for k, expected in fx["seeds"].items():
+        e = Engine(abi.options_default(hash_word_size=int(k)), ex)
+        db = e.pack(codes, offsets)
+        got = sorted(e.seeds(db))
+        want = sorted((s[0], fx["oligos"][s[1]], s[2], s[3], s[4]) for s in expected)
+        assert got == want, "word size %s" % k
+        db.close()
+        e.close()
+    for case in gu.load("g5_search_w34.json.gz")["cases"]:
+        expanded, codes, offsets = gu.g5_inputs(case)
+        e = Engine(gu.options_from(case["options"]), expanded)
+        db = e.pack(codes, offsets)
+        assert gu.hits_as_keys(e.search(db)) == case["hits"], (case["config"], case["options"]["hash_word_size"])
+        db.close()
+        e.close()
+
+
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
 def test_g5_search_golden(Engine, cfg):
     fx = gu.load("g5_search_cfg%d.json.gz" % cfg)
@@ -464,6 +491,14 @@ def test_g5_readme_example(Engine):
     (2, 800, 40, 48, {"min_primer_tm": 0.0, "max_primer_dg": -8.0, "max_mismatch": 2, "max_gap": 0}),
     (2, 800, 40, 49, {"hash_word_size": 6, "max_len": 250}),
     (2, 800, 40, 50, {"target_t": 330.0, "salt": 0.2, "primer_strand": 2e-7}),
+    # the shortest hash words (options.cpp:639): seed lists so dense that 1-kb targets are seeded in windows and the
+    # chunk-halving / window-shortening repairs run
+    (2, 120, 12, 51, {"hash_word_size": 4}),
+    (3, 60, 8, 52, {"hash_word_size": 3}),
+    (5, 60, 8, 53, {"hash_word_size": 4}),
+    # targets beyond the reach of the first cull, with and without probes
+    (3, 600, 40, 54, {"max_len": 350}),
+    (2, 600, 40, 55, {"max_len": 500, "single_primer_pcr": 0}),
 ])
 def test_search_vs_oracle(Engine, oracle, cfg, nt, na, seed, kw):
     wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
@@ -876,3 +911,74 @@ def test_shared_oligos_are_bound_once(Engine, oracle, monkeypatch):
     db.close()
     e.close()
     assert shared * 3 < every * 2, (shared, every)
+
+
+def test_seed_kernels_agree(Engine, oracle, monkeypatch):
+    """The round-3 seed kernel (tnt_seed2.hip.h: private regions, phase-A items straight into their buckets' queues) and
+    the round-2 one (TNT_MI355X_SEED_V2=1: sharded lists + bucket pass) hand the bind stage the same work and end in the
+    same hits as the oracle."""
+    for cfg, nt, na, kw in ((2, 1500, 96, {}), (3, 1500, 96, {}), (5, 800, 60, {}), (4, 500, 90, {}), (3, 500, 30, {"max_len": 300})):
+        wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=60 + cfg)
+        for k, v in kw.items():
+            setattr(wl.options, k, v)
+        want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+        res = []
+        for old in (False, True):
+            if old:
+                monkeypatch.setenv("TNT_MI355X_SEED_V2", "1")
+            else:
+                monkeypatch.delenv("TNT_MI355X_SEED_V2", raising=False)
+            e = Engine(wl.options, wl.expanded)
+            db = e.pack(wl.codes, wl.offsets)
+            hits = tc.sorted_hit_keys(e.search(db))
+            t = e.timing()
+            cull = sorted(map(tuple, e.first_cull(db))) if wl.options.assay_format == abi.ASSAY_PCR else []
+            res.append((hits, cull, (t.n_seeds, t.n_binds, t.n_bound, t.n_hits)))
+            db.close()
+            e.close()
+        monkeypatch.delenv("TNT_MI355X_SEED_V2", raising=False)
+        assert res[0][0] == want and res[1][0] == want and len(want) > 0, cfg
+        assert res[0][1] == res[1][1], cfg
+        assert res[0][2] == res[1][2], (cfg, res[0][2], res[1][2])
+
+
+def test_window_overflow_in_a_mixed_database(Engine, oracle):
+    """A low-complexity stretch in a long target overflows the seed list of its window even with one assay per pass: the
+    windows shrink and the long targets are searched again -- the short targets of the same database, whose hits were
+    collected before, must be reported once (the split into whole and windowed targets does not move)."""
+    wl = synth.make_workload(2, n_targets=64, n_assays=4, seed=97)
+    codes = wl.codes.copy()
+    lens = np.diff(wl.offsets.astype(np.int64))
+    # targets 0..39 glued into one 40-kb target, the rest stay short; a poly-A run inside the long one
+    offsets = np.array([0, int(lens[:40].sum())] + [int(lens[:40 + i + 1].sum()) for i in range(24)], dtype=np.uint64)
+    codes[5000:9000] = 0
+    assays = wl.assays[:3] + [synth.Assay("polyA", "AAAAAAAAAAAAAAAAAAAAAAAA", "TTTTTTTTTTTTTTTTTTTTTTCG", None)]
+    ex = synth.expand_assays(assays)
+    wl.options.hash_word_size = 5
+    want = tc.sorted_hit_keys(oracle.search(wl.options, ex, codes, offsets))
+    e = Engine(wl.options, ex)
+    db = e.pack(codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    assert got == want and len(want) > 0
+    assert len(set(got)) == len(got) or len(set(want)) != len(want)
+    db.close()
+    e.close()
+
+
+def test_skipped_targets_are_not_searched(Engine, oracle):
+    """tnt_db_skip_targets: what the front end does with records beyond --max-target-len (only their fragments are
+    searched, tntblast_local.cpp:282-289,438-468)."""
+    wl = synth.make_workload(3, n_targets=300, n_assays=16, seed=98)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    all_hits = tc.sorted_hit_keys(e.search(db))
+    mask = np.zeros(300, dtype=np.uint8)
+    mask[::3] = 1
+    db.skip_targets(mask)
+    got = tc.sorted_hit_keys(e.search(db))
+    want = [h for h in all_hits if h[2] % 3 != 0]
+    assert got == want and 0 < len(want) < len(all_hits)
+    db.skip_targets(np.zeros(300, dtype=np.uint8))
+    assert tc.sorted_hit_keys(e.search(db)) == all_hits
+    db.close()
+    e.close()

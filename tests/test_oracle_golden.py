@@ -128,3 +128,16 @@ def test_g9_dinkelbach(oracle):
         assert not bad, (case["name"], len(bad), bad[:2])
         for i, o in enumerate(so):
             assert list(oracle.structure(opt, o, so[(i * 7 + 3) % len(so)], g["ct_a"], g["ct_b"])) == case["structure"][i], (case["name"], o)
+
+
+def test_g4_g5_short_hash_words(oracle):
+    """-W 3 and -W 4 (options.cpp:639): reference-generated seed lists and hit sets (tests/gen_golden_w34.py)."""
+    fx = gu.load("g4_seeds_w34.json.gz")
+    codes, offsets = gu.pack_targets(fx["targets"])
+    for k, expected in fx["seeds"].items():
+        got = sorted(tuple(s) for s in oracle.seeds(abi.options_default(hash_word_size=int(k)), fx["oligos"], codes, offsets))
+        assert got == sorted(tuple(s) for s in expected), "word size %s" % k
+    for case in gu.load("g5_search_w34.json.gz")["cases"]:
+        expanded, codes, offsets = gu.g5_inputs(case)
+        hits = oracle.search(gu.options_from(case["options"]), expanded, codes, offsets)
+        assert gu.hits_as_keys(hits) == case["hits"] and len(hits) > 0, (case["config"], case["options"]["hash_word_size"])

@@ -528,9 +528,10 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 		n_items = n_dev < a.n_items ? n_dev : a.n_items;
 	}
 	for (uint32_t base = blockIdx.x * BIND_THREADS; base < n_items; base += gridDim.x * BIND_THREADS) {
-		const bool active = base + tid < n_items;
-		uint32_t idx = 0;
-		if (active) idx = index ? index[base + tid] : base + tid;
+		uint32_t idx = 0xFFFFFFFFu; // (a queue filled by the seed kernel has slots without an item: QUEUE_HOLE, tnt_seed2.hip.h)
+		if (base + tid < n_items) idx = index ? index[base + tid] : base + tid;
+		const bool active = idx != 0xFFFFFFFFu;
+		if (!active) idx = 0;
 
 		// ------------------------------------------------------------------ item decode
 		Item it = active ? a.items[idx] : Item{0, 0, 0, 0};

@@ -110,8 +110,9 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 	}
 
 	for (uint32_t base = blockIdx.x * THREADS; base < n_items; base += gridDim.x * THREADS) {
-		const bool active = base + tid < n_items;
-		const uint32_t idx = active ? index[base + tid] : 0u;
+		// (a queue the seed kernel fills directly has slots without an item: 0xFFFFFFFF, QUEUE_HOLE of tnt_seed2.hip.h)
+		const uint32_t idx = base + tid < n_items ? index[base + tid] : 0xFFFFFFFFu;
+		const bool active = idx != 0xFFFFFFFFu;
 		const Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
 		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
 		const int L = active ? a.olig_len[slot.oligo] : 0;

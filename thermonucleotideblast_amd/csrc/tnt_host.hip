@@ -27,6 +27,7 @@
 #include "../../include/tnt_mi355x.h"
 #include "tnt_dev.h"
 #include "tnt_seed.hip.h"
+#include "tnt_seed2.hip.h"
 #include "tnt_bind.hip.h"
 #include "tnt_filter.hip.h"
 #include "tnt_pair.hip.h"
@@ -488,6 +489,17 @@ struct tnt_ctx {
 	int unit_rows = 64; // rows of the unit-level kernel instance this context's oligos need (64 or MAX_OLIGO)
 	bool filter_general = false; // the general buckets (degenerate windows, merged short queues) meet the pre-filter too
 	bool seed_lds = false; // the seed kernel instance with LDS-resident tables serves this context
+	// round-3 seed kernel of the search path (tnt_seed2.hip.h): items / groups in regions private to a wavefront, phase-A
+	// items straight into the queue of their length bucket
+	bool seed2 = false;
+	static constexpr uint32_t MAX_REGIONS = 8192;
+	DevBuf<uint32_t> slot_pack;      // [slot] bucket | bucket_general << 8 | oligo length << 16
+	DevBuf<uint32_t> region_counts;  // [2 * MAX_REGIONS] items, groups of every region
+	DevBuf<uint32_t> q_state;        // [MAX_REGIONS][MAX_BUCKETS][2]
+	DevBuf<uint32_t> q_base, q_cap;  // [bucket] region of every phase-A queue inside `qa`
+	std::vector<uint32_t> h_q_base, h_q_cap;
+	bool q_planned_exceptions = false;
+	uint32_t batch_regions = 0;      // regions (wavefronts) of the batch that ran last
 	DevBuf<Thresh> thresh;
 	DevBuf<AssayDev> assays;
 	DevBuf<uint32_t> wt_ent, wl_off;
@@ -699,34 +711,39 @@ template <bool LDS_TABLES> void launch_seed(const SeedArgs &s, int mode, int blo
 }
 
 // One phase of binding: split the queue by oligo length, then one launch per length bucket.
+// `direct`: the queues of the length buckets are in place already (the round-3 seed kernel writes its phase-A items straight
+// into them, region q_base[i] of c->qa, slots handed out in C_BUCKET + i * BUCKET_STRIDE; unused slots hold QUEUE_HOLE).
 void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_exceptions, const uint32_t *src, const uint32_t *src_count,
-                       const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always */)
+                       const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always */,
+                       bool direct = false)
 {
 	if (c->opt.use_dinkelbach) merge_mode = 2; // the Dinkelbach passes only exist in the longest general instance
 	uint32_t *cnt = c->counters.p;
-	(void)hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream);
-	BucketArgs k;
-	memset(&k, 0, sizeof(k));
-	k.src = src;
-	k.src_count = src_count;
-	k.shard_counts = shard_counts;
-	k.shard_region = uint32_t(ITEM_CAP / N_SHARD);
-	k.items = c->items.p;
-	k.slots = b.slots;
-	k.olig_len = c->olig_len.p;
-	k.db = v;
-	k.has_exceptions = has_exceptions ? 1 : 0;
-	k.dst = c->qbucket.p;
-	k.cap = uint32_t(ITEM_CAP);
-	k.counters = cnt + C_BUCKET;
-	k.n_buckets = int(c->bucket_lmax.size());
-	k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads(c->bucket_lmax.back()));
-	if (merge_mode == 1) k.merge_below = 0;
-	if (merge_mode == 2) k.merge_below = 0xFFFFFFFFu;
-	k.err = cnt + C_ERR;
-	k.item_rep = (c->dedupe && shard_counts) ? c->item_rep.p : nullptr; // phase A only: phase-B items are never duplicates
-	hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
-	hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
+	if (!direct) {
+		(void)hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream);
+		BucketArgs k;
+		memset(&k, 0, sizeof(k));
+		k.src = src;
+		k.src_count = src_count;
+		k.shard_counts = shard_counts;
+		k.shard_region = uint32_t(ITEM_CAP / N_SHARD);
+		k.items = c->items.p;
+		k.slots = b.slots;
+		k.olig_len = c->olig_len.p;
+		k.db = v;
+		k.has_exceptions = has_exceptions ? 1 : 0;
+		k.dst = c->qbucket.p;
+		k.cap = uint32_t(ITEM_CAP);
+		k.counters = cnt + C_BUCKET;
+		k.n_buckets = int(c->bucket_lmax.size());
+		k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads(c->bucket_lmax.back()));
+		if (merge_mode == 1) k.merge_below = 0;
+		if (merge_mode == 2) k.merge_below = 0xFFFFFFFFu;
+		k.err = cnt + C_ERR;
+		k.item_rep = (c->dedupe && shard_counts) ? c->item_rep.p : nullptr; // phase A only: phase-B items are never duplicates
+		hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
+		hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
+	}
 	(void)hipEventRecord(c->phase_ready, c->stream);
 	for (int l = 0; l < tnt_ctx::BIND_LANES; l++) (void)hipStreamWaitEvent(c->lane_stream[l], c->phase_ready, 0);
 	int n_launch = 0;
@@ -735,10 +752,13 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		const size_t i = k;
 		// general instances other than the last (merge) bucket only see windows with degenerate bases
 		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) continue;
+		if (direct && c->h_q_cap[i] == 0) continue; // no slot routes its items here
 		const int lane = c->serial_bind ? 0 : n_launch++ % tnt_ctx::BIND_LANES;
 		if (c->serial_bind) n_launch = 1;
-		b.index = c->qbucket.p;
-		b.index_base_dev = cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
+		const uint32_t *queue = direct ? c->qa.p + c->h_q_base[i] : c->qbucket.p;
+		uint32_t *survivors = c->qsurv.p ? c->qsurv.p + (direct ? c->h_q_base[i] : 0u) : nullptr;
+		b.index = queue;
+		b.index_base_dev = direct ? nullptr : cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
 		b.audit = nullptr;
@@ -756,17 +776,17 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.slots = b.slots;
 			f.thresh = b.thresh;
 			f.items = b.items;
-			f.index = c->qbucket.p;
+			f.index = queue;
 			f.index_base_dev = b.index_base_dev;
 			f.n_items_dev = b.n_items_dev;
 			f.n_items = uint32_t(ITEM_CAP);
-			f.survivors = c->qsurv.p;
+			f.survivors = survivors;
 			f.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 3;
 			f.result = b.result;
 			f.n_rejected = cnt + C_FILTERED;
 			f.audit = c->filter_audit ? c->audit.p : nullptr;
 			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
-			b.index = c->qsurv.p;
+			b.index = survivors;
 			b.n_items_dev = f.n_survivors;
 			b.audit = f.audit;
 		}
@@ -826,6 +846,8 @@ int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
 		HIP_TRY(c->hits.alloc(c->hit_cap), c->err);
 		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
+		HIP_TRY(c->region_counts.alloc(2 * tnt_ctx::MAX_REGIONS), c->err);
+		HIP_TRY(c->q_state.alloc(size_t(tnt_ctx::MAX_REGIONS) * MAX_BUCKETS * 2), c->err);
 	}
 	return ensure_scratch(c, need_lmax);
 }
@@ -1160,7 +1182,19 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				                        "library does not reproduce (TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 binds every use on its own)");
 		}
 	}
+	// the round-3 seed kernel serves every search but those that mark shared oligos in the seed kernel
+	c->seed2 = !c->dedupe && !getenv("TNT_MI355X_SEED_V2");
+	std::vector<uint32_t> slot_pack(std::max<size_t>(1, c->h_slots.size()), 0u);
+	for (size_t si = 0; si < c->h_slots.size(); si++) {
+		const Slot &sl = c->h_slots[si];
+		if (sl.oligo < 0) continue;
+		uint32_t b0 = uint32_t(sl.bucket), b1 = uint32_t(sl.bucket_general);
+		if (opt->use_dinkelbach) b0 = b1 = uint32_t(c->bucket_lmax.size() - 1); // the Dinkelbach passes only exist in the longest general instance
+		slot_pack[si] = b0 | (b1 << 8) | (uint32_t(c->oligos[size_t(sl.oligo)].size()) << 16);
+	}
+	if (c->bucket_lmax.size() > size_t(MAX_BUCKETS)) FAIL(TNT_E_LIMIT, "too many oligo length classes");
 	hipError_t e = hipSuccess;
+	if ((e = c->slot_pack.upload(slot_pack)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
 	std::vector<Tables> tv(1, c->h_tab);
 	std::vector<FilterTables> fv(1, c->h_ftab);
 	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->ftab.upload(fv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
@@ -1901,12 +1935,57 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	}
 	s.err = cnt + C_ERR;
 	s.debug = cnt + C_DEBUG + 8;
+	const bool direct = c->seed2 && !seeds_only; // the round-3 seed kernel: private regions, phase-A items straight into their buckets' queues
+	if (direct) {
+		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * 4, tnt_ctx::MAX_REGIONS / S2_WAVES)));
+		const uint32_t regions = blocks * S2_WAVES;
+		c->batch_regions = regions;
+		HIP_TRY(hipMemsetAsync(c->region_counts.p, 0, sizeof(uint32_t) * 2 * regions, c->stream), c->err);
+		HIP_TRY(hipMemsetAsync(c->q_state.p, 0, sizeof(uint32_t) * size_t(regions) * MAX_BUCKETS * 2, c->stream), c->err);
+		HIP_TRY(hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream), c->err);
+		Seed2Args q;
+		memset(&q, 0, sizeof(q));
+		q.db = v;
+		q.unit_target = db->unit_target.p;
+		q.unit0 = uint32_t(u0), q.unit1 = uint32_t(u1);
+		q.word_size = c->opt.hash_word_size;
+		q.wlist = c->wlist.p, q.wl_off = c->wl_off.p, q.wl_seq = c->wl_seq.p;
+		q.assays = c->assays.p;
+		q.max_len = c->opt.max_len;
+		q.single_primer_pcr = c->opt.single_primer_pcr;
+		q.slot_pack = c->slot_pack.p;
+		q.has_exceptions = db->n_exceptions != 0 ? 1 : 0;
+		q.items = c->items.p, q.item_region = uint32_t(ITEM_CAP / regions);
+		q.groups = c->groups.p, q.group_region = uint32_t(GROUP_CAP / regions);
+		q.region_counts = c->region_counts.p;
+		q.queue = c->qa.p;
+		q.q_base = c->q_base.p, q.q_cap = c->q_cap.p;
+		q.q_count = cnt + C_BUCKET;
+		q.q_state = c->q_state.p;
+		q.n_buckets = int(c->bucket_lmax.size());
+		q.stat_items = cnt + C_ITEMS, q.stat_groups = cnt + C_GROUPS, q.stat_phase_a = cnt + C_QA;
+		q.big_count = cnt + C_BIG;
+		q.err = cnt + C_ERR;
+		const size_t n_words2 = size_t(1) << (2 * c->opt.hash_word_size);
+		const size_t off_stride2 = (n_words2 + 1 + 1) & ~size_t(1);
+		for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
+			q.assay_begin = c->chunk_begin[ch];
+			q.assay_end = c->chunk_begin[ch + 1];
+			q.wt_off = c->wt_off.p + ch * off_stride2;
+			q.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
+			q.chunk_has_probe = 0;
+			for (uint32_t ai = q.assay_begin; ai < q.assay_end; ai++)
+				if (c->h_assays[ai].kind == 0 && c->h_assays[ai].has_probe) q.chunk_has_probe = 1;
+			q.last_chunk = ch + 2 == c->chunk_begin.size() ? 1 : 0;
+			hipLaunchKernelGGL(seed2_kernel, dim3(blocks), dim3(S2_THREADS), 0, c->stream, q);
+		}
+	}
 	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
 	// the streaming instance keeps the chunk's tables in LDS: one persistent workgroup per CU
 	const int lds_blocks = int(std::min<size_t>((u1 - u0 + SEED_LDS_WAVES - 1) / SEED_LDS_WAVES, size_t(c->n_cu)));
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	const size_t off_stride = (n_words + 1 + 1) & ~size_t(1); // every chunk's offset table starts on a dword
-	for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
+	for (size_t ch = 0; ch + 1 < c->chunk_begin.size() && !direct; ch++) {
 		s.assay_begin = c->chunk_begin[ch];
 		s.assay_end = c->chunk_begin[ch + 1];
 		s.wt_off = c->wt_off.p + ch * off_stride;
@@ -1926,7 +2005,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
-	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->qa.p, nullptr, cnt + C_QA);
+	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->qa.p, nullptr, cnt + C_QA, 0, direct);
 	if (c->dedupe) {
 		PropagateArgs pa;
 		memset(&pa, 0, sizeof(pa));
@@ -2023,7 +2102,7 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 		size_t a1 = a0, ent = 0;
 		double sum_sq = 0.0;
 		std::fill(mult.begin(), mult.end(), 0u);
-		while (a1 < n_assays && a1 - a0 < size_t(SEED_MAX_ASSAYS)) {
+		while (a1 < n_assays && a1 - a0 < size_t(c->seed2 ? S2_ASSAYS : SEED_MAX_ASSAYS)) {
 			const auto &ae = c->assay_entries[a1];
 			double add_sq = 0.0;
 			for (const auto &we : ae) add_sq += 2.0 * double(mult[we.first]++) + 1.0;
@@ -2084,6 +2163,50 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	const double gb = (double(GROUP_CAP) / 2.0) / std::max<double>(1.0, double(n_assays));
 	tb = std::min(tb, gb);
 	targets_per_batch = size_t(std::max(1.0, std::min(tb, double(n_units)))); // in work units
+	// Regions of the phase-A queues (round-3 seed kernel): the buffer is shared out by the expected number of seeds of the
+	// slots a bucket serves (query words of their oligos; windows with a degenerate target base go to the general bucket of
+	// their length, so with such a database both get the share).  A region that overflows anyway raises ERR_ITEM_OVERFLOW:
+	// the search is repeated with smaller batches.
+	const bool exc = db->n_exceptions != 0;
+	if (c->seed2 && (c->h_q_base.empty() || c->q_planned_exceptions != exc)) {
+		const size_t nb = c->bucket_lmax.size();
+		std::vector<double> weight(nb, 0.0);
+		for (size_t si = 0; si < c->h_slots.size(); si++) {
+			const Slot &sl = c->h_slots[si];
+			if (sl.oligo < 0) continue;
+			const double w = double(std::max<size_t>(1, c->oligos[size_t(sl.oligo)].size()));
+			if (c->opt.use_dinkelbach) {
+				weight[nb - 1] += w;
+				continue;
+			}
+			weight[size_t(sl.bucket)] += w;
+			if (exc) weight[size_t(sl.bucket_general)] += w;
+		}
+		double total = 0.0;
+		for (double w : weight) total += w;
+		// every wavefront may hold one open block per bucket on top of the bucket's share
+		size_t nb_used = 0;
+		for (size_t b = 0; b < nb; b++) nb_used += weight[b] > 0.0 ? 1 : 0;
+		const uint64_t floor_slots = std::min<uint64_t>(uint64_t(tnt_ctx::MAX_REGIONS) * QUEUE_BLOCK, (uint64_t(ITEM_CAP) / (2 * std::max<size_t>(1, nb_used))) & ~uint64_t(QUEUE_BLOCK - 1));
+		uint64_t used = 0;
+		for (size_t b = 0; b < nb; b++) used += weight[b] > 0.0 ? floor_slots : 0;
+		const double spare = double(ITEM_CAP) - double(used);
+		c->h_q_base.assign(nb, 0);
+		c->h_q_cap.assign(nb, 0);
+		uint64_t at = 0;
+		for (size_t b = 0; b < nb; b++) {
+			if (!(weight[b] > 0.0)) continue;
+			uint64_t cap = floor_slots + uint64_t(spare * weight[b] / total);
+			cap &= ~uint64_t(QUEUE_BLOCK - 1);
+			c->h_q_base[b] = uint32_t(at);
+			c->h_q_cap[b] = uint32_t(cap);
+			at += cap;
+		}
+		HIP_TRY(hipStreamSynchronize(c->stream), c->err);
+		HIP_TRY(c->q_base.upload(c->h_q_base), c->err);
+		HIP_TRY(c->q_cap.upload(c->h_q_cap), c->err);
+		c->q_planned_exceptions = exc;
+	}
 	return TNT_OK;
 }
 
@@ -2776,9 +2899,20 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 			ctx->err = err_text(err);
 			return TNT_E_LIMIT;
 		}
-		for (uint32_t r = 0; r < N_SHARD; r++) {
-			const uint32_t ni = cnt[C_ITEMS + r * SHARD_STRIDE], ng = cnt[C_GROUPS + r * SHARD_STRIDE];
+		// where the seed kernel left its items and groups: 32 shards (round-2 kernel), or one region per wavefront
+		std::vector<uint32_t> rc;
+		uint32_t n_regions = N_SHARD;
+		size_t ir = item_region, gr = group_region;
+		if (ctx->seed2) {
+			n_regions = ctx->batch_regions;
+			ir = ITEM_CAP / n_regions, gr = GROUP_CAP / n_regions;
+			rc.resize(2 * size_t(n_regions));
+			HIP_TRY(hipMemcpy(rc.data(), ctx->region_counts.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
+		}
+		for (uint32_t r = 0; r < n_regions; r++) {
+			const uint32_t ni = ctx->seed2 ? rc[2 * r] : cnt[C_ITEMS + r * SHARD_STRIDE], ng = ctx->seed2 ? rc[2 * r + 1] : cnt[C_GROUPS + r * SHARD_STRIDE];
 			if (!ni) continue;
+			const size_t item_region = ir, group_region = gr;
 			items.resize(ni);
 			groups.resize(ng);
 			HIP_TRY(hipMemcpy(items.data(), ctx->items.p + r * item_region, ni * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
