@@ -329,7 +329,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 					const uint32_t sm = minus ? 0u : ~0u;      // primers look towards higher keys on the minus strand, lower on the plus strand
 					// groups a primer may pair with: the other strand, the other oligo (any oligo with single-primer PCR)
 					const uint32_t pmask = minus ? (single ? 0xCu : (4u << (1u - role))) : (single ? 0x3u : (1u << (1u - role)));
-					uint32_t next_d = ~0u;  // distance - 1 to the list successor
+					uint32_t next_d = ~0u;  // distance - 1 to the list successor (the minimum over all keys of (key - k - 1) as an unsigned number)
 					uint32_t far_d = 0;     // distance to the farthest partner within reach (0: none)
 					uint32_t pn_d = ~0u;    // distance to the nearest probe on the partner's side
 					if (in_reach) {
@@ -398,7 +398,8 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 					if (valid) {
 						// one LDS add per valid seed: its assay's count, and the strand of its successor
 						uint32_t add = 1u << 20;
-						if (next_d != ~0u) add += ((0x13u >> (((k + next_d + 1u) >> 7) & 7u)) & 1u) ? 1u : (1u << 10);
+						if (int32_t(next_d) >= 0) add += // (keys below this one leave huge values behind, not ~0: a successor is less than 2^25 away)
+							 ((0x13u >> (((k + next_d + 1u) >> 7) & 7u)) & 1u) ? 1u : (1u << 10);
 						atomicAdd(agg + la, add);
 					}
 				}
