@@ -424,6 +424,7 @@ struct tnt_db {
 	std::vector<uint32_t> h_unit_target, h_unit_begin, h_unit_end;
 	std::vector<int32_t> h_unit_own_lo, h_unit_own_hi; // coordinates whose hits the unit reports
 	DevBuf<uint32_t> unit_target, unit_begin, unit_end;
+	DevBuf<uint4> unit_rec;         // whole-target units: {target, bases, first packed word (64 bits)}: one scalar load per unit
 	DevBuf<int32_t> unit_own_lo, unit_own_hi;
 	uint32_t max_unit_len = 0;
 	size_t n_short_units = 0;       // units [0, n_short_units) are whole targets, the rest windows of long targets
@@ -504,6 +505,8 @@ struct tnt_ctx {
 	DevBuf<AssayDev> assays;
 	DevBuf<uint32_t> wt_ent, wl_off;
 	DevBuf<unsigned long long> wl_seq;
+	std::vector<unsigned long long> h_wl_seq; // host copy: the per-entry copies of a chunk's table are made from it (plan)
+	DevBuf<unsigned long long> wt_seq;        // [entry][2] the packed oligo of every table entry (the round-3 seed kernel reads entry and oligo with one index)
 	DevBuf<uint16_t> wt_off, wlist;
 	std::vector<std::vector<std::pair<uint16_t, uint32_t>>> assay_entries; // per assay: (word, entry bits)
 	std::vector<uint32_t> chunk_ent_base;  // first entry of every chunk in wt_ent
@@ -1202,7 +1205,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
 	    (e = c->slot_canon.upload(c->h_slot_canon)) != hipSuccess || (e = c->slot_next.upload(c->h_slot_next)) != hipSuccess ||
 	    (e = c->assays.upload(c->h_assays)) != hipSuccess || (e = c->wl_off.upload(wl_off)) != hipSuccess ||
-	    (e = c->wl_seq.upload(wl_seq)) != hipSuccess ||
+	    (e = c->wl_seq.upload(wl_seq)) != hipSuccess || (c->h_wl_seq = wl_seq, false) ||
 	    (e = c->wlist.upload(wlist)) != hipSuccess)
 		FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
 #undef FAIL
@@ -1295,7 +1298,13 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 			db->max_unit_len = std::max(db->max_unit_len, e - uint32_t(b) + uint32_t(k));
 		}
 	}
+	std::vector<uint4> rec(db->n_short_units + 4, make_uint4(0, 0, 0, 0)); // (slack: the kernel fetches two units ahead)
+	for (size_t u = 0; u < db->n_short_units; u++) {
+		const uint32_t t = db->h_unit_target[u];
+		rec[u] = make_uint4(t, db->h_len[t], uint32_t(db->h_word_off[t]), uint32_t(db->h_word_off[t] >> 32));
+	}
 	hipError_t e;
+	if ((e = db->unit_rec.upload(rec)) != hipSuccess) return e;
 	if ((e = db->unit_target.upload(db->h_unit_target)) != hipSuccess || (e = db->unit_begin.upload(db->h_unit_begin)) != hipSuccess ||
 	    (e = db->unit_end.upload(db->h_unit_end)) != hipSuccess || (e = db->unit_own_lo.upload(db->h_unit_own_lo)) != hipSuccess ||
 	    (e = db->unit_own_hi.upload(db->h_unit_own_hi)) != hipSuccess)
@@ -1946,10 +1955,10 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		Seed2Args q;
 		memset(&q, 0, sizeof(q));
 		q.db = v;
-		q.unit_target = db->unit_target.p;
+		q.unit_rec = db->unit_rec.p;
 		q.unit0 = uint32_t(u0), q.unit1 = uint32_t(u1);
 		q.word_size = c->opt.hash_word_size;
-		q.wlist = c->wlist.p, q.wl_off = c->wl_off.p, q.wl_seq = c->wl_seq.p;
+		q.wlist = c->wlist.p, q.wl_off = c->wl_off.p;
 		q.assays = c->assays.p;
 		q.max_len = c->opt.max_len;
 		q.single_primer_pcr = c->opt.single_primer_pcr;
@@ -1966,6 +1975,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		q.stat_items = cnt + C_ITEMS, q.stat_groups = cnt + C_GROUPS, q.stat_phase_a = cnt + C_QA;
 		q.big_count = cnt + C_BIG;
 		q.err = cnt + C_ERR;
+		q.debug = cnt + C_DEBUG + 8;
 		const size_t n_words2 = size_t(1) << (2 * c->opt.hash_word_size);
 		const size_t off_stride2 = (n_words2 + 1 + 1) & ~size_t(1);
 		for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
@@ -1973,6 +1983,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 			q.assay_end = c->chunk_begin[ch + 1];
 			q.wt_off = c->wt_off.p + ch * off_stride2;
 			q.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
+			q.wt_seq = reinterpret_cast<const uint4 *>(c->wt_seq.p) + c->chunk_ent_base[ch];
 			q.chunk_has_probe = 0;
 			for (uint32_t ai = q.assay_begin; ai < q.assay_end; ai++)
 				if (c->h_assays[ai].kind == 0 && c->h_assays[ai].has_probe) q.chunk_has_probe = 1;
@@ -2143,6 +2154,15 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 		HIP_TRY(hipStreamSynchronize(c->stream), c->err);
 		HIP_TRY(c->wt_off.upload(off), c->err);
 		HIP_TRY(c->wt_ent.upload(ent), c->err);
+		{
+			std::vector<unsigned long long> es(ent.size() * 2 + 2, 0ull);
+			for (size_t i = 0; i < ent.size(); i++) {
+				const uint32_t en = ent[i];
+				const size_t li = (size_t(en >> WT_ASSAY_SHIFT) * 3u + ((en >> 8) & 3u)) * 2u + ((en & WT_MINUS) ? 1u : 0u);
+				es[2 * i] = c->h_wl_seq[2 * li], es[2 * i + 1] = c->h_wl_seq[2 * li + 1];
+			}
+			HIP_TRY(c->wt_seq.upload(es), c->err);
+		}
 		c->planned_chunks = chunk_begin;
 	}
 	c->chunk_begin = chunk_begin;
@@ -2600,6 +2620,10 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	{
 		const uint32_t *d = cnt + C_DEBUG;
 		const double w = d[7] ? double(d[7]) : 1.0;
+		if (ctx->seed2)
+			fprintf(stderr, "seed2 waves %u; kilo-cycles per wave: setup %.0f scan %.0f dense %.0f sort %.0f cull %.0f emit %.0f\n", d[15], double(d[8]) / (d[15] ? d[15] : 1),
+			        double(d[9]) / (d[15] ? d[15] : 1), double(d[10]) / (d[15] ? d[15] : 1), double(d[11]) / (d[15] ? d[15] : 1), double(d[12]) / (d[15] ? d[15] : 1), double(d[13]) / (d[15] ? d[15] : 1));
+		else
 		fprintf(stderr, "seed waves %u; kilo-cycles per wave: scan+dedupe %.0f (dedupe %.0f) sort %.0f cull %.0f phaseB %.0f prefix+groups %.0f emit %.0f\n", d[15], double(d[8]) / (d[15] ? d[15] : 1),
 		        double(d[14]) / (d[15] ? d[15] : 1), double(d[9]) / (d[15] ? d[15] : 1), double(d[10]) / (d[15] ? d[15] : 1), double(d[11]) / (d[15] ? d[15] : 1), double(d[12]) / (d[15] ? d[15] : 1), double(d[13]) / (d[15] ? d[15] : 1));
 		fprintf(stderr, "wave-DPs %u; cycles per wave-DP: fill %.0f trace %.0f trim %.0f eval %.0f other-enum %.0f thresholds %.0f output %.0f\n", d[7],

@@ -19,6 +19,12 @@
 //    keys, collected with LDS min / max atomics while the seeds are sorted; the loop over the assay's segment that is
 //    left computes the successor (and the nearest probe, for TaqMan assays) with two instructions per key.  Longer
 //    targets take the general loop (reach tested per pair), written with selects;
+//  * the stage is a chain of dependent steps per target and was parked in s_waitcnt for 60 % of its wave-cycles (PMC,
+//    profiles/r03b_pmc_*): what it waits for is memory, so the global round trips on a target's critical path went from
+//    about two dozen to about eight -- the unit's record (target, length, first word) comes with ONE scalar load issued
+//    two units ahead, its packed words one unit ahead (they are parked in LDS: scan and diagonal test read them there),
+//    a table entry and the packed oligo it belongs to are fetched with the same index (one round trip per dense pass,
+//    two passes in flight), the per-slot and per-assay constants sit in LDS;
 //  * phase-A items go STRAIGHT into the queue of the length bucket that binds them (blocks of 64 slots handed out per
 //    bucket, unused slots hold QUEUE_HOLE): the bucket pass over the phase-A queue (two passes over 52 M entries on
 //    config 2) is gone and the pre-filter reads the windows of one target back to back.
@@ -36,19 +42,20 @@ constexpr int S2_THREADS = 64 * S2_WAVES;
 constexpr int S2_CAP = 512;            // seeds of one target x one assay chunk held in LDS
 constexpr int S2_ASSAYS = 128;         // assays per chunk (7-bit local index in the key)
 constexpr int S2_SWEEP = 16;           // positions per lane and sweep
+constexpr int S2_TGT_WORDS = 128;       // packed words of a target parked in LDS (2 048 bases); longer targets are read from HBM
 constexpr uint32_t QUEUE_BLOCK = 64;   // queue slots handed out at a time (one filter / bind wavefront reads one block)
 constexpr uint32_t QUEUE_HOLE = 0xFFFFFFFFu; // a queue slot without an item
 
 struct Seed2Args {
 	DbView db;
-	const uint32_t *unit_target; // work units = whole targets
+	const uint4 *unit_rec;       // work units = whole targets: {target, bases, first packed word lo, hi}; readable two records past unit1
 	uint32_t unit0, unit1;
 	int word_size;
 	const uint16_t *wt_off;      // this chunk's bucket offsets [4^k + 1], relative to wt_ent
 	const uint32_t *wt_ent;      // this chunk's entries (tnt_dev.h)
 	const uint16_t *wlist;       // concatenated word lists
 	const uint32_t *wl_off;      // [((assay * 3 + role) * 2 + minus)] -> first word
-	const unsigned long long *wl_seq; // [list][2]: the strand-specific oligo, 2 bits per base
+	const uint4 *wt_seq;         // [entry] the strand-specific oligo of the entry's list, 2 bits per base, base 0 in the low bits
 	uint32_t assay_begin, assay_end;
 	const AssayDev *assays;
 	int chunk_has_probe;         // some PCR assay of the chunk has a probe (TaqMan)
@@ -71,6 +78,7 @@ struct Seed2Args {
 	uint32_t *stat_items, *stat_groups, *stat_phase_a; // statistics (one add per wavefront and launch)
 	uint32_t *big_count;         // groups of more than 64 items
 	uint32_t *err;
+	uint32_t *debug;             // experimental builds only (TNT_EXP_STATS): cycles per phase
 };
 
 __device__ __forceinline__ uint32_t s2_key(uint32_t la, uint32_t ent, uint32_t p)
@@ -83,21 +91,57 @@ __device__ __forceinline__ uint32_t s2_rank(unsigned long long m) // set bits of
 	return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
 }
 
+// Is (wi, p) the first seed of its diagonal?  Packed form for plain A/C/G/T oligos whose compared stretch fits 32 bases:
+// XOR the target and the oligo along the diagonal and look for a run of `ws` matching bases that starts before the seed
+// (bind_oligo.cpp:98-99: stable sort by diagonal + unique keeps the smallest word index).  W0..W2 = the three packed
+// target words from word (p - kmax) >> 4 on; seq = the oligo (128 bits).  All in 32-bit halves: v_alignbit funnels.
+__device__ __forceinline__ bool s2_first_packed(uint32_t W0, uint32_t W1, uint32_t W2, const uint4 seq, uint32_t wi, uint32_t p, uint32_t kmax, int ws)
+{
+	const uint32_t sh = ((p - kmax) & 15u) * 2u;
+	const uint32_t t_lo = __builtin_amdgcn_alignbit(W1, W0, sh), t_hi = __builtin_amdgcn_alignbit(W2, W1, sh);
+	const uint32_t s2 = (wi - kmax) * 2u, word = s2 >> 5, sh2 = s2 & 31u;
+	const uint32_t oa = word == 0 ? seq.x : (word == 1 ? seq.y : (word == 2 ? seq.z : seq.w));
+	const uint32_t ob = word == 0 ? seq.y : (word == 1 ? seq.z : (word == 2 ? seq.w : 0u));
+	const uint32_t oc = word == 0 ? seq.z : (word == 1 ? seq.w : 0u);
+	const uint32_t o_lo = __builtin_amdgcn_alignbit(ob, oa, sh2), o_hi = __builtin_amdgcn_alignbit(oc, ob, sh2);
+	const uint32_t x_lo = t_lo ^ o_lo, x_hi = t_hi ^ o_hi;
+	// one bit per matching base (even bit positions), 32 bases in two words
+	uint32_t z_lo = ~(x_lo | (x_lo >> 1)) & 0x55555555u, z_hi = ~(x_hi | (x_hi >> 1)) & 0x55555555u;
+	// runs of `ws` matching bases: r = z & z>>2 & ... & z>>2(ws-1) over the 64-bit value (hi:lo)
+	uint32_t r_lo = z_lo, r_hi = z_hi;
+	for (int i = 1; i < ws; i++) {
+		r_lo &= __builtin_amdgcn_alignbit(z_hi, z_lo, 2 * i);
+		r_hi &= z_hi >> (2 * i);
+	}
+	// ... that start before the seed: bases [0, kmax)
+	const uint32_t b_lo = kmax >= 16u ? ~0u : ((1u << (2u * kmax)) - 1u);
+	const uint32_t b_hi = kmax <= 16u ? 0u : (kmax >= 32u ? ~0u : ((1u << (2u * kmax - 32u)) - 1u));
+	return ((r_lo & b_lo) | (r_hi & b_hi)) == 0u;
+}
+
 __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 {
 	__shared__ uint32_t s_raw[S2_WAVES][S2_CAP];      // kept seeds (keys) as the dense pass finds them
 	__shared__ uint32_t s_srt[S2_WAVES][S2_CAP];      // candidates of the scan, then the keys grouped by assay
+	__shared__ uint32_t s_tgt[S2_WAVES][S2_TGT_WORDS + 4]; // the packed words of the target (targets of up to 2 048 bases)
 	__shared__ uint16_t s_hist[S2_WAVES][S2_ASSAYS];  // seeds per assay
 	__shared__ uint16_t s_off[S2_WAVES][S2_ASSAYS];   // scatter cursors, then the END of every assay's segment
 	__shared__ __attribute__((aligned(16))) uint32_t s_ext[S2_WAVES][S2_ASSAYS * 4]; // per assay: smallest key of F-, of R-, largest key of F+, of R+
 	__shared__ uint32_t s_agg[S2_WAVES][S2_ASSAYS];   // per assay: successors on the minus strand | on the plus strand << 10 | valid seeds << 20
-	__shared__ unsigned long long s_vmask[S2_WAVES][S2_CAP / 64]; // valid seeds of every round of 64
 	__shared__ uint32_t s_qh[S2_WAVES][MAX_BUCKETS], s_qcur[S2_WAVES][MAX_BUCKETS], s_qend[S2_WAVES][MAX_BUCKETS];
 	__shared__ uint32_t s_qpos[S2_WAVES][MAX_BUCKETS], s_qsplit[S2_WAVES][MAX_BUCKETS], s_qnew[S2_WAVES][MAX_BUCKETS];
 	__shared__ uint8_t s_af[S2_ASSAYS];               // per assay of the chunk: 1 probe / padlock assay (hash-overload lists), 2 PCR with a probe
+	__shared__ uint32_t s_slot[S2_ASSAYS * 3];        // slot_pack of the chunk's slots
+	__shared__ uint32_t s_qbase[MAX_BUCKETS], s_qcap[MAX_BUCKETS];
+	// pointers the emission needs: read from LDS where they are used (kept in registers they spill to scratch memory,
+	// and a scratch reload is a vector-memory load -- see the emission)
+	enum { COLD_ITEMS = 0, COLD_GROUPS, COLD_QUEUE, COLD_Q_COUNT, COLD_BIG, COLD_ERR, COLD_N };
+	__shared__ unsigned long long s_cold[COLD_N];
+	typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64; // (volatile: not hoisted out of the loops, not kept in registers)
+	auto cold = [&](int k) __attribute__((always_inline)) { return *(lds_vu64 *)(&s_cold[k]); };
 
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	uint32_t *raw = s_raw[wv], *srt = s_srt[wv];
+	uint32_t *raw = s_raw[wv], *srt = s_srt[wv], *tgt = s_tgt[wv];
 	uint16_t *hist = s_hist[wv], *off = s_off[wv];
 	uint32_t *ext = s_ext[wv], *agg = s_agg[wv];
 	const uint32_t wmask = (1u << (2 * a.word_size)) - 1u;
@@ -109,14 +153,21 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 		const AssayDev A = a.assays[a.assay_begin + i];
 		s_af[i] = uint8_t((A.kind != 0 ? 1 : 0) | ((A.kind == 0 && A.has_probe) ? 2 : 0));
 	}
+	for (uint32_t i = threadIdx.x; i < n_chunk * 3u; i += S2_THREADS) s_slot[i] = a.slot_pack[a.assay_begin * 3u + i];
+	if (int(threadIdx.x) < a.n_buckets) s_qbase[threadIdx.x] = a.q_base[threadIdx.x], s_qcap[threadIdx.x] = a.q_cap[threadIdx.x];
+	if (threadIdx.x == 0) {
+		s_cold[COLD_ITEMS] = (unsigned long long)a.items, s_cold[COLD_GROUPS] = (unsigned long long)a.groups, s_cold[COLD_QUEUE] = (unsigned long long)a.queue;
+		s_cold[COLD_Q_COUNT] = (unsigned long long)a.q_count, s_cold[COLD_BIG] = (unsigned long long)a.big_count, s_cold[COLD_ERR] = (unsigned long long)a.err;
+	}
 	// the wavefront's private output region (items, groups) and the queue blocks it is filling; both persist across the
 	// chunk launches of a batch
-	const uint32_t region = blockIdx.x * S2_WAVES + wv;
+	const uint32_t region = uint32_t(__builtin_amdgcn_readfirstlane(int(blockIdx.x * S2_WAVES + wv)));
 	if (lane < MAX_BUCKETS) {
 		s_qh[wv][lane] = 0;
 		s_qcur[wv][lane] = a.q_state[(region * MAX_BUCKETS + lane) * 2];
 		s_qend[wv][lane] = a.q_state[(region * MAX_BUCKETS + lane) * 2 + 1];
 	}
+	if (lane < 4) tgt[S2_TGT_WORDS + lane] = 0; // (slack behind the last word: the scan and the diagonal test read ahead)
 	__syncthreads();
 
 	const uint32_t item_lo = region * a.item_region, group_lo = region * a.group_region;
@@ -124,96 +175,125 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 	const uint32_t item_first = item_cur, group_first = group_cur;
 	uint32_t n_phase_a = 0;
 
-	for (uint32_t unit = a.unit0 + region; unit < a.unit1; unit += gridDim.x * S2_WAVES) {
-		const uint32_t t = a.unit_target[unit];
-		const uint32_t len = a.db.len[t];
+	// Software pipeline over the wavefront's units: the record of unit i + 2 (one scalar load) and the packed words of
+	// unit i + 1 (two dwords per lane) are in flight while unit i is processed.
+	const uint32_t stride = gridDim.x * S2_WAVES;
+	auto load_rec = [&](uint32_t u) __attribute__((always_inline)) { return a.unit_rec[u < a.unit1 ? u : a.unit1]; }; // (a zero record behind the last unit)
+	auto load_words = [&](const uint4 rec, uint32_t &w0, uint32_t &w1) __attribute__((always_inline)) {
+		const uint32_t nw = (rec.y + 15u) >> 4; // words of the target
+		const uint32_t *pk = a.db.packed + (uint64_t(rec.z) | (uint64_t(rec.w) << 32));
+		w0 = uint32_t(lane) < nw && nw <= uint32_t(S2_TGT_WORDS) ? pk[lane] : 0u;
+		w1 = uint32_t(lane) + 64u < nw && nw <= uint32_t(S2_TGT_WORDS) ? pk[lane + 64] : 0u;
+	};
+#ifdef TNT_EXP_STATS
+	long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#define S2_STAMP(K)                                               \
+	do {                                                          \
+		const long long now_ = __builtin_readcyclecounter();      \
+		st_acc[K] += now_ - st_last;                              \
+		st_last = now_;                                           \
+	} while (0)
+#else
+#define S2_STAMP(K) do { } while (0)
+#endif
+	uint32_t unit = a.unit0 + region;
+	uint4 rec_cur = load_rec(unit), rec_next = load_rec(unit + stride);
+	uint32_t wc0, wc1;
+	load_words(rec_cur, wc0, wc1);
+
+	for (; unit < a.unit1; unit += stride) {
+		const uint32_t t = rec_cur.x, len = rec_cur.y;
+		const uint32_t *pk = a.db.packed + (uint64_t(rec_cur.z) | (uint64_t(rec_cur.w) << 32));
+		const bool in_lds = ((len + 15u) >> 4) <= uint32_t(S2_TGT_WORDS);
+		// this unit's words -> LDS; the next unit's words and the record behind it -> in flight
+		tgt[lane] = wc0, tgt[lane + 64] = wc1;
+		rec_cur = rec_next;
+		load_words(rec_next, wc0, wc1);
+		rec_next = load_rec(unit + 2 * stride);
 		if (len < uint32_t(a.word_size)) continue; // tntblast_local.cpp:513
-		const uint32_t *pk = a.db.packed + a.db.word_off[t];
 		const uint32_t npos = len - a.word_size + 1;
 		// the first cull's reach covers the whole target: "a partner within max_len + 50" is "a partner" (see the head)
 		const bool in_reach = npos - 1u <= threshold;
 		for (uint32_t i = lane; i < (n_chunk + 1u) / 2u; i += 64) reinterpret_cast<uint32_t *>(hist)[i] = 0;
 		uint32_t nkept = 0; // kept seeds so far (wave-uniform)
+		wave_sync();
+		S2_STAMP(0);
+		// (address spaces spelled out: merged into one generic pointer the two reads become FLAT loads, which count against
+		// both the vector-memory and the LDS counter)
+		typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+		typedef __attribute__((address_space(1))) const uint32_t glb_cu32;
+		auto tw = [&](uint32_t w) __attribute__((always_inline)) {
+			uint32_t v;
+			if (in_lds) v = *((lds_cu32 *)tgt + w);
+			else v = *((glb_cu32 *)pk + w);
+			return v;
+		};
 
 		// ---------------------------------------------------------------- scan + diagonal de-duplication
 		uint32_t *cand = srt; // position | entry index << 15
-		// dense pass over the candidate list: the first seed of every (oligo, strand, diagonal) survives
-		auto drain = [&](uint32_t ncand) __attribute__((always_inline)) {
-			wave_sync(); // the list was written by other lanes
-			for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
-				const uint32_t c = c0 + uint32_t(lane);
-				bool first = false;
-				uint32_t key = 0, la = 0;
-				if (c < ncand) {
-					const uint32_t cv = cand[c];
-					const uint32_t cp = cv & 0x7FFFu, ent = a.wt_ent[cv >> 15];
-					const uint32_t wi = ent & 127u;
-					const uint32_t assay = ent >> WT_ASSAY_SHIFT;
-					const uint32_t li = (assay * 3u + ((ent >> 8) & 3u)) * 2u + ((ent & WT_MINUS) ? 1u : 0u);
-					const uint32_t kmax = wi < cp ? wi : cp;
-					if ((ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) first = first_on_diagonal_packed(pk, a.wl_seq + 2 * li, wi, cp, a.word_size);
-					else first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
-					la = assay - a.assay_begin;
-					key = s2_key(la, ent, cp);
-				}
-				const unsigned long long m = __builtin_amdgcn_ballot_w64(first);
-				if (first) {
-					const uint32_t slot = nkept + s2_rank(m);
-					if (slot < uint32_t(S2_CAP)) {
-						raw[slot] = key;
-						atomicAdd(reinterpret_cast<unsigned int *>(hist) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
-					}
-				}
-				nkept += uint32_t(__builtin_popcountll(m));
-			}
-			wave_sync();
+		// One candidate: its table entry and the oligo the entry belongs to come with the same index (two loads, one
+		// round trip); the target words come from LDS.
+		struct Cand {
+			uint32_t cp, ent;
+			uint4 seq;
+			bool live;
 		};
-		// position-by-position scan of [p_begin, p_end): the overflow path of the sweep (bursts of shared words)
-		auto scan_slow = [&](uint32_t p_begin, uint32_t p_end) __attribute__((always_inline)) {
-			uint32_t p = p_begin + lane, e_done = 0;
-			while (true) {
-				uint32_t filled = 0; // wave-uniform
-				while (true) {
-					uint32_t e0 = 0, cnt = 0;
-					if (p < p_end) {
-						const uint32_t w = target_word(pk, p, wmask);
-						e0 = uint32_t(a.wt_off[w]) + e_done;
-						const uint32_t e1 = a.wt_off[w + 1];
-						cnt = e1 > e0 ? e1 - e0 : 0u;
-					}
-					// exclusive prefix of cnt over the lanes
-					uint32_t incl = cnt;
-#pragma unroll
-					for (int d = 1; d < 64; d <<= 1) {
-						const uint32_t y = __shfl_up(incl, d);
-						if (lane >= d) incl += y;
-					}
-					const uint32_t at = filled + incl - cnt;
-					const uint32_t fit = at < uint32_t(S2_CAP) ? (cnt < uint32_t(S2_CAP) - at ? cnt : uint32_t(S2_CAP) - at) : 0u;
-					for (uint32_t x = 0; x < fit; x++) cand[at + x] = p | ((e0 + x) << 15);
-					bool over = false;
-					if (p < p_end) {
-						if (fit == cnt) p += 64, e_done = 0;
-						else e_done += fit, over = true;
-					}
-					const uint32_t total = __shfl(incl, 63);
-					filled = filled + total < uint32_t(S2_CAP) ? filled + total : uint32_t(S2_CAP);
-					if (__builtin_amdgcn_ballot_w64(over) != 0 || __builtin_amdgcn_ballot_w64(p < p_end) == 0) break;
-				}
-				drain(filled);
-				if (__builtin_amdgcn_ballot_w64(p < p_end) == 0) break;
+		auto fetch = [&](uint32_t c, uint32_t ncand) __attribute__((always_inline)) {
+			Cand x;
+			x.live = c < ncand;
+			x.cp = 0, x.ent = 0, x.seq = make_uint4(0, 0, 0, 0);
+			if (x.live) {
+				const uint32_t cv = cand[c];
+				x.cp = cv & 0x7FFFu;
+				x.ent = a.wt_ent[cv >> 15];
+				x.seq = a.wt_seq[cv >> 15];
 			}
+			return x;
 		};
-		{
-			// Sweeps of 64 x 16 positions: a lane loads the two packed words that hold its positions (and the k - 1 bases
-			// behind them), extracts the k-mers with shifts and reads their bucket bounds -- both bounds with one 2-byte
-			// aligned dword gather, all 16 gathers in flight at once; one wave-wide prefix sum gives every lane its slice of
-			// the candidate list.
+		auto settle = [&](const Cand &x) __attribute__((always_inline)) {
+			bool first = false;
+			uint32_t key = 0, la = 0;
+			if (x.live) {
+				const uint32_t wi = x.ent & 127u, cp = x.cp;
+				const uint32_t assay = x.ent >> WT_ASSAY_SHIFT;
+				const uint32_t kmax = wi < cp ? wi : cp;
+				if (kmax == 0u) {
+					first = true;
+				} else if ((x.ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) {
+					const uint32_t w0 = (cp - kmax) >> 4;
+					first = s2_first_packed(tw(w0), tw(w0 + 1), tw(w0 + 2), x.seq, wi, cp, kmax, a.word_size);
+				} else {
+					const uint32_t li = (assay * 3u + ((x.ent >> 8) & 3u)) * 2u + ((x.ent & WT_MINUS) ? 1u : 0u);
+					first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
+				}
+				la = assay - a.assay_begin;
+				key = s2_key(la, x.ent, cp);
+			}
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(first);
+			if (first) {
+				const uint32_t slot = nkept + s2_rank(m);
+				if (slot < uint32_t(S2_CAP)) {
+					raw[slot] = key;
+					atomicAdd(reinterpret_cast<unsigned int *>(hist) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
+				}
+			}
+			nkept += uint32_t(__builtin_popcountll(m));
+		};
+		// Sweeps of 64 x 16 positions: a lane takes the two packed words that hold its positions (and the k - 1 bases behind
+		// them), extracts the k-mers with shifts and reads their bucket bounds -- both bounds with one 2-byte aligned dword
+		// gather, all 16 gathers in flight at once; one wave-wide prefix sum gives every lane its slice of the candidate
+		// list.  The list is drained (dense pass below) when the next sweep does not fit, and at the end; a sweep that does
+		// not fit an empty list (a burst of words shared by many expanded assays) is scanned position by position, the list
+		// drained as often as it fills.
+		uint32_t base = 0;          // first position of the next sweep
+		uint32_t slow_p = ~0u, slow_end = 0, slow_done = 0; // position-by-position scan of [.., slow_end): this lane's position, entries of it already taken
+		bool slow = false;          // wave-uniform
+		for (;;) {
 			uint32_t ncand = 0;
-			for (uint32_t base = 0; base < npos; base += 64 * S2_SWEEP) {
+			while (!slow && base < npos) {
 				const uint32_t p0 = base + uint32_t(lane) * S2_SWEEP;
 				unsigned long long v = 0;
-				if (p0 < npos) v = (unsigned long long)pk[p0 >> 4] | ((unsigned long long)pk[(p0 >> 4) + 1] << 32);
+				if (p0 < npos) v = (unsigned long long)tw(p0 >> 4) | ((unsigned long long)tw((p0 >> 4) + 1) << 32);
 				uint32_t bnd[S2_SWEEP]; // first entry | count << 16
 				uint32_t mine = 0;
 #pragma unroll
@@ -232,15 +312,14 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 					if (lane >= d) incl += y;
 				}
 				const uint32_t total = __shfl(incl, 63);
-				if (total == 0) continue;
-				if (ncand + total > uint32_t(S2_CAP)) { // make room
-					drain(ncand);
-					ncand = 0;
-				}
-				if (total > uint32_t(S2_CAP)) { // a burst (words shared by many expanded assays): position by position
-					const uint32_t e = base + 64 * S2_SWEEP;
-					scan_slow(base, e < npos ? e : npos);
-					continue;
+				if (ncand + total > uint32_t(S2_CAP)) {
+					if (ncand == 0) { // a burst: position by position
+						slow = true;
+						slow_p = base + uint32_t(lane), slow_done = 0;
+						slow_end = base + 64 * S2_SWEEP < npos ? base + 64 * S2_SWEEP : npos;
+						base += 64 * S2_SWEEP;
+					}
+					break; // drain, then take this sweep again (or scan it slowly)
 				}
 				uint32_t o = ncand + incl - mine;
 #pragma unroll
@@ -249,8 +328,54 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 					for (uint32_t n = bnd[q] >> 16; n > 0; n--, e++) cand[o++] = (p0 + q) | (e << 15);
 				}
 				ncand += total;
+				base += 64 * S2_SWEEP;
 			}
-			drain(ncand);
+			if (slow) {
+				while (true) {
+					uint32_t e0 = 0, cnt = 0;
+					if (slow_p < slow_end) {
+						const uint32_t wd = slow_p >> 4, shp = (slow_p & 15u) * 2u;
+						const uint32_t w = uint32_t(((unsigned long long)tw(wd) | ((unsigned long long)tw(wd + 1) << 32)) >> shp) & wmask;
+						e0 = uint32_t(a.wt_off[w]) + slow_done;
+						const uint32_t e1 = a.wt_off[w + 1];
+						cnt = e1 > e0 ? e1 - e0 : 0u;
+					}
+					uint32_t incl = cnt; // inclusive prefix of cnt over the lanes
+#pragma unroll
+					for (int d = 1; d < 64; d <<= 1) {
+						const uint32_t y = __shfl_up(incl, d);
+						if (lane >= d) incl += y;
+					}
+					const uint32_t at = ncand + incl - cnt;
+					const uint32_t fit = at < uint32_t(S2_CAP) ? (cnt < uint32_t(S2_CAP) - at ? cnt : uint32_t(S2_CAP) - at) : 0u;
+					for (uint32_t x = 0; x < fit; x++) cand[at + x] = slow_p | ((e0 + x) << 15);
+					bool over = false;
+					if (slow_p < slow_end) {
+						if (fit == cnt) slow_p += 64, slow_done = 0;
+						else slow_done += fit, over = true;
+					}
+					const uint32_t total = __shfl(incl, 63);
+					ncand = ncand + total < uint32_t(S2_CAP) ? ncand + total : uint32_t(S2_CAP);
+					if (__builtin_amdgcn_ballot_w64(over) != 0) break;
+					if (__builtin_amdgcn_ballot_w64(slow_p < slow_end) == 0) {
+						slow = false;
+						break;
+					}
+				}
+			}
+			// dense pass over the candidate list, two rounds of 64 in flight: the first seed of every (oligo, strand,
+			// diagonal) survives
+			wave_sync(); // the list was written by other lanes
+			S2_STAMP(1);
+			for (uint32_t c0 = 0; c0 < ncand; c0 += 128) {
+				const Cand x0 = fetch(c0 + uint32_t(lane), ncand);
+				const Cand x1 = fetch(c0 + 64u + uint32_t(lane), ncand);
+				settle(x0);
+				if (c0 + 64u < ncand) settle(x1);
+			}
+			wave_sync();
+			S2_STAMP(2);
+			if (!slow && base >= npos) break;
 		}
 		uint32_t n = nkept;
 		if (n > uint32_t(S2_CAP)) {
@@ -300,6 +425,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 		}
 		wave_sync();
 
+		S2_STAMP(3);
 		// ---------------------------------------------------------------- first cull, one lane per seed
 		// The seeds sit in `srt`, grouped by assay: segment of assay la = [off[la] - hist[la], off[la]), keys of one
 		// segment compare like the reference's list after the cull's stable sort by target_loc (amplicon_search.cpp:688).
@@ -311,18 +437,20 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 		//  * the strand of the list element FOLLOWING a valid seed is counted (:748-755; past-the-end counts nothing, Q4):
 		//    the counts decide which strand is bound first (:131).
 		// Probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454): every seed is valid.
+		uint32_t n_valid_all = 0; // valid seeds so far (wave-uniform)
 		for (uint32_t i0 = 0; i0 < n; i0 += 64) {
 			const uint32_t i = i0 + uint32_t(lane);
 			bool valid = false;
+			uint32_t kk = 0;
 			if (i < n) {
 				const uint32_t k = srt[i];
+				kk = k;
 				const uint32_t la = k >> 25, g = (k >> 7) & 7u;
 				const uint32_t af = s_af[la];
 				if (af & 1u) {
 					valid = true;
 				} else {
 					const uint32_t cnt = hist[la], s0 = uint32_t(off[la]) - cnt;
-					if (cnt > uint32_t(LIST_MAX)) atomicOr(a.err, ERR_LIST_OVERFLOW);
 					const bool minus = (0x13u >> g) & 1u;      // F-, R-, P-
 					const bool probe_me = g >= 4u;
 					const uint32_t role = g & 1u;              // primers: 0 F, 1 R
@@ -405,24 +533,34 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 				}
 				if (valid && (af & 1u)) atomicAdd(agg + la, 1u << 20);
 			}
+			// the valid seeds, still grouped by assay, move to `raw` (dead since the counting sort): the emission works on them only
 			const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
-			if (lane == 0) s_vmask[wv][i0 >> 6] = vm;
+			if (valid) raw[n_valid_all + s2_rank(vm)] = kk;
+			n_valid_all += uint32_t(__builtin_popcountll(vm));
 		}
 		wave_sync();
 
+		S2_STAMP(4);
 		// ---------------------------------------------------------------- emission: items, groups, phase-A queues
 		// Phase B = what the reference binds only after both primers were tried on the first strand
 		// (amplicon_search.cpp:131-353): the other strand's primers and the probe.
+		// No vector-memory LOAD in here: a load's wait would also wait for the stores in front of it (loads, stores and
+		// atomics retire in issue order), i.e. for the items and groups of the round before.  The pointers come from LDS.
 		uint32_t exc0 = 0, exc1 = 0;
 		if (a.has_exceptions) exc0 = a.db.exc_off[t], exc1 = a.db.exc_off[t + 1];
-		uint32_t carry_la = ~0u; // assay of the last valid seed so far
-		bool overflow = false;
-		for (uint32_t i0 = 0; i0 < n && !overflow; i0 += 64) {
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		typedef __attribute__((address_space(1))) u32x4 glb_u32x4; // an Item / a Group as one 16-byte store
+		typedef __attribute__((address_space(1))) uint32_t glb_u32;
+		static_assert(sizeof(Item) == 16 && sizeof(Group) == 16, "items and groups are written as one dwordx4");
+		glb_u32x4 *const g_items = (glb_u32x4 *)cold(COLD_ITEMS);
+		glb_u32x4 *const g_groups = (glb_u32x4 *)cold(COLD_GROUPS);
+		glb_u32 *const g_queue = (glb_u32 *)cold(COLD_QUEUE);
+		uint32_t carry_la = ~0u; // assay of the last seed of the round before
+		for (uint32_t i0 = 0; i0 < n_valid_all; i0 += 64) {
 			const uint32_t i = i0 + uint32_t(lane);
-			const unsigned long long vm = s_vmask[wv][i0 >> 6];
-			if (vm == 0) continue;
-			const bool valid = (vm >> lane) & 1ull;
-			const uint32_t k = i < n ? srt[i] : 0u;
+			const bool valid = i < n_valid_all;
+			const uint32_t n_valid = n_valid_all - i0 < 64u ? n_valid_all - i0 : 64u;
+			const uint32_t k = valid ? raw[i] : 0u;
 			const uint32_t la = k >> 25, g = (k >> 7) & 7u, wi = k & 127u, p = (k >> 10) & 0x7FFFu;
 			const uint32_t ag = valid ? agg[la] : 0u;
 			const bool minus_first = (ag & 1023u) < ((ag >> 10) & 1023u);
@@ -430,47 +568,31 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 			const uint32_t role = g >= 4u ? 2u : (g & 1u);
 			const bool nonpcr = valid && (s_af[la] & 1u);
 			const bool pb = valid && !nonpcr && (role == 2u || minus != minus_first);
-			const uint32_t n_valid = uint32_t(__builtin_popcountll(vm));
-			// the first valid seed of every assay opens the group
-			const unsigned long long before = vm & ((1ull << lane) - 1ull);
-			uint32_t la_prev = carry_la;
-			{
-				const int pl = before ? 63 - __builtin_clzll(before) : lane;
-				const uint32_t got = uint32_t(__shfl(int(la), pl));
-				if (before) la_prev = got;
-			}
+			// the first seed of every assay opens the group
+			uint32_t la_prev = uint32_t(__shfl_up(int(la), 1));
+			if (lane == 0) la_prev = carry_la;
 			const bool first = valid && la_prev != la;
 			const unsigned long long fm = __builtin_amdgcn_ballot_w64(first);
 			const uint32_t n_first = uint32_t(__builtin_popcountll(fm));
-			if (item_cur + n_valid > item_lo + a.item_region) {
-				if (lane == 0) atomicOr(a.err, ERR_ITEM_OVERFLOW);
-				overflow = true;
-				continue;
+			if (item_cur + n_valid > item_lo + a.item_region || group_cur + n_first > group_lo + a.group_region) {
+				if (lane == 0) __hip_atomic_fetch_or((glb_u32 *)cold(COLD_ERR), item_cur + n_valid > item_lo + a.item_region ? ERR_ITEM_OVERFLOW : ERR_GROUP_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				break;
 			}
-			if (group_cur + n_first > group_lo + a.group_region) {
-				if (lane == 0) atomicOr(a.err, ERR_GROUP_OVERFLOW);
-				overflow = true;
-				continue;
-			}
-			const uint32_t o = item_cur + s2_rank(vm);
+			const uint32_t o = item_cur + uint32_t(lane);
 			const uint32_t gidx = group_cur + uint32_t(__builtin_popcountll(fm & ((2ull << lane) - 1ull))) - 1u;
 			const uint32_t assay = a.assay_begin + la;
 			if (first) {
 				const uint32_t nv = ag >> 20;
-				a.groups[gidx] = Group{unit, assay | (minus_first ? GROUP_MINUS_FIRST : 0u), o, nv};
-				if (nv > 64u) atomicAdd(a.big_count, 1u);
+				g_groups[gidx] = u32x4{unit, assay | (minus_first ? GROUP_MINUS_FIRST : 0u), o, nv}; // Group{target (unit), assay | flags, first, count}
+				if (nv > 64u) __hip_atomic_fetch_add((glb_u32 *)cold(COLD_BIG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			uint32_t bucket = ~0u;
 			if (valid) {
 				const uint32_t slot = assay * 3u + role; // the Slot table is laid out [assay][role]
-				Item it;
-				it.target = t;
-				it.tloc = p;
-				it.info = wi | (minus ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | (slot << ITEM_SLOT_SHIFT);
-				it.group = gidx;
-				a.items[o] = it;
+				// Item{target, tloc, info, group}
+				g_items[o] = u32x4{t, p, wi | (minus ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | (slot << ITEM_SLOT_SHIFT), gidx};
 				if (!pb) {
-					const uint32_t sp = a.slot_pack[slot];
+					const uint32_t sp = s_slot[la * 3u + role];
 					bucket = sp & 0xFFu;
 					if (exc1 > exc0) { // same window as the bind kernel, bind_oligo.cpp:502-505
 						int start = int(p) - (int(wi) + FLANK);
@@ -500,12 +622,12 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 						s_qpos[wv][lane] = cur;
 						s_qsplit[wv][lane] = end;
 						if (cur + h > end) { // the block is full: the rest of the round goes to a new one
-							const uint32_t at = atomicAdd(a.q_count + lane * BUCKET_STRIDE, QUEUE_BLOCK);
-							if (at + QUEUE_BLOCK > a.q_cap[lane]) {
-								atomicOr(a.err, ERR_ITEM_OVERFLOW);
+							const uint32_t at = __hip_atomic_fetch_add((glb_u32 *)cold(COLD_Q_COUNT) + lane * BUCKET_STRIDE, QUEUE_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							if (at + QUEUE_BLOCK > s_qcap[lane]) {
+								__hip_atomic_fetch_or((glb_u32 *)cold(COLD_ERR), ERR_ITEM_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 								s_qnew[wv][lane] = ~0u;
 							} else {
-								const uint32_t nb = a.q_base[lane] + at;
+								const uint32_t nb = s_qbase[lane] + at;
 								s_qnew[wv][lane] = nb;
 								s_qend[wv][lane] = nb + QUEUE_BLOCK;
 								cur = nb - (end - cur); // so that cur + h lands h - (end - cur) slots into the new block
@@ -523,16 +645,23 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 						const uint32_t nb = s_qnew[wv][bucket];
 						pos = nb == ~0u ? ~0u : nb + (pos - split);
 					}
-					if (pos != ~0u) a.queue[pos] = o;
+					if (pos != ~0u) g_queue[pos] = o;
 				}
 				n_phase_a += uint32_t(__builtin_popcountll(am));
 			}
 			item_cur += n_valid;
 			group_cur += n_first;
-			carry_la = uint32_t(__shfl(int(la), 63 - __builtin_clzll(vm)));
+			carry_la = uint32_t(__shfl(int(la), int(n_valid) - 1));
 		}
 		wave_sync();
+		S2_STAMP(5);
 	}
+#ifdef TNT_EXP_STATS
+	if (lane == 0 && a.debug) { // setup, scan, dense pass, sort, cull, emission: kilo-cycles
+		for (int q = 0; q < 6; q++) atomicAdd(a.debug + q, uint32_t(st_acc[q] >> 10));
+		atomicAdd(a.debug + 7, 1u);
+	}
+#endif
 
 	// what is left of the wavefront's last blocks holds no item
 	wave_sync();
