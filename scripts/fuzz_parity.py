@@ -118,9 +118,10 @@ def main():
         except Exception as e:
             got = ("error", str(e)[:60])
         ok = got == want or (isinstance(got, tuple) and isinstance(want, tuple))
-        if not ok and isinstance(got, tuple) and "overflowed the LDS buffer" in got[1]:
+        if not ok and isinstance(got, tuple) and ("overflowed the LDS buffer" in got[1] or "more than 32768 seeds of one assay" in got[1]):
             # the documented capacity limit (more seeds of one assay chunk inside one seed work unit than
-            # the LDS lists hold -- word size 5 on long targets): reported as TNT_E_LIMIT, never a silent difference
+            # the LDS lists hold -- word size 5 on long targets; more than 32 768 seeds of one assay on one target -- word size 3
+            # on targets of 100 kb and more): reported as TNT_E_LIMIT, never a silent difference
             limited += 1
             ok = True
         if isinstance(want, list):

@@ -463,6 +463,17 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 	__shared__ uint8_t s_pf[PF * BIND_THREADS];
 
 	const int tid = threadIdx.x;
+	// A workgroup without work leaves before it stages the tables: the grid is sized for full queues, the queues behind the
+	// pre-filter are short, and the launches of a phase share the CUs with each other (side streams) -- an idle workgroup
+	// that fills 40 KB of LDS tables first keeps a CU from the launch next to it.
+	{
+		uint32_t n_all = a.n_items;
+		if (a.n_items_dev) {
+			const uint32_t n_dev = *a.n_items_dev;
+			n_all = n_dev < n_all ? n_dev : n_all;
+		}
+		if (uint32_t(blockIdx.x) * uint32_t(BIND_THREADS) >= n_all) return;
+	}
 	if (PLAIN) {
 		for (int at = tid; at < 5 * 4 * NBP; at += BIND_THREADS) {
 			const int xpc = at / (4 * NBP), x = (at / NBP) & 3, qp = (at % NBP) / NB, q = at % NB;

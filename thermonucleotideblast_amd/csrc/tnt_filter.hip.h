@@ -93,6 +93,14 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 	typedef short s2 __attribute__((ext_vector_type(2))); // (X, M2) of a cell, or (stack, loop entry) of a table entry: one register
 
 	const int tid = threadIdx.x;
+	{ // a workgroup without work leaves before it stages the table (the grid is sized for full queues)
+		uint32_t n_all = a.n_items;
+		if (a.n_items_dev) {
+			const uint32_t n_dev = *a.n_items_dev;
+			n_all = n_dev < n_all ? n_dev : n_all;
+		}
+		if (uint32_t(blockIdx.x) * uint32_t(THREADS) >= n_all) return;
+	}
 	for (int i = tid; i < FILT_CLASSES * FILT_PLANE; i += THREADS) s_tab[i] = (&a.tab->plane[0][0])[i];
 	static_assert(sizeof(a.tab->plane) == sizeof(uint32_t) * FILT_CLASSES * FILT_PLANE, "table size");
 	__syncthreads();

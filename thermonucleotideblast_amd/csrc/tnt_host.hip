@@ -473,8 +473,6 @@ struct tnt_ctx {
 	// pre-filter of the bind stage (tnt_filter.hip.h)
 	FilterTables h_ftab;
 	DevBuf<FilterTables> ftab;
-	DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
-	DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
 	bool filter_on = false, filter_audit = false;
 	bool serial_bind = false; // profiling: every launch of the bind stage on one side stream (per-kernel durations add up to the stage time)
 	DevBuf<uint8_t> olig_base;
@@ -485,7 +483,6 @@ struct tnt_ctx {
 	// that repeat an earlier item of their target take its bind result (the reference's per-target BindCache, a6)
 	std::vector<uint32_t> h_slot_canon, h_slot_next;
 	DevBuf<uint32_t> slot_canon, slot_next;
-	DevBuf<uint32_t> item_rep;
 	bool dedupe = false;
 	int unit_rows = 64; // rows of the unit-level kernel instance this context's oligos need (64 or MAX_OLIGO)
 	bool filter_general = false; // the general buckets (degenerate windows, merged short queues) meet the pre-filter too
@@ -493,10 +490,9 @@ struct tnt_ctx {
 	// round-3 seed kernel of the search path (tnt_seed2.hip.h): items / groups in regions private to a wavefront, phase-A
 	// items straight into the queue of their length bucket
 	bool seed2 = false;
+	int pipeline_batches = 1;        // batches a large search is cut into on two buffer sets (TNT_MI355X_PIPELINE; 1: one batch after the other on one stream -- measured faster)
 	static constexpr uint32_t MAX_REGIONS = 8192;
 	DevBuf<uint32_t> slot_pack;      // [slot] bucket | bucket_general << 8 | oligo length << 16
-	DevBuf<uint32_t> region_counts;  // [2 * MAX_REGIONS] items, groups of every region
-	DevBuf<uint32_t> q_state;        // [MAX_REGIONS][MAX_BUCKETS][2]
 	DevBuf<uint32_t> q_base, q_cap;  // [bucket] region of every phase-A queue inside `qa`
 	std::vector<uint32_t> h_q_base, h_q_cap;
 	bool q_planned_exceptions = false;
@@ -512,19 +508,34 @@ struct tnt_ctx {
 	std::vector<uint32_t> chunk_ent_base;  // first entry of every chunk in wt_ent
 	std::vector<uint32_t> planned_chunks;  // chunk_begin the device tables were built for
 
-	// work buffers
-	DevBuf<Item> items;
-	DevBuf<int32_t> result;
-	DevBuf<Group> groups;
-	DevBuf<uint32_t> active, qa, qb;
-	DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
+	// Work buffers of one internal batch.  Two sets: the seed stage of batch n + 1 runs on a stream of its own and fills one
+	// set while the bind and pair stages of batch n work on the other (tnt_search_enqueue).
+	struct BatchSet {
+		DevBuf<Item> items;
+		DevBuf<int32_t> result;
+		DevBuf<Group> groups;
+		DevBuf<uint32_t> active, qa, qb;
+		DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
+		DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
+		DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
+		DevBuf<uint32_t> item_rep;
+		DevBuf<BoundRec> pool;
+		DevBuf<uint32_t> counters;       // per-batch counters; the search-wide ones (hits, error word, totals) live in set 0's
+		DevBuf<uint32_t> region_counts;  // [2 * MAX_REGIONS] items, groups of every region
+		DevBuf<uint32_t> q_state;        // [MAX_REGIONS][MAX_BUCKETS][2]
+		hipEvent_t seeded = nullptr, released = nullptr; // the seed stage filled the set / the pair stage is done with it
+		bool used = false;
+	};
+	BatchSet set[2];
+	int cur = 0;
+	BatchSet &S() { return set[cur]; }
+	uint32_t *G() { return set[0].counters.p; } // search-wide counters
+	hipStream_t seed_stream = nullptr;
 	bool dev_hits_valid = false; // ctx->hits still equals the host copy of the last collected search
 	size_t dev_hits_n = 0;
 	DevBuf<uint8_t> hit_blob;   // compact form of the hits (tnt_search_hits_compact)
 	DevBuf<uint32_t> hit_sizes;
-	DevBuf<BoundRec> pool;
 	DevBuf<Hit> hits;
-	DevBuf<uint32_t> counters; // 0 items, 1 groups, 2 pool, 3 hits, 4 err, 5 seeds, 6 active
 	DevBuf<uint8_t> trace;
 	DevBuf<uint16_t> ties;
 	DevBuf<uint8_t> best;
@@ -560,6 +571,11 @@ struct tnt_ctx {
 			if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
 		}
 		if (phase_ready) (void)hipEventDestroy(phase_ready);
+		for (BatchSet &W : set) {
+			if (W.seeded) (void)hipEventDestroy(W.seeded);
+			if (W.released) (void)hipEventDestroy(W.released);
+		}
+		if (seed_stream) (void)hipStreamDestroy(seed_stream);
 		if (stream) (void)hipStreamDestroy(stream);
 	}
 };
@@ -574,11 +590,11 @@ enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items *
 static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
-__global__ void accumulate_kernel(uint32_t *cnt)
+__global__ void accumulate_kernel(uint32_t *cnt, uint32_t *g) // cnt: the batch's counters, g: the search-wide ones
 {
-	unsigned long long *ti = reinterpret_cast<unsigned long long *>(cnt + C_TOT_ITEMS_LO);
-	unsigned long long *tg = reinterpret_cast<unsigned long long *>(cnt + C_TOT_GROUPS_LO);
-	unsigned long long *tb = reinterpret_cast<unsigned long long *>(cnt + C_TOT_BINDS_LO);
+	unsigned long long *ti = reinterpret_cast<unsigned long long *>(g + C_TOT_ITEMS_LO);
+	unsigned long long *tg = reinterpret_cast<unsigned long long *>(g + C_TOT_GROUPS_LO);
+	unsigned long long *tb = reinterpret_cast<unsigned long long *>(g + C_TOT_BINDS_LO);
 	for (uint32_t r = 0; r < N_SHARD; r++) {
 		*ti += cnt[C_ITEMS + r * SHARD_STRIDE];
 		*tg += cnt[C_GROUPS + r * SHARD_STRIDE];
@@ -587,7 +603,7 @@ __global__ void accumulate_kernel(uint32_t *cnt)
 	*tb += cnt[C_QB];
 	*tb -= cnt[C_DUPS];
 	cnt[C_DUPS] = 0;
-	cnt[C_TOT_BOUND] += cnt[C_POOL];
+	g[C_TOT_BOUND] += cnt[C_POOL];
 }
 
 static size_t cap_from_env(const char *name, size_t dflt_m)
@@ -715,13 +731,13 @@ template <bool LDS_TABLES> void launch_seed(const SeedArgs &s, int mode, int blo
 
 // One phase of binding: split the queue by oligo length, then one launch per length bucket.
 // `direct`: the queues of the length buckets are in place already (the round-3 seed kernel writes its phase-A items straight
-// into them, region q_base[i] of c->qa, slots handed out in C_BUCKET + i * BUCKET_STRIDE; unused slots hold QUEUE_HOLE).
+// into them, region q_base[i] of c->S().qa, slots handed out in C_BUCKET + i * BUCKET_STRIDE; unused slots hold QUEUE_HOLE).
 void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_exceptions, const uint32_t *src, const uint32_t *src_count,
-                       const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always */,
+                       const uint32_t *shard_counts, int merge_mode = 0 /* 0: short queues go to the longest general instance; 1: never; 2: always; 3: queues up to 8 x as long */,
                        bool direct = false)
 {
 	if (c->opt.use_dinkelbach) merge_mode = 2; // the Dinkelbach passes only exist in the longest general instance
-	uint32_t *cnt = c->counters.p;
+	uint32_t *cnt = c->S().counters.p, *gcnt = c->G();
 	if (!direct) {
 		(void)hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream);
 		BucketArgs k;
@@ -730,20 +746,23 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		k.src_count = src_count;
 		k.shard_counts = shard_counts;
 		k.shard_region = uint32_t(ITEM_CAP / N_SHARD);
-		k.items = c->items.p;
+		k.items = c->S().items.p;
 		k.slots = b.slots;
 		k.olig_len = c->olig_len.p;
 		k.db = v;
 		k.has_exceptions = has_exceptions ? 1 : 0;
-		k.dst = c->qbucket.p;
+		k.dst = c->S().qbucket.p;
 		k.cap = uint32_t(ITEM_CAP);
 		k.counters = cnt + C_BUCKET;
 		k.n_buckets = int(c->bucket_lmax.size());
 		k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads(c->bucket_lmax.back()));
 		if (merge_mode == 1) k.merge_below = 0;
 		if (merge_mode == 2) k.merge_below = 0xFFFFFFFFu;
-		k.err = cnt + C_ERR;
-		k.item_rep = (c->dedupe && shard_counts) ? c->item_rep.p : nullptr; // phase A only: phase-B items are never duplicates
+		// phase B of a search: few of its windows pass the pre-filter, and a launch per length class costs its start-up
+		// and the serial tail of its slowest lane (0.2 - 0.3 ms each, eighteen of them on config 2) whatever it binds
+		if (merge_mode == 3) k.merge_below *= 8;
+		k.err = gcnt + C_ERR;
+		k.item_rep = (c->dedupe && shard_counts) ? c->S().item_rep.p : nullptr; // phase A only: phase-B items are never duplicates
 		hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 		hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	}
@@ -758,8 +777,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		if (direct && c->h_q_cap[i] == 0) continue; // no slot routes its items here
 		const int lane = c->serial_bind ? 0 : n_launch++ % tnt_ctx::BIND_LANES;
 		if (c->serial_bind) n_launch = 1;
-		const uint32_t *queue = direct ? c->qa.p + c->h_q_base[i] : c->qbucket.p;
-		uint32_t *survivors = c->qsurv.p ? c->qsurv.p + (direct ? c->h_q_base[i] : 0u) : nullptr;
+		const uint32_t *queue = direct ? c->S().qa.p + c->h_q_base[i] : c->S().qbucket.p;
+		uint32_t *survivors = c->S().qsurv.p ? c->S().qsurv.p + (direct ? c->h_q_base[i] : 0u) : nullptr;
 		b.index = queue;
 		b.index_base_dev = direct ? nullptr : cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
@@ -786,8 +805,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.survivors = survivors;
 			f.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 3;
 			f.result = b.result;
-			f.n_rejected = cnt + C_FILTERED;
-			f.audit = c->filter_audit ? c->audit.p : nullptr;
+			f.n_rejected = gcnt + C_FILTERED;
+			f.audit = c->filter_audit ? c->S().audit.p : nullptr;
 			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
 			b.index = survivors;
 			b.n_items_dev = f.n_survivors;
@@ -833,24 +852,35 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 	return TNT_OK;
 }
 
+int ensure_set(tnt_ctx *c, int k)
+{
+	tnt_ctx::BatchSet &W = c->set[k];
+	if (W.items.p) return TNT_OK;
+	HIP_TRY(W.items.alloc(ITEM_CAP), c->err);
+	HIP_TRY(W.result.alloc(ITEM_CAP), c->err);
+	HIP_TRY(W.groups.alloc(GROUP_CAP), c->err);
+	HIP_TRY(W.active.alloc(GROUP_CAP), c->err);
+	HIP_TRY(W.qa.alloc(ITEM_CAP), c->err);
+	HIP_TRY(W.qb.alloc(ITEM_CAP), c->err);
+	HIP_TRY(W.qbucket.alloc(ITEM_CAP), c->err);
+	if (c->filter_on) HIP_TRY(W.qsurv.alloc(ITEM_CAP), c->err);
+	if (c->filter_audit) HIP_TRY(W.audit.alloc(ITEM_CAP), c->err);
+	if (c->dedupe) HIP_TRY(W.item_rep.alloc(ITEM_CAP), c->err);
+	HIP_TRY(W.pool.alloc(POOL_CAP), c->err);
+	HIP_TRY(W.counters.alloc(C_COUNT), c->err);
+	HIP_TRY(W.region_counts.alloc(2 * tnt_ctx::MAX_REGIONS), c->err);
+	HIP_TRY(W.q_state.alloc(size_t(tnt_ctx::MAX_REGIONS) * MAX_BUCKETS * 2), c->err);
+	HIP_TRY(hipEventCreateWithFlags(&W.seeded, hipEventDisableTiming), c->err);
+	HIP_TRY(hipEventCreateWithFlags(&W.released, hipEventDisableTiming), c->err);
+	return TNT_OK;
+}
+
 int ensure_work_buffers(tnt_ctx *c, int need_lmax)
 {
-	if (!c->items.p) {
-		HIP_TRY(c->items.alloc(ITEM_CAP), c->err);
-		HIP_TRY(c->result.alloc(ITEM_CAP), c->err);
-		HIP_TRY(c->groups.alloc(GROUP_CAP), c->err);
-		HIP_TRY(c->active.alloc(GROUP_CAP), c->err);
-		HIP_TRY(c->qa.alloc(ITEM_CAP), c->err);
-		HIP_TRY(c->qb.alloc(ITEM_CAP), c->err);
-		HIP_TRY(c->qbucket.alloc(ITEM_CAP), c->err);
-		if (c->filter_on) HIP_TRY(c->qsurv.alloc(ITEM_CAP), c->err);
-		if (c->filter_audit) HIP_TRY(c->audit.alloc(ITEM_CAP), c->err);
-		if (c->dedupe) HIP_TRY(c->item_rep.alloc(ITEM_CAP), c->err);
-		HIP_TRY(c->pool.alloc(POOL_CAP), c->err);
+	if (!c->set[0].items.p) {
+		const int rc = ensure_set(c, 0);
+		if (rc) return rc;
 		HIP_TRY(c->hits.alloc(c->hit_cap), c->err);
-		HIP_TRY(c->counters.alloc(C_COUNT), c->err);
-		HIP_TRY(c->region_counts.alloc(2 * tnt_ctx::MAX_REGIONS), c->err);
-		HIP_TRY(c->q_state.alloc(size_t(tnt_ctx::MAX_REGIONS) * MAX_BUCKETS * 2), c->err);
 	}
 	return ensure_scratch(c, need_lmax);
 }
@@ -866,20 +896,20 @@ BindArgs bind_args(tnt_ctx *c, const DbView &v)
 	a.olig_len = c->olig_len.p;
 	a.slots = c->slots.p;
 	a.thresh = c->thresh.p;
-	a.items = c->items.p;
-	a.result = c->result.p;
-	a.pool = c->pool.p;
+	a.items = c->S().items.p;
+	a.result = c->S().result.p;
+	a.pool = c->S().pool.p;
 	a.pool_cap = uint32_t(POOL_CAP);
-	a.pool_count = c->counters.p + C_POOL;
+	a.pool_count = c->S().counters.p + C_POOL;
 	a.trace = c->trace.p;
 	a.best = c->best.p;
 	a.stack = c->stack.p;
 	a.ties = c->ties.p;
-	a.err = c->counters.p + C_ERR;
-	a.groups = c->groups.p;
-	a.active = c->active.p;
-	a.n_active = c->counters.p + C_ACTIVE;
-	a.debug = c->counters.p + C_DEBUG;
+	a.err = c->G() + C_ERR;
+	a.groups = c->S().groups.p;
+	a.active = c->S().active.p;
+	a.n_active = c->S().counters.p + C_ACTIVE;
+	a.debug = c->G() + C_DEBUG;
 	return a;
 }
 
@@ -1187,6 +1217,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	}
 	// the round-3 seed kernel serves every search but those that mark shared oligos in the seed kernel
 	c->seed2 = !c->dedupe && !getenv("TNT_MI355X_SEED_V2");
+	if (const char *pe = getenv("TNT_MI355X_PIPELINE")) c->pipeline_batches = std::max(1, std::min(64, atoi(pe)));
 	std::vector<uint32_t> slot_pack(std::max<size_t>(1, c->h_slots.size()), 0u);
 	for (size_t si = 0; si < c->h_slots.size(); si++) {
 		const Slot &sl = c->h_slots[si];
@@ -1895,22 +1926,29 @@ int tnt_db_ingest_timing(const tnt_db *db, tnt_ingest_timing *out)
 	return TNT_OK;
 }
 
-// One internal batch: seed -> bind -> filter -> pair, all on the context stream.
-static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seeds_only)
+// One internal batch: seed -> bind -> filter -> pair.  `pipelined`: the batch works on buffer set c->cur; its seed stage runs
+// on the seed stream (behind the pair stage of the batch that used the set before), everything else on the context stream
+// (behind its seed stage), so that the seed stage of the next batch -- issue-bound scalar / LDS work with long memory waits
+// -- runs beside the bind stage of this one.  Otherwise everything runs on the context stream with set 0.
+static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seeds_only, bool pipelined = false)
 {
 	// one internal batch = a range of seed work units; target indices stay those of the whole database
 	const DbView v = make_view(db, 0, db->n_targets);
-	uint32_t *cnt = c->counters.p;
+	if (!pipelined) c->cur = 0;
+	tnt_ctx::BatchSet &W = c->S();
+	uint32_t *cnt = W.counters.p, *gcnt = c->G();
+	hipStream_t seed_stream = pipelined ? c->seed_stream : c->stream;
+	if (pipelined && W.used) HIP_TRY(hipStreamWaitEvent(seed_stream, W.released, 0), c->err); // the set is free again
 	// hits and the error word accumulate over batches; the rest restarts
-	HIP_TRY(hipMemsetAsync(cnt + C_POOL, 0, sizeof(uint32_t) * 3, c->stream), c->err);
-	HIP_TRY(hipMemsetAsync(cnt + C_ITEMS, 0, sizeof(uint32_t) * 3 * N_SHARD * SHARD_STRIDE, c->stream), c->err);
+	HIP_TRY(hipMemsetAsync(cnt + C_POOL, 0, sizeof(uint32_t) * 4, seed_stream), c->err);
+	HIP_TRY(hipMemsetAsync(cnt + C_ITEMS, 0, sizeof(uint32_t) * 3 * N_SHARD * SHARD_STRIDE, seed_stream), c->err);
 
-	hipEvent_t ev[4];
-	for (int i = 0; i < 4; i++) {
+	hipEvent_t ev[5]; // seed start, bind start, bind end, pair end, seed end
+	for (int i = 0; i < 5; i++) {
 		HIP_TRY(hipEventCreate(&ev[i]), c->err);
 		c->events.push_back(ev[i]);
 	}
-	HIP_TRY(hipEventRecord(ev[0], c->stream), c->err);
+	HIP_TRY(hipEventRecord(ev[0], seed_stream), c->err);
 
 	SeedArgs s;
 	memset(&s, 0, sizeof(s));
@@ -1927,31 +1965,31 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	s.max_len = c->opt.max_len;
 	s.single_primer_pcr = c->opt.single_primer_pcr;
 	if (!seeds_only) {
-		s.items = c->items.p;
+		s.items = c->S().items.p;
 		s.item_cap = uint32_t(ITEM_CAP);
 		s.item_count = cnt + C_ITEMS;
-		s.groups = c->groups.p;
+		s.groups = c->S().groups.p;
 		s.group_cap = uint32_t(GROUP_CAP);
 		s.group_count = cnt + C_GROUPS;
-		s.qa = c->qa.p;
+		s.qa = c->S().qa.p;
 		s.qa_count = cnt + C_QA;
 		s.big_count = cnt + C_BIG;
-		if (c->dedupe) s.slot_canon = c->slot_canon.p, s.slot_next = c->slot_next.p, s.item_rep = c->item_rep.p;
+		if (c->dedupe) s.slot_canon = c->slot_canon.p, s.slot_next = c->slot_next.p, s.item_rep = c->S().item_rep.p;
 	} else {
 		s.seeds_out = c->seeds_out.p;
 		s.seeds_cap = uint32_t(c->seeds_out.n);
 		s.seeds_count = cnt + C_SEEDS;
 	}
-	s.err = cnt + C_ERR;
-	s.debug = cnt + C_DEBUG + 8;
+	s.err = gcnt + C_ERR;
+	s.debug = gcnt + C_DEBUG + 8;
 	const bool direct = c->seed2 && !seeds_only; // the round-3 seed kernel: private regions, phase-A items straight into their buckets' queues
 	if (direct) {
 		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * 4, tnt_ctx::MAX_REGIONS / S2_WAVES)));
 		const uint32_t regions = blocks * S2_WAVES;
 		c->batch_regions = regions;
-		HIP_TRY(hipMemsetAsync(c->region_counts.p, 0, sizeof(uint32_t) * 2 * regions, c->stream), c->err);
-		HIP_TRY(hipMemsetAsync(c->q_state.p, 0, sizeof(uint32_t) * size_t(regions) * MAX_BUCKETS * 2, c->stream), c->err);
-		HIP_TRY(hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, c->stream), c->err);
+		HIP_TRY(hipMemsetAsync(c->S().region_counts.p, 0, sizeof(uint32_t) * 2 * regions, seed_stream), c->err);
+		HIP_TRY(hipMemsetAsync(c->S().q_state.p, 0, sizeof(uint32_t) * size_t(regions) * MAX_BUCKETS * 2, seed_stream), c->err);
+		HIP_TRY(hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, seed_stream), c->err);
 		Seed2Args q;
 		memset(&q, 0, sizeof(q));
 		q.db = v;
@@ -1964,18 +2002,18 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		q.single_primer_pcr = c->opt.single_primer_pcr;
 		q.slot_pack = c->slot_pack.p;
 		q.has_exceptions = db->n_exceptions != 0 ? 1 : 0;
-		q.items = c->items.p, q.item_region = uint32_t(ITEM_CAP / regions);
-		q.groups = c->groups.p, q.group_region = uint32_t(GROUP_CAP / regions);
-		q.region_counts = c->region_counts.p;
-		q.queue = c->qa.p;
+		q.items = c->S().items.p, q.item_region = uint32_t(ITEM_CAP / regions);
+		q.groups = c->S().groups.p, q.group_region = uint32_t(GROUP_CAP / regions);
+		q.region_counts = c->S().region_counts.p;
+		q.queue = c->S().qa.p;
 		q.q_base = c->q_base.p, q.q_cap = c->q_cap.p;
 		q.q_count = cnt + C_BUCKET;
-		q.q_state = c->q_state.p;
+		q.q_state = c->S().q_state.p;
 		q.n_buckets = int(c->bucket_lmax.size());
 		q.stat_items = cnt + C_ITEMS, q.stat_groups = cnt + C_GROUPS, q.stat_phase_a = cnt + C_QA;
 		q.big_count = cnt + C_BIG;
-		q.err = cnt + C_ERR;
-		q.debug = cnt + C_DEBUG + 8;
+		q.err = gcnt + C_ERR;
+		q.debug = gcnt + C_DEBUG + 8;
 		const size_t n_words2 = size_t(1) << (2 * c->opt.hash_word_size);
 		const size_t off_stride2 = (n_words2 + 1 + 1) & ~size_t(1);
 		for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
@@ -1988,7 +2026,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 			for (uint32_t ai = q.assay_begin; ai < q.assay_end; ai++)
 				if (c->h_assays[ai].kind == 0 && c->h_assays[ai].has_probe) q.chunk_has_probe = 1;
 			q.last_chunk = ch + 2 == c->chunk_begin.size() ? 1 : 0;
-			hipLaunchKernelGGL(seed2_kernel, dim3(blocks), dim3(S2_THREADS), 0, c->stream, q);
+			hipLaunchKernelGGL(seed2_kernel, dim3(blocks), dim3(S2_THREADS), 0, seed_stream, q);
 		}
 	}
 	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
@@ -2003,9 +2041,14 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		s.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
 		s.n_ent = c->chunk_ent_base[ch + 1] - c->chunk_ent_base[ch];
 		if (c->seed_lds && s.n_ent <= uint32_t(SEED_LDS_ENT))
-			launch_seed<true>(s, seeds_only ? SEED_LIST : (s.item_rep ? SEED_SEARCH_SHARED : SEED_SEARCH), lds_blocks, 64 * SEED_LDS_WAVES, c->stream);
+			launch_seed<true>(s, seeds_only ? SEED_LIST : (s.item_rep ? SEED_SEARCH_SHARED : SEED_SEARCH), lds_blocks, 64 * SEED_LDS_WAVES, seed_stream);
 		else
-			launch_seed<false>(s, seeds_only ? SEED_LIST : (s.item_rep ? SEED_SEARCH_SHARED : SEED_SEARCH), seed_blocks, SEED_THREADS, c->stream);
+			launch_seed<false>(s, seeds_only ? SEED_LIST : (s.item_rep ? SEED_SEARCH_SHARED : SEED_SEARCH), seed_blocks, SEED_THREADS, seed_stream);
+	}
+	HIP_TRY(hipEventRecord(ev[4], seed_stream), c->err);
+	if (pipelined) { // the stages behind the seed stage run on the context stream
+		HIP_TRY(hipEventRecord(W.seeded, seed_stream), c->err);
+		HIP_TRY(hipStreamWaitEvent(c->stream, W.seeded, 0), c->err);
 	}
 	HIP_TRY(hipEventRecord(ev[1], c->stream), c->err);
 	if (seeds_only) { // (every event of the set is recorded: the stage timings walk over all of them)
@@ -2016,45 +2059,45 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 
 	// phase A: first strand of the PCR groups, every seed of the probe / padlock groups
 	BindArgs b = bind_args(c, v);
-	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->qa.p, nullptr, cnt + C_QA, 0, direct);
+	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->S().qa.p, nullptr, cnt + C_QA, 0, direct);
 	if (c->dedupe) {
 		PropagateArgs pa;
 		memset(&pa, 0, sizeof(pa));
-		pa.src = c->qa.p;
+		pa.src = c->S().qa.p;
 		pa.shard_counts = cnt + C_QA;
 		pa.shard_region = uint32_t(ITEM_CAP / N_SHARD);
 		pa.cap = uint32_t(ITEM_CAP);
-		pa.items = c->items.p;
-		pa.item_rep = c->item_rep.p;
-		pa.result = c->result.p;
-		pa.groups = c->groups.p;
-		pa.active = c->active.p;
+		pa.items = c->S().items.p;
+		pa.item_rep = c->S().item_rep.p;
+		pa.result = c->S().result.p;
+		pa.groups = c->S().groups.p;
+		pa.active = c->S().active.p;
 		pa.n_active = cnt + C_ACTIVE;
 		pa.n_dups = cnt + C_DUPS;
 		hipLaunchKernelGGL(propagate_kernel, dim3(1024), dim3(256), 0, c->stream, pa);
 	}
 
 	FilterArgs f;
-	f.groups = c->groups.p;
-	f.items = c->items.p;
-	f.active = c->active.p;
+	f.groups = c->S().groups.p;
+	f.items = c->S().items.p;
+	f.active = c->S().active.p;
 	f.n_active = cnt + C_ACTIVE;
-	f.qb = c->qb.p;
+	f.qb = c->S().qb.p;
 	f.qb_count = cnt + C_QB;
 	hipLaunchKernelGGL(filter_kernel, dim3(256), dim3(256), 0, c->stream, f);
 
 	// phase B: the other strand and the probes of the groups that are still alive
-	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->qb.p, cnt + C_QB, nullptr);
+	launch_bind_phase(c, b, v, db->n_exceptions != 0, c->S().qb.p, cnt + C_QB, nullptr, getenv("TNT_MI355X_PHASE_B_BUCKETS") ? 0 : 3);
 	HIP_TRY(hipEventRecord(ev[2], c->stream), c->err);
 
 	PairArgs p;
 	memset(&p, 0, sizeof(p));
-	p.groups = c->groups.p;
-	p.active = c->active.p;
+	p.groups = c->S().groups.p;
+	p.active = c->S().active.p;
 	p.n_active = cnt + C_ACTIVE;
-	p.items = c->items.p;
-	p.result = c->result.p;
-	p.pool = c->pool.p;
+	p.items = c->S().items.p;
+	p.result = c->S().result.p;
+	p.pool = c->S().pool.p;
 	p.assays = c->assays.p;
 	p.db = v;
 	p.max_len = c->opt.max_len;
@@ -2064,8 +2107,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	p.target_strand = c->opt.target_strand;
 	p.hits = c->hits.p;
 	p.hit_cap = uint32_t(c->hit_cap);
-	p.hit_count = cnt + C_HITS;
-	p.err = cnt + C_ERR;
+	p.hit_count = gcnt + C_HITS;
+	p.err = gcnt + C_ERR;
 	p.n_big = cnt + C_BIG;
 	p.unit_target = db->unit_target.p;
 	p.unit_own_lo = db->unit_own_lo.p;
@@ -2080,8 +2123,12 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	}
 	hipLaunchKernelGGL(pair_kernel<PAIR_MAX>, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
 	if (p.big_enabled) hipLaunchKernelGGL(pair_kernel<PAIR_BIG>, dim3(64), dim3(PAIR_THREADS), 0, c->stream, p);
-	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt);
+	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt, gcnt);
 	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
+	if (pipelined) {
+		HIP_TRY(hipEventRecord(W.released, c->stream), c->err);
+		W.used = true;
+	}
 	HIP_TRY(hipGetLastError(), c->err);
 	return TNT_OK;
 }
@@ -2331,7 +2378,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		ctx->err = std::string("before the long-target path: ") + hipGetErrorString(stale);
 		return TNT_E_DEVICE;
 	}
-	uint32_t *cnt = ctx->counters.p;
+	uint32_t *cnt = ctx->S().counters.p;
 	// ---- seeds of every window (the seed kernel's unit-level output: kept seeds before the cull)
 	std::vector<SeedOut> raw;
 	for (int attempt = 0;; attempt++) {
@@ -2501,12 +2548,12 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
-		HIP_TRY(hipMemcpy(ctx->items.p, bind_items.data() + c0, nc * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
-		HIP_TRY(hipMemcpy(ctx->qb.p, queue.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(hipMemcpy(ctx->S().items.p, bind_items.data() + c0, nc * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(hipMemcpy(ctx->S().qb.p, queue.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
 		HIP_TRY(hipMemcpy(cnt + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
 		BindArgs b = bind_args(ctx, v);
 		b.groups = nullptr;
-		launch_bind_phase(ctx, b, v, db->n_exceptions != 0, ctx->qb.p, cnt + C_QB, nullptr);
+		launch_bind_phase(ctx, b, v, db->n_exceptions != 0, ctx->S().qb.p, cnt + C_QB, nullptr);
 		uint32_t h[C_COUNT];
 		HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
@@ -2516,10 +2563,10 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 			return TNT_E_LIMIT;
 		}
 		std::vector<int32_t> res(nc);
-		HIP_TRY(hipMemcpy(res.data(), ctx->result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
+		HIP_TRY(hipMemcpy(res.data(), ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
 		const size_t np = std::min<size_t>(h[C_POOL], POOL_CAP), base = pool.size();
 		pool.resize(base + np);
-		if (np) HIP_TRY(hipMemcpy(pool.data() + base, ctx->pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		if (np) HIP_TRY(hipMemcpy(pool.data() + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
 		for (size_t i = 0; i < nc; i++) result[c0 + i] = res[i] >= 0 ? int32_t(base + size_t(res[i])) : res[i];
 		ctx->acc_items += nc;
 	}
@@ -2591,18 +2638,40 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	if (rc) return rc;
 	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
 	ctx->events.clear();
-	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	ctx->cur = 0;
 	size_t tpb = 1;
 	rc = plan(ctx, db, tpb);
 	if (rc) return rc;
 	tpb = std::max<size_t>(1, size_t(double(tpb) * ctx->batch_scale));
 	ctx->n_batches = 0;
 	const size_t n_units = db->n_short_units; // the windows of long targets are handled by search_long_targets
-	for (size_t u0 = 0; u0 < n_units; u0 += tpb) {
-		rc = enqueue_batch(ctx, db, u0, std::min(n_units, u0 + tpb), false);
+	// Large searches are cut into several batches on two buffer sets so that the seed stage of one batch runs beside the bind
+	// stage of the batch before it (enqueue_batch); small ones stay one batch on the context stream.
+	const bool pipelined = ctx->pipeline_batches > 1 && n_units >= size_t(ctx->pipeline_batches) * 32768;
+	if (pipelined) {
+		tpb = std::min(tpb, (n_units + size_t(ctx->pipeline_batches) - 1) / size_t(ctx->pipeline_batches));
+		rc = ensure_set(ctx, 1);
 		if (rc) return rc;
+		if (!ctx->seed_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->seed_stream, hipStreamNonBlocking), ctx->err);
+		HIP_TRY(hipMemsetAsync(ctx->set[1].counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	}
+	HIP_TRY(hipMemsetAsync(ctx->set[0].counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	ctx->set[0].used = ctx->set[1].used = false;
+	hipEvent_t start = nullptr;
+	if (pipelined) { // the seed stream starts behind whatever the context stream holds (the counters' reset above)
+		HIP_TRY(hipEventCreateWithFlags(&start, hipEventDisableTiming), ctx->err);
+		HIP_TRY(hipEventRecord(start, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamWaitEvent(ctx->seed_stream, start, 0), ctx->err);
+	}
+	for (size_t u0 = 0; u0 < n_units; u0 += tpb) {
+		if (pipelined) ctx->cur = int(ctx->n_batches & 1);
+		rc = enqueue_batch(ctx, db, u0, std::min(n_units, u0 + tpb), false, pipelined);
+		if (rc) break;
 		ctx->n_batches++;
 	}
+	ctx->cur = 0;
+	if (start) (void)hipEventDestroy(start);
+	if (rc) return rc;
 	ctx->pending = true;
 	ctx->pending_db = db;
 	return TNT_OK;
@@ -2613,7 +2682,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	if (!ctx || !ctx->pending) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	uint32_t cnt[C_COUNT];
-	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpyAsync(cnt, ctx->S().counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	ctx->pending = false;
 #ifdef TNT_EXP_STATS
@@ -2700,15 +2769,17 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	// stage timings
 	tnt_timing &T = ctx->timing;
 	memset(&T, 0, sizeof(T));
-	for (size_t b = 0; b + 3 < ctx->events.size(); b += 4) {
+	// (with the seed stage of the next batch running beside the bind stage of this one the stage times overlap: their sum
+	// exceeds total_ms)
+	for (size_t b = 0; b + 4 < ctx->events.size(); b += 5) {
 		float ms = 0;
-		if (hipEventElapsedTime(&ms, ctx->events[b], ctx->events[b + 1]) == hipSuccess) T.seed_ms += ms;
+		if (hipEventElapsedTime(&ms, ctx->events[b], ctx->events[b + 4]) == hipSuccess) T.seed_ms += ms;
 		if (hipEventElapsedTime(&ms, ctx->events[b + 1], ctx->events[b + 2]) == hipSuccess) T.bind_ms += ms;
 		if (hipEventElapsedTime(&ms, ctx->events[b + 2], ctx->events[b + 3]) == hipSuccess) T.pair_ms += ms;
 	}
-	if (ctx->events.size() >= 4) {
+	if (ctx->events.size() >= 5) {
 		float ms = 0;
-		if (hipEventElapsedTime(&ms, ctx->events.front(), ctx->events.back()) == hipSuccess) T.total_ms = ms;
+		if (hipEventElapsedTime(&ms, ctx->events.front(), ctx->events[ctx->events.size() - 2]) == hipSuccess) T.total_ms = ms;
 	}
 	T.n_binds = (uint64_t(cnt[C_TOT_BINDS_HI]) << 32) | cnt[C_TOT_BINDS_LO]; // DP evaluations (phase A + phase B)
 	T.n_seeds = (uint64_t(cnt[C_TOT_GROUPS_HI]) << 32) | cnt[C_TOT_GROUPS_LO]; // (target, assay) groups that reached the bind stage
@@ -2759,7 +2830,7 @@ int tnt_search_hits_compact(tnt_ctx *ctx, const void **device_blob, size_t *n_by
 	a.n = uint32_t(n);
 	a.sizes = ctx->hit_sizes.p;
 	a.blob = ctx->hit_blob.p;
-	a.total = ctx->counters.p + C_DEBUG; // scratch word, read back below
+	a.total = ctx->S().counters.p + C_DEBUG; // scratch word, read back below
 	const int blocks = int(std::min<size_t>(1024, (n + 255) / 256 + 1));
 	hipLaunchKernelGGL(hit_size_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
 	hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
@@ -2835,11 +2906,11 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 	const double words = double(size_t(1) << (2 * ctx->opt.hash_word_size));
 	const size_t cap = size_t(double(db->n_bases) * double(ctx->n_entries) / words * 2.0) + (1u << 20);
 	HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err);
-	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	HIP_TRY(hipMemsetAsync(ctx->S().counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 	rc = enqueue_batch(ctx, db, 0, db->h_unit_target.size(), true);
 	if (rc) return rc;
 	uint32_t cnt[C_COUNT];
-	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpyAsync(cnt, ctx->S().counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	if (cnt[C_ERR]) {
 		ctx->err = err_text(cnt[C_ERR]);
@@ -2903,7 +2974,7 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
 	ctx->events.clear();
 	ctx->dev_hits_valid = false;
-	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	HIP_TRY(hipMemsetAsync(ctx->S().counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 	size_t tpb = 1;
 	rc = plan(ctx, db, tpb);
 	if (rc) return rc;
@@ -2916,7 +2987,7 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 		rc = enqueue_batch(ctx, db, u0, std::min(n_units, u0 + tpb), false);
 		if (rc) return rc;
 		uint32_t cnt[C_COUNT];
-		HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipMemcpyAsync(cnt, ctx->S().counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 		const uint32_t err = cnt[C_ERR] & ~(ERR_HIT_OVERFLOW | ERR_POOL_OVERFLOW); // (the stages behind the seed kernel are not looked at)
 		if (err) {
@@ -2931,7 +3002,7 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 			n_regions = ctx->batch_regions;
 			ir = ITEM_CAP / n_regions, gr = GROUP_CAP / n_regions;
 			rc.resize(2 * size_t(n_regions));
-			HIP_TRY(hipMemcpy(rc.data(), ctx->region_counts.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
+			HIP_TRY(hipMemcpy(rc.data(), ctx->S().region_counts.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
 		}
 		for (uint32_t r = 0; r < n_regions; r++) {
 			const uint32_t ni = ctx->seed2 ? rc[2 * r] : cnt[C_ITEMS + r * SHARD_STRIDE], ng = ctx->seed2 ? rc[2 * r + 1] : cnt[C_GROUPS + r * SHARD_STRIDE];
@@ -2939,8 +3010,8 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 			const size_t item_region = ir, group_region = gr;
 			items.resize(ni);
 			groups.resize(ng);
-			HIP_TRY(hipMemcpy(items.data(), ctx->items.p + r * item_region, ni * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
-			HIP_TRY(hipMemcpy(groups.data(), ctx->groups.p + r * group_region, ng * sizeof(Group), hipMemcpyDeviceToHost), ctx->err);
+			HIP_TRY(hipMemcpy(items.data(), ctx->S().items.p + r * item_region, ni * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
+			HIP_TRY(hipMemcpy(groups.data(), ctx->S().groups.p + r * group_region, ng * sizeof(Group), hipMemcpyDeviceToHost), ctx->err);
 			for (const Item &it : items) {
 				const uint32_t slot = it.info >> ITEM_SLOT_SHIFT, assay = slot / 3u;
 				if (ctx->h_assays[assay].kind != 0) continue; // probe / padlock lists are not culled (every seed is an item)
@@ -3006,8 +3077,8 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 	DevBuf<BindFull> dfull;
 	HIP_TRY(dslots.upload(slots), ctx->err);
 	HIP_TRY(dfull.alloc(n), ctx->err);
-	HIP_TRY(hipMemcpy(ctx->items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
-	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->S().items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+	HIP_TRY(hipMemsetAsync(ctx->S().counters.p, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 	BindArgs b = bind_args(ctx, make_view(db, 0, db->n_targets));
 	b.slots = dslots.p;
 	b.groups = nullptr;
@@ -3023,13 +3094,13 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		for (size_t i = 0; i < n; i++) queue[i] = uint32_t(i);
 		const uint32_t n32 = uint32_t(n);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err); // the counters were cleared on the stream
-		HIP_TRY(hipMemcpy(ctx->qb.p, queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
-		HIP_TRY(hipMemcpy(ctx->counters.p + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
-		launch_bind_phase(ctx, b, b.db, db->n_exceptions != 0, ctx->qb.p, ctx->counters.p + C_QB, nullptr, route == TNT_ROUTE_BUCKETS ? 1 : 2);
+		HIP_TRY(hipMemcpy(ctx->S().qb.p, queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(hipMemcpy(ctx->S().counters.p + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		launch_bind_phase(ctx, b, b.db, db->n_exceptions != 0, ctx->S().qb.p, ctx->S().counters.p + C_QB, nullptr, route == TNT_ROUTE_BUCKETS ? 1 : 2);
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);
 	uint32_t cnt[C_COUNT];
-	HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpyAsync(cnt, ctx->S().counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	if (cnt[C_ERR]) {
 		ctx->err = err_text(cnt[C_ERR]);
@@ -3038,10 +3109,10 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 	if (route != TNT_ROUTE_UNIT) {
 		// what the throughput instances leave behind: a status per request and, for bound ones, the pool record
 		std::vector<int32_t> res(n);
-		HIP_TRY(hipMemcpy(res.data(), ctx->result.p, n * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
+		HIP_TRY(hipMemcpy(res.data(), ctx->S().result.p, n * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
 		const size_t n_pool = std::min<size_t>(cnt[C_POOL], POOL_CAP);
 		std::vector<BoundRec> recs(n_pool);
-		if (n_pool) HIP_TRY(hipMemcpy(recs.data(), ctx->pool.p, n_pool * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		if (n_pool) HIP_TRY(hipMemcpy(recs.data(), ctx->S().pool.p, n_pool * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
 		for (size_t i = 0; i < n; i++) {
 			tnt_bind &o = out[i];
 			memset(&o, 0, sizeof(o));
@@ -3128,7 +3199,7 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 	HIP_TRY(dslots.upload(slots), ctx->err);
 	HIP_TRY(dscore.alloc(2 * n), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
-	HIP_TRY(hipMemcpy(ctx->items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->S().items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
 	HIP_TRY(hipMemset(dscore.p, 0xFF, 2 * n * sizeof(int32_t)), ctx->err);
 	std::vector<uint32_t> order;
 	for (const auto &kv : by_rows) order.insert(order.end(), kv.second.begin(), kv.second.end());
@@ -3141,8 +3212,8 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 	f.olig_len = ctx->olig_len.p;
 	f.slots = dslots.p;
 	f.thresh = ctx->thresh.p;
-	f.items = ctx->items.p;
-	f.result = ctx->result.p;
+	f.items = ctx->S().items.p;
+	f.result = ctx->S().result.p;
 	f.score_out = dscore.p;
 	size_t at = 0;
 	for (const auto &kv : by_rows) {
@@ -3213,7 +3284,7 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	HIP_TRY(dslots.upload(slots), ctx->err);
 	HIP_TRY(dfull.alloc(items.size()), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
-	HIP_TRY(hipMemcpy(ctx->items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->S().items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
 	DbView v;
 	memset(&v, 0, sizeof(v));
 	BindArgs b = bind_args(ctx, v);
