@@ -43,7 +43,11 @@ def parse():
     ap.add_argument("--targets", type=int, default=None, help="override targets per GPU (weak) / in total (strong)")
     ap.add_argument("--assays", type=int, default=None)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the bounded CPU baseline sample")
+    ap.add_argument("--parity-targets", type=int, default=65536, help="cap of the parity sample (targets checked against the CPU checkers)")
+    ap.add_argument("--gather", choices=("padded", "exact"), default="padded",
+                    help="N > 1: transfer of the compact hit records to rank 0 -- one dist.gather of blobs padded to the largest rank "
+                         "(default) or exact-size isend / irecv (falls back to the padded gather when a transfer fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective-selftest", action="store_true",
                     help="single GPU: run the multi-GPU step (RCCL process group of one rank, staged gather) instead of the plain one")
@@ -81,7 +85,20 @@ def launch(args):
     sys.exit(rc)
 
 
-def cpu_baseline(wl, budget_s):
+def deal_pieces(config, scaling, world, rank, targets=None):
+    """(targets per piece, pieces of this rank).  Weak scaling: every rank owns one piece of the per-GPU size of the
+    configuration.  Strong scaling: one database of the configuration's full size, generated in PIECES pieces that are
+    dealt to the ranks in contiguous runs (rank r gets pieces [r * PIECES / world, (r + 1) * PIECES / world))."""
+    full = {1: 1000, 2: 1_000_000, 3: 1_000_000, 4: 1_250_000, 5: 625_000}[config]
+    full_total = {1: 1000, 2: 1_000_000, 3: 1_000_000, 4: 10_000_000, 5: 5_000_000}[config]
+    if scaling == "strong":
+        if PIECES % world:
+            raise SystemExit("strong scaling deals %d pieces: --gpus must divide it" % PIECES)
+        return max(1, (targets or full_total) // PIECES), list(range(rank * PIECES // world, (rank + 1) * PIECES // world)), full, full_total
+    return targets or full, [rank], full, full_total
+
+
+def cpu_baseline(wl, budget_s, max_targets=None):
     """Bounded sample of the same workload on the host cores: the reference's own objects
     (oracle/_ref, kind 'reference') when they are present, else this repo's restatement ('port').
     Returns (record, hits of the sample, number of targets in the sample)."""
@@ -98,8 +115,9 @@ def cpu_baseline(wl, budget_s):
     total_t, total_n = 0.0, 0
     first = 0
     hits = []
-    while total_t < budget_s and first < wl.n_targets:
-        last = min(wl.n_targets, first + n)
+    limit = min(wl.n_targets, max_targets) if max_targets else wl.n_targets
+    while total_t < budget_s and first < limit:
+        last = min(limit, first + n)
         codes = wl.codes[int(wl.offsets[first]):int(wl.offsets[last])]
         offs = wl.offsets[first:last + 1] - wl.offsets[first]
         t0 = time.perf_counter()
@@ -164,9 +182,23 @@ def parity_sample(gpu_hits, wl, n_sample, ref_keys, threads):
     if ref_keys is not None:
         r = sorted(ref_keys)
         odd = sorted({k[2] for k in set(r) ^ set(g)})
-        out["reference_objects"] = {"hits": len(r), "hit_multiset_equal": r == g, "targets_that_differ": odd[:16],
-                                    "note": "the reference's first cull reads one element past the end of a std::list (Q4): its "
-                                            "output varies between runs on such targets"}
+        rec = {"hits": len(r), "hit_multiset_equal": r == g, "targets_that_differ": odd[:16],
+               "note": "the reference's first cull reads one element past the end of a std::list (Q4): its "
+                       "output varies between runs on such targets"}
+        if odd:
+            # Where the threaded run of the reference differs, run its objects again on those targets alone, on ONE thread
+            # (the stack byte the cull reads past end() is then the same every time): that pins the Q4 fence to the
+            # reference where the reference is deterministic.
+            ref = tc.RefImpl()
+            same = True
+            for t in odd[:16]:
+                c1 = wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])]
+                o1 = np.array([0, len(c1)], dtype=np.uint64)
+                one = sorted(tc.hit_key(h) for h in ref.search(wl.options, wl.expanded, c1, o1, first=t, threads=1))
+                same = same and one == [k for k in g if k[2] == t]
+            rec["reference_1thread_equal"] = same
+            rec["reference_1thread_targets"] = len(odd[:16])
+        out["reference_objects"] = rec
     return out
 
 
@@ -185,22 +217,44 @@ def launch_only(args, rank, world):
         h.forward_align = b"5' ACGT 3'"
     t0 = time.perf_counter()
     allhits, counts = shard.gather_hits(mine)
-    blobs, counts2 = shard.finish_compact(shard.stage_compact(shard.pack_hits(mine), len(mine)))
+    # the compact records in both forms of the transfer, and the exact form with a send that fails on the last rank: all
+    # ranks must agree on the failure and deliver through the padded gather
+    got = {}
+    for mode in ("padded", "exact", "exact-failing"):
+        real_isend = dist.isend
+        if mode == "exact-failing" and world > 1 and rank == world - 1:
+            def broken(*a, **k):
+                raise RuntimeError("simulated transport failure")
+            dist.isend = broken
+        try:
+            st = shard.stage_compact(shard.pack_hits(mine), len(mine), mode="exact" if mode != "padded" else "padded")
+            if mode == "exact-failing" and world > 1 and rank == 0:
+                # the root's receive from the failing rank would never complete: it is abandoned like a transport error
+                class Dead:
+                    def wait(self):
+                        raise RuntimeError("simulated transport failure")
+                st.reqs = [Dead() if i == len(st.reqs) - 1 else r for i, r in enumerate(st.reqs)]
+            got[mode] = shard.finish_compact(st) + (st.mode,)
+        finally:
+            dist.isend = real_isend
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     per_rank = [torch.zeros_like(el) for _ in range(world)]
     dist.all_gather(per_rank, el)
     ok = True
+    modes = {k: v[2] for k, v in got.items()}
     if rank == 0:
         want = [r * 1000 + i for r in range(world) for i in range(r + 2)]
-        ok = counts == counts2 == [r + 2 for r in range(world)] and [h.seq_index for h in allhits] == want
-        unpacked = shard.unpack_all(blobs)
-        ok = ok and [h.seq_index for h in unpacked] == want and all(h.forward_align == b"5' ACGT 3'" for h in unpacked)
+        ok = counts == [r + 2 for r in range(world)] and [h.seq_index for h in allhits] == want
+        for mode, (blobs, counts2, _) in got.items():
+            unpacked = shard.unpack_all(blobs)
+            ok = ok and counts2 == counts and [h.seq_index for h in unpacked] == want and all(h.forward_align == b"5' ACGT 3'" for h in unpacked)
+        ok = ok and (world == 1 or modes["exact-failing"].startswith("padded (after"))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "launch-only check of the %d-rank path (no GPU work)" % world, "value": 0.0, "unit": "evals/s",
                           "n_gpus": int(one.item()), "rccl_ranks": world, "backend": "gloo", "launch_only": True,
-                          "gather_ok": bool(ok), "steps": 0, "warmup": 0, "ms_per_step": 0.0,
+                          "gather_ok": bool(ok), "gather_modes": modes, "steps": 0, "warmup": 0, "ms_per_step": 0.0,
                           "ms_per_step_per_rank": [1000.0 * float(x.item()) for x in per_rank]}), flush=True)
     if not ok:
         sys.exit(1)
@@ -237,16 +291,7 @@ def main():
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
 
     # ---- workload: same assays everywhere; the targets of this rank are resident before the timed region
-    full = {1: 1000, 2: 1_000_000, 3: 1_000_000, 4: 1_250_000, 5: 625_000}[args.config]
-    full_total = {1: 1000, 2: 1_000_000, 3: 1_000_000, 4: 10_000_000, 5: 5_000_000}[args.config]
-    if args.scaling == "strong":
-        if PIECES % world:
-            raise SystemExit("strong scaling deals %d pieces: --gpus must divide it" % PIECES)
-        per_piece = max(1, (args.targets or full_total) // PIECES)
-        my_pieces = list(range(rank * PIECES // world, (rank + 1) * PIECES // world))
-    else:
-        per_piece = args.targets or full
-        my_pieces = [rank]
+    per_piece, my_pieces, full, full_total = deal_pieces(args.config, args.scaling, world, rank, args.targets)
     eng = None
     dbs = []
     pack_s = 0.0
@@ -281,7 +326,7 @@ def main():
         device memory, page-locked receive buffer on rank 0; the same code runs on gloo in tests/test_distributed_cpu.py).
         The gather of one search travels while the next search runs; every search and every gather of the n steps is
         complete when this returns."""
-        acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_hits": 0, "gather_bytes": 0}
+        acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_hits": 0, "gather_bytes": 0, "gather_mode": None}
         if n <= 0:
             return acc
         todo = [db for _ in range(n) for db in dbs]
@@ -298,12 +343,17 @@ def main():
                     last["hits"] = hits
             else:
                 comp = eng.hits_compact()  # packed on the device: ~350 bytes per hit instead of 1 464
-                st = shard.stage_compact((comp[0], comp[1]), comp[2], device="cuda", always_collective=selftest)
+                if comp is None:  # targets seeded in windows: their hits only exist in the host copy -- packed here
+                    st = shard.stage_compact(shard.pack_hits(hits), len(hits), device="cuda", always_collective=selftest, mode=args.gather)
+                else:
+                    st = shard.stage_compact((comp[0], comp[1]), comp[2], device="cuda", always_collective=selftest, mode=args.gather)
+                acc["gather_mode"] = st.mode
                 if i + 1 < len(todo):
                     eng.enqueue(todo[i + 1])
                 else:
                     last["hits"] = hits
                 _, counts = shard.finish_compact(st)
+                acc["gather_mode"] = st.mode  # ("padded (after a failed exact transfer)" when the exact form failed)
                 nh = int(sum(counts))
                 acc["gather_bytes"] = int(sum(st.sizes))
             acc["seed"] += tm.seed_ms
@@ -381,7 +431,8 @@ def main():
             "config": {"workload": "config%d: %d expanded assays (%d oligos) x %d x %d-base synthetic targets %s"
                                    % (args.config, len(eng.expanded), n_oligos, n_targets_rank if args.scaling == "weak" else n_targets_all,
                                       tl, "per GPU" if args.scaling == "weak" else "in total, dealt to the GPUs in %d pieces" % PIECES),
-                       "sharding": "targets by sequence, no data-path collective, hit records gathered to rank 0 over RCCL every step",
+                       "sharding": ("targets by sequence, no data-path collective, compact hit records gathered to rank 0 over RCCL every step (%s)"
+                                    % acc["gather_mode"]) if (world > 1 or selftest) else "one GPU: no gather (N > 1: targets by sequence, hit records gathered to rank 0 over RCCL)",
                        "thresholds": "-e 40 -E 40, all other options default"},
             "targets_per_s": n_targets_all * args.steps / elapsed,
             "hits_per_step": n_hits,
@@ -391,6 +442,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "bind stage: bucket_kernel + filter_kernel<L> (pre-filter) + bind_kernel<L> on the survivors",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("profiles/bind_pmc.json: rocprofv3 --pmc passes of this workload in a run of their own "
+                                            "(scripts/pmc_collect.sh), not measured by this process") if traffic is not None else None,
                          "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once) over the stage time "
                                  "(HIP events on the library's stream); the stage is bound by VALU issue and LDS bank "
                                  "conflicts, not by HBM (DESIGN.md 4.2, 4.2a); traffic = PMC 2*FETCH_SIZE + WRITE_SIZE per step "
@@ -407,7 +460,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and wl0 is not None:
             try:
-                cb, cpu_keys, n_sample = cpu_baseline(wl0, args.cpu_seconds)
+                cb, cpu_keys, n_sample = cpu_baseline(wl0, args.cpu_seconds, args.parity_targets)
                 if cb is not None and last["hits"] is not None and len(dbs) == 1:
                     line["parity_sample"] = parity_sample(last["hits"], wl0, n_sample, cpu_keys if cb["kind"] == "reference" else None,
                                                           os.cpu_count() or 1)

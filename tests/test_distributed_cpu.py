@@ -43,11 +43,12 @@ def _worker(rank, world, port, q):
         allhits, counts = shard.gather_hits(local)
         keys = tc.sorted_hit_keys(allhits)
         # the compact form (what bench.py sends): exact byte counts per rank, unpacked on the root by the library
-        blobs, counts2 = shard.finish_compact(shard.stage_compact(shard.pack_hits(local), len(local)))
-        if rank == 0:
-            assert counts2 == counts
-            assert tc.sorted_hit_keys(shard.unpack_all(blobs)) == keys
-            assert sum(len(b) for b in blobs) < sum(counts) * 1464 // 3
+        for mode in ("padded", "exact"):
+            blobs, counts2 = shard.finish_compact(shard.stage_compact(shard.pack_hits(local), len(local), mode=mode))
+            if rank == 0:
+                assert counts2 == counts
+                assert tc.sorted_hit_keys(shard.unpack_all(blobs)) == keys
+                assert sum(len(b) for b in blobs) < sum(counts) * 1464 // 3
         if rank == 0:
             whole = tc.sorted_hit_keys(ora.search(wl.options, wl.expanded, codes, offsets, threads=2))
             q.put((ranges, counts, keys == whole, len(whole)))
@@ -101,6 +102,41 @@ def test_bench_launcher_starts_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["gather_ok"] is True
     assert len(line["ms_per_step_per_rank"]) == 2
+
+
+def test_bench_launcher_eight_ranks():
+    """The driver's 8-GPU form of the job: eight ranks started by the launcher, both forms of the compact gather, and the
+    exact form with a failing send (all ranks agree and deliver through the padded gather)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--launch-only"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["gather_ok"] is True
+    assert line["gather_modes"] == {"padded": "padded", "exact": "exact", "exact-failing": "padded (after a failed exact transfer)"}
+
+
+def test_strong_scaling_deals_every_piece_once():
+    """bench.py --scaling strong: the configuration's full database in 8 pieces, contiguous runs per rank."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for cfg, total in ((4, 10_000_000), (5, 5_000_000)):
+        for world in (1, 2, 4, 8):
+            seen = []
+            for rank in range(world):
+                per_piece, pieces, full, full_total = bench.deal_pieces(cfg, "strong", world, rank)
+                assert per_piece == total // bench.PIECES and full_total == total
+                assert pieces == list(range(pieces[0], pieces[0] + bench.PIECES // world))
+                seen += pieces
+            assert seen == list(range(bench.PIECES))
+        with pytest.raises(SystemExit):
+            bench.deal_pieces(cfg, "strong", 3, 0)
+    per_piece, pieces, full, _ = bench.deal_pieces(4, "weak", 8, 5)
+    assert (per_piece, pieces) == (1_250_000, [5]) and full == 1_250_000
+    assert bench.deal_pieces(2, "weak", 1, 0, targets=5000)[:2] == (5000, [0])
 
 
 def test_gather_returns_owned_records(checkers):

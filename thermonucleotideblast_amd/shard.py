@@ -9,8 +9,11 @@ per-rank hit counts followed by the transfer of the records to rank 0 (RCCL over
 backend on GPUs; the same code runs on "gloo" for the CPU tests).  Two forms of the transfer:
   * stage_hits / finish_gather: ONE gather of the full tnt_hit arrays, padded to the largest rank (1 464 bytes per hit);
   * stage_compact / finish_compact: the compact records of tnt_search_hits_compact (numbers + text lengths + text bytes,
-    about 350 bytes per hit for 20-mers), every rank sending exactly its bytes to rank 0 (send / recv sized from the
-    all-gathered byte counts, nothing padded).  bench.py uses this one.
+    about 350 bytes per hit for 20-mers).  mode "padded" (default, what bench.py runs): ONE `dist.gather` of the blobs
+    padded to the largest rank's byte count -- a plain collective, the form that has run on RCCL; with the same workload
+    on every rank the padding is a few per cent.  mode "exact": every rank sends exactly its bytes to rank 0 (isend /
+    irecv sized from the all-gathered byte counts); if posting or completing those fails on any rank, all ranks agree
+    on it (one all-reduce) and repeat the transfer in the padded form.
 """
 import ctypes as C
 
@@ -158,46 +161,72 @@ def pack_hits(hits):
 
 
 class _StagedCompact:
-    def __init__(self, mine, sizes, counts, device, root, reqs, recv):
+    def __init__(self, mine, sizes, counts, device, root, reqs, recv, mode="exact", padded=None, failed=False):
         self.mine, self.sizes, self.counts, self.device, self.root, self.reqs, self.recv = mine, sizes, counts, device, root, reqs, recv
+        self.mode, self.padded, self.failed = mode, padded, failed
 
 
-def stage_compact(blob, n_hits, device="cpu", root=0, always_collective=False):
-    """`blob` = this rank's compact records: bytes (CPU) or (device pointer, n_bytes) from Engine.hits_compact().
-    All-gather of (hit count, byte count); then every other rank posts the send of exactly its bytes and the root the
-    matching receives.  The caller may start the next search right away: the blob is only rewritten by the next
-    hits_compact() call."""
+def _as_tensor(blob, device):
+    """This rank's compact records as a uint8 tensor on `device`: bytes (CPU) or (device pointer, n_bytes)."""
     import torch
-    import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_initialized() else 1
     if isinstance(blob, tuple):
         nbytes = int(blob[1])
-        mine = torch.as_tensor(_DeviceBytes(blob[0], max(1, nbytes)), device=device)[:nbytes]
-    else:
-        nbytes = len(blob)
-        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8) if nbytes else torch.empty(0, dtype=torch.uint8)
-        if device != "cpu":
-            mine = mine.to(device)
+        return torch.as_tensor(_DeviceBytes(blob[0], max(1, nbytes)), device=device)[:nbytes], nbytes
+    nbytes = len(blob)
+    mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8) if nbytes else torch.empty(0, dtype=torch.uint8)
+    if device != "cpu":
+        mine = mine.to(device)
+    return mine, nbytes
+
+
+def stage_compact(blob, n_hits, device="cpu", root=0, always_collective=False, mode="padded"):
+    """`blob` = this rank's compact records: bytes (CPU) or (device pointer, n_bytes) from Engine.hits_compact().
+    All-gather of (hit count, byte count); then, mode "padded": a copy of the records into a send buffer of the largest
+    rank's size (the gather itself runs in finish_compact); mode "exact": every other rank posts the send of exactly its
+    bytes and the root the matching receives.  Either way the caller may start the next search right away: the blob is
+    only rewritten by the next hits_compact() call (padded: it has been copied; exact: the send reads it, so collect
+    the next search only after finish_compact)."""
+    import torch
+    import torch.distributed as dist
+    if mode not in ("padded", "exact"):
+        raise ValueError("mode must be 'padded' or 'exact'")
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine, nbytes = _as_tensor(blob, device)
     if world == 1 and not (always_collective and dist.is_initialized()):
-        return _StagedCompact(mine, [nbytes], [int(n_hits)], device, root, [], [])
+        return _StagedCompact(mine, [nbytes], [int(n_hits)], device, root, [], [], mode)
     me = torch.tensor([int(n_hits), nbytes], dtype=torch.int64, device=device)
     every = [torch.zeros_like(me) for _ in range(world)]
     dist.all_gather(every, me)
     counts = [int(e[0].item()) for e in every]
     sizes = [int(e[1].item()) for e in every]
     rank = dist.get_rank()
-    reqs, recv = [], []
-    if rank == root:
-        for r in range(world):
-            if r == root or sizes[r] == 0:
-                recv.append(None)
-                continue
-            buf = torch.empty(sizes[r], dtype=torch.uint8, device=device)
-            recv.append(buf)
-            reqs.append(dist.irecv(buf, src=r))
-    elif nbytes:
-        reqs.append(dist.isend(mine, dst=root))
-    return _StagedCompact(mine, sizes, counts, device, root, reqs, recv)
+    if mode == "padded":
+        return _StagedCompact(mine, sizes, counts, device, root, [], [], mode, padded=_pad(mine, nbytes, max(1, max(sizes)), device))
+    reqs, recv, failed = [], [], False
+    try:
+        if rank == root:
+            for r in range(world):
+                if r == root or sizes[r] == 0:
+                    recv.append(None)
+                    continue
+                buf = torch.empty(sizes[r], dtype=torch.uint8, device=device)
+                recv.append(buf)
+                reqs.append(dist.irecv(buf, src=r))
+        elif nbytes:
+            reqs.append(dist.isend(mine, dst=root))
+    except Exception:  # agreed on by all ranks in finish_compact, which then runs the padded form
+        failed = True
+    return _StagedCompact(mine, sizes, counts, device, root, reqs, recv, mode, failed=failed)
+
+
+def _pad(mine, nbytes, nmax, device):
+    import torch
+    buf = torch.zeros(nmax, dtype=torch.uint8, device=device)
+    if nbytes:
+        buf[:nbytes].copy_(mine[:nbytes])
+    if device != "cpu":
+        torch.cuda.current_stream().synchronize()  # the copy is done before the library rewrites the blob
+    return buf
 
 
 def finish_compact(st):
@@ -205,14 +234,35 @@ def finish_compact(st):
     device buffers are copied into page-locked host memory.  Elsewhere returns ([own blob], counts)."""
     import torch
     import torch.distributed as dist
-    for r in st.reqs:
-        r.wait()
+    world = len(st.sizes)
     rank = dist.get_rank() if dist.is_initialized() else 0
+    collective = dist.is_initialized() and (world > 1 or st.padded is not None or st.reqs or st.recv)
+    parts = None
+    if collective and st.mode == "exact":
+        failed = st.failed
+        for r in st.reqs:
+            try:
+                r.wait()
+            except Exception:
+                failed = True
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int64, device=st.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):  # some rank could not send or receive: every rank repeats the transfer as one padded gather
+            st.padded = _pad(st.mine, st.sizes[rank], max(1, max(st.sizes)), st.device)
+            st.mode = "padded (after a failed exact transfer)"
+        elif rank == st.root:
+            parts = [st.mine if r == st.root else st.recv[r] for r in range(world)] if st.recv else [st.mine]
+    if collective and st.padded is not None:
+        out = [torch.empty_like(st.padded) for _ in range(world)] if rank == st.root else None
+        dist.gather(st.padded, out, dst=st.root)
+        if rank == st.root:
+            parts = out
     if rank != st.root:
         if st.device != "cpu":
             torch.cuda.current_stream().synchronize()
         return [st.mine], st.counts
-    parts = [st.mine if r == st.root else st.recv[r] for r in range(len(st.sizes))] if st.recv else [st.mine]
+    if parts is None:
+        parts = [st.mine]
     total = sum(st.sizes)
     host = torch.empty(max(1, total), dtype=torch.uint8) if st.device == "cpu" else _pinned_bytes(total)
     out, o = [], 0
