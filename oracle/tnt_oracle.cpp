@@ -1715,15 +1715,21 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 			}
 	struct Cls {
 		bool on;
-		float tk, theta0;
+		float tk, theta0, ct_scale;
 		std::vector<int> fpos, close; // [prev pair * 49 + cur pair] in evaluate order
 	} cls[2];
 	const double min_tm[2] = {double(opt->min_primer_tm), double(opt->min_probe_tm)};
+	const double max_dg[2] = {double(opt->max_primer_dg), double(opt->max_probe_dg)};
 	for (int k = 0; k < 2; k++) {
 		Cls &C = cls[k];
-		const double Tk = min_tm[k] + 273.15;
+		// the threshold of the cascade (bind_oligo.cpp:600-624) the bound is taken against: the minimum Tm where there is one,
+		// else a negative maximum dG (the same automaton at the target temperature, no strand-concentration term)
+		const bool by_tm = min_tm[k] > 0.0 && min_tm[k] < 150.0;
+		const bool by_dg = !by_tm && max_dg[k] < 0.0 && opt->target_t > 273.15f && opt->target_t < 423.15f;
+		const double Tk = by_tm ? min_tm[k] + 273.15 : double(opt->target_t);
 		C.tk = float(Tk);
-		C.on = ok && min_tm[k] > 0.0 && min_tm[k] < 150.0;
+		C.ct_scale = by_tm ? 1.0f : 0.0f;
+		C.on = ok && (by_tm || by_dg);
 		C.fpos.assign(NBP * NBP, 0);
 		C.close.assign(NBP * NBP, NEG);
 		if (!C.on) continue;
@@ -1749,7 +1755,7 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 				C.close[prev * NBP + cur] = units(std::max(std::max(f, 0.0), u1) - gap_price);
 			}
 		const double g_init = double(P.init_H) - Tk * double(P.init_S), g_at = double(P.at_H) - Tk * double(P.at_S);
-		C.theta0 = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02);
+		C.theta0 = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02 - (by_dg ? max_dg[k] : 0.0));
 	}
 #pragma omp parallel for schedule(dynamic, 256)
 	for (long k = 0; k < long(n); k++) {
@@ -1817,7 +1823,7 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		score[2 * k] = std::min(best, SAT);
 		if (C.on) {
 			const float log_ct = logf((r.ct - 0.5f * 0.0f) * 1.0f);
-			const float th = C.theta0 - C.tk * (1.9872e-3f * log_ct);
+			const float th = C.theta0 - C.ct_scale * (C.tk * (1.9872e-3f * log_ct));
 			score[2 * k + 1] = int(floorf(th * float(UNITS))) - 1;
 		} else {
 			score[2 * k + 1] = INT32_MIN;

@@ -23,6 +23,11 @@ OPTION_SETS = [
     ("-e 30 -E 35, 0.9 M salt, 300 K", dict(min_primer_tm=30.0, min_probe_tm=35.0, salt=0.9, target_t=300.0)),
     ("-e 20 -E 62, 10 mM salt, 333 K", dict(min_primer_tm=20.0, min_probe_tm=62.0, salt=0.01, target_t=333.15)),
     ("-e 45 -E 45, asymmetric Ct", dict(min_primer_tm=45.0, min_probe_tm=45.0, primer_strand=2.0e-6, probe_strand=5.0e-8)),
+    # dG-only runs (options.cpp:833-916 accepts -z / -g without -e): the bound is taken against the maximum dG
+    ("-g -8 -G -6, no minimum Tm", dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-8.0, max_probe_dg=-6.0)),
+    ("-g -12 -G -10, 0.2 M salt, 300 K", dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-12.0, max_probe_dg=-10.0, salt=0.2, target_t=300.0)),
+    ("-g -5 -G -7, 10 mM salt, 330 K", dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-5.0, max_probe_dg=-7.0, salt=0.01, target_t=330.0)),
+    ("-e 45 for primers, -G -9 for probes", dict(min_primer_tm=45.0, min_probe_tm=0.0, max_probe_dg=-9.0)),
 ]
 
 
@@ -84,20 +89,23 @@ def check_option_set(oracle, name, kw, n, seed):
     fb = oracle.filter_bound(opt, oligos, codes, offsets, reqs)
     role = np.array([r[5] for r in rows])
     min_tm = np.where(role == 1, opt.min_probe_tm, opt.min_primer_tm).astype(np.float64)
-    ct = np.where(role == 1, opt.probe_strand, opt.primer_strand).astype(np.float64)
+    max_dg = np.where(role == 1, opt.max_probe_dg, opt.max_primer_dg).astype(np.float64)
     valid = np.array([b.valid for b in out]) > 0
     tm = np.array([b.tm for b in out], dtype=np.float64)
     dH = np.array([b.dH for b in out], dtype=np.float64)
     dS = np.array([b.dS for b in out], dtype=np.float64)
+    dg = np.array([b.dg for b in out], dtype=np.float64)
     bound, theta = fb[:, 0].astype(np.int64), fb[:, 1].astype(np.int64)
-    accepted = valid & (tm >= min_tm)
+    # the threshold the class's bound is taken against: the minimum Tm where there is one, else the maximum dG
+    by_tm = min_tm > 0.0
+    accepted = valid & np.where(by_tm, tm >= min_tm, dg <= max_dg)
     rejected = (bound < theta) & (bound < 32767)  # a saturated bound is never rejected
     assert accepted.sum() > n // 50, (name, int(accepted.sum()))
     bad = np.nonzero(accepted & rejected)[0]
     assert len(bad) == 0, "%s: the filter rejects %d accepted windows, e.g. request %r bound %d theta %d tm %.3f" % (
         name, len(bad), rows[bad[0]], bound[bad[0]], theta[bad[0]], tm[bad[0]])
     # stronger: bound >= -(dH - Tk dS) + G_init + min(0, 2 G_AT) - margin for every window with an alignment
-    Tk = min_tm + 273.15
+    Tk = np.where(by_tm, min_tm + 273.15, float(opt.target_t))
     g_init = 0.2 - Tk * (-5.6746737e-3)
     g_at = 2.2 - Tk * 6.9321301e-3
     phi = -(dH - Tk * dS) + g_init + np.minimum(0.0, 2.0 * g_at)
@@ -123,7 +131,7 @@ def test_filter_is_off_where_its_premises_fail(oracle):
     codes = np.concatenate([synth.encode(t) for t in targets])
     offsets = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
     reqs = tc.make_reqs([r[:6] + (9.0e-7,) for r in rows])
-    for kw in (dict(min_primer_tm=0.0, min_probe_tm=0.0), dict(allow_dangle_5=1, min_primer_tm=40.0, min_probe_tm=40.0),
+    for kw in (dict(min_primer_tm=0.0, min_probe_tm=0.0), dict(min_primer_tm=-5.0, min_probe_tm=0.0, max_primer_dg=0.0, max_probe_dg=3.0), dict(allow_dangle_5=1, min_primer_tm=40.0, min_probe_tm=40.0),
                dict(allow_dangle_3=1, min_primer_tm=40.0, min_probe_tm=40.0)):
         fb = oracle.filter_bound(abi.options_default(**kw), oligos, codes, offsets, reqs)
         assert (fb[:, 1] == np.iinfo(np.int32).min).all(), kw

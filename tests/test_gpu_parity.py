@@ -149,7 +149,7 @@ def test_random_windows_production_vs_oracle(Engine, oracle, seed, kw):
     e.close()
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 4])
+@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 8])
 def test_filter_kernel_equals_its_checker(Engine, oracle, k):
     """The pre-filter kernel (every row-count instance the oligo lengths pick) against the oracle-side restatement whose
     soundness tests/test_filter_bound.py checks: same bound, same threshold, for every window."""
@@ -177,7 +177,10 @@ def test_filter_kernel_equals_its_checker(Engine, oracle, k):
 def test_filter_changes_no_result(Engine, oracle, monkeypatch):
     """The same searches with the pre-filter on, off and in audit mode (everything is bound and the bind kernel raises an
     error if it accepts a window the filter marked): identical hits, and the filter does reject most windows."""
-    for cfg, nt, na, kw in [(2, 30000, 96, {}), (3, 20000, 96, dict(min_primer_tm=50.0, min_probe_tm=45.0)), (5, 6000, 200, {})]:
+    for cfg, nt, na, kw in [(2, 30000, 96, {}), (3, 20000, 96, dict(min_primer_tm=50.0, min_probe_tm=45.0)), (5, 6000, 200, {}),
+                            # dG-only thresholds: the bound is taken against the maximum dG at the target temperature
+                            (2, 20000, 96, dict(min_primer_tm=0.0, max_primer_dg=-10.0)),
+                            (3, 12000, 48, dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-9.0, max_probe_dg=-11.0))]:
         wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=31)
         for k_, v_ in kw.items():
             setattr(wl.options, k_, v_)
@@ -194,7 +197,7 @@ def test_filter_changes_no_result(Engine, oracle, monkeypatch):
             res[mode] = tc.sorted_hit_keys(e.search(db))
             tm = e.timing()
             if mode == "on":
-                assert tm.n_filtered > tm.n_binds // 2, (cfg, tm.n_filtered, tm.n_binds)
+                assert tm.n_filtered > tm.n_binds // (2 if not kw or "max_primer_dg" not in kw else 5), (cfg, tm.n_filtered, tm.n_binds)
             else:
                 assert tm.n_filtered == 0
             db.close()
@@ -497,6 +500,8 @@ def test_g5_readme_example(Engine):
     (3, 60, 8, 52, {"hash_word_size": 3}),
     (5, 60, 8, 53, {"hash_word_size": 4}),
     # targets beyond the reach of the first cull, with and without probes
+    # dG-only thresholds with probes (the pre-filter's bound against the maximum dG)
+    (3, 800, 40, 56, {"min_primer_tm": 0.0, "min_probe_tm": 0.0, "max_primer_dg": -9.0, "max_probe_dg": -8.0}),
     (3, 600, 40, 54, {"max_len": 350}),
     (2, 600, 40, 55, {"max_len": 500, "single_primer_pcr": 0}),
 ])

@@ -44,10 +44,17 @@ struct FilterTables {
 	// per class and entry two 16-bit values in one word (one ds_read_b32 per cell): low half the stack, counted when
 	// favourable; high half the entry into a loop through this diagonal step, minus the gap price
 	uint32_t plane[FILT_CLASSES][FILT_PLANE];
-	float tk[FILT_CLASSES];                     // min_tm + 273.15
+	float tk[FILT_CLASSES];                     // temperature of the bound: min_tm + 273.15 (Tm threshold) or target_t (dG threshold)
 	float theta0[FILT_CLASSES];                 // threshold without the strand-concentration term, kcal/mol (margin included)
-	int32_t enabled[FILT_CLASSES];              // 0: windows of this class are never rejected
+	float ct_scale[FILT_CLASSES];               // 1: the threshold carries - Tk R ln(Ct) (Tm threshold); 0: it does not (dG threshold)
+	int32_t enabled[FILT_CLASSES];              // 0: windows of this class are never rejected; FILT_BY_TM / FILT_BY_DG
 };
+// Which threshold of the cascade (bind_oligo.cpp:600-624) a class's bound is taken against.  The minimum Tm where there is
+// one (> 0 C): a rejected window fails the cascade's FIRST test, so its status is the reference's.  Else the maximum dG,
+// where it is negative: the same automaton at the target temperature; acceptance needs dH - T dS <= max_dg, so a window
+// whose bound of -(dH - T dS) stays below -max_dg cannot pass -- but it may fail the Tm range first (status 1, not 2), so
+// callers that report statuses (tnt_bind_batch_routed) bind such windows instead (FilterArgs2::status_exact).
+constexpr int FILT_BY_TM = 1, FILT_BY_DG = 2;
 
 struct FilterArgs2 {
 	const FilterTables *tab;
@@ -67,6 +74,7 @@ struct FilterArgs2 {
 	uint32_t *n_rejected;           // statistics: windows rejected here (device counter)
 	uint8_t *audit;                 // optional: audit mode marks what the filter would reject and lets everything through
 	int32_t *score_out;             // optional (unit-level entry): bound and threshold per item, [2 * idx]
+	int32_t status_exact;           // reject only where the status is certain (bounds against the minimum Tm)
 };
 
 // bits 0-1 of Thresh index -> class: 0 primer thresholds, 1..3 probe thresholds (tnt_host.hip builds th[0..3])
@@ -273,9 +281,9 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 		bool pass = true;
 		int theta = INT32_MIN;
 		if (a.tab->enabled[cls]) {
-			const float th = a.tab->theta0[cls] - a.tab->tk[cls] * (1.9872e-3f * slot.log_ct);
+			const float th = a.tab->theta0[cls] - a.tab->ct_scale[cls] * (a.tab->tk[cls] * (1.9872e-3f * slot.log_ct));
 			theta = int(floorf(th * float(FILT_UNITS))) - 1;
-			pass = best >= theta || best >= FILT_SAT;
+			pass = best >= theta || best >= FILT_SAT || (a.status_exact && a.tab->enabled[cls] != FILT_BY_TM);
 		}
 		if (DEGEN && unfilterable) pass = true, best = INT32_MAX, theta = INT32_MIN;
 		if (a.score_out && active) a.score_out[2 * idx] = best, a.score_out[2 * idx + 1] = theta;

@@ -258,16 +258,21 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 				ok = ok && T.H[g1 * NBP + c] == 0.0f && T.S[g1 * NBP + c] == 0.0f && T.H[g2 * NBP + c] == 0.0f && T.S[g2 * NBP + c] == 0.0f;
 			}
 	const double min_tm[FILT_CLASSES] = {double(opt.min_primer_tm), double(opt.min_probe_tm)};
+	const double max_dg[FILT_CLASSES] = {double(opt.max_primer_dg), double(opt.max_probe_dg)};
 	// table units: FILT_UNITS per kcal/mol, rounded up, 16 bits ("not possible" = FILT_NEG: a price of 16 kcal/mol)
 	auto units = [](double kcal) { return int(std::min(double(FILT_SAT), std::max(double(FILT_NEG), std::ceil(kcal * double(FILT_UNITS))))); };
 	auto pack = [](int stack, int entry) { return uint32_t(uint16_t(int16_t(stack))) | (uint32_t(uint16_t(int16_t(entry))) << 16); };
 	for (int cls = 0; cls < FILT_CLASSES; cls++) {
 		int v[FILT_PLANE][2];
 		for (int i = 0; i < FILT_PLANE; i++) v[i][0] = 0, v[i][1] = FILT_NEG;
-		const double Tk = min_tm[cls] + 273.15;
+		// the threshold the bound is taken against (tnt_filter.hip.h, FILT_BY_*): the minimum Tm, else a negative maximum dG
+		const bool by_tm = min_tm[cls] > 0.0 && min_tm[cls] < 150.0;
+		const bool by_dg = !by_tm && max_dg[cls] < 0.0 && opt.target_t > 273.15 && opt.target_t < 423.15;
+		const double Tk = by_tm ? min_tm[cls] + 273.15 : double(opt.target_t);
 		F.tk[cls] = float(Tk);
+		F.ct_scale[cls] = by_tm ? 1.0f : 0.0f;
 		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i] = pack(0, FILT_NEG);
-		if (!ok || !(min_tm[cls] > 0.0) || !(min_tm[cls] < 150.0)) continue;
+		if (!ok || !(by_tm || by_dg)) continue;
 		const double sc = double(T.salt) * double(T.log_na); // per counted column (nuc_cruc.cpp:2270: 0.5 per base)
 		auto phi = [&](int prev, int cur) { return -(double(T.H[prev * NBP + cur]) - Tk * (double(T.S[prev * NBP + cur]) + sc)); };
 		double pb1 = -Tk * double(T.bulge_S[1]), pb2 = 1.0e30, pl3 = 1.0e30;
@@ -320,8 +325,8 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i] = pack(v[i][0], v[i][1]);
 		const double g_init = double(T.init_H) - Tk * double(T.init_S);
 		const double g_at = double(T.at_H) - Tk * double(T.at_S);
-		F.theta0[cls] = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02); // 0.02 kcal/mol: float32 rounding of the reference's sums, generously
-		F.enabled[cls] = 1;
+		F.theta0[cls] = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02 - (by_dg ? max_dg[cls] : 0.0)); // 0.02 kcal/mol: float32 rounding of the reference's sums, generously
+		F.enabled[cls] = by_tm ? FILT_BY_TM : FILT_BY_DG;
 	}
 }
 
@@ -474,6 +479,7 @@ struct tnt_ctx {
 	FilterTables h_ftab;
 	DevBuf<FilterTables> ftab;
 	bool filter_on = false, filter_audit = false;
+	bool filter_status_exact = false; // set around launches whose caller reports statuses (tnt_bind_batch_routed)
 	bool serial_bind = false; // profiling: every launch of the bind stage on one side stream (per-kernel durations add up to the stage time)
 	DevBuf<uint8_t> olig_base;
 	DevBuf<uint32_t> olig_q4;
@@ -807,6 +813,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.result = b.result;
 			f.n_rejected = gcnt + C_FILTERED;
 			f.audit = c->filter_audit ? c->S().audit.p : nullptr;
+			f.status_exact = c->filter_status_exact ? 1 : 0;
 			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
 			b.index = survivors;
 			b.n_items_dev = f.n_survivors;
@@ -3096,7 +3103,9 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err); // the counters were cleared on the stream
 		HIP_TRY(hipMemcpy(ctx->S().qb.p, queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
 		HIP_TRY(hipMemcpy(ctx->S().counters.p + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		ctx->filter_status_exact = true; // this caller reports the status of every request
 		launch_bind_phase(ctx, b, b.db, db->n_exceptions != 0, ctx->S().qb.p, ctx->S().counters.p + C_QB, nullptr, route == TNT_ROUTE_BUCKETS ? 1 : 2);
+		ctx->filter_status_exact = false;
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);
 	uint32_t cnt[C_COUNT];
