@@ -39,6 +39,11 @@
 
 using namespace tnt;
 
+namespace tnt { // tnt_sort.hip
+hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *target_rank, const AssayDev *assays, uint32_t n_assays,
+                           uint32_t n_buckets, Item *items, uint32_t *bucket, hipStream_t stream);
+}
+
 static_assert(sizeof(Hit) == sizeof(tnt_hit), "device Hit must mirror tnt_hit");
 static_assert(MAX_OLIGO == TNT_MAX_OLIGO && ALIGN_TEXT == TNT_ALIGN_TEXT && FLANK == TNT_FLANK, "ABI constants");
 
@@ -416,6 +421,27 @@ template <class T> struct DevBuf {
 	~DevBuf() { release(); }
 };
 
+// page-locked host array that only grows (the long-target path moves tens of megabytes per search in both directions:
+// from pageable memory those copies run at a tenth of the link's speed)
+template <class T> struct PinnedBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	hipError_t ensure(size_t n)
+	{
+		if (n <= cap) return hipSuccess;
+		if (p) (void)hipHostFree(p);
+		p = nullptr, cap = 0;
+		const size_t want = n + n / 4 + 1024;
+		const hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault);
+		if (e == hipSuccess) cap = want;
+		return e;
+	}
+	~PinnedBuf()
+	{
+		if (p) (void)hipHostFree(p);
+	}
+};
+
 } // namespace
 
 struct tnt_db {
@@ -551,6 +577,9 @@ struct tnt_ctx {
 	int n_cu = 0;
 
 	tnt_hit *h_hits = nullptr; // pinned host buffer the hit records are copied into (library owned)
+	PinnedBuf<Item> pin_items, pin_bind; // long-target path: the sorted seeds, the work items of the kept ones
+	PinnedBuf<uint32_t> pin_list;
+	PinnedBuf<int32_t> pin_result;
 	size_t h_hits_cap = 0;
 	std::vector<tnt_seed> h_seeds;
 	std::vector<int32_t> h_cull_rows; // tnt_first_cull
@@ -610,6 +639,13 @@ __global__ void accumulate_kernel(uint32_t *cnt, uint32_t *g) // cnt: the batch'
 	*tb -= cnt[C_DUPS];
 	cnt[C_DUPS] = 0;
 	g[C_TOT_BOUND] += cnt[C_POOL];
+}
+
+// q[i] = i for i < n, *count = n: the queue of a bind phase over every item of a buffer (long-target path)
+__global__ void iota_kernel(uint32_t *q, uint32_t n, uint32_t *count)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = i;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *count = n;
 }
 
 static size_t cap_from_env(const char *name, size_t dflt_m)
@@ -2317,7 +2353,7 @@ struct LongJob {
 	std::vector<ListT<PAIR_HOST> *> lists; // one scratch list
 	int mode; // 0: first culls, 1: pairing
 	// first-cull input / output
-	const std::vector<Item> *all_items;
+	const Item *all_items;
 	const std::vector<uint32_t> *seg_begin; // [n_groups + 1] segments of all_items (sorted in list order)
 	const std::vector<uint32_t> *seg_assay;
 	const tnt_ctx *ctx;
@@ -2332,7 +2368,7 @@ static void *long_job_main(void *p)
 	LongJob &J = *static_cast<LongJob *>(p);
 	if (J.mode == 0) {
 		ListT<PAIR_HOST> *l = new ListT<PAIR_HOST>;
-		const std::vector<Item> &items = *J.all_items;
+		const Item *items = J.all_items;
 		const size_t n_seg = J.seg_begin->size() - 1;
 		for (size_t g = J.next.fetch_add(1); g < n_seg; g = J.next.fetch_add(1)) {
 			const uint32_t b = (*J.seg_begin)[g], e = (*J.seg_begin)[g + 1];
@@ -2386,8 +2422,8 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		return TNT_E_DEVICE;
 	}
 	uint32_t *cnt = ctx->S().counters.p;
-	// ---- seeds of every window (the seed kernel's unit-level output: kept seeds before the cull)
-	std::vector<SeedOut> raw;
+	// ---- seeds of every window (the seed kernel's unit-level output: kept seeds before the cull); they stay on the device
+	size_t n_raw = 0;
 	for (int attempt = 0;; attempt++) {
 		size_t tpb = 1;
 		int rc = plan(ctx, db, tpb);
@@ -2435,76 +2471,60 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 			ctx->err = "seed output overflow on a long target";
 			return TNT_E_LIMIT;
 		}
-		raw.resize(h[C_SEEDS]);
-		if (!raw.empty()) HIP_TRY(hipMemcpy(raw.data(), ctx->seeds_out.p, raw.size() * sizeof(SeedOut), hipMemcpyDeviceToHost), ctx->err);
-		ctx->seeds_out.release();
+		n_raw = h[C_SEEDS];
 		break;
 	}
-	if (raw.empty()) return TNT_OK;
-	lap("seed windows + copy");
+	if (n_raw == 0) {
+		ctx->seeds_out.release();
+		return TNT_OK;
+	}
+	lap("seed windows");
 
-	// ---- per (target, assay) lists in the reference's list order: a counting sort into (target, assay) buckets, then
-	// every bucket by its keys (the buckets on several threads)
-	struct Keyed {
-		unsigned long long key;
-		Item item;
-	};
+	// ---- per (target, assay) lists in the reference's list order, assembled on the device (tnt_sort.hip: key kernel, two
+	// stable radix sorts, gather); the host gets the seeds as work items, list after list, and the list of every item
 	const size_t n_assays_all = ctx->h_assays.size();
 	std::vector<uint32_t> long_targets; // the targets these windows belong to, ascending
 	for (size_t u = u0; u < u1; u++)
 		if (long_targets.empty() || long_targets.back() != db->h_unit_target[u]) long_targets.push_back(db->h_unit_target[u]);
 	std::sort(long_targets.begin(), long_targets.end());
 	long_targets.erase(std::unique(long_targets.begin(), long_targets.end()), long_targets.end());
-	auto bucket_of_seed = [&](const SeedOut &sd) {
-		const size_t tr = size_t(std::lower_bound(long_targets.begin(), long_targets.end(), sd.target) - long_targets.begin());
-		return tr * n_assays_all + size_t(sd.assay_role >> 2);
-	};
 	const size_t n_buckets = long_targets.size() * n_assays_all;
-	std::vector<uint32_t> bucket_first(n_buckets + 1, 0);
-	for (const SeedOut &sd : raw) bucket_first[bucket_of_seed(sd) + 1]++;
-	for (size_t b = 0; b < n_buckets; b++) bucket_first[b + 1] += bucket_first[b];
-	std::vector<Keyed> keyed(raw.size());
+	if (n_buckets >= (size_t(1) << 32)) {
+		ctx->err = "too many (target, assay) lists on the long targets of this batch";
+		return TNT_E_LIMIT;
+	}
+	HIP_TRY(ctx->pin_items.ensure(n_raw), ctx->err);
+	HIP_TRY(ctx->pin_list.ensure(n_raw), ctx->err);
+	Item *const sorted = ctx->pin_items.p;
+	uint32_t *const list_of = ctx->pin_list.p;
 	{
-		std::vector<uint32_t> cursor(bucket_first.begin(), bucket_first.end() - 1);
-		for (const SeedOut &sd : raw) {
-			const uint32_t assay = sd.assay_role >> 2, role = sd.assay_role & 3u;
-			const AssayDev &A = ctx->h_assays[assay];
-			// the order of seed_key (tnt_seed.hip.h): PCR lists by (target_loc, assembly group F- R- F+ R+ P- P+, word);
-			// hash-overload lists by (list, diagonal, word)
-			unsigned long long k;
-			if (A.kind == 0) {
-				const unsigned long long rank = role == 2 ? (sd.strand_minus ? 4u : 5u) : ((sd.strand_minus ? 0u : 2u) + role);
-				k = ((unsigned long long)sd.target_loc << 24) | (rank << 21) | ((unsigned long long)sd.query_loc << 14);
-			} else {
-				const unsigned long long listid = (sd.strand_minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
-				k = (listid << 54) | ((unsigned long long)(long(sd.query_loc) - long(sd.target_loc) + (1l << 33)) << 20) | ((unsigned long long)sd.query_loc << 13);
-			}
-			Keyed &o = keyed[cursor[bucket_of_seed(sd)]++];
-			o.key = k;
-			o.item = Item{sd.target, sd.target_loc, sd.query_loc | (sd.strand_minus ? ITEM_MINUS : 0u) | ((assay * 3u + role) << ITEM_SLOT_SHIFT), 0};
-		}
+		std::vector<uint32_t> rank(db->n_targets, 0);
+		for (size_t r = 0; r < long_targets.size(); r++) rank[long_targets[r]] = uint32_t(r);
+		DevBuf<uint32_t> d_rank, d_list;
+		DevBuf<Item> d_items;
+		HIP_TRY(d_rank.upload(rank), ctx->err);
+		HIP_TRY(d_list.alloc(n_raw), ctx->err);
+		HIP_TRY(d_items.alloc(n_raw), ctx->err);
+		HIP_TRY(long_sort_seeds(ctx->seeds_out.p, uint32_t(n_raw), d_rank.p, ctx->assays.p, uint32_t(n_assays_all), uint32_t(n_buckets), d_items.p, d_list.p, ctx->stream), ctx->err);
+		HIP_TRY(hipMemcpy(sorted, d_items.p, n_raw * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
+		HIP_TRY(hipMemcpy(list_of, d_list.p, n_raw * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
+		ctx->seeds_out.release();
 	}
-	parallel_for_each(n_buckets, [&](size_t b) {
-		std::sort(keyed.begin() + bucket_first[b], keyed.begin() + bucket_first[b + 1], [](const Keyed &x, const Keyed &y) { return x.key < y.key; });
-	});
-	std::vector<Item> sorted(raw.size());
 	std::vector<uint32_t> seg_begin, seg_assay;
-	for (size_t b = 0; b < n_buckets; b++) {
-		if (bucket_first[b] == bucket_first[b + 1]) continue;
-		seg_begin.push_back(bucket_first[b]);
-		seg_assay.push_back(uint32_t(b % n_assays_all));
-		for (uint32_t i = bucket_first[b]; i < bucket_first[b + 1]; i++) sorted[i] = keyed[i].item;
-	}
-	seg_begin.push_back(uint32_t(sorted.size()));
-	std::vector<Keyed>().swap(keyed);
+	for (size_t i = 0; i < n_raw; i++)
+		if (i == 0 || list_of[i] != list_of[i - 1]) {
+			seg_begin.push_back(uint32_t(i));
+			seg_assay.push_back(uint32_t(list_of[i] % n_assays_all));
+		}
+	seg_begin.push_back(uint32_t(n_raw));
 	lap("keys + sort");
 
 	// ---- first cull of every list (amplicon_search.cpp:128-131) on the host
-	std::vector<uint8_t> valid(sorted.size(), 0), minus_first(seg_assay.size(), 0);
+	std::vector<uint8_t> valid(n_raw, 0), minus_first(seg_assay.size(), 0);
 	LongJob job;
 	memset(&job.args, 0, sizeof(job.args));
 	job.mode = 0;
-	job.all_items = &sorted;
+	job.all_items = sorted;
 	job.seg_begin = &seg_begin;
 	job.seg_assay = &seg_assay;
 	job.ctx = ctx;
@@ -2512,7 +2532,9 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	job.minus_first = &minus_first;
 	job.overflow = false;
 	job.groups = nullptr;
-	const unsigned workers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	// (the lists of one target are few and long -- 96 lists of 19 000 seeds for a 5-Mb target against config 2 -- so the
+	// workers are as many as the host has cores to spare, up to 64)
+	const unsigned workers = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 	job.next = 0;
 	if (!run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job)) {
 		ctx->err = "could not start a host thread for the lists of long targets";
@@ -2525,39 +2547,51 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 
 	lap("first cull");
 	// ---- the kept seeds become bind work items, grouped per (target, assay)
-	std::vector<Item> bind_items;
+	Item *bind_items = nullptr;
+	size_t n_bind = 0;
 	std::vector<Group> groups;
 	std::vector<uint32_t> unit_target;
 	std::vector<int32_t> own_lo, own_hi;
-	for (size_t g = 0; g + 1 < seg_begin.size(); g++) {
-		const uint32_t first = uint32_t(bind_items.size());
-		for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++)
-			if (valid[i]) bind_items.push_back(sorted[i]);
-		const uint32_t count = uint32_t(bind_items.size()) - first;
-		if (!count) continue;
-		const uint32_t t = sorted[seg_begin[g]].target;
-		if (unit_target.empty() || unit_target.back() != t) unit_target.push_back(t), own_lo.push_back(INT32_MIN), own_hi.push_back(INT32_MAX);
-		groups.push_back(Group{uint32_t(unit_target.size() - 1), seg_assay[g] | (minus_first[g] ? GROUP_MINUS_FIRST : 0u), first, count});
+	{
+		// (two passes over the lists on the worker threads: count, then copy to the counted places)
+		const size_t n_seg = seg_assay.size();
+		std::vector<uint32_t> first_of(n_seg + 1, 0);
+		parallel_for_each(n_seg, [&](size_t g) {
+			uint32_t c = 0;
+			for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++) c += valid[i] ? 1u : 0u;
+			first_of[g + 1] = c;
+		});
+		for (size_t g = 0; g < n_seg; g++) first_of[g + 1] += first_of[g];
+		n_bind = first_of[n_seg];
+		HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
+		bind_items = ctx->pin_bind.p;
+		parallel_for_each(n_seg, [&](size_t g) {
+			uint32_t o = first_of[g];
+			for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++)
+				if (valid[i]) bind_items[o++] = sorted[i];
+		});
+		for (size_t g = 0; g < n_seg; g++) {
+			const uint32_t count = first_of[g + 1] - first_of[g];
+			if (!count) continue;
+			const uint32_t t = sorted[seg_begin[g]].target;
+			if (unit_target.empty() || unit_target.back() != t) unit_target.push_back(t), own_lo.push_back(INT32_MIN), own_hi.push_back(INT32_MAX);
+			groups.push_back(Group{uint32_t(unit_target.size() - 1), seg_assay[g] | (minus_first[g] ? GROUP_MINUS_FIRST : 0u), first_of[g], count});
+		}
 	}
-	if (bind_items.empty()) return TNT_OK;
+	if (n_bind == 0) return TNT_OK;
 
 	lap("work items");
 	// ---- bind them on the device, a million at a time: bucket -> pre-filter -> bind, as a search phase does
 	const DbView v = make_view(db, 0, db->n_targets);
-	std::vector<int32_t> result(bind_items.size(), -1);
+	HIP_TRY(ctx->pin_result.ensure(n_bind), ctx->err);
+	int32_t *const result = ctx->pin_result.p;
 	std::vector<BoundRec> pool;
 	const size_t CHUNK = size_t(1) << 20;
-	for (size_t c0 = 0; c0 < bind_items.size(); c0 += CHUNK) {
-		const size_t nc = std::min(CHUNK, bind_items.size() - c0);
-		std::vector<uint32_t> queue(nc);
-		for (size_t i = 0; i < nc; i++) queue[i] = uint32_t(i);
-		const uint32_t n32 = uint32_t(nc);
-		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	for (size_t c0 = 0; c0 < n_bind; c0 += CHUNK) {
+		const size_t nc = std::min(CHUNK, n_bind - c0);
 		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
-		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
-		HIP_TRY(hipMemcpy(ctx->S().items.p, bind_items.data() + c0, nc * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
-		HIP_TRY(hipMemcpy(ctx->S().qb.p, queue.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
-		HIP_TRY(hipMemcpy(cnt + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(hipMemcpyAsync(ctx->S().items.p, bind_items + c0, nc * sizeof(Item), hipMemcpyHostToDevice, ctx->stream), ctx->err);
+		hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->S().qb.p, uint32_t(nc), cnt + C_QB); // the queue: every item
 		BindArgs b = bind_args(ctx, v);
 		b.groups = nullptr;
 		launch_bind_phase(ctx, b, v, db->n_exceptions != 0, ctx->S().qb.p, cnt + C_QB, nullptr);
@@ -2569,12 +2603,14 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 			ctx->err = err_text(h[C_ERR]);
 			return TNT_E_LIMIT;
 		}
-		std::vector<int32_t> res(nc);
-		HIP_TRY(hipMemcpy(res.data(), ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
+		int32_t *const res = result + c0;
+		HIP_TRY(hipMemcpy(res, ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
 		const size_t np = std::min<size_t>(h[C_POOL], POOL_CAP), base = pool.size();
 		pool.resize(base + np);
 		if (np) HIP_TRY(hipMemcpy(pool.data() + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
-		for (size_t i = 0; i < nc; i++) result[c0 + i] = res[i] >= 0 ? int32_t(base + size_t(res[i])) : res[i];
+		if (base)
+			for (size_t i = 0; i < nc; i++)
+				if (res[i] >= 0) res[i] = int32_t(base + size_t(res[i]));
 		ctx->acc_items += nc;
 	}
 
@@ -2586,8 +2622,8 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		PairArgs &p = job.args;
 		memset(&p, 0, sizeof(p));
 		p.groups = groups.data();
-		p.items = bind_items.data();
-		p.result = result.data();
+		p.items = bind_items;
+		p.result = result;
 		p.pool = pool.data();
 		p.assays = ctx->h_assays.data();
 		p.db.first_seq_index = db->first_seq_index;
@@ -2889,9 +2925,14 @@ int tnt_hits_unpack(const void *blob, size_t n_bytes, tnt_hit *out, size_t cap, 
 
 int tnt_search(tnt_ctx *ctx, tnt_db *db, const tnt_hit **hits, size_t *n_hits)
 {
-	const int rc = tnt_search_enqueue(ctx, db);
+	const bool timing = getenv("TNT_MI355X_LONG_TIMING") != nullptr;
+	const double t0 = timing ? now_ms() : 0.0;
+	int rc = tnt_search_enqueue(ctx, db);
 	if (rc) return rc;
-	return tnt_search_collect(ctx, hits, n_hits);
+	const double t1 = timing ? now_ms() : 0.0;
+	rc = tnt_search_collect(ctx, hits, n_hits);
+	if (timing) fprintf(stderr, "tnt_search: enqueue %.2f ms, collect %.2f ms\n", t1 - t0, now_ms() - t1);
+	return rc;
 }
 
 int tnt_last_timing(tnt_ctx *ctx, tnt_timing *out)
