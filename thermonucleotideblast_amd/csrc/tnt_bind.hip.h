@@ -40,6 +40,7 @@ struct BindArgs {
 	const uint32_t *n_items_dev; // when set, the item count is read from the device counter (n_items caps it)
 	const uint32_t *index;       // optional work list: item indices to bind (one length bucket of a phase queue)
 	const uint32_t *index_base_dev; // when set, the work list starts at index[*index_base_dev]
+	uint32_t index_stride;       // words between two entries of the work list (0 / 1: plain indices; 4: the seed kernel's 16-byte queue entries)
 	int32_t *result;           // per item: pool index (>= 0) or -status
 	BoundRec *pool;
 	uint32_t pool_cap;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 	}
 	for (uint32_t base = blockIdx.x * BIND_THREADS; base < n_items; base += gridDim.x * BIND_THREADS) {
 		uint32_t idx = 0xFFFFFFFFu; // (a queue filled by the seed kernel has slots without an item: QUEUE_HOLE, tnt_seed2.hip.h)
-		if (base + tid < n_items) idx = index ? index[base + tid] : base + tid;
+		if (base + tid < n_items) idx = index ? index[size_t(base + tid) * (a.index_stride ? a.index_stride : 1u)] : base + tid;
 		const bool active = idx != 0xFFFFFFFFu;
 		if (!active) idx = 0;
 

@@ -75,6 +75,11 @@ struct FilterArgs2 {
 	uint8_t *audit;                 // optional: audit mode marks what the filter would reject and lets everything through
 	int32_t *score_out;             // optional (unit-level entry): bound and threshold per item, [2 * idx]
 	int32_t status_exact;           // reject only where the status is certain (bounds against the minimum Tm)
+	// Self-contained queue entries (the round-3 seed kernel writes them for its phase-A items, tnt_seed2.hip.h): item index
+	// (0xFFFFFFFF: no item) | first packed word of the window | start & 15, W << 4, L << 12 | Item::info.  With them the
+	// kernel reads its queue as a stream and touches neither the items nor the per-target arrays, and a rejected window
+	// writes nothing (the seed kernel has set its result to "not bound").
+	const uint4 *fat;
 };
 
 // bits 0-1 of Thresh index -> class: 0 primer thresholds, 1..3 probe thresholds (tnt_host.hip builds th[0..3])
@@ -127,27 +132,46 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 
 	for (uint32_t base = blockIdx.x * THREADS; base < n_items; base += gridDim.x * THREADS) {
 		// (a queue the seed kernel fills directly has slots without an item: 0xFFFFFFFF, QUEUE_HOLE of tnt_seed2.hip.h)
-		const uint32_t idx = base + tid < n_items ? index[base + tid] : 0xFFFFFFFFu;
+		uint32_t idx;
+		Item it = Item{0, 0, 0, 0};
+		uint4 fe = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+		if (a.fat) {
+			if (base + tid < n_items) fe = a.fat[base + tid];
+			idx = fe.x;
+			it.info = fe.w;
+			if (DEGEN && idx != 0xFFFFFFFFu) it = a.items[idx]; // (the exception lists go by target and position)
+		} else {
+			idx = base + tid < n_items ? index[base + tid] : 0xFFFFFFFFu;
+			if (idx != 0xFFFFFFFFu) it = a.items[idx];
+		}
 		const bool active = idx != 0xFFFFFFFFu;
-		const Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
 		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
-		const int L = active ? a.olig_len[slot.oligo] : 0;
 		const bool minus = (it.info & ITEM_MINUS) != 0;
 		const int qloc = int(it.info & 127u);
-		const uint32_t tlen = active ? a.db.len[it.target] : 0u;
-		// window, bind_oligo.cpp:502-505; plain windows only (the bucket pass routes windows with degenerate bases elsewhere)
-		int start = int(it.tloc) - (qloc + FLANK);
-		if (start < 0) start = 0;
-		int stop = start + L + 2 * FLANK;
-		if (stop > int(tlen)) stop = int(tlen);
-		const int W = active ? stop - start : 0;
+		int L, start, stop, W;
+		if (a.fat) {
+			L = int((fe.z >> 12) & 0xFFu);
+			W = active ? int((fe.z >> 4) & 0xFFu) : 0;
+			const int s_abs = int(it.tloc) - (qloc + FLANK);
+			start = DEGEN ? (s_abs < 0 ? 0 : s_abs) : int(fe.z & 15u); // (only start & 15 and W matter to the plain instance)
+			stop = start + W;
+		} else {
+			L = active ? a.olig_len[slot.oligo] : 0;
+			const uint32_t tlen = active ? a.db.len[it.target] : 0u;
+			// window, bind_oligo.cpp:502-505; plain windows only (the bucket pass routes windows with degenerate bases elsewhere)
+			start = int(it.tloc) - (qloc + FLANK);
+			if (start < 0) start = 0;
+			stop = start + L + 2 * FLANK;
+			if (stop > int(tlen)) stop = int(tlen);
+			W = active ? stop - start : 0;
+		}
 		// The window stays in registers: the packed words that hold [start, stop), shifted so that base `start` sits in the
 		// low bits.  Column j reads base start + j - 1 as it is (plus-strand binding, bind_oligo.cpp:1227-1276) or the
 		// complement of base stop - j (minus strand: complement, reversed, :524-573).
 		constexpr int NW = (WMAX + 15) / 16; // words of the shifted stream
 		uint32_t wv[NW];
 		{
-			const uint32_t *pk = a.db.packed + (active ? a.db.word_off[it.target] : 0ull) + uint32_t(start >> 4);
+			const uint32_t *pk = a.fat ? a.db.packed + fe.y : a.db.packed + (active ? a.db.word_off[it.target] : 0ull) + uint32_t(start >> 4);
 			uint32_t raw[NW + 1];
 #pragma unroll
 			for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u; // rows are padded and the array has eight words of slack behind its end (NW + 1 <= 6 words are read)
@@ -291,7 +315,7 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 			if (active) a.audit[idx] = pass ? 0 : 1;
 			pass = true;
 		}
-		if (active && !pass) a.result[idx] = -1; // bind_oligo.cpp:600-606: Tm below the minimum
+		if (active && !pass && !a.fat) a.result[idx] = -1; // bind_oligo.cpp:600-606: Tm below the minimum (fat entries: set by the seed kernel)
 		if (surv) {
 			// Survivors collect in a per-wavefront LDS buffer and leave for the list 64 at a time: one global atomic per 64
 			// survivors (a hot counter sustains only ~88 atomics per microsecond -- one per wavefront and trip, as a first

@@ -549,6 +549,7 @@ struct tnt_ctx {
 		DevBuf<uint32_t> active, qa, qb;
 		DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
 		DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
+		DevBuf<uint4> qfat;       // phase-A queues of the round-3 seed kernel: self-contained entries (FilterArgs2::fat)
 		DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
 		DevBuf<uint32_t> item_rep;
 		DevBuf<BoundRec> pool;
@@ -819,9 +820,11 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		if (direct && c->h_q_cap[i] == 0) continue; // no slot routes its items here
 		const int lane = c->serial_bind ? 0 : n_launch++ % tnt_ctx::BIND_LANES;
 		if (c->serial_bind) n_launch = 1;
-		const uint32_t *queue = direct ? c->S().qa.p + c->h_q_base[i] : c->S().qbucket.p;
+		// (direct: the queue holds 16-byte entries whose first word is the item index)
+		const uint32_t *queue = direct ? reinterpret_cast<const uint32_t *>(c->S().qfat.p + c->h_q_base[i]) : c->S().qbucket.p;
 		uint32_t *survivors = c->S().qsurv.p ? c->S().qsurv.p + (direct ? c->h_q_base[i] : 0u) : nullptr;
 		b.index = queue;
+		b.index_stride = direct ? 4 : 1;
 		b.index_base_dev = direct ? nullptr : cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
@@ -841,6 +844,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.thresh = b.thresh;
 			f.items = b.items;
 			f.index = queue;
+			f.fat = direct ? c->S().qfat.p + c->h_q_base[i] : nullptr;
 			f.index_base_dev = b.index_base_dev;
 			f.n_items_dev = b.n_items_dev;
 			f.n_items = uint32_t(ITEM_CAP);
@@ -852,6 +856,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.status_exact = c->filter_status_exact ? 1 : 0;
 			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
 			b.index = survivors;
+			b.index_stride = 1;
 			b.n_items_dev = f.n_survivors;
 			b.audit = f.audit;
 		}
@@ -907,6 +912,7 @@ int ensure_set(tnt_ctx *c, int k)
 	HIP_TRY(W.qb.alloc(ITEM_CAP), c->err);
 	HIP_TRY(W.qbucket.alloc(ITEM_CAP), c->err);
 	if (c->filter_on) HIP_TRY(W.qsurv.alloc(ITEM_CAP), c->err);
+	if (c->seed2) HIP_TRY(W.qfat.alloc(ITEM_CAP), c->err);
 	if (c->filter_audit) HIP_TRY(W.audit.alloc(ITEM_CAP), c->err);
 	if (c->dedupe) HIP_TRY(W.item_rep.alloc(ITEM_CAP), c->err);
 	HIP_TRY(W.pool.alloc(POOL_CAP), c->err);
@@ -2025,7 +2031,9 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	}
 	s.err = gcnt + C_ERR;
 	s.debug = gcnt + C_DEBUG + 8;
-	const bool direct = c->seed2 && !seeds_only; // the round-3 seed kernel: private regions, phase-A items straight into their buckets' queues
+	// the round-3 seed kernel: private regions, phase-A items straight into their buckets' queues (its queue entries hold the
+	// windows' packed-word index in 32 bits)
+	const bool direct = c->seed2 && !seeds_only && db->h_word_off[db->n_targets] < (uint64_t(1) << 32);
 	if (direct) {
 		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * 4, tnt_ctx::MAX_REGIONS / S2_WAVES)));
 		const uint32_t regions = blocks * S2_WAVES;
@@ -2048,7 +2056,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		q.items = c->S().items.p, q.item_region = uint32_t(ITEM_CAP / regions);
 		q.groups = c->S().groups.p, q.group_region = uint32_t(GROUP_CAP / regions);
 		q.region_counts = c->S().region_counts.p;
-		q.queue = c->S().qa.p;
+		q.queue = c->S().qfat.p;
+		q.result = c->S().result.p;
 		q.q_base = c->q_base.p, q.q_cap = c->q_cap.p;
 		q.q_count = cnt + C_BUCKET;
 		q.q_state = c->S().q_state.p;
@@ -2069,7 +2078,9 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 			for (uint32_t ai = q.assay_begin; ai < q.assay_end; ai++)
 				if (c->h_assays[ai].kind == 0 && c->h_assays[ai].has_probe) q.chunk_has_probe = 1;
 			q.last_chunk = ch + 2 == c->chunk_begin.size() ? 1 : 0;
-			hipLaunchKernelGGL(seed2_kernel, dim3(blocks), dim3(S2_THREADS), 0, seed_stream, q);
+			// (an instance compiled for the default word size -W 7, one that takes it at run time)
+			if (q.word_size == 7) hipLaunchKernelGGL(seed2_kernel<7>, dim3(blocks), dim3(S2_THREADS), 0, seed_stream, q);
+			else hipLaunchKernelGGL(seed2_kernel<0>, dim3(blocks), dim3(S2_THREADS), 0, seed_stream, q);
 		}
 	}
 	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));

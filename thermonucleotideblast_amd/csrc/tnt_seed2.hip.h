@@ -68,7 +68,8 @@ struct Seed2Args {
 	Group *groups;
 	uint32_t group_region;
 	uint32_t *region_counts;     // [2 * regions]: items, groups in every region (kept across the chunk launches of a batch)
-	uint32_t *queue;             // phase-A queues, one region per length bucket
+	uint4 *queue;                // phase-A queues, one region per length bucket: self-contained entries (FilterArgs2::fat)
+	int32_t *result;             // [item] set to "not bound" here: the pre-filter writes nothing for the windows it rejects
 	const uint32_t *q_base;      // [bucket] first slot of the bucket's region
 	const uint32_t *q_cap;       // [bucket] slots of the region (a multiple of QUEUE_BLOCK)
 	uint32_t *q_count;           // [bucket * BUCKET_STRIDE] slots handed out (device counter)
@@ -94,24 +95,29 @@ __device__ __forceinline__ uint32_t s2_rank(unsigned long long m) // set bits of
 // Is (wi, p) the first seed of its diagonal?  Packed form for plain A/C/G/T oligos whose compared stretch fits 32 bases:
 // XOR the target and the oligo along the diagonal and look for a run of `ws` matching bases that starts before the seed
 // (bind_oligo.cpp:98-99: stable sort by diagonal + unique keeps the smallest word index).  W0..W2 = the three packed
-// target words from word (p - kmax) >> 4 on; seq = the oligo (128 bits).  All in 32-bit halves: v_alignbit funnels.
-__device__ __forceinline__ bool s2_first_packed(uint32_t W0, uint32_t W1, uint32_t W2, const uint4 seq, uint32_t wi, uint32_t p, uint32_t kmax, int ws)
+// target words from word (p - kmax) >> 4 on; (o_lo, o_hi) = the oligo from base wi - kmax on (base 0 of the oligo
+// whenever the seed lies at least wi bases into the target, i.e. nearly always).  All in 32-bit halves: v_alignbit
+// funnels.  WS: the word size when the instance is compiled for one (7), 0 = the run-time value `ws`.
+template <int WS> __device__ __forceinline__ bool s2_first_packed(uint32_t W0, uint32_t W1, uint32_t W2, uint32_t o_lo, uint32_t o_hi, uint32_t p, uint32_t kmax, int ws)
 {
 	const uint32_t sh = ((p - kmax) & 15u) * 2u;
 	const uint32_t t_lo = __builtin_amdgcn_alignbit(W1, W0, sh), t_hi = __builtin_amdgcn_alignbit(W2, W1, sh);
-	const uint32_t s2 = (wi - kmax) * 2u, word = s2 >> 5, sh2 = s2 & 31u;
-	const uint32_t oa = word == 0 ? seq.x : (word == 1 ? seq.y : (word == 2 ? seq.z : seq.w));
-	const uint32_t ob = word == 0 ? seq.y : (word == 1 ? seq.z : (word == 2 ? seq.w : 0u));
-	const uint32_t oc = word == 0 ? seq.z : (word == 1 ? seq.w : 0u);
-	const uint32_t o_lo = __builtin_amdgcn_alignbit(ob, oa, sh2), o_hi = __builtin_amdgcn_alignbit(oc, ob, sh2);
 	const uint32_t x_lo = t_lo ^ o_lo, x_hi = t_hi ^ o_hi;
 	// one bit per matching base (even bit positions), 32 bases in two words
-	uint32_t z_lo = ~(x_lo | (x_lo >> 1)) & 0x55555555u, z_hi = ~(x_hi | (x_hi >> 1)) & 0x55555555u;
+	const uint32_t z_lo = ~(x_lo | (x_lo >> 1)) & 0x55555555u, z_hi = ~(x_hi | (x_hi >> 1)) & 0x55555555u;
 	// runs of `ws` matching bases: r = z & z>>2 & ... & z>>2(ws-1) over the 64-bit value (hi:lo)
-	uint32_t r_lo = z_lo, r_hi = z_hi;
-	for (int i = 1; i < ws; i++) {
-		r_lo &= __builtin_amdgcn_alignbit(z_hi, z_lo, 2 * i);
-		r_hi &= z_hi >> (2 * i);
+	uint32_t r_lo, r_hi;
+	if (WS == 7) { // runs of 2, of 4, then 4 + 2 + 1
+		const uint32_t a_lo = z_lo & __builtin_amdgcn_alignbit(z_hi, z_lo, 2), a_hi = z_hi & (z_hi >> 2);
+		const uint32_t b_lo = a_lo & __builtin_amdgcn_alignbit(a_hi, a_lo, 4), b_hi = a_hi & (a_hi >> 4);
+		r_lo = b_lo & __builtin_amdgcn_alignbit(a_hi, a_lo, 8) & __builtin_amdgcn_alignbit(z_hi, z_lo, 12);
+		r_hi = b_hi & (a_hi >> 8) & (z_hi >> 12);
+	} else {
+		r_lo = z_lo, r_hi = z_hi;
+		for (int i = 1; i < ws; i++) {
+			r_lo &= __builtin_amdgcn_alignbit(z_hi, z_lo, 2 * i);
+			r_hi &= z_hi >> (2 * i);
+		}
 	}
 	// ... that start before the seed: bases [0, kmax)
 	const uint32_t b_lo = kmax >= 16u ? ~0u : ((1u << (2u * kmax)) - 1u);
@@ -119,7 +125,7 @@ __device__ __forceinline__ bool s2_first_packed(uint32_t W0, uint32_t W1, uint32
 	return ((r_lo & b_lo) | (r_hi & b_hi)) == 0u;
 }
 
-__global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
+template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 {
 	__shared__ uint32_t s_raw[S2_WAVES][S2_CAP];      // kept seeds (keys) as the dense pass finds them
 	__shared__ uint32_t s_srt[S2_WAVES][S2_CAP];      // candidates of the scan, then the keys grouped by assay
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 	__shared__ uint32_t s_qbase[MAX_BUCKETS], s_qcap[MAX_BUCKETS];
 	// pointers the emission needs: read from LDS where they are used (kept in registers they spill to scratch memory,
 	// and a scratch reload is a vector-memory load -- see the emission)
-	enum { COLD_ITEMS = 0, COLD_GROUPS, COLD_QUEUE, COLD_Q_COUNT, COLD_BIG, COLD_ERR, COLD_N };
+	enum { COLD_ITEMS = 0, COLD_GROUPS, COLD_QUEUE, COLD_Q_COUNT, COLD_BIG, COLD_ERR, COLD_RESULT, COLD_N };
 	__shared__ unsigned long long s_cold[COLD_N];
 	typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64; // (volatile: not hoisted out of the loops, not kept in registers)
 	auto cold = [&](int k) __attribute__((always_inline)) { return *(lds_vu64 *)(&s_cold[k]); };
@@ -158,6 +164,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 	if (threadIdx.x == 0) {
 		s_cold[COLD_ITEMS] = (unsigned long long)a.items, s_cold[COLD_GROUPS] = (unsigned long long)a.groups, s_cold[COLD_QUEUE] = (unsigned long long)a.queue;
 		s_cold[COLD_Q_COUNT] = (unsigned long long)a.q_count, s_cold[COLD_BIG] = (unsigned long long)a.big_count, s_cold[COLD_ERR] = (unsigned long long)a.err;
+		s_cold[COLD_RESULT] = (unsigned long long)a.result;
 	}
 	// the wavefront's private output region (items, groups) and the queue blocks it is filling; both persist across the
 	// chunk launches of a batch
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 		const uint32_t t = rec_cur.x, len = rec_cur.y;
 		const uint32_t *pk = a.db.packed + (uint64_t(rec_cur.z) | (uint64_t(rec_cur.w) << 32));
 		const bool in_lds = ((len + 15u) >> 4) <= uint32_t(S2_TGT_WORDS);
+		const uint32_t rec_words = rec_cur.z; // first packed word of the target (the host checks that the packed array stays below 2^32 words)
 		// this unit's words -> LDS; the next unit's words and the record behind it -> in flight
 		tgt[lane] = wc0, tgt[lane + 64] = wc1;
 		rec_cur = rec_next;
@@ -234,19 +242,20 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 		// One candidate: its table entry and the oligo the entry belongs to come with the same index (two loads, one
 		// round trip); the target words come from LDS.
 		struct Cand {
-			uint32_t cp, ent;
-			uint4 seq;
+			uint32_t cp, ent, idx;
+			uint2 seq; // the first 32 bases of the entry's oligo
 			bool live;
 		};
 		auto fetch = [&](uint32_t c, uint32_t ncand) __attribute__((always_inline)) {
 			Cand x;
 			x.live = c < ncand;
-			x.cp = 0, x.ent = 0, x.seq = make_uint4(0, 0, 0, 0);
+			x.cp = 0, x.ent = 0, x.idx = 0, x.seq = make_uint2(0, 0);
 			if (x.live) {
 				const uint32_t cv = cand[c];
 				x.cp = cv & 0x7FFFu;
-				x.ent = a.wt_ent[cv >> 15];
-				x.seq = a.wt_seq[cv >> 15];
+				x.idx = cv >> 15;
+				x.ent = a.wt_ent[x.idx];
+				x.seq = *reinterpret_cast<const uint2 *>(a.wt_seq + x.idx);
 			}
 			return x;
 		};
@@ -261,7 +270,16 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 					first = true;
 				} else if ((x.ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) {
 					const uint32_t w0 = (cp - kmax) >> 4;
-					first = s2_first_packed(tw(w0), tw(w0 + 1), tw(w0 + 2), x.seq, wi, cp, kmax, a.word_size);
+					uint32_t o_lo = x.seq.x, o_hi = x.seq.y;
+					if (kmax != wi) { // the seed sits less than wi bases into the target: the oligo from base wi - kmax on (rare)
+						const uint4 q = a.wt_seq[x.idx];
+						const uint32_t s2 = (wi - kmax) * 2u, word = s2 >> 5, sh2 = s2 & 31u;
+						const uint32_t oa = word == 0 ? q.x : (word == 1 ? q.y : (word == 2 ? q.z : q.w));
+						const uint32_t ob = word == 0 ? q.y : (word == 1 ? q.z : (word == 2 ? q.w : 0u));
+						const uint32_t oc = word == 0 ? q.z : (word == 1 ? q.w : 0u);
+						o_lo = __builtin_amdgcn_alignbit(ob, oa, sh2), o_hi = __builtin_amdgcn_alignbit(oc, ob, sh2);
+					}
+					first = s2_first_packed<WS>(tw(w0), tw(w0 + 1), tw(w0 + 2), o_lo, o_hi, cp, kmax, a.word_size);
 				} else {
 					const uint32_t li = (assay * 3u + ((x.ent >> 8) & 3u)) * 2u + ((x.ent & WT_MINUS) ? 1u : 0u);
 					first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
@@ -363,15 +381,19 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 					}
 				}
 			}
-			// dense pass over the candidate list, two rounds of 64 in flight: the first seed of every (oligo, strand,
+			// dense pass over the candidate list, four rounds of 64 in flight: the first seed of every (oligo, strand,
 			// diagonal) survives
 			wave_sync(); // the list was written by other lanes
 			S2_STAMP(1);
-			for (uint32_t c0 = 0; c0 < ncand; c0 += 128) {
+			for (uint32_t c0 = 0; c0 < ncand; c0 += 256) {
 				const Cand x0 = fetch(c0 + uint32_t(lane), ncand);
 				const Cand x1 = fetch(c0 + 64u + uint32_t(lane), ncand);
+				const Cand x2 = fetch(c0 + 128u + uint32_t(lane), ncand);
+				const Cand x3 = fetch(c0 + 192u + uint32_t(lane), ncand);
 				settle(x0);
 				if (c0 + 64u < ncand) settle(x1);
+				if (c0 + 128u < ncand) settle(x2);
+				if (c0 + 192u < ncand) settle(x3);
 			}
 			wave_sync();
 			S2_STAMP(2);
@@ -554,7 +576,8 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 		static_assert(sizeof(Item) == 16 && sizeof(Group) == 16, "items and groups are written as one dwordx4");
 		glb_u32x4 *const g_items = (glb_u32x4 *)cold(COLD_ITEMS);
 		glb_u32x4 *const g_groups = (glb_u32x4 *)cold(COLD_GROUPS);
-		glb_u32 *const g_queue = (glb_u32 *)cold(COLD_QUEUE);
+		glb_u32x4 *const g_queue = (glb_u32x4 *)cold(COLD_QUEUE);
+		glb_u32 *const g_result = (glb_u32 *)cold(COLD_RESULT);
 		uint32_t carry_la = ~0u; // assay of the last seed of the round before
 		for (uint32_t i0 = 0; i0 < n_valid_all; i0 += 64) {
 			const uint32_t i = i0 + uint32_t(lane);
@@ -587,17 +610,23 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 				if (nv > 64u) __hip_atomic_fetch_add((glb_u32 *)cold(COLD_BIG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			uint32_t bucket = ~0u;
+			u32x4 fat = u32x4{0xFFFFFFFFu, 0u, 0u, 0u};
 			if (valid) {
 				const uint32_t slot = assay * 3u + role; // the Slot table is laid out [assay][role]
 				// Item{target, tloc, info, group}
-				g_items[o] = u32x4{t, p, wi | (minus ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | (slot << ITEM_SLOT_SHIFT), gidx};
+				const uint32_t info = wi | (minus ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | (slot << ITEM_SLOT_SHIFT);
+				g_items[o] = u32x4{t, p, info, gidx};
+				g_result[o] = 0xFFFFFFFFu; // -1: not bound (what the pre-filter's rejection means; a bind overwrites it)
 				if (!pb) {
 					const uint32_t sp = s_slot[la * 3u + role];
 					bucket = sp & 0xFFu;
-					if (exc1 > exc0) { // same window as the bind kernel, bind_oligo.cpp:502-505
-						int start = int(p) - (int(wi) + FLANK);
-						if (start < 0) start = 0;
-						const uint32_t stop = uint32_t(start) + (sp >> 16) + 2u * FLANK;
+					// the window, bind_oligo.cpp:502-505
+					int start = int(p) - (int(wi) + FLANK);
+					if (start < 0) start = 0;
+					uint32_t stop = uint32_t(start) + (sp >> 16) + 2u * FLANK;
+					if (stop > len) stop = len;
+					fat = u32x4{o, uint32_t(rec_words + uint32_t(start >> 4)), uint32_t(start & 15) | ((stop - uint32_t(start)) << 4) | ((sp >> 16) << 12), info};
+					if (exc1 > exc0) { // windows with a degenerate target base go to the general instance of their length
 						uint32_t lo = exc0, hi = exc1;
 						while (lo < hi) {
 							const uint32_t mid = (lo + hi) >> 1;
@@ -645,7 +674,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 						const uint32_t nb = s_qnew[wv][bucket];
 						pos = nb == ~0u ? ~0u : nb + (pos - split);
 					}
-					if (pos != ~0u) g_queue[pos] = o;
+					if (pos != ~0u) g_queue[pos] = fat;
 				}
 				n_phase_a += uint32_t(__builtin_popcountll(am));
 			}
@@ -668,7 +697,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
 	if (lane < a.n_buckets) {
 		const uint32_t cur = s_qcur[wv][lane], end = s_qend[wv][lane];
 		if (a.last_chunk)
-			for (uint32_t x = cur; x < end; x++) a.queue[x] = QUEUE_HOLE;
+			for (uint32_t x = cur; x < end; x++) a.queue[x] = make_uint4(QUEUE_HOLE, 0, 0, 0);
 		a.q_state[(region * MAX_BUCKETS + lane) * 2] = cur;
 		a.q_state[(region * MAX_BUCKETS + lane) * 2 + 1] = end;
 	}
