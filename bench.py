@@ -409,7 +409,7 @@ def main():
                 # rate: 1 024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction
                 si = rec.get("seed_kernel_insts_per_step")
                 if si and seed_ms_step > 0:
-                    # the seed stage is a chain of short dependent per-target steps: ~5 200 wave-instructions per target
+                    # the seed stage is a chain of short dependent per-target steps: ~3 700 wave-instructions per target (round 2: 5 200)
                     n_all, n_v = sum(si.values()), si["SQ_INSTS_VALU"]
                     seed_issue = {"wave_instructions_per_step": n_all, "valu_wave_instructions_per_step": n_v, "unit": "wave-instructions/s",
                                   "achieved_all": n_all / (seed_ms_step * 1e-3), "achieved_valu": n_v / (seed_ms_step * 1e-3),
@@ -421,6 +421,19 @@ def main():
                             "frac_guide": ach / VALU_PEAK_GUIDE, "wave_instructions_per_step": n_valu}
             except Exception:
                 traffic = None
+        # the streaming part of the seed stage alone (SURVEY 8(d) means the HBM roofline for THIS scan): its share of the
+        # kernel's cycles from the phase stamps of a diagnostic build (profiles/seed_phases.json) x this run's stage time
+        scan_only = None
+        ph = os.path.join(ROOT, "profiles", "seed_phases.json")
+        if os.path.exists(ph) and args.config == 2 and per_piece == full and args.scaling == "weak" and seed_ms_step > 0:
+            try:
+                share = json.load(open(ph))["share"]["scan"]
+                scan_ms = share * seed_ms_step
+                gbs = alg_bytes / (scan_ms * 1e-3) / 1e9
+                scan_only = {"ms_per_step": scan_ms, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "share_of_seed_kernel": share,
+                             "source": "profiles/seed_phases.json (scripts/seed_phases.py: s_memtime stamps of a TNT_EXP_STATS build, a run of its own)"}
+            except Exception:
+                scan_only = None
         tl = n_bases_rank // max(1, n_targets_rank)
         line = {
             "metric": "oligo x target-base evaluations per second (seed + NN-thermodynamic bind + pairing)",
@@ -439,7 +452,7 @@ def main():
             "gather_bytes_per_search": acc["gather_bytes"],
             "pack_and_h2d_s": pack_s,
             "stage_ms_per_step": {"seed": seed_ms_step, "bind": bind_ms_step, "pair": pair_ms / steps},
-            "roofline": {"bound": "hbm", "kernel": "bind stage: bucket_kernel + filter_kernel<L> (pre-filter) + bind_kernel<L> on the survivors",
+            "roofline": {"bound": "hbm", "kernel": "bind stage: filter_kernel<L> (pre-filter, on the queues the seed kernel filled) + bind_kernel<L> on the survivors; phase B through bucket_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("profiles/bind_pmc.json: rocprofv3 --pmc passes of this workload in a run of their own "
@@ -447,16 +460,16 @@ def main():
                          "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once) over the stage time "
                                  "(HIP events on the library's stream); the stage is bound by VALU issue and LDS bank "
                                  "conflicts, not by HBM (DESIGN.md 4.2, 4.2a); traffic = PMC 2*FETCH_SIZE + WRITE_SIZE per step "
-                                 "of the full-size config (profiles/bind_pmc.json; round 1: 56.5 GB)",
+                                 "of the full-size config (profiles/bind_pmc.json; round 1: 56.5 GB, round 2: 20.7 GB)",
                          "dp_per_s": n_binds / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0,
                          "valu_issue": valu},
             # the streaming stage, for which SURVEY 8(d) means the HBM roofline: the seed kernels of a step (scan + cull)
-            "roofline_seed": {"bound": "hbm", "kernel": "seed stage (scan + dedupe + first cull + emission)", "achieved": seed_achieved,
+            "roofline_seed": {"bound": "hbm", "kernel": "seed stage: seed2_kernel (scan + diagonal de-duplication + first cull + emission into the buckets' queues)", "achieved": seed_achieved,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": seed_achieved / HBM_PEAK_GBS,
                               "note": "a chain of short dependent per-target steps (scan, de-duplication, counting sort, first cull, "
                                       "emission), bound by instruction issue and LDS round trips, not by the 0.25 B/base it streams "
                                       "(DESIGN.md 4.1); issue = PMC instruction counts of the stage (profiles/bind_pmc.json) over its time",
-                              "issue": seed_issue},
+                              "issue": seed_issue, "scan_only": scan_only},
         }
         if world == 1 and not args.no_cpu_baseline and wl0 is not None:
             try:

@@ -7,7 +7,8 @@ import sys
 
 src = sys.argv[1]
 d = json.load(open(src))["kernels"]
-stage = ["bucket_kernel", "filter_kernel<L>", "bind_kernel<L>"]
+stage = [k for k in ("bucket_kernel", "filter_kernel<L>", "bind_kernel<L>") if k in d]
+seed = "seed2_kernel" if "seed2_kernel" in d else "seed_kernel"  # (round 3: tnt_seed2.hip.h)
 fetch = sum(float(d[k]["FETCH_SIZE"]) for k in stage)   # KB per search (= per step of the full-size config)
 write = sum(float(d[k]["WRITE_SIZE"]) for k in stage)
 old = {}
@@ -19,12 +20,12 @@ out = {
     "kernel": "bind stage of one step (config 2, 1 000 000 x 1 kb targets): bucket_kernel + filter_kernel<L> + bind_kernel<L> on the survivors",
     "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
     "per_kernel_KB": {k: {"FETCH_SIZE": float(v["FETCH_SIZE"]), "WRITE_SIZE": float(v["WRITE_SIZE"])}
-                      for k, v in d.items() if k in stage + ["seed_kernel", "pair_kernel"]},
+                      for k, v in d.items() if k in stage + [seed, "pair_kernel"]},
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_step": int((2.0 * fetch + write) * 1024),
     "SQ_INSTS_VALU_per_step": sum(float(d[k]["SQ_INSTS_VALU"]) for k in stage),
     # the seed stage's instruction counts (wave-instructions per step): what bounds it is issue, not the 250 MB it streams
-    "seed_kernel_insts_per_step": {k: float(d["seed_kernel"][k]) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")},
+    "seed_kernel_insts_per_step": {k: float(d[seed][k]) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")},
     "history": (old.get("history") or ([{"hbm_bytes_per_step": old["round1"]["hbm_bytes_per_step"], "SQ_INSTS_VALU_per_step": old["round1"]["SQ_INSTS_VALU_per_step"], "state": "round 1 (r01k)"}] if "round1" in old else []))
                + ([{"hbm_bytes_per_step": old["hbm_bytes_per_step"], "SQ_INSTS_VALU_per_step": old["SQ_INSTS_VALU_per_step"], "state": old.get("source", "")[:40]}] if "hbm_bytes_per_step" in old and old.get("source") != None and src not in old.get("source", "") else []),
 }
