@@ -87,6 +87,13 @@ def random_case(rng, case, max_code=18, dangle=True):
             unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
             p = int(rng.integers(0, len(codes) - 200))
             codes[p:p + 120] = np.resize(unit, 120)
+    if o.hash_word_size <= 4:
+        # -W 3 / -W 4 seed every position dozens of times: a smaller case keeps the CPU checkers (the single-threaded
+        # reference in scripts/fuzz_oracle.py above all) at seconds per case
+        nt4 = min(len(offsets) - 1, 16)
+        offsets = offsets[:nt4 + 1]
+        codes = codes[:int(offsets[-1])]
+        wl.expanded = wl.expanded[:6]
     return cfg, wl, codes, offsets
 
 
