@@ -1704,7 +1704,7 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 	const double UNITS = 1000.0;
 	auto units = [&](double kcal) { return int(std::min(double(SAT), std::max(double(NEG), std::ceil(kcal * UNITS)))); };
 	const double log_na = double(logf(opt->salt));
-	bool ok = !opt->allow_dangle_5 && !opt->allow_dangle_3 && !opt->use_dinkelbach && log_na <= 0.0;
+	bool ok = !opt->use_dinkelbach && log_na <= 0.0;
 	for (int i = 0; i < 513; i++) ok = ok && P.loop_S[i] <= 0.0f && P.bulge_S[i] <= 0.0f;
 	ok = ok && P.asym_S <= 0.0f && P.bulge_at_S <= 0.0f;
 	for (int x = A; x <= I; x++)
@@ -1755,7 +1755,27 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 				C.close[prev * NBP + cur] = units(std::max(std::max(f, 0.0), u1) - gap_price);
 			}
 		const double g_init = double(P.init_H) - Tk * double(P.init_S), g_at = double(P.at_H) - Tk * double(P.at_S);
-		C.theta0 = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02 - (by_dg ? max_dg[k] : 0.0));
+		// dangling-end options: one more column per end, worth at most the sum of the two single-dangle stacks on the closing
+		// pair (evaluate_alignment's frayed end, nuc_cruc.cpp:1737-1768), and one column's salt charge less
+		double dangle = 0.0;
+		if (opt->allow_dangle_5 || opt->allow_dangle_3) {
+			auto raw = [&](int prev, int cur) { return std::max(0.0, -(double(P.H[prev * NBP + cur]) - Tk * double(P.S[prev * NBP + cur]))); };
+			double d_start = 0.0, d_stop = 0.0;
+			for (int c = 0; c < NBP; c++) {
+				if (!P.wc[c] || c / NB > I || c % NB > I) continue;
+				double qs = 0.0, ts = 0.0, qe = 0.0, te = 0.0;
+				for (int x = A; x <= I; x++) {
+					qs = std::max(qs, raw(x * NB + E, c)), ts = std::max(ts, raw(E * NB + x, c));
+					qe = std::max(qe, raw(c, x * NB + E)), te = std::max(te, raw(c, E * NB + x));
+				}
+				d_start = std::max(d_start, qs + ts), d_stop = std::max(d_stop, qe + te);
+			}
+			// --dangle5 adds the column in front of the alignment (the 5' end of the query, read first: the stack INTO the first
+			// Watson-Crick pair), --dangle3 the one behind it; a dangling column counts one base where the salt term assumed two
+			const int ends = (opt->allow_dangle_5 ? 1 : 0) + (opt->allow_dangle_3 ? 1 : 0);
+			dangle = (opt->allow_dangle_5 ? d_start : 0.0) + (opt->allow_dangle_3 ? d_stop : 0.0) - 0.5 * double(ends) * Tk * sc; // (sc <= 0)
+		}
+		C.theta0 = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02 - (by_dg ? max_dg[k] : 0.0) - dangle);
 	}
 #pragma omp parallel for schedule(dynamic, 256)
 	for (long k = 0; k < long(n); k++) {

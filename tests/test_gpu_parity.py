@@ -149,7 +149,7 @@ def test_random_windows_production_vs_oracle(Engine, oracle, seed, kw):
     e.close()
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 8])
+@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 8, 9, 11])
 def test_filter_kernel_equals_its_checker(Engine, oracle, k):
     """The pre-filter kernel (every row-count instance the oligo lengths pick) against the oracle-side restatement whose
     soundness tests/test_filter_bound.py checks: same bound, same threshold, for every window."""
@@ -180,7 +180,9 @@ def test_filter_changes_no_result(Engine, oracle, monkeypatch):
     for cfg, nt, na, kw in [(2, 30000, 96, {}), (3, 20000, 96, dict(min_primer_tm=50.0, min_probe_tm=45.0)), (5, 6000, 200, {}),
                             # dG-only thresholds: the bound is taken against the maximum dG at the target temperature
                             (2, 20000, 96, dict(min_primer_tm=0.0, max_primer_dg=-10.0)),
-                            (3, 12000, 48, dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-9.0, max_probe_dg=-11.0))]:
+                            (3, 12000, 48, dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-9.0, max_probe_dg=-11.0)),
+                            # dangling-end options: the threshold carries the most a dangling / frayed end can add
+                            (2, 20000, 96, dict(allow_dangle_5=1, allow_dangle_3=1))]:
         wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=31)
         for k_, v_ in kw.items():
             setattr(wl.options, k_, v_)
@@ -987,3 +989,22 @@ def test_skipped_targets_are_not_searched(Engine, oracle):
     assert tc.sorted_hit_keys(e.search(db)) == all_hits
     db.close()
     e.close()
+
+
+def test_pipelined_batches_give_the_same_hits(Engine, oracle, monkeypatch):
+    """TNT_MI355X_PIPELINE=n: a large search cut into n batches on two buffer sets, the seed stage of one batch on its own
+    stream beside the bind stage of the batch before it (off by default: measured slower) -- same hits."""
+    wl = synth.make_workload(3, n_targets=110000, n_assays=6, seed=77)
+    res = {}
+    for n in ("1", "3"):
+        monkeypatch.setenv("TNT_MI355X_PIPELINE", n)
+        e = Engine(wl.options, wl.expanded)
+        db = e.pack(wl.codes, wl.offsets)
+        res[n] = [tc.sorted_hit_keys(e.search(db)) for _ in range(2)]  # (twice: the buffer sets are reused)
+        db.close()
+        e.close()
+    monkeypatch.delenv("TNT_MI355X_PIPELINE", raising=False)
+    assert res["1"][0] == res["1"][1] == res["3"][0] == res["3"][1] and len(res["1"][0]) > 100
+    sample = 4000
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes[:int(wl.offsets[sample])], wl.offsets[:sample + 1]))
+    assert [h for h in res["3"][0] if h[2] < sample] == want

@@ -253,7 +253,7 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 	for (int b = bA; b <= bI; b++) wc[b * NB + bI] = wc[bI * NB + b] = true;
 	// premises: every loop / bulge / asymmetry / AT-bulge term is an entropy penalty, the salt term
 	// destabilises, stacks on a gap column carry nothing, no dangling-end columns
-	bool ok = !opt.allow_dangle_5 && !opt.allow_dangle_3 && !opt.use_dinkelbach && T.log_na <= 0.0f && T.salt >= 0.0f;
+	bool ok = !opt.use_dinkelbach && T.log_na <= 0.0f && T.salt >= 0.0f;
 	for (int i = 0; i < 513; i++) ok = ok && T.loop_S[i] <= 0.0f && T.bulge_S[i] <= 0.0f;
 	ok = ok && T.asym_S <= 0.0f && T.bulge_at_S <= 0.0f;
 	for (int x = bA; x <= bI; x++)
@@ -330,7 +330,30 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i] = pack(v[i][0], v[i][1]);
 		const double g_init = double(T.init_H) - Tk * double(T.init_S);
 		const double g_at = double(T.at_H) - Tk * double(T.at_S);
-		F.theta0[cls] = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02 - (by_dg ? max_dg[cls] : 0.0)); // 0.02 kcal/mol: float32 rounding of the reference's sums, generously
+		// Dangling-end options (enumerate_dimer_alignments, nuc_cruc.cpp:1068-1137): the trimmed alignment gets one more column
+		// per end -- a dangling base, or both bases of a frayed end, which evaluate_alignment credits as the SUM of the two
+		// single-dangle stacks (:1737-1768).  Each end therefore adds at most D = max over the closing Watson-Crick pair of
+		// (best (q,E) stack + best (E,t) stack), and a dangling column carries one base where the salt term's count assumed
+		// two: one column's salt charge less.  Both are constants: they loosen the threshold.
+		double dangle = 0.0;
+		if (opt.allow_dangle_5 || opt.allow_dangle_3) {
+			auto raw = [&](int prev, int cur) { return std::max(0.0, -(double(T.H[prev * NBP + cur]) - Tk * double(T.S[prev * NBP + cur]))); };
+			double d_start = 0.0, d_stop = 0.0;
+			for (int c = 0; c < NBP; c++) {
+				if (!wc[c] || c / NB > bI || c % NB > bI) continue;
+				double qs = 0.0, ts = 0.0, qe = 0.0, te = 0.0;
+				for (int x = bA; x <= bI; x++) {
+					qs = std::max(qs, raw(x * NB + bE, c)), ts = std::max(ts, raw(bE * NB + x, c));
+					qe = std::max(qe, raw(c, x * NB + bE)), te = std::max(te, raw(c, bE * NB + x));
+				}
+				d_start = std::max(d_start, qs + ts), d_stop = std::max(d_stop, qe + te);
+			}
+			// --dangle5 adds the column in front of the alignment (the 5' end of the query, read first: the stack INTO the first
+			// Watson-Crick pair), --dangle3 the one behind it; a dangling column counts one base where the salt term assumed two
+			const int ends = (opt.allow_dangle_5 ? 1 : 0) + (opt.allow_dangle_3 ? 1 : 0);
+			dangle = (opt.allow_dangle_5 ? d_start : 0.0) + (opt.allow_dangle_3 ? d_stop : 0.0) - 0.5 * double(ends) * Tk * sc; // (sc <= 0)
+		}
+		F.theta0[cls] = float(g_init + std::min(0.0, 2.0 * g_at) - 0.02 - (by_dg ? max_dg[cls] : 0.0) - dangle); // 0.02 kcal/mol: float32 rounding of the reference's sums, generously
 		F.enabled[cls] = by_tm ? FILT_BY_TM : FILT_BY_DG;
 	}
 }
@@ -2175,7 +2198,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		const double expect = double(db->max_unit_len) * double(max_ent) / double(size_t(1) << (2 * c->opt.hash_word_size));
 		p.big_enabled = (c->force_big || expect > 16.0) ? 1 : 0;
 	}
-	hipLaunchKernelGGL(pair_kernel<PAIR_MAX>, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
+	hipLaunchKernelGGL(pair_kernel<PAIR_SMALL>, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
+	hipLaunchKernelGGL(pair_kernel<PAIR_MAX>, dim3(2048), dim3(PAIR_THREADS), 0, c->stream, p);
 	if (p.big_enabled) hipLaunchKernelGGL(pair_kernel<PAIR_BIG>, dim3(64), dim3(PAIR_THREADS), 0, c->stream, p);
 	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt, gcnt);
 	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);

@@ -35,7 +35,9 @@ namespace tnt {
 
 constexpr int PAIR_THREADS = 64;
 constexpr int PAIR_HOST = 1 << 15; // entries of one (target, assay) list in the host replay
-constexpr int PAIR_MAX = 64;  // entries of one (target, assay) group handled by the common instance of the pair kernel
+constexpr int PAIR_SMALL = 16; // entries of one (target, assay) group handled by the common instance of the pair kernel (its per-lane lists live in
+                               // scratch memory: a quarter of the 64-entry instance's, which serves the groups of 17 to 64 entries)
+constexpr int PAIR_MAX = 64;
 constexpr int PAIR_BIG = 512; // ... and by the instance for crowded groups (short hash words, repeats); == LIST_MAX of the seed kernel
 
 struct PairArgs {
@@ -448,13 +450,15 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 // per-lane lists live in scratch memory, so the common instance keeps them small.
 template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(PairArgs a)
 {
-	if (N != PAIR_MAX && *a.n_big == 0) return;
+	if (N == PAIR_BIG && *a.n_big == 0) return;
 	const uint32_t n_active = *a.n_active;
 	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS) {
 		const Group G = a.groups[a.active[gi]];
 		const uint32_t count = G.count & ~GROUP_ALIVE;
-		if ((N == PAIR_MAX) != (count <= uint32_t(PAIR_MAX))) {
-			if (N == PAIR_MAX && !a.big_enabled) atomicOr(a.err, ERR_LIST_OVERFLOW);
+		// every group is paired by the smallest instance that holds it
+		const int fits = count <= uint32_t(PAIR_SMALL) ? PAIR_SMALL : (count <= uint32_t(PAIR_MAX) ? PAIR_MAX : PAIR_BIG);
+		if (fits != N) {
+			if (N == PAIR_MAX && fits == PAIR_BIG && !a.big_enabled) atomicOr(a.err, ERR_LIST_OVERFLOW);
 			continue;
 		}
 		pair_group<N>(a, G);
