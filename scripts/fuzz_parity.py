@@ -111,10 +111,14 @@ def main():
         cfg, wl, codes, offsets = random_case(rng, case)
         if only is not None and case != only:
             continue
+        t_case = time.time()
+        if case and case % 50 == 0:  # (progress, flushed: a run cut short still tells how far it got)
+            print("... %d cases, %d hits compared, %d differ, %.0f s" % (case, total_hits, bad, time.time() - t0), flush=True)
         try:
             want = tc.sorted_hit_keys(ora.search(wl.options, wl.expanded, codes, offsets))
         except AssertionError as e:  # the oracle refuses (e.g. word size vs oligo length): both must refuse
             want = ("error", str(e)[:60])
+        t_ora = time.time() - t_case
         try:
             from thermonucleotideblast_amd.engine import Engine
             eng = Engine(wl.options, wl.expanded)
@@ -124,6 +128,10 @@ def main():
             eng.close()
         except Exception as e:
             got = ("error", str(e)[:60])
+        t_gpu = time.time() - t_case - t_ora
+        if os.environ.get("FUZZ_SLOW") and time.time() - t_case > float(os.environ["FUZZ_SLOW"]):
+            print("slow case %d: cfg %d k %d, %d targets (longest %d), oracle %.1f s, library %.1f s" % (
+                case, cfg, wl.options.hash_word_size, len(offsets) - 1, int(np.diff(offsets.astype(np.int64)).max()), t_ora, t_gpu), flush=True)
         ok = got == want or (isinstance(got, tuple) and isinstance(want, tuple))
         if not ok and isinstance(got, tuple) and ("overflowed the LDS buffer" in got[1] or "more than 32768 seeds of one assay" in got[1]):
             # the documented capacity limit (more seeds of one assay chunk inside one seed work unit than

@@ -545,6 +545,7 @@ struct tnt_ctx {
 	// round-3 seed kernel of the search path (tnt_seed2.hip.h): items / groups in regions private to a wavefront, phase-A
 	// items straight into the queue of their length bucket
 	bool seed2 = false;
+	size_t item_cap = 0, group_cap = 0; // capacities of the work buffers (ensure_work_buffers)
 	int pipeline_batches = 1;        // batches a large search is cut into on two buffer sets (TNT_MI355X_PIPELINE; 1: one batch after the other on one stream -- measured faster)
 	static constexpr uint32_t MAX_REGIONS = 8192;
 	DevBuf<uint32_t> slot_pack;      // [slot] bucket | bucket_general << 8 | oligo length << 16
@@ -678,8 +679,8 @@ static size_t cap_from_env(const char *name, size_t dflt_m)
 	const long v = e ? atol(e) : 0;
 	return size_t(v >= 16 && v <= 2048 ? size_t(v) : dflt_m) << 20;
 }
-static const size_t ITEM_CAP = cap_from_env("TNT_MI355X_ITEM_CAP_M", 768);  // bind work items per internal batch
-static const size_t GROUP_CAP = cap_from_env("TNT_MI355X_GROUP_CAP_M", 256);
+static const size_t ITEM_CAP_MAX = cap_from_env("TNT_MI355X_ITEM_CAP_M", 768);  // bind work items per internal batch: the most a context allocates
+static const size_t GROUP_CAP_MAX = cap_from_env("TNT_MI355X_GROUP_CAP_M", 256); // (tnt_ctx::item_cap / group_cap: what it has, sized by the databases it met)
 constexpr size_t POOL_CAP = size_t(4) << 20;
 
 DbView make_view(const tnt_db *db, size_t t0, size_t t1)
@@ -811,14 +812,14 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		k.src = src;
 		k.src_count = src_count;
 		k.shard_counts = shard_counts;
-		k.shard_region = uint32_t(ITEM_CAP / N_SHARD);
+		k.shard_region = uint32_t(c->item_cap / N_SHARD);
 		k.items = c->S().items.p;
 		k.slots = b.slots;
 		k.olig_len = c->olig_len.p;
 		k.db = v;
 		k.has_exceptions = has_exceptions ? 1 : 0;
 		k.dst = c->S().qbucket.p;
-		k.cap = uint32_t(ITEM_CAP);
+		k.cap = uint32_t(c->item_cap);
 		k.counters = cnt + C_BUCKET;
 		k.n_buckets = int(c->bucket_lmax.size());
 		k.merge_below = uint32_t(bind_grid(c, c->bucket_lmax.back()) * bind_threads(c->bucket_lmax.back()));
@@ -850,7 +851,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.index_stride = direct ? 4 : 1;
 		b.index_base_dev = direct ? nullptr : cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
-		b.n_items = uint32_t(ITEM_CAP); // cap on the device count
+		b.n_items = uint32_t(c->item_cap); // cap on the device count
 		b.audit = nullptr;
 		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) &&
 		    has_filter_instance(c->bucket_lmax[i] & 0xFF, !(c->bucket_lmax[i] & BUCKET_PLAIN))) { // (none beyond 64 rows: such a bucket goes to the bind kernel as it is)
@@ -870,7 +871,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.fat = direct ? c->S().qfat.p + c->h_q_base[i] : nullptr;
 			f.index_base_dev = b.index_base_dev;
 			f.n_items_dev = b.n_items_dev;
-			f.n_items = uint32_t(ITEM_CAP);
+			f.n_items = uint32_t(c->item_cap);
 			f.survivors = survivors;
 			f.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 3;
 			f.result = b.result;
@@ -923,36 +924,61 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 	return TNT_OK;
 }
 
-int ensure_set(tnt_ctx *c, int k)
+// (re)allocates buffer set k at the context's current capacities
+int alloc_set(tnt_ctx *c, int k)
 {
 	tnt_ctx::BatchSet &W = c->set[k];
-	if (W.items.p) return TNT_OK;
-	HIP_TRY(W.items.alloc(ITEM_CAP), c->err);
-	HIP_TRY(W.result.alloc(ITEM_CAP), c->err);
-	HIP_TRY(W.groups.alloc(GROUP_CAP), c->err);
-	HIP_TRY(W.active.alloc(GROUP_CAP), c->err);
-	HIP_TRY(W.qa.alloc(ITEM_CAP), c->err);
-	HIP_TRY(W.qb.alloc(ITEM_CAP), c->err);
-	HIP_TRY(W.qbucket.alloc(ITEM_CAP), c->err);
-	if (c->filter_on) HIP_TRY(W.qsurv.alloc(ITEM_CAP), c->err);
-	if (c->seed2) HIP_TRY(W.qfat.alloc(ITEM_CAP), c->err);
-	if (c->filter_audit) HIP_TRY(W.audit.alloc(ITEM_CAP), c->err);
-	if (c->dedupe) HIP_TRY(W.item_rep.alloc(ITEM_CAP), c->err);
+	HIP_TRY(W.items.alloc(c->item_cap), c->err);
+	HIP_TRY(W.result.alloc(c->item_cap), c->err);
+	HIP_TRY(W.groups.alloc(c->group_cap), c->err);
+	HIP_TRY(W.active.alloc(c->group_cap), c->err);
+	HIP_TRY(W.qa.alloc(c->item_cap), c->err);
+	HIP_TRY(W.qb.alloc(c->item_cap), c->err);
+	HIP_TRY(W.qbucket.alloc(c->item_cap), c->err);
+	if (c->filter_on) HIP_TRY(W.qsurv.alloc(c->item_cap), c->err);
+	if (c->seed2) HIP_TRY(W.qfat.alloc(c->item_cap), c->err);
+	if (c->filter_audit) HIP_TRY(W.audit.alloc(c->item_cap), c->err);
+	if (c->dedupe) HIP_TRY(W.item_rep.alloc(c->item_cap), c->err);
 	HIP_TRY(W.pool.alloc(POOL_CAP), c->err);
 	HIP_TRY(W.counters.alloc(C_COUNT), c->err);
 	HIP_TRY(W.region_counts.alloc(2 * tnt_ctx::MAX_REGIONS), c->err);
 	HIP_TRY(W.q_state.alloc(size_t(tnt_ctx::MAX_REGIONS) * MAX_BUCKETS * 2), c->err);
-	HIP_TRY(hipEventCreateWithFlags(&W.seeded, hipEventDisableTiming), c->err);
-	HIP_TRY(hipEventCreateWithFlags(&W.released, hipEventDisableTiming), c->err);
+	if (!W.seeded) HIP_TRY(hipEventCreateWithFlags(&W.seeded, hipEventDisableTiming), c->err);
+	if (!W.released) HIP_TRY(hipEventCreateWithFlags(&W.released, hipEventDisableTiming), c->err);
 	return TNT_OK;
 }
 
-int ensure_work_buffers(tnt_ctx *c, int need_lmax)
+int ensure_set(tnt_ctx *c, int k) { return c->set[k].items.p ? TNT_OK : alloc_set(c, k); }
+
+// Work buffers sized for what the context is asked to search: `db` (expected raw seeds of the whole database x 8: a batch is
+// planned for every raw seed becoming an item, plan()) and / or `min_items` requests of a unit-level entry.  They grow
+// (never shrink) up to ITEM_CAP_MAX / GROUP_CAP_MAX, beyond which a search runs in several batches: a context that only ever
+// sees small databases -- the front end on a few records, the test-suite -- does not allocate (and clear page tables for) the
+// 40 GB a million targets need.
+int ensure_work_buffers(tnt_ctx *c, int need_lmax, const tnt_db *db = nullptr, size_t min_items = 0)
 {
-	if (!c->set[0].items.p) {
-		const int rc = ensure_set(c, 0);
+	auto pow2 = [](double x) {
+		size_t p = size_t(1) << 24; // 16 M entries at least
+		while (double(p) < x && p < (size_t(1) << 40)) p <<= 1;
+		return p;
+	};
+	double want_i = double(min_items), want_g = 0.0;
+	if (db) {
+		const double words = double(size_t(1) << (2 * c->opt.hash_word_size));
+		want_i = std::max(want_i, 8.0 * double(db->n_bases) * double(c->n_entries) / words);
+		want_g = 2.0 * double(db->n_targets) * double(std::max<size_t>(1, c->h_assays.size()));
+	}
+	const size_t items = std::min(ITEM_CAP_MAX, pow2(want_i)), groups = std::min(GROUP_CAP_MAX, pow2(want_g));
+	if (!c->set[0].items.p || items > c->item_cap || groups > c->group_cap) {
+		HIP_TRY(hipDeviceSynchronize(), c->err); // nothing may still use the buffers that are replaced
+		c->item_cap = std::max(c->item_cap, items);
+		c->group_cap = std::max(c->group_cap, groups);
+		c->h_q_base.clear(); // (the queue regions are shares of the item capacity: planned again)
+		const bool second = c->set[1].items.p != nullptr;
+		int rc = alloc_set(c, 0);
+		if (rc == TNT_OK && second) rc = alloc_set(c, 1);
 		if (rc) return rc;
-		HIP_TRY(c->hits.alloc(c->hit_cap), c->err);
+		if (!c->hits.p) HIP_TRY(c->hits.alloc(c->hit_cap), c->err);
 	}
 	return ensure_scratch(c, need_lmax);
 }
@@ -2038,10 +2064,10 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	s.single_primer_pcr = c->opt.single_primer_pcr;
 	if (!seeds_only) {
 		s.items = c->S().items.p;
-		s.item_cap = uint32_t(ITEM_CAP);
+		s.item_cap = uint32_t(c->item_cap);
 		s.item_count = cnt + C_ITEMS;
 		s.groups = c->S().groups.p;
-		s.group_cap = uint32_t(GROUP_CAP);
+		s.group_cap = uint32_t(c->group_cap);
 		s.group_count = cnt + C_GROUPS;
 		s.qa = c->S().qa.p;
 		s.qa_count = cnt + C_QA;
@@ -2076,8 +2102,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		q.single_primer_pcr = c->opt.single_primer_pcr;
 		q.slot_pack = c->slot_pack.p;
 		q.has_exceptions = db->n_exceptions != 0 ? 1 : 0;
-		q.items = c->S().items.p, q.item_region = uint32_t(ITEM_CAP / regions);
-		q.groups = c->S().groups.p, q.group_region = uint32_t(GROUP_CAP / regions);
+		q.items = c->S().items.p, q.item_region = uint32_t(c->item_cap / regions);
+		q.groups = c->S().groups.p, q.group_region = uint32_t(c->group_cap / regions);
 		q.region_counts = c->S().region_counts.p;
 		q.queue = c->S().qfat.p;
 		q.result = c->S().result.p;
@@ -2142,8 +2168,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		memset(&pa, 0, sizeof(pa));
 		pa.src = c->S().qa.p;
 		pa.shard_counts = cnt + C_QA;
-		pa.shard_region = uint32_t(ITEM_CAP / N_SHARD);
-		pa.cap = uint32_t(ITEM_CAP);
+		pa.shard_region = uint32_t(c->item_cap / N_SHARD);
+		pa.cap = uint32_t(c->item_cap);
 		pa.items = c->S().items.p;
 		pa.item_rep = c->S().item_rep.p;
 		pa.result = c->S().result.p;
@@ -2291,7 +2317,7 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 		c->planned_chunks = chunk_begin;
 	}
 	c->chunk_begin = chunk_begin;
-	// batch of targets: expected kept seeds (<= raw) must stay below ITEM_CAP / 2
+	// batch of targets: expected kept seeds (<= raw) must stay below c->item_cap / 2
 	// (units = targets, or overlapping windows of long targets: count their positions, not the bases)
 	const size_t n_units = std::max<size_t>(1, db->h_unit_target.size());
 	double unit_positions = 0.0;
@@ -2304,8 +2330,8 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	const double per_target = std::max(1.0, per_base * avg_len);
 	// (per_target counts raw seeds; the first cull keeps a small part of them for PCR assays, all of them for probes:
 	// a batch is sized for every raw seed becoming an item, an overflow of a shard region is repaired by halving it)
-	double tb = (double(ITEM_CAP) * 0.75) / per_target;
-	const double gb = (double(GROUP_CAP) / 2.0) / std::max<double>(1.0, double(n_assays));
+	double tb = (double(c->item_cap) * 0.75) / per_target;
+	const double gb = (double(c->group_cap) / 2.0) / std::max<double>(1.0, double(n_assays));
 	tb = std::min(tb, gb);
 	targets_per_batch = size_t(std::max(1.0, std::min(tb, double(n_units)))); // in work units
 	// Regions of the phase-A queues (round-3 seed kernel): the buffer is shared out by the expected number of seeds of the
@@ -2332,10 +2358,10 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 		// every wavefront may hold one open block per bucket on top of the bucket's share
 		size_t nb_used = 0;
 		for (size_t b = 0; b < nb; b++) nb_used += weight[b] > 0.0 ? 1 : 0;
-		const uint64_t floor_slots = std::min<uint64_t>(uint64_t(tnt_ctx::MAX_REGIONS) * QUEUE_BLOCK, (uint64_t(ITEM_CAP) / (2 * std::max<size_t>(1, nb_used))) & ~uint64_t(QUEUE_BLOCK - 1));
+		const uint64_t floor_slots = std::min<uint64_t>(uint64_t(tnt_ctx::MAX_REGIONS) * QUEUE_BLOCK, (uint64_t(c->item_cap) / (2 * std::max<size_t>(1, nb_used))) & ~uint64_t(QUEUE_BLOCK - 1));
 		uint64_t used = 0;
 		for (size_t b = 0; b < nb; b++) used += weight[b] > 0.0 ? floor_slots : 0;
-		const double spare = double(ITEM_CAP) - double(used);
+		const double spare = double(c->item_cap) - double(used);
 		c->h_q_base.assign(nb, 0);
 		c->h_q_cap.assign(nb, 0);
 		uint64_t at = 0;
@@ -2712,7 +2738,7 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	if (ctx) ctx->dev_hits_valid = false;
 	if (!ctx || !db || db->ctx != ctx) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, ctx->lmax);
+	int rc = ensure_work_buffers(ctx, ctx->lmax, db);
 	if (rc) return rc;
 	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
 	ctx->events.clear();
@@ -2981,7 +3007,7 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
 {
 	if (!ctx || !db || db->ctx != ctx || !seeds || !n_seeds) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, ctx->lmax);
+	int rc = ensure_work_buffers(ctx, ctx->lmax, db);
 	if (rc) return rc;
 	size_t tpb = 1;
 	rc = plan(ctx, db, tpb);
@@ -3052,7 +3078,7 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 		return TNT_E_UNSUPPORTED;
 	}
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, ctx->lmax);
+	int rc = ensure_work_buffers(ctx, ctx->lmax, db);
 	if (rc) return rc;
 	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
 	ctx->events.clear();
@@ -3064,7 +3090,7 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 	ctx->h_cull_rows.clear();
 	std::vector<Item> items;
 	std::vector<Group> groups;
-	const size_t n_units = db->n_short_units, item_region = ITEM_CAP / N_SHARD, group_region = GROUP_CAP / N_SHARD;
+	const size_t n_units = db->n_short_units, item_region = ctx->item_cap / N_SHARD, group_region = ctx->group_cap / N_SHARD;
 	for (size_t u0 = 0; u0 < n_units; u0 += tpb) {
 		// a whole batch of the search (the stages behind the seed kernel run too; their results are not looked at)
 		rc = enqueue_batch(ctx, db, u0, std::min(n_units, u0 + tpb), false);
@@ -3083,7 +3109,7 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 		size_t ir = item_region, gr = group_region;
 		if (ctx->seed2) {
 			n_regions = ctx->batch_regions;
-			ir = ITEM_CAP / n_regions, gr = GROUP_CAP / n_regions;
+			ir = ctx->item_cap / n_regions, gr = ctx->group_cap / n_regions;
 			rc.resize(2 * size_t(n_regions));
 			HIP_TRY(hipMemcpy(rc.data(), ctx->S().region_counts.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
 		}
@@ -3125,9 +3151,9 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		return TNT_E_ARG;
 	}
 	if (n == 0) return TNT_OK;
-	if (n > ITEM_CAP || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
+	if (n > ITEM_CAP_MAX || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, ctx->unit_rows); // the unit-level kernel instance is bind_kernel<64 or 128, true>
+	int rc = ensure_work_buffers(ctx, ctx->unit_rows, nullptr, n); // the unit-level kernel instance is bind_kernel<64 or 128, true>
 	if (rc) return rc;
 	auto bucket_of = [&](int id) -> int32_t { // position of an instance in the context's bucket list (it holds the instances of every oligo)
 		for (size_t i = 0; i < ctx->bucket_lmax.size(); i++)
@@ -3247,9 +3273,9 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 		return TNT_E_ARG;
 	}
 	if (n == 0) return TNT_OK;
-	if (n > ITEM_CAP || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
+	if (n > ITEM_CAP_MAX || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, 64);
+	int rc = ensure_work_buffers(ctx, 64, nullptr, n);
 	if (rc) return rc;
 	if (!db->host_copy) {
 		ctx->err = "tnt_filter_bound needs a database packed from codes (tnt_db_create)";
