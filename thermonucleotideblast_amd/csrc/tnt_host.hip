@@ -2594,8 +2594,8 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	job.overflow = false;
 	job.groups = nullptr;
 	// (the lists of one target are few and long -- 96 lists of 19 000 seeds for a 5-Mb target against config 2 -- so the
-	// workers are as many as the host has cores to spare, up to 64)
-	const unsigned workers = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+	// workers are as many as the host has cores, up to 128: one round of lists instead of two)
+	const unsigned workers = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
 	job.next = 0;
 	if (!run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job)) {
 		ctx->err = "could not start a host thread for the lists of long targets";
