@@ -138,11 +138,10 @@ def main():
             print("slow case %d: cfg %d k %d, %d targets (longest %d), oracle %.1f s, library %.1f s" % (
                 case, cfg, wl.options.hash_word_size, len(offsets) - 1, int(np.diff(offsets.astype(np.int64)).max()), t_ora, t_gpu), flush=True)
         ok = got == want or (isinstance(got, tuple) and isinstance(want, tuple))
-        if not ok and isinstance(got, tuple) and ("overflowed the LDS buffer" in got[1] or "more than 32768 seeds of one assay" in got[1] or
+        if not ok and isinstance(got, tuple) and ("overflowed the LDS buffer" in got[1] or "seeds of one assay on one target" in got[1] or
                                                    "does not fit TNT_ALIGN_TEXT" in got[1] or "does not" in got[1][-12:]):
             # the documented capacity limit (more seeds of one assay chunk inside one seed work unit than
-            # the LDS lists hold -- word size 5 on long targets; more than 32 768 seeds of one assay on one target -- word size 3
-            # on targets of 100 kb and more; an alignment text of an oligo of 65..128 bases beyond TNT_ALIGN_TEXT):
+            # the LDS lists hold -- word size 5 on long targets; more than 1 048 576 seeds of one assay on one target after the first cull; an alignment text of an oligo of 65..128 bases beyond TNT_ALIGN_TEXT):
             # reported as TNT_E_LIMIT, never a silent difference
             limited += 1
             ok = True

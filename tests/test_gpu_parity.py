@@ -658,6 +658,53 @@ def test_genome_sized_target(Engine, oracle):
     e.close()
 
 
+@pytest.mark.parametrize("cfg,kw", [(2, {}), (3, {}), (2, {"single_primer_pcr": 1}), (5, {})])
+def test_long_target_first_cull_on_the_device_equals_the_host_replay(Engine, cfg, kw, monkeypatch):
+    """The first cull of the lists of windowed targets runs on the device (nearest-element scans, tnt_sort.hip);
+    TNT_MI355X_LONG_HOST_CULL=1 replays cull_oligo_match list by list on host threads instead: same hits, same order."""
+    wl = synth.make_workload(cfg, n_targets=600, n_assays=16, seed=57)
+    for k, v in kw.items():
+        setattr(wl.options, k, v)
+    lens = np.diff(wl.offsets.astype(np.int64))
+    cut = len(lens) - 3  # the first `cut` targets become one long record, three short ones stay
+    offsets = np.array([0, int(lens[:cut].sum())] + [int(lens[:cut + i + 1].sum()) for i in range(3)], dtype=np.uint64)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    got = [tc.hit_key(h) for h in e.search(db)]
+    monkeypatch.setenv("TNT_MI355X_LONG_HOST_CULL", "1")
+    host = [tc.hit_key(h) for h in e.search(db)]
+    monkeypatch.delenv("TNT_MI355X_LONG_HOST_CULL")
+    assert len(got) > 5
+    assert got == host
+    db.close()
+    e.close()
+
+
+def test_lists_of_a_chromosome_sized_target(Engine, monkeypatch):
+    """A 30-Mb record: ~110 000 seeds per (target, assay) list before the first cull, ~20 000 behind it (round 2 refused
+    lists of more than 32 768 seeds).  The device cull and the host replay of cull_oligo_match give the same hits."""
+    wl = synth.make_workload(2, n_targets=30000, n_assays=8, seed=61)
+    offsets = np.array([0, int(wl.offsets[-1])], dtype=np.uint64)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    got = [tc.hit_key(h) for h in e.search(db)]
+    monkeypatch.setenv("TNT_MI355X_LONG_HOST_CULL", "1")
+    host = [tc.hit_key(h) for h in e.search(db)]
+    monkeypatch.delenv("TNT_MI355X_LONG_HOST_CULL")
+    assert len(got) > 50
+    assert got == host
+    # the amplicons of the 30 000 pieces searched one by one are there too (but for the few whose primer windows the piece ends cut)
+    db2 = e.pack(wl.codes, wl.offsets)
+    pieces = e.search(db2)
+    starts = wl.offsets.astype(np.int64)
+    moved = set((h.assay_id, h.degen_id, int(starts[h.seq_index]) + h.amplicon_start, int(starts[h.seq_index]) + h.amplicon_stop) for h in pieces)
+    whole = set((h.assay_id, h.degen_id, h.amplicon_start, h.amplicon_stop) for h in e.search(db))
+    assert len(moved) > 20 and len(moved & whole) >= 0.95 * len(moved)
+    db.close()
+    db2.close()
+    e.close()
+
+
 def test_randomised_options_and_shapes(Engine, checkers):
     """A slice of scripts/fuzz_parity.py: random option sets (thresholds, clamps, salt, Ct, temperature, word size 5-8,
     strands, dangles, assay formats) x target shapes (ragged, long, IUPAC-laden, repetitive) against the oracle."""

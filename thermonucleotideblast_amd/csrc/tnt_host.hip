@@ -34,12 +34,18 @@
 #include "tnt_ingest.hip.h"
 #include <zlib.h>
 #include <pthread.h>
+#include <unistd.h>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include "santalucia_tables.inc"
 
 using namespace tnt;
 
 namespace tnt { // tnt_sort.hip
+hipError_t long_first_cull(const Item *items, const uint32_t *bucket, uint32_t n, const AssayDev *assays, uint32_t n_assays, int max_len, int single_primer,
+                           Item *kept, uint32_t *n_kept, Group **groups, uint32_t *n_groups, hipStream_t stream);
 hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *target_rank, const AssayDev *assays, uint32_t n_assays,
                            uint32_t n_buckets, Item *items, uint32_t *bucket, hipStream_t stream);
 }
@@ -459,6 +465,19 @@ template <class T> struct PinnedBuf {
 		if (e == hipSuccess) cap = want;
 		return e;
 	}
+	// the same, keeping the first `used` elements when the buffer is replaced
+	hipError_t ensure_keep(size_t n, size_t used)
+	{
+		if (n <= cap) return hipSuccess;
+		T *q = nullptr;
+		const size_t want = n + n / 2 + 1024;
+		const hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&q), want * sizeof(T), hipHostMallocDefault);
+		if (e != hipSuccess) return e;
+		if (p && used) memcpy(q, p, used * sizeof(T));
+		if (p) (void)hipHostFree(p);
+		p = q, cap = want;
+		return hipSuccess;
+	}
 	~PinnedBuf()
 	{
 		if (p) (void)hipHostFree(p);
@@ -507,9 +526,10 @@ struct tnt_ctx {
 	hipStream_t stream = nullptr;
 	// The length buckets of a phase are independent launches: they run on BIND_LANES side streams (each with its
 	// own scratch slabs) so that the drain of one launch overlaps the ramp-up of the next.
-	static constexpr int BIND_LANES = 4;
-	hipStream_t lane_stream[BIND_LANES] = {nullptr, nullptr, nullptr, nullptr};
-	hipEvent_t lane_done[BIND_LANES] = {nullptr, nullptr, nullptr, nullptr};
+	static constexpr int BIND_LANES = 8; // at most; `lanes` of them are used (TNT_MI355X_BIND_LANES, default 4)
+	int lanes = 4;
+	hipStream_t lane_stream[BIND_LANES] = {};
+	hipEvent_t lane_done[BIND_LANES] = {};
 	hipEvent_t phase_ready = nullptr;
 	size_t lane_trace = 0, lane_cols = 0, lane_ties = 0; // scratch elements per lane
 
@@ -605,6 +625,7 @@ struct tnt_ctx {
 	PinnedBuf<Item> pin_items, pin_bind; // long-target path: the sorted seeds, the work items of the kept ones
 	PinnedBuf<uint32_t> pin_list;
 	PinnedBuf<int32_t> pin_result;
+	PinnedBuf<BoundRec> pin_pool;        // the bound oligos of all bind passes of a long-target search
 	size_t h_hits_cap = 0;
 	std::vector<tnt_seed> h_seeds;
 	std::vector<int32_t> h_cull_rows; // tnt_first_cull
@@ -834,7 +855,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	}
 	(void)hipEventRecord(c->phase_ready, c->stream);
-	for (int l = 0; l < tnt_ctx::BIND_LANES; l++) (void)hipStreamWaitEvent(c->lane_stream[l], c->phase_ready, 0);
+	for (int l = 0; l < c->lanes; l++) (void)hipStreamWaitEvent(c->lane_stream[l], c->phase_ready, 0);
 	int n_launch = 0;
 	// longest buckets first: they take the longest per item, the short ones fill the gaps
 	for (size_t k = c->bucket_lmax.size(); k-- > 0;) {
@@ -842,7 +863,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		// general instances other than the last (merge) bucket only see windows with degenerate bases
 		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) continue;
 		if (direct && c->h_q_cap[i] == 0) continue; // no slot routes its items here
-		const int lane = c->serial_bind ? 0 : n_launch++ % tnt_ctx::BIND_LANES;
+		const int lane = c->serial_bind ? 0 : n_launch++ % c->lanes;
 		if (c->serial_bind) n_launch = 1;
 		// (direct: the queue holds 16-byte entries whose first word is the item index)
 		const uint32_t *queue = direct ? reinterpret_cast<const uint32_t *>(c->S().qfat.p + c->h_q_base[i]) : c->S().qbucket.p;
@@ -890,7 +911,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.ties = c->ties.p + size_t(lane) * c->lane_ties;
 		launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
 	}
-	for (int l = 0; l < tnt_ctx::BIND_LANES && l < n_launch; l++) {
+	for (int l = 0; l < c->lanes && l < n_launch; l++) {
 		(void)hipEventRecord(c->lane_done[l], c->lane_stream[l]);
 		(void)hipStreamWaitEvent(c->stream, c->lane_done[l], 0);
 	}
@@ -917,10 +938,10 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 		n_ties = std::max(n_ties, lanes * TIE_CAP);
 	}
 	c->lane_trace = n_trace, c->lane_cols = n_cols, c->lane_ties = n_ties;
-	HIP_TRY(c->trace.alloc(n_trace * tnt_ctx::BIND_LANES), c->err);
-	HIP_TRY(c->best.alloc(n_cols * tnt_ctx::BIND_LANES), c->err);
-	HIP_TRY(c->stack.alloc(n_cols * tnt_ctx::BIND_LANES), c->err);
-	HIP_TRY(c->ties.alloc(n_ties * tnt_ctx::BIND_LANES), c->err);
+	HIP_TRY(c->trace.alloc(n_trace * c->lanes), c->err);
+	HIP_TRY(c->best.alloc(n_cols * c->lanes), c->err);
+	HIP_TRY(c->stack.alloc(n_cols * c->lanes), c->err);
+	HIP_TRY(c->ties.alloc(n_ties * c->lanes), c->err);
 	return TNT_OK;
 }
 
@@ -1091,7 +1112,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	if (hipStreamCreate(&c->stream) != hipSuccess) FAIL(TNT_E_DEVICE, "hipStreamCreate failed");
 	if (const char *e = getenv("TNT_MI355X_HIT_CAP")) // initial capacity of the hit buffer (it grows on demand)
 		c->hit_cap = std::max<size_t>(16, strtoull(e, nullptr, 10));
-	for (int i = 0; i < tnt_ctx::BIND_LANES; i++)
+	if (const char *e = getenv("TNT_MI355X_BIND_LANES")) c->lanes = std::max(1, std::min(int(tnt_ctx::BIND_LANES), atoi(e)));
+	for (int i = 0; i < c->lanes; i++)
 		if (hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->lane_done[i], hipEventDisableTiming) != hipSuccess)
 			FAIL(TNT_E_DEVICE, "hipStreamCreate failed");
@@ -2390,80 +2412,104 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 // keeps, through the same bucket -> pre-filter -> bind kernels as everything else) on the device; its seed lists are
 // merged per (target, assay) on the host, where the first cull, the bind / cull sequence and the pairing loops run on the
 // complete lists with the code the pair kernel runs (tnt_pair.hip.h is compiled for both sides).
-// `n` workers with stacks of `bytes` (the host lists are large): fn gets its argument n times, the workers share a work
-// counter inside it
-static bool run_threads_with_stack(unsigned n, size_t bytes, void *(*fn)(void *), void *arg)
+// The host workers of this path: a process-wide pool of threads with 512-MB stacks (pair_group<PAIR_HOST> keeps its lists
+// on the stack), started at the first long-target search and parked on a condition variable between runs -- starting 64
+// or 128 threads with such stacks costs 2-3 ms every time, as much as the culls and the pairing they are started for.
+// run(n, f): f(0) .. f(n - 1), the workers take the indices one at a time; one run at a time (searches of several
+// contexts take turns).
+class HostPool
 {
-	pthread_attr_t attr;
-	pthread_attr_init(&attr);
-	pthread_attr_setstacksize(&attr, bytes);
+	std::mutex run_mu, mu;
+	std::condition_variable cv_work, cv_done;
 	std::vector<pthread_t> th;
-	for (unsigned w = 0; w < n; w++) {
-		pthread_t t;
-		if (pthread_create(&t, &attr, fn, arg) == 0) th.push_back(t);
+	const std::function<void(size_t)> *fn = nullptr;
+	size_t n = 0;
+	std::atomic<size_t> next{0};
+	unsigned busy = 0;
+	uint64_t generation = 0;
+	bool stop = false;
+	pid_t owner = 0;
+
+	static void *worker_main(void *p)
+	{
+		static_cast<HostPool *>(p)->worker();
+		return nullptr;
 	}
-	for (pthread_t t : th) pthread_join(t, nullptr);
-	pthread_attr_destroy(&attr);
-	return !th.empty(); // no worker at all: the caller fails (fn needs the large stack, it must not run on the caller's)
-}
-
-struct LongJob {
-	PairArgs args;
-	const std::vector<Group> *groups;
-	// first cull
-	std::vector<ListT<PAIR_HOST> *> lists; // one scratch list
-	int mode; // 0: first culls, 1: pairing
-	// first-cull input / output
-	const Item *all_items;
-	const std::vector<uint32_t> *seg_begin; // [n_groups + 1] segments of all_items (sorted in list order)
-	const std::vector<uint32_t> *seg_assay;
-	const tnt_ctx *ctx;
-	std::vector<uint8_t> *valid;            // per item of all_items
-	std::vector<uint8_t> *minus_first;      // per segment
-	std::atomic<bool> overflow{false};
-	std::atomic<size_t> next{0};            // the workers take the lists / groups one at a time
-};
-
-static void *long_job_main(void *p)
-{
-	LongJob &J = *static_cast<LongJob *>(p);
-	if (J.mode == 0) {
-		ListT<PAIR_HOST> *l = new ListT<PAIR_HOST>;
-		const Item *items = J.all_items;
-		const size_t n_seg = J.seg_begin->size() - 1;
-		for (size_t g = J.next.fetch_add(1); g < n_seg; g = J.next.fetch_add(1)) {
-			const uint32_t b = (*J.seg_begin)[g], e = (*J.seg_begin)[g + 1];
-			const AssayDev &A = J.ctx->h_assays[(*J.seg_assay)[g]];
-			if (e - b > uint32_t(PAIR_HOST)) {
-				J.overflow = true;
-				continue;
-			}
-			if (A.kind != 0) { // probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454)
-				for (uint32_t i = b; i < e; i++) (*J.valid)[i] = 1;
-				continue;
-			}
-			// amplicon(): the assembled match list (already in the order the cull's stable sort by target_loc leaves it in)
-			l->n = int(e - b);
-			for (uint32_t i = b; i < e; i++) {
-				Entry &en = l->e[i - b];
-				const uint32_t role = (items[i].info >> ITEM_SLOT_SHIFT) % 3u;
-				en.loc5 = en.loc3 = 0;
-				en.tloc = items[i].tloc;
-				en.rec = int32_t(i); // remember which item this is
-				en.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((items[i].info & ITEM_MINUS) ? MMINUS : MPLUS));
-			}
-			int cm = 0, cp = 0;
-			cull(*l, J.ctx->opt.max_len, A.has_probe != 0, J.ctx->opt.single_primer_pcr != 0, cm, cp); // amplicon_search.cpp:128
-			for (int i = 0; i < l->n; i++) (*J.valid)[size_t(l->e[i].rec)] = 1;
-			(*J.minus_first)[g] = cm < cp ? 1 : 0; // :131
+	void worker()
+	{
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			cv_work.wait(lk, [&] { return stop || generation != seen; });
+			if (stop) return;
+			seen = generation;
+			lk.unlock();
+			for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) (*fn)(i);
+			lk.lock();
+			if (--busy == 0) cv_done.notify_all();
 		}
-		delete l;
-	} else {
-		const size_t n_grp = J.groups->size();
-		for (size_t g = J.next.fetch_add(1); g < n_grp; g = J.next.fetch_add(1)) pair_group<PAIR_HOST>(J.args, (*J.groups)[g]);
 	}
-	return nullptr;
-}
+
+public:
+	static HostPool &get()
+	{
+		static HostPool pool;
+		return pool;
+	}
+	~HostPool()
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			stop = true;
+		}
+		cv_work.notify_all();
+		if (owner == getpid())
+			for (pthread_t t : th) pthread_join(t, nullptr);
+	}
+	unsigned size()
+	{
+		std::lock_guard<std::mutex> g(run_mu);
+		start();
+		return unsigned(th.size());
+	}
+	// false: no worker thread could be started (f needs the large stack, it must not run on the caller's)
+	bool run(size_t count, const std::function<void(size_t)> &f)
+	{
+		std::lock_guard<std::mutex> g(run_mu);
+		start();
+		if (th.empty()) return false;
+		if (count == 0) return true;
+		std::unique_lock<std::mutex> lk(mu);
+		fn = &f;
+		n = count;
+		next = 0;
+		busy = unsigned(th.size());
+		generation++;
+		cv_work.notify_all();
+		cv_done.wait(lk, [&] { return busy == 0; });
+		fn = nullptr;
+		return true;
+	}
+
+private:
+	void start() // (under run_mu)
+	{
+		if (!th.empty() && owner != getpid()) th.clear(); // a forked child has none of its parent's threads
+		if (!th.empty()) return;
+		owner = getpid();
+		// the lists of one target are few and long (96 lists of 19 000 seeds for a 5-Mb target against config 2): as many
+		// workers as the host has cores, up to 128
+		const unsigned want = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+		pthread_attr_t attr;
+		pthread_attr_init(&attr);
+		pthread_attr_setstacksize(&attr, size_t(512) << 20); // address space, not memory: pages are touched as far as a list reaches
+		for (unsigned w = 0; w < want; w++) {
+			pthread_t t;
+			if (pthread_create(&t, &attr, worker_main, this) == 0) th.push_back(t);
+		}
+		pthread_attr_destroy(&attr);
+	}
+};
 
 static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &out)
 {
@@ -2554,89 +2600,148 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		ctx->err = "too many (target, assay) lists on the long targets of this batch";
 		return TNT_E_LIMIT;
 	}
-	HIP_TRY(ctx->pin_items.ensure(n_raw), ctx->err);
-	HIP_TRY(ctx->pin_list.ensure(n_raw), ctx->err);
-	Item *const sorted = ctx->pin_items.p;
-	uint32_t *const list_of = ctx->pin_list.p;
+	// The lists are assembled AND culled on the device (tnt_sort.hip): only the seeds the first cull keeps, and one group
+	// record per list, come back.  TNT_MI355X_LONG_HOST_CULL=1 keeps round 2's route (every seed to the host, cull_oligo_match
+	// replayed per list on the worker threads) as the cross-check of the device cull.
+	const bool host_cull = getenv("TNT_MI355X_LONG_HOST_CULL") != nullptr;
+	HostPool &workers = HostPool::get();
+	DevBuf<uint32_t> d_rank, d_list;
+	DevBuf<Item> d_items, d_kept;
 	{
 		std::vector<uint32_t> rank(db->n_targets, 0);
 		for (size_t r = 0; r < long_targets.size(); r++) rank[long_targets[r]] = uint32_t(r);
-		DevBuf<uint32_t> d_rank, d_list;
-		DevBuf<Item> d_items;
 		HIP_TRY(d_rank.upload(rank), ctx->err);
 		HIP_TRY(d_list.alloc(n_raw), ctx->err);
 		HIP_TRY(d_items.alloc(n_raw), ctx->err);
 		HIP_TRY(long_sort_seeds(ctx->seeds_out.p, uint32_t(n_raw), d_rank.p, ctx->assays.p, uint32_t(n_assays_all), uint32_t(n_buckets), d_items.p, d_list.p, ctx->stream), ctx->err);
-		HIP_TRY(hipMemcpy(sorted, d_items.p, n_raw * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
-		HIP_TRY(hipMemcpy(list_of, d_list.p, n_raw * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
 		ctx->seeds_out.release();
 	}
-	std::vector<uint32_t> seg_begin, seg_assay;
-	for (size_t i = 0; i < n_raw; i++)
-		if (i == 0 || list_of[i] != list_of[i - 1]) {
-			seg_begin.push_back(uint32_t(i));
-			seg_assay.push_back(uint32_t(list_of[i] % n_assays_all));
-		}
-	seg_begin.push_back(uint32_t(n_raw));
 	lap("keys + sort");
 
-	// ---- first cull of every list (amplicon_search.cpp:128-131) on the host
-	std::vector<uint8_t> valid(n_raw, 0), minus_first(seg_assay.size(), 0);
-	LongJob job;
-	memset(&job.args, 0, sizeof(job.args));
-	job.mode = 0;
-	job.all_items = sorted;
-	job.seg_begin = &seg_begin;
-	job.seg_assay = &seg_assay;
-	job.ctx = ctx;
-	job.valid = &valid;
-	job.minus_first = &minus_first;
-	job.overflow = false;
-	job.groups = nullptr;
-	// (the lists of one target are few and long -- 96 lists of 19 000 seeds for a 5-Mb target against config 2 -- so the
-	// workers are as many as the host has cores, up to 128: one round of lists instead of two)
-	const unsigned workers = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
-	job.next = 0;
-	if (!run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job)) {
-		ctx->err = "could not start a host thread for the lists of long targets";
-		return TNT_E_DEVICE;
-	}
-	if (job.overflow) {
-		ctx->err = "more than 32768 seeds of one assay on one target";
-		return TNT_E_LIMIT;
-	}
-
-	lap("first cull");
-	// ---- the kept seeds become bind work items, grouped per (target, assay)
-	Item *bind_items = nullptr;
+	Item *bind_items = nullptr; // the kept seeds, list after list (pinned host copy: the pairing reads it)
 	size_t n_bind = 0;
 	std::vector<Group> groups;
 	std::vector<uint32_t> unit_target;
 	std::vector<int32_t> own_lo, own_hi;
-	{
-		// (two passes over the lists on the worker threads: count, then copy to the counted places)
-		const size_t n_seg = seg_assay.size();
-		std::vector<uint32_t> first_of(n_seg + 1, 0);
-		parallel_for_each(n_seg, [&](size_t g) {
-			uint32_t c = 0;
-			for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++) c += valid[i] ? 1u : 0u;
-			first_of[g + 1] = c;
+	if (!host_cull) {
+		// ---- first cull of every list (amplicon_search.cpp:128-131) on the device
+		HIP_TRY(d_kept.alloc(n_raw), ctx->err);
+		Group *d_groups = nullptr;
+		uint32_t n_kept = 0, n_groups = 0;
+		const hipError_t ce = long_first_cull(d_items.p, d_list.p, uint32_t(n_raw), ctx->assays.p, uint32_t(n_assays_all), ctx->opt.max_len, ctx->opt.single_primer_pcr,
+		                                      d_kept.p, &n_kept, &d_groups, &n_groups, ctx->stream);
+		std::vector<Group> all(n_groups);
+		hipError_t ge = ce;
+		if (ge == hipSuccess && n_groups) ge = hipMemcpy(all.data(), d_groups, size_t(n_groups) * sizeof(Group), hipMemcpyDeviceToHost);
+		if (d_groups) (void)hipFree(d_groups);
+		HIP_TRY(ge, ctx->err);
+		d_items.release();
+		d_list.release();
+		n_bind = n_kept;
+		for (const Group &g : all) {
+			if (g.count == 0) continue;
+			if (g.count > uint32_t(PAIR_HOST)) {
+				ctx->err = "more than 1048576 seeds of one assay on one target after the first cull";
+				return TNT_E_LIMIT;
+			}
+			groups.push_back(g);
+		}
+		// (Group::target = rank of the target among the windowed ones)
+		unit_target = long_targets;
+		own_lo.assign(unit_target.size(), INT32_MIN);
+		own_hi.assign(unit_target.size(), INT32_MAX);
+		lap("first cull (device)");
+		if (n_bind) {
+			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
+			bind_items = ctx->pin_bind.p;
+			HIP_TRY(hipMemcpyAsync(bind_items, d_kept.p, n_bind * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err); // (done by the first sync of the bind loop)
+		}
+	} else {
+		HIP_TRY(ctx->pin_items.ensure(n_raw), ctx->err);
+		HIP_TRY(ctx->pin_list.ensure(n_raw), ctx->err);
+		Item *const sorted = ctx->pin_items.p;
+		uint32_t *const list_of = ctx->pin_list.p;
+		HIP_TRY(hipMemcpy(sorted, d_items.p, n_raw * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
+		HIP_TRY(hipMemcpy(list_of, d_list.p, n_raw * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
+		d_items.release();
+		d_list.release();
+		std::vector<uint32_t> seg_begin, seg_assay;
+		for (size_t i = 0; i < n_raw; i++)
+			if (i == 0 || list_of[i] != list_of[i - 1]) {
+				seg_begin.push_back(uint32_t(i));
+				seg_assay.push_back(uint32_t(list_of[i] % n_assays_all));
+			}
+		seg_begin.push_back(uint32_t(n_raw));
+		lap("lists to the host");
+
+		// ---- first cull of every list (amplicon_search.cpp:128-131) on the host
+		std::vector<uint8_t> valid(n_raw, 0), minus_first(seg_assay.size(), 0);
+		std::atomic<bool> overflow(false);
+		const bool started = workers.run(seg_assay.size(), [&](size_t g) {
+			const uint32_t b = seg_begin[g], e = seg_begin[g + 1];
+			const AssayDev &A = ctx->h_assays[seg_assay[g]];
+			if (e - b > uint32_t(PAIR_HOST)) {
+				overflow = true;
+				return;
+			}
+			if (A.kind != 0) { // probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454)
+				for (uint32_t i = b; i < e; i++) valid[i] = 1;
+				return;
+			}
+			// amplicon(): the assembled match list (already in the order the cull's stable sort by target_loc leaves it in)
+			static thread_local std::unique_ptr<ListT<PAIR_HOST>> scratch;
+			if (!scratch) scratch.reset(new ListT<PAIR_HOST>);
+			ListT<PAIR_HOST> &l = *scratch;
+			l.n = int(e - b);
+			for (uint32_t i = b; i < e; i++) {
+				Entry &en = l.e[i - b];
+				const uint32_t role = (sorted[i].info >> ITEM_SLOT_SHIFT) % 3u;
+				en.loc5 = en.loc3 = 0;
+				en.tloc = sorted[i].tloc;
+				en.rec = int32_t(i); // remember which item this is
+				en.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((sorted[i].info & ITEM_MINUS) ? MMINUS : MPLUS));
+			}
+			int cm = 0, cp = 0;
+			cull(l, ctx->opt.max_len, A.has_probe != 0, ctx->opt.single_primer_pcr != 0, cm, cp); // amplicon_search.cpp:128
+			for (int i = 0; i < l.n; i++) valid[size_t(l.e[i].rec)] = 1;
+			minus_first[g] = cm < cp ? 1 : 0; // :131
 		});
-		for (size_t g = 0; g < n_seg; g++) first_of[g + 1] += first_of[g];
-		n_bind = first_of[n_seg];
-		HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
-		bind_items = ctx->pin_bind.p;
-		parallel_for_each(n_seg, [&](size_t g) {
-			uint32_t o = first_of[g];
-			for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++)
-				if (valid[i]) bind_items[o++] = sorted[i];
-		});
-		for (size_t g = 0; g < n_seg; g++) {
-			const uint32_t count = first_of[g + 1] - first_of[g];
-			if (!count) continue;
-			const uint32_t t = sorted[seg_begin[g]].target;
-			if (unit_target.empty() || unit_target.back() != t) unit_target.push_back(t), own_lo.push_back(INT32_MIN), own_hi.push_back(INT32_MAX);
-			groups.push_back(Group{uint32_t(unit_target.size() - 1), seg_assay[g] | (minus_first[g] ? GROUP_MINUS_FIRST : 0u), first_of[g], count});
+		if (!started) {
+			ctx->err = "could not start a host thread for the lists of long targets";
+			return TNT_E_DEVICE;
+		}
+		if (overflow) {
+			ctx->err = "more than 1048576 seeds of one assay on one target";
+			return TNT_E_LIMIT;
+		}
+
+		lap("first cull (host)");
+		// ---- the kept seeds become bind work items, grouped per (target, assay)
+		{
+			// (two passes over the lists on the worker threads: count, then copy to the counted places)
+			const size_t n_seg = seg_assay.size();
+			std::vector<uint32_t> first_of(n_seg + 1, 0);
+			workers.run(n_seg, [&](size_t g) {
+				uint32_t c = 0;
+				for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++) c += valid[i] ? 1u : 0u;
+				first_of[g + 1] = c;
+			});
+			for (size_t g = 0; g < n_seg; g++) first_of[g + 1] += first_of[g];
+			n_bind = first_of[n_seg];
+			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
+			bind_items = ctx->pin_bind.p;
+			workers.run(n_seg, [&](size_t g) {
+				uint32_t o = first_of[g];
+				for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++)
+					if (valid[i]) bind_items[o++] = sorted[i];
+			});
+			for (size_t g = 0; g < n_seg; g++) {
+				const uint32_t count = first_of[g + 1] - first_of[g];
+				if (!count) continue;
+				const uint32_t t = sorted[seg_begin[g]].target;
+				if (unit_target.empty() || unit_target.back() != t) unit_target.push_back(t), own_lo.push_back(INT32_MIN), own_hi.push_back(INT32_MAX);
+				groups.push_back(Group{uint32_t(unit_target.size() - 1), seg_assay[g] | (minus_first[g] ? GROUP_MINUS_FIRST : 0u), first_of[g], count});
+			}
 		}
 	}
 	if (n_bind == 0) return TNT_OK;
@@ -2646,46 +2751,60 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	const DbView v = make_view(db, 0, db->n_targets);
 	HIP_TRY(ctx->pin_result.ensure(n_bind), ctx->err);
 	int32_t *const result = ctx->pin_result.p;
-	std::vector<BoundRec> pool;
-	const size_t CHUNK = size_t(1) << 20;
-	for (size_t c0 = 0; c0 < n_bind; c0 += CHUNK) {
-		const size_t nc = std::min(CHUNK, n_bind - c0);
+	// (up to 16 M items per pass; a pass that binds more records than the device pool holds is repeated with half as many)
+	size_t n_pool = 0;
+	size_t chunk = std::min(ctx->item_cap, size_t(1) << 24);
+	for (size_t c0 = 0; c0 < n_bind;) {
+		const size_t nc = std::min(chunk, n_bind - c0);
 		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
-		HIP_TRY(hipMemcpyAsync(ctx->S().items.p, bind_items + c0, nc * sizeof(Item), hipMemcpyHostToDevice, ctx->stream), ctx->err);
+		if (host_cull) HIP_TRY(hipMemcpyAsync(ctx->S().items.p, bind_items + c0, nc * sizeof(Item), hipMemcpyHostToDevice, ctx->stream), ctx->err);
+		else HIP_TRY(hipMemcpyAsync(ctx->S().items.p, d_kept.p + c0, nc * sizeof(Item), hipMemcpyDeviceToDevice, ctx->stream), ctx->err);
 		hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->S().qb.p, uint32_t(nc), cnt + C_QB); // the queue: every item
 		BindArgs b = bind_args(ctx, v);
 		b.groups = nullptr;
 		launch_bind_phase(ctx, b, v, db->n_exceptions != 0, ctx->S().qb.p, cnt + C_QB, nullptr);
 		uint32_t h[C_COUNT];
+		int32_t *const res = result + c0;
+		HIP_TRY(hipMemcpyAsync(res, ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 		HIP_TRY(hipGetLastError(), ctx->err);
+		if (h[C_ERR] == ERR_POOL_OVERFLOW && chunk > (size_t(1) << 16)) {
+			chunk /= 2;
+			continue;
+		}
 		if (h[C_ERR]) {
 			ctx->err = err_text(h[C_ERR]);
 			return TNT_E_LIMIT;
 		}
-		int32_t *const res = result + c0;
-		HIP_TRY(hipMemcpy(res, ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
-		const size_t np = std::min<size_t>(h[C_POOL], POOL_CAP), base = pool.size();
-		pool.resize(base + np);
-		if (np) HIP_TRY(hipMemcpy(pool.data() + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		const size_t np = std::min<size_t>(h[C_POOL], POOL_CAP), base = n_pool;
+		if (base + np >= (size_t(1) << 31)) {
+			ctx->err = "more than 2^31 bound oligos on the long targets of this batch";
+			return TNT_E_LIMIT;
+		}
+		HIP_TRY(ctx->pin_pool.ensure_keep(base + np, base), ctx->err);
+		if (np) HIP_TRY(hipMemcpy(ctx->pin_pool.p + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		n_pool += np;
 		if (base)
 			for (size_t i = 0; i < nc; i++)
 				if (res[i] >= 0) res[i] = int32_t(base + size_t(res[i]));
 		ctx->acc_items += nc;
+		c0 += nc;
 	}
+	const BoundRec *const pool = ctx->pin_pool.p;
 
 	lap("bind on the device");
 	// ---- the bind / cull sequence and the pairing loops on the whole lists (pair_group, compiled for the host)
-	std::vector<Hit> hits(std::max<size_t>(1024, pool.size() * 2));
+	size_t hit_cap = std::max<size_t>(1024, n_pool);
+	std::unique_ptr<Hit[]> hits(new Hit[hit_cap]); // (not initialised: a record is 1.4 kB, pages are touched as hits arrive)
 	for (;;) {
 		uint32_t n_hits = 0, err = 0, zero = 0;
-		PairArgs &p = job.args;
+		PairArgs p;
 		memset(&p, 0, sizeof(p));
 		p.groups = groups.data();
 		p.items = bind_items;
 		p.result = result;
-		p.pool = pool.data();
+		p.pool = pool;
 		p.assays = ctx->h_assays.data();
 		p.db.first_seq_index = db->first_seq_index;
 		p.max_len = ctx->opt.max_len;
@@ -2693,43 +2812,44 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		p.min_max_primer_clamp = ctx->opt.min_max_primer_clamp;
 		p.assay_format = ctx->opt.assay_format;
 		p.target_strand = ctx->opt.target_strand;
-		p.hits = hits.data();
-		p.hit_cap = uint32_t(hits.size());
+		p.hits = hits.get();
+		p.hit_cap = uint32_t(std::min<size_t>(hit_cap, UINT32_MAX));
 		p.hit_count = &n_hits;
 		p.err = &err;
 		p.n_big = &zero;
 		p.unit_target = unit_target.data();
 		p.unit_own_lo = own_lo.data();
 		p.unit_own_hi = own_hi.data();
-		job.mode = 1;
-		job.groups = &groups;
-		job.next = 0;
-		if (!run_threads_with_stack(workers, size_t(64) << 20, long_job_main, &job)) {
+		if (!workers.run(groups.size(), [&](size_t g) { pair_group<PAIR_HOST>(p, groups[g]); })) {
 			ctx->err = "could not start a host thread for the lists of long targets";
 			return TNT_E_DEVICE;
 		}
-		if (err & ERR_HIT_OVERFLOW) {
-			hits.resize(hits.size() * 4);
+		if ((err & ERR_HIT_OVERFLOW) && hit_cap < UINT32_MAX) {
+			hit_cap *= 4;
+			hits.reset(new Hit[hit_cap]);
 			continue;
 		}
 		if (err) {
 			ctx->err = err_text(err);
 			return TNT_E_LIMIT;
 		}
-		out.resize(n_hits);
-		if (n_hits) memcpy(out.data(), hits.data(), size_t(n_hits) * sizeof(tnt_hit));
+		lap("pairing");
 		// The workers took the groups as they came: put the hits back into the order one thread produces -- groups by
 		// (target, assay position), the hits of a group in the order its worker wrote them (a worker's slots ascend) --, so
 		// that the output does not depend on the scheduling.
 		std::map<std::pair<int32_t, int32_t>, uint32_t> position; // (assay id, degen id) -> first position in the assay list
 		for (size_t ai = ctx->h_assays.size(); ai-- > 0;) position[{ctx->h_assays[ai].id, ctx->h_assays[ai].degen_id}] = uint32_t(ai);
-		std::stable_sort(out.begin(), out.end(), [&](const tnt_hit &x, const tnt_hit &y) {
-			if (x.seq_index != y.seq_index) return x.seq_index < y.seq_index;
-			return position[{x.assay_id, x.degen_id}] < position[{y.assay_id, y.degen_id}];
-		});
+		std::vector<std::pair<uint64_t, uint32_t>> order(n_hits); // ((target, assay position), slot)
+		for (uint32_t i = 0; i < n_hits; i++) {
+			const tnt_hit &x = reinterpret_cast<const tnt_hit &>(hits[i]);
+			order[i] = {(uint64_t(uint32_t(x.seq_index)) << 32) | position[{x.assay_id, x.degen_id}], i};
+		}
+		std::sort(order.begin(), order.end());
+		out.resize(n_hits);
+		for (uint32_t i = 0; i < n_hits; i++) memcpy(&out[i], &hits[order[i].second], sizeof(tnt_hit));
 		break;
 	}
-	lap("pairing");
+	lap("hits in order");
 	return TNT_OK;
 }
 

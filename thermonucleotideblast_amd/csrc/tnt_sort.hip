@@ -10,6 +10,7 @@
 #include <cstring>
 #include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "tnt_dev.h"
 #include "tnt_seed.hip.h"
@@ -55,6 +56,141 @@ __global__ __launch_bounds__(256) void long_gather_kernel(const SeedOut *seeds, 
 	}
 }
 
+// ---- first cull of the assembled lists (cull_oligo_match, amplicon_search.cpp:679-765, on lists nothing is bound on yet)
+// The list is in target_loc order, so the reference's loops -- F over the minus-strand primers, R over the plus-strand
+// primers behind it until target_loc is more than max_len + 50 away, P over the probes between the two -- reduce to
+// questions about the NEAREST element of a class before / behind a list position:
+//   no probe:  a minus-strand primer stays iff the next plus-strand primer of an admissible role is within the threshold,
+//              a plus-strand primer iff the last minus-strand primer of an admissible role is;
+//   probe:     a minus-strand primer looks for that plus-strand primer behind the next probe, a plus-strand primer for the
+//              minus-strand primer before the last probe, a probe for the nearest primers on either side of itself
+// (admissible: the other role, any role with --single-primer-pcr, :716).  "Nearest of a class" is one max-scan over six
+// running positions (three classes forwards, three backwards: the backward ones scan the mirrored array).
+struct Near6 {
+	uint32_t v[6]; // position + 1 (0: none): last minus F, last minus R, last probe | mirrored: next plus F, next plus R, next probe
+};
+struct Near6Max {
+	__host__ __device__ Near6 operator()(const Near6 &a, const Near6 &b) const
+	{
+		Near6 r;
+		for (int i = 0; i < 6; i++) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i];
+		return r;
+	}
+};
+struct Tally4 {
+	uint32_t valid, head, minus, plus; // kept seeds, list heads, successors of kept seeds on the minus / plus strand (:748-755)
+};
+struct Tally4Sum {
+	__host__ __device__ Tally4 operator()(const Tally4 &a, const Tally4 &b) const { return Tally4{a.valid + b.valid, a.head + b.head, a.minus + b.minus, a.plus + b.plus}; }
+};
+
+__device__ inline uint32_t item_role(const Item &it) { return (it.info >> ITEM_SLOT_SHIFT) % 3u; }
+
+__global__ __launch_bounds__(256) void long_near_kernel(const Item *items, uint32_t n, Near6 *near)
+{
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		Near6 r;
+		const Item f = items[k], b = items[n - 1u - k];
+		const uint32_t rf = item_role(f), rb = item_role(b);
+		const bool f_minus = (f.info & ITEM_MINUS) != 0, b_minus = (b.info & ITEM_MINUS) != 0;
+		r.v[0] = (f_minus && rf == 0) ? k + 1u : 0u;
+		r.v[1] = (f_minus && rf == 1) ? k + 1u : 0u;
+		r.v[2] = rf == 2 ? k + 1u : 0u;
+		r.v[3] = (!b_minus && rb == 0) ? k + 1u : 0u;
+		r.v[4] = (!b_minus && rb == 1) ? k + 1u : 0u;
+		r.v[5] = rb == 2 ? k + 1u : 0u;
+		near[k] = r;
+	}
+}
+
+struct NearView {
+	const Near6 *near; // inclusive max-scan of long_near_kernel's output
+	const uint32_t *bucket;
+	uint32_t n;
+	// the last element of class c (0 minus F, 1 minus R, 2 probe) before position i in i's list, or n
+	__device__ uint32_t last(uint32_t i, int c) const
+	{
+		if (i == 0 || i >= n) return n;
+		const uint32_t v = near[i - 1u].v[c];
+		return (v && bucket[v - 1u] == bucket[i]) ? v - 1u : n;
+	}
+	// the next element of class c (0 plus F, 1 plus R, 2 probe) behind position i in i's list, or n
+	__device__ uint32_t next(uint32_t i, int c) const
+	{
+		if (i + 1u >= n) return n;
+		const uint32_t v = near[n - 2u - i].v[3 + c];
+		return (v && bucket[n - v] == bucket[i]) ? n - v : n;
+	}
+};
+
+__global__ __launch_bounds__(256) void long_cull_kernel(const Item *items, const uint32_t *bucket, const Near6 *near, uint32_t n, const AssayDev *assays, uint32_t n_assays,
+                                                       uint32_t threshold, int single_primer, Tally4 *tally)
+{
+	const NearView nv{near, bucket, n};
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const Item it = items[i];
+		const uint32_t list = bucket[i];
+		const AssayDev A = assays[list % n_assays];
+		const uint32_t role = item_role(it);
+		const bool minus = (it.info & ITEM_MINUS) != 0;
+		bool valid = false;
+		if (A.kind != 0) {
+			valid = true; // probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454)
+		} else if (role < 2u) {
+			// partner roles: the other one; both with single_primer
+			for (int b = 0; b < 2 && !valid; b++) {
+				if (!single_primer && uint32_t(b) == role) continue;
+				if (minus) {
+					uint32_t from = i;
+					if (A.has_probe) from = nv.next(i, 2);
+					const uint32_t r = from < n ? nv.next(from, b) : n;
+					valid = r < n && items[r].tloc - it.tloc <= threshold;
+				} else {
+					uint32_t from = i;
+					if (A.has_probe) from = nv.last(i, 2);
+					const uint32_t f = from < n ? nv.last(from, b) : n;
+					valid = f < n && it.tloc - items[f].tloc <= threshold;
+				}
+			}
+		} else if (A.has_probe) {
+			for (int a = 0; a < 2 && !valid; a++)
+				for (int b = 0; b < 2 && !valid; b++) {
+					if (!single_primer && a == b) continue;
+					const uint32_t f = nv.last(i, a), r = nv.next(i, b);
+					valid = f < n && r < n && items[r].tloc - items[f].tloc <= threshold;
+				}
+		}
+		Tally4 t{valid ? 1u : 0u, (i == 0 || bucket[i - 1u] != list) ? 1u : 0u, 0u, 0u};
+		if (valid && A.kind == 0 && i + 1u < n && bucket[i + 1u] == list) { // the reference reads the mask of the element BEHIND each kept one
+			if (items[i + 1u].info & ITEM_MINUS) t.minus = 1u;
+			else t.plus = 1u;
+		}
+		tally[i] = t;
+	}
+}
+
+// kept seeds to their places; the head and the tail of every list leave what the list's group needs
+__global__ __launch_bounds__(256) void long_keep_kernel(const Item *items, const uint32_t *bucket, const Tally4 *tally, uint32_t n, Item *kept, uint4 *seg_head, uint4 *seg_tail)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const Tally4 t = tally[i];
+		const Tally4 before = i ? tally[i - 1u] : Tally4{0u, 0u, 0u, 0u};
+		if (t.valid != before.valid) kept[before.valid] = items[i];
+		const uint32_t list = bucket[i];
+		if (t.head != before.head) seg_head[t.head - 1u] = make_uint4(list, before.valid, before.minus, before.plus);
+		if (i + 1u == n || bucket[i + 1u] != list) seg_tail[t.head - 1u] = make_uint4(t.valid, t.minus, t.plus, 0u);
+	}
+}
+
+__global__ __launch_bounds__(256) void long_group_kernel(const uint4 *seg_head, const uint4 *seg_tail, uint32_t n_seg, uint32_t n_assays, Group *groups)
+{
+	for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_seg; s += gridDim.x * blockDim.x) {
+		const uint4 h = seg_head[s], t = seg_tail[s];
+		const uint32_t minus = t.y - h.z, plus = t.z - h.w;
+		groups[s] = Group{h.x / n_assays, (h.x % n_assays) | (minus < plus ? GROUP_MINUS_FIRST : 0u), h.y, t.x - h.y}; // amplicon_search.cpp:131
+	}
+}
+
 struct Scratch {
 	void *p = nullptr;
 	hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
@@ -94,6 +230,46 @@ hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *tar
 	if ((e = rocprim::radix_sort_pairs(tmp.p, need2, b0, bucket, i1, i0, size_t(n), 0u, bits, stream)) != hipSuccess) return e;
 	hipLaunchKernelGGL(long_gather_kernel, dim3(blocks), dim3(256), 0, stream, seeds, i0, n, items);
 	if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; // (the scratch arrays are freed on return)
+	return hipGetLastError();
+}
+
+// First cull of the assembled lists on the device: items[n] / bucket[n] as long_sort_seeds left them -> the kept seeds,
+// list after list (kept[n], caller's buffer; *n_kept of them), and one group per list (groups[n_seg], allocated here with
+// hipMalloc, the caller frees it): Group::target = rank of the target among the windowed targets, ::assay with
+// GROUP_MINUS_FIRST from the reference's successor counts, ::first / ::count = its kept seeds.
+hipError_t long_first_cull(const Item *items, const uint32_t *bucket, uint32_t n, const AssayDev *assays, uint32_t n_assays, int max_len, int single_primer,
+                           Item *kept, uint32_t *n_kept, Group **groups, uint32_t *n_groups, hipStream_t stream)
+{
+	*n_kept = *n_groups = 0;
+	*groups = nullptr;
+	if (n == 0) return hipSuccess;
+	Scratch near_in, near_out, tally_out, tmp, head, tail;
+	hipError_t e;
+	if ((e = near_in.alloc(size_t(n) * sizeof(Near6))) != hipSuccess || (e = near_out.alloc(size_t(n) * sizeof(Near6))) != hipSuccess ||
+	    (e = tally_out.alloc(size_t(n) * sizeof(Tally4))) != hipSuccess)
+		return e;
+	Near6 *const nr_in = static_cast<Near6 *>(near_in.p), *const nr = static_cast<Near6 *>(near_out.p);
+	Tally4 *const tl_in = static_cast<Tally4 *>(near_in.p), *const tl = static_cast<Tally4 *>(tally_out.p); // (the tallies reuse the scanned array's input)
+	size_t need = 0, need2 = 0;
+	if ((e = rocprim::inclusive_scan(nullptr, need, nr_in, nr, size_t(n), Near6Max(), stream)) != hipSuccess) return e;
+	if ((e = rocprim::inclusive_scan(nullptr, need2, tl_in, tl, size_t(n), Tally4Sum(), stream)) != hipSuccess) return e;
+	if ((e = tmp.alloc(std::max(need, need2))) != hipSuccess) return e;
+	const int blocks = int(std::min<size_t>(4096, (size_t(n) + 255) / 256));
+	hipLaunchKernelGGL(long_near_kernel, dim3(blocks), dim3(256), 0, stream, items, n, nr_in);
+	if ((e = rocprim::inclusive_scan(tmp.p, need, nr_in, nr, size_t(n), Near6Max(), stream)) != hipSuccess) return e;
+	hipLaunchKernelGGL(long_cull_kernel, dim3(blocks), dim3(256), 0, stream, items, bucket, nr, n, assays, n_assays, uint32_t(max_len) + 50u, single_primer, tl_in);
+	if ((e = rocprim::inclusive_scan(tmp.p, need2, tl_in, tl, size_t(n), Tally4Sum(), stream)) != hipSuccess) return e;
+	Tally4 total;
+	if ((e = hipMemcpyAsync(&total, tl + (n - 1u), sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+	if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+	if ((e = head.alloc(size_t(total.head) * sizeof(uint4))) != hipSuccess || (e = tail.alloc(size_t(total.head) * sizeof(uint4))) != hipSuccess) return e;
+	if ((e = hipMalloc((void **)groups, size_t(total.head) * sizeof(Group))) != hipSuccess) return e;
+	hipLaunchKernelGGL(long_keep_kernel, dim3(blocks), dim3(256), 0, stream, items, bucket, tl, n, kept, static_cast<uint4 *>(head.p), static_cast<uint4 *>(tail.p));
+	hipLaunchKernelGGL(long_group_kernel, dim3(int(std::min<size_t>(1024, (size_t(total.head) + 255) / 256))), dim3(256), 0, stream, static_cast<const uint4 *>(head.p),
+	                   static_cast<const uint4 *>(tail.p), total.head, n_assays, *groups);
+	if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+	*n_kept = total.valid;
+	*n_groups = total.head;
 	return hipGetLastError();
 }
 
