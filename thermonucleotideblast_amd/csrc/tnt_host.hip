@@ -26,6 +26,7 @@
 
 #include "../../include/tnt_mi355x.h"
 #include "tnt_dev.h"
+#include "tnt_arena.h"
 #include "tnt_seed.hip.h"
 #include "tnt_seed2.hip.h"
 #include "tnt_bind.hip.h"
@@ -44,10 +45,12 @@
 using namespace tnt;
 
 namespace tnt { // tnt_sort.hip
+size_t long_sort_bytes(size_t n);
+size_t long_cull_bytes(size_t n, size_t n_lists_max);
 hipError_t long_first_cull(const Item *items, const uint32_t *bucket, uint32_t n, const AssayDev *assays, uint32_t n_assays, int max_len, int single_primer,
-                           Item *kept, uint32_t *n_kept, Group **groups, uint32_t *n_groups, hipStream_t stream);
+                           Item *kept, uint32_t *n_kept, Group **groups, uint32_t *n_groups, DeviceArena &arena, hipStream_t stream);
 hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *target_rank, const AssayDev *assays, uint32_t n_assays,
-                           uint32_t n_buckets, Item *items, uint32_t *bucket, hipStream_t stream);
+                           uint32_t n_buckets, Item *items, uint32_t *bucket, DeviceArena &arena, hipStream_t stream);
 }
 
 static_assert(sizeof(Hit) == sizeof(tnt_hit), "device Hit must mirror tnt_hit");
@@ -618,6 +621,7 @@ struct tnt_ctx {
 	DevBuf<uint8_t> best;
 	DevBuf<uint32_t> stack;
 	DevBuf<SeedOut> seeds_out;
+	DeviceArena long_arena; // device arrays of the long-target path (lists, scans, kept seeds)
 	int bind_blocks = 0; // grid of the 256-thread instances
 	int n_cu = 0;
 
@@ -2543,7 +2547,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 			ctx->err = "too many seeds on the long targets of this batch";
 			return TNT_E_LIMIT;
 		}
-		HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err);
+		if (cap > ctx->seeds_out.n) HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err); // (kept for the next search)
 		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 		rc = enqueue_batch(ctx, db, u0, u1, true);
 		if (rc) return rc;
@@ -2574,17 +2578,14 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 			ctx->err = err_text(h[C_ERR]);
 			return TNT_E_LIMIT;
 		}
-		if (h[C_SEEDS] > cap) {
+		if (h[C_SEEDS] > ctx->seeds_out.n) {
 			ctx->err = "seed output overflow on a long target";
 			return TNT_E_LIMIT;
 		}
 		n_raw = h[C_SEEDS];
 		break;
 	}
-	if (n_raw == 0) {
-		ctx->seeds_out.release();
-		return TNT_OK;
-	}
+	if (n_raw == 0) return TNT_OK;
 	lap("seed windows");
 
 	// ---- per (target, assay) lists in the reference's list order, assembled on the device (tnt_sort.hip: key kernel, two
@@ -2605,16 +2606,24 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	// replayed per list on the worker threads) as the cross-check of the device cull.
 	const bool host_cull = getenv("TNT_MI355X_LONG_HOST_CULL") != nullptr;
 	HostPool &workers = HostPool::get();
-	DevBuf<uint32_t> d_rank, d_list;
-	DevBuf<Item> d_items, d_kept;
+	// (all device arrays of this path come out of one allocation the context keeps: tnt_arena.h)
+	DeviceArena &arena = ctx->long_arena;
+	const size_t n_lists_max = std::min(n_raw, n_buckets);
+	HIP_TRY(arena.reserve(8 * 256 + db->n_targets * sizeof(uint32_t) + n_raw * (2 * sizeof(Item) + sizeof(uint32_t)) +
+	                      std::max(long_sort_bytes(n_raw), long_cull_bytes(n_raw, n_lists_max))),
+	        ctx->err);
+	uint32_t *const d_rank = arena.take<uint32_t>(db->n_targets), *const d_list = arena.take<uint32_t>(n_raw);
+	Item *const d_items = arena.take<Item>(n_raw), *const d_kept = arena.take<Item>(n_raw);
+	if (!d_rank || !d_list || !d_items || !d_kept) {
+		ctx->err = "the device arena of the long-target path is too small";
+		return TNT_E_DEVICE;
+	}
 	{
 		std::vector<uint32_t> rank(db->n_targets, 0);
 		for (size_t r = 0; r < long_targets.size(); r++) rank[long_targets[r]] = uint32_t(r);
-		HIP_TRY(d_rank.upload(rank), ctx->err);
-		HIP_TRY(d_list.alloc(n_raw), ctx->err);
-		HIP_TRY(d_items.alloc(n_raw), ctx->err);
-		HIP_TRY(long_sort_seeds(ctx->seeds_out.p, uint32_t(n_raw), d_rank.p, ctx->assays.p, uint32_t(n_assays_all), uint32_t(n_buckets), d_items.p, d_list.p, ctx->stream), ctx->err);
-		ctx->seeds_out.release();
+		HIP_TRY(hipMemcpy(d_rank, rank.data(), rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(long_sort_seeds(ctx->seeds_out.p, uint32_t(n_raw), d_rank, ctx->assays.p, uint32_t(n_assays_all), uint32_t(n_buckets), d_items, d_list, arena, ctx->stream), ctx->err);
+		if (timing) HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	}
 	lap("keys + sort");
 
@@ -2625,18 +2634,14 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	std::vector<int32_t> own_lo, own_hi;
 	if (!host_cull) {
 		// ---- first cull of every list (amplicon_search.cpp:128-131) on the device
-		HIP_TRY(d_kept.alloc(n_raw), ctx->err);
 		Group *d_groups = nullptr;
 		uint32_t n_kept = 0, n_groups = 0;
-		const hipError_t ce = long_first_cull(d_items.p, d_list.p, uint32_t(n_raw), ctx->assays.p, uint32_t(n_assays_all), ctx->opt.max_len, ctx->opt.single_primer_pcr,
-		                                      d_kept.p, &n_kept, &d_groups, &n_groups, ctx->stream);
+		HIP_TRY(long_first_cull(d_items, d_list, uint32_t(n_raw), ctx->assays.p, uint32_t(n_assays_all), ctx->opt.max_len, ctx->opt.single_primer_pcr, d_kept, &n_kept,
+		                        &d_groups, &n_groups, arena, ctx->stream),
+		        ctx->err);
 		std::vector<Group> all(n_groups);
-		hipError_t ge = ce;
-		if (ge == hipSuccess && n_groups) ge = hipMemcpy(all.data(), d_groups, size_t(n_groups) * sizeof(Group), hipMemcpyDeviceToHost);
-		if (d_groups) (void)hipFree(d_groups);
-		HIP_TRY(ge, ctx->err);
-		d_items.release();
-		d_list.release();
+		if (n_groups) HIP_TRY(hipMemcpyAsync(all.data(), d_groups, size_t(n_groups) * sizeof(Group), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 		n_bind = n_kept;
 		for (const Group &g : all) {
 			if (g.count == 0) continue;
@@ -2654,17 +2659,16 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		if (n_bind) {
 			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
 			bind_items = ctx->pin_bind.p;
-			HIP_TRY(hipMemcpyAsync(bind_items, d_kept.p, n_bind * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err); // (done by the first sync of the bind loop)
+			HIP_TRY(hipMemcpyAsync(bind_items, d_kept, n_bind * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err); // (done by the first sync of the bind loop)
 		}
 	} else {
 		HIP_TRY(ctx->pin_items.ensure(n_raw), ctx->err);
 		HIP_TRY(ctx->pin_list.ensure(n_raw), ctx->err);
 		Item *const sorted = ctx->pin_items.p;
 		uint32_t *const list_of = ctx->pin_list.p;
-		HIP_TRY(hipMemcpy(sorted, d_items.p, n_raw * sizeof(Item), hipMemcpyDeviceToHost), ctx->err);
-		HIP_TRY(hipMemcpy(list_of, d_list.p, n_raw * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
-		d_items.release();
-		d_list.release();
+		HIP_TRY(hipMemcpyAsync(sorted, d_items, n_raw * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipMemcpyAsync(list_of, d_list, n_raw * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 		std::vector<uint32_t> seg_begin, seg_assay;
 		for (size_t i = 0; i < n_raw; i++)
 			if (i == 0 || list_of[i] != list_of[i - 1]) {
@@ -2758,7 +2762,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		const size_t nc = std::min(chunk, n_bind - c0);
 		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
 		if (host_cull) HIP_TRY(hipMemcpyAsync(ctx->S().items.p, bind_items + c0, nc * sizeof(Item), hipMemcpyHostToDevice, ctx->stream), ctx->err);
-		else HIP_TRY(hipMemcpyAsync(ctx->S().items.p, d_kept.p + c0, nc * sizeof(Item), hipMemcpyDeviceToDevice, ctx->stream), ctx->err);
+		else HIP_TRY(hipMemcpyAsync(ctx->S().items.p, d_kept + c0, nc * sizeof(Item), hipMemcpyDeviceToDevice, ctx->stream), ctx->err);
 		hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->S().qb.p, uint32_t(nc), cnt + C_QB); // the queue: every item
 		BindArgs b = bind_args(ctx, v);
 		b.groups = nullptr;
@@ -2974,6 +2978,11 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		// targets seeded in windows: lists merged per (target, assay), culled and paired whole on the host
 		std::vector<tnt_hit> extra;
 		const int rc = search_long_targets(ctx, ctx->pending_db, extra);
+		// (its device arrays are kept for the next search -- allocating 17 GB for a 250-Mb record takes 0.4 s -- up to 48 GB)
+		if (ctx->long_arena.cap + ctx->seeds_out.n * sizeof(SeedOut) > (size_t(48) << 30)) {
+			ctx->long_arena.release();
+			ctx->seeds_out.release();
+		}
 		if (rc) return rc;
 		if (!extra.empty()) {
 			const size_t total = n + extra.size();

@@ -173,6 +173,26 @@ template <class Less> TNT_HD void merge_runs(Entry *e, Entry *tmp, int lo, int m
 	for (int i = lo; i < hi; i++) e[i] = tmp[i];
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host replay of long lists (windowed targets: up to a million entries): the same merges in an order that keeps the two
+// halves of a block in the cache -- a block is finished before its neighbour is begun, instead of one width after the
+// other across the whole list --, and a merge that would hand back its input (no element of the left run is preceded by
+// the head of the right run: the loop of merge_runs takes the whole left run first, then the right one) is skipped.
+// 96 lists of 165 000 entries (a 250-Mb record against config 2) otherwise stream 1 GB each through every core's memory
+// channel: 0.8 s.
+template <class Less> void sort_block(Entry *e, Entry *tmp, int lo, int size, Less less)
+{
+	if (size < 2) return;
+	const int half = size / 2;
+	sort_block(e, tmp, lo, half, less);
+	sort_block(e, tmp, lo + half, half, less);
+	const Entry &head = e[lo + half];
+	int a = lo;
+	while (a < lo + half && !less(head, e[a])) a++;
+	if (a < lo + half) merge_runs(e, tmp, lo, lo + half, lo + size, less);
+}
+#endif
+
 template <class Less> TNT_HD void list_sort(Entry *e, Entry *tmp, int n, Less less)
 {
 	if (n < 2) return;
@@ -181,8 +201,12 @@ template <class Less> TNT_HD void list_sort(Entry *e, Entry *tmp, int n, Less le
 	for (int bit = 30; bit >= 0; bit--) {
 		const int size = 1 << bit;
 		if (!(n & size)) continue;
+#if !defined(__HIP_DEVICE_COMPILE__)
+		sort_block(e, tmp, start, size, less);
+#else
 		for (int width = 1; width < size; width <<= 1)
 			for (int lo = start; lo < start + size; lo += 2 * width) merge_runs(e, tmp, lo, lo + width, lo + 2 * width, less);
+#endif
 		start += size;
 	}
 	// final merges: the last (smallest) block into its left neighbour, and so on
@@ -511,7 +535,10 @@ template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 	}
 	if (!any_bound) return;
 #if !defined(__HIP_DEVICE_COMPILE__)
-	if (l.n > 64) { // host replay of long lists: the same order (keys are unique), not quadratic
+	bool in_order = true; // (the lists of windowed targets arrive in list order: tnt_sort.hip)
+	for (int i = 1; i < l.n && in_order; i++) in_order = order[i - 1] < order[i];
+	if (in_order) {
+	} else if (l.n > 64) { // host replay of long lists: the same order (keys are unique), not quadratic
 		unsigned long long *idx = new unsigned long long[size_t(l.n)];
 		Entry *cp = new Entry[size_t(l.n)];
 		for (int i = 0; i < l.n; i++) idx[i] = uint32_t(i), cp[i] = l.e[i];

@@ -13,6 +13,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "tnt_dev.h"
+#include "tnt_arena.h"
 #include "tnt_seed.hip.h"
 
 namespace tnt {
@@ -191,83 +192,73 @@ __global__ __launch_bounds__(256) void long_group_kernel(const uint4 *seg_head, 
 	}
 }
 
-struct Scratch {
-	void *p = nullptr;
-	hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-	~Scratch()
-	{
-		if (p) (void)hipFree(p);
-	}
-};
-
 } // namespace
 
 // seeds[n] (device) -> items[n], bucket[n] (device, caller's buffers): the seeds as bind work items, list after list
 // (bucket = rank of the target among the windowed targets * n_assays + assay), every list in the reference's order.
-// Returns hipSuccess or the first error.
+// Scratch from `arena` (given back on return; long_sort_bytes(n) says how much).  Returns hipSuccess or the first error.
+size_t long_sort_bytes(size_t n) { return n * 28 + (n * 12 + (size_t(16) << 20)) + 8 * 256; } // keys, indices, buckets + rocPRIM's double buffers and histograms
+
 hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *target_rank, const AssayDev *assays, uint32_t n_assays,
-                           uint32_t n_buckets, Item *items, uint32_t *bucket, hipStream_t stream)
+                           uint32_t n_buckets, Item *items, uint32_t *bucket, DeviceArena &arena, hipStream_t stream)
 {
 	if (n == 0) return hipSuccess;
-	Scratch key0, key1, idx0, idx1, bkt0, tmp;
+	const size_t mark = arena.mark();
+	unsigned long long *k0 = arena.take<unsigned long long>(n), *k1 = arena.take<unsigned long long>(n);
+	uint32_t *i0 = arena.take<uint32_t>(n), *i1 = arena.take<uint32_t>(n), *b0 = arena.take<uint32_t>(n);
 	hipError_t e;
-	if ((e = key0.alloc(size_t(n) * 8)) != hipSuccess || (e = key1.alloc(size_t(n) * 8)) != hipSuccess || (e = idx0.alloc(size_t(n) * 4)) != hipSuccess ||
-	    (e = idx1.alloc(size_t(n) * 4)) != hipSuccess || (e = bkt0.alloc(size_t(n) * 4)) != hipSuccess)
-		return e;
-	unsigned long long *k0 = static_cast<unsigned long long *>(key0.p), *k1 = static_cast<unsigned long long *>(key1.p);
-	uint32_t *i0 = static_cast<uint32_t *>(idx0.p), *i1 = static_cast<uint32_t *>(idx1.p), *b0 = static_cast<uint32_t *>(bkt0.p);
 	const int blocks = int(std::min<size_t>(4096, (size_t(n) + 255) / 256));
-	hipLaunchKernelGGL(long_keys_kernel, dim3(blocks), dim3(256), 0, stream, seeds, n, assays, k0, i0);
 	size_t need = 0, need2 = 0;
-	if ((e = rocprim::radix_sort_pairs(nullptr, need, k0, k1, i0, i1, size_t(n), 0u, 45u, stream)) != hipSuccess) return e;
 	unsigned bits = 1;
 	while (bits < 32 && (1ull << bits) < (unsigned long long)n_buckets) bits++;
+	if ((e = rocprim::radix_sort_pairs(nullptr, need, k0, k1, i0, i1, size_t(n), 0u, 45u, stream)) != hipSuccess) return e;
 	if ((e = rocprim::radix_sort_pairs(nullptr, need2, b0, bucket, i1, i0, size_t(n), 0u, bits, stream)) != hipSuccess) return e;
-	if ((e = tmp.alloc(std::max(need, need2))) != hipSuccess) return e;
+	uint8_t *tmp = arena.take<uint8_t>(std::max(need, need2));
+	if (!k0 || !k1 || !i0 || !i1 || !b0 || !tmp) return hipErrorOutOfMemory;
+	hipLaunchKernelGGL(long_keys_kernel, dim3(blocks), dim3(256), 0, stream, seeds, n, assays, k0, i0);
 	// stable LSD sorts: by the in-list key, then by the list
-	if ((e = rocprim::radix_sort_pairs(tmp.p, need, k0, k1, i0, i1, size_t(n), 0u, 45u, stream)) != hipSuccess) return e;
+	if ((e = rocprim::radix_sort_pairs(tmp, need, k0, k1, i0, i1, size_t(n), 0u, 45u, stream)) != hipSuccess) return e;
 	hipLaunchKernelGGL(long_bucket_kernel, dim3(blocks), dim3(256), 0, stream, seeds, i1, n, target_rank, n_assays, b0);
-	if ((e = rocprim::radix_sort_pairs(tmp.p, need2, b0, bucket, i1, i0, size_t(n), 0u, bits, stream)) != hipSuccess) return e;
+	if ((e = rocprim::radix_sort_pairs(tmp, need2, b0, bucket, i1, i0, size_t(n), 0u, bits, stream)) != hipSuccess) return e;
 	hipLaunchKernelGGL(long_gather_kernel, dim3(blocks), dim3(256), 0, stream, seeds, i0, n, items);
-	if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; // (the scratch arrays are freed on return)
+	arena.rewind(mark); // (the stream is in order: what takes this room next runs behind the kernels above)
 	return hipGetLastError();
 }
 
 // First cull of the assembled lists on the device: items[n] / bucket[n] as long_sort_seeds left them -> the kept seeds,
-// list after list (kept[n], caller's buffer; *n_kept of them), and one group per list (groups[n_seg], allocated here with
-// hipMalloc, the caller frees it): Group::target = rank of the target among the windowed targets, ::assay with
-// GROUP_MINUS_FIRST from the reference's successor counts, ::first / ::count = its kept seeds.
+// list after list (kept[n], caller's buffer; *n_kept of them), and one group per list (groups[*n_groups], taken from the
+// arena and left there: the caller copies them): Group::target = rank of the target among the windowed targets, ::assay
+// with GROUP_MINUS_FIRST from the reference's successor counts, ::first / ::count = its kept seeds.  n_lists_max: upper
+// bound of the number of lists (for the reservation); the scratch stays taken until the caller rewinds the arena.
+size_t long_cull_bytes(size_t n, size_t n_lists_max) { return n * (sizeof(Near6) * 2 + sizeof(Tally4)) + (size_t(16) << 20) + std::min(n, n_lists_max) * 48 + 8 * 256; }
+
 hipError_t long_first_cull(const Item *items, const uint32_t *bucket, uint32_t n, const AssayDev *assays, uint32_t n_assays, int max_len, int single_primer,
-                           Item *kept, uint32_t *n_kept, Group **groups, uint32_t *n_groups, hipStream_t stream)
+                           Item *kept, uint32_t *n_kept, Group **groups, uint32_t *n_groups, DeviceArena &arena, hipStream_t stream)
 {
 	*n_kept = *n_groups = 0;
 	*groups = nullptr;
 	if (n == 0) return hipSuccess;
-	Scratch near_in, near_out, tally_out, tmp, head, tail;
 	hipError_t e;
-	if ((e = near_in.alloc(size_t(n) * sizeof(Near6))) != hipSuccess || (e = near_out.alloc(size_t(n) * sizeof(Near6))) != hipSuccess ||
-	    (e = tally_out.alloc(size_t(n) * sizeof(Tally4))) != hipSuccess)
-		return e;
-	Near6 *const nr_in = static_cast<Near6 *>(near_in.p), *const nr = static_cast<Near6 *>(near_out.p);
-	Tally4 *const tl_in = static_cast<Tally4 *>(near_in.p), *const tl = static_cast<Tally4 *>(tally_out.p); // (the tallies reuse the scanned array's input)
+	Near6 *const nr_in = arena.take<Near6>(n), *const nr = arena.take<Near6>(n);
+	Tally4 *const tl_in = reinterpret_cast<Tally4 *>(nr_in), *const tl = arena.take<Tally4>(n); // (the tallies reuse the scanned array's input)
 	size_t need = 0, need2 = 0;
 	if ((e = rocprim::inclusive_scan(nullptr, need, nr_in, nr, size_t(n), Near6Max(), stream)) != hipSuccess) return e;
 	if ((e = rocprim::inclusive_scan(nullptr, need2, tl_in, tl, size_t(n), Tally4Sum(), stream)) != hipSuccess) return e;
-	if ((e = tmp.alloc(std::max(need, need2))) != hipSuccess) return e;
+	uint8_t *const tmp = arena.take<uint8_t>(std::max(need, need2));
+	if (!nr_in || !nr || !tl || !tmp) return hipErrorOutOfMemory;
 	const int blocks = int(std::min<size_t>(4096, (size_t(n) + 255) / 256));
 	hipLaunchKernelGGL(long_near_kernel, dim3(blocks), dim3(256), 0, stream, items, n, nr_in);
-	if ((e = rocprim::inclusive_scan(tmp.p, need, nr_in, nr, size_t(n), Near6Max(), stream)) != hipSuccess) return e;
+	if ((e = rocprim::inclusive_scan(tmp, need, nr_in, nr, size_t(n), Near6Max(), stream)) != hipSuccess) return e;
 	hipLaunchKernelGGL(long_cull_kernel, dim3(blocks), dim3(256), 0, stream, items, bucket, nr, n, assays, n_assays, uint32_t(max_len) + 50u, single_primer, tl_in);
-	if ((e = rocprim::inclusive_scan(tmp.p, need2, tl_in, tl, size_t(n), Tally4Sum(), stream)) != hipSuccess) return e;
+	if ((e = rocprim::inclusive_scan(tmp, need2, tl_in, tl, size_t(n), Tally4Sum(), stream)) != hipSuccess) return e;
 	Tally4 total;
 	if ((e = hipMemcpyAsync(&total, tl + (n - 1u), sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
 	if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-	if ((e = head.alloc(size_t(total.head) * sizeof(uint4))) != hipSuccess || (e = tail.alloc(size_t(total.head) * sizeof(uint4))) != hipSuccess) return e;
-	if ((e = hipMalloc((void **)groups, size_t(total.head) * sizeof(Group))) != hipSuccess) return e;
-	hipLaunchKernelGGL(long_keep_kernel, dim3(blocks), dim3(256), 0, stream, items, bucket, tl, n, kept, static_cast<uint4 *>(head.p), static_cast<uint4 *>(tail.p));
-	hipLaunchKernelGGL(long_group_kernel, dim3(int(std::min<size_t>(1024, (size_t(total.head) + 255) / 256))), dim3(256), 0, stream, static_cast<const uint4 *>(head.p),
-	                   static_cast<const uint4 *>(tail.p), total.head, n_assays, *groups);
-	if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+	uint4 *const head = arena.take<uint4>(total.head), *const tail = arena.take<uint4>(total.head);
+	*groups = arena.take<Group>(total.head);
+	if (!head || !tail || !*groups) return hipErrorOutOfMemory;
+	hipLaunchKernelGGL(long_keep_kernel, dim3(blocks), dim3(256), 0, stream, items, bucket, tl, n, kept, head, tail);
+	hipLaunchKernelGGL(long_group_kernel, dim3(int(std::min<size_t>(1024, (size_t(total.head) + 255) / 256))), dim3(256), 0, stream, head, tail, total.head, n_assays, *groups);
 	*n_kept = total.valid;
 	*n_groups = total.head;
 	return hipGetLastError();
