@@ -1691,7 +1691,7 @@ int tntor_first_cull(const tnt_options *opt, const tnt_assay *assays, size_t n_a
 // -(dH - Tk dS) over all alignments of a window, restated in the order evaluate_alignment reads an alignment
 // (nuc_cruc.cpp:1620-2299; the kernel sweeps the other way), on plain windows.  score[2k] = bound, score[2k+1] =
 // threshold of request k (INT32_MIN: this class is never rejected), both in 1e-3 kcal/mol (the bound saturates at 32 767); INT32_MAX / INT32_MIN when the
-// window holds inosine or a skipped code (such windows are never rejected).  tests/test_filter_bound.py holds it against
+// window holds a skipped code (such windows are never rejected).  tests/test_filter_bound.py holds it against
 // tntor_bind_batch ("accepted => bound >= threshold") and tests/test_gpu_parity.py against the kernel (equal integers).
 int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_oligos, const uint8_t *codes, const uint64_t *offsets,
                        size_t n_targets, uint32_t first_seq_index, const tnt_bind_req *req, size_t n, int32_t *score)
@@ -1791,10 +1791,11 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		const unsigned stop = std::min(start + unsigned(L) + 2 * TNT_FLANK, seq_len);
 		// IUPAC codes (5..15 = M R S V W Y H K D B N) become "any of A C G T": resolve_degenerate (nuc_cruc.cpp:14-201) turns
 		// them into one of the four per aligned pair, so the maximum over the four bounds whatever it picks.  Inosine in the
-		// target and the codes the window loader skips (> 15) are not modelled: bound = INT32_MAX, the window is never rejected.
+		// target (code 4) takes the same column value: the maximum runs over A C G T I.  The codes the window loader skips
+		// (> 15) are not modelled: bound = INT32_MAX, the window is never rejected.
 		const int ANY = -1;
 		bool modelled = true;
-		for (unsigned p = start; p < stop; p++) modelled = modelled && (seq[p] <= 3 || (seq[p] >= 5 && seq[p] <= 15));
+		for (unsigned p = start; p < stop; p++) modelled = modelled && seq[p] <= 15;
 		if (!modelled) {
 			score[2 * k] = INT32_MAX;
 			score[2 * k + 1] = INT32_MIN;
@@ -1821,8 +1822,8 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		// table value of (previous pair, current pair), maximised over the bases an ANY column can stand for
 		auto entry = [&](const std::vector<int> &tab, int qp, int tp, int qc, int tc) {
 			int m = INT32_MIN;
-			for (int x = (tp == ANY ? 0 : tp); x <= (tp == ANY ? 3 : tp); x++)
-				for (int y = (tc == ANY ? 0 : tc); y <= (tc == ANY ? 3 : tc); y++) m = std::max(m, tab[(qp * NB + x) * NBP + qc * NB + y]);
+			for (int x = (tp == ANY ? int(A) : tp); x <= (tp == ANY ? int(I) : tp); x++)
+				for (int y = (tc == ANY ? int(A) : tc); y <= (tc == ANY ? int(I) : tc); y++) m = std::max(m, tab[(qp * NB + x) * NBP + qc * NB + y]);
 			return m;
 		};
 		for (int a = 1; a <= L; a++)

@@ -35,9 +35,10 @@ OPTION_SETS = [
 ]
 
 
-def make_windows(rng, n, lo=12, hi=40, degen=0.3):
+def make_windows(rng, n, lo=12, hi=40, degen=0.3, inosine=0.04):
     """`degen`: share of the targets that get one to three IUPAC letters (compatible with the base they replace or not)
-    and, rarely, an inosine or an unknown base (windows the filter does not model and must let through)."""
+    or -- a share `inosine` of those letters -- an inosine (a column the filter reads like an IUPAC code: the maximum
+    over A C G T I)."""
     oligos = sorted({synth._rand_oligo(rng, lo, hi) for _ in range(64)})
     targets, rows = [], []
     for t in range(n):
@@ -67,7 +68,7 @@ def make_windows(rng, n, lo=12, hi=40, degen=0.3):
             for _ in range(int(rng.integers(1, 4))):
                 k = int(rng.integers(0, len(seq)))
                 r = rng.random()
-                if r < 0.04:
+                if r < inosine:
                     seq[k] = "I"
                 elif r < 0.5:  # a code that contains the base it replaces
                     seq[k] = str(rng.choice([c for c in "MRSVWYHKDBN" if seq[k] in synth.expand_oligo(c)] or ["N"]))
@@ -81,10 +82,10 @@ def make_windows(rng, n, lo=12, hi=40, degen=0.3):
     return oligos, targets, rows
 
 
-def check_option_set(oracle, name, kw, n, seed):
+def check_option_set(oracle, name, kw, n, seed, **window_kw):
     rng = np.random.default_rng([2024, seed])
     opt = abi.options_default(**kw)
-    oligos, targets, rows = make_windows(rng, n)
+    oligos, targets, rows = make_windows(rng, n, **window_kw)
     rows = [r[:6] + ((opt.probe_strand if r[5] else opt.primer_strand),) for r in rows]
     codes = np.concatenate([synth.encode(t) for t in targets])
     offsets = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
@@ -133,6 +134,15 @@ def test_filter_never_rejects_an_accepted_window(oracle, k):
     assert res["rejected_by_filter"] > 0  # the filter does something
 
 
+@pytest.mark.parametrize("k", [0, 5, 9])
+def test_filter_with_inosine_in_the_target(oracle, k):
+    """Windows with one to three inosines (DB_I, seq.h:19) in the target: the column takes the maximum over A C G T I."""
+    n = int(os.environ.get("TNT_FILTER_PROPERTY_N", "40000"))
+    name, kw = OPTION_SETS[k]
+    res = check_option_set(oracle, name + ", inosine in the targets", kw, n, 100 + k, degen=1.0, inosine=0.7)
+    assert res["rejected_by_filter"] > 0
+
+
 def test_filter_is_off_where_its_premises_fail(oracle):
     rng = np.random.default_rng(5)
     oligos, targets, rows = make_windows(rng, 200)
@@ -143,7 +153,8 @@ def test_filter_is_off_where_its_premises_fail(oracle):
                dict(use_dinkelbach=1, min_primer_tm=40.0, min_probe_tm=40.0)):
         fb = oracle.filter_bound(abi.options_default(**kw), oligos, codes, offsets, reqs)
         assert (fb[:, 1] == np.iinfo(np.int32).min).all(), kw
-    # an inosine in the target takes the window out of the filter's reach; an IUPAC code only loosens the bound
+    # an inosine or an IUPAC code in the target only loosens the bound; a code the window loader skips takes the window out
+    # of the filter's reach
     opt = abi.options_default(min_primer_tm=40.0, min_probe_tm=40.0)
     oligos, targets, rows = make_windows(rng, 200, degen=0.0)
     codes = np.concatenate([synth.encode(t) for t in targets])
@@ -153,7 +164,9 @@ def test_filter_is_off_where_its_premises_fail(oracle):
     codes2 = codes.copy()
     codes2[int(offsets[3]) + 12] = abi.DB_CODES.index("I")
     codes2[int(offsets[4]) + 12] = abi.DB_CODES.index("N")
+    codes2[int(offsets[5]) + 12] = 16  # DB_GAP (seq.h:34): skipped by the window loader
     fb = oracle.filter_bound(opt, oligos, codes2, offsets, reqs)
-    assert tuple(fb[3]) == (np.iinfo(np.int32).max, np.iinfo(np.int32).min)
+    assert tuple(fb[5]) == (np.iinfo(np.int32).max, np.iinfo(np.int32).min)
+    assert fb[3, 0] >= plain[3, 0] and fb[3, 1] == plain[3, 1]
     assert fb[4, 0] >= plain[4, 0] and fb[4, 1] == plain[4, 1]
-    assert (np.delete(fb, [3, 4], axis=0) == np.delete(plain, [3, 4], axis=0)).all()
+    assert (np.delete(fb, [3, 4, 5], axis=0) == np.delete(plain, [3, 4, 5], axis=0)).all()

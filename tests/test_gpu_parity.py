@@ -157,7 +157,8 @@ def test_filter_kernel_equals_its_checker(Engine, oracle, k):
     name, kw = fbt.OPTION_SETS[k]
     rng = np.random.default_rng([99, k])
     opt = abi.options_default(**kw)
-    oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=64)
+    # (sets 1, 5, 9 -- a Tm, a dG and a dangle set -- on windows full of inosines: the column value ANY)
+    oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=64, **(dict(degen=0.8, inosine=0.6) if k in (1, 5, 9) else {}))
     if k == 2:  # some degenerate target bases: those windows are outside the filter
         targets = [t if i % 7 else t[:5] + "N" + t[6:] for i, t in enumerate(targets)]
     rows = [r[:6] + ((opt.probe_strand if r[5] else opt.primer_strand),) for r in rows]
@@ -182,8 +183,17 @@ def test_filter_changes_no_result(Engine, oracle, monkeypatch):
                             (2, 20000, 96, dict(min_primer_tm=0.0, max_primer_dg=-10.0)),
                             (3, 12000, 48, dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-9.0, max_probe_dg=-11.0)),
                             # dangling-end options: the threshold carries the most a dangling / frayed end can add
-                            (2, 20000, 96, dict(allow_dangle_5=1, allow_dangle_3=1))]:
+                            (2, 20000, 96, dict(allow_dangle_5=1, allow_dangle_3=1)),
+                            # inosine in the targets (one base in 300): the windows that hold one are filtered like IUPAC windows
+                            (2, 20000, 96, dict(inosine=1))]:
         wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=31)
+        if kw.pop("inosine", 0):
+            where = np.random.default_rng(8).random(len(wl.codes)) < 1.0 / 300.0
+            wl.codes[where] = abi.DB_CODES.index("I")
+            kw = {}
+            inosine = True
+        else:
+            inosine = False
         for k_, v_ in kw.items():
             setattr(wl.options, k_, v_)
         res = {}
@@ -205,7 +215,7 @@ def test_filter_changes_no_result(Engine, oracle, monkeypatch):
             db.close()
             e.close()
         assert res["on"] == res["off"] == res["audit"] and len(res["on"]) > 0
-        if cfg == 2:
+        if cfg == 2 or inosine:
             assert res["on"] == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
 
 

@@ -31,7 +31,7 @@
 namespace tnt {
 
 constexpr int FILT_X = 6;                        // target base of a column: A C G T, 4 = none (before the first column / behind the window),
-constexpr int FILT_NONE = 4, FILT_ANY = 5;       // 5 = an IUPAC code: whatever resolve_degenerate (nuc_cruc.cpp:14-201) makes of it is one of A C G T
+constexpr int FILT_NONE = 4, FILT_ANY = 5;       // 5 = an IUPAC code (whatever resolve_degenerate, nuc_cruc.cpp:14-201, makes of it is one of A C G T) or inosine
 constexpr int FILT_ENTRIES = FILT_X * FILT_X * NBP; // index ((x' * 6 + x) * 49 + q' * 7 + q): previous column / row = (x', q'), current = (x, q)
 constexpr int FILT_PLANE = 28 * 64;              // entries per class (>= FILT_ENTRIES)
 constexpr int FILT_CLASSES = 2;                  // threshold sets by minimum Tm: primers, probes
@@ -87,8 +87,9 @@ __device__ __forceinline__ int filter_class(int thresh_index) { return thresh_in
 
 // DEGEN: the instance for windows that may hold non-ACGT target codes (the general buckets).  An IUPAC code (M R S V W Y H K
 // D B N) is resolved per aligned pair to one of A C G T (resolve_degenerate), so its column takes, entry by entry, the
-// maximum over the four bases (the ANY rows of the table): still an upper bound.  Inosine in the target and codes the
-// window loader skips (gap, unknown: bind_oligo.cpp, Q6) are not modelled: such a window passes unfiltered.
+// maximum over the four bases (the ANY rows of the table): still an upper bound.  Inosine in the target takes the same column
+// value (the ANY rows are the maximum over A C G T I).  Codes the window loader skips (gap, unknown: bind_oligo.cpp, Q6) are
+// not modelled: such a window passes unfiltered.
 // wave-synchronous LDS hand-off inside one wavefront
 __device__ __forceinline__ void filt_wave_sync()
 {
@@ -196,7 +197,7 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 				}
 				for (uint32_t x = lo; x < e1 && a.db.exc_pos[x] < uint32_t(stop); x++) {
 					const int code = a.db.exc_code[x];
-					if (code < 5 || code > 15) unfilterable = true; // inosine; skipped codes (the window shrinks)
+					if (code > 15) unfilterable = true; // skipped codes (the window shrinks); inosine (4) and the IUPAC codes read as ANY
 					const int r = int(a.db.exc_pos[x]) - start;
 #pragma unroll
 					for (int k = 0; k < NW; k++)

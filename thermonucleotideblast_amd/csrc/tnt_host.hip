@@ -304,38 +304,40 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 				if (wc[pm] && pm / NB <= bI && pm % NB <= bI) u1[c] = std::max(u1[c], phi(pm, c));
 			u1[c] += gap_price - pb1;
 		}
-		for (int xp = 0; xp < 4; xp++)
-			for (int x = 0; x < 4; x++)
-				for (int qp = bA; qp <= bI; qp++)
-					for (int q = bA; q <= bI; q++) {
-						// the sweep runs against the order evaluate_alignment reads the columns in: cell (i, j) = (q, x) comes
-						// first there, its diagonal neighbour (i-1, j-1) = (q', x') second
-						const int first = q * NB + x, second = qp * NB + xp;
-						const int at = (xp * FILT_X + x) * NBP + qp * NB + q;
-						const double f = phi(first, second);
-						const double fpos = (wc[first] || wc[second]) ? std::max(f, 0.0) : 0.0; // a stack inside a loop is never credited
-						v[at][0] = units(fpos);
-						if (wc[second]) // a loop / bulge is closed by a Watson-Crick column
-							v[at][1] = units(std::max(std::max(f, 0.0), u1[second]) - gap_price);
+		// the two table values of (previous column, current column) = ((x', q'), (x, q)), target bases as codes A C G T I.
+		// The sweep runs against the order evaluate_alignment reads the columns in: cell (i, j) = (q, x) comes first there, its
+		// diagonal neighbour (i-1, j-1) = (q', x') second.
+		auto cell = [&](int xp, int x, int qp, int q, int k) {
+			const int first = q * NB + x, second = qp * NB + xp;
+			const double f = phi(first, second);
+			if (k == 0) return units((wc[first] || wc[second]) ? std::max(f, 0.0) : 0.0); // a stack inside a loop is never credited
+			if (!wc[second]) return int(FILT_NEG);                                          // a loop / bulge is closed by a Watson-Crick column
+			return units(std::max(std::max(f, 0.0), u1[second]) - gap_price);
+		};
+		// A column that holds an IUPAC code (FILT_ANY) is resolved per aligned pair to one of A C G T (resolve_degenerate,
+		// nuc_cruc.cpp:14-201), so the maximum over the four bases bounds whatever it picks, in either role of the column.
+		// Inosine in the TARGET (seq.h DB_I) takes the same column value: the maximum runs over A C G T I.
+		for (int qp = bA; qp <= bI; qp++)
+			for (int q = bA; q <= bI; q++)
+				for (int k = 0; k < 2; k++) {
+					auto at = [&](int xp, int x) { return (xp * FILT_X + x) * NBP + qp * NB + q; };
+					int all = INT32_MIN;
+					for (int xp = bA; xp <= bI; xp++) {
+						int row = INT32_MIN;
+						for (int x = bA; x <= bI; x++) {
+							const int c = cell(xp, x, qp, q, k);
+							row = std::max(row, c), all = std::max(all, c);
+							if (xp < 4 && x < 4) v[at(xp, x)][k] = c;
+						}
+						if (xp < 4) v[at(xp, FILT_ANY)][k] = row; // (x', ANY)
 					}
-		// columns that hold an IUPAC code (FILT_ANY): resolve_degenerate turns the code into one of A C G T per aligned pair
-		// (nuc_cruc.cpp:14-201), so the maximum over the four bases bounds whatever it picks -- in either role of the column
-		for (int qq = 0; qq < NBP; qq++) {
-			auto at = [&](int xp, int x) { return (xp * FILT_X + x) * NBP + qq; };
-			for (int k = 0; k < 2; k++) {
-				for (int xp = 0; xp < 4; xp++) { // (x', ANY)
-					int m = v[at(xp, 0)][k];
-					for (int x = 1; x < 4; x++) m = std::max(m, v[at(xp, x)][k]);
-					v[at(xp, FILT_ANY)][k] = m;
+					for (int x = bA; x <= bT; x++) { // (ANY, x)
+						int col = INT32_MIN;
+						for (int xp = bA; xp <= bI; xp++) col = std::max(col, cell(xp, x, qp, q, k));
+						v[at(FILT_ANY, x)][k] = col;
+					}
+					v[at(FILT_ANY, FILT_ANY)][k] = all;
 				}
-				for (int x = 0; x < FILT_X; x++) { // (ANY, x), x = ANY included (its column of the table was filled above)
-					if (x == FILT_NONE) continue;
-					int m = v[at(0, x)][k];
-					for (int xp = 1; xp < 4; xp++) m = std::max(m, v[at(xp, x)][k]);
-					v[at(FILT_ANY, x)][k] = m;
-				}
-			}
-		}
 		for (int i = 0; i < FILT_PLANE; i++) F.plane[cls][i] = pack(v[i][0], v[i][1]);
 		const double g_init = double(T.init_H) - Tk * double(T.init_S);
 		const double g_at = double(T.at_H) - Tk * double(T.at_S);
