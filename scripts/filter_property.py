@@ -19,6 +19,7 @@ SETS = [(name, kw, {}) for name, kw in T.OPTION_SETS]
 # inosine-bearing windows (every target gets one to three letters, 70 % of them inosines), against a Tm, a dG and a dangle set
 SETS += [(T.OPTION_SETS[k][0] + ", inosine in the targets", T.OPTION_SETS[k][1], dict(degen=1.0, inosine=0.7)) for k in (0, 5, 9)]
 only = sys.argv[2] if len(sys.argv) > 2 else ""  # substring of the names of the sets to run
+SETS += [(name, kw, dict(lo=65, hi=128)) for name, kw in T.LONG_OLIGO_SETS]
 for k, (name, kw, wkw) in enumerate(SETS):
     if only not in name:
         continue

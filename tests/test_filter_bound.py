@@ -143,6 +143,25 @@ def test_filter_with_inosine_in_the_target(oracle, k):
     assert res["rejected_by_filter"] > 0
 
 
+# thresholds a run with long hybridisation probes / MIPS arms would set (at -e 40 an unrelated 120-base window already reaches the
+# bound: 2 % rejected; at -e 60 three quarters of the windows that fail are rejected)
+LONG_OLIGO_SETS = [
+    ("-e 60 -E 60, oligos of 65-128 bases", dict(min_primer_tm=60.0, min_probe_tm=60.0)),
+    ("-e 40 -E 70, oligos of 65-128 bases", dict(min_primer_tm=40.0, min_probe_tm=70.0)),
+    ("-g -25 -G -25, no minimum Tm, oligos of 65-128 bases", dict(min_primer_tm=0.0, min_probe_tm=0.0, max_primer_dg=-25.0, max_probe_dg=-25.0)),
+]
+
+
+@pytest.mark.parametrize("k", range(len(LONG_OLIGO_SETS)))
+def test_filter_with_oligos_of_65_to_128_bases(oracle, k):
+    """The same bound (bulges up to the longest window, loops up to 2 x 128 + the window are priced; perfect sites saturate
+    the 16-bit sums and pass)."""
+    n = int(os.environ.get("TNT_FILTER_PROPERTY_N", "40000")) // 8
+    name, kw = LONG_OLIGO_SETS[k]
+    res = check_option_set(oracle, name, kw, n, 200 + k, lo=65, hi=128)
+    assert res["rejected_by_filter"] > n // 100
+
+
 def test_filter_is_off_where_its_premises_fail(oracle):
     rng = np.random.default_rng(5)
     oligos, targets, rows = make_windows(rng, 200)

@@ -149,16 +149,21 @@ def test_random_windows_production_vs_oracle(Engine, oracle, seed, kw):
     e.close()
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 8, 9, 11])
+@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 8, 9, 11, 100, 102])
 def test_filter_kernel_equals_its_checker(Engine, oracle, k):
     """The pre-filter kernel (every row-count instance the oligo lengths pick) against the oracle-side restatement whose
     soundness tests/test_filter_bound.py checks: same bound, same threshold, for every window."""
     import test_filter_bound as fbt
-    name, kw = fbt.OPTION_SETS[k]
+    long_oligos = k >= 100  # (100, 102: a Tm and a dG set for oligos of 65 to 128 bases -- the 128-row instances)
+    k %= 100
+    name, kw = fbt.LONG_OLIGO_SETS[k] if long_oligos else fbt.OPTION_SETS[k]
     rng = np.random.default_rng([99, k])
     opt = abi.options_default(**kw)
     # (sets 1, 5, 9 -- a Tm, a dG and a dangle set -- on windows full of inosines: the column value ANY)
-    oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=64, **(dict(degen=0.8, inosine=0.6) if k in (1, 5, 9) else {}))
+    if long_oligos:
+        oligos, targets, rows = fbt.make_windows(rng, 6000, lo=65, hi=128)
+    else:
+        oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=64, **(dict(degen=0.8, inosine=0.6) if k in (1, 5, 9) else {}))
     if k == 2:  # some degenerate target bases: those windows are outside the filter
         targets = [t if i % 7 else t[:5] + "N" + t[6:] for i, t in enumerate(targets)]
     rows = [r[:6] + ((opt.probe_strand if r[5] else opt.primer_strand),) for r in rows]
@@ -321,16 +326,29 @@ def test_first_cull_vs_oracle(Engine, oracle, cfg, nt, na, seed, kw):
 
 
 @pytest.mark.parametrize("kind,seed", [("probe", 1), ("probe", 2), ("padlock", 3), ("pcr", 4), ("pcr", 5)])
-def test_long_oligos_vs_oracle(Engine, oracle, kind, seed):
-    """Oligos of 65..128 bases run through the 128-row instances (rows in scratch memory, no pre-filter): binds through all
-    three routes and complete searches against the oracle (itself held against the reference on the same workloads,
-    tests/test_oracle_vs_reference.py::test_long_oligos); 129 bases are refused."""
+def test_long_oligos_vs_oracle(Engine, oracle, kind, seed, monkeypatch):
+    """Oligos of 65..128 bases run through the 128-row instances (rows in scratch memory): binds through all three routes and
+    complete searches against the oracle (itself held against the reference on the same workloads,
+    tests/test_oracle_vs_reference.py::test_long_oligos); 129 bases are refused.  The 128-row pre-filter is used when the
+    context's calibration finds that it rejects a quarter of its sample: the search is repeated with it forced on, forced
+    on in audit mode (every window bound; an accepted window the filter had marked is an error) and forced off."""
     import longwl
     wl = longwl.make(kind, seed)
     oligos = sorted({o for x in wl.expanded for o in (x.forward, x.reverse, x.probe) if o})
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    for force, audit in (("1", True), ("1", False), ("0", False)):
+        monkeypatch.setenv("TNT_MI355X_FILTER_LONG", force)
+        if audit:
+            monkeypatch.setenv("TNT_MI355X_FILTER_AUDIT", "1")
+        e2 = Engine(wl.options, wl.expanded)
+        db2 = e2.pack(wl.codes, wl.offsets)
+        assert tc.sorted_hit_keys(e2.search(db2)) == want, (force, audit)
+        db2.close()
+        e2.close()
+        monkeypatch.delenv("TNT_MI355X_FILTER_AUDIT", raising=False)
+    monkeypatch.delenv("TNT_MI355X_FILTER_LONG")
     e = Engine(wl.options, wl.expanded)
     db = e.pack(wl.codes, wl.offsets)
-    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
     assert tc.sorted_hit_keys(e.search(db)) == want and len(want) > 10
     sa = oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
     rows = [(s[0], s[1], s[2], s[3], s[4], i % 2, 9e-7 if i % 3 else 2.5e-7) for i, s in enumerate(sa[:5000])]

@@ -7,7 +7,7 @@
 #include "tnt_filter.hip.h"
 
 #ifndef TNT_INST_LIST
-#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_LONG_LADDER(G) TNT_LONG_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F) TNT_LMAX_LADDER(D)
+#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_LONG_LADDER(G) TNT_LONG_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F) TNT_LMAX_LADDER(D) TNT_LONG_LADDER(F) TNT_LONG_LADDER(D)
 #endif
 
 namespace tnt {

@@ -97,7 +97,7 @@ struct Slot {
 // general ones for windows with degenerate target bases and for short queues that are bound in one launch
 #define TNT_LMAX_LADDER(X) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
 // oligos of 65 to 128 bases (long hybridisation probes, MIPS arms): the same two flavours, rows mostly in scratch memory;
-// they do not meet the pre-filter
+// they meet the pre-filter (128-row instances of the F / D kinds) when the context's calibration says it pays
 #define TNT_LONG_LADDER(X) X(128)
 // instances of the pre-filter kernel (tnt_filter.hip.h): the row counts of both ladders above
 #define TNT_FILTER_LADDER(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)

@@ -264,7 +264,11 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 		// The maximum of X over the window needs no instruction per cell: X never decreases along a diagonal (the stack
 		// term is >= 0, also through the padding rows and columns), so it is reached in the last row or the last column.
 		const s2 EDGE = {0, short(FILT_NEG)}; // a cell outside the matrix: X = 0, M2 = none
-		s2 PA[LMAX], PB[LMAX];
+		// (instances of more than 64 rows -- oligos of 65 to 128 bases -- update one register set in place: a column reads the
+		// cell to its left before it writes its own, so the alternate set is only there to spare the short instances a
+		// dependency; 128 rows of it would not fit the register file)
+		constexpr bool INPLACE = LMAX > 64;
+		s2 PA[LMAX], PB[INPLACE ? 1 : LMAX];
 #pragma unroll
 		for (int i = 0; i < LMAX; i++) PA[i] = EDGE;
 		s2 bestpk = EDGE;
@@ -294,8 +298,8 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
 			const int t1 = j < W ? column_base(j + 1) : FILT_NONE;     // column j + 1 (none: behind the window, or padding of an odd width)
 			const int t2 = j + 1 < W ? column_base(j + 2) : FILT_NONE; // column j + 2
-			column(PA, PB, tab_base + (tp * FILT_X + t) * (NBP * 4));
-			column(PB, PA, tab_base + (t * FILT_X + t1) * (NBP * 4));
+			column(PA, INPLACE ? PA : PB, tab_base + (tp * FILT_X + t) * (NBP * 4));
+			column(INPLACE ? PA : PB, PA, tab_base + (t * FILT_X + t1) * (NBP * 4));
 			tp = t1, t = t2;
 		}
 #pragma unroll
@@ -361,9 +365,11 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 // host-side launchers, defined in tnt_bind_inst.hip next to the bind kernel instances of the same lengths
 #define X(N) void launch_filter_##N(const FilterArgs2 &a, int blocks, hipStream_t stream);
 TNT_FILTER_LADDER(X)
+TNT_LONG_LADDER(X)
 #undef X
 #define X(N) void launch_filter_degen_##N(const FilterArgs2 &a, int blocks, hipStream_t stream);
 TNT_LMAX_LADDER(X)
+TNT_LONG_LADDER(X)
 #undef X
 
 } // namespace tnt

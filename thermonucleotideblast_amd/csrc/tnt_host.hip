@@ -553,6 +553,8 @@ struct tnt_ctx {
 	FilterTables h_ftab;
 	DevBuf<FilterTables> ftab;
 	bool filter_on = false, filter_audit = false;
+	bool filter_long = true; // the 128-row pre-filter instances are worth their time (calibrate_long_filter)
+	float filter_long_rate = -1.0f; // share of the calibration windows they rejected (-1: not measured)
 	bool filter_status_exact = false; // set around launches whose caller reports statuses (tnt_bind_batch_routed)
 	bool serial_bind = false; // profiling: every launch of the bind stage on one side stream (per-kernel durations add up to the stage time)
 	DevBuf<uint8_t> olig_base;
@@ -785,6 +787,7 @@ bool has_filter_instance(int rows, bool degen)
 		switch (rows) {
 #define X(N) case N: return true;
 			TNT_LMAX_LADDER(X)
+			TNT_LONG_LADDER(X)
 #undef X
 		default: return false;
 		}
@@ -792,6 +795,7 @@ bool has_filter_instance(int rows, bool degen)
 	switch (rows) {
 #define X(N) case N: return true;
 		TNT_FILTER_LADDER(X)
+		TNT_LONG_LADDER(X)
 #undef X
 	default: return false;
 	}
@@ -803,6 +807,7 @@ void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t strea
 		switch (rows) {
 #define X(N) case N: tnt::launch_filter_degen_##N(a, blocks, stream); break;
 			TNT_LMAX_LADDER(X)
+			TNT_LONG_LADDER(X)
 #undef X
 		default: break;
 		}
@@ -811,6 +816,7 @@ void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t strea
 	switch (rows) {
 #define X(N) case N: tnt::launch_filter_##N(a, blocks, stream); break;
 		TNT_FILTER_LADDER(X)
+		TNT_LONG_LADDER(X)
 #undef X
 	default: break;
 	}
@@ -880,8 +886,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
 		b.n_items = uint32_t(c->item_cap); // cap on the device count
 		b.audit = nullptr;
-		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) &&
-		    has_filter_instance(c->bucket_lmax[i] & 0xFF, !(c->bucket_lmax[i] & BUCKET_PLAIN))) { // (none beyond 64 rows: such a bucket goes to the bind kernel as it is)
+		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) && ((c->bucket_lmax[i] & 0xFF) <= 64 || c->filter_long) &&
+		    has_filter_instance(c->bucket_lmax[i] & 0xFF, !(c->bucket_lmax[i] & BUCKET_PLAIN))) {
 			// every window first meets the pre-filter: what cannot reach the minimum Tm is rejected there, the rest of the
 			// bucket is compacted into qsurv (same offset) and bound by the full kernel.  (The general buckets -- windows
 			// with degenerate target bases, merged short queues -- go through the instance that reads the exception lists.)
@@ -1083,6 +1089,66 @@ void tnt_options_default(tnt_options *o) // options.h:85-170, tntblast.h:19-76
 }
 
 const char *tnt_last_error(const tnt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+// The pre-filter of oligos of 65 to 128 bases costs a fifth of the bind it spares (5 ns against 22 ns per window), and whether it
+// spares any hangs on the thresholds: against -E 40 an unrelated 120-base window already reaches the bound (0.7 % rejected: the
+// search is a fifth SLOWER with the filter), against -E 60 nine windows in ten are rejected (three times faster).  So a context
+// with such oligos measures it once: the filter kernel itself on 2 048 random windows that share an 8-mer with their oligo (what
+// a seed hands over), thresholds and strand concentrations of the context's own slots; the long instances are used when they
+// reject a quarter of them.  TNT_MI355X_FILTER_LONG=0 / 1 overrides.
+static int calibrate_long_filter(tnt_ctx *c)
+{
+	if (const char *e = getenv("TNT_MI355X_FILTER_LONG")) {
+		c->filter_long = atoi(e) != 0;
+		return TNT_OK;
+	}
+	std::vector<const Slot *> longs;
+	for (const Slot &sl : c->h_slots)
+		if (sl.oligo >= 0 && c->oligos[size_t(sl.oligo)].size() > 64 && longs.size() < 64) longs.push_back(&sl);
+	if (longs.empty() || !c->filter_on) return TNT_OK;
+	const size_t N = 2048, TLEN = 320;
+	std::vector<uint8_t> codes(N * TLEN);
+	std::vector<uint64_t> offsets(N + 1);
+	std::vector<tnt_bind_req> req(N);
+	uint64_t state = 0x9E3779B97F4A7C15ull; // (fixed: the same decision for the same context every time)
+	auto next = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return uint32_t(state >> 33);
+	};
+	for (size_t i = 0; i <= N; i++) offsets[i] = i * TLEN;
+	for (size_t i = 0; i < N; i++) {
+		const Slot &sl = *longs[i % longs.size()];
+		const std::string &q = c->oligos[size_t(sl.oligo)];
+		uint8_t *t = codes.data() + i * TLEN;
+		for (size_t k = 0; k < TLEN; k++) t[k] = uint8_t(next() & 3u);
+		// an 8-mer of the oligo, reverse-complemented, where the window's seed would sit (plus-strand binding)
+		const int ql = int(next() % uint32_t(q.size() - 8)), at = 150;
+		for (int k = 0; k < 8; k++) {
+			int b = -1;
+			switch (q[size_t(ql + 7 - k)]) {
+			case 'A': case 'a': b = 3; break;
+			case 'C': case 'c': b = 2; break;
+			case 'G': case 'g': b = 1; break;
+			case 'T': case 't': b = 0; break;
+			default: break;
+			}
+			if (b >= 0) t[at + k] = uint8_t(b);
+		}
+		req[i] = tnt_bind_req{int32_t(i), sl.oligo, TNT_PLUS, std::min(ql, 127), at, sl.thresh == 0 ? 0 : 1, expf(sl.log_ct)};
+	}
+	tnt_db *db = nullptr;
+	int rc = tnt_db_create(c, codes.data(), offsets.data(), N, 0, &db);
+	if (rc) return rc;
+	std::vector<int32_t> score(2 * N);
+	rc = tnt_filter_bound(c, db, req.data(), N, score.data());
+	tnt_db_destroy(db);
+	if (rc) return rc;
+	size_t rejected = 0;
+	for (size_t i = 0; i < N; i++) rejected += (score[2 * i] < score[2 * i + 1] && score[2 * i] < FILT_SAT) ? 1 : 0;
+	c->filter_long_rate = float(double(rejected) / double(N));
+	c->filter_long = c->filter_long_rate >= 0.25f;
+	return TNT_OK;
+}
 
 int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_assays, int device, tnt_ctx **out)
 {
@@ -1365,6 +1431,13 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	    (e = c->wl_seq.upload(wl_seq)) != hipSuccess || (c->h_wl_seq = wl_seq, false) ||
 	    (e = c->wlist.upload(wlist)) != hipSuccess)
 		FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
+	if (max_L > 64) {
+		const int crc = calibrate_long_filter(c);
+		if (crc) {
+			const std::string why = c->err.empty() ? std::string("calibration of the long pre-filter failed") : c->err;
+			FAIL(crc, why);
+		}
+	}
 #undef FAIL
 	*out = c;
 	return TNT_OK;
