@@ -235,7 +235,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits);
 /* The hits of the last collected search where the pair kernel left them, in device memory (same records, same order as
  * the host copy): what a multi-GPU driver hands to RCCL without a round trip through the host (the reference's master
  * receives packed hit lists from its MPI workers, tntblast_master.cpp:811-828).  Valid until the next search on this
- * context.  TNT_E_UNSUPPORTED when the host copy was post-processed (duplicate removal for windowed long targets). */
+ * context.  (The hits of targets that are seeded in windows are paired on host threads and copied behind the device's own.) */
 int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hits);
 
 /* The same hits in compact form, packed on the device: what the gather of a multi-GPU run sends (about 350 bytes per hit

@@ -866,6 +866,33 @@ def test_torch_coexists_with_the_library(Engine):
     e.close()
 
 
+def test_hits_of_windowed_targets_have_a_device_copy(Engine):
+    """Targets seeded in windows are paired on host threads; their hits are copied behind the device's own, so that the
+    device view and the compact form (what the multi-GPU gather sends) hold every hit of such a database too."""
+    import torch
+    from thermonucleotideblast_amd import shard
+    wl = synth.make_workload(2, n_targets=3000, n_assays=24, seed=33)
+    lens = np.diff(wl.offsets.astype(np.int64))
+    cut = 2000  # one 2-Mb record in front of 1 000 short ones
+    offsets = np.array([0, int(lens[:cut].sum())] + [int(lens[:cut + i + 1].sum()) for i in range(len(lens) - cut)], dtype=np.uint64)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    e.enqueue(db)
+    hits = e.collect(copy=False)
+    assert len([h for h in hits if h.seq_index == 0]) > 5 and len([h for h in hits if h.seq_index > 0]) > 5
+    dev = e.hits_device()
+    assert dev is not None and dev[1] == len(hits)
+    nbytes = len(hits) * C.sizeof(abi.tnt_hit)
+    t = torch.as_tensor(shard._DeviceBytes(dev[0], nbytes), device="cuda")
+    assert bytes(t.cpu().numpy().tobytes()) == bytes(np.frombuffer(hits, dtype=np.uint8).tobytes())
+    comp = e.hits_compact()
+    assert comp is not None and comp[2] == len(hits)
+    blob = bytes(torch.as_tensor(shard._DeviceBytes(comp[0], comp[1]), device="cuda").cpu().numpy().tobytes())
+    assert blob == shard.pack_hits(hits)
+    db.close()
+    e.close()
+
+
 def test_hits_device_view_matches_host_copy(Engine):
     """tnt_search_hits_device: the records the multi-GPU gather takes from device memory are the host records."""
     import torch

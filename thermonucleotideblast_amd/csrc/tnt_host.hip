@@ -3072,6 +3072,14 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 			}
 			memcpy(ctx->h_hits + n, extra.data(), extra.size() * sizeof(tnt_hit));
 			n_unique = total;
+			// the device copy follows (tnt_search_hits_device / _compact: the multi-GPU gather takes the records from there)
+			if (total > ctx->hit_cap) {
+				ctx->hit_cap = total + total / 2;
+				HIP_TRY(ctx->hits.alloc(ctx->hit_cap), ctx->err);
+				HIP_TRY(hipMemcpy(ctx->hits.p, ctx->h_hits, total * sizeof(tnt_hit), hipMemcpyHostToDevice), ctx->err);
+			} else {
+				HIP_TRY(hipMemcpy(ctx->hits.p + n, ctx->h_hits + n, extra.size() * sizeof(tnt_hit), hipMemcpyHostToDevice), ctx->err);
+			}
 		}
 	}
 	// stage timings
@@ -3094,8 +3102,8 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n_unique;
 	T.n_filtered = cnt[C_FILTERED];
-	ctx->dev_hits_valid = n_unique == n; // hits of long targets only exist on the host
-	ctx->dev_hits_n = n;
+	ctx->dev_hits_valid = true; // (the hits of long targets, paired on the host, were copied behind the device's own)
+	ctx->dev_hits_n = n_unique;
 	if (hits) *hits = ctx->h_hits;
 	if (n_hits) *n_hits = n_unique;
 	return TNT_OK;

@@ -305,8 +305,8 @@ class Engine:
         return out
 
     def hits_device(self):
-        """(device pointer, count) of the last collected search's hit records as the pair kernel left them, or None
-        when the host copy was post-processed (windowed long targets): see tnt_search_hits_device."""
+        """(device pointer, count) of the last collected search's hit records in device memory (those of targets seeded in
+        windows, paired on host threads, are copied behind the pair kernel's own): see tnt_search_hits_device."""
         ptr = C.c_void_p()
         n = C.c_size_t()
         rc = self.lib.tnt_search_hits_device(self._h, C.byref(ptr), C.byref(n))
@@ -316,8 +316,7 @@ class Engine:
         return (ptr.value or 0), n.value
 
     def hits_compact(self):
-        """(device pointer, bytes, count) of the last collected search's hits in compact form (tnt_search_hits_compact),
-        or None when the host copy was post-processed (windowed long targets)."""
+        """(device pointer, bytes, count) of the last collected search's hits in compact form (tnt_search_hits_compact)."""
         ptr, nb, n = C.c_void_p(), C.c_size_t(), C.c_size_t()
         rc = self.lib.tnt_search_hits_compact(self._h, C.byref(ptr), C.byref(nb), C.byref(n))
         if rc == -4:  # TNT_E_UNSUPPORTED
