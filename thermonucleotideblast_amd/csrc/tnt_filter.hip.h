@@ -175,7 +175,7 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 			const uint32_t *pk = a.fat ? a.db.packed + fe.y : a.db.packed + (active ? a.db.word_off[it.target] : 0ull) + uint32_t(start >> 4);
 			uint32_t raw[NW + 1];
 #pragma unroll
-			for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u; // rows are padded and the array has eight words of slack behind its end (NW + 1 <= 6 words are read)
+			for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u; // rows are padded and the array has sixteen words of slack behind its end (NW + 1 <= 10 words are read)
 			const uint32_t sh = uint32_t(start & 15) * 2u;
 #pragma unroll
 			for (int k = 0; k < NW; k++) wv[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);

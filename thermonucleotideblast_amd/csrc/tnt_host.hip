@@ -535,6 +535,8 @@ struct tnt_ctx {
 	int lanes = 4;
 	hipStream_t lane_stream[BIND_LANES] = {};
 	hipEvent_t lane_done[BIND_LANES] = {};
+	bool split_filter = false;                 // all pre-filter launches on lane 0, the bind launches behind them on the other lanes (TNT_MI355X_SPLIT_FILTER)
+	hipEvent_t filtered[MAX_BUCKETS] = {};      // split_filter: bucket i has met its pre-filter
 	hipEvent_t phase_ready = nullptr;
 	size_t lane_trace = 0, lane_cols = 0, lane_ties = 0; // scratch elements per lane
 
@@ -655,6 +657,8 @@ struct tnt_ctx {
 	{
 		for (hipEvent_t e : events) (void)hipEventDestroy(e);
 		if (h_hits) (void)hipHostFree(h_hits);
+		for (hipEvent_t ev : filtered)
+			if (ev) (void)hipEventDestroy(ev);
 		for (int i = 0; i < BIND_LANES; i++) {
 			if (lane_done[i]) (void)hipEventDestroy(lane_done[i]);
 			if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
@@ -711,6 +715,7 @@ static size_t cap_from_env(const char *name, size_t dflt_m)
 static const size_t ITEM_CAP_MAX = cap_from_env("TNT_MI355X_ITEM_CAP_M", 768);  // bind work items per internal batch: the most a context allocates
 static const size_t GROUP_CAP_MAX = cap_from_env("TNT_MI355X_GROUP_CAP_M", 256); // (tnt_ctx::item_cap / group_cap: what it has, sized by the databases it met)
 constexpr size_t POOL_CAP = size_t(4) << 20;
+constexpr size_t PACKED_SLACK = 16; // zero words behind the packed targets: a window loader reads (MAX_OLIGO + 2 * FLANK + 15) / 16 + 1 = 10 words from its first word
 
 DbView make_view(const tnt_db *db, size_t t0, size_t t1)
 {
@@ -875,7 +880,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		// general instances other than the last (merge) bucket only see windows with degenerate bases
 		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) continue;
 		if (direct && c->h_q_cap[i] == 0) continue; // no slot routes its items here
-		const int lane = c->serial_bind ? 0 : n_launch++ % c->lanes;
+		const bool split = c->split_filter && !c->serial_bind && c->lanes >= 2;
+		const int lane = c->serial_bind ? 0 : (split ? 1 + n_launch++ % (c->lanes - 1) : n_launch++ % c->lanes);
 		if (c->serial_bind) n_launch = 1;
 		// (direct: the queue holds 16-byte entries whose first word is the item index)
 		const uint32_t *queue = direct ? reinterpret_cast<const uint32_t *>(c->S().qfat.p + c->h_q_base[i]) : c->S().qbucket.p;
@@ -911,7 +917,12 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.n_rejected = gcnt + C_FILTERED;
 			f.audit = c->filter_audit ? c->S().audit.p : nullptr;
 			f.status_exact = c->filter_status_exact ? 1 : 0;
-			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
+			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[split ? 0 : lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
+			if (split) { // the filter kernels, each of which fills the device, queue up on lane 0; the bind launches follow theirs on the other lanes
+				if (!c->filtered[i]) (void)hipEventCreateWithFlags(&c->filtered[i], hipEventDisableTiming);
+				(void)hipEventRecord(c->filtered[i], c->lane_stream[0]);
+				(void)hipStreamWaitEvent(c->lane_stream[lane], c->filtered[i], 0);
+			}
 			b.index = survivors;
 			b.index_stride = 1;
 			b.n_items_dev = f.n_survivors;
@@ -923,7 +934,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.ties = c->ties.p + size_t(lane) * c->lane_ties;
 		launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
 	}
-	for (int l = 0; l < c->lanes && l < n_launch; l++) {
+	for (int l = 0; l < c->lanes && (l < n_launch || c->split_filter); l++) {
 		(void)hipEventRecord(c->lane_done[l], c->lane_stream[l]);
 		(void)hipStreamWaitEvent(c->stream, c->lane_done[l], 0);
 	}
@@ -1185,6 +1196,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	if (const char *e = getenv("TNT_MI355X_HIT_CAP")) // initial capacity of the hit buffer (it grows on demand)
 		c->hit_cap = std::max<size_t>(16, strtoull(e, nullptr, 10));
 	if (const char *e = getenv("TNT_MI355X_BIND_LANES")) c->lanes = std::max(1, std::min(int(tnt_ctx::BIND_LANES), atoi(e)));
+	c->split_filter = getenv("TNT_MI355X_SPLIT_FILTER") != nullptr;
 	for (int i = 0; i < c->lanes; i++)
 		if (hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->lane_done[i], hipEventDisableTiming) != hipSuccess)
@@ -1571,7 +1583,7 @@ int tnt_db_create(tnt_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, s
 		words += ((len + 15) / 16 + 3) / 4 * 4; // 16-byte aligned rows: a wavefront reads whole dwordx4 lines
 	}
 	db->h_word_off[n_targets] = words;
-	db->h_packed.assign(words + 8, 0u); // slack: the window loaders read up to six words from a window's first word
+	db->h_packed.assign(words + PACKED_SLACK, 0u); // slack: the window loaders read up to ten words from a window's first word (the 128-row pre-filter)
 	// exceptions: count first (codes > 3 keep their low two bits in the stream)
 	std::vector<uint32_t> exc_count(n_targets + 1, 0);
 	parallel_for(n_targets, [&](size_t t) {
@@ -1862,10 +1874,10 @@ int tnt_db_create_from_fasta(tnt_ctx *ctx, const char *text, size_t n_bytes, uin
 	}
 	db->h_word_off[n] = words;
 	db->n_exceptions = db->h_exc_off[n];
-	if ((e = db->packed.alloc(words + 8)) != hipSuccess || (e = db->word_off.upload(db->h_word_off)) != hipSuccess ||
+	if ((e = db->packed.alloc(words + PACKED_SLACK)) != hipSuccess || (e = db->word_off.upload(db->h_word_off)) != hipSuccess ||
 	    (e = db->exc_off.upload(db->h_exc_off)) != hipSuccess || (e = db->exc_pos.alloc(std::max<uint64_t>(1, db->n_exceptions))) != hipSuccess ||
 	    (e = db->exc_code.alloc(std::max<uint64_t>(1, db->n_exceptions))) != hipSuccess ||
-	    (e = hipMemsetAsync(db->packed.p, 0, (words + 8) * sizeof(uint32_t), ctx->stream)) != hipSuccess) {
+	    (e = hipMemsetAsync(db->packed.p, 0, (words + PACKED_SLACK) * sizeof(uint32_t), ctx->stream)) != hipSuccess) {
 		ctx->err = std::string("target allocation: ") + hipGetErrorString(e);
 		return TNT_E_DEVICE;
 	}
