@@ -261,7 +261,7 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
  * cull_oligo_match (amplicon_search.cpp:96-131, :679-765) = the work items the bind stage is handed.  Rows of seven ints:
  * seq_index, assay (position in the context's assay list), role (0 forward, 1 reverse, 2 probe), strand, query_loc,
  * target_loc, and 1 when the minus strand is bound first (:131).  The array belongs to the context (valid until the next
- * call).  Targets that are seeded in windows are culled on the host: TNT_E_UNSUPPORTED for a database that holds one. */
+ * call).  Targets that are seeded in windows: their lists are assembled and culled whole on the device (same rows). */
 int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_rows);
 int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out);
 /* The same requests through the kernels tnt_search() runs (bind_oligo.cpp:502-748 for each): TNT_ROUTE_BUCKETS splits

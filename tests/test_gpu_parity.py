@@ -325,6 +325,31 @@ def test_first_cull_vs_oracle(Engine, oracle, cfg, nt, na, seed, kw):
     e.close()
 
 
+@pytest.mark.parametrize("cfg,kw,host", [(2, {}, False), (3, {}, False), (3, {"max_len": 400}, False), (2, {"single_primer_pcr": 0}, False),
+                                         (3, {"single_primer_pcr": 0}, False), (3, {}, True)])
+def test_first_cull_of_windowed_targets_vs_oracle(Engine, oracle, cfg, kw, host, monkeypatch):
+    """The same rows for targets that are seeded in windows: their lists are assembled and culled on the device
+    (nearest-element scans over the whole list, tnt_sort.hip; `host`: the replay of cull_oligo_match on host threads) --
+    every kept seed and the strand its list binds first, against the oracle's list-based restatement."""
+    wl = synth.make_workload(cfg, n_targets=700, n_assays=32, seed=44)
+    for k, v in kw.items():
+        setattr(wl.options, k, v)
+    lens = np.diff(wl.offsets.astype(np.int64))
+    # a 400-kb record, a 250-kb record, fifty short ones
+    cuts = [0, 400, 650] + list(range(651, 701))
+    offsets = np.array([int(lens[:c].sum()) for c in cuts], dtype=np.uint64)
+    if host:
+        monkeypatch.setenv("TNT_MI355X_LONG_HOST_CULL", "1")
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    got = e.first_cull(db)
+    want = oracle.first_cull(wl.options, wl.expanded, wl.codes, offsets)
+    assert sorted(map(tuple, got)) == sorted(map(tuple, want))
+    assert len([r for r in want if r[0] == 0]) > 100 and len([r for r in want if r[0] == 1]) > 100 and len([r for r in want if r[0] > 1]) > 5
+    db.close()
+    e.close()
+
+
 @pytest.mark.parametrize("kind,seed", [("probe", 1), ("probe", 2), ("padlock", 3), ("pcr", 4), ("pcr", 5)])
 def test_long_oligos_vs_oracle(Engine, oracle, kind, seed, monkeypatch):
     """Oligos of 65..128 bases run through the 128-row instances (rows in scratch memory): binds through all three routes and

@@ -2602,7 +2602,8 @@ private:
 	}
 };
 
-static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &out)
+// cull_rows != nullptr: stop behind the first cull and append its outcome as rows of tnt_first_cull
+static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &out, std::vector<int32_t> *cull_rows = nullptr)
 {
 	const size_t u0 = db->n_short_units, u1 = db->h_unit_target.size();
 	if (u0 >= u1) return TNT_OK;
@@ -2657,7 +2658,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 				// searched and collected) stay what they are: build_units does not look at unit_scale for the split
 				ctx->unit_scale *= 0.5;
 				HIP_TRY(build_units(ctx, db), ctx->err);
-				return search_long_targets(ctx, db, out); // the unit ranges changed
+				return search_long_targets(ctx, db, out, cull_rows); // the unit ranges changed
 			}
 			continue;
 		}
@@ -2836,6 +2837,21 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 		}
 	}
 	if (n_bind == 0) return TNT_OK;
+	if (cull_rows) { // tnt_first_cull: the kept seeds of the PCR lists and the strand their group binds first
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err); // (the device route's copy of the kept seeds)
+		for (const Group &g : groups) {
+			const uint32_t assay = g.assay & GROUP_ASSAY_MASK;
+			if (ctx->h_assays[assay].kind != 0) continue; // probe / padlock lists are not culled
+			for (uint32_t i = g.first; i < g.first + g.count; i++) {
+				const Item &it = bind_items[i];
+				const uint32_t slot = it.info >> ITEM_SLOT_SHIFT;
+				const int32_t row[7] = {int32_t(db->first_seq_index + it.target), int32_t(assay), int32_t(slot % 3u), (it.info & ITEM_MINUS) ? TNT_MINUS : TNT_PLUS,
+				                        int32_t(it.info & 127u), int32_t(it.tloc), (g.assay & GROUP_MINUS_FIRST) ? 1 : 0};
+				cull_rows->insert(cull_rows->end(), row, row + 7);
+			}
+		}
+		return TNT_OK;
+	}
 
 	lap("work items");
 	// ---- bind them on the device, a million at a time: bucket -> pre-filter -> bind, as a search phase does
@@ -3297,10 +3313,6 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 		ctx->err = "a search is pending on this context: collect it first";
 		return TNT_E_ARG;
 	}
-	if (!db->h_long_targets.empty()) {
-		ctx->err = "tnt_first_cull: the lists of targets seeded in windows are culled on the host (search_long_targets)";
-		return TNT_E_UNSUPPORTED;
-	}
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	int rc = ensure_work_buffers(ctx, ctx->lmax, db);
 	if (rc) return rc;
@@ -3355,6 +3367,11 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 				ctx->h_cull_rows.insert(ctx->h_cull_rows.end(), row, row + 7);
 			}
 		}
+	}
+	if (!db->h_long_targets.empty()) { // targets seeded in windows: their lists are assembled and culled whole (tnt_sort.hip)
+		std::vector<tnt_hit> none;
+		rc = search_long_targets(ctx, db, none, &ctx->h_cull_rows);
+		if (rc) return rc;
 	}
 	*rows = ctx->h_cull_rows.data();
 	*n_rows = ctx->h_cull_rows.size() / 7;
