@@ -891,6 +891,32 @@ def test_torch_coexists_with_the_library(Engine):
     e.close()
 
 
+def test_long_targets_in_several_passes(Engine, monkeypatch):
+    """A database with several windowed records goes through the long-target path in passes of whole records (bounded device
+    memory: TNT_MI355X_LONG_PASS_SEEDS); one record per pass gives the hits of one pass over all of them, in the same order --
+    also for the rows of tnt_first_cull."""
+    wl = synth.make_workload(3, n_targets=1600, n_assays=24, seed=52)
+    lens = np.diff(wl.offsets.astype(np.int64))
+    cuts = [0, 500, 900, 1200, 1500] + list(range(1501, 1601))  # records of 500, 400, 300 and 300 kb, a hundred short ones
+    offsets = np.array([int(lens[:c].sum()) for c in cuts], dtype=np.uint64)
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    def parts(hits):  # (hits of the four windowed records in the order they come, the others -- the pair kernel's, in no order -- sorted)
+        return [tc.hit_key(h) for h in hits if h.seq_index < 4], sorted(tc.hit_key(h) for h in hits if h.seq_index >= 4)
+    first = e.search(db)
+    whole = parts(first)
+    n_records_hit = len({h.seq_index for h in first})
+    rows = sorted(map(tuple, e.first_cull(db)))
+    monkeypatch.setenv("TNT_MI355X_LONG_PASS_SEEDS", "1")
+    assert parts(e.search(db)) == whole
+    assert sorted(map(tuple, e.first_cull(db))) == rows
+    monkeypatch.setenv("TNT_MI355X_LONG_PASS_SEEDS", "60000")  # two or three records per pass
+    assert parts(e.search(db)) == whole
+    assert n_records_hit > 4 and len(whole[0]) > 20
+    db.close()
+    e.close()
+
+
 def test_hits_of_windowed_targets_have_a_device_copy(Engine):
     """Targets seeded in windows are paired on host threads; their hits are copied behind the device's own, so that the
     device view and the compact form (what the multi-GPU gather sends) hold every hit of such a database too."""

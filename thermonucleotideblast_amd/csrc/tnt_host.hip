@@ -2602,10 +2602,12 @@ private:
 	}
 };
 
-// cull_rows != nullptr: stop behind the first cull and append its outcome as rows of tnt_first_cull
-static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &out, std::vector<int32_t> *cull_rows = nullptr)
+// One pass over the windows [u0, u1) of some of the long targets (whole targets: their lists are culled and paired whole).
+// cull_rows != nullptr: stop behind the first cull and append its outcome as rows of tnt_first_cull.
+// LONG_RESTART: the windows were rebuilt at half their length (a window's seed list overflowed): every pass starts again.
+constexpr int LONG_RESTART = 1000;
+static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const size_t u1, std::vector<tnt_hit> &out, std::vector<int32_t> *cull_rows)
 {
-	const size_t u0 = db->n_short_units, u1 = db->h_unit_target.size();
 	if (u0 >= u1) return TNT_OK;
 	const bool timing = getenv("TNT_MI355X_LONG_TIMING") != nullptr; // phase times of this path on stderr
 	auto t_last = std::chrono::steady_clock::now();
@@ -2658,7 +2660,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 				// searched and collected) stay what they are: build_units does not look at unit_scale for the split
 				ctx->unit_scale *= 0.5;
 				HIP_TRY(build_units(ctx, db), ctx->err);
-				return search_long_targets(ctx, db, out, cull_rows); // the unit ranges changed
+				return LONG_RESTART; // the unit ranges changed
 			}
 			continue;
 		}
@@ -2958,6 +2960,41 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	}
 	lap("hits in order");
 	return TNT_OK;
+}
+
+// The targets that are seeded in windows, a few at a time: the device arrays of a pass are ~150 bytes per seed (tnt_sort.hip), so a
+// database that holds a whole genome goes through in passes of whole records whose expected seeds stay below 256 M
+// (TNT_MI355X_LONG_PASS_SEEDS; a single record beyond that is a pass of its own).  Hits come out in target order.
+static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &out, std::vector<int32_t> *cull_rows = nullptr)
+{
+	const size_t rows0 = cull_rows ? cull_rows->size() : 0;
+	double cap = 256.0e6;
+	if (const char *e = getenv("TNT_MI355X_LONG_PASS_SEEDS")) cap = std::max(1.0, atof(e));
+	for (;;) {
+		out.clear();
+		if (cull_rows) cull_rows->resize(rows0);
+		const size_t u0 = db->n_short_units, u1 = db->h_unit_target.size();
+		const double per_position = double(ctx->n_entries) / double(size_t(1) << (2 * ctx->opt.hash_word_size));
+		bool restart = false;
+		for (size_t ua = u0; ua < u1 && !restart;) {
+			size_t ub = ua;
+			double seeds = 0.0;
+			while (ub < u1) { // one more whole record
+				size_t ue = ub;
+				double s = 0.0;
+				while (ue < u1 && db->h_unit_target[ue] == db->h_unit_target[ub]) s += double(db->h_unit_end[ue] - db->h_unit_begin[ue]) * per_position, ue++;
+				if (ub > ua && seeds + s > cap) break;
+				seeds += s, ub = ue;
+			}
+			std::vector<tnt_hit> part;
+			const int rc = search_long_pass(ctx, db, ua, ub, part, cull_rows);
+			if (rc == LONG_RESTART) restart = true;
+			else if (rc) return rc;
+			else out.insert(out.end(), part.begin(), part.end());
+			ua = ub;
+		}
+		if (!restart) return TNT_OK;
+	}
 }
 
 int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
