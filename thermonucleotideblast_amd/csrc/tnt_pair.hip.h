@@ -35,7 +35,10 @@ namespace tnt {
 
 constexpr int PAIR_THREADS = 64;
 constexpr int PAIR_HOST = 1 << 20; // entries of one (target, assay) list in the host replay (arrays on 512-MB thread stacks: only the pages a list touches exist)
-constexpr int PAIR_SMALL = 16; // entries of one (target, assay) group handled by the common instance of the pair kernel (its per-lane lists live in
+#ifndef TNT_PAIR_SMALL
+#define TNT_PAIR_SMALL 16
+#endif
+constexpr int PAIR_SMALL = TNT_PAIR_SMALL; // entries of one (target, assay) group handled by the common instance of the pair kernel (its per-lane lists live in
                                // scratch memory: a quarter of the 64-entry instance's, which serves the groups of 17 to 64 entries)
 constexpr int PAIR_MAX = 64;
 constexpr int PAIR_BIG = 512; // ... and by the instance for crowded groups (short hash words, repeats); == LIST_MAX of the seed kernel
