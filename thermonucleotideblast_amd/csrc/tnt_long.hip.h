@@ -1,0 +1,511 @@
+// tnt_long.hip.h -- the long-target path of the library: targets that do not fit one seed work unit (genomes, chromosomes;
+// dense seeding with short hash words).  Part of tnt_host.hip's translation unit (included there: it uses the context, the
+// planner, the seed launch and the bind phases defined above it); the device side of the list assembly and of the first cull
+// is tnt_sort.hip.  Product code: nothing here includes or links anything under oracle/.
+#ifndef TNT_LONG_HIP_H
+#define TNT_LONG_HIP_H
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Targets that do not fit one seed work unit (genomes; dense seeding with short hash words).  The reference's culls, its
+// choice of the strand that is bound first and its pairing loops act on the lists of the WHOLE target
+// (amplicon_search.cpp:96-674, padlock_search.cpp, probe_search.cpp), and the first cull's outcome is not local
+// (cull_oligo_match counts the strands of list successors, sort_by_oligo_loc is not a strict weak order: SURVEY Q4, Q5).
+// So such a target is only SEEDED (windows of k-mer positions, every position once) and BOUND (every seed the first cull
+// keeps, through the same bucket -> pre-filter -> bind kernels as everything else) on the device; its seed lists are
+// merged per (target, assay) on the host, where the first cull, the bind / cull sequence and the pairing loops run on the
+// complete lists with the code the pair kernel runs (tnt_pair.hip.h is compiled for both sides).
+// The host workers of this path: a process-wide pool of threads with 512-MB stacks (pair_group<PAIR_HOST> keeps its lists
+// on the stack), started at the first long-target search and parked on a condition variable between runs -- starting 64
+// or 128 threads with such stacks costs 2-3 ms every time, as much as the culls and the pairing they are started for.
+// run(n, f): f(0) .. f(n - 1), the workers take the indices one at a time; one run at a time (searches of several
+// contexts take turns).
+class HostPool
+{
+	std::mutex run_mu, mu;
+	std::condition_variable cv_work, cv_done;
+	std::vector<pthread_t> th;
+	const std::function<void(size_t)> *fn = nullptr;
+	size_t n = 0;
+	std::atomic<size_t> next{0};
+	unsigned busy = 0;
+	uint64_t generation = 0;
+	bool stop = false;
+	pid_t owner = 0;
+
+	static void *worker_main(void *p)
+	{
+		static_cast<HostPool *>(p)->worker();
+		return nullptr;
+	}
+	void worker()
+	{
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			cv_work.wait(lk, [&] { return stop || generation != seen; });
+			if (stop) return;
+			seen = generation;
+			lk.unlock();
+			for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) (*fn)(i);
+			lk.lock();
+			if (--busy == 0) cv_done.notify_all();
+		}
+	}
+
+public:
+	static HostPool &get()
+	{
+		static HostPool pool;
+		return pool;
+	}
+	~HostPool()
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			stop = true;
+		}
+		cv_work.notify_all();
+		if (owner == getpid())
+			for (pthread_t t : th) pthread_join(t, nullptr);
+	}
+	unsigned size()
+	{
+		std::lock_guard<std::mutex> g(run_mu);
+		start();
+		return unsigned(th.size());
+	}
+	// false: no worker thread could be started (f needs the large stack, it must not run on the caller's)
+	bool run(size_t count, const std::function<void(size_t)> &f)
+	{
+		std::lock_guard<std::mutex> g(run_mu);
+		start();
+		if (th.empty()) return false;
+		if (count == 0) return true;
+		std::unique_lock<std::mutex> lk(mu);
+		fn = &f;
+		n = count;
+		next = 0;
+		busy = unsigned(th.size());
+		generation++;
+		cv_work.notify_all();
+		cv_done.wait(lk, [&] { return busy == 0; });
+		fn = nullptr;
+		return true;
+	}
+
+private:
+	void start() // (under run_mu)
+	{
+		if (!th.empty() && owner != getpid()) th.clear(); // a forked child has none of its parent's threads
+		if (!th.empty()) return;
+		owner = getpid();
+		// the lists of one target are few and long (96 lists of 19 000 seeds for a 5-Mb target against config 2): as many
+		// workers as the host has cores, up to 128
+		const unsigned want = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+		pthread_attr_t attr;
+		pthread_attr_init(&attr);
+		pthread_attr_setstacksize(&attr, size_t(512) << 20); // address space, not memory: pages are touched as far as a list reaches
+		for (unsigned w = 0; w < want; w++) {
+			pthread_t t;
+			if (pthread_create(&t, &attr, worker_main, this) == 0) th.push_back(t);
+		}
+		pthread_attr_destroy(&attr);
+	}
+};
+
+// One pass over the windows [u0, u1) of some of the long targets (whole targets: their lists are culled and paired whole).
+// cull_rows != nullptr: stop behind the first cull and append its outcome as rows of tnt_first_cull.
+// LONG_RESTART: the windows were rebuilt at half their length (a window's seed list overflowed): every pass starts again.
+constexpr int LONG_RESTART = 1000;
+static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const size_t u1, std::vector<tnt_hit> &out, std::vector<int32_t> *cull_rows)
+{
+	if (u0 >= u1) return TNT_OK;
+	const bool timing = getenv("TNT_MI355X_LONG_TIMING") != nullptr; // phase times of this path on stderr
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "long targets: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	if (hipError_t stale = hipGetLastError()) { // nothing before this point may have failed
+		ctx->err = std::string("before the long-target path: ") + hipGetErrorString(stale);
+		return TNT_E_DEVICE;
+	}
+	uint32_t *cnt = ctx->S().counters.p;
+	// ---- seeds of every window (the seed kernel's unit-level output: kept seeds before the cull); they stay on the device
+	size_t n_raw = 0;
+	for (int attempt = 0;; attempt++) {
+		size_t tpb = 1;
+		int rc = plan(ctx, db, tpb);
+		if (rc) return rc;
+		double positions = 0.0;
+		for (size_t u = u0; u < u1; u++) positions += double(db->h_unit_end[u] - db->h_unit_begin[u]);
+		const double words = double(size_t(1) << (2 * ctx->opt.hash_word_size));
+		const size_t cap = size_t(positions * double(ctx->n_entries) / words * 1.5) + (size_t(1) << 20);
+		if (cap > (size_t(1) << 31)) {
+			ctx->err = "too many seeds on the long targets of this batch";
+			return TNT_E_LIMIT;
+		}
+		if (cap > ctx->seeds_out.n) HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err); // (kept for the next search)
+		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+		rc = enqueue_batch(ctx, db, u0, u1, true);
+		if (rc) return rc;
+		uint32_t h[C_COUNT];
+		HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		if (hipError_t bad = hipGetLastError()) {
+			ctx->err = std::string("seeding the windows of long targets: ") + hipGetErrorString(bad);
+			return TNT_E_DEVICE;
+		}
+		if ((h[C_ERR] & ERR_SEED_OVERFLOW) && attempt < 16) { // a window's list overflowed: fewer assays per pass, then shorter windows
+			if (ctx->chunk_begin.size() < ctx->h_assays.size() + 1) {
+				ctx->chunk_scale *= 0.5;
+			} else {
+				if (ctx->unit_scale < 1.0 / 64.0) { // the windows are at their shortest already
+					ctx->err = err_text(ERR_SEED_OVERFLOW);
+					return TNT_E_LIMIT;
+				}
+				// shorter windows for the targets that are seeded in windows; the whole targets (units below u0, already
+				// searched and collected) stay what they are: build_units does not look at unit_scale for the split
+				ctx->unit_scale *= 0.5;
+				HIP_TRY(build_units(ctx, db), ctx->err);
+				return LONG_RESTART; // the unit ranges changed
+			}
+			continue;
+		}
+		if (h[C_ERR]) {
+			ctx->err = err_text(h[C_ERR]);
+			return TNT_E_LIMIT;
+		}
+		if (h[C_SEEDS] > ctx->seeds_out.n) {
+			ctx->err = "seed output overflow on a long target";
+			return TNT_E_LIMIT;
+		}
+		n_raw = h[C_SEEDS];
+		break;
+	}
+	if (n_raw == 0) return TNT_OK;
+	lap("seed windows");
+
+	// ---- per (target, assay) lists in the reference's list order, assembled on the device (tnt_sort.hip: key kernel, two
+	// stable radix sorts, gather); the host gets the seeds as work items, list after list, and the list of every item
+	const size_t n_assays_all = ctx->h_assays.size();
+	std::vector<uint32_t> long_targets; // the targets these windows belong to, ascending
+	for (size_t u = u0; u < u1; u++)
+		if (long_targets.empty() || long_targets.back() != db->h_unit_target[u]) long_targets.push_back(db->h_unit_target[u]);
+	std::sort(long_targets.begin(), long_targets.end());
+	long_targets.erase(std::unique(long_targets.begin(), long_targets.end()), long_targets.end());
+	const size_t n_buckets = long_targets.size() * n_assays_all;
+	if (n_buckets >= (size_t(1) << 32)) {
+		ctx->err = "too many (target, assay) lists on the long targets of this batch";
+		return TNT_E_LIMIT;
+	}
+	// The lists are assembled AND culled on the device (tnt_sort.hip): only the seeds the first cull keeps, and one group
+	// record per list, come back.  TNT_MI355X_LONG_HOST_CULL=1 keeps round 2's route (every seed to the host, cull_oligo_match
+	// replayed per list on the worker threads) as the cross-check of the device cull.
+	const bool host_cull = getenv("TNT_MI355X_LONG_HOST_CULL") != nullptr;
+	HostPool &workers = HostPool::get();
+	// (all device arrays of this path come out of one allocation the context keeps: tnt_arena.h)
+	DeviceArena &arena = ctx->long_arena;
+	const size_t n_lists_max = std::min(n_raw, n_buckets);
+	HIP_TRY(arena.reserve(8 * 256 + db->n_targets * sizeof(uint32_t) + n_raw * (2 * sizeof(Item) + sizeof(uint32_t)) +
+	                      std::max(long_sort_bytes(n_raw), long_cull_bytes(n_raw, n_lists_max))),
+	        ctx->err);
+	uint32_t *const d_rank = arena.take<uint32_t>(db->n_targets), *const d_list = arena.take<uint32_t>(n_raw);
+	Item *const d_items = arena.take<Item>(n_raw), *const d_kept = arena.take<Item>(n_raw);
+	if (!d_rank || !d_list || !d_items || !d_kept) {
+		ctx->err = "the device arena of the long-target path is too small";
+		return TNT_E_DEVICE;
+	}
+	{
+		std::vector<uint32_t> rank(db->n_targets, 0);
+		for (size_t r = 0; r < long_targets.size(); r++) rank[long_targets[r]] = uint32_t(r);
+		HIP_TRY(hipMemcpy(d_rank, rank.data(), rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
+		HIP_TRY(long_sort_seeds(ctx->seeds_out.p, uint32_t(n_raw), d_rank, ctx->assays.p, uint32_t(n_assays_all), uint32_t(n_buckets), d_items, d_list, arena, ctx->stream), ctx->err);
+		if (timing) HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	}
+	lap("keys + sort");
+
+	Item *bind_items = nullptr; // the kept seeds, list after list (pinned host copy: the pairing reads it)
+	size_t n_bind = 0;
+	std::vector<Group> groups;
+	std::vector<uint32_t> unit_target;
+	std::vector<int32_t> own_lo, own_hi;
+	if (!host_cull) {
+		// ---- first cull of every list (amplicon_search.cpp:128-131) on the device
+		Group *d_groups = nullptr;
+		uint32_t n_kept = 0, n_groups = 0;
+		HIP_TRY(long_first_cull(d_items, d_list, uint32_t(n_raw), ctx->assays.p, uint32_t(n_assays_all), ctx->opt.max_len, ctx->opt.single_primer_pcr, d_kept, &n_kept,
+		                        &d_groups, &n_groups, arena, ctx->stream),
+		        ctx->err);
+		std::vector<Group> all(n_groups);
+		if (n_groups) HIP_TRY(hipMemcpyAsync(all.data(), d_groups, size_t(n_groups) * sizeof(Group), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		n_bind = n_kept;
+		for (const Group &g : all) {
+			if (g.count == 0) continue;
+			if (g.count > uint32_t(PAIR_HOST)) {
+				ctx->err = "more than 1048576 seeds of one assay on one target after the first cull";
+				return TNT_E_LIMIT;
+			}
+			groups.push_back(g);
+		}
+		// (Group::target = rank of the target among the windowed ones)
+		unit_target = long_targets;
+		own_lo.assign(unit_target.size(), INT32_MIN);
+		own_hi.assign(unit_target.size(), INT32_MAX);
+		lap("first cull (device)");
+		if (n_bind) {
+			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
+			bind_items = ctx->pin_bind.p;
+			HIP_TRY(hipMemcpyAsync(bind_items, d_kept, n_bind * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err); // (done by the first sync of the bind loop)
+		}
+	} else {
+		HIP_TRY(ctx->pin_items.ensure(n_raw), ctx->err);
+		HIP_TRY(ctx->pin_list.ensure(n_raw), ctx->err);
+		Item *const sorted = ctx->pin_items.p;
+		uint32_t *const list_of = ctx->pin_list.p;
+		HIP_TRY(hipMemcpyAsync(sorted, d_items, n_raw * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipMemcpyAsync(list_of, d_list, n_raw * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		std::vector<uint32_t> seg_begin, seg_assay;
+		for (size_t i = 0; i < n_raw; i++)
+			if (i == 0 || list_of[i] != list_of[i - 1]) {
+				seg_begin.push_back(uint32_t(i));
+				seg_assay.push_back(uint32_t(list_of[i] % n_assays_all));
+			}
+		seg_begin.push_back(uint32_t(n_raw));
+		lap("lists to the host");
+
+		// ---- first cull of every list (amplicon_search.cpp:128-131) on the host
+		std::vector<uint8_t> valid(n_raw, 0), minus_first(seg_assay.size(), 0);
+		std::atomic<bool> overflow(false);
+		const bool started = workers.run(seg_assay.size(), [&](size_t g) {
+			const uint32_t b = seg_begin[g], e = seg_begin[g + 1];
+			const AssayDev &A = ctx->h_assays[seg_assay[g]];
+			if (e - b > uint32_t(PAIR_HOST)) {
+				overflow = true;
+				return;
+			}
+			if (A.kind != 0) { // probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454)
+				for (uint32_t i = b; i < e; i++) valid[i] = 1;
+				return;
+			}
+			// amplicon(): the assembled match list (already in the order the cull's stable sort by target_loc leaves it in)
+			static thread_local std::unique_ptr<ListT<PAIR_HOST>> scratch;
+			if (!scratch) scratch.reset(new ListT<PAIR_HOST>);
+			ListT<PAIR_HOST> &l = *scratch;
+			l.n = int(e - b);
+			for (uint32_t i = b; i < e; i++) {
+				Entry &en = l.e[i - b];
+				const uint32_t role = (sorted[i].info >> ITEM_SLOT_SHIFT) % 3u;
+				en.loc5 = en.loc3 = 0;
+				en.tloc = sorted[i].tloc;
+				en.rec = int32_t(i); // remember which item this is
+				en.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((sorted[i].info & ITEM_MINUS) ? MMINUS : MPLUS));
+			}
+			int cm = 0, cp = 0;
+			cull(l, ctx->opt.max_len, A.has_probe != 0, ctx->opt.single_primer_pcr != 0, cm, cp); // amplicon_search.cpp:128
+			for (int i = 0; i < l.n; i++) valid[size_t(l.e[i].rec)] = 1;
+			minus_first[g] = cm < cp ? 1 : 0; // :131
+		});
+		if (!started) {
+			ctx->err = "could not start a host thread for the lists of long targets";
+			return TNT_E_DEVICE;
+		}
+		if (overflow) {
+			ctx->err = "more than 1048576 seeds of one assay on one target";
+			return TNT_E_LIMIT;
+		}
+
+		lap("first cull (host)");
+		// ---- the kept seeds become bind work items, grouped per (target, assay)
+		{
+			// (two passes over the lists on the worker threads: count, then copy to the counted places)
+			const size_t n_seg = seg_assay.size();
+			std::vector<uint32_t> first_of(n_seg + 1, 0);
+			workers.run(n_seg, [&](size_t g) {
+				uint32_t c = 0;
+				for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++) c += valid[i] ? 1u : 0u;
+				first_of[g + 1] = c;
+			});
+			for (size_t g = 0; g < n_seg; g++) first_of[g + 1] += first_of[g];
+			n_bind = first_of[n_seg];
+			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
+			bind_items = ctx->pin_bind.p;
+			workers.run(n_seg, [&](size_t g) {
+				uint32_t o = first_of[g];
+				for (uint32_t i = seg_begin[g]; i < seg_begin[g + 1]; i++)
+					if (valid[i]) bind_items[o++] = sorted[i];
+			});
+			for (size_t g = 0; g < n_seg; g++) {
+				const uint32_t count = first_of[g + 1] - first_of[g];
+				if (!count) continue;
+				const uint32_t t = sorted[seg_begin[g]].target;
+				if (unit_target.empty() || unit_target.back() != t) unit_target.push_back(t), own_lo.push_back(INT32_MIN), own_hi.push_back(INT32_MAX);
+				groups.push_back(Group{uint32_t(unit_target.size() - 1), seg_assay[g] | (minus_first[g] ? GROUP_MINUS_FIRST : 0u), first_of[g], count});
+			}
+		}
+	}
+	if (n_bind == 0) return TNT_OK;
+	if (cull_rows) { // tnt_first_cull: the kept seeds of the PCR lists and the strand their group binds first
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err); // (the device route's copy of the kept seeds)
+		for (const Group &g : groups) {
+			const uint32_t assay = g.assay & GROUP_ASSAY_MASK;
+			if (ctx->h_assays[assay].kind != 0) continue; // probe / padlock lists are not culled
+			for (uint32_t i = g.first; i < g.first + g.count; i++) {
+				const Item &it = bind_items[i];
+				const uint32_t slot = it.info >> ITEM_SLOT_SHIFT;
+				const int32_t row[7] = {int32_t(db->first_seq_index + it.target), int32_t(assay), int32_t(slot % 3u), (it.info & ITEM_MINUS) ? TNT_MINUS : TNT_PLUS,
+				                        int32_t(it.info & 127u), int32_t(it.tloc), (g.assay & GROUP_MINUS_FIRST) ? 1 : 0};
+				cull_rows->insert(cull_rows->end(), row, row + 7);
+			}
+		}
+		return TNT_OK;
+	}
+
+	lap("work items");
+	// ---- bind them on the device, a million at a time: bucket -> pre-filter -> bind, as a search phase does
+	const DbView v = make_view(db, 0, db->n_targets);
+	HIP_TRY(ctx->pin_result.ensure(n_bind), ctx->err);
+	int32_t *const result = ctx->pin_result.p;
+	// (up to 16 M items per pass; a pass that binds more records than the device pool holds is repeated with half as many)
+	size_t n_pool = 0;
+	size_t chunk = std::min(ctx->item_cap, size_t(1) << 24);
+	for (size_t c0 = 0; c0 < n_bind;) {
+		const size_t nc = std::min(chunk, n_bind - c0);
+		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+		if (host_cull) HIP_TRY(hipMemcpyAsync(ctx->S().items.p, bind_items + c0, nc * sizeof(Item), hipMemcpyHostToDevice, ctx->stream), ctx->err);
+		else HIP_TRY(hipMemcpyAsync(ctx->S().items.p, d_kept + c0, nc * sizeof(Item), hipMemcpyDeviceToDevice, ctx->stream), ctx->err);
+		hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->S().qb.p, uint32_t(nc), cnt + C_QB); // the queue: every item
+		BindArgs b = bind_args(ctx, v);
+		b.groups = nullptr;
+		launch_bind_phase(ctx, b, v, db->n_exceptions != 0, ctx->S().qb.p, cnt + C_QB, nullptr);
+		uint32_t h[C_COUNT];
+		int32_t *const res = result + c0;
+		HIP_TRY(hipMemcpyAsync(res, ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		HIP_TRY(hipGetLastError(), ctx->err);
+		if (h[C_ERR] == ERR_POOL_OVERFLOW && chunk > (size_t(1) << 16)) {
+			chunk /= 2;
+			continue;
+		}
+		if (h[C_ERR]) {
+			ctx->err = err_text(h[C_ERR]);
+			return TNT_E_LIMIT;
+		}
+		const size_t np = std::min<size_t>(h[C_POOL], POOL_CAP), base = n_pool;
+		if (base + np >= (size_t(1) << 31)) {
+			ctx->err = "more than 2^31 bound oligos on the long targets of this batch";
+			return TNT_E_LIMIT;
+		}
+		HIP_TRY(ctx->pin_pool.ensure_keep(base + np, base), ctx->err);
+		if (np) HIP_TRY(hipMemcpy(ctx->pin_pool.p + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		n_pool += np;
+		if (base)
+			for (size_t i = 0; i < nc; i++)
+				if (res[i] >= 0) res[i] = int32_t(base + size_t(res[i]));
+		ctx->acc_items += nc;
+		c0 += nc;
+	}
+	const BoundRec *const pool = ctx->pin_pool.p;
+
+	lap("bind on the device");
+	// ---- the bind / cull sequence and the pairing loops on the whole lists (pair_group, compiled for the host)
+	size_t hit_cap = std::max<size_t>(1024, n_pool);
+	std::unique_ptr<Hit[]> hits(new Hit[hit_cap]); // (not initialised: a record is 1.4 kB, pages are touched as hits arrive)
+	for (;;) {
+		uint32_t n_hits = 0, err = 0, zero = 0;
+		PairArgs p;
+		memset(&p, 0, sizeof(p));
+		p.groups = groups.data();
+		p.items = bind_items;
+		p.result = result;
+		p.pool = pool;
+		p.assays = ctx->h_assays.data();
+		p.db.first_seq_index = db->first_seq_index;
+		p.max_len = ctx->opt.max_len;
+		p.single_primer_pcr = ctx->opt.single_primer_pcr;
+		p.min_max_primer_clamp = ctx->opt.min_max_primer_clamp;
+		p.assay_format = ctx->opt.assay_format;
+		p.target_strand = ctx->opt.target_strand;
+		p.hits = hits.get();
+		p.hit_cap = uint32_t(std::min<size_t>(hit_cap, UINT32_MAX));
+		p.hit_count = &n_hits;
+		p.err = &err;
+		p.n_big = &zero;
+		p.unit_target = unit_target.data();
+		p.unit_own_lo = own_lo.data();
+		p.unit_own_hi = own_hi.data();
+		if (!workers.run(groups.size(), [&](size_t g) { pair_group<PAIR_HOST>(p, groups[g]); })) {
+			ctx->err = "could not start a host thread for the lists of long targets";
+			return TNT_E_DEVICE;
+		}
+		if ((err & ERR_HIT_OVERFLOW) && hit_cap < UINT32_MAX) {
+			hit_cap *= 4;
+			hits.reset(new Hit[hit_cap]);
+			continue;
+		}
+		if (err) {
+			ctx->err = err_text(err);
+			return TNT_E_LIMIT;
+		}
+		lap("pairing");
+		// The workers took the groups as they came: put the hits back into the order one thread produces -- groups by
+		// (target, assay position), the hits of a group in the order its worker wrote them (a worker's slots ascend) --, so
+		// that the output does not depend on the scheduling.
+		std::map<std::pair<int32_t, int32_t>, uint32_t> position; // (assay id, degen id) -> first position in the assay list
+		for (size_t ai = ctx->h_assays.size(); ai-- > 0;) position[{ctx->h_assays[ai].id, ctx->h_assays[ai].degen_id}] = uint32_t(ai);
+		std::vector<std::pair<uint64_t, uint32_t>> order(n_hits); // ((target, assay position), slot)
+		for (uint32_t i = 0; i < n_hits; i++) {
+			const tnt_hit &x = reinterpret_cast<const tnt_hit &>(hits[i]);
+			order[i] = {(uint64_t(uint32_t(x.seq_index)) << 32) | position[{x.assay_id, x.degen_id}], i};
+		}
+		std::sort(order.begin(), order.end());
+		out.resize(n_hits);
+		for (uint32_t i = 0; i < n_hits; i++) memcpy(&out[i], &hits[order[i].second], sizeof(tnt_hit));
+		break;
+	}
+	lap("hits in order");
+	return TNT_OK;
+}
+
+// The targets that are seeded in windows, a few at a time: the device arrays of a pass are ~150 bytes per seed (tnt_sort.hip), so a
+// database that holds a whole genome goes through in passes of whole records whose expected seeds stay below 256 M
+// (TNT_MI355X_LONG_PASS_SEEDS; a single record beyond that is a pass of its own).  Hits come out in target order.
+static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &out, std::vector<int32_t> *cull_rows = nullptr)
+{
+	const size_t rows0 = cull_rows ? cull_rows->size() : 0;
+	double cap = 256.0e6;
+	if (const char *e = getenv("TNT_MI355X_LONG_PASS_SEEDS")) cap = std::max(1.0, atof(e));
+	for (;;) {
+		out.clear();
+		if (cull_rows) cull_rows->resize(rows0);
+		const size_t u0 = db->n_short_units, u1 = db->h_unit_target.size();
+		const double per_position = double(ctx->n_entries) / double(size_t(1) << (2 * ctx->opt.hash_word_size));
+		bool restart = false;
+		for (size_t ua = u0; ua < u1 && !restart;) {
+			size_t ub = ua;
+			double seeds = 0.0;
+			while (ub < u1) { // one more whole record
+				size_t ue = ub;
+				double s = 0.0;
+				while (ue < u1 && db->h_unit_target[ue] == db->h_unit_target[ub]) s += double(db->h_unit_end[ue] - db->h_unit_begin[ue]) * per_position, ue++;
+				if (ub > ua && seeds + s > cap) break;
+				seeds += s, ub = ue;
+			}
+			std::vector<tnt_hit> part;
+			const int rc = search_long_pass(ctx, db, ua, ub, part, cull_rows);
+			if (rc == LONG_RESTART) restart = true;
+			else if (rc) return rc;
+			else out.insert(out.end(), part.begin(), part.end());
+			ua = ub;
+		}
+		if (!restart) return TNT_OK;
+	}
+}
+
+#endif
