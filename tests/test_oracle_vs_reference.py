@@ -68,6 +68,44 @@ def test_first_cull(ref, oracle, cfg, nt, na, seed, kw):
     assert sorted(map(tuple, a[:, :6])) == sorted(map(tuple, b[:, :6])) and len(a) > 100
 
 
+LONG_RECORD_CASES = [(2, 2000, 24, {}), (3, 1500, 24, {}), (3, 1000, 16, {"max_len": 400, "single_primer_pcr": 0}), (5, 600, 24, {}),
+                     (2, 300, 16, {"hash_word_size": 5})]
+
+
+def _long_record(cfg, nt, na, kw):
+    """A workload whose first nt - 5 targets are one record (0.3 to 2 Mb) in front of five short ones."""
+    wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=140 + cfg)
+    for k, v in kw.items():
+        setattr(wl.options, k, v)
+    lens = np.diff(wl.offsets.astype(np.int64))
+    cut = nt - 5
+    offsets = np.array([0, int(lens[:cut].sum())] + [int(lens[:cut + i + 1].sum()) for i in range(5)], dtype=np.uint64)
+    return wl, offsets
+
+
+@pytest.mark.parametrize("cfg,nt,na,kw", LONG_RECORD_CASES)
+def test_search_long_records(ref, oracle, cfg, nt, na, kw):
+    """The oracle against the reference where the lists are long (thousands of seeds per (target, assay): the first cull's
+    successor counts, Q4, and the merge order of std::list::sort under sort_by_oligo_loc, Q5, act on whole-record lists) --
+    the link between the reference and the GPU parity tests of the long-target path, which compare with the oracle."""
+    wl, offsets = _long_record(cfg, nt, na, kw)
+    a = tc.sorted_hit_keys(ref.search(wl.options, wl.expanded, wl.codes, offsets))
+    b = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, offsets))
+    assert a == b
+    assert len(a) > 20
+
+
+@pytest.mark.parametrize("cfg,nt,na,kw", [c for c in LONG_RECORD_CASES if c[0] != 5])
+def test_first_cull_long_records(ref, oracle, cfg, nt, na, kw):
+    """cull_oligo_match on the lists of a long record: the same seeds survive, and the strand bound first agrees (on these inputs
+    the element the reference reads one node past the list, Q4, does not decide)."""
+    wl, offsets = _long_record(cfg, nt, na, kw)
+    a = oracle.first_cull(wl.options, wl.expanded, wl.codes, offsets)
+    b = ref.first_cull(wl.options, wl.expanded, wl.codes, offsets)
+    assert sorted(map(tuple, a[:, :6])) == sorted(map(tuple, b[:, :6])) and len(a) > 5000
+    assert sorted(map(tuple, a)) == sorted(map(tuple, b))
+
+
 @pytest.mark.parametrize("kind,seed", [("probe", 1), ("probe", 2), ("padlock", 3), ("pcr", 4), ("pcr", 5)])
 def test_long_oligos(ref, oracle, kind, seed):
     """Oligos of 65..128 bases (the library's long instances): seeds, binds, hits and self-structure of the oracle against
