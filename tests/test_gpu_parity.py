@@ -487,6 +487,20 @@ def test_g4_g5_short_hash_words_golden(Engine):
         e.close()
 
 
+def test_g10_long_records_golden(Engine):
+    """Reference-generated hit sets and first-cull rows of records of 0.25-0.6 Mb (tests/gen_golden_long.py): the long-target
+    path -- windows, lists and first cull on the device, pairing on host threads -- against the reference itself."""
+    for case in gu.load("g10_long_records.json.gz")["cases"]:
+        expanded, codes, offsets = gu.g5_inputs(case)
+        e = Engine(gu.options_from(case["options"]), expanded)
+        db = e.pack(codes, offsets)
+        assert gu.hits_as_keys(e.search(db)) == case["hits"], case["config"]
+        if "first_cull" in case:
+            assert sorted([int(v) for v in r] for r in e.first_cull(db)) == case["first_cull"], case["config"]
+        db.close()
+        e.close()
+
+
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
 def test_g5_search_golden(Engine, cfg):
     fx = gu.load("g5_search_cfg%d.json.gz" % cfg)

@@ -141,3 +141,16 @@ def test_g4_g5_short_hash_words(oracle):
         expanded, codes, offsets = gu.g5_inputs(case)
         hits = oracle.search(gu.options_from(case["options"]), expanded, codes, offsets)
         assert gu.hits_as_keys(hits) == case["hits"] and len(hits) > 0, (case["config"], case["options"]["hash_word_size"])
+
+
+def test_g10_long_records(oracle):
+    """Records of 0.25-0.6 Mb (the library seeds them in windows): the reference's hit sets over whole-record lists and the
+    seeds its first cull keeps, with the strand bound first (tests/gen_golden_long.py)."""
+    for case in gu.load("g10_long_records.json.gz")["cases"]:
+        expanded, codes, offsets = gu.g5_inputs(case)
+        opt = gu.options_from(case["options"])
+        hits = oracle.search(opt, expanded, codes, offsets)
+        assert gu.hits_as_keys(hits) == case["hits"] and len(hits) > 20, case["config"]
+        if "first_cull" in case:
+            rows = sorted([int(v) for v in r] for r in oracle.first_cull(opt, expanded, codes, offsets))
+            assert rows == case["first_cull"] and len(rows) > 2000, case["config"]
