@@ -269,8 +269,11 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
  * length (exact / plain ladder; the general ladder for windows with degenerate target bases); TNT_ROUTE_MERGED binds
  * the whole queue with the longest general instance (what a search does with short queues).  These instances keep a
  * status for every request and the record + alignment text of bound ones only: status is always set; tm, dH, dS, dg,
- * anchors, num_mm, num_gap, loc5, loc3, align are set when status == 0; the other fields are -1 (0 for the window). */
-enum { TNT_ROUTE_UNIT = 0, TNT_ROUTE_BUCKETS = 1, TNT_ROUTE_MERGED = 2 };
+ * anchors, num_mm, num_gap, loc5, loc3, align are set when status == 0; the other fields are -1 (0 for the window).
+ * TNT_ROUTE_WAVE is TNT_ROUTE_BUCKETS with every bucket bound by the wavefront-per-window form of the kernel (one wavefront
+ * per request, query rows across the lanes, trace words in LDS); TNT_ROUTE_WAVE_UNIT is the unit-level form of that
+ * kernel: every field set, like TNT_ROUTE_UNIT. */
+enum { TNT_ROUTE_UNIT = 0, TNT_ROUTE_BUCKETS = 1, TNT_ROUTE_MERGED = 2, TNT_ROUTE_WAVE = 3, TNT_ROUTE_WAVE_UNIT = 4 };
 int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out, int route);
 
 /* Unit-level entry to the bind stage's pre-filter (tnt_filter.hip.h): for every request score[2k] = an upper bound, in

@@ -42,8 +42,10 @@ def test_g1_delta_g(Engine):
         e.close()
 
 
-def test_g2_binds_golden(Engine):
-    """10k reference NucCruc evaluations per option set: mismatches, bulges, loops, IUPAC, inosine, clipped windows, ties."""
+@pytest.mark.parametrize("route", [0, 4])
+def test_g2_binds_golden(Engine, route):
+    """10k reference NucCruc evaluations per option set: mismatches, bulges, loops, IUPAC, inosine, clipped windows, ties.
+    Route 0: the unit-level instance of the lane-per-window kernel; 4: of the wavefront-per-window kernel (tnt_wbind.hip.h)."""
     fx = gu.load("g2_binds.json.gz")
     codes, offsets = gu.pack_targets(fx["targets"])
     ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
@@ -52,7 +54,7 @@ def test_g2_binds_golden(Engine):
         om = {o: i for i, o in enumerate(e.oligos)}
         reqs = tc.make_reqs((r[0], om[fx["oligos"][r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in fx["requests"])
         db = e.pack(codes, offsets)
-        out = e.bind_batch(db, reqs)
+        out = e.bind_batch(db, reqs, route=route)
         bad = [(i, gu.compare_bind(x, gu.bind_record(out[i]))) for i, x in enumerate(case["expected"])]
         bad = [b for b in bad if b[1]]
         assert not bad, "%s: %d of %d differ, first %r" % (case["name"], len(bad), len(case["expected"]), bad[:2])
@@ -63,11 +65,12 @@ def test_g2_binds_golden(Engine):
 ROUTED_FIELDS = [3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 21]  # tm dH dS dg a5 a3 mm gap loc5 loc3 align: what a throughput instance keeps
 
 
-@pytest.mark.parametrize("route", [1, 2])
+@pytest.mark.parametrize("route", [1, 2, 3])
 def test_g2_binds_golden_production_instances(Engine, route):
     """The G2 cases through the kernels tnt_search runs (bucket_kernel + one launch per length bucket: exact / plain
-    ladder / general instances, 256- and 768-thread; route 2: everything through the longest general instance): the
-    status of every request and the record + text of every bound one must equal the reference's."""
+    ladder / general instances, 256- and 768-thread; route 2: everything through the longest general instance; route 3:
+    every bucket through the wavefront-per-window kernel): the status of every request and the record + text of every
+    bound one must equal the reference's."""
     fx = gu.load("g2_binds.json.gz")
     codes, offsets = gu.pack_targets(fx["targets"])
     ex = [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(fx["oligos"])]
@@ -133,12 +136,12 @@ def test_random_windows_production_vs_oracle(Engine, oracle, seed, kw):
     db = e.pack(codes, offsets)
     n_bound = sum(1 for w in want if w.status == 0)
     assert n_bound > 50, n_bound
-    for route in (0, 1, 2):
+    for route in (0, 1, 2, 3, 4):
         out = e.bind_batch(db, reqs, route=route)
         bad = []
         for i, w in enumerate(want):
             x, got = gu.bind_record(w), gu.bind_record(out[i])
-            if route == 0:
+            if route in (0, 4):
                 d = gu.compare_bind(x, got)
             else:
                 d = [(k, x[k], got[k]) for k in ([0] + (ROUTED_FIELDS if x[0] == 0 else [])) if x[k] != got[k]]
@@ -1175,3 +1178,21 @@ def test_pipelined_batches_give_the_same_hits(Engine, oracle, monkeypatch):
     sample = 4000
     want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes[:int(wl.offsets[sample])], wl.offsets[:sample + 1]))
     assert [h for h in res["3"][0] if h[2] < sample] == want
+
+
+def test_queue_region_overflow_is_repaired(Engine, oracle, monkeypatch):
+    """The region of a length bucket inside the phase-A queue overflows (TNT_MI355X_QUEUE_SLOTS: a test hook that caps every
+    region): the seed kernel raises ERR_ITEM_OVERFLOW, the filter / bind launches of that batch stay inside the bucket's
+    own region (they used to be capped by the whole buffer: the next bucket's entries, of another oligo length, or memory
+    behind the buffer), and the search is repeated with smaller batches until it fits -- same hits as the oracle."""
+    wl = synth.make_workload(5, n_targets=3000, n_assays=40, seed=123)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    monkeypatch.setenv("TNT_MI355X_QUEUE_SLOTS", "8192")
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    assert e.timing().n_binds > 8 * 8192  # more windows than the capped regions hold at once: the repair ran
+    assert got == want and len(want) > 50
+    assert tc.sorted_hit_keys(e.search(db)) == want
+    db.close()
+    e.close()

@@ -418,6 +418,516 @@ __device__ Score evaluate_hairpin(const LaneCtx &c, const Tables *tab, const Ali
 	return evaluate_alignment<BIND_THREADS>(c, al.k0, al.k1, MODE_HAIRPIN, dH, dS);
 }
 
+// The trace words of one DP as the serial tail reads them.  Lane-per-window kernels keep them in an HBM slab laid out
+// [column][row][lane]: the path mostly runs down a diagonal, so PF cells of the current diagonal are fetched at once (one
+// memory latency instead of one per step) and parked in LDS.
+template <int LMAX, int STRIDE, int PF> struct SlabTrace {
+	const uint8_t *trace; // this lane's first trace word
+	uint8_t *pf;          // this lane's PF-entry slice of the LDS prefetch buffer
+	int pf_i, pf_j;       // first cell of the diagonal run held in pf (none: -1)
+	__device__ __forceinline__ void reset() { pf_i = pf_j = -1; }
+	__device__ __forceinline__ int get(int li, int lj)
+	{
+		int d = pf_i - li;
+		if (pf_i < 0 || d < 0 || d >= PF || pf_j - lj != d) {
+			uint8_t v[PF];
+#pragma unroll
+			for (int k = 0; k < PF; k++) v[k] = (li - k >= 1 && lj - k >= 1) ? trace[(size_t(lj - k - 1) * LMAX + size_t(li - k - 1)) * STRIDE] : uint8_t(0);
+#pragma unroll
+			for (int k = 0; k < PF; k++) pf[k * STRIDE] = v[k];
+			pf_i = li, pf_j = lj;
+			d = 0;
+		}
+		return int(pf[d * STRIDE]);
+	}
+};
+
+// The serial tail of one (oligo, window): everything behind the DP fill -- tm_dimer's loop over the maximal cells,
+// enumerate_dimer_alignments + trace_back, evaluate_alignment, the threshold cascade, anchors and counts, footprint, record
+// and alignment text.  Shared by the lane-per-window kernel (bind_kernel, below: STRIDE = workgroup size, per-lane slices of
+// LDS / scratch arrays) and the wavefront-per-window kernel (tnt_wbind.hip.h: STRIDE = 1, one lane runs it).
+//   FULL / DINK: as for bind_kernel.  QRY_LDS: `qry` holds the oligo in row order (row i-1 = query[L-i]).
+//   LONG_TEXT: the alignment text may not fit ALIGN_TEXT (oligos beyond 64 bases).
+//   A maximal cell is (i << CODE_SHIFT) | j; cells are numbered li * wstride + lj for the branch-cursor stack, whose entries
+//   are  key (cell * 4 + state, 24 bits) | trace mask << 24 | cursor << 28.
+// Returns true when a Dinkelbach pass has to follow (Tcur updated).
+template <bool FULL, bool DINK, bool QRY_LDS, bool LONG_TEXT, int STRIDE, int CODE_SHIFT, typename TIE_T, class TRACE>
+__device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const uint8_t *s_lut, const uint8_t *s_hs_map, const float2 *s_hs_val, const TailConst &s_k,
+                                          const uint8_t *win, const uint8_t *qry, uint8_t *cols, uint8_t *best, uint32_t *stack, TIE_T *ties, int ncols, int wstride,
+                                          uint32_t idx, const Item &it, const Slot &slot, int L, int W, int start, int stop, bool minus, int xmode, int gmax, int nmax,
+                                          int max_ij, float &Tcur, float &dk_q, long long st_fill0 = 0)
+{
+	LaneCtx c;
+	c.tab = a.tab;
+	c.lut = s_lut;
+	c.hs_map = s_hs_map;
+	c.hs_val = s_hs_val;
+	c.k = &s_k;
+	c.win = win;
+	c.query = a.olig_base + size_t(slot.oligo) * MAX_OLIGO;
+	c.cols = cols;
+	c.L = L;
+	c.W = W;
+	c.log_ct = slot.log_ct;
+
+#ifdef TNT_EXP_STATS
+	long long st_trace = 0, st_trim = 0, st_eval = 0;
+	const long long st_tail0 = __builtin_readcyclecounter();
+#endif
+	bool best_valid = false;
+	float best_dH = 0.0f, best_dS = 0.0f, best_tm = 0.0f;
+	AlignInfo bi = {0, 0, 0, 0, 0, 0};
+
+#define QUERY(K) (QRY_LDS ? int(qry[(L - 1 - (K)) * STRIDE]) : int(c.query[(K)]))
+#define TARGET(K) int(win[(K) * STRIDE])
+
+	// tm_dimer: every maximal cell in row-major order (nuc_cruc.cpp:2533-2537).  Cell codes (i << 8 | j)
+	// sort row-major numerically; the first maximal cell lives in max_ij, later ties in ties[1..nmax-1].
+	if (nmax > TIE_CAP) {
+		atomicOr(a.err, ERR_TIE_OVERFLOW);
+		nmax = TIE_CAP;
+	}
+	if (nmax > 1) {
+		ties[0] = TIE_T(max_ij);
+		for (int x = 1; x < nmax; x++) { // insertion sort, rare path
+			const TIE_T v = ties[x * STRIDE];
+			int y = x - 1;
+			while (y >= 0 && ties[y * STRIDE] > v) {
+				ties[(y + 1) * STRIDE] = ties[y * STRIDE];
+				y--;
+			}
+			ties[(y + 1) * STRIDE] = v;
+		}
+	}
+	for (int mc = 0; mc < nmax; mc++) {
+		const int code = (nmax == 1) ? max_ij : int(ties[mc * STRIDE]);
+		const int ci = code >> CODE_SHIFT, cj = code & ((1 << CODE_SHIFT) - 1);
+
+		// ---------------- enumerate_dimer_alignments, nuc_cruc.cpp:973-1170
+		bool first_time = true;
+		int sp = 0;
+		int zero_count = -1;
+		unsigned trace_count = 0;
+		float best_dg = best_dH - Tcur * best_dS;
+		while (true) {
+			if (!first_time && sp == 0 && zero_count <= 0) break;
+			if (16u < trace_count) break;
+			trace_count++;
+			first_time = false;
+
+#ifdef TNT_EXP_STATS
+			const long long st_a = __builtin_readcyclecounter();
+#endif
+			// ---------------- trace_back, nuc_cruc.cpp:1409-1618
+			AlignInfo al;
+			al.k0 = 1;
+			int n = 0; // columns written at cols[1 + n]
+			int li = ci, lj = cj;
+			al.fm_q = L - li;
+			al.fm_t = lj - 1;
+			al.lm_q = 0;
+			al.lm_t = 0;
+			int truncate_at_zero = 0;
+			bool count_zeros = false;
+			if (zero_count < 0) {
+				zero_count = 0;
+				count_zeros = true;
+			} else {
+				truncate_at_zero = zero_count--;
+			}
+			int key = -1;
+			int mask = 1;
+			tr.reset();
+			while (true) {
+				bool valid = true;
+				int local;
+				if (((mask & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1)) > 1) { // PATH_SPLIT
+					int f = 0;
+					for (; f < sp; f++)
+						if (int(stack[f * STRIDE] & 0xFFFFFFu) == key) break;
+					if (f == sp) {
+						const int curb = (mask & 1) ? 1 : ((mask & 2) ? 2 : 4);
+						if (sp < ncols) {
+							stack[sp * STRIDE] = uint32_t(key) | (uint32_t(mask) << 24) | (uint32_t(curb) << 28);
+							sp++;
+						} else {
+							atomicOr(a.err, ERR_STACK_OVERFLOW);
+						}
+						local = curb;
+					} else {
+						local = int(stack[f * STRIDE] >> 28);
+					}
+				} else {
+					local = mask;
+				}
+				// border cells hold M = I_query = I_target = -1 (nuc_cruc.h:531-536)
+				const bool inside = (li >= 1 && lj >= 1);
+				// The path mostly runs down a diagonal: PF cells of the current diagonal are fetched at once (one
+				// memory latency instead of one per step) and refilled when the walk leaves the run.
+				int tw = TW_M_NEG | TW_IQ_NEG | TW_IT_NEG; // border cell
+				if (inside) tw = tr.get(li, lj);
+				const int cidx = li * wstride + lj;
+				if (local == 1) { // query_target
+					if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
+						valid = false;
+					} else {
+						if ((tw & TW_M_NEG) == TW_M_NEG) valid = false;
+						else if (tw & TW_M_LE0) {
+							if (count_zeros) zero_count++;
+							else if (--truncate_at_zero == 0) valid = false;
+						}
+						cols[(1 + n) * STRIDE] = mk_col(QUERY(L - li), TARGET(lj - 1));
+						n++;
+						al.lm_q = L - li;
+						al.lm_t = lj - 1;
+						mask = ((tw & TW_M_NOT_M) ? 0 : 1) | ((tw & TW_M_NOT_IT) ? 0 : 2) | ((tw & TW_M_NOT_IQ) ? 0 : 4);
+						key = cidx * 4 + 0;
+						li--, lj--;
+					}
+				} else if (local == 4) { // gap_target: GAP in the query strand, state I_query
+					if (lj < 1) {
+						valid = false;
+					} else {
+						if ((tw & TW_IQ_NEG) == TW_IQ_NEG) valid = false;
+						cols[(1 + n) * STRIDE] = mk_col(bGAP, TARGET(lj - 1));
+						n++;
+						al.lm_q = L - li + 1;
+						al.lm_t = lj - 1;
+						mask = ((tw & TW_IQ_LT) ? 0 : 1) | ((tw & TW_IQ_GT) ? 0 : 4); // insert >= extend: from M; extend >= insert: from I_query
+						key = cidx * 4 + 1;
+						lj--;
+					}
+				} else { // query_gap: GAP in the target strand, state I_target
+					if (li > L || li < 1 /* Q7 fence */) {
+						valid = false;
+					} else {
+						if ((tw & TW_IT_NEG) == TW_IT_NEG) valid = false;
+						cols[(1 + n) * STRIDE] = mk_col(QUERY(L - li), bGAP);
+						n++;
+						al.lm_q = L - li;
+						al.lm_t = lj;
+						mask = ((tw & TW_IT_LT) ? 0 : 1) | ((tw & TW_IT_GT) ? 0 : 2);
+						key = cidx * 4 + 2;
+						li--;
+					}
+				}
+				if (!valid) break;
+			}
+			al.k1 = 1 + n;
+#ifdef TNT_EXP_STATS
+			const long long st_b = __builtin_readcyclecounter();
+			st_trace += st_b - st_a;
+#endif
+
+			// trim frayed ends, :1022-1054
+			while (al.k1 > al.k0) {
+				const uint8_t cw = cols[(al.k1 - 1) * STRIDE];
+				if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
+				if (!is_virtual(col_q(cw))) --al.lm_q;
+				if (!is_virtual(col_t(cw))) ++al.lm_t;
+				al.k1--;
+			}
+			while (al.k1 > al.k0) {
+				const uint8_t cw = cols[al.k0 * STRIDE];
+				if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
+				if (!is_virtual(col_q(cw))) ++al.fm_q;
+				if (!is_virtual(col_t(cw))) --al.fm_t;
+				al.k0++;
+			}
+			// advance the branch odometer, :1058-1066
+			if (zero_count == 0 && sp > 0) {
+				while (sp > 0) {
+					uint32_t e = stack[(sp - 1) * STRIDE];
+					const int m = int((e >> 24) & 15u);
+					int cb = int(e >> 28);
+					bool more = false;
+					while ((cb = cb << 1) < 8)
+						if (cb & m) {
+							more = true;
+							break;
+						}
+					if (more) {
+						stack[(sp - 1) * STRIDE] = (e & 0xFFFFFFFu) | (uint32_t(cb) << 28);
+						break;
+					}
+					sp--;
+				}
+				zero_count = -1;
+			}
+#define CONSIDER(SCORE)                                                                              \
+	do {                                                                                             \
+	const Score s_ = (SCORE);                                                                    \
+	if (s_.ok) {                                                                                 \
+		const float local_dg = s_.dH - Tcur * s_.dS;                                               \
+		if (!best_valid || local_dg < best_dg) { /* :1160-1167 */                                \
+			best_valid = true;                                                                   \
+			best_dg = local_dg;                                                                  \
+			best_dH = s_.dH, best_dS = s_.dS, best_tm = s_.tm;                                   \
+			bi = al;                                                                             \
+			for (int k = al.k0; k < al.k1; k++) best[k * STRIDE] = cols[k * STRIDE]; \
+		}                                                                                        \
+	}                                                                                            \
+	} while (0)
+
+			if (FULL && xmode == 3) {
+				// ---------------- enumerate_hairpin_alignments, nuc_cruc.cpp:1264-1405
+				if (al.k1 - al.k0 >= 3) CONSIDER(evaluate_hairpin<STRIDE>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+				// the open end of the stem always gets its dangling / frayed bases (:1307-1324)
+				if (al.lm_t != 0 || al.lm_q != L - 1) {
+					int qb, tb;
+					if (al.lm_t == 0) tb = bE;
+					else tb = QUERY(--al.lm_t);
+					if (al.lm_q == L - 1) qb = bE;
+					else qb = QUERY(++al.lm_q);
+					cols[al.k1 * STRIDE] = mk_col(qb, tb);
+					al.k1++;
+				}
+				const int align_size = al.k1 - al.k0;
+				if (align_size < 3) continue;
+				CONSIDER(evaluate_hairpin<STRIDE>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+				if (align_size <= 3) continue;
+				// an A-T closing pair carries a penalty: try without it (:1356-1405)
+				const int lp = lut_pair(s_lut, QUERY(al.fm_t), QUERY(al.fm_q));
+				if (lp == P_GC || lp == P_CG) continue;
+				al.fm_q++;
+				al.fm_t--;
+				al.k0++;
+				CONSIDER(evaluate_hairpin<STRIDE>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
+				continue;
+			}
+
+			// dangling ends, :1088-1137 (off by default, tntblast.h:55-56)
+			if (s_k.dangle5 && (al.fm_q != 0 || al.fm_t != W - 1)) {
+				int qb, tb;
+				if (al.fm_q == 0) qb = bE;
+				else qb = QUERY(--al.fm_q);
+				if (al.fm_t == W - 1) tb = bE;
+				else tb = TARGET(++al.fm_t);
+				if (al.k1 == al.k0) al.k0 = al.k1 = 1; // empty alignment: restart inside the buffer
+				al.k0--;
+				cols[al.k0 * STRIDE] = mk_col(qb, tb);
+			}
+			if (s_k.dangle3 && (al.lm_q != L - 1 || al.lm_t != 0)) {
+				int qb, tb;
+				if (al.lm_q == L - 1) qb = bE;
+				else qb = QUERY(++al.lm_q);
+				if (al.lm_t == 0) tb = bE;
+				else tb = TARGET(--al.lm_t);
+				cols[al.k1 * STRIDE] = mk_col(qb, tb);
+				al.k1++;
+			}
+			if (al.k1 - al.k0 < 3) continue; // :1148
+#ifdef TNT_EXP_STATS
+			const long long st_c = __builtin_readcyclecounter();
+			st_trim += st_c - st_b;
+#endif
+
+#ifndef TNT_EXP_NOEVAL
+			CONSIDER(evaluate_alignment<STRIDE>(c, al.k0, al.k1, (FULL && xmode == 2) ? MODE_HOMO_DIMER : MODE_HETERO_DIMER));
+#endif
+#ifdef TNT_EXP_STATS
+			st_eval += __builtin_readcyclecounter() - st_c;
+#endif
+#undef CONSIDER
+		}
+	}
+
+	if (DINK) { // the while condition of the Dinkelbach loop, nuc_cruc.cpp:2414-2432
+		const float last_q = dk_q;
+		dk_q = best_dH - Tcur * best_dS; // delta_G() at this pass's temperature (0 when nothing aligned: curr_align.clear())
+		if (dk_q < 0.0f && dk_q > last_q) {
+			Tcur = 273.15f + best_tm; // temperature(NC_ZERO_C + local_tm)
+			return true;           // fill again at that temperature
+		}
+	}
+#ifdef TNT_EXP_STATS
+	const long long st_thr0 = __builtin_readcyclecounter();
+#endif
+	// ------------------------------------------------------------------ thresholds, bind_oligo.cpp:600-714
+	const Thresh th = a.thresh[slot.thresh];
+	const float tm = best_tm;
+	const float dg = best_dH - s_k.temperature * best_dS; // delta_G(), nuc_cruc.h:1217
+	int status = 0;
+	if (tm < th.min_tm || tm > th.max_tm) status = 1;
+	else if (dg < th.min_dg || dg > th.max_dg) status = 2;
+
+#ifdef TNT_EXP_NOOUT
+	a.result[idx] = -1 - (status & 1);
+	return false;
+#endif
+	int a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0, loc5 = 0, loc3 = 0;
+	if (best_valid && (FULL || status == 0)) {
+		const int front_q = col_q(best[bi.k0 * STRIDE]), front_t = col_t(best[bi.k0 * STRIDE]);
+		const int back_q = col_q(best[(bi.k1 - 1) * STRIDE]), back_t = col_t(best[(bi.k1 - 1) * STRIDE]);
+		{ // anchor5_query, nuc_cruc_anchor.cpp:143-192
+			int qi = 0, ti = bi.fm_q + bi.fm_t;
+			bool go = !(front_t == bE);
+			if (front_q == bE) ti--;
+			if (ti >= W) go = false;
+			while (go) {
+				if (qi >= L || ti < 0) break;
+				if (!is_complementary(QUERY(qi), TARGET(ti))) break;
+				a5++, qi++, ti--;
+			}
+		}
+		{ // anchor3_query, nuc_cruc_anchor.cpp:249-298
+			int qi = L - 1, ti = (bi.lm_q + bi.lm_t + 1) - L;
+			bool go = !(back_t == bE);
+			if (back_q == bE) ti++;
+			if (ti >= W || ti < 0) go = false;
+			while (go) {
+				if (qi < 0 || ti >= W) break;
+				if (!is_complementary(QUERY(qi), TARGET(ti))) break;
+				a3++, qi--, ti++;
+			}
+		}
+		{ // num_mismatch_by_query / num_gap / max_contiguous_target_degen, nuc_cruc.h:389-483
+			int aligned = 0, run = 0;
+			for (int k = bi.k0; k < bi.k1; k++) {
+				const uint8_t cw = best[k * STRIDE];
+				const int q = col_q(cw), t = col_t(cw);
+				if (!is_virtual(q)) {
+					if (!is_virtual(t) && !is_complementary(q, t)) mm++;
+					aligned++;
+				}
+				gap += (q == bGAP) + (t == bGAP);
+				if (t >= bM && t <= bN) {
+					run++;
+					if (run > poly) poly = run;
+				} else {
+					run = 0;
+				}
+			}
+			mm += L - aligned;
+		}
+		if (!status) {
+			if (a5 < th.clamp5) status = 3;
+			else if (a3 < th.clamp3) status = 4;
+			else if (mm > th.max_mm) status = 5;
+			else if (gap > th.max_gap) status = 6;
+			else if (poly > th.max_poly) status = 7;
+		}
+		// alignment_range (nuc_cruc_anchor.cpp:379-396) -> plus-strand footprint
+		const int qf = bi.fm_q, ql = bi.lm_q, tf = bi.lm_t, tl = bi.fm_t;
+		loc5 = loc3 = start;
+		if (minus) { // bind_oligo.cpp:721-731
+			loc5 += (stop - start - 1) - tl;
+			loc3 += (stop - start - 1) - tf;
+			loc5 -= qf;
+			loc3 += (L - 1) - ql;
+		} else { // bind_oligo.cpp:1424-1434
+			loc5 += tf;
+			loc3 += tl;
+			loc3 += qf;
+			loc5 -= (L - 1) - ql;
+		}
+	} else if (!best_valid && !status) {
+		status = 8; // SURVEY Q11 fence: no alignment is never a bind
+	}
+
+#ifdef TNT_EXP_STATS
+	const long long st_out0 = __builtin_readcyclecounter();
+#endif
+	// ------------------------------------------------------------------ output
+	char *text = nullptr;
+	int32_t res = -status;
+	BoundRec *rec = nullptr;
+	if (!FULL && status == 0 && a.audit && a.audit[idx]) atomicOr(a.err, ERR_FILTER_UNSOUND);
+	if (status == 0 && !FULL) {
+		const uint32_t slotp = atomicAdd(a.pool_count, 1u);
+		if (slotp < a.pool_cap) {
+			rec = a.pool + slotp;
+			rec->loc5 = loc5, rec->loc3 = loc3;
+			rec->tm = tm, rec->dH = best_dH, rec->dS = best_dS;
+			rec->a5 = a5, rec->a3 = a3, rec->mm = mm, rec->gap = gap;
+			text = rec->text;
+			res = int32_t(slotp);
+			if (a.groups && !(atomicOr(&a.groups[it.group].count, GROUP_ALIVE) & GROUP_ALIVE))
+				a.active[atomicAdd(a.n_active, 1u)] = it.group;
+		} else {
+			atomicOr(a.err, ERR_POOL_OVERFLOW);
+			res = -100;
+		}
+	}
+	if (FULL) {
+		BindFull &f = a.full[idx];
+		f.status = status, f.target_start = start, f.target_stop = stop;
+		f.tm = tm, f.dH = best_dH, f.dS = best_dS, f.dg = dg;
+		f.a5 = a5, f.a3 = a3, f.mm = mm, f.gap = gap, f.poly = poly;
+		f.loc5 = loc5, f.loc3 = loc3;
+		f.q_first = bi.fm_q, f.q_last = bi.lm_q, f.t_first = bi.lm_t, f.t_last = bi.fm_t;
+		f.valid = best_valid ? 1 : 0;
+		f.dp_max = gmax;
+		f.n_max = nmax;
+		f.text[0] = 0;
+		if (best_valid) text = f.text;
+	} else {
+		a.result[idx] = res;
+	}
+
+	if (text) { // operator<<(ostream&, NucCruc), nuc_cruc_output.cpp:74-205
+		int prefix = bi.fm_q < (W - 1 - bi.fm_t) ? bi.fm_q : (W - 1 - bi.fm_t);
+		if (prefix < 0) prefix = 0;
+		int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
+		if (suffix < 0) suffix = 0;
+		// three lines of prefix + columns + suffix and 18 characters of decoration: the field holds every alignment of
+		// a 64-mer; one of a longer oligo that does not fit fails the call (never a cut text)
+		if (LONG_TEXT && 3 * (prefix + (bi.k1 - bi.k0) + suffix) + 18 >= ALIGN_TEXT) {
+			atomicOr(a.err, ERR_TEXT_OVERFLOW);
+			prefix = suffix = 0, bi.k1 = bi.k0;
+		}
+		// (written a dword at a time: every lane writes into a record of its own, so a byte store is a memory request)
+		int o = 0;
+		uint32_t acc = 0;
+		static_assert(offsetof(BoundRec, text) % 4 == 0 && offsetof(BindFull, text) % 4 == 0 && sizeof(BoundRec) % 4 == 0 && sizeof(BindFull) % 4 == 0 && ALIGN_TEXT % 4 == 0,
+		              "text fields on 4-byte boundaries");
+		uint32_t *text32 = reinterpret_cast<uint32_t *>(text);
+		auto put = [&](char ch) __attribute__((always_inline)) {
+			acc |= uint32_t(uint8_t(ch)) << ((o & 3) * 8);
+			o++;
+			if ((o & 3) == 0) text32[(o >> 2) - 1] = acc, acc = 0;
+		};
+		put('5'), put('\''), put(' ');
+		for (int i = 0; i < prefix; i++) put(base_letter(QUERY(bi.fm_q - prefix + i)));
+		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_q(best[k * STRIDE])));
+		for (int i = 0; i < suffix; i++) put(base_letter(QUERY(bi.lm_q + 1 + i)));
+		put(' '), put('3'), put('\''), put('\n');
+		put(' '), put(' '), put(' ');
+		for (int i = 0; i < prefix; i++) put(is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ');
+		for (int k = bi.k0; k < bi.k1; k++) {
+			const uint8_t cw = best[k * STRIDE];
+			put(is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ');
+		}
+		for (int i = 0; i < suffix; i++) put(is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ');
+		put('\n');
+		put('3'), put('\''), put(' ');
+		for (int i = prefix; i > 0; i--) put(base_letter(TARGET(bi.fm_t + i)));
+		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_t(best[k * STRIDE])));
+		for (int i = 1; i <= suffix; i++) put(base_letter(TARGET(bi.lm_t - i)));
+		put(' '), put('5'), put('\'');
+		text32[o >> 2] = acc; // the rest and the terminating zero (acc holds zeros above the characters written)
+		if (rec) rec->text_len = o;
+	}
+#ifdef TNT_EXP_STATS
+	{ // wave-level cycle breakdown of the tail (s_memtime ticks / 64, lane 0 of every wave; waves re-converge here)
+		const long long st_end = __builtin_readcyclecounter();
+		if ((threadIdx.x & 63) == 0) {
+			atomicAdd(a.debug + 0, uint32_t((st_tail0 - st_fill0) >> 6));
+			atomicAdd(a.debug + 1, uint32_t(st_trace >> 6));
+			atomicAdd(a.debug + 2, uint32_t(st_trim >> 6));
+			atomicAdd(a.debug + 3, uint32_t(st_eval >> 6));
+			atomicAdd(a.debug + 4, uint32_t((st_thr0 - st_tail0 - st_trace - st_trim - st_eval) >> 6));
+			atomicAdd(a.debug + 5, uint32_t((st_out0 - st_thr0) >> 6));
+			atomicAdd(a.debug + 6, uint32_t((st_end - st_out0) >> 6));
+			atomicAdd(a.debug + 7, 1u);
+		}
+	}
+#endif
+#undef QUERY
+#undef TARGET
+	return false;
+}
+
 // The bind kernel proper.  LMAX = rows kept in registers (oligos of this launch have L <= LMAX).
 // EXACT: every item of the launch has L == LMAX (the host buckets the queues by length).
 // PLAIN: no window of the launch holds a degenerate (IUPAC) target base (the bucket kernel routes windows that
@@ -824,488 +1334,16 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 		continue;
 #endif
 
-		LaneCtx c;
-		c.tab = a.tab;
-		c.lut = s_lut;
-		c.hs_map = s_hs_map;
-		c.hs_val = s_hs_val;
-		c.k = &s_k;
-		c.win = win;
-		c.query = a.olig_base + size_t(slot.oligo) * MAX_OLIGO;
-		c.cols = cols;
-		c.L = L;
-		c.W = W;
-		c.log_ct = slot.log_ct;
-
+		{
+			SlabTrace<LMAX, BIND_THREADS, PF> tr{trace, s_pf + tid, -1, -1};
+			if (bind_tail<FULL, DINK, QRY_LDS, (LMAX > 64), BIND_THREADS, 8, uint16_t>(a, tr, s_lut, s_hs_map, s_hs_val, s_k, win, qry, cols, best, stack, ties, NCOLS, WMAX + 1, idx, it,
+			                                                                           slot, L, W, start, stop, minus, xmode, gmax, nmax, max_ij, Tcur, dk_q
 #ifdef TNT_EXP_STATS
-		long long st_trace = 0, st_trim = 0, st_eval = 0;
-		const long long st_tail0 = __builtin_readcyclecounter();
+			                                                                           , st_fill0
 #endif
-		bool best_valid = false;
-		float best_dH = 0.0f, best_dS = 0.0f, best_tm = 0.0f;
-		AlignInfo bi = {0, 0, 0, 0, 0, 0};
-
-#define TRACE_AT(I, J) trace[(((J)-1) * LMAX + ((I)-1)) * BIND_THREADS]
-#define QUERY(K) (QRY_LDS ? int(qry[(L - 1 - (K)) * BIND_THREADS]) : int(c.query[(K)]))
-#define TARGET(K) int(win[(K) * BIND_THREADS])
-
-		// tm_dimer: every maximal cell in row-major order (nuc_cruc.cpp:2533-2537).  Cell codes (i << 8 | j)
-		// sort row-major numerically; the first maximal cell lives in max_ij, later ties in ties[1..nmax-1].
-		if (nmax > TIE_CAP) {
-			atomicOr(a.err, ERR_TIE_OVERFLOW);
-			nmax = TIE_CAP;
-		}
-		if (nmax > 1) {
-			ties[0] = uint16_t(max_ij);
-			for (int x = 1; x < nmax; x++) { // insertion sort, rare path
-				const uint16_t v = ties[x * BIND_THREADS];
-				int y = x - 1;
-				while (y >= 0 && ties[y * BIND_THREADS] > v) {
-					ties[(y + 1) * BIND_THREADS] = ties[y * BIND_THREADS];
-					y--;
-				}
-				ties[(y + 1) * BIND_THREADS] = v;
-			}
-		}
-		for (int mc = 0; mc < nmax; mc++) {
-			const int code = (nmax == 1) ? max_ij : int(ties[mc * BIND_THREADS]);
-			const int ci = code >> 8, cj = code & 255;
-
-			// ---------------- enumerate_dimer_alignments, nuc_cruc.cpp:973-1170
-			bool first_time = true;
-			int sp = 0;
-			int zero_count = -1;
-			unsigned trace_count = 0;
-			float best_dg = best_dH - Tcur * best_dS;
-			while (true) {
-				if (!first_time && sp == 0 && zero_count <= 0) break;
-				if (16u < trace_count) break;
-				trace_count++;
-				first_time = false;
-
-#ifdef TNT_EXP_STATS
-				const long long st_a = __builtin_readcyclecounter();
-#endif
-				// ---------------- trace_back, nuc_cruc.cpp:1409-1618
-				AlignInfo al;
-				al.k0 = 1;
-				int n = 0; // columns written at cols[1 + n]
-				int li = ci, lj = cj;
-				al.fm_q = L - li;
-				al.fm_t = lj - 1;
-				al.lm_q = 0;
-				al.lm_t = 0;
-				int truncate_at_zero = 0;
-				bool count_zeros = false;
-				if (zero_count < 0) {
-					zero_count = 0;
-					count_zeros = true;
-				} else {
-					truncate_at_zero = zero_count--;
-				}
-				int key = -1;
-				int mask = 1;
-				int pf_i = -1, pf_j = -1; // first cell of the diagonal run held in s_pf (none yet)
-				while (true) {
-					bool valid = true;
-					int local;
-					if (((mask & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1)) > 1) { // PATH_SPLIT
-						int f = 0;
-						for (; f < sp; f++)
-							if (int(stack[f * BIND_THREADS] & 0xFFFFu) == key) break;
-						if (f == sp) {
-							const int curb = (mask & 1) ? 1 : ((mask & 2) ? 2 : 4);
-							if (sp < NCOLS) {
-								stack[sp * BIND_THREADS] = uint32_t(key) | (uint32_t(mask) << 16) | (uint32_t(curb) << 20);
-								sp++;
-							} else {
-								atomicOr(a.err, ERR_STACK_OVERFLOW);
-							}
-							local = curb;
-						} else {
-							local = int((stack[f * BIND_THREADS] >> 20) & 15u);
-						}
-					} else {
-						local = mask;
-					}
-					// border cells hold M = I_query = I_target = -1 (nuc_cruc.h:531-536)
-					const bool inside = (li >= 1 && lj >= 1);
-					// The path mostly runs down a diagonal: PF cells of the current diagonal are fetched at once (one
-					// memory latency instead of one per step) and refilled when the walk leaves the run.
-					int tw = TW_M_NEG | TW_IQ_NEG | TW_IT_NEG; // border cell
-					if (inside) {
-						int d = pf_i - li;
-						if (pf_i < 0 || d < 0 || d >= PF || pf_j - lj != d) {
-							uint8_t v[PF];
-#pragma unroll
-							for (int k = 0; k < PF; k++) v[k] = (li - k >= 1 && lj - k >= 1) ? TRACE_AT(li - k, lj - k) : uint8_t(0);
-#pragma unroll
-							for (int k = 0; k < PF; k++) s_pf[k * BIND_THREADS + tid] = v[k];
-							pf_i = li, pf_j = lj;
-							d = 0;
-						}
-						tw = int(s_pf[d * BIND_THREADS + tid]);
-					}
-					const int cidx = li * (WMAX + 1) + lj;
-					if (local == 1) { // query_target
-						if (li > L || lj < 1 || li < 1 /* Q7 fence */) {
-							valid = false;
-						} else {
-							if ((tw & TW_M_NEG) == TW_M_NEG) valid = false;
-							else if (tw & TW_M_LE0) {
-								if (count_zeros) zero_count++;
-								else if (--truncate_at_zero == 0) valid = false;
-							}
-							cols[(1 + n) * BIND_THREADS] = mk_col(QUERY(L - li), TARGET(lj - 1));
-							n++;
-							al.lm_q = L - li;
-							al.lm_t = lj - 1;
-							mask = ((tw & TW_M_NOT_M) ? 0 : 1) | ((tw & TW_M_NOT_IT) ? 0 : 2) | ((tw & TW_M_NOT_IQ) ? 0 : 4);
-							key = cidx * 4 + 0;
-							li--, lj--;
-						}
-					} else if (local == 4) { // gap_target: GAP in the query strand, state I_query
-						if (lj < 1) {
-							valid = false;
-						} else {
-							if ((tw & TW_IQ_NEG) == TW_IQ_NEG) valid = false;
-							cols[(1 + n) * BIND_THREADS] = mk_col(bGAP, TARGET(lj - 1));
-							n++;
-							al.lm_q = L - li + 1;
-							al.lm_t = lj - 1;
-							mask = ((tw & TW_IQ_LT) ? 0 : 1) | ((tw & TW_IQ_GT) ? 0 : 4); // insert >= extend: from M; extend >= insert: from I_query
-							key = cidx * 4 + 1;
-							lj--;
-						}
-					} else { // query_gap: GAP in the target strand, state I_target
-						if (li > L || li < 1 /* Q7 fence */) {
-							valid = false;
-						} else {
-							if ((tw & TW_IT_NEG) == TW_IT_NEG) valid = false;
-							cols[(1 + n) * BIND_THREADS] = mk_col(QUERY(L - li), bGAP);
-							n++;
-							al.lm_q = L - li;
-							al.lm_t = lj;
-							mask = ((tw & TW_IT_LT) ? 0 : 1) | ((tw & TW_IT_GT) ? 0 : 2);
-							key = cidx * 4 + 2;
-							li--;
-						}
-					}
-					if (!valid) break;
-				}
-				al.k1 = 1 + n;
-#ifdef TNT_EXP_STATS
-				const long long st_b = __builtin_readcyclecounter();
-				st_trace += st_b - st_a;
-#endif
-
-				// trim frayed ends, :1022-1054
-				while (al.k1 > al.k0) {
-					const uint8_t cw = cols[(al.k1 - 1) * BIND_THREADS];
-					if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
-					if (!is_virtual(col_q(cw))) --al.lm_q;
-					if (!is_virtual(col_t(cw))) ++al.lm_t;
-					al.k1--;
-				}
-				while (al.k1 > al.k0) {
-					const uint8_t cw = cols[al.k0 * BIND_THREADS];
-					if (is_wc(lut_pair(s_lut, col_q(cw), col_t(cw)))) break;
-					if (!is_virtual(col_q(cw))) ++al.fm_q;
-					if (!is_virtual(col_t(cw))) --al.fm_t;
-					al.k0++;
-				}
-				// advance the branch odometer, :1058-1066
-				if (zero_count == 0 && sp > 0) {
-					while (sp > 0) {
-						uint32_t e = stack[(sp - 1) * BIND_THREADS];
-						const int m = int((e >> 16) & 15u);
-						int cb = int((e >> 20) & 15u);
-						bool more = false;
-						while ((cb = cb << 1) < 8)
-							if (cb & m) {
-								more = true;
-								break;
-							}
-						if (more) {
-							stack[(sp - 1) * BIND_THREADS] = (e & 0xFFFFFu) | (uint32_t(cb) << 20);
-							break;
-						}
-						sp--;
-					}
-					zero_count = -1;
-				}
-#define CONSIDER(SCORE)                                                                              \
-	do {                                                                                             \
-		const Score s_ = (SCORE);                                                                    \
-		if (s_.ok) {                                                                                 \
-			const float local_dg = s_.dH - Tcur * s_.dS;                                               \
-			if (!best_valid || local_dg < best_dg) { /* :1160-1167 */                                \
-				best_valid = true;                                                                   \
-				best_dg = local_dg;                                                                  \
-				best_dH = s_.dH, best_dS = s_.dS, best_tm = s_.tm;                                   \
-				bi = al;                                                                             \
-				for (int k = al.k0; k < al.k1; k++) best[k * BIND_THREADS] = cols[k * BIND_THREADS]; \
-			}                                                                                        \
-		}                                                                                            \
-	} while (0)
-
-				if (FULL && xmode == 3) {
-					// ---------------- enumerate_hairpin_alignments, nuc_cruc.cpp:1264-1405
-					if (al.k1 - al.k0 >= 3) CONSIDER(evaluate_hairpin<BIND_THREADS>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
-					// the open end of the stem always gets its dangling / frayed bases (:1307-1324)
-					if (al.lm_t != 0 || al.lm_q != L - 1) {
-						int qb, tb;
-						if (al.lm_t == 0) tb = bE;
-						else tb = QUERY(--al.lm_t);
-						if (al.lm_q == L - 1) qb = bE;
-						else qb = QUERY(++al.lm_q);
-						cols[al.k1 * BIND_THREADS] = mk_col(qb, tb);
-						al.k1++;
-					}
-					const int align_size = al.k1 - al.k0;
-					if (align_size < 3) continue;
-					CONSIDER(evaluate_hairpin<BIND_THREADS>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
-					if (align_size <= 3) continue;
-					// an A-T closing pair carries a penalty: try without it (:1356-1405)
-					const int lp = lut_pair(s_lut, QUERY(al.fm_t), QUERY(al.fm_q));
-					if (lp == P_GC || lp == P_CG) continue;
-					al.fm_q++;
-					al.fm_t--;
-					al.k0++;
-					CONSIDER(evaluate_hairpin<BIND_THREADS>(c, a.tab, al, QRY_LDS ? nullptr : c.query, qry, L));
-					continue;
-				}
-
-				// dangling ends, :1088-1137 (off by default, tntblast.h:55-56)
-				if (s_k.dangle5 && (al.fm_q != 0 || al.fm_t != W - 1)) {
-					int qb, tb;
-					if (al.fm_q == 0) qb = bE;
-					else qb = QUERY(--al.fm_q);
-					if (al.fm_t == W - 1) tb = bE;
-					else tb = TARGET(++al.fm_t);
-					if (al.k1 == al.k0) al.k0 = al.k1 = 1; // empty alignment: restart inside the buffer
-					al.k0--;
-					cols[al.k0 * BIND_THREADS] = mk_col(qb, tb);
-				}
-				if (s_k.dangle3 && (al.lm_q != L - 1 || al.lm_t != 0)) {
-					int qb, tb;
-					if (al.lm_q == L - 1) qb = bE;
-					else qb = QUERY(++al.lm_q);
-					if (al.lm_t == 0) tb = bE;
-					else tb = TARGET(--al.lm_t);
-					cols[al.k1 * BIND_THREADS] = mk_col(qb, tb);
-					al.k1++;
-				}
-				if (al.k1 - al.k0 < 3) continue; // :1148
-#ifdef TNT_EXP_STATS
-				const long long st_c = __builtin_readcyclecounter();
-				st_trim += st_c - st_b;
-#endif
-
-#ifndef TNT_EXP_NOEVAL
-				CONSIDER(evaluate_alignment<BIND_THREADS>(c, al.k0, al.k1, (FULL && xmode == 2) ? MODE_HOMO_DIMER : MODE_HETERO_DIMER));
-#endif
-#ifdef TNT_EXP_STATS
-				st_eval += __builtin_readcyclecounter() - st_c;
-#endif
-#undef CONSIDER
-			}
-		}
-
-		if (DINK) { // the while condition of the Dinkelbach loop, nuc_cruc.cpp:2414-2432
-			const float last_q = dk_q;
-			dk_q = best_dH - Tcur * best_dS; // delta_G() at this pass's temperature (0 when nothing aligned: curr_align.clear())
-			if (dk_q < 0.0f && dk_q > last_q) {
-				Tcur = 273.15f + best_tm; // temperature(NC_ZERO_C + local_tm)
+			                                                                           ))
 				goto dinkelbach_pass;
-			}
 		}
-#ifdef TNT_EXP_STATS
-		const long long st_thr0 = __builtin_readcyclecounter();
-#endif
-		// ------------------------------------------------------------------ thresholds, bind_oligo.cpp:600-714
-		const Thresh th = a.thresh[slot.thresh];
-		const float tm = best_tm;
-		const float dg = best_dH - s_k.temperature * best_dS; // delta_G(), nuc_cruc.h:1217
-		int status = 0;
-		if (tm < th.min_tm || tm > th.max_tm) status = 1;
-		else if (dg < th.min_dg || dg > th.max_dg) status = 2;
-
-#ifdef TNT_EXP_NOOUT
-		a.result[idx] = -1 - (status & 1);
-		continue;
-#endif
-		int a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0, loc5 = 0, loc3 = 0;
-		if (best_valid && (FULL || status == 0)) {
-			const int front_q = col_q(best[bi.k0 * BIND_THREADS]), front_t = col_t(best[bi.k0 * BIND_THREADS]);
-			const int back_q = col_q(best[(bi.k1 - 1) * BIND_THREADS]), back_t = col_t(best[(bi.k1 - 1) * BIND_THREADS]);
-			{ // anchor5_query, nuc_cruc_anchor.cpp:143-192
-				int qi = 0, ti = bi.fm_q + bi.fm_t;
-				bool go = !(front_t == bE);
-				if (front_q == bE) ti--;
-				if (ti >= W) go = false;
-				while (go) {
-					if (qi >= L || ti < 0) break;
-					if (!is_complementary(QUERY(qi), TARGET(ti))) break;
-					a5++, qi++, ti--;
-				}
-			}
-			{ // anchor3_query, nuc_cruc_anchor.cpp:249-298
-				int qi = L - 1, ti = (bi.lm_q + bi.lm_t + 1) - L;
-				bool go = !(back_t == bE);
-				if (back_q == bE) ti++;
-				if (ti >= W || ti < 0) go = false;
-				while (go) {
-					if (qi < 0 || ti >= W) break;
-					if (!is_complementary(QUERY(qi), TARGET(ti))) break;
-					a3++, qi--, ti++;
-				}
-			}
-			{ // num_mismatch_by_query / num_gap / max_contiguous_target_degen, nuc_cruc.h:389-483
-				int aligned = 0, run = 0;
-				for (int k = bi.k0; k < bi.k1; k++) {
-					const uint8_t cw = best[k * BIND_THREADS];
-					const int q = col_q(cw), t = col_t(cw);
-					if (!is_virtual(q)) {
-						if (!is_virtual(t) && !is_complementary(q, t)) mm++;
-						aligned++;
-					}
-					gap += (q == bGAP) + (t == bGAP);
-					if (t >= bM && t <= bN) {
-						run++;
-						if (run > poly) poly = run;
-					} else {
-						run = 0;
-					}
-				}
-				mm += L - aligned;
-			}
-			if (!status) {
-				if (a5 < th.clamp5) status = 3;
-				else if (a3 < th.clamp3) status = 4;
-				else if (mm > th.max_mm) status = 5;
-				else if (gap > th.max_gap) status = 6;
-				else if (poly > th.max_poly) status = 7;
-			}
-			// alignment_range (nuc_cruc_anchor.cpp:379-396) -> plus-strand footprint
-			const int qf = bi.fm_q, ql = bi.lm_q, tf = bi.lm_t, tl = bi.fm_t;
-			loc5 = loc3 = start;
-			if (minus) { // bind_oligo.cpp:721-731
-				loc5 += (stop - start - 1) - tl;
-				loc3 += (stop - start - 1) - tf;
-				loc5 -= qf;
-				loc3 += (L - 1) - ql;
-			} else { // bind_oligo.cpp:1424-1434
-				loc5 += tf;
-				loc3 += tl;
-				loc3 += qf;
-				loc5 -= (L - 1) - ql;
-			}
-		} else if (!best_valid && !status) {
-			status = 8; // SURVEY Q11 fence: no alignment is never a bind
-		}
-
-#ifdef TNT_EXP_STATS
-		const long long st_out0 = __builtin_readcyclecounter();
-#endif
-		// ------------------------------------------------------------------ output
-		char *text = nullptr;
-		int32_t res = -status;
-		BoundRec *rec = nullptr;
-		if (!FULL && status == 0 && a.audit && a.audit[idx]) atomicOr(a.err, ERR_FILTER_UNSOUND);
-		if (status == 0 && !FULL) {
-			const uint32_t slotp = atomicAdd(a.pool_count, 1u);
-			if (slotp < a.pool_cap) {
-				rec = a.pool + slotp;
-				rec->loc5 = loc5, rec->loc3 = loc3;
-				rec->tm = tm, rec->dH = best_dH, rec->dS = best_dS;
-				rec->a5 = a5, rec->a3 = a3, rec->mm = mm, rec->gap = gap;
-				text = rec->text;
-				res = int32_t(slotp);
-				if (a.groups && !(atomicOr(&a.groups[it.group].count, GROUP_ALIVE) & GROUP_ALIVE))
-					a.active[atomicAdd(a.n_active, 1u)] = it.group;
-			} else {
-				atomicOr(a.err, ERR_POOL_OVERFLOW);
-				res = -100;
-			}
-		}
-		if (FULL) {
-			BindFull &f = a.full[idx];
-			f.status = status, f.target_start = start, f.target_stop = stop;
-			f.tm = tm, f.dH = best_dH, f.dS = best_dS, f.dg = dg;
-			f.a5 = a5, f.a3 = a3, f.mm = mm, f.gap = gap, f.poly = poly;
-			f.loc5 = loc5, f.loc3 = loc3;
-			f.q_first = bi.fm_q, f.q_last = bi.lm_q, f.t_first = bi.lm_t, f.t_last = bi.fm_t;
-			f.valid = best_valid ? 1 : 0;
-			f.dp_max = gmax;
-			f.n_max = nmax;
-			f.text[0] = 0;
-			if (best_valid) text = f.text;
-		} else {
-			a.result[idx] = res;
-		}
-
-		if (text) { // operator<<(ostream&, NucCruc), nuc_cruc_output.cpp:74-205
-			int prefix = bi.fm_q < (W - 1 - bi.fm_t) ? bi.fm_q : (W - 1 - bi.fm_t);
-			if (prefix < 0) prefix = 0;
-			int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
-			if (suffix < 0) suffix = 0;
-			// three lines of prefix + columns + suffix and 18 characters of decoration: the field holds every alignment of
-			// a 64-mer; one of a longer oligo that does not fit fails the call (never a cut text)
-			if (LMAX > 64 && 3 * (prefix + (bi.k1 - bi.k0) + suffix) + 18 >= ALIGN_TEXT) {
-				atomicOr(a.err, ERR_TEXT_OVERFLOW);
-				prefix = suffix = 0, bi.k1 = bi.k0;
-			}
-			// (written a dword at a time: every lane writes into a record of its own, so a byte store is a memory request)
-			int o = 0;
-			uint32_t acc = 0;
-			static_assert(offsetof(BoundRec, text) % 4 == 0 && offsetof(BindFull, text) % 4 == 0 && sizeof(BoundRec) % 4 == 0 && sizeof(BindFull) % 4 == 0 && ALIGN_TEXT % 4 == 0,
-			              "text fields on 4-byte boundaries");
-			uint32_t *text32 = reinterpret_cast<uint32_t *>(text);
-			auto put = [&](char ch) __attribute__((always_inline)) {
-				acc |= uint32_t(uint8_t(ch)) << ((o & 3) * 8);
-				o++;
-				if ((o & 3) == 0) text32[(o >> 2) - 1] = acc, acc = 0;
-			};
-			put('5'), put('\''), put(' ');
-			for (int i = 0; i < prefix; i++) put(base_letter(QUERY(bi.fm_q - prefix + i)));
-			for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_q(best[k * BIND_THREADS])));
-			for (int i = 0; i < suffix; i++) put(base_letter(QUERY(bi.lm_q + 1 + i)));
-			put(' '), put('3'), put('\''), put('\n');
-			put(' '), put(' '), put(' ');
-			for (int i = 0; i < prefix; i++) put(is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ');
-			for (int k = bi.k0; k < bi.k1; k++) {
-				const uint8_t cw = best[k * BIND_THREADS];
-				put(is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ');
-			}
-			for (int i = 0; i < suffix; i++) put(is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ');
-			put('\n');
-			put('3'), put('\''), put(' ');
-			for (int i = prefix; i > 0; i--) put(base_letter(TARGET(bi.fm_t + i)));
-			for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_t(best[k * BIND_THREADS])));
-			for (int i = 1; i <= suffix; i++) put(base_letter(TARGET(bi.lm_t - i)));
-			put(' '), put('5'), put('\'');
-			text32[o >> 2] = acc; // the rest and the terminating zero (acc holds zeros above the characters written)
-			if (rec) rec->text_len = o;
-		}
-#ifdef TNT_EXP_STATS
-		{ // wave-level cycle breakdown of the tail (s_memtime ticks / 64, lane 0 of every wave; waves re-converge here)
-			const long long st_end = __builtin_readcyclecounter();
-			if ((tid & 63) == 0) {
-				atomicAdd(a.debug + 0, uint32_t((st_tail0 - st_fill0) >> 6));
-				atomicAdd(a.debug + 1, uint32_t(st_trace >> 6));
-				atomicAdd(a.debug + 2, uint32_t(st_trim >> 6));
-				atomicAdd(a.debug + 3, uint32_t(st_eval >> 6));
-				atomicAdd(a.debug + 4, uint32_t((st_thr0 - st_tail0 - st_trace - st_trim - st_eval) >> 6));
-				atomicAdd(a.debug + 5, uint32_t((st_out0 - st_thr0) >> 6));
-				atomicAdd(a.debug + 6, uint32_t((st_end - st_out0) >> 6));
-				atomicAdd(a.debug + 7, 1u);
-			}
-		}
-#endif
-#undef TRACE_AT
-#undef QUERY
-#undef TARGET
 	}
 }
 
@@ -1321,6 +1359,14 @@ TNT_LONG_LADDER(X)
 #define X(N) void launch_bind_exact_##N(const BindArgs &a, int blocks, hipStream_t stream);
 TNT_EXACT_LADDER(X)
 #undef X
+// the wavefront-per-window form (tnt_wbind.hip.h, instances in tnt_wbind_inst.hip): N = query rows per lane, oligos of up
+// to 64 * N bases; `full` = the unit-level form (any request kind, dp_max / n_max reported)
+#define TNT_WBIND_LADDER(X) X(1) X(2)
+#define X(N) void launch_wbind_##N(const BindArgs &a, int blocks, hipStream_t stream); void launch_wbind_full_##N(const BindArgs &a, int blocks, hipStream_t stream);
+TNT_WBIND_LADDER(X)
+#undef X
+constexpr int wb_waves(int R) { return R == 1 ? 4 : (R == 2 ? 2 : 1); }    // wavefronts (= windows in flight) per workgroup
+constexpr int wb_blocks_per_cu(int R) { return R == 1 ? 3 : (R == 2 ? 2 : 1); } // resident workgroups (LDS: 54 KB / 67 KB each)
 
 } // namespace tnt
 #endif

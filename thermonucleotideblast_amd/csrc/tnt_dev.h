@@ -212,6 +212,13 @@ constexpr uint32_t N_SHARD = 32, SHARD_STRIDE = 32;
 // linear index -> physical index of a sharded array: `pre` = exclusive prefix sums of the shard counts
 // (N_SHARD + 1 entries), `region` = capacity of one shard
 #if defined(__HIPCC__)
+// wave-synchronous LDS hand-off between phases of the same wavefront
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ uint32_t shard_locate(const uint32_t *pre, uint32_t lin, uint32_t region)
 {
 	uint32_t r = 0;

@@ -436,8 +436,10 @@ template <class T> struct DevBuf {
 	hipError_t alloc(size_t count)
 	{
 		release();
-		n = count;
-		return hipMalloc((void **)&p, std::max<size_t>(1, count) * sizeof(T));
+		const hipError_t e = hipMalloc((void **)&p, std::max<size_t>(1, count) * sizeof(T));
+		if (e != hipSuccess) p = nullptr; // a failed allocation leaves an empty buffer (n = 0): callers that keep buffers across
+		else n = count;                  // searches and only grow them (`cap > buf.n`) allocate again instead of using a null pointer
+		return e;
 	}
 	hipError_t upload(const std::vector<T> &v)
 	{
@@ -558,6 +560,7 @@ struct tnt_ctx {
 	bool filter_long = true; // the 128-row pre-filter instances are worth their time (calibrate_long_filter)
 	float filter_long_rate = -1.0f; // share of the calibration windows they rejected (-1: not measured)
 	bool filter_status_exact = false; // set around launches whose caller reports statuses (tnt_bind_batch_routed)
+	int wave_from = 0;        // buckets of this many rows or more are bound by the wavefront-per-window kernel (tnt_wbind.hip.h); 0: none (TNT_MI355X_WAVE_BIND)
 	bool serial_bind = false; // profiling: every launch of the bind stage on one side stream (per-kernel durations add up to the stage time)
 	DevBuf<uint8_t> olig_base;
 	DevBuf<uint32_t> olig_q4;
@@ -582,6 +585,7 @@ struct tnt_ctx {
 	std::vector<uint32_t> h_q_base, h_q_cap;
 	bool q_planned_exceptions = false;
 	uint32_t batch_regions = 0;      // regions (wavefronts) of the batch that ran last
+	bool batch_direct = false;       // ... and whether it went through seed2_kernel (per-wavefront regions) or the round-2 kernel (32 shards)
 	DevBuf<Thresh> thresh;
 	DevBuf<AssayDev> assays;
 	DevBuf<uint32_t> wt_ent, wl_off;
@@ -785,6 +789,21 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 	}
 }
 
+// the wavefront-per-window form of the bind kernel (tnt_wbind.hip.h): rows per lane by the longest oligo of the launch
+int wbind_rows_per_lane(int rows) { return rows <= 64 ? 1 : 2; }
+void launch_wbind(tnt_ctx *c, const BindArgs &a, int rows, bool full, hipStream_t stream, size_t n_items = 0 /* 0: a full queue */)
+{
+	const int R = wbind_rows_per_lane(rows);
+	int blocks = c->n_cu * wb_blocks_per_cu(R) * 2; // persistent grid: 2 x the resident workgroups
+	if (n_items) blocks = int(std::min<size_t>(size_t(blocks), (n_items + size_t(wb_waves(R)) - 1) / size_t(wb_waves(R))));
+	switch (R) {
+#define X(N) case N: if (full) tnt::launch_wbind_full_##N(a, blocks, stream); else tnt::launch_wbind_##N(a, blocks, stream); break;
+		TNT_WBIND_LADDER(X)
+#undef X
+	default: break;
+	}
+}
+
 // is there a pre-filter instance of this many rows (degen: for windows with any target code)?
 bool has_filter_instance(int rows, bool degen)
 {
@@ -890,7 +909,11 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.index_stride = direct ? 4 : 1;
 		b.index_base_dev = direct ? nullptr : cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
 		b.n_items_dev = cnt + C_BUCKET + i * BUCKET_STRIDE;
-		b.n_items = uint32_t(c->item_cap); // cap on the device count
+		// cap on the device count.  Direct queues: the bucket's own region -- when a region overflows the seed kernel keeps
+		// counting blocks past q_cap (and raises ERR_ITEM_OVERFLOW: the batch is repeated smaller), and the launches behind it
+		// in this batch must not read into the next bucket's region or past the end of the queue buffer meanwhile
+		const uint32_t queue_cap = direct ? c->h_q_cap[i] : uint32_t(c->item_cap);
+		b.n_items = queue_cap;
 		b.audit = nullptr;
 		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) && ((c->bucket_lmax[i] & 0xFF) <= 64 || c->filter_long) &&
 		    has_filter_instance(c->bucket_lmax[i] & 0xFF, !(c->bucket_lmax[i] & BUCKET_PLAIN))) {
@@ -910,7 +933,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.fat = direct ? c->S().qfat.p + c->h_q_base[i] : nullptr;
 			f.index_base_dev = b.index_base_dev;
 			f.n_items_dev = b.n_items_dev;
-			f.n_items = uint32_t(c->item_cap);
+			f.n_items = queue_cap;
 			f.survivors = survivors;
 			f.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 3;
 			f.result = b.result;
@@ -932,7 +955,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.best = c->best.p + size_t(lane) * c->lane_cols;
 		b.stack = c->stack.p + size_t(lane) * c->lane_cols;
 		b.ties = c->ties.p + size_t(lane) * c->lane_ties;
-		launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
+		if (c->wave_from && (c->bucket_lmax[i] & 0xFF) >= c->wave_from && !c->opt.use_dinkelbach) launch_wbind(c, b, c->bucket_lmax[i] & 0xFF, false, c->lane_stream[lane]);
+		else launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
 	}
 	for (int l = 0; l < c->lanes && (l < n_launch || c->split_filter); l++) {
 		(void)hipEventRecord(c->lane_done[l], c->lane_stream[l]);
@@ -1312,6 +1336,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	c->filter_audit = c->filter_on && getenv("TNT_MI355X_FILTER_AUDIT");
 	c->filter_general = c->filter_on && !getenv("TNT_MI355X_NO_FILTER_GENERAL");
 	c->serial_bind = getenv("TNT_MI355X_SERIAL_BIND") != nullptr;
+	if (const char *e = getenv("TNT_MI355X_WAVE_BIND")) c->wave_from = std::max(0, atoi(e)); // A/B switch: 1 = every bucket, 33 = oligos of 33 bases and more, ...
 	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
 	std::vector<uint32_t> orv(std::max<size_t>(1, c->oligos.size()) * (MAX_OLIGO / 4), 0);
 	std::vector<int32_t> ol(std::max<size_t>(1, c->oligos.size()), 0);
@@ -2196,6 +2221,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	// the round-3 seed kernel: private regions, phase-A items straight into their buckets' queues (its queue entries hold the
 	// windows' packed-word index in 32 bits)
 	const bool direct = c->seed2 && !seeds_only && db->h_word_off[db->n_targets] < (uint64_t(1) << 32);
+	c->batch_direct = direct;
 	if (direct) {
 		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * 4, tnt_ctx::MAX_REGIONS / S2_WAVES)));
 		const uint32_t regions = blocks * S2_WAVES;
@@ -2481,6 +2507,8 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 		for (size_t b = 0; b < nb; b++) {
 			if (!(weight[b] > 0.0)) continue;
 			uint64_t cap = floor_slots + uint64_t(spare * weight[b] / total);
+			// (test hook: regions of at most this many slots, so that a small workload overflows one and meets the repair)
+			if (const char *e = getenv("TNT_MI355X_QUEUE_SLOTS")) cap = std::min<uint64_t>(cap, std::max<uint64_t>(QUEUE_BLOCK, strtoull(e, nullptr, 10)));
 			cap &= ~uint64_t(QUEUE_BLOCK - 1);
 			c->h_q_base[b] = uint32_t(at);
 			c->h_q_cap[b] = uint32_t(cap);
@@ -2876,17 +2904,20 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 			return TNT_E_LIMIT;
 		}
 		// where the seed kernel left its items and groups: 32 shards (round-2 kernel), or one region per wavefront
-		std::vector<uint32_t> rc;
+		// (the batch says which kernel filled it: a database of 2^32 packed words or more goes through the round-2 kernel also
+		// in a context that otherwise uses seed2_kernel)
+		std::vector<uint32_t> region_n;
 		uint32_t n_regions = N_SHARD;
 		size_t ir = item_region, gr = group_region;
-		if (ctx->seed2) {
+		const bool by_wavefront = ctx->batch_direct && ctx->batch_regions != 0;
+		if (by_wavefront) {
 			n_regions = ctx->batch_regions;
 			ir = ctx->item_cap / n_regions, gr = ctx->group_cap / n_regions;
-			rc.resize(2 * size_t(n_regions));
-			HIP_TRY(hipMemcpy(rc.data(), ctx->S().region_counts.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
+			region_n.resize(2 * size_t(n_regions));
+			HIP_TRY(hipMemcpy(region_n.data(), ctx->S().region_counts.p, region_n.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
 		}
 		for (uint32_t r = 0; r < n_regions; r++) {
-			const uint32_t ni = ctx->seed2 ? rc[2 * r] : cnt[C_ITEMS + r * SHARD_STRIDE], ng = ctx->seed2 ? rc[2 * r + 1] : cnt[C_GROUPS + r * SHARD_STRIDE];
+			const uint32_t ni = by_wavefront ? region_n[2 * r] : cnt[C_ITEMS + r * SHARD_STRIDE], ng = by_wavefront ? region_n[2 * r + 1] : cnt[C_GROUPS + r * SHARD_STRIDE];
 			if (!ni) continue;
 			const size_t item_region = ir, group_region = gr;
 			items.resize(ni);
@@ -2922,7 +2953,11 @@ int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, 
 int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out, int route)
 {
 	if (!ctx || !db || db->ctx != ctx || (!req && n) || (!out && n)) return TNT_E_ARG;
-	if (route != TNT_ROUTE_UNIT && route != TNT_ROUTE_BUCKETS && route != TNT_ROUTE_MERGED) return TNT_E_ARG;
+	if (route != TNT_ROUTE_UNIT && route != TNT_ROUTE_BUCKETS && route != TNT_ROUTE_MERGED && route != TNT_ROUTE_WAVE && route != TNT_ROUTE_WAVE_UNIT) return TNT_E_ARG;
+	if ((route == TNT_ROUTE_WAVE || route == TNT_ROUTE_WAVE_UNIT) && ctx->opt.use_dinkelbach) {
+		ctx->err = "the wavefront-per-window kernel has no Dinkelbach passes";
+		return TNT_E_UNSUPPORTED;
+	}
 	if (ctx->pending) {
 		ctx->err = "a search is pending on this context: collect it first";
 		return TNT_E_ARG;
@@ -2973,6 +3008,9 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 	if (route == TNT_ROUTE_UNIT) {
 		b.full = dfull.p;
 		launch_bind(ctx, b, int(std::min<size_t>(ctx->bind_blocks, (n + size_t(bind_threads(0)) - 1) / size_t(bind_threads(0)))), 0);
+	} else if (route == TNT_ROUTE_WAVE_UNIT) {
+		b.full = dfull.p;
+		launch_wbind(ctx, b, ctx->unit_rows, true, ctx->stream, n);
 	} else {
 		// the path tnt_search takes: the queue is split by bucket_kernel and every request is bound by the throughput
 		// instance of its oligo length (exact / plain ladder / general for windows with degenerate bases)
@@ -2983,7 +3021,10 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		HIP_TRY(hipMemcpy(ctx->S().qb.p, queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
 		HIP_TRY(hipMemcpy(ctx->S().counters.p + C_QB, &n32, sizeof(uint32_t), hipMemcpyHostToDevice), ctx->err);
 		ctx->filter_status_exact = true; // this caller reports the status of every request
-		launch_bind_phase(ctx, b, b.db, db->n_exceptions != 0, ctx->S().qb.p, ctx->S().counters.p + C_QB, nullptr, route == TNT_ROUTE_BUCKETS ? 1 : 2);
+		const int wave_from = ctx->wave_from;
+		if (route == TNT_ROUTE_WAVE) ctx->wave_from = 1; // every length bucket through the wavefront-per-window kernel
+		launch_bind_phase(ctx, b, b.db, db->n_exceptions != 0, ctx->S().qb.p, ctx->S().counters.p + C_QB, nullptr, route == TNT_ROUTE_MERGED ? 2 : 1);
+		ctx->wave_from = wave_from;
 		ctx->filter_status_exact = false;
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);
@@ -2994,7 +3035,7 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		ctx->err = err_text(cnt[C_ERR]);
 		return TNT_E_LIMIT;
 	}
-	if (route != TNT_ROUTE_UNIT) {
+	if (route != TNT_ROUTE_UNIT && route != TNT_ROUTE_WAVE_UNIT) {
 		// what the throughput instances leave behind: a status per request and, for bound ones, the pool record
 		std::vector<int32_t> res(n);
 		HIP_TRY(hipMemcpy(res.data(), ctx->S().result.p, n * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);

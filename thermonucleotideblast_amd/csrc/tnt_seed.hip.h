@@ -144,14 +144,6 @@ __device__ __forceinline__ void key_decode(unsigned long long k, uint32_t &wi, u
 
 __device__ __forceinline__ uint32_t key_role(unsigned long long k) { return uint32_t(k >> 1) & 3u; }
 
-// wave-synchronous LDS hand-off between phases of the same wavefront
-__device__ __forceinline__ void wave_sync()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // Is (wi, p) the first seed of its diagonal?  Word-list form (any oligo).
 __device__ __forceinline__ bool first_on_diagonal_words(const uint32_t *pk, const uint16_t *wl, uint32_t wi, uint32_t p, uint32_t wmask)
 {

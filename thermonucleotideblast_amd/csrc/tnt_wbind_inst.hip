@@ -1,0 +1,19 @@
+// tnt_wbind_inst.hip -- instances of the wavefront-per-window bind kernel (tnt_wbind.hip.h): rows per lane 1 (oligos up to
+// 64 bases), 2 (up to 128); the throughput form and the unit-level form (FULL: any request kind, dp_max / n_max reported).
+#include "tnt_wbind.hip.h"
+
+namespace tnt {
+
+#define X(N)                                                                                                             \
+	void launch_wbind_##N(const BindArgs &a, int blocks, hipStream_t stream)                                             \
+	{                                                                                                                    \
+		hipLaunchKernelGGL((wbind_kernel<N, false>), dim3(blocks), dim3(64 * wb_waves(N)), 0, stream, a);                 \
+	}                                                                                                                    \
+	void launch_wbind_full_##N(const BindArgs &a, int blocks, hipStream_t stream)                                        \
+	{                                                                                                                    \
+		hipLaunchKernelGGL((wbind_kernel<N, true>), dim3(blocks), dim3(64 * wb_waves(N)), 0, stream, a);                  \
+	}
+TNT_WBIND_LADDER(X)
+#undef X
+
+} // namespace tnt

@@ -348,7 +348,8 @@ class Engine:
 
     def bind_batch(self, batch, reqs, route=0):
         """route 0: the unit-level kernel instance (full record); 1: the throughput instances a search runs, queue split
-        by oligo length; 2: the longest general throughput instance (tnt_bind_batch_routed)."""
+        by oligo length; 2: the longest general throughput instance; 3: like 1 with every bucket bound by the
+        wavefront-per-window kernel; 4: the unit-level instance of that kernel (tnt_bind_batch_routed)."""
         out = (abi.tnt_bind * len(reqs))()
         self._check(self.lib.tnt_bind_batch_routed(self._h, batch._h, reqs, len(reqs), out, route))
         return out
