@@ -48,6 +48,9 @@ def main():
             if m:
                 per_filt[int(m.group(1))].append(d)
     out = {"searches": searches, "kernels": {}}
+    head = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".git_head")  # written before the snapshot leaves for the GPU box
+    if os.path.exists(head):
+        out["git_head"] = open(head).read().strip()
     for k in sorted(set(counters) | set(dur)):
         e = {c: v / searches for c, v in sorted(counters[k].items())}
         if dur[k]:

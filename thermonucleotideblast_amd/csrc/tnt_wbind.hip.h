@@ -294,7 +294,8 @@ template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void 
 					// values: zeros after the clamp; their trace words go to a dump slot
 					uint8_t *tp = colvalid ? trace + (size_t(i - 1) * PITCH + size_t(j - 1)) : dump;
 					*tp = uint8_t(tw);
-					if (!colvalid) M = FULL ? -1 : 0, Mz = 0, Iqz = 0, Itz = 0;
+					if (FULL) M = colvalid ? M : -1;
+					Mz = colvalid ? Mz : 0, Iqz = colvalid ? Iqz : 0, Itz = colvalid ? Itz : 0; // (selects: a branch here splits the step's schedule)
 					// running maximum of the lane (nuc_cruc.cpp:670-691: all cells that hold the maximum)
 					const bool counts = colvalid && i <= lim;
 					const int Mv = FULL ? (counts ? M : INT32_MIN) : (counts ? Mz : 0);
