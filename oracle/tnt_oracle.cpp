@@ -19,11 +19,11 @@
 //        treated as terminal without pushing a column.
 //  * Q11 when no enumerated alignment is valid the reference keeps stale
 //        first/last_match; such windows are reported as "no bind".
-//  * a6  the per-target BindCache (tntblast.h:247-324) is not modelled here (the
-//        product binds repeated (oligo, window) pairs once, with the results of
-//        the uncached computation); it only changes results when one oligo string
-//        is evaluated under two different threshold sets / strand concentrations
-//        on the same target.
+//  * a6  the per-target BindCache (tntblast.h:247-324) IS modelled (round 4): amplicon() and padlock() memoise every
+//        evaluated (oligo string, window) per target and strand -- the partial record where the threshold cascade
+//        stopped -- and re-apply the caller's thresholds to the memo on a hit (bind_oligo.cpp:508-512,750-803), whatever
+//        strand concentration and threshold set made it; hybrid() binds with a cache of its own per call
+//        (probe_search.cpp:96,166).  tntor_set_bind_cache(0) switches the memo off (every use evaluated on its own).
 
 #include <algorithm>
 #include <cmath>
@@ -33,6 +33,7 @@
 #include <deque>
 #include <list>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include <omp.h>
 
@@ -1097,15 +1098,62 @@ static void load_window(Melt &m, const uint8_t *seq, unsigned start, unsigned st
 	m.target.assign(d.begin(), d.end());
 }
 
+// BindCacheKey / BindCacheValue, tntblast.h:247-324: one map per target and strand (tntblast_local.cpp:371-372, cleared
+// per target :505-506), keyed by the oligo STRING and the window -- not by the strand concentration or the thresholds of
+// whoever evaluated it first.
+struct CacheKey {
+	std::string oligo;
+	unsigned start, stop;
+	bool operator==(const CacheKey &o) const { return oligo == o.oligo && start == o.start && stop == o.stop; }
+};
+struct CacheKeyHash {
+	size_t operator()(const CacheKey &k) const { return std::hash<std::string>()(k.oligo) ^ ((size_t(k.start) << 32) | size_t(k.stop)); }
+};
+struct CacheVal { // what the cascade had computed when it stopped; the rest stays zero / empty (bind_oligo.cpp:600-714)
+	float tm = 0, dg = 0, dH = 0, dS = 0;
+	unsigned a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0;
+	int t5 = 0, t3 = 0;
+	std::string align;
+	bool no_alignment = false; // the Q11 fence of this file: a window without a valid alignment stays "no bind" on a hit too
+};
+typedef std::unordered_map<CacheKey, CacheVal, CacheKeyHash> BindCache;
+struct Caches {
+	BindCache plus, minus;
+	void clear() { BindCache().swap(plus), BindCache().swap(minus); }
+};
+static bool g_bind_cache = true; // tntor_set_bind_cache
+
 // One seed through NucCruc + the threshold cascade, bind_oligo.cpp:502-748 / :1202-1446.
-// Returns the cascade status (0 = bound) and fills `out` / `b`.
+// Returns the cascade status (0 = bound) and fills `out` / `b`.  `cache` (with the oligo string): the per-target memo of
+// the strand; a hit re-applies the thresholds to the memo (bind_oligo.cpp:396-428 / :763-803) instead of evaluating.
 static int bind_one(Melt &m, const uint8_t *seq, unsigned seq_len, unsigned qloc, unsigned tloc, bool minus,
-                    const Thresh &th, tnt_bind *b, Info *out)
+                    const Thresh &th, tnt_bind *b, Info *out, BindCache *cache = nullptr, const std::string *oligo = nullptr)
 {
 	const unsigned window = unsigned(m.query.size());
 	const unsigned target_length = window + 2 * TNT_FLANK;
 	const unsigned start = unsigned(std::max(int(tloc) - int(qloc + TNT_FLANK), 0));
 	const unsigned stop = std::min(start + target_length, seq_len);
+	if (!g_bind_cache) cache = nullptr;
+	CacheKey key;
+	if (cache) {
+		key.oligo = *oligo, key.start = start, key.stop = stop;
+		const BindCache::const_iterator hit = cache->find(key);
+		if (hit != cache->end()) {
+			const CacheVal &v = hit->second;
+			if (v.tm < th.min_tm || v.tm > th.max_tm) return 1;
+			if (v.dg < th.min_dg || v.dg > th.max_dg) return 2;
+			if (v.no_alignment) return 8;
+			if (v.a5 < th.clamp5 || v.a3 < th.clamp3) return 3;
+			if (v.mm > th.max_mm) return 5;
+			if (v.gap > th.max_gap) return 6;
+			if (v.poly > th.max_poly) return 7;
+			if (out) {
+				out->loc5 = v.t5, out->loc3 = v.t3, out->tm = v.tm, out->dH = v.dH, out->dS = v.dS;
+				out->a5 = v.a5, out->a3 = v.a3, out->mm = v.mm, out->gap = v.gap, out->align = v.align;
+			}
+			return 0;
+		}
+	}
 	load_window(m, seq, start, stop, minus);
 
 	const float tm = m.approximate_tm_heterodimer();
@@ -1168,6 +1216,21 @@ static int bind_one(Melt &m, const uint8_t *seq, unsigned seq_len, unsigned qloc
 		out->loc5 = loc5, out->loc3 = loc3, out->tm = tm, out->dH = m.cur.dH, out->dS = m.cur.dS;
 		out->a5 = a5, out->a3 = a3, out->mm = mm, out->gap = gap, out->align = text;
 	}
+	if (cache) { // the memo holds what the cascade had looked at when it stopped (bind_oligo.cpp:600-714, :750-757)
+		CacheVal v;
+		v.tm = tm;
+		if (status != 1) v.dg = dg;
+		if (status == 8) v.no_alignment = true;
+		if (status == 0 || (status >= 3 && status <= 7)) {
+			v.a5 = a5;
+			if (status != 3) v.a3 = a3;
+			if (status == 0 || status >= 5) v.mm = mm;
+			if (status == 0 || status >= 6) v.gap = gap;
+			if (status == 0 || status == 7) v.poly = poly;
+		}
+		if (status == 0) v.dH = m.cur.dH, v.dS = m.cur.dS, v.t5 = loc5, v.t3 = loc3, v.align = text;
+		(*cache)[key] = v;
+	}
 	return status;
 }
 
@@ -1185,8 +1248,9 @@ static bool bound_less(const Info &a, const Info &b)
 
 // mask overload, bind_oligo.cpp:456-827 / :1159-1530
 static void bind_mask(std::list<Info> &info, uint8_t oligo_mask, const uint8_t *seq, unsigned seq_len, Melt &m,
-                      bool minus, const Thresh &th)
+                      bool minus, const Thresh &th, Caches *cc = nullptr, const std::string *oligo = nullptr)
 {
+	BindCache *cache = cc ? (minus ? &cc->minus : &cc->plus) : nullptr;
 	std::list<Info> curr;
 	const uint8_t want = uint8_t(oligo_mask | (minus ? MMINUS : MPLUS));
 	for (std::list<Info>::iterator it = info.begin(); it != info.end();) {
@@ -1197,7 +1261,7 @@ static void bind_mask(std::list<Info> &info, uint8_t oligo_mask, const uint8_t *
 		curr.push_front(*it);
 		it = info.erase(it);
 		Info &o = curr.front();
-		if (bind_one(m, seq, seq_len, o.qloc, o.tloc, minus, th, nullptr, &o) != 0) curr.pop_front();
+		if (bind_one(m, seq, seq_len, o.qloc, o.tloc, minus, th, nullptr, &o, cache, oligo) != 0) curr.pop_front();
 	}
 	if (curr.empty()) return;
 	curr.sort(bound_less);
@@ -1211,13 +1275,14 @@ static void bind_mask(std::list<Info> &info, uint8_t oligo_mask, const uint8_t *
 
 // hash overload, bind_oligo.cpp:124-454 / :829-1157
 static void bind_hash(std::list<Info> &info, const Seeder &h, const uint8_t *seq, unsigned seq_len,
-                      const std::string &oligo, Melt &m, bool minus, const Thresh &th)
+                      const std::string &oligo, Melt &m, bool minus, const Thresh &th, Caches *cc = nullptr)
 {
+	BindCache *cache = cc ? (minus ? &cc->minus : &cc->plus) : nullptr;
 	std::list<Info> seeds, hits;
 	match_oligo(seeds, h, oligo, 0, !minus); // same seeds, same diagonal order (sort_by_delta / unique_by_delta)
 	for (Info &s : seeds) {
 		Info o;
-		if (bind_one(m, seq, seq_len, s.qloc, s.tloc, minus, th, nullptr, &o) == 0) hits.push_back(o);
+		if (bind_one(m, seq, seq_len, s.qloc, s.tloc, minus, th, nullptr, &o, cache, &oligo) == 0) hits.push_back(o);
 	}
 	info.clear();
 	if (hits.empty()) return;
@@ -1334,7 +1399,7 @@ static bool first_cull(const tnt_options &o, const tnt_assay &A, const Seeder &h
 
 // amplicon(), amplicon_search.cpp:58-677
 static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const uint8_t *seq, unsigned seq_len,
-                     int seq_index, Melt &m, std::vector<tnt_hit> &out)
+                     int seq_index, Melt &m, std::vector<tnt_hit> &out, Caches *cc = nullptr)
 {
 	const tnt_options &o = cx.opt;
 	const bool has_probe = A.probe != nullptr;
@@ -1358,7 +1423,7 @@ static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const u
 	for (int s = 0; s < 4; s++) {
 		m.set_query(steps[s].fwd ? F : R);
 		m.ct = steps[s].fwd ? fs : rs; // strand(c, 0) = c, nuc_cruc.h:890-910
-		bind_mask(ml, steps[s].fwd ? MF : MR, seq, seq_len, m, steps[s].minus, pt);
+		bind_mask(ml, steps[s].fwd ? MF : MR, seq, seq_len, m, steps[s].minus, pt, cc, steps[s].fwd ? &F : &R);
 		if (s < 3) {
 			// a cull follows the first three binds; the list-empty early return is absent after the
 			// third bind of the minus-first branch only (:199) but present in the plus-first one (:286-290)
@@ -1373,8 +1438,8 @@ static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const u
 		                    unsigned(o.probe_clamp_3), unsigned(o.max_gap), unsigned(o.max_mismatch), unsigned(o.max_poly_degen)};
 		m.set_query(Pp);
 		m.ct = ps;
-		bind_mask(ml, MP, seq, seq_len, m, true, prt);
-		bind_mask(ml, MP, seq, seq_len, m, false, prt);
+		bind_mask(ml, MP, seq, seq_len, m, true, prt, cc, &Pp);
+		bind_mask(ml, MP, seq, seq_len, m, false, prt, cc, &Pp);
 	}
 	ml.sort(oligo_loc_less); // :356
 
@@ -1433,7 +1498,7 @@ static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const u
 
 // padlock(), padlock_search.cpp:62-361
 static void padlock(const Ctx &cx, const tnt_assay &A, const Seeder &h, const uint8_t *seq, unsigned seq_len,
-                    int seq_index, Melt &m, int max_len, std::vector<tnt_hit> &out)
+                    int seq_index, Melt &m, int max_len, std::vector<tnt_hit> &out, Caches *cc = nullptr)
 {
 	const tnt_options &o = cx.opt;
 	const float fs = cx.fwd_strand / A.forward_degen, rs = cx.rev_strand / A.reverse_degen;
@@ -1448,10 +1513,10 @@ static void padlock(const Ctx &cx, const tnt_assay &A, const Seeder &h, const ui
 		if (o.target_strand & (minus ? TNT_STRAND_MINUS : TNT_STRAND_PLUS)) {
 			m.set_query(R);
 			m.ct = rs;
-			bind_hash(up, h, seq, seq_len, R, m, minus, up_t);
+			bind_hash(up, h, seq, seq_len, R, m, minus, up_t, cc);
 			m.set_query(F);
 			m.ct = fs;
-			bind_hash(down, h, seq, seq_len, F, m, minus, down_t);
+			bind_hash(down, h, seq, seq_len, F, m, minus, down_t, cc);
 		}
 		for (const Info &u : up)
 			for (const Info &d : down) {
@@ -1510,6 +1575,10 @@ using namespace tor;
 extern "C" {
 
 const char *tntor_last_error(void) { return g_err.c_str(); }
+
+// The reference's per-target BindCache (a6) on (default) or off: off, every use of an oligo is evaluated on its own -- what the
+// library computes for contexts it accepts, where the two agree (same strand concentration and thresholds for every use).
+void tntor_set_bind_cache(int on) { g_bind_cache = on != 0; }
 
 int tntor_tables(const tnt_options *opt, int32_t *delta_g, float *param_H, float *param_S, float *loop_S, float *bulge_S,
                  float *hairpin_S, float *scalars)
@@ -1613,19 +1682,21 @@ int tntor_search(const tnt_options *opt, const tnt_assay *assays, size_t n_assay
 			Melt m(opt->target_t, opt->salt, opt->allow_dangle_5 != 0, opt->allow_dangle_3 != 0);
 			m.dinkelbach = opt->use_dinkelbach != 0;
 			std::vector<tnt_hit> local;
+			Caches cc; // plus / minus strand memo of the target (tntblast_local.cpp:371-372)
 #pragma omp for schedule(dynamic, 16)
 			for (long t = 0; t < long(n_targets); t++) {
 				const uint8_t *seq = codes + offsets[t];
 				const unsigned len = unsigned(offsets[t + 1] - offsets[t]);
 				if (len < unsigned(opt->hash_word_size)) continue;
 				h.hash(seq, len);
+				cc.clear(); // tntblast_local.cpp:505-506
 				for (size_t a = 0; a < n_assays; a++) {
 					const tnt_assay &A = assays[a];
 					const int si = int(first_seq_index + t);
 					if (A.forward && A.reverse) { // dispatch, tntblast_local.cpp:559-626
-						if (opt->assay_format == TNT_ASSAY_PCR) amplicon(cx, A, h, seq, len, si, m, local);
-						else if (opt->assay_format == TNT_ASSAY_PADLOCK) padlock(cx, A, h, seq, len, si, m, 0, local);
-						else if (opt->assay_format == TNT_ASSAY_MIPS) padlock(cx, A, h, seq, len, si, m, opt->max_len, local);
+						if (opt->assay_format == TNT_ASSAY_PCR) amplicon(cx, A, h, seq, len, si, m, local, &cc);
+						else if (opt->assay_format == TNT_ASSAY_PADLOCK) padlock(cx, A, h, seq, len, si, m, 0, local, &cc);
+						else if (opt->assay_format == TNT_ASSAY_MIPS) padlock(cx, A, h, seq, len, si, m, opt->max_len, local, &cc);
 					} else if (A.probe) {
 						hybrid(cx, A, h, seq, len, si, m, local);
 					}

@@ -15,6 +15,9 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"\[clone.*", "", name).strip()
+    m = re.search(r"wbind_kernel<(\d+), *(true|false)", name)  # the wavefront-per-window form: rows per lane
+    if m:
+        return "wbind_kernel<%s>" % ("unit" if m.group(2) == "true" else "R")
     m = re.search(r"(bind_kernel)<(\d+), *(true|false)", name)
     if m:
         return "bind_kernel<%s>" % ("unit" if m.group(3) == "true" else "L")

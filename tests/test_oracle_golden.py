@@ -89,17 +89,21 @@ def test_threads_do_not_change_results(oracle):
 
 def test_g8_reference_bind_cache_quirk_is_pinned(oracle):
     """G8 (reference-generated): one oligo as a primer of one assay and as the TaqMan probe of another.  The reference's
-    per-target BindCache gives the probe the primer's evaluation (its Tm at the primer's strand concentration; nothing
-    where the primer's threshold cascade had stopped early), so its hits differ from the uncached computation -- which is
-    what the oracle and the library compute; the library refuses such an assay set (tests/test_gpu_parity.py)."""
+    per-target BindCache gives the probe the primer's evaluation (its Tm at the primer's strand concentration; a record of
+    zeros where the primer's threshold cascade had stopped early), so its hits differ from the uncached computation.  The
+    oracle models the cache since round 4: oracle == reference; with the memo off it computes what the library computes
+    under TNT_MI355X_UNCACHED_SHARED_OLIGOS (the library refuses such an assay set otherwise, tests/test_gpu_parity.py)."""
     g = gu.load("g8_bindcache.json.gz")
     assays = [synth.Assay(a[0], a[1], a[2], a[3]) for a in g["assays"]]
     opt = gu.options_from(g["options"])
     codes, offsets = gu.pack_targets(g["targets"])
-    got = [list(k) for k in tc.sorted_hit_keys(oracle.search(opt, synth.expand_assays(assays), codes, offsets))]
     ref = g["hits"]
+    got = [list(k) for k in tc.sorted_hit_keys(oracle.search(opt, synth.expand_assays(assays), codes, offsets))]
+    assert len(ref) == 113 and got == ref
+    # the uncached computation: what round 3 pinned the quirk with
+    got = [list(k) for k in tc.sorted_hit_keys(oracle.search(opt, synth.expand_assays(assays), codes, offsets, bind_cache=False))]
     both = [h for h in got if h in ref]
-    assert len(ref) == 113 and len(got) == 135 and len(both) == 57
+    assert len(got) == 135 and len(both) == 57
     # the PCR assay (its oligos are evaluated first on every target) is not affected
     assert sorted(h for h in got if h[0] == 0) == sorted(h for h in ref if h[0] == 0)
     # where both report the same TaqMan amplicon, only the probe's Tm differs (it was computed at the primer's Ct)

@@ -171,3 +171,42 @@ def test_random_option_sets(checkers):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_oracle.py"), "24", "5"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 differ" in r.stdout
+
+
+def _conflict_workload(kind, seed):
+    """Assay sets in which one oligo string is evaluated under two strand concentrations / threshold sets on the same
+    target: the inputs on which the reference's per-target BindCache (a6) changes results."""
+    if kind == "taqman":  # the probe of a TaqMan assay is the forward primer of a PCR assay listed behind / in front of it
+        wl = synth.make_workload(3, n_targets=300, n_assays=12, seed=seed)
+        extra = [synth.Assay("swap%d" % i, a.probe, a.reverse, None) for i, a in enumerate(wl.assays)]
+        assays = [x for i, pair in enumerate(zip(wl.assays, extra)) for x in (pair if i % 2 == 0 else pair[::-1])]
+        wl.options.min_primer_tm, wl.options.min_probe_tm = 45.0, 30.0
+        wl.options.primer_clamp, wl.options.probe_clamp_5 = 2, 1
+    elif kind == "degenerate":  # an explicit expansion listed next to its degenerate parent: another Ct divisor
+        wl = synth.make_workload(4, n_targets=200, n_assays=20, seed=seed)
+        assays = []
+        for i, a in enumerate(wl.assays):
+            assays.append(a)
+            if synth.degeneracy(a.forward) > 1 or synth.degeneracy(a.reverse) > 1:
+                assays.append(synth.Assay("expl%d" % i, synth.expand_oligo(a.forward)[0], synth.expand_oligo(a.reverse)[-1], None))
+        assert len(assays) > len(wl.assays)
+    else:  # padlock: the upstream arm of one assay is the downstream arm of the next (5' clamp against 3' clamp)
+        wl = synth.make_workload(5, n_targets=200, n_assays=20, seed=seed)
+        pads = [a for a in wl.assays if a.forward and a.reverse]
+        extra = [synth.Assay("swap%d" % i, a.reverse, a.forward, None) for i, a in enumerate(pads)]
+        assays = list(wl.assays) + extra
+        wl.options.probe_clamp_5, wl.options.probe_clamp_3 = 3, 1
+    return wl, synth.expand_assays(assays)
+
+
+@pytest.mark.parametrize("kind,seed", [("taqman", 61), ("taqman", 62), ("degenerate", 63), ("padlock", 64)])
+def test_search_with_bind_cache_conflicts(ref, oracle, kind, seed):
+    """Row a6: oracle == reference on assay sets whose results hang on the BindCache (first evaluation of an (oligo, window)
+    per target and strand wins, thresholds re-applied to its partial record on a hit, bind_oligo.cpp:508-512,750-803)."""
+    wl, ex = _conflict_workload(kind, seed)
+    a = tc.sorted_hit_keys(ref.search(wl.options, ex, wl.codes, wl.offsets, threads=1))
+    b = tc.sorted_hit_keys(oracle.search(wl.options, ex, wl.codes, wl.offsets))
+    c = tc.sorted_hit_keys(oracle.search(wl.options, ex, wl.codes, wl.offsets, bind_cache=False))
+    assert a == b and len(a) > 0
+    if kind != "padlock":
+        assert b != c  # the memo does change these results

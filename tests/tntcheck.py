@@ -202,7 +202,15 @@ class _CpuImpl:
         assert rc == 0, self.error()
         return out
 
-    def search(self, opt, expanded, codes, offsets, first=0, threads=0):
+    def search(self, opt, expanded, codes, offsets, first=0, threads=0, bind_cache=True):
+        """bind_cache=False (oracle only): every use of an oligo is evaluated on its own instead of through the reference's
+        per-target BindCache (a6) -- the semantics of TNT_MI355X_UNCACHED_SHARED_OLIGOS."""
+        if not bind_cache:
+            self.lib.tntor_set_bind_cache(0)
+            try:
+                return self.search(opt, expanded, codes, offsets, first, threads)
+            finally:
+                self.lib.tntor_set_bind_cache(1)
         codes, pc = as_u8(codes)
         offsets, po = as_u64(offsets)
         arr = c_assays(expanded)
