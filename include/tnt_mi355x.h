@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNT_ABI_VERSION 4
+#define TNT_ABI_VERSION 5
 
 /* Longest oligo the gfx950 bind kernels accept (reference cap: MAX_SEQUENCE_LENGTH
  * 1024, nuc_cruc.h:80).  Up to 64 bases the rows of the alignment live in
@@ -228,9 +228,14 @@ int tnt_db_ingest_timing(const tnt_db *db, tnt_ingest_timing *out);
  * the context until the next tnt_search / tnt_ctx_destroy.                                  */
 int tnt_search(tnt_ctx *ctx, tnt_db *db, const tnt_hit **hits, size_t *n_hits);
 
-/* Asynchronous form used by bench.py: enqueue on the context's stream, no host sync. */
+/* Asynchronous form used by bench.py: enqueue on the context's stream, no host sync.  tnt_search_collect with
+ * hits == NULL leaves the records on the device (tnt_search_hits_device / _compact, tnt_gang_gather take them from
+ * there) instead of copying sizeof(tnt_hit) = 1464 bytes per hit to the host.                                       */
 int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db);
 int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits);
+/* Collect, and hand the hits to the host in the compact form of tnt_search_hits_compact (about 290 bytes per hit;
+ * tnt_hits_unpack is the inverse): the blob sits in page-locked memory of the context until its next search.      */
+int tnt_search_collect_compact(tnt_ctx *ctx, const void **host_blob, size_t *n_bytes, size_t *n_hits);
 
 /* The hits of the last collected search where the pair kernel left them, in device memory (same records, same order as
  * the host copy): what a multi-GPU driver hands to RCCL without a round trip through the host (the reference's master
@@ -246,6 +251,24 @@ int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hit
  * out == NULL it only reports the count.                                                                           */
 int tnt_search_hits_compact(tnt_ctx *ctx, const void **device_blob, size_t *n_bytes, size_t *n_hits);
 int tnt_hits_unpack(const void *blob, size_t n_bytes, tnt_hit *out, size_t cap, size_t *n_hits);
+
+/* ---- several GPUs in one process (ABI v5).  The reference's master deals targets to its MPI workers and receives their
+ * packed hit lists (tntblast_master.cpp:438-461,811-828; tntblast_worker.cpp:173-186,602).  Here: one context per
+ * device (tnt_ctx_create(..., device, ...)), one caller thread per context while they search, targets dealt out by the
+ * caller (they are independent; seq_index is global through first_seq_index), and tnt_gang_gather to bring the hits of
+ * the searches they collected last to the host: the compact blobs travel to the first context's device over RCCL
+ * (ncclSend / ncclRecv in one group, an all-reduce of the hit counts as the check) and cross to the host in one copy;
+ * where RCCL cannot serve (absent, or two contexts on one device) every device copies its own blob ("host" transport,
+ * same bytes).  TNT_MI355X_GATHER=host|rccl forces one.                                                              */
+int tnt_device_count(void); /* visible HIP devices (0: none) */
+typedef struct tnt_gang tnt_gang;
+int tnt_gang_create(tnt_ctx *const *ctx, int n, tnt_gang **out);
+void tnt_gang_destroy(tnt_gang *gang);
+const char *tnt_gang_transport(const tnt_gang *gang);  /* "rccl", or "host" / "host (<why not rccl>)" */
+const char *tnt_gang_last_error(const tnt_gang *gang); /* gang may be NULL: last creation error */
+/* For every rank r (has == NULL or has[r] != 0) whose context holds a collected search: blobs[r] -> its compact hit blob
+ * in host memory owned by the gang (valid until the next gather), n_bytes[r], n_hits[r]; other ranks get NULL / 0.    */
+int tnt_gang_gather(tnt_gang *gang, const uint8_t *has, const void **blobs, size_t *n_bytes, size_t *n_hits);
 
 /* per-stage device timings of the last search, in ms (HIP events on the context stream) */
 typedef struct tnt_timing {

@@ -29,7 +29,7 @@ def _oligo_set(expanded):
 def test_native_library_is_loaded(Engine):
     from thermonucleotideblast_amd import engine
     lib = engine.load_library()
-    assert lib.tnt_abi_version() == 4
+    assert lib.tnt_abi_version() == 5
     assert any("libtnt_mi355x.so" in line for line in open("/proc/self/maps"))
 
 
@@ -1196,3 +1196,68 @@ def test_queue_region_overflow_is_repaired(Engine, oracle, monkeypatch):
     assert tc.sorted_hit_keys(e.search(db)) == want
     db.close()
     e.close()
+
+
+def test_gang_gathers_the_hits_of_several_contexts(Engine, oracle):
+    """tnt_gang_*: the hits of searches collected on several contexts reach the host as compact blobs, rank by rank.  One
+    context = an RCCL communicator of one rank (its blob reaches the receive buffer on the same device, the all-reduce of
+    the hit counts runs); three contexts on ONE device = the host-merged transport (RCCL wants one rank per device).
+    Either way the records equal those of plain searches and of the oracle."""
+    from thermonucleotideblast_amd.engine import Gang
+    wl = synth.make_workload(3, n_targets=900, n_assays=24, seed=201)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    cuts = [0, 250, 600, 900]
+    for n_rank in (1, 3):
+        engines = [Engine(wl.options, wl.expanded) for _ in range(n_rank)]
+        gang = Gang(engines)
+        assert gang.transport == "rccl" if n_rank == 1 else gang.transport.startswith("host")
+        got = []
+        for rnd in range(2):  # two rounds: the buffers of the gang are reused
+            dbs = []
+            for r, e in enumerate(engines):
+                lo, hi = (cuts[r], cuts[r + 1]) if n_rank == 3 else (0, 900)
+                c = wl.codes[int(wl.offsets[lo]):int(wl.offsets[hi])]
+                o = wl.offsets[lo:hi + 1] - wl.offsets[lo]
+                dbs.append(e.pack(c, o, first_seq_index=lo))
+                e.enqueue(dbs[-1])
+            counts = [e.collect_device() for e in engines]
+            per_rank = gang.gather()
+            assert [len(h) for h in per_rank] == counts
+            got = sorted(k for h in per_rank for k in tc.sorted_hit_keys(h))
+            assert got == want and len(want) > 20, (n_rank, rnd)
+            # a rank may sit a round out
+            if n_rank == 3:
+                some = gang.gather([1, 0, 1])
+                assert some[1] is None and len(some[0]) == counts[0] and len(some[2]) == counts[2]
+            for d in dbs:
+                d.close()
+        gang.close()
+        for e in engines:
+            e.close()
+
+
+def test_cli_deals_batches_to_several_contexts(Engine, tmp_path, monkeypatch):
+    """tntblast-mi355x --gpus N: the streamed batches are dealt to N contexts (here three on one device: host-merged
+    gather), searched by one thread each and filed in batch order -- the output file does not depend on N."""
+    import os
+    import subprocess
+    import __graft_entry__ as g
+    wl = synth.make_workload(3, n_targets=700, n_assays=16, seed=202)
+    fa, assay = tmp_path / "db.fna", tmp_path / "assays.txt"
+    with open(fa, "w") as f:
+        for t in range(wl.n_targets):
+            f.write(">t%d\n%s\n" % (t, synth.decode(wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])])))
+    with open(assay, "w") as f:
+        for a in wl.assays:
+            f.write("%s\t%s\t%s\t%s\n" % (a.name, a.forward, a.reverse, a.probe))
+    outs = {}
+    for label, env, extra in (("one", {}, ["--gpus", "1"]), ("three", {"TNT_MI355X_DEVICES": "0,0,0", "TNT_MI355X_CHUNK_BYTES": "60000", "TNT_MI355X_VERBOSE_GANG": "1"}, ["--gpus", "3"]),
+                              ("default", {"TNT_MI355X_CHUNK_BYTES": "200000"}, [])):
+        out = tmp_path / ("out_%s.txt" % label)
+        r = subprocess.run([g.CLI, "-i", str(assay), "-d", str(fa), "-o", str(out), "-e", "40", "-E", "40"] + extra, capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+        outs[label] = open(out).read()
+        if label == "three":
+            assert "3 device context(s), gather over host" in r.stderr, r.stderr
+    assert outs["one"] == outs["three"] == outs["default"] and outs["one"].count("amplicon range") > 20

@@ -34,6 +34,8 @@
 #include "tnt_pair.hip.h"
 #include "tnt_ingest.hip.h"
 #include <zlib.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is looked up at run time (tnt_gang_create)
 #include <pthread.h>
 #include <unistd.h>
 #include <chrono>
@@ -640,6 +642,10 @@ struct tnt_ctx {
 	PinnedBuf<uint32_t> pin_list;
 	PinnedBuf<int32_t> pin_result;
 	PinnedBuf<BoundRec> pin_pool;        // the bound oligos of all bind passes of a long-target search
+	PinnedBuf<uint8_t> pin_blob;         // tnt_search_collect_compact: the hits of the last search in wire form
+	bool compact_in_search = false;      // the compaction kernels run behind the pair stage of every search (set by the first request for the compact form)
+	size_t blob_cap_hits = 0;            // records the blob of the pending search was sized for (0: not packed with the search)
+	size_t blob_hits = 0, blob_bytes = 0; // what ctx->hit_blob holds: valid while blob_hits == dev_hits_n and blob_bytes != 0
 	size_t h_hits_cap = 0;
 	std::vector<tnt_seed> h_seeds;
 	std::vector<int32_t> h_cull_rows; // tnt_first_cull
@@ -683,7 +689,8 @@ enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items *
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
-       C_BUCKET = C_GROUPS + N_SHARD * SHARD_STRIDE, C_DEBUG = C_BUCKET + MAX_BUCKETS * BUCKET_STRIDE, C_COUNT = C_DEBUG + 16 };
+       C_BUCKET = C_GROUPS + N_SHARD * SHARD_STRIDE, C_DEBUG = C_BUCKET + MAX_BUCKETS * BUCKET_STRIDE,
+       C_BLOB = C_DEBUG + 16 /* compact hit blob of the search: bytes, hits (enqueue_compaction) */, C_COUNT = C_BLOB + 2 };
 static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
@@ -2524,6 +2531,8 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 
 #include "tnt_long.hip.h" // search_long_targets: the targets that are seeded in windows
 
+static int enqueue_compaction(tnt_ctx *ctx, size_t cap_hits, const uint32_t *n_dev); // (with tnt_search_hits_compact, below)
+
 int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 {
 	if (ctx) ctx->dev_hits_valid = false;
@@ -2567,14 +2576,25 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	ctx->cur = 0;
 	if (start) (void)hipEventDestroy(start);
 	if (rc) return rc;
+	ctx->blob_cap_hits = 0, ctx->blob_hits = 0, ctx->blob_bytes = 0;
+	if (ctx->compact_in_search && db->h_long_targets.empty()) { // (the hits of windowed targets join the list on the host, at collect time)
+		const size_t cap_hits = std::min<size_t>(ctx->hit_cap, std::max<size_t>(4 * ctx->dev_hits_n, size_t(1) << 16));
+		rc = enqueue_compaction(ctx, cap_hits, ctx->G() + C_HITS);
+		if (rc) return rc;
+		ctx->blob_cap_hits = cap_hits;
+	}
 	ctx->pending = true;
 	ctx->pending_db = db;
 	return TNT_OK;
 }
 
-int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
+// Shared by tnt_search_collect and tnt_search_collect_compact.  want_records: the 1 464-byte hit records are copied to the
+// library's pinned host buffer (47 MB per search of config 2); without, they stay on the device (tnt_search_hits_device /
+// _compact and the gang's gather take them from there).
+static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits, size_t *n_hits)
 {
 	if (!ctx || !ctx->pending) return TNT_E_ARG;
+	if (ctx->pending_db && !ctx->pending_db->h_long_targets.empty()) want_records = true; // (the hits of windowed targets are made on the host)
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->S().counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
@@ -2622,7 +2642,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 			if (cnt[C_ERR] & ERR_LIST_OVERFLOW) ctx->force_big = true;
 			const int rc = tnt_search_enqueue(ctx, ctx->pending_db);
 			if (rc) return rc;
-			return tnt_search_collect(ctx, hits, n_hits);
+			return collect_search(ctx, want_records, hits, n_hits);
 		}
 	}
 	ctx->retries = 0;
@@ -2631,7 +2651,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		return TNT_E_LIMIT;
 	}
 	const size_t n = std::min<size_t>(cnt[C_HITS], ctx->hit_cap);
-	if (n > ctx->h_hits_cap) {
+	if (want_records && n > ctx->h_hits_cap) {
 		if (ctx->h_hits) (void)hipHostFree(ctx->h_hits);
 		ctx->h_hits = nullptr;
 		ctx->h_hits_cap = 0;
@@ -2639,7 +2659,7 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hits), cap * sizeof(tnt_hit), hipHostMallocDefault), ctx->err);
 		ctx->h_hits_cap = cap;
 	}
-	if (n) HIP_TRY(hipMemcpy(ctx->h_hits, ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
+	if (n && want_records) HIP_TRY(hipMemcpy(ctx->h_hits, ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
 	size_t n_unique = n;
 	if (ctx->pending_db && !ctx->pending_db->h_long_targets.empty()) {
 		// targets seeded in windows: lists merged per (target, assay), culled and paired whole on the host
@@ -2696,8 +2716,28 @@ int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
 	T.n_filtered = cnt[C_FILTERED];
 	ctx->dev_hits_valid = true; // (the hits of long targets, paired on the host, were copied behind the device's own)
 	ctx->dev_hits_n = n_unique;
-	if (hits) *hits = ctx->h_hits;
+	if (ctx->blob_cap_hits && n_unique <= ctx->blob_cap_hits && cnt[C_BLOB + 1] == n_unique) ctx->blob_hits = n_unique, ctx->blob_bytes = cnt[C_BLOB];
+	if (hits) *hits = want_records ? ctx->h_hits : nullptr;
 	if (n_hits) *n_hits = n_unique;
+	return TNT_OK;
+}
+
+int tnt_search_collect(tnt_ctx *ctx, const tnt_hit **hits, size_t *n_hits)
+{
+	return collect_search(ctx, hits != nullptr, hits, n_hits); // hits == NULL: the records stay on the device
+}
+
+int tnt_search_collect_compact(tnt_ctx *ctx, const void **host_blob, size_t *n_bytes, size_t *n_hits)
+{
+	if (!ctx || !host_blob || !n_bytes || !n_hits) return TNT_E_ARG;
+	int rc = collect_search(ctx, false, nullptr, nullptr);
+	if (rc) return rc;
+	const void *dev = nullptr;
+	rc = tnt_search_hits_compact(ctx, &dev, n_bytes, n_hits);
+	if (rc) return rc;
+	HIP_TRY(ctx->pin_blob.ensure(*n_bytes + 8), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->pin_blob.p, dev, *n_bytes, hipMemcpyDeviceToHost), ctx->err);
+	*host_blob = ctx->pin_blob.p;
 	return TNT_OK;
 }
 
@@ -2717,6 +2757,28 @@ int tnt_search_hits_device(tnt_ctx *ctx, const void **device_hits, size_t *n_hit
 	return TNT_OK;
 }
 
+// The compaction kernels behind the pair stage of a search, on the context's stream: the hit count is read from the device
+// counter, the blob's byte count lands in the counter block (C_BLOB) that tnt_search_collect fetches anyway.  Sized for
+// `cap_hits` records; a search that reports more is packed again by tnt_search_hits_compact.
+static int enqueue_compaction(tnt_ctx *ctx, size_t cap_hits, const uint32_t *n_dev)
+{
+	const size_t worst = 8 + cap_hits * (size_t(HIT_POD_BYTES) + 8 + 3 * size_t(ALIGN_TEXT));
+	if (ctx->hit_blob.n < worst) HIP_TRY(ctx->hit_blob.alloc(worst + worst / 4 + 4096), ctx->err);
+	if (ctx->hit_sizes.n < cap_hits + 1) HIP_TRY(ctx->hit_sizes.alloc(cap_hits + cap_hits / 4 + 1024), ctx->err);
+	HitPackArgs a;
+	a.hits = ctx->hits.p;
+	a.n = uint32_t(cap_hits);
+	a.n_dev = n_dev;
+	a.sizes = ctx->hit_sizes.p;
+	a.blob = ctx->hit_blob.p;
+	a.total = ctx->G() + C_BLOB;
+	const int blocks = int(std::min<size_t>(2048, (cap_hits + 3) / 4 + 1)); // one wavefront per hit, four per workgroup
+	hipLaunchKernelGGL(hit_size_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+	hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+	hipLaunchKernelGGL(hit_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+	return TNT_OK;
+}
+
 int tnt_search_hits_compact(tnt_ctx *ctx, const void **device_blob, size_t *n_bytes, size_t *n_hits)
 {
 	if (!ctx || !device_blob || !n_bytes || !n_hits) return TNT_E_ARG;
@@ -2728,27 +2790,24 @@ int tnt_search_hits_compact(tnt_ctx *ctx, const void **device_blob, size_t *n_by
 		ctx->err = "the hits of targets that were seeded in windows only exist in the host copy";
 		return TNT_E_UNSUPPORTED;
 	}
-	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	const size_t n = ctx->dev_hits_n;
-	const size_t worst = 8 + n * (size_t(HIT_POD_BYTES) + 8 + 3 * size_t(ALIGN_TEXT));
-	if (ctx->hit_blob.n < worst) HIP_TRY(ctx->hit_blob.alloc(worst + worst / 4 + 4096), ctx->err);
-	if (ctx->hit_sizes.n < n + 1) HIP_TRY(ctx->hit_sizes.alloc(n + n / 4 + 1024), ctx->err);
-	HitPackArgs a;
-	a.hits = ctx->hits.p;
-	a.n = uint32_t(n);
-	a.sizes = ctx->hit_sizes.p;
-	a.blob = ctx->hit_blob.p;
-	a.total = ctx->S().counters.p + C_DEBUG; // scratch word, read back below
-	const int blocks = int(std::min<size_t>(1024, (n + 255) / 256 + 1));
-	hipLaunchKernelGGL(hit_size_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-	hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
-	hipLaunchKernelGGL(hit_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-	uint32_t total = 0;
-	HIP_TRY(hipMemcpyAsync(&total, a.total, sizeof(total), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+	if (ctx->blob_hits == n && ctx->blob_bytes) { // packed behind the search already (tnt_search_enqueue)
+		*device_blob = ctx->hit_blob.p;
+		*n_bytes = ctx->blob_bytes;
+		*n_hits = n;
+		return TNT_OK;
+	}
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	const int rc = enqueue_compaction(ctx, n, nullptr);
+	if (rc) return rc;
+	uint32_t total[2] = {0, 0};
+	HIP_TRY(hipMemcpyAsync(total, ctx->G() + C_BLOB, sizeof(total), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	HIP_TRY(hipGetLastError(), ctx->err);
+	ctx->compact_in_search = true; // a caller that wants the compact form once wants it after every search
+	ctx->blob_hits = n, ctx->blob_bytes = total[0];
 	*device_blob = ctx->hit_blob.p;
-	*n_bytes = total;
+	*n_bytes = total[0];
 	*n_hits = n;
 	return TNT_OK;
 }
@@ -2785,6 +2844,201 @@ int tnt_hits_unpack(const void *blob, size_t n_bytes, tnt_hit *out, size_t cap, 
 		}
 		at = (t + 3) & ~size_t(3);
 	}
+	return TNT_OK;
+}
+
+
+int tnt_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU: the gang
+// One process, one context per device, one host thread per context while they search (targets are independent; the
+// caller deals its batches out).  What the reference's master collects from its MPI workers (packed hit lists,
+// tntblast_master.cpp:811-828; the workers send theirs, tntblast_worker.cpp:602) is collected here from the devices: the
+// compact blobs (tnt_search_hits_compact) travel to the first context's device over RCCL -- ncclSend / ncclRecv in one
+// group, sized from the byte counts the ranks report; an all-reduce of the hit counts rides along as the check that every
+// record arrived -- and reach the host in ONE copy.  RCCL is looked up at run time (dlopen): where it is missing, fails
+// to initialise, or two contexts share a device (RCCL wants one rank per device), every device copies its own blob to
+// the host instead ("host" transport) -- same bytes in the same order.
+struct tnt_gang {
+	std::vector<tnt_ctx *> ctx;
+	std::string err, transport;
+	void *lib = nullptr;
+	std::vector<ncclComm_t> comms;
+	decltype(&ncclCommInitAll) p_init = nullptr;
+	decltype(&ncclCommDestroy) p_destroy = nullptr;
+	decltype(&ncclGroupStart) p_group_start = nullptr;
+	decltype(&ncclGroupEnd) p_group_end = nullptr;
+	decltype(&ncclSend) p_send = nullptr;
+	decltype(&ncclRecv) p_recv = nullptr;
+	decltype(&ncclAllReduce) p_all_reduce = nullptr;
+	decltype(&ncclGetErrorString) p_error = nullptr;
+	uint8_t *recv = nullptr;             // on the first context's device
+	size_t recv_cap = 0;
+	std::vector<unsigned long long *> count_dev; // per rank: {its hit count, the sum over the ranks}
+	PinnedBuf<uint8_t> host;
+	~tnt_gang()
+	{
+		if (!comms.empty() && p_destroy)
+			for (ncclComm_t c : comms) (void)p_destroy(c);
+		for (size_t r = 0; r < count_dev.size(); r++)
+			if (count_dev[r] && hipSetDevice(ctx[r]->device) == hipSuccess) (void)hipFree(count_dev[r]);
+		if (recv && hipSetDevice(ctx[0]->device) == hipSuccess) (void)hipFree(recv);
+		if (lib) dlclose(lib);
+	}
+};
+
+int tnt_gang_create(tnt_ctx *const *ctx, int n, tnt_gang **out)
+{
+	if (!ctx || n < 1 || !out) return TNT_E_ARG;
+	for (int r = 0; r < n; r++)
+		if (!ctx[r]) return TNT_E_ARG;
+	std::unique_ptr<tnt_gang> g(new tnt_gang);
+	g->ctx.assign(ctx, ctx + n);
+	g->transport = "host";
+	bool distinct = true;
+	for (int a = 0; a < n; a++)
+		for (int b = a + 1; b < n; b++)
+			if (ctx[a]->device == ctx[b]->device) distinct = false;
+	const char *forced = getenv("TNT_MI355X_GATHER"); // "host": never RCCL; "rccl": fail instead of falling back
+	const bool want_rccl = !(forced && !strcmp(forced, "host"));
+	std::string why;
+	if (!distinct) why = "two contexts share a device";
+	if (want_rccl && distinct) {
+		for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+			if ((g->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!g->lib) why = "librccl not found";
+		if (g->lib) {
+			g->p_init = reinterpret_cast<decltype(g->p_init)>(dlsym(g->lib, "ncclCommInitAll"));
+			g->p_destroy = reinterpret_cast<decltype(g->p_destroy)>(dlsym(g->lib, "ncclCommDestroy"));
+			g->p_group_start = reinterpret_cast<decltype(g->p_group_start)>(dlsym(g->lib, "ncclGroupStart"));
+			g->p_group_end = reinterpret_cast<decltype(g->p_group_end)>(dlsym(g->lib, "ncclGroupEnd"));
+			g->p_send = reinterpret_cast<decltype(g->p_send)>(dlsym(g->lib, "ncclSend"));
+			g->p_recv = reinterpret_cast<decltype(g->p_recv)>(dlsym(g->lib, "ncclRecv"));
+			g->p_all_reduce = reinterpret_cast<decltype(g->p_all_reduce)>(dlsym(g->lib, "ncclAllReduce"));
+			g->p_error = reinterpret_cast<decltype(g->p_error)>(dlsym(g->lib, "ncclGetErrorString"));
+			if (!g->p_init || !g->p_destroy || !g->p_group_start || !g->p_group_end || !g->p_send || !g->p_recv || !g->p_all_reduce || !g->p_error) {
+				why = "librccl lacks an entry point";
+			} else {
+				std::vector<int> devs(size_t(n), 0);
+				for (int r = 0; r < n; r++) devs[size_t(r)] = ctx[r]->device;
+				g->comms.assign(size_t(n), nullptr);
+				const ncclResult_t e = g->p_init(g->comms.data(), n, devs.data());
+				if (e != ncclSuccess) {
+					why = std::string("ncclCommInitAll: ") + g->p_error(e);
+					g->comms.clear();
+				} else {
+					g->transport = "rccl";
+					g->count_dev.assign(size_t(n), nullptr);
+					for (int r = 0; r < n; r++) {
+						if (hipSetDevice(ctx[r]->device) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&g->count_dev[size_t(r)]), 2 * sizeof(unsigned long long)) != hipSuccess) {
+							g_create_error = "tnt_gang_create: device allocation failed";
+							return TNT_E_DEVICE;
+						}
+					}
+				}
+			}
+		}
+	}
+	if (g->transport != "rccl" && forced && !strcmp(forced, "rccl")) {
+		g_create_error = "tnt_gang_create: RCCL transport asked for (TNT_MI355X_GATHER=rccl) but not available: " + why;
+		return TNT_E_DEVICE;
+	}
+	if (g->transport != "rccl" && !why.empty()) g->transport = "host (" + why + ")";
+	*out = g.release();
+	return TNT_OK;
+}
+
+void tnt_gang_destroy(tnt_gang *g) { delete g; }
+const char *tnt_gang_transport(const tnt_gang *g) { return g ? g->transport.c_str() : ""; }
+const char *tnt_gang_last_error(const tnt_gang *g) { return g ? g->err.c_str() : g_create_error.c_str(); }
+
+int tnt_gang_gather(tnt_gang *g, const uint8_t *has, const void **blobs, size_t *n_bytes, size_t *n_hits)
+{
+	if (!g || !blobs || !n_bytes || !n_hits) return TNT_E_ARG;
+	const size_t n = g->ctx.size();
+	std::vector<const void *> dev(n, nullptr);
+	std::vector<size_t> off(n + 1, 0);
+	unsigned long long sum = 0;
+	for (size_t r = 0; r < n; r++) {
+		n_bytes[r] = n_hits[r] = 0;
+		blobs[r] = nullptr;
+		if (has && !has[r]) {
+			off[r + 1] = off[r];
+			continue;
+		}
+		const int rc = tnt_search_hits_compact(g->ctx[r], &dev[r], &n_bytes[r], &n_hits[r]); // (synchronises the context's stream)
+		if (rc) {
+			g->err = "rank " + std::to_string(r) + ": " + g->ctx[r]->err;
+			return rc;
+		}
+		off[r + 1] = off[r] + ((n_bytes[r] + 15) & ~size_t(15));
+		sum += n_hits[r];
+	}
+	const size_t total = off[n];
+	HIP_TRY(g->host.ensure(total + 16), g->err);
+	if (g->transport == "rccl") {
+		tnt_ctx *c0 = g->ctx[0];
+		HIP_TRY(hipSetDevice(c0->device), g->err);
+		if (total > g->recv_cap) {
+			if (g->recv) (void)hipFree(g->recv);
+			g->recv = nullptr, g->recv_cap = 0;
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->recv), total + total / 2 + 4096), g->err);
+			g->recv_cap = total + total / 2 + 4096;
+		}
+		for (size_t r = 0; r < n; r++) { // every rank's hit count next to the place of the sum
+			const unsigned long long mine[2] = {(has && !has[r]) ? 0ull : (unsigned long long)n_hits[r], 0ull};
+			HIP_TRY(hipSetDevice(g->ctx[r]->device), g->err);
+			HIP_TRY(hipMemcpyAsync(g->count_dev[r], mine, sizeof(mine), hipMemcpyHostToDevice, g->ctx[r]->stream), g->err);
+			HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream), g->err); // (`mine` leaves scope)
+		}
+		HIP_TRY(hipSetDevice(c0->device), g->err);
+		if (dev[0] && n_bytes[0]) HIP_TRY(hipMemcpyAsync(g->recv + off[0], dev[0], n_bytes[0], hipMemcpyDeviceToDevice, c0->stream), g->err);
+		ncclResult_t e = g->p_group_start();
+		for (size_t r = 0; r < n && e == ncclSuccess; r++) {
+			HIP_TRY(hipSetDevice(g->ctx[r]->device), g->err);
+			e = g->p_all_reduce(g->count_dev[r], g->count_dev[r] + 1, 1, ncclUint64, ncclSum, g->comms[r], g->ctx[r]->stream);
+		}
+		for (size_t r = 1; r < n && e == ncclSuccess; r++) {
+			if (!dev[r] || !n_bytes[r]) continue;
+			HIP_TRY(hipSetDevice(g->ctx[r]->device), g->err);
+			e = g->p_send(dev[r], n_bytes[r], ncclUint8, 0, g->comms[r], g->ctx[r]->stream);
+			if (e != ncclSuccess) break;
+			HIP_TRY(hipSetDevice(c0->device), g->err);
+			e = g->p_recv(g->recv + off[r], n_bytes[r], ncclUint8, int(r), g->comms[0], c0->stream);
+		}
+		const ncclResult_t e2 = g->p_group_end();
+		if (e == ncclSuccess) e = e2;
+		if (e != ncclSuccess) {
+			g->err = std::string("RCCL gather: ") + g->p_error(e);
+			return TNT_E_DEVICE;
+		}
+		for (size_t r = 1; r < n; r++) {
+			HIP_TRY(hipSetDevice(g->ctx[r]->device), g->err);
+			HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream), g->err);
+		}
+		HIP_TRY(hipSetDevice(c0->device), g->err);
+		unsigned long long seen = 0;
+		if (total) HIP_TRY(hipMemcpyAsync(g->host.p, g->recv, total, hipMemcpyDeviceToHost, c0->stream), g->err);
+		HIP_TRY(hipMemcpyAsync(&seen, g->count_dev[0] + 1, sizeof(seen), hipMemcpyDeviceToHost, c0->stream), g->err);
+		HIP_TRY(hipStreamSynchronize(c0->stream), g->err);
+		if (seen != sum) {
+			g->err = "RCCL gather: the ranks' hit counts add up to " + std::to_string(seen) + ", the blobs hold " + std::to_string(sum);
+			return TNT_E_DEVICE;
+		}
+	} else {
+		for (size_t r = 0; r < n; r++) {
+			if (!dev[r] || !n_bytes[r]) continue;
+			HIP_TRY(hipSetDevice(g->ctx[r]->device), g->err);
+			HIP_TRY(hipMemcpy(g->host.p + off[r], dev[r], n_bytes[r], hipMemcpyDeviceToHost), g->err);
+		}
+	}
+	for (size_t r = 0; r < n; r++)
+		if (!(has && !has[r])) blobs[r] = g->host.p + off[r];
 	return TNT_OK;
 }
 

@@ -757,25 +757,54 @@ static_assert(HIT_POD_BYTES == int(sizeof(Hit)) - 3 * ALIGN_TEXT, "the numbers o
 
 struct HitPackArgs {
 	const Hit *hits;
-	uint32_t n;
-	uint32_t *sizes;   // [n] record sizes, then (in place) exclusive offsets
-	uint8_t *blob;     // output
-	uint32_t *total;   // [0] bytes of the blob (header included)
+	uint32_t n;            // hits to pack ...
+	const uint32_t *n_dev; // ... or, when set, the device counter that holds their number (capped by n)
+	uint32_t *sizes;       // [n] record sizes, then (in place) exclusive offsets
+	uint8_t *blob;         // output
+	uint32_t *total;       // [0] bytes of the blob (header included), [1] hits in it
 };
-
-__device__ __forceinline__ uint32_t text_len(const char *t)
+__device__ __forceinline__ uint32_t hit_pack_count(const HitPackArgs &a)
 {
-	uint32_t n = 0;
-	while (n < uint32_t(ALIGN_TEXT - 1) && t[n]) n++;
-	return n;
+	if (!a.n_dev) return a.n;
+	const uint32_t n = *a.n_dev;
+	return n < a.n ? n : a.n;
 }
 
+// strlen of one 448-byte text field by a whole wavefront: every lane looks at two dwords of the field (read coalesced),
+// the first zero byte is the minimum over the lanes
+__device__ __forceinline__ uint32_t wave_text_len(const char *t, int lane)
+{
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(t);
+	uint32_t first = uint32_t(ALIGN_TEXT - 1);
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int d = lane + 64 * k;
+		if (d < ALIGN_TEXT / 4) {
+			const uint32_t v = w[d];
+			const uint32_t z = (v - 0x01010101u) & ~v & 0x80808080u; // a set high bit marks a zero byte (the lowest one is exact)
+			if (z) {
+				const uint32_t at = uint32_t(d) * 4u + (uint32_t(__builtin_ctz(z)) >> 3);
+				first = at < first ? at : first;
+			}
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t other = uint32_t(__shfl_xor(int(first), o));
+		first = other < first ? other : first;
+	}
+	return first;
+}
+
+// one wavefront per hit
 __global__ __launch_bounds__(256) void hit_size_kernel(HitPackArgs a)
 {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+	const uint32_t n = hit_pack_count(a);
+	const int lane = threadIdx.x & 63;
+	for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += (gridDim.x * blockDim.x) >> 6) {
 		const Hit &h = a.hits[i];
-		const uint32_t bytes = uint32_t(HIT_POD_BYTES) + 8u + text_len(h.forward_align) + text_len(h.reverse_align) + text_len(h.probe_align);
-		a.sizes[i] = (bytes + 3u) & ~3u;
+		const uint32_t bytes = uint32_t(HIT_POD_BYTES) + 8u + wave_text_len(h.forward_align, lane) + wave_text_len(h.reverse_align, lane) + wave_text_len(h.probe_align, lane);
+		if (lane == 0) a.sizes[i] = (bytes + 3u) & ~3u;
 	}
 }
 
@@ -783,7 +812,8 @@ __global__ __launch_bounds__(256) void hit_size_kernel(HitPackArgs a)
 __global__ __launch_bounds__(1024) void hit_scan_kernel(HitPackArgs a)
 {
 	__shared__ uint32_t s_part[1024];
-	const uint32_t per = (a.n + 1023u) / 1024u, b = threadIdx.x * per, e = b + per < a.n ? b + per : a.n;
+	const uint32_t n = hit_pack_count(a);
+	const uint32_t per = (n + 1023u) / 1024u, b = threadIdx.x * per, e = b + per < n ? b + per : n;
 	uint32_t sum = 0;
 	for (uint32_t i = b; i < e; i++) sum += a.sizes[i];
 	s_part[threadIdx.x] = sum;
@@ -796,7 +826,8 @@ __global__ __launch_bounds__(1024) void hit_scan_kernel(HitPackArgs a)
 			run += v;
 		}
 		a.total[0] = run;
-		reinterpret_cast<uint32_t *>(a.blob)[0] = a.n;
+		a.total[1] = n;
+		reinterpret_cast<uint32_t *>(a.blob)[0] = n;
 		reinterpret_cast<uint32_t *>(a.blob)[1] = run;
 	}
 	__syncthreads();
@@ -808,23 +839,31 @@ __global__ __launch_bounds__(1024) void hit_scan_kernel(HitPackArgs a)
 	}
 }
 
+// one wavefront per hit: the numbers as dwords, the texts byte by byte with the lanes side by side
 __global__ __launch_bounds__(256) void hit_pack_kernel(HitPackArgs a)
 {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+	const uint32_t n = hit_pack_count(a);
+	const int lane = threadIdx.x & 63;
+	for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += (gridDim.x * blockDim.x) >> 6) {
 		const Hit &h = a.hits[i];
 		uint8_t *o = a.blob + a.sizes[i];
 		const uint32_t *src = reinterpret_cast<const uint32_t *>(&h);
 		uint32_t *dst = reinterpret_cast<uint32_t *>(o);
-		for (int k = 0; k < HIT_POD_BYTES / 4; k++) dst[k] = src[k];
+		if (lane < HIT_POD_BYTES / 4) dst[lane] = src[lane];
 		const char *txt[3] = {h.forward_align, h.reverse_align, h.probe_align};
 		uint32_t len[3];
-		for (int k = 0; k < 3; k++) len[k] = text_len(txt[k]);
-		dst[HIT_POD_BYTES / 4] = len[0] | (len[1] << 16);
-		dst[HIT_POD_BYTES / 4 + 1] = len[2];
+		for (int k = 0; k < 3; k++) len[k] = wave_text_len(txt[k], lane);
+		if (lane == 0) {
+			dst[HIT_POD_BYTES / 4] = len[0] | (len[1] << 16);
+			dst[HIT_POD_BYTES / 4 + 1] = len[2];
+		}
 		uint8_t *w = o + HIT_POD_BYTES + 8;
-		for (int k = 0; k < 3; k++)
-			for (uint32_t c = 0; c < len[k]; c++) *w++ = uint8_t(txt[k][c]);
-		while ((w - o) & 3) *w++ = 0;
+		for (int k = 0; k < 3; k++) {
+			for (uint32_t c = uint32_t(lane); c < len[k]; c += 64) w[c] = uint8_t(txt[k][c]);
+			w += len[k];
+		}
+		const uint32_t pad = uint32_t(-int32_t(len[0] + len[1] + len[2])) & 3u;
+		if (uint32_t(lane) < pad) w[lane] = 0;
 	}
 }
 

@@ -31,6 +31,7 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tnt_mi355x.h"
@@ -68,6 +69,7 @@ struct Options {
 	long max_target_len = 500000; // --max-target-len, DEFAULT_FRAGMENT_TARGET_LENGTH (tntblast.h:61)
 	enum { MASK_PRIMERS = 1, MASK_PROBE = 2, REPLACE_PRIMERS = 4 }; // tntblast.h:115-117
 	int mask = 0;                 // -k / -K / -r
+	int gpus = 0;                 // --gpus: devices the database is dealt to (0: every visible device)
 };
 
 constexpr size_t INVALID_INDEX = ~size_t(0); // hybrid_sig.h:25
@@ -749,6 +751,7 @@ void parse_args(int argc, char **argv, Options &o)
 	                        {"blast-include", required_argument, &flag, 22},
 	                        {"blast-exclude", required_argument, &flag, 23},
 	                        {"max-poly-degen", required_argument, &flag, 24},
+	                        {"gpus", required_argument, &flag, 25},
 	                        {nullptr, 0, nullptr, 0}};
 	if (argc == 1) {
 		usage();
@@ -798,6 +801,10 @@ void parse_args(int argc, char **argv, Options &o)
 			case 20: o.rescale_ct = parse_bool(optarg); break;
 			case 21: o.best_match = true; break;
 			case 24: o.t.max_poly_degen = abs(atoi(optarg)); break;
+			case 25: // --gpus: the role of `mpirun -np` for the reference's master / worker build (tntblast_master.cpp)
+				o.gpus = atoi(optarg);
+				if (o.gpus < 1) fail("Please specify --gpus >= 1");
+				break;
 			default: fail(std::string("--") + longs[idx].name + " is not supported by the MI355X front end");
 			}
 			break;
@@ -899,9 +906,28 @@ void validate_search_threshold(Options &o, const std::vector<Assay> &assays) // 
 
 int main(int argc, char **argv)
 {
-	tnt_ctx *ctx = nullptr;
-	tnt_db *db = nullptr;
+	// One context per device (--gpus N; default: every visible device).  The streaming reader's batches of whole records are
+	// dealt to the devices in turn -- targets are independent, seq_index is global -- and searched by one host thread per
+	// device; the hits of a round come back through the gang (compact blobs gathered to the first device over RCCL, one copy to
+	// the host; host merge where RCCL cannot serve) and are filed in batch order, so the output does not depend on N.  This is
+	// the role of the reference's master / workers (tntblast_master.cpp:438-461,811-828; tntblast_worker.cpp:173-186,602).
+	std::vector<tnt_ctx *> ctxs;
+	tnt_ctx *ctx = nullptr; // the first context: oligo structure, masking and fragment searches of batch 0's device ...
+	tnt_gang *gang = nullptr;
+	std::vector<tnt_db *> dbs;
 	tnt_fasta_reader *reader = nullptr;
+	auto release = [&]() {
+		for (tnt_db *d : dbs)
+			if (d) tnt_db_destroy(d);
+		dbs.clear();
+		if (reader) tnt_fasta_close(reader);
+		reader = nullptr;
+		if (gang) tnt_gang_destroy(gang);
+		gang = nullptr;
+		for (tnt_ctx *c : ctxs)
+			if (c) tnt_ctx_destroy(c);
+		ctxs.clear();
+	};
 	try {
 		Options opt;
 		parse_args(argc, argv, opt);
@@ -929,7 +955,34 @@ int main(int argc, char **argv)
 			ta[i].probe = e.probe.empty() ? nullptr : e.probe.c_str();
 			ta[i].forward_degen = e.forward_degen, ta[i].reverse_degen = e.reverse_degen, ta[i].probe_degen = e.probe_degen;
 		}
-		if (tnt_ctx_create(&opt.t, ta.data(), ta.size(), 0, &ctx) != TNT_OK) fail(tnt_last_error(nullptr));
+		{
+			// rank -> device: 0 .. N-1, or the list in TNT_MI355X_DEVICES (several ranks may name one device: host-merged gather)
+			std::vector<int> devices;
+			if (const char *e = getenv("TNT_MI355X_DEVICES")) {
+				std::stringstream ss(e);
+				std::string tok;
+				while (std::getline(ss, tok, ','))
+					if (!tok.empty()) devices.push_back(atoi(tok.c_str()));
+			}
+			const int visible = tnt_device_count();
+			if (visible < 1) fail("no HIP device");
+			int n = opt.gpus ? opt.gpus : (devices.empty() ? visible : int(devices.size()));
+			if (devices.empty()) {
+				if (n > visible) fail("--gpus asks for more devices than are visible");
+				for (int r = 0; r < n; r++) devices.push_back(r);
+			}
+			if (int(devices.size()) < n) fail("TNT_MI355X_DEVICES names fewer devices than --gpus");
+			devices.resize(size_t(n));
+			for (int r = 0; r < n; r++) {
+				tnt_ctx *c = nullptr;
+				if (tnt_ctx_create(&opt.t, ta.data(), ta.size(), devices[size_t(r)], &c) != TNT_OK) fail(tnt_last_error(nullptr));
+				ctxs.push_back(c);
+			}
+			ctx = ctxs[0];
+			if (tnt_gang_create(ctxs.data(), n, &gang) != TNT_OK) fail(tnt_gang_last_error(nullptr));
+			if (getenv("TNT_MI355X_VERBOSE_GANG")) std::cerr << "tntblast-mi355x: " << n << " device context(s), gather over " << tnt_gang_transport(gang) << std::endl;
+		}
+		const size_t n_rank = ctxs.size();
 		if (opt.verbose) std::cout << "Reading sequence database: " << opt.dbase << std::endl;
 		// The database streams through the device in batches of whole records (TNT_MI355X_CHUNK_BYTES of text each,
 		// default 1 GiB): the next batch is read and inflated while this one is searched.
@@ -958,119 +1011,172 @@ int main(int argc, char **argv)
 		max_product_length += 2;
 		size_t n_targets = 0, n_seen = 0;
 		std::vector<std::string> all_deflines; // -m 3 only
-		while (true) {
-			if (tnt_fasta_next(reader, ctx, chunk, &db) != TNT_OK) fail(tnt_last_error(ctx));
-			if (!db) break;
-			const size_t first = n_targets;
-			n_targets += tnt_db_num_targets(db);
-			if (opt.format & Options::INVERSE_TARGET)
-				for (size_t t = 0; t < tnt_db_num_targets(db); t++) {
-					const char *defline = "";
-					size_t dl = 0;
-					(void)tnt_db_defline(db, t, &defline, &dl);
-					all_deflines.emplace_back(defline, dl);
-				}
-			// targets whose record is longer than --max-target-len are searched in fragments (tntblast_local.cpp:282-289,
-			// 438-468): the record's size in the file -- defline and line ends included -- is what the reference goes by
-			std::vector<char> is_long(tnt_db_num_targets(db), 0);
+		struct Batch { // one batch of whole records on its way through a device
+			tnt_db *db = nullptr;
+			size_t first = 0;
+			std::vector<char> is_long;
 			std::vector<size_t> long_targets;
-			for (size_t t = 0; t < tnt_db_num_targets(db); t++) {
-				uint64_t approx = 0;
-				if (tnt_db_target_info(db, t, nullptr, &approx) != TNT_OK) fail("tnt_db_target_info failed");
-				if (approx > uint64_t(opt.max_target_len)) is_long[t] = 1, long_targets.push_back(t);
-			}
-			const tnt_hit *hits = nullptr;
-			size_t n_hits = 0;
-			std::vector<Record> batch; // this batch's records: masked (if asked for), then filed under their assays
-			// (records beyond --max-target-len are not searched whole: only their fragments are, below)
-			if (!long_targets.empty() && tnt_db_skip_targets(ctx, db, reinterpret_cast<const uint8_t *>(is_long.data()), is_long.size()) != TNT_OK)
-				fail(tnt_last_error(ctx));
-			if (tnt_search(ctx, db, &hits, &n_hits) != TNT_OK) fail(tnt_last_error(ctx));
-			for (size_t i = 0; i < n_hits; i++) {
-				if (is_long[size_t(hits[i].seq_index) - first]) continue; // (none: skipped above)
-				Record rec{hits[i], n_seen++, std::string(), std::string()};
-				const int na = tnt_hit_sequence(ctx, db, &hits[i], amp.data(), amp.size());
-				if (na < 0) fail("amplicon longer than the sequence buffer");
-				rec.amplicon.assign(amp.data(), size_t(na));
-				const char *defline = "";
-				size_t dl = 0;
-				(void)tnt_db_defline(db, size_t(hits[i].seq_index) - first, &defline, &dl);
-				rec.defline.assign(defline, dl);
-				batch.push_back(rec);
-			}
-			if (!long_targets.empty()) {
-				// the fragments become the targets of a database of their own
-				struct Frag {
-					size_t target;
-					unsigned int start, stop, max_stop, len; // [start, stop] of the cut, bases actually read
-				};
-				std::vector<Frag> frags;
-				std::vector<uint8_t> codes;
-				std::vector<uint64_t> offs(1, 0);
-				std::vector<uint8_t> whole;
-				for (size_t t : long_targets) {
-					uint32_t n_bases = 0;
-					uint64_t approx = 0;
-					(void)tnt_db_target_info(db, t, &n_bases, &approx);
-					whole.resize(std::max<size_t>(1, n_bases));
-					if (tnt_db_target_codes(ctx, db, t, whole.data(), whole.size()) < 0) fail(tnt_last_error(ctx));
-					const unsigned int max_stop = (unsigned int)(approx - 1);
-					const unsigned int delta = seq_len_increment((unsigned int)approx, (unsigned int)opt.max_target_len).first;
-					unsigned int start = 0, stop = delta;
-					while (true) {
-						// read_bio_seq(target, start, stop + max_product_length), sequence_data_fastx.cpp:296-372
-						const uint64_t want_stop = uint64_t(stop) + max_product_length;
-						const uint64_t last = std::min<uint64_t>(want_stop, n_bases ? n_bases - 1 : 0);
-						const unsigned int len = (n_bases && start <= last) ? (unsigned int)(last - start + 1) : 0u;
-						if (len >= (unsigned int)opt.t.hash_word_size) { // shorter pieces are skipped (tntblast_local.cpp:513-531)
-							frags.push_back(Frag{t, start, stop, max_stop, len});
-							codes.insert(codes.end(), whole.begin() + start, whole.begin() + start + len);
-							offs.push_back(codes.size());
-						}
-						if (stop == max_stop) break;
-						start = stop + 1;
-						stop = std::min(stop + delta, max_stop);
-						fragmented = true;
-					}
+			std::string error;
+		};
+		bool at_end = false;
+		std::vector<tnt_hit> unpacked;
+		while (!at_end) {
+			// ---- a round: up to one batch per device, read in file order
+			std::vector<Batch> round;
+			for (size_t k = 0; k < n_rank && !at_end; k++) {
+				tnt_db *db = nullptr;
+				if (tnt_fasta_next(reader, ctxs[k], chunk, &db) != TNT_OK) fail(tnt_last_error(ctxs[k]));
+				if (!db) {
+					at_end = true;
+					break;
 				}
-				if (!frags.empty()) {
-					tnt_db *fdb = nullptr;
-					if (tnt_db_create(ctx, codes.data(), offs.data(), frags.size(), 0, &fdb) != TNT_OK) fail(tnt_last_error(ctx));
-					const tnt_hit *fh = nullptr;
-					size_t nf = 0;
-					if (tnt_search(ctx, fdb, &fh, &nf) != TNT_OK) fail(tnt_last_error(ctx));
-					for (size_t i = 0; i < nf; i++) {
-						const Frag &F = frags[size_t(fh[i].seq_index)];
-						const int lo = fh[i].has_primers ? fh[i].amplicon_start : fh[i].probe_start;
-						const int hi = fh[i].has_primers ? fh[i].amplicon_stop : fh[i].probe_stop;
-						// matches cut off by the fragment's edges are dropped (tntblast_local.cpp:638-648)
-						if (F.start != 0 && lo <= 0) continue;
-						if (F.stop != F.max_stop && hi >= int(F.len) - 1) continue;
-						Record rec{fh[i], n_seen++, std::string(), std::string()};
-						const int na = tnt_hit_sequence(ctx, fdb, &fh[i], amp.data(), amp.size());
-						if (na < 0) fail("amplicon longer than the sequence buffer");
-						rec.amplicon.assign(amp.data(), size_t(na));
-						rec.h.seq_index = int(first + F.target);
-						if (rec.h.has_primers) rec.h.amplicon_start += int(F.start), rec.h.amplicon_stop += int(F.start); // offset_ranges
-						if (rec.h.has_probe) rec.h.probe_start += int(F.start), rec.h.probe_stop += int(F.start);
+				dbs.push_back(db);
+				Batch B;
+				B.db = db;
+				B.first = n_targets;
+				n_targets += tnt_db_num_targets(db);
+				if (opt.format & Options::INVERSE_TARGET)
+					for (size_t t = 0; t < tnt_db_num_targets(db); t++) {
 						const char *defline = "";
 						size_t dl = 0;
-						(void)tnt_db_defline(db, F.target, &defline, &dl);
-						rec.defline.assign(defline, dl);
-						batch.push_back(rec);
+						(void)tnt_db_defline(db, t, &defline, &dl);
+						all_deflines.emplace_back(defline, dl);
 					}
-					tnt_db_destroy(fdb);
+				// targets whose record is longer than --max-target-len are searched in fragments (tntblast_local.cpp:282-289,
+				// 438-468): the record's size in the file -- defline and line ends included -- is what the reference goes by
+				B.is_long.assign(tnt_db_num_targets(db), 0);
+				for (size_t t = 0; t < tnt_db_num_targets(db); t++) {
+					uint64_t approx = 0;
+					if (tnt_db_target_info(db, t, nullptr, &approx) != TNT_OK) fail("tnt_db_target_info failed");
+					if (approx > uint64_t(opt.max_target_len)) B.is_long[t] = 1, B.long_targets.push_back(t);
 				}
+				round.push_back(std::move(B));
 			}
-			apply_masks(ctx, opt, batch, 0, [&](const Record &r, int slot) { // tntblast_util.cpp:97-137
-				const Expanded &e = expanded[size_t(r.h.degen_id)];
-				if (slot == 2) return e.probe;
-				const int which = slot == 0 ? r.h.forward_oligo : r.h.reverse_oligo; // single-primer amplicons swap identities
-				return which == 0 ? e.forward : e.reverse;
-			});
-			for (Record &rec : batch) results[size_t(rec.h.assay_id)].push_back(rec);
-			tnt_db_destroy(db);
-			db = nullptr;
+			if (round.empty()) break;
+			// ---- every device searches its batch (one host thread per context; the records stay on the devices)
+			auto search_batch = [&](size_t k) {
+				Batch &B = round[k];
+				// (records beyond --max-target-len are not searched whole: only their fragments are, below)
+				if (!B.long_targets.empty() && tnt_db_skip_targets(ctxs[k], B.db, reinterpret_cast<const uint8_t *>(B.is_long.data()), B.is_long.size()) != TNT_OK) {
+					B.error = tnt_last_error(ctxs[k]);
+					return;
+				}
+				size_t n = 0;
+				if (tnt_search_enqueue(ctxs[k], B.db) != TNT_OK || tnt_search_collect(ctxs[k], nullptr, &n) != TNT_OK) B.error = tnt_last_error(ctxs[k]);
+			};
+			{
+				std::vector<std::thread> workers;
+				for (size_t k = 1; k < round.size(); k++) workers.emplace_back(search_batch, k);
+				search_batch(0);
+				for (std::thread &w : workers) w.join();
+			}
+			for (const Batch &B : round)
+				if (!B.error.empty()) fail(B.error);
+			// ---- the hits of the round come to the host through the gang, rank by rank = batch by batch
+			std::vector<uint8_t> has(n_rank, 0);
+			for (size_t k = 0; k < round.size(); k++) has[k] = 1;
+			std::vector<const void *> blobs(n_rank, nullptr);
+			std::vector<size_t> blob_bytes(n_rank, 0), blob_hits(n_rank, 0);
+			if (tnt_gang_gather(gang, has.data(), blobs.data(), blob_bytes.data(), blob_hits.data()) != TNT_OK) fail(tnt_gang_last_error(gang));
+			for (size_t k = 0; k < round.size(); k++) {
+				tnt_ctx *ctx = ctxs[k]; // (this batch's device: amplicon text, fragments and masking run where its targets are)
+				tnt_db *db = round[k].db;
+				const size_t first = round[k].first;
+				const std::vector<char> &is_long = round[k].is_long;
+				const std::vector<size_t> &long_targets = round[k].long_targets;
+				size_t n_hits = 0;
+				unpacked.resize(std::max<size_t>(1, blob_hits[k]));
+				if (tnt_hits_unpack(blobs[k], blob_bytes[k], unpacked.data(), unpacked.size(), &n_hits) != TNT_OK || n_hits != blob_hits[k]) fail("malformed hit blob");
+				const tnt_hit *hits = unpacked.data();
+				std::vector<Record> batch; // this batch's records: masked (if asked for), then filed under their assays
+				for (size_t i = 0; i < n_hits; i++) {
+					if (is_long[size_t(hits[i].seq_index) - first]) continue; // (none: skipped above)
+					Record rec{hits[i], n_seen++, std::string(), std::string()};
+					const int na = tnt_hit_sequence(ctx, db, &hits[i], amp.data(), amp.size());
+					if (na < 0) fail("amplicon longer than the sequence buffer");
+					rec.amplicon.assign(amp.data(), size_t(na));
+					const char *defline = "";
+					size_t dl = 0;
+					(void)tnt_db_defline(db, size_t(hits[i].seq_index) - first, &defline, &dl);
+					rec.defline.assign(defline, dl);
+					batch.push_back(rec);
+				}
+				if (!long_targets.empty()) {
+					// the fragments become the targets of a database of their own
+					struct Frag {
+						size_t target;
+						unsigned int start, stop, max_stop, len; // [start, stop] of the cut, bases actually read
+					};
+					std::vector<Frag> frags;
+					std::vector<uint8_t> codes;
+					std::vector<uint64_t> offs(1, 0);
+					std::vector<uint8_t> whole;
+					for (size_t t : long_targets) {
+						uint32_t n_bases = 0;
+						uint64_t approx = 0;
+						(void)tnt_db_target_info(db, t, &n_bases, &approx);
+						whole.resize(std::max<size_t>(1, n_bases));
+						if (tnt_db_target_codes(ctx, db, t, whole.data(), whole.size()) < 0) fail(tnt_last_error(ctx));
+						const unsigned int max_stop = (unsigned int)(approx - 1);
+						const unsigned int delta = seq_len_increment((unsigned int)approx, (unsigned int)opt.max_target_len).first;
+						unsigned int start = 0, stop = delta;
+						while (true) {
+							// read_bio_seq(target, start, stop + max_product_length), sequence_data_fastx.cpp:296-372
+							const uint64_t want_stop = uint64_t(stop) + max_product_length;
+							const uint64_t last = std::min<uint64_t>(want_stop, n_bases ? n_bases - 1 : 0);
+							const unsigned int len = (n_bases && start <= last) ? (unsigned int)(last - start + 1) : 0u;
+							if (len >= (unsigned int)opt.t.hash_word_size) { // shorter pieces are skipped (tntblast_local.cpp:513-531)
+								frags.push_back(Frag{t, start, stop, max_stop, len});
+								codes.insert(codes.end(), whole.begin() + start, whole.begin() + start + len);
+								offs.push_back(codes.size());
+							}
+							if (stop == max_stop) break;
+							start = stop + 1;
+							stop = std::min(stop + delta, max_stop);
+							fragmented = true;
+						}
+					}
+					if (!frags.empty()) {
+						tnt_db *fdb = nullptr;
+						if (tnt_db_create(ctx, codes.data(), offs.data(), frags.size(), 0, &fdb) != TNT_OK) fail(tnt_last_error(ctx));
+						const tnt_hit *fh = nullptr;
+						size_t nf = 0;
+						if (tnt_search(ctx, fdb, &fh, &nf) != TNT_OK) fail(tnt_last_error(ctx));
+						for (size_t i = 0; i < nf; i++) {
+							const Frag &F = frags[size_t(fh[i].seq_index)];
+							const int lo = fh[i].has_primers ? fh[i].amplicon_start : fh[i].probe_start;
+							const int hi = fh[i].has_primers ? fh[i].amplicon_stop : fh[i].probe_stop;
+							// matches cut off by the fragment's edges are dropped (tntblast_local.cpp:638-648)
+							if (F.start != 0 && lo <= 0) continue;
+							if (F.stop != F.max_stop && hi >= int(F.len) - 1) continue;
+							Record rec{fh[i], n_seen++, std::string(), std::string()};
+							const int na = tnt_hit_sequence(ctx, fdb, &fh[i], amp.data(), amp.size());
+							if (na < 0) fail("amplicon longer than the sequence buffer");
+							rec.amplicon.assign(amp.data(), size_t(na));
+							rec.h.seq_index = int(first + F.target);
+							if (rec.h.has_primers) rec.h.amplicon_start += int(F.start), rec.h.amplicon_stop += int(F.start); // offset_ranges
+							if (rec.h.has_probe) rec.h.probe_start += int(F.start), rec.h.probe_stop += int(F.start);
+							const char *defline = "";
+							size_t dl = 0;
+							(void)tnt_db_defline(db, F.target, &defline, &dl);
+							rec.defline.assign(defline, dl);
+							batch.push_back(rec);
+						}
+						tnt_db_destroy(fdb);
+					}
+				}
+				apply_masks(ctx, opt, batch, 0, [&](const Record &r, int slot) { // tntblast_util.cpp:97-137
+					const Expanded &e = expanded[size_t(r.h.degen_id)];
+					if (slot == 2) return e.probe;
+					const int which = slot == 0 ? r.h.forward_oligo : r.h.reverse_oligo; // single-primer amplicons swap identities
+					return which == 0 ? e.forward : e.reverse;
+				});
+				for (Record &rec : batch) results[size_t(rec.h.assay_id)].push_back(rec);
+				tnt_db_destroy(db);
+				for (tnt_db *&d : dbs)
+					if (d == db) d = nullptr;
+			}
+			dbs.clear();
 		}
 		tnt_fasta_close(reader);
 		reader = nullptr;
@@ -1340,13 +1446,11 @@ int main(int argc, char **argv)
 				if (!e.probe.empty()) std::cout << "\tP = " << e.probe << std::endl;
 			}
 		}
-		tnt_ctx_destroy(ctx);
+		release();
 		return EXIT_SUCCESS;
 	} catch (const Fail &f) {
 		std::cerr << "Caught the error: " << f.msg << std::endl;
-		if (db) tnt_db_destroy(db);
-		if (reader) tnt_fasta_close(reader);
-		if (ctx) tnt_ctx_destroy(ctx);
+		release();
 		return EXIT_FAILURE;
 	}
 }

@@ -98,6 +98,16 @@ def load_library():
     lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
     lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
     lib.tnt_db_skip_targets.argtypes = [C.c_void_p, C.c_void_p, P(C.c_uint8), C.c_size_t]
+    lib.tnt_search_collect_compact.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t), P(C.c_size_t)]
+    lib.tnt_device_count.restype = C.c_int
+    lib.tnt_gang_create.argtypes = [P(C.c_void_p), C.c_int, P(C.c_void_p)]
+    lib.tnt_gang_destroy.argtypes = [C.c_void_p]
+    lib.tnt_gang_destroy.restype = None
+    lib.tnt_gang_transport.argtypes = [C.c_void_p]
+    lib.tnt_gang_transport.restype = C.c_char_p
+    lib.tnt_gang_last_error.argtypes = [C.c_void_p]
+    lib.tnt_gang_last_error.restype = C.c_char_p
+    lib.tnt_gang_gather.argtypes = [C.c_void_p, P(C.c_uint8), P(C.c_void_p), P(C.c_size_t), P(C.c_size_t)]
     if lib.tnt_abi_version() != abi.TNT_ABI_VERSION:
         raise TntError("ABI version mismatch")
     _lib = lib
@@ -112,6 +122,7 @@ EXPORTED_SYMBOLS = [
     "tnt_last_timing", "tnt_seeds", "tnt_first_cull", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_info", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
+    "tnt_search_collect_compact", "tnt_device_count", "tnt_gang_create", "tnt_gang_destroy", "tnt_gang_transport", "tnt_gang_last_error", "tnt_gang_gather",
 ]
 
 
@@ -304,6 +315,29 @@ class Engine:
         C.memmove(out, view, C.sizeof(abi.tnt_hit) * n.value)
         return out
 
+    def collect_device(self):
+        """Collects the enqueued search and leaves the hit records on the device (tnt_search_collect with hits == NULL);
+        returns their number."""
+        n = C.c_size_t()
+        self._check(self.lib.tnt_search_collect(self._h, None, C.byref(n)))
+        return n.value
+
+    def collect_compact(self):
+        """Collects the enqueued search; the hits reach the host in compact form (tnt_search_collect_compact).  Returns
+        (host address of the blob -- page-locked memory of the context, valid until its next search --, bytes, hits)."""
+        ptr, nb, n = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._check(self.lib.tnt_search_collect_compact(self._h, C.byref(ptr), C.byref(nb), C.byref(n)))
+        return (ptr.value or 0), nb.value, n.value
+
+    def unpack(self, address, n_bytes, n_hits):
+        """tnt_hits_unpack: the records of a compact blob in host memory."""
+        out = (abi.tnt_hit * max(1, n_hits))()
+        n = C.c_size_t()
+        rc = self.lib.tnt_hits_unpack(C.c_void_p(address), n_bytes, out, n_hits, C.byref(n))
+        if rc != 0 or n.value != n_hits:
+            raise TntError("tnt_hits_unpack failed (%d)" % rc)
+        return (abi.tnt_hit * n_hits).from_buffer(out) if n_hits else (abi.tnt_hit * 0)()
+
     def hits_device(self):
         """(device pointer, count) of the last collected search's hit records in device memory (those of targets seeded in
         windows, paired on host threads, are copied behind the pair kernel's own): see tnt_search_hits_device."""
@@ -373,3 +407,36 @@ class Engine:
         if n < 0:
             raise TntError("tnt_hit_sequence failed (%d)" % n)
         return buf.value.decode()
+
+
+class Gang:
+    """Several contexts of one process, one per device (or several on one device: host transport), and the gather of
+    their hits to the host (tnt_gang_*): what tntblast-mi355x --gpus N runs on."""
+
+    def __init__(self, engines):
+        self.lib = load_library()
+        self.engines = list(engines)
+        arr = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+        self._h = C.c_void_p()
+        rc = self.lib.tnt_gang_create(arr, len(self.engines), C.byref(self._h))
+        if rc != 0:
+            raise TntError((self.lib.tnt_gang_last_error(None) or b"").decode() or "tnt_gang_create failed (%d)" % rc)
+
+    @property
+    def transport(self):
+        return self.lib.tnt_gang_transport(self._h).decode()
+
+    def gather(self, has=None):
+        """Per rank the hit records (unpacked) of its last collected search; None for ranks left out."""
+        n = len(self.engines)
+        blobs, nb, nh = (C.c_void_p * n)(), (C.c_size_t * n)(), (C.c_size_t * n)()
+        mask = None if has is None else (C.c_uint8 * n)(*[1 if x else 0 for x in has])
+        rc = self.lib.tnt_gang_gather(self._h, mask, blobs, nb, nh)
+        if rc != 0:
+            raise TntError(self.lib.tnt_gang_last_error(self._h).decode())
+        return [None if (has is not None and not has[r]) else self.engines[r].unpack(blobs[r] or 0, nb[r], nh[r]) for r in range(n)]
+
+    def close(self):
+        if self._h:
+            self.lib.tnt_gang_destroy(self._h)
+            self._h = C.c_void_p()
