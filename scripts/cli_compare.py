@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end check of the command-line front end on the GPU box: the same assay file + FASTA database through
 the reference binary (oracle/_ref/tntblast, OMP_NUM_THREADS=1) and through tntblast-mi355x; the two output
-files must be byte-identical.   python scripts/cli_compare.py [workdir]"""
+files must be byte-identical.   python scripts/cli_compare.py [workdir]
+With a second argument `stub`: oracle/_ref/tntblast_stub -- the reference's own program with the work loop of its OpenMP
+region replaced by the binding of INTEGRATION.md (oracle/build_stub.py) -- takes the front end's place, on the cases that
+need neither masking nor fragmentation (both are the caller's business at the C ABI)."""
 import os
 import subprocess
 import sys
@@ -16,6 +19,8 @@ from thermonucleotideblast_amd import synth  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "tntblast")
 CLI = os.path.join(ROOT, "thermonucleotideblast_amd", "tntblast-mi355x")
+STUB = os.path.join(ROOT, "oracle", "_ref", "tntblast_stub")
+STUB_SKIPS = ("mask_primers_k", "mask_probe_K", "replace_primers_r", "mask_all_krK_m1", "fragment_default", "fragment_small")
 
 CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("pcr", 2, 300, 24, 3, ["-e", "40"]),
@@ -118,8 +123,12 @@ def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False, name=None):
 
 def main():
     work = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "cli")
+    stub = len(sys.argv) > 2 and sys.argv[2] == "stub"
+    program = STUB if stub else CLI
     bad = 0
     for name, cfg, nt, na, seed, flags in CASES:
+        if stub and name in STUB_SKIPS:
+            continue
         d = os.path.join(work, name)
         os.makedirs(d, exist_ok=True)
         for f in os.listdir(d):
@@ -129,7 +138,7 @@ def main():
         common = ["-i", os.path.join(d, "assays.txt"), "-d", os.path.join(d, "db.fna")] + flags
         env = dict(os.environ, OMP_NUM_THREADS="1")
         r1 = subprocess.run([REF] + common + ["-o", os.path.join(d, "ref.out")], env=env, capture_output=True, text=True)
-        r2 = subprocess.run([CLI] + common + ["-o", os.path.join(d, "hip.out")], capture_output=True, text=True)
+        r2 = subprocess.run([program] + common + ["-o", os.path.join(d, "hip.out")], env=env if stub else None, capture_output=True, text=True)
         if r1.returncode or r2.returncode:
             print(name, "FAILED to run: ref rc", r1.returncode, "hip rc", r2.returncode, r1.stderr[-300:], r2.stderr[-300:])
             bad += 1

@@ -1261,3 +1261,41 @@ def test_cli_deals_batches_to_several_contexts(Engine, tmp_path, monkeypatch):
         if label == "three":
             assert "3 device context(s), gather over host" in r.stderr, r.stderr
     assert outs["one"] == outs["three"] == outs["default"] and outs["one"].count("amplicon range") > 20
+
+
+@pytest.mark.parametrize("cfg", [3, 4, 5])
+def test_full_size_configs_through_the_bench(Engine, cfg):
+    """BASELINE.json configs 3, 4, 5 at the size of one GPU's shard (1 M x 1 kb x 96 TaqMan triplets; 1.25 M x 2 kb x 1 000
+    assays = 2 043 expanded; 625 k targets with degenerate bases x padlock + probe mix), one warm-up + one step of bench.py
+    with a parity sample of 16 384 targets against the oracle: the capacity repairs, multi-chunk seed passes and
+    multi-million-hit buffers of that scale run under the driver's eyes, not only in profiles/."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", str(cfg), "--steps", "1", "--warmup", "1", "--cpu-seconds", "4",
+                        "--parity-targets", "16384"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    print("config %d per-GPU shard: %.1f ms per step, %.3g evals/s, %d hits per step; parity sample %s" % (
+        cfg, line["ms_per_step"], line["value"], line["hits_per_step"], line["parity_sample"]))
+    assert line["hit_multiset_equal"] is True and line["tm_max_abs_err"] == 0.0 and line["dg_max_abs_err"] == 0.0
+    assert line["parity_sample"]["hits_gpu"] == line["parity_sample"]["hits_cpu"] > 0
+    assert line["config"]["workload"] and line["n_gpus"] == 1
+
+
+def test_integration_stub_drops_in(Engine, checkers, tmp_path):
+    """INTEGRATION.md's binding compiled for real (oracle/build_stub.py: the reference's tntblast_local.cpp with the work loop
+    of its OpenMP region replaced by tnt_ctx_create / tnt_db_create / tnt_search / tnt_hit -> hybrid_sig, linked with the
+    reference's other objects and libtnt_mi355x.so): its output files and closing statistics equal the reference binary's on
+    every front-end case that needs neither masking nor fragmentation."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "tntblast")) or not os.path.exists(os.path.join(root, "oracle", "_ref", "tntblast_stub")):
+        pytest.skip("no oracle/_ref/tntblast or tntblast_stub")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cli_compare.py"), str(tmp_path), "stub"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-500:]
+    assert r.stdout.count("identical") >= 20
