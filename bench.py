@@ -260,6 +260,26 @@ def launch_only(args, rank, world):
         sys.exit(1)
 
 
+def roofline_of_bind_stage(hbm_achieved, traffic, valu, n_binds, bind_ms_step):
+    """The dominant stage (pre-filter + bind kernels).  What bounds it is VALU issue (integer DP: DESIGN.md 4.2, 4.2a), so where
+    the instruction counts of the workload are on file (profiles/bind_pmc.json, config 2 at full size) the line prices it against
+    the VALU issue peak of the guide; the algorithmic-bytes figure against HBM (tiny by construction) stays beside it."""
+    kernel = "bind stage: filter_kernel<L> (pre-filter, on the queues the seed kernel filled) + bind_kernel<L> on the survivors; phase B through bucket_kernel"
+    hbm = {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+           "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once) over the stage time (HIP events on the library's stream)"}
+    src = ("profiles/bind_pmc.json: rocprofv3 --pmc passes of this workload in a run of their own (scripts/pmc_collect.sh), not measured by this process"
+           if traffic is not None else None)
+    dps = n_binds / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0
+    if valu:
+        return {"bound": "valu", "kernel": kernel, "achieved": valu["achieved"], "peak": valu["peak_guide"], "unit": valu["unit"], "frac": valu["frac_guide"],
+                "traffic": traffic, "traffic_source": src, "dp_per_s": dps, "hbm": hbm, "valu_issue": valu,
+                "note": "bound by VALU issue, not by HBM: achieved = VALU wave-instructions per step (PMC SQ_INSTS_VALU of this workload, "
+                        "profiles/bind_pmc.json) over this run's stage time (HIP events); peak = 1 024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction "
+                        "(the guide's wave64 rate for full-rate ops; half of this stage's instructions are half-rate packed / three-operand forms); "
+                        "traffic = PMC 2*FETCH_SIZE + WRITE_SIZE per step"}
+    return dict({"bound": "hbm", "kernel": kernel, "traffic": traffic, "traffic_source": src, "dp_per_s": dps, "valu_issue": None}, **hbm)
+
+
 def main():
     args = parse()
     in_rank_env = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -423,16 +443,19 @@ def main():
         # the streaming part of the seed stage alone (SURVEY 8(d) means the HBM roofline for THIS scan): its share of the
         # kernel's cycles from the phase stamps of a diagnostic build (profiles/seed_phases.json) x this run's stage time
         scan_only = None
-        ph = os.path.join(ROOT, "profiles", "seed_phases.json")
-        if os.path.exists(ph) and args.config == 2 and per_piece == full and args.scaling == "weak" and seed_ms_step > 0:
+        if world == 1 and len(dbs) == 1:
+            # the scan of the seed stage on its own (tnt_seed_scan_only: every k-mer of every target looked up in the query-word
+            # table of every assay chunk, candidates counted, nothing behind it), timed with HIP events on the library's stream:
+            # the launch SURVEY 8(d) prices against the HBM roofline (0.25 B per target base and chunk)
             try:
-                share = json.load(open(ph))["share"]["scan"]
-                scan_ms = share * seed_ms_step
+                scan_ms, n_cand = eng.scan_only(dbs[0], repeats=10)
                 gbs = alg_bytes / (scan_ms * 1e-3) / 1e9
-                scan_only = {"ms_per_step": scan_ms, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "share_of_seed_kernel": share,
-                             "source": "profiles/seed_phases.json (scripts/seed_phases.py: s_memtime stamps of a TNT_EXP_STATS build, a run of its own)"}
-            except Exception:
-                scan_only = None
+                scan_only = {"ms_per_pass": scan_ms, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "candidates_per_pass": int(n_cand),
+                             "candidates_per_target_base": n_cand / float(n_bases_rank),
+                             "source": "measured: tnt_seed_scan_only, 10 passes behind a warm-up, HIP events on the library's stream "
+                                       "(achieved = 0.25 B/base x bases / time of one pass over all assay chunks; rocprofv3 summary of the same launch: profiles/)"}
+            except Exception as ex:  # noqa: BLE001
+                scan_only = {"error": str(ex)}
         tl = n_bases_rank // max(1, n_targets_rank)
         line = {
             "metric": "oligo x target-base evaluations per second (seed + NN-thermodynamic bind + pairing)",
@@ -451,17 +474,7 @@ def main():
             "gather_bytes_per_search": acc["gather_bytes"],
             "pack_and_h2d_s": pack_s,
             "stage_ms_per_step": {"seed": seed_ms_step, "bind": bind_ms_step, "pair": pair_ms / steps},
-            "roofline": {"bound": "hbm", "kernel": "bind stage: filter_kernel<L> (pre-filter, on the queues the seed kernel filled) + bind_kernel<L> on the survivors; phase B through bucket_kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": ("profiles/bind_pmc.json: rocprofv3 --pmc passes of this workload in a run of their own "
-                                            "(scripts/pmc_collect.sh), not measured by this process") if traffic is not None else None,
-                         "note": "algorithmic bytes = 0.25 B/target-base (2-bit packed targets read once) over the stage time "
-                                 "(HIP events on the library's stream); the stage is bound by VALU issue and LDS bank "
-                                 "conflicts, not by HBM (DESIGN.md 4.2, 4.2a); traffic = PMC 2*FETCH_SIZE + WRITE_SIZE per step "
-                                 "of the full-size config (profiles/bind_pmc.json; round 1: 56.5 GB, round 2: 20.7 GB)",
-                         "dp_per_s": n_binds / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0,
-                         "valu_issue": valu},
+            "roofline": roofline_of_bind_stage(achieved, traffic, valu, n_binds, bind_ms_step),
             # the streaming stage, for which SURVEY 8(d) means the HBM roofline: the seed kernels of a step (scan + cull)
             "roofline_seed": {"bound": "hbm", "kernel": "seed stage: seed2_kernel (scan + diagonal de-duplication + first cull + emission into the buckets' queues)", "achieved": seed_achieved,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": seed_achieved / HBM_PEAK_GBS,

@@ -287,6 +287,13 @@ int tnt_seeds(tnt_ctx *ctx, tnt_db *db, const tnt_seed **seeds, size_t *n_seeds)
  * call).  Targets that are seeded in windows: their lists are assembled and culled whole on the device (same rows). */
 int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_rows);
 int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out);
+/* Measurement entry: the scan of the seed stage on its own (DNAHash::hash + the word look-ups of find / find_complement,
+ * seq_hash.h:524-642,749-779, with nothing behind them): every k-mer of every whole-target work unit is looked up in the
+ * inverted query-word table of each assay chunk and the candidates are counted.  `repeats` timed passes behind one
+ * warm-up; *ms_per_pass = HIP-event time of one pass over the database (all chunks), *n_candidates = raw seeds of one pass
+ * (before the diagonal de-duplication).  Streams 0.25 bytes per target base and chunk: the stage SURVEY 8(d) prices against
+ * the HBM roofline.                                                                                                      */
+int tnt_seed_scan_only(tnt_ctx *ctx, tnt_db *db, int repeats, float *ms_per_pass, uint64_t *n_candidates);
 /* The same requests through the kernels tnt_search() runs (bind_oligo.cpp:502-748 for each): TNT_ROUTE_BUCKETS splits
  * the queue by oligo length like a search phase does, so every request is bound by the throughput instance of its
  * length (exact / plain ladder; the general ladder for windows with degenerate target bases); TNT_ROUTE_MERGED binds

@@ -89,10 +89,10 @@ struct Slot {
 	int32_t bucket_general; // ... and the one for windows that hold a degenerate target base
 };
 
-// Instances of the bind kernel (rows kept in registers): every oligo length up to 32 has its own, so the
-// oligos of one launch all have exactly LMAX rows; coarser above.
+// Instances of the bind kernel (rows kept in registers): every oligo length up to 40 has its own (probes of 33 to 40 bases
+// since round 4: config 5), so the oligos of one launch all have exactly LMAX rows; coarser above.
 // Exact instances (every oligo of the launch has exactly LMAX rows: no per-row length test; plain windows only) ...
-#define TNT_EXACT_LADDER(X) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#define TNT_EXACT_LADDER(X) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40)
 // ... and a ladder (L <= LMAX) in two flavours: plain windows (A/C/G/T targets) for the other lengths, and
 // general ones for windows with degenerate target bases and for short queues that are bound in one launch
 #define TNT_LMAX_LADDER(X) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
@@ -100,7 +100,7 @@ struct Slot {
 // they meet the pre-filter (128-row instances of the F / D kinds) when the context's calibration says it pays
 #define TNT_LONG_LADDER(X) X(128)
 // instances of the pre-filter kernel (tnt_filter.hip.h): the row counts of both ladders above
-#define TNT_FILTER_LADDER(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
+#define TNT_FILTER_LADDER(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
 constexpr int MAX_BUCKETS = 48;
 constexpr int BUCKET_EXACT = 0x100, BUCKET_PLAIN = 0x200; // flags on the instance id kept by the host (lmax | flags)
 

@@ -3199,6 +3199,62 @@ int tnt_first_cull(tnt_ctx *ctx, tnt_db *db, const int32_t **rows, size_t *n_row
 	return TNT_OK;
 }
 
+int tnt_seed_scan_only(tnt_ctx *ctx, tnt_db *db, int repeats, float *ms_per_pass, uint64_t *n_candidates)
+{
+	if (!ctx || !db || db->ctx != ctx || !ms_per_pass || !n_candidates || repeats < 1) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "a search is pending on this context: collect it first";
+		return TNT_E_ARG;
+	}
+	if (db->n_short_units == 0 || !db->unit_rec.p) {
+		ctx->err = "tnt_seed_scan_only: the database has no whole-target work units";
+		return TNT_E_UNSUPPORTED;
+	}
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx, ctx->lmax, db);
+	if (rc) return rc;
+	size_t tpb = 1;
+	rc = plan(ctx, db, tpb); // the chunk tables of the context
+	if (rc) return rc;
+	DevBuf<unsigned long long> count;
+	HIP_TRY(count.alloc(1), ctx->err);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	HIP_TRY(hipEventCreate(&e0), ctx->err);
+	HIP_TRY(hipEventCreate(&e1), ctx->err);
+	ScanOnlyArgs a;
+	memset(&a, 0, sizeof(a));
+	a.db = make_view(db, 0, db->n_targets);
+	a.unit_rec = db->unit_rec.p;
+	a.unit0 = 0, a.unit1 = uint32_t(db->n_short_units);
+	a.word_size = ctx->opt.hash_word_size;
+	a.n_candidates = count.p;
+	const size_t n_words = size_t(1) << (2 * ctx->opt.hash_word_size);
+	const size_t off_stride = (n_words + 1 + 1) & ~size_t(1);
+	const int blocks = ctx->n_cu * 2; // two 1024-thread workgroups per CU (32 KB of LDS each at k = 7)
+	float total = 0.0f;
+	for (int r = 0; r <= repeats; r++) { // (pass 0 warms up and is not timed)
+		HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(unsigned long long), ctx->stream), ctx->err);
+		HIP_TRY(hipEventRecord(e0, ctx->stream), ctx->err);
+		for (size_t ch = 0; ch + 1 < ctx->chunk_begin.size(); ch++) {
+			a.wt_off = ctx->wt_off.p + ch * off_stride;
+			hipLaunchKernelGGL(scan_only_kernel, dim3(blocks), dim3(SCAN_THREADS), n_words * sizeof(uint16_t), ctx->stream, a);
+		}
+		HIP_TRY(hipEventRecord(e1, ctx->stream), ctx->err);
+		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, e0, e1), ctx->err);
+		if (r) total += ms;
+	}
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	HIP_TRY(hipGetLastError(), ctx->err);
+	unsigned long long n = 0;
+	HIP_TRY(hipMemcpy(&n, count.p, sizeof(n), hipMemcpyDeviceToHost), ctx->err);
+	*ms_per_pass = total / float(repeats);
+	*n_candidates = n;
+	return TNT_OK;
+}
+
 int tnt_bind_batch(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, tnt_bind *out)
 {
 	return tnt_bind_batch_routed(ctx, db, req, n, out, TNT_ROUTE_UNIT);

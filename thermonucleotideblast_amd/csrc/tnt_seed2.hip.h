@@ -711,5 +711,59 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The scan on its own (a measurement launch, not part of a search): what SURVEY 8(d) calls the streaming half of the seed
+// stage -- every k-mer of every target looked up in the inverted query-word table, the candidates counted -- with nothing
+// behind it.  The table of one assay chunk sits in LDS as 16-bit bucket sizes (4^k entries: 32 KB at k = 7); one
+// wavefront per target, a lane takes 16 consecutive positions (two packed dwords), the next target's words are in flight
+// while this one's are looked up.  tnt_seed_scan_only() times it with events on the context's stream; bench.py reports
+// it as roofline_seed.scan_only (source: measured), profiles/ holds the rocprofv3 summary of the same launch.
+constexpr int SCAN_THREADS = 1024;
+struct ScanOnlyArgs {
+	DbView db;
+	const uint4 *unit_rec; // whole-target work units (as for seed2_kernel)
+	uint32_t unit0, unit1;
+	int word_size;
+	const uint16_t *wt_off; // bucket offsets [4^k + 1] of the chunk
+	unsigned long long *n_candidates;
+};
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_only_kernel(ScanOnlyArgs a)
+{
+	extern __shared__ uint16_t s_cnt[]; // [4^k] candidates per word
+	const uint32_t n_words = 1u << (2 * a.word_size), wmask = n_words - 1u;
+	for (uint32_t w = threadIdx.x; w < n_words; w += SCAN_THREADS) s_cnt[w] = uint16_t(a.wt_off[w + 1] - a.wt_off[w]);
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * SCAN_THREADS + threadIdx.x) >> 6, n_waves = (gridDim.x * SCAN_THREADS) >> 6;
+	unsigned long long mine = 0;
+	auto rec_of = [&](uint32_t u) __attribute__((always_inline)) { return a.unit_rec[u < a.unit1 ? u : a.unit1]; }; // (a zero record behind the last)
+	uint32_t unit = a.unit0 + wave;
+	uint4 rec = rec_of(unit);
+	for (; unit < a.unit1; unit += n_waves) {
+		const uint4 next = rec_of(unit + n_waves);
+		const uint32_t len = rec.y;
+		const uint32_t *pk = a.db.packed + (uint64_t(rec.z) | (uint64_t(rec.w) << 32));
+		const uint32_t npos = len >= uint32_t(a.word_size) ? len - uint32_t(a.word_size) + 1u : 0u;
+		for (uint32_t base = 0; base < npos; base += 64 * 16) {
+			const uint32_t p0 = base + uint32_t(lane) * 16u;
+			if (p0 < npos) {
+				const unsigned long long v = (unsigned long long)pk[p0 >> 4] | ((unsigned long long)pk[(p0 >> 4) + 1] << 32); // (the rows end in slack words)
+				uint32_t sum = 0;
+#pragma unroll
+				for (int q = 0; q < 16; q++) {
+					const uint32_t c = s_cnt[uint32_t(v >> (2 * q)) & wmask];
+					sum += (p0 + uint32_t(q) < npos) ? c : 0u;
+				}
+				mine += sum;
+			}
+		}
+		rec = next;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) mine += (unsigned long long)__shfl_xor((long long)mine, o);
+	if (lane == 0 && mine) atomicAdd(a.n_candidates, mine);
+}
+
 } // namespace tnt
 #endif

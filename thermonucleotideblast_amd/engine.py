@@ -98,6 +98,7 @@ def load_library():
     lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
     lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
     lib.tnt_db_skip_targets.argtypes = [C.c_void_p, C.c_void_p, P(C.c_uint8), C.c_size_t]
+    lib.tnt_seed_scan_only.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_float), P(C.c_uint64)]
     lib.tnt_search_collect_compact.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t), P(C.c_size_t)]
     lib.tnt_device_count.restype = C.c_int
     lib.tnt_gang_create.argtypes = [P(C.c_void_p), C.c_int, P(C.c_void_p)]
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "tnt_last_timing", "tnt_seeds", "tnt_first_cull", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_info", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
-    "tnt_search_collect_compact", "tnt_device_count", "tnt_gang_create", "tnt_gang_destroy", "tnt_gang_transport", "tnt_gang_last_error", "tnt_gang_gather",
+    "tnt_seed_scan_only", "tnt_search_collect_compact", "tnt_device_count", "tnt_gang_create", "tnt_gang_destroy", "tnt_gang_transport", "tnt_gang_last_error", "tnt_gang_gather",
 ]
 
 
@@ -314,6 +315,12 @@ class Engine:
         out = (abi.tnt_hit * n.value)()
         C.memmove(out, view, C.sizeof(abi.tnt_hit) * n.value)
         return out
+
+    def scan_only(self, batch, repeats=5):
+        """(ms per pass, raw candidates per pass) of the seed stage's scan on its own (tnt_seed_scan_only)."""
+        ms, n = C.c_float(), C.c_uint64()
+        self._check(self.lib.tnt_seed_scan_only(self._h, batch._h, repeats, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def collect_device(self):
         """Collects the enqueued search and leaves the hit records on the device (tnt_search_collect with hits == NULL);
