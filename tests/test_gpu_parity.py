@@ -516,29 +516,77 @@ def test_g5_search_golden(Engine, cfg):
     e.close()
 
 
-def test_g8_bind_cache_conflict_is_refused(Engine, oracle, monkeypatch):
-    """An assay set in which the reference's per-target BindCache would hand one caller's evaluation to another with a
-    different strand concentration / threshold set (G8) is refused with a message, never searched silently differently;
-    with TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 every use is bound on its own (the oracle's semantics)."""
-    from thermonucleotideblast_amd.engine import TntError
+def test_g8_bind_cache_semantics(Engine, oracle, monkeypatch):
+    """Row a6 where it changes results (golden G8, reference-generated): one oligo as a primer of one assay and as the
+    TaqMan probe of another.  The reference's per-target BindCache hands the first evaluation of an (oligo string, window)
+    to every later caller, whatever its strand concentration and thresholds; the library replays that (cache replay,
+    tnt_pair.hip.h): its hits equal the reference's.  With TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 every use is bound on its
+    own (the oracle with the memo off)."""
     g = gu.load("g8_bindcache.json.gz")
     ex = synth.expand_assays([synth.Assay(a[0], a[1], a[2], a[3]) for a in g["assays"]])
     opt = gu.options_from(g["options"])
-    monkeypatch.delenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", raising=False)
-    with pytest.raises(TntError, match="bind cache"):
-        Engine(opt, ex)
-    monkeypatch.setenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", "1")
     codes, offsets = gu.pack_targets(g["targets"])
+    monkeypatch.delenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", raising=False)
     e = Engine(opt, ex)
     db = e.pack(codes, offsets)
-    assert tc.sorted_hit_keys(e.search(db)) == tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets, bind_cache=False))
+    got = [list(k) for k in tc.sorted_hit_keys(e.search(db))]
+    assert got == g["hits"] and len(got) == 113
+    assert got == [list(k) for k in tc.sorted_hit_keys(e.search(db))]  # (the replay's buffers are reused)
+    assert got == [list(k) for k in tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets))]
     db.close()
     e.close()
-    # the same oligo as a primer and as a stand-alone probe is fine: hybrid() binds with a cache of its own
-    monkeypatch.delenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", raising=False)
-    a = g["assays"]
-    ok = synth.expand_assays([synth.Assay(a[0][0], a[0][1], a[0][2], None), synth.Assay("probe", None, None, a[0][1])])
-    e = Engine(opt, ok)
+    monkeypatch.setenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS", "1")
+    e = Engine(opt, ex)
+    db = e.pack(codes, offsets)
+    uncached = tc.sorted_hit_keys(e.search(db))
+    assert uncached == tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets, bind_cache=False)) and len(uncached) == 135
+    db.close()
+    e.close()
+
+
+def _shared_oligo_workload(kind, seed):
+    """Assay sets in which one oligo string is evaluated under two strand concentrations / threshold sets on one target
+    (the inputs of tests/test_oracle_vs_reference.py::test_search_with_bind_cache_conflicts, oracle == reference there)."""
+    if kind == "taqman":  # the probe of a TaqMan assay is the forward primer of a PCR assay listed behind / in front of it
+        wl = synth.make_workload(3, n_targets=300, n_assays=12, seed=seed)
+        extra = [synth.Assay("swap%d" % i, a.probe, a.reverse, None) for i, a in enumerate(wl.assays)]
+        assays = [x for i, pair in enumerate(zip(wl.assays, extra)) for x in (pair if i % 2 == 0 else pair[::-1])]
+        wl.options.min_primer_tm, wl.options.min_probe_tm = 45.0, 30.0
+        wl.options.primer_clamp, wl.options.probe_clamp_5 = 2, 1
+    elif kind == "degenerate":  # an explicit expansion listed next to its degenerate parent: another Ct divisor
+        wl = synth.make_workload(4, n_targets=200, n_assays=20, seed=seed)
+        assays = []
+        for i, a in enumerate(wl.assays):
+            assays.append(a)
+            if synth.degeneracy(a.forward) > 1 or synth.degeneracy(a.reverse) > 1:
+                assays.append(synth.Assay("expl%d" % i, synth.expand_oligo(a.forward)[0], synth.expand_oligo(a.reverse)[-1], None))
+    else:  # padlock: the upstream arm of one assay is the downstream arm of the next (5' clamp against 3' clamp)
+        wl = synth.make_workload(5, n_targets=200, n_assays=20, seed=seed)
+        pads = [a for a in wl.assays if a.forward and a.reverse]
+        assays = list(wl.assays) + [synth.Assay("swap%d" % i, a.reverse, a.forward, None) for i, a in enumerate(pads)]
+        wl.options.probe_clamp_5, wl.options.probe_clamp_3 = 3, 1
+    return wl, synth.expand_assays(assays)
+
+
+@pytest.mark.parametrize("kind,seed", [("taqman", 61), ("taqman", 62), ("degenerate", 63), ("padlock", 64), ("taqman", 65)])
+def test_shared_oligos_across_classes_follow_the_bind_cache(Engine, oracle, kind, seed):
+    """Row a6: searches of assay sets whose results hang on the reference's BindCache == the oracle (== the reference,
+    CPU suite), through the cache replay; the other assays of the same context go the ordinary way."""
+    wl, ex = _shared_oligo_workload(kind, seed)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, ex, wl.codes, wl.offsets))
+    e = Engine(wl.options, ex)
+    db = e.pack(wl.codes, wl.offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    assert got == want and len(want) > 0
+    # the same in two batches of targets (the memo is per target)
+    half = wl.n_targets // 2
+    parts = []
+    for lo, hi in ((0, half), (half, wl.n_targets)):
+        d = e.pack(wl.codes[int(wl.offsets[lo]):int(wl.offsets[hi])], wl.offsets[lo:hi + 1] - wl.offsets[lo], first_seq_index=lo)
+        parts += list(tc.sorted_hit_keys(e.search(d)))
+        d.close()
+    assert sorted(parts) == want
+    db.close()
     e.close()
 
 

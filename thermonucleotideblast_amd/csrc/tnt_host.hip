@@ -51,6 +51,8 @@ size_t long_sort_bytes(size_t n);
 size_t long_cull_bytes(size_t n, size_t n_lists_max);
 hipError_t long_first_cull(const Item *items, const uint32_t *bucket, uint32_t n, const AssayDev *assays, uint32_t n_assays, int max_len, int single_primer,
                            Item *kept, uint32_t *n_kept, Group **groups, uint32_t *n_groups, DeviceArena &arena, hipStream_t stream);
+hipError_t sort_pairs_u64_u32(void *tmp, size_t &tmp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                              size_t n, hipStream_t stream);
 hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *target_rank, const AssayDev *assays, uint32_t n_assays,
                            uint32_t n_buckets, Item *items, uint32_t *bucket, DeviceArena &arena, hipStream_t stream);
 }
@@ -643,6 +645,17 @@ struct tnt_ctx {
 	PinnedBuf<int32_t> pin_result;
 	PinnedBuf<BoundRec> pin_pool;        // the bound oligos of all bind passes of a long-target search
 	PinnedBuf<uint8_t> pin_blob;         // tnt_search_collect_compact: the hits of the last search in wire form
+	// Row a6: assays that hold an oligo used under two strand concentrations / threshold sets go through the replay of the
+	// reference's per-target BindCache (tnt_pair.hip.h, cache_replay_kernel) instead of the ordinary pairing
+	bool cache_replay = false;
+	uint32_t n_cache_assays = 0;
+	DevBuf<unsigned long long> ck_in, ck_out; // sort keys of their groups (target << 32 | assay)
+	DevBuf<uint32_t> cv_in, cv_out, c_origin, c_counts; // c_counts: {groups, items, pool records}
+	DevBuf<ConflictRec> c_recs;
+	DevBuf<Item> c_items;
+	DevBuf<BindFull> c_full;
+	DevBuf<BoundRec> c_pool;
+	DevBuf<uint8_t> c_sort_tmp;
 	bool compact_in_search = false;      // the compaction kernels run behind the pair stage of every search (set by the first request for the compact form)
 	size_t blob_cap_hits = 0;            // records the blob of the pending search was sized for (0: not packed with the search)
 	size_t blob_hits = 0, blob_bytes = 0; // what ctx->hit_blob holds: valid while blob_hits == dev_hits_n and blob_bytes != 0
@@ -1439,17 +1452,25 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		// early, bind_oligo.cpp:600-612,750-803).  Which evaluation comes first depends on the whole bind / cull history of
 		// the target; that is not reproduced here, so an assay set in which it could matter is refused, loudly.
 		std::map<int32_t, std::string> cls; // oligo -> (strand concentration, thresholds) as bytes
+		std::vector<char> shared(c->oligos.size(), 0);
 		for (const Slot &sl : c->h_slots) {
 			if (sl.oligo < 0) continue;
 			if (c->h_assays[size_t(sl.assay)].kind == 2) continue; // hybrid() binds with a cache of its own (probe_search.cpp:96,166)
 			std::string key(reinterpret_cast<const char *>(&sl.log_ct), sizeof(sl.log_ct));
 			key.append(reinterpret_cast<const char *>(&th[size_t(sl.thresh)]), sizeof(Thresh));
 			const auto it = cls.emplace(sl.oligo, key);
-			if (!it.second && it.first->second != key && !getenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS"))
-				FAIL(TNT_E_UNSUPPORTED, "oligo " + c->oligos[size_t(sl.oligo)] + " is used under two strand concentrations or threshold sets: the reference's "
-				                        "per-target bind cache would reuse the first evaluation for the second (tntblast.h:247-270), which this "
-				                        "library does not reproduce (TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 binds every use on its own)");
+			if (!it.second && it.first->second != key) shared[size_t(sl.oligo)] = 1;
 		}
+		// Such a context is searched with the memo's semantics since round 4: the assays that hold a shared oligo are paired by
+		// the cache replay (first evaluation of an (oligo string, window) per target and strand wins, later callers apply their
+		// thresholds to it).  TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 keeps the uncached computation (every use on its own).
+		if (!getenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS"))
+			for (const Slot &sl : c->h_slots)
+				if (sl.oligo >= 0 && shared[size_t(sl.oligo)] && c->h_assays[size_t(sl.assay)].kind != 2 && !c->h_assays[size_t(sl.assay)].cache_replay) {
+					c->h_assays[size_t(sl.assay)].cache_replay = 1;
+					c->n_cache_assays++;
+					c->cache_replay = true;
+				}
 	}
 	// the round-3 seed kernel serves every search but those that mark shared oligos in the seed kernel
 	c->seed2 = !c->dedupe && !getenv("TNT_MI355X_SEED_V2");
@@ -2169,6 +2190,73 @@ int tnt_db_ingest_timing(const tnt_db *db, tnt_ingest_timing *out)
 	return TNT_OK;
 }
 
+// Row a6 behind the ordinary stages of a batch: the groups of the assays that share an oligo across strand concentrations /
+// threshold sets are collected, every one of their items is bound in full by the unit-level kernel instance, the groups are
+// sorted by (target, assay) and replayed target by target with the reference's BindCache semantics (tnt_pair.hip.h).
+static int ensure_cache_buffers(tnt_ctx *c, size_t n_units, size_t &cap_groups, size_t &cap_items, size_t &tmp_bytes)
+{
+	cap_groups = std::max<size_t>(1, n_units * size_t(c->n_cache_assays)); // every (target, flagged assay) at most once
+	cap_items = std::min<size_t>(size_t(1) << 24, std::max<size_t>(size_t(1) << 18, 16 * cap_groups));
+	if (c->ck_in.n < cap_groups) {
+		HIP_TRY(c->ck_in.alloc(cap_groups), c->err);
+		HIP_TRY(c->ck_out.alloc(cap_groups), c->err);
+		HIP_TRY(c->cv_in.alloc(cap_groups), c->err);
+		HIP_TRY(c->cv_out.alloc(cap_groups), c->err);
+		HIP_TRY(c->c_recs.alloc(cap_groups), c->err);
+	}
+	if (c->c_items.n < cap_items) {
+		HIP_TRY(c->c_items.alloc(cap_items), c->err);
+		HIP_TRY(c->c_origin.alloc(cap_items), c->err);
+		HIP_TRY(c->c_full.alloc(cap_items), c->err);
+		HIP_TRY(c->c_pool.alloc(cap_items), c->err);
+	}
+	if (!c->c_counts.p) HIP_TRY(c->c_counts.alloc(4), c->err);
+	tmp_bytes = 0;
+	HIP_TRY(sort_pairs_u64_u32(nullptr, tmp_bytes, c->ck_in.p, c->ck_out.p, c->cv_in.p, c->cv_out.p, cap_groups, c->stream), c->err);
+	if (c->c_sort_tmp.n < tmp_bytes) HIP_TRY(c->c_sort_tmp.alloc(tmp_bytes + tmp_bytes / 4 + 256), c->err);
+	return TNT_OK;
+}
+
+static int enqueue_cache_replay(tnt_ctx *c, PairArgs p, bool direct, size_t cap_groups, size_t cap_items, size_t tmp_bytes, uint32_t *cnt)
+{
+	HIP_TRY(hipMemsetAsync(c->ck_in.p, 0xFF, cap_groups * sizeof(unsigned long long), c->stream), c->err);
+	HIP_TRY(hipMemsetAsync(c->c_counts.p, 0, 4 * sizeof(uint32_t), c->stream), c->err);
+	CacheCollectArgs k;
+	memset(&k, 0, sizeof(k));
+	k.groups = p.groups;
+	if (direct) k.seg_counts = c->S().region_counts.p + 1, k.seg_count_stride = 2, k.n_segs = c->batch_regions, k.seg_size = uint32_t(c->group_cap / c->batch_regions);
+	else k.seg_counts = cnt + C_GROUPS, k.seg_count_stride = SHARD_STRIDE, k.n_segs = N_SHARD, k.seg_size = uint32_t(c->group_cap / N_SHARD);
+	k.assays = p.assays;
+	k.items = p.items;
+	k.keys = c->ck_in.p, k.vals = c->cv_in.p, k.recs = c->c_recs.p;
+	k.cap_groups = uint32_t(cap_groups);
+	k.n_groups = c->c_counts.p;
+	k.citems = c->c_items.p, k.corigin = c->c_origin.p;
+	k.cap_items = uint32_t(cap_items);
+	k.n_items = c->c_counts.p + 1;
+	k.err = p.err;
+	hipLaunchKernelGGL(cache_collect_kernel, dim3(std::min<uint32_t>(k.n_segs, 4096u)), dim3(256), 0, c->stream, k);
+	// every collected item in full: status, Tm, dH, dS, dG, anchors, counts, footprint, text -- whatever its own thresholds say
+	BindArgs b = bind_args(c, p.db);
+	b.items = c->c_items.p;
+	b.n_items = uint32_t(cap_items);
+	b.n_items_dev = c->c_counts.p + 1;
+	b.index = nullptr;
+	b.groups = nullptr;
+	b.full = c->c_full.p;
+	launch_bind(c, b, c->bind_blocks, 0);
+	HIP_TRY(sort_pairs_u64_u32(c->c_sort_tmp.p, tmp_bytes, c->ck_in.p, c->ck_out.p, c->cv_in.p, c->cv_out.p, cap_groups, c->stream), c->err);
+	CacheReplayArgs r;
+	r.p = p;
+	r.p.slots = c->slots.p, r.p.thresh = c->thresh.p;
+	r.p.citems = c->c_items.p, r.p.cfull = c->c_full.p, r.p.corigin = c->c_origin.p;
+	r.p.cpool = c->c_pool.p, r.p.cpool_cap = uint32_t(cap_items), r.p.cpool_count = c->c_counts.p + 2;
+	r.keys = c->ck_out.p, r.vals = c->cv_out.p, r.recs = c->c_recs.p;
+	r.cap_groups = uint32_t(cap_groups);
+	hipLaunchKernelGGL(cache_replay_kernel, dim3(uint32_t(std::min<size_t>(8192, (cap_groups + PAIR_THREADS - 1) / PAIR_THREADS))), dim3(PAIR_THREADS), 0, c->stream, r);
+	return TNT_OK;
+}
+
 // One internal batch: seed -> bind -> filter -> pair.  `pipelined`: the batch works on buffer set c->cur; its seed stage runs
 // on the seed stream (behind the pair stage of the batch that used the set before), everything else on the context stream
 // (behind its seed stage), so that the seed stage of the next batch -- issue-bound scalar / LDS work with long memory waits
@@ -2370,9 +2458,19 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		const double expect = double(db->max_unit_len) * double(max_ent) / double(size_t(1) << (2 * c->opt.hash_word_size));
 		p.big_enabled = (c->force_big || expect > 16.0) ? 1 : 0;
 	}
+	size_t cache_groups = 0, cache_items = 0, cache_tmp = 0;
+	if (c->cache_replay) { // (the pair kernels leave the groups of the flagged assays to the replay: p.citems set)
+		const int crc = ensure_cache_buffers(c, u1 - u0, cache_groups, cache_items, cache_tmp);
+		if (crc) return crc;
+		p.citems = c->c_items.p;
+	}
 	hipLaunchKernelGGL(pair_kernel<PAIR_SMALL>, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
 	hipLaunchKernelGGL(pair_kernel<PAIR_MAX>, dim3(2048), dim3(PAIR_THREADS), 0, c->stream, p);
 	if (p.big_enabled) hipLaunchKernelGGL(pair_kernel<PAIR_BIG>, dim3(64), dim3(PAIR_THREADS), 0, c->stream, p);
+	if (c->cache_replay) {
+		const int crc = enqueue_cache_replay(c, p, direct, cache_groups, cache_items, cache_tmp, cnt);
+		if (crc) return crc;
+	}
 	hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, c->stream, cnt, gcnt);
 	HIP_TRY(hipEventRecord(ev[3], c->stream), c->err);
 	if (pipelined) {
@@ -2538,7 +2636,12 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	if (ctx) ctx->dev_hits_valid = false;
 	if (!ctx || !db || db->ctx != ctx) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	int rc = ensure_work_buffers(ctx, ctx->lmax, db);
+	if (ctx->cache_replay && !db->h_long_targets.empty()) {
+		ctx->err = "an oligo is used under two strand concentrations or threshold sets (the reference's bind cache decides such assays) and the database holds a "
+		           "target that is seeded in windows: the cache replay pairs whole-target work units only (TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 searches without the memo)";
+		return TNT_E_UNSUPPORTED;
+	}
+	int rc = ensure_work_buffers(ctx, ctx->cache_replay ? std::max(ctx->lmax, ctx->unit_rows) : ctx->lmax, db); // (the replay binds through the unit-level instance)
 	if (rc) return rc;
 	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
 	ctx->events.clear();
@@ -2551,7 +2654,7 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	const size_t n_units = db->n_short_units; // the windows of long targets are handled by search_long_targets
 	// Large searches are cut into several batches on two buffer sets so that the seed stage of one batch runs beside the bind
 	// stage of the batch before it (enqueue_batch); small ones stay one batch on the context stream.
-	const bool pipelined = ctx->pipeline_batches > 1 && n_units >= size_t(ctx->pipeline_batches) * 32768;
+	const bool pipelined = ctx->pipeline_batches > 1 && n_units >= size_t(ctx->pipeline_batches) * 32768 && !ctx->cache_replay;
 	if (pipelined) {
 		tpb = std::min(tpb, (n_units + size_t(ctx->pipeline_batches) - 1) / size_t(ctx->pipeline_batches));
 		rc = ensure_set(ctx, 1);

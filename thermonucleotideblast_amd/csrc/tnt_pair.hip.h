@@ -68,7 +68,24 @@ struct PairArgs {
 	const uint32_t *unit_target;
 	const int32_t *unit_own_lo, *unit_own_hi;
 	int big_enabled;            // the PAIR_BIG instance is launched as well (else a crowded group is an error the host repairs)
+	// Replay of the reference's per-target BindCache (row a6; cache_replay_kernel): the groups of the assays that share an
+	// oligo with another strand concentration / threshold set are paired by pair_group<N, true>, whose bind steps ask
+	// cache_resolve() for every entry in the order the reference evaluates them.
+	const Slot *slots;
+	const Thresh *thresh;
+	const Item *citems;         // the items of those groups, copied side by side ...
+	const BindFull *cfull;      // ... and their full bind records (unit-level kernel instance: every field, whatever the status)
+	uint32_t *corigin;          // per citem: 0xFFFFFFFF = not evaluated yet, else the citem whose evaluation the memo of its key holds
+	BoundRec *cpool;            // bound records as the memo hands them out
+	uint32_t cpool_cap;
+	uint32_t *cpool_count;
 };
+
+// one group of an assay that goes through the cache replay: where its items were copied to
+struct ConflictRec {
+	uint32_t group, cfirst, count, pad;
+};
+constexpr int CACHE_RUN_MAX = 64; // such groups per target (= assays that share an oligo across classes)
 
 enum : uint8_t { MF = 1, MR = 2, MP = 4, MPLUS = 8, MMINUS = 16, MVALID = 32 }; // oligo_info, tntblast.h:147-154
 
@@ -295,7 +312,8 @@ template <int N> TNT_HD void bind_step(ListT<N> &l, uint8_t want, const BoundRec
 }
 
 struct PairArgs;
-template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G);
+struct ConflictRec;
+template <int N, bool CACHED = false> TNT_HD void pair_group(const PairArgs &a, const Group G, const ConflictRec *run = nullptr, int n_run = 0, uint32_t cfirst = 0);
 
 TNT_HD inline Hit *alloc_hit(const PairArgs &a)
 {
@@ -473,6 +491,77 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 	}
 }
 
+// One request to the reference's BindCache (tntblast.h:247-324; bind_oligo.cpp:508-512 miss, :750-803 / :396-428 hit).  The
+// entry stands for citem ci = -2 - rec.  Its key is (oligo string, window, strand); the memo of a key is the FIRST
+// evaluation of it on this target -- whatever strand concentration and threshold set asked --, holding what that caller's
+// threshold cascade had looked at when it stopped (the rest zero / empty).  A later request applies ITS thresholds to the
+// memo.  `run` = the target's groups of such assays up to and including the current one, in assay order: the citems
+// evaluated so far are found there (corigin != 0xFFFFFFFF).
+TNT_HD inline void cache_resolve(const PairArgs &a, Entry &e, const ConflictRec *run, int n_run)
+{
+	if (e.rec >= -1) return;
+	const uint32_t ci = uint32_t(-2 - e.rec);
+	const Item it = a.citems[ci];
+	const Slot sl = a.slots[it.info >> ITEM_SLOT_SHIFT];
+	const BindFull &own = a.cfull[ci];
+	uint32_t origin = ci;
+	for (int g = 0; g < n_run && origin == ci; g++)
+		for (uint32_t x = run[g].cfirst; x < run[g].cfirst + run[g].count; x++) {
+			if (x == ci || a.corigin[x] == 0xFFFFFFFFu) continue;
+			const Item ix = a.citems[x];
+			if ((ix.info ^ it.info) & ITEM_MINUS) continue; // one memo per strand (tntblast_local.cpp:371-372)
+			if (a.slots[ix.info >> ITEM_SLOT_SHIFT].oligo != sl.oligo) continue;
+			const BindFull &fx = a.cfull[x];
+			if (fx.target_start != own.target_start || fx.target_stop != own.target_stop) continue;
+			origin = a.corigin[x];
+			break;
+		}
+	a.corigin[ci] = origin;
+	const BindFull &U = a.cfull[origin];
+	const Thresh th = a.thresh[sl.thresh];
+	int status = own.status;
+	const int s1 = U.status; // where the first caller's cascade stopped: 0 bound, 1 Tm, 2 dG, 3 / 4 anchors, 5 mismatches, 6 gaps, 7 poly-degenerate, 8 no alignment
+	const bool full = s1 == 0;
+	const float tm = U.tm, dg = s1 == 1 ? 0.0f : U.dg;
+	const int a5 = (full || (s1 >= 3 && s1 <= 7)) ? U.a5 : 0, a3 = (full || (s1 >= 4 && s1 <= 7)) ? U.a3 : 0;
+	const int mm = (full || (s1 >= 5 && s1 <= 7)) ? U.mm : 0, gap = (full || (s1 >= 6 && s1 <= 7)) ? U.gap : 0, poly = (full || s1 == 7) ? U.poly : 0;
+	if (origin != ci) { // a hit: the caller's thresholds against the memo
+		status = 0;
+		if (tm < th.min_tm || tm > th.max_tm) status = 1;
+		else if (dg < th.min_dg || dg > th.max_dg) status = 2;
+		else if (s1 == 8) status = 8;
+		else if (a5 < th.clamp5 || a3 < th.clamp3) status = 3;
+		else if (mm > th.max_mm) status = 5;
+		else if (gap > th.max_gap) status = 6;
+		else if (poly > th.max_poly) status = 7;
+	}
+	if (status != 0) {
+		e.rec = -1;
+		return;
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t at = atomicAdd(a.cpool_count, 1u);
+#else
+	const uint32_t at = __atomic_fetch_add(a.cpool_count, 1u, __ATOMIC_RELAXED);
+#endif
+	if (at >= a.cpool_cap) {
+		TNT_SET_ERR(a.err, ERR_POOL_OVERFLOW);
+		e.rec = -1;
+		return;
+	}
+	BoundRec &r = a.cpool[at];
+	r.loc5 = full ? U.loc5 : 0, r.loc3 = full ? U.loc3 : 0;
+	r.tm = tm, r.dH = full ? U.dH : 0.0f, r.dS = full ? U.dS : 0.0f;
+	r.a5 = a5, r.a3 = a3, r.mm = mm, r.gap = gap;
+	int n = 0;
+	if (full)
+		for (; n < ALIGN_TEXT - 1 && U.text[n]; n++) r.text[n] = U.text[n];
+	r.text[n] = 0;
+	r.text_len = n;
+	e.rec = int32_t(at);
+	e.loc5 = r.loc5, e.loc3 = r.loc3;
+}
+
 // N = PAIR_MAX: the groups of up to PAIR_MAX items (all of them in practice); N = PAIR_BIG: the crowded rest.  The
 // per-lane lists live in scratch memory, so the common instance keeps them small.
 template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(PairArgs a)
@@ -481,6 +570,7 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 	const uint32_t n_active = *a.n_active;
 	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS) {
 		const Group G = a.groups[a.active[gi]];
+		if (a.citems && a.assays[G.assay & GROUP_ASSAY_MASK].cache_replay) continue; // paired by cache_replay_kernel
 		const uint32_t count = G.count & ~GROUP_ALIVE;
 		// every group is paired by the smallest instance that holds it
 		const int fits = count <= uint32_t(PAIR_SMALL) ? PAIR_SMALL : (count <= uint32_t(PAIR_MAX) ? PAIR_MAX : PAIR_BIG);
@@ -492,12 +582,14 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 	}
 }
 
-template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
+// CACHED: the group belongs to an assay that goes through the replay of the reference's BindCache: its items are
+// a.citems[cfirst ...], nothing is known about them until a bind step asks (cache_resolve), records come from a.cpool.
+template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Group G, const ConflictRec *run, int n_run, uint32_t cfirst)
 {
 	const AssayDev A = a.assays[G.assay & GROUP_ASSAY_MASK];
 	const int seq_index = int(a.db.first_seq_index + a.unit_target[G.target]);
 	const int own_lo = a.unit_own_lo[G.target], own_hi = a.unit_own_hi[G.target];
-	const BoundRec *pool = a.pool;
+	const BoundRec *pool = CACHED ? a.cpool : a.pool;
 
 	const uint32_t g_count = G.count & ~GROUP_ALIVE;
 	if (g_count > uint32_t(N)) {
@@ -513,8 +605,8 @@ template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 	bool any_bound = false;
 	unsigned long long order[N];
 	for (int i = 0; i < l.n; i++) {
-		const Item it = a.items[G.first + i];
-		const int32_t res = a.result[G.first + i];
+		const Item it = CACHED ? a.citems[cfirst + uint32_t(i)] : a.items[G.first + i];
+		const int32_t res = CACHED ? -2 - int32_t(cfirst + uint32_t(i)) : a.result[G.first + i];
 		{
 			const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u, wi = it.info & 127u;
 			const bool minus = (it.info & ITEM_MINUS) != 0;
@@ -530,13 +622,13 @@ template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 		}
 		Entry &e = l.e[i];
 		e.tloc = it.tloc;
-		e.rec = res >= 0 ? res : -1;
+		e.rec = CACHED ? res : (res >= 0 ? res : -1);
 		e.loc5 = e.loc3 = 0;
 		const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u;
 		e.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((it.info & ITEM_MINUS) ? MMINUS : MPLUS));
 		if (res >= 0) any_bound = true;
 	}
-	if (!any_bound) return;
+	if (!any_bound && !CACHED) return;
 #if !defined(__HIP_DEVICE_COMPILE__)
 	bool in_order = true; // (the lists of windowed targets arrive in list order: tnt_sort.hip)
 	for (int i = 1; i < l.n && in_order; i++) in_order = order[i - 1] < order[i];
@@ -576,6 +668,9 @@ template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 			const bool minus = minus_first ? (s < 2) : (s >= 2);
 			// a bound entry takes its coordinates from the bind result
 			const uint8_t want = uint8_t((fwd ? MF : MR) | (minus ? MMINUS : MPLUS));
+			if (CACHED) // the entries of this oligo and strand meet the memo in list order (bind_oligo.cpp:476-512)
+				for (int i = 0; i < l.n; i++)
+					if ((l.e[i].mask & want) == want) cache_resolve(a, l.e[i], run, n_run);
 			for (int i = 0; i < l.n; i++)
 				if ((l.e[i].mask & want) == want && l.e[i].rec >= 0) {
 					l.e[i].loc5 = pool[l.e[i].rec].loc5;
@@ -592,6 +687,9 @@ template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 			if (l.n == 0) return;
 			for (int pass = 0; pass < 2; pass++) {
 				const uint8_t want = uint8_t(MP | (pass == 0 ? MMINUS : MPLUS));
+				if (CACHED)
+					for (int i = 0; i < l.n; i++)
+						if ((l.e[i].mask & want) == want) cache_resolve(a, l.e[i], run, n_run);
 				for (int i = 0; i < l.n; i++)
 					if ((l.e[i].mask & want) == want && l.e[i].rec >= 0) {
 						l.e[i].loc5 = pool[l.e[i].rec].loc5;
@@ -676,6 +774,8 @@ template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 	// (bind_oligo.cpp:431-453)
 	Entry lists[4][N];
 	int ln[4] = {0, 0, 0, 0};
+	if (CACHED) // the hash overload evaluates every seed of a list, list after list, in diagonal order (bind_oligo.cpp:124-175)
+		for (int i = 0; i < l.n; i++) cache_resolve(a, l.e[i], run, n_run);
 	for (int i = 0; i < l.n; i++) {
 		Entry e = l.e[i];
 		if (e.rec < 0) continue;
@@ -744,6 +844,94 @@ template <int N> TNT_HD void pair_group(const PairArgs &a, const Group G)
 				copy_text(out->forward_align, bd.text);
 				copy_text(out->reverse_align, bu.text);
 			}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row a6, the reference's per-target BindCache where it changes results: an oligo string used under two strand
+// concentrations / threshold sets among the PCR / padlock assays of a context.  The assays that hold such an oligo are
+// flagged (AssayDev::cache_replay); behind the ordinary stages of a batch
+//   cache_collect_kernel  picks their groups out of the seed kernel's output, copies their items side by side (citems)
+//                         and writes one sort key (target, assay) per group;
+//   the unit-level bind kernel evaluates EVERY citem in full (BindFull: all fields, whatever the status);
+//   a radix sort puts the groups in (target, assay) order;
+//   cache_replay_kernel   walks the groups of a target in assay order, one lane per target, through pair_group<N, true>.
+struct CacheCollectArgs {
+	const Group *groups;
+	const uint32_t *seg_counts; // groups in segment s: seg_counts[s * seg_count_stride]
+	uint32_t seg_count_stride, n_segs, seg_size;
+	const AssayDev *assays;
+	const Item *items;
+	unsigned long long *keys;   // [cap_groups], preset to ~0
+	uint32_t *vals;
+	ConflictRec *recs;
+	uint32_t cap_groups;
+	uint32_t *n_groups;
+	Item *citems;
+	uint32_t *corigin;
+	uint32_t cap_items;
+	uint32_t *n_items;
+	uint32_t *err;
+};
+
+__global__ __launch_bounds__(256) void cache_collect_kernel(CacheCollectArgs a)
+{
+	for (uint32_t s = blockIdx.x; s < a.n_segs; s += gridDim.x) {
+		const uint32_t n = a.seg_counts[size_t(s) * a.seg_count_stride];
+		for (uint32_t i = threadIdx.x; i < n && i < a.seg_size; i += blockDim.x) {
+			const uint32_t gi = s * a.seg_size + i;
+			const Group G = a.groups[gi];
+			const uint32_t assay = G.assay & GROUP_ASSAY_MASK;
+			if (!a.assays[assay].cache_replay) continue;
+			const uint32_t count = G.count & ~GROUP_ALIVE;
+			const uint32_t slot = atomicAdd(a.n_groups, 1u);
+			const uint32_t cf = atomicAdd(a.n_items, count);
+			if (slot >= a.cap_groups || cf + count > a.cap_items) {
+				atomicOr(a.err, ERR_ITEM_OVERFLOW);
+				continue;
+			}
+			a.recs[slot] = ConflictRec{gi, cf, count, 0u};
+			a.keys[slot] = ((unsigned long long)G.target << 32) | assay;
+			a.vals[slot] = slot;
+			for (uint32_t k = 0; k < count; k++) {
+				Item it = a.items[G.first + k];
+				it.info &= ~ITEM_PHASE_B;
+				a.citems[cf + k] = it;
+				a.corigin[cf + k] = 0xFFFFFFFFu;
+			}
+		}
+	}
+}
+
+struct CacheReplayArgs {
+	PairArgs p;
+	const unsigned long long *keys; // sorted; unused slots hold ~0 and come last
+	const uint32_t *vals;
+	const ConflictRec *recs;
+	uint32_t cap_groups;
+};
+
+__global__ __launch_bounds__(PAIR_THREADS) void cache_replay_kernel(CacheReplayArgs a)
+{
+	for (uint32_t i = blockIdx.x * PAIR_THREADS + threadIdx.x; i < a.cap_groups; i += gridDim.x * PAIR_THREADS) {
+		const unsigned long long key = a.keys[i];
+		if (key == ~0ull) continue;
+		if (i > 0 && (a.keys[i - 1] >> 32) == (key >> 32)) continue; // not the first group of its target
+		ConflictRec run[CACHE_RUN_MAX];
+		int n_run = 0;
+		for (uint32_t j = i; j < a.cap_groups && a.keys[j] != ~0ull && (a.keys[j] >> 32) == (key >> 32); j++) {
+			if (n_run == CACHE_RUN_MAX) {
+				atomicOr(a.p.err, ERR_LIST_OVERFLOW);
+				break;
+			}
+			const ConflictRec r = a.recs[a.vals[j]];
+			run[n_run++] = r;
+			if (r.count > uint32_t(PAIR_MAX)) {
+				atomicOr(a.p.err, ERR_LIST_OVERFLOW);
+				continue;
+			}
+			pair_group<PAIR_MAX, true>(a.p, a.p.groups[r.group], run, n_run, r.cfirst);
+		}
 	}
 }
 

@@ -264,4 +264,12 @@ hipError_t long_first_cull(const Item *items, const uint32_t *bucket, uint32_t n
 	return hipGetLastError();
 }
 
+// 64-bit keys with 32-bit values, ascending (the groups of the cache replay in (target, assay) order, tnt_pair.hip.h).  With
+// tmp == nullptr only the scratch size is reported.
+hipError_t sort_pairs_u64_u32(void *tmp, size_t &tmp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                              size_t n, hipStream_t stream)
+{
+	return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, 64u, stream);
+}
+
 } // namespace tnt
