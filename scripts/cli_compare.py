@@ -63,6 +63,9 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("long_probes", "probe", 60, 6, 31, ["-E", "45"]),
     ("long_padlock_arms", "padlock", 60, 6, 33, ["-A", "PADLOCK", "-E", "45"]),
     ("long_primer", "pcr", 60, 6, 34, ["-e", "45"]),
+    # row a6: the probe of every TaqMan assay is also the forward primer of a PCR assay listed next to it -- one oligo string under
+    # two strand concentrations / threshold sets: the reference's per-target BindCache decides (the library replays it)
+    ("shared_oligos", 3, 250, 10, 35, ["-e", "45", "-E", "30", "--primer-clamp", "2", "--probe-clamp5", "1"]),
 ]
 
 LONG_RECORDS = {"long_target": 150, "fragment_default": 620, "fragment_small": 64}
@@ -114,9 +117,13 @@ def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False, name=None):
                 f.write(b"@seq%d synthetic read\n" % t + seq + b"\n+\n" + bytes(q) + b"\n")
         else:
             f.write(synth.to_fasta(wl.codes, offsets))
+    assays = list(wl.assays)
+    if name == "shared_oligos":
+        extra = [synth.Assay("swap%d" % i, a.probe, a.reverse, None) for i, a in enumerate(wl.assays)]
+        assays = [x for i, pair in enumerate(zip(wl.assays, extra)) for x in (pair if i % 2 == 0 else pair[::-1])]
     with open(os.path.join(d, "assays.txt"), "w") as f:
         f.write("# name forward reverse [probe]   (tntblast assay file)\n")
-        for a in wl.assays:
+        for a in assays:
             cols = [a.name] + [x for x in (a.forward, a.reverse, a.probe) if x]
             f.write("\t".join(cols) + "\n")
 

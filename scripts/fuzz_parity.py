@@ -15,6 +15,7 @@ import longwl  # noqa: E402
 import tntcheck as tc  # noqa: E402
 from thermonucleotideblast_amd import abi, synth  # noqa: E402
 
+SHARED_FRACTION = float(os.environ.get("FUZZ_SHARED", "0.15"))  # share of the cases whose assay list uses an oligo under two classes (row a6)
 LONG_FRACTION = float(os.environ.get("FUZZ_LONG", "0"))  # share of the cases that use oligos of 65..128 bases (tests/longwl.py)
 
 
@@ -102,6 +103,33 @@ def random_case(rng, case, max_code=18, dangle=True):
     return cfg, wl, codes, offsets
 
 
+def share_oligos(case, wl, offsets):
+    """Row a6: some assays get a sibling that uses one of their oligos under another strand concentration / threshold set
+    (the probe as a primer, the same pair at another Ct divisor, padlock arms swapped) -- the reference's per-target
+    BindCache then decides, and the library's cache replay has to follow it.  Own random stream; whole-target work units
+    only (the replay does not pair windowed targets)."""
+    rng = np.random.default_rng([case, 4243])
+    if rng.random() >= SHARED_FRACTION or int(np.diff(offsets.astype(np.int64)).max(initial=0)) > 20000 or wl.options.hash_word_size < 6:
+        return False
+    out, did = [], 0
+    for e in wl.expanded:
+        sib = None
+        if e.forward and e.reverse and rng.random() < 0.5:
+            r = rng.random()
+            if e.probe and r < 0.5:
+                sib = synth.ExpandedAssay(e.id, 0, e.probe, e.reverse, None, 1, e.reverse_degen, 1)
+            elif r < 0.75:
+                sib = synth.ExpandedAssay(e.id, 0, e.forward, e.reverse, e.probe, e.forward_degen * 2, e.reverse_degen, e.probe_degen)
+            else:
+                sib = synth.ExpandedAssay(e.id, 0, e.reverse, e.forward, None, e.reverse_degen, e.forward_degen, 1)
+        for x in ((sib, e) if (sib is not None and rng.random() < 0.5) else (e, sib)):
+            if x is not None:
+                out.append(synth.ExpandedAssay(x.id, did, x.forward, x.reverse, x.probe, x.forward_degen, x.reverse_degen, x.probe_degen))
+                did += 1
+    wl.expanded = out
+    return True
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -110,12 +138,14 @@ def main():
     ora = tc.OracleImpl()
     bad = 0
     limited = 0
+    shared = 0
     t0 = time.time()
     total_hits = 0
     for case in range(n_cases):
         cfg, wl, codes, offsets = random_case(rng, case)
         if only is not None and case != only:
             continue
+        shared += 1 if share_oligos(case, wl, offsets) else 0
         t_case = time.time()
         if case and case % 50 == 0:  # (progress, flushed: a run cut short still tells how far it got)
             print("... %d cases, %d hits compared, %d differ, %.0f s" % (case, total_hits, bad, time.time() - t0), flush=True)
@@ -160,7 +190,8 @@ def main():
                     pickle.dump({"options": {n: getattr(wl.options, n) for n, _ in abi.tnt_options._fields_}, "expanded": [(e.id, e.degen_id, e.forward, e.reverse, e.probe, e.forward_degen, e.reverse_degen, e.probe_degen) for e in wl.expanded],
                                  "codes": codes, "offsets": offsets, "only_hip": list(sg - sw), "only_oracle": list(sw - sg)},
                                 open(os.path.join(ROOT, "gpurun_out", "fuzz_case.pkl"), "wb"))
-    print("%d cases, %d hits compared, %d differ, %d refused at the seed-list limit, %.0f s" % (n_cases, total_hits, bad, limited, time.time() - t0))
+    print("%d cases (%d with an oligo shared across classes), %d hits compared, %d differ, %d refused at the seed-list limit, %.0f s" % (
+        n_cases, shared, total_hits, bad, limited, time.time() - t0))
     sys.exit(1 if bad else 0)
 
 
