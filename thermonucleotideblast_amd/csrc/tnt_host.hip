@@ -2318,8 +2318,12 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	const bool direct = c->seed2 && !seeds_only && db->h_word_off[db->n_targets] < (uint64_t(1) << 32);
 	c->batch_direct = direct;
 	if (direct) {
-		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * 4, tnt_ctx::MAX_REGIONS / S2_WAVES)));
-		const uint32_t regions = blocks * S2_WAVES;
+		// the instance with the chunk's bucket offsets in LDS (hash words of up to 7 bases): one 1024-thread workgroup per CU;
+		// else four 256-thread workgroups per CU that read them through L1 / L2 -- 16 wavefronts per CU either way
+		const bool ltab = c->opt.hash_word_size <= 7 && !getenv("TNT_MI355X_SEED_GLOBAL_TABLE");
+		const size_t S2_WAVES = size_t(s2_waves(ltab));
+		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * (ltab ? 1 : 4), tnt_ctx::MAX_REGIONS / S2_WAVES)));
+		const uint32_t regions = blocks * uint32_t(S2_WAVES);
 		c->batch_regions = regions;
 		HIP_TRY(hipMemsetAsync(c->S().region_counts.p, 0, sizeof(uint32_t) * 2 * regions, seed_stream), c->err);
 		HIP_TRY(hipMemsetAsync(c->S().q_state.p, 0, sizeof(uint32_t) * size_t(regions) * MAX_BUCKETS * 2, seed_stream), c->err);
@@ -2362,8 +2366,10 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 				if (c->h_assays[ai].kind == 0 && c->h_assays[ai].has_probe) q.chunk_has_probe = 1;
 			q.last_chunk = ch + 2 == c->chunk_begin.size() ? 1 : 0;
 			// (an instance compiled for the default word size -W 7, one that takes it at run time)
-			if (q.word_size == 7) hipLaunchKernelGGL(seed2_kernel<7>, dim3(blocks), dim3(S2_THREADS), 0, seed_stream, q);
-			else hipLaunchKernelGGL(seed2_kernel<0>, dim3(blocks), dim3(S2_THREADS), 0, seed_stream, q);
+			if (q.word_size == 7 && ltab) hipLaunchKernelGGL((seed2_kernel<7, true>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
+			else if (q.word_size == 7) hipLaunchKernelGGL((seed2_kernel<7, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
+			else if (ltab) hipLaunchKernelGGL((seed2_kernel<0, true>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
+			else hipLaunchKernelGGL((seed2_kernel<0, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
 		}
 	}
 	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));

@@ -37,8 +37,13 @@
 
 namespace tnt {
 
-constexpr int S2_WAVES = 4;            // wavefronts (= targets in flight) per workgroup
-constexpr int S2_THREADS = 64 * S2_WAVES;
+// wavefronts (= targets in flight) per workgroup.  LTAB (round 4): the chunk's bucket offsets sit in LDS (32 KB at k = 7, staged
+// once per launch) and ONE 1024-thread workgroup per CU shares them -- the scan's sixteen gathers per lane and sweep become LDS
+// reads (the scan on its own: 0.28 ms per pass over config 2 against 1.0 ms inside the kernel with the table behind L1 / L2);
+// the same 16 wavefronts per CU fit next to the table because two per-wavefront arrays share their space with others that are
+// dead while they are in use (the target's words with the extreme keys, the emission's scratch words with the candidate list).
+constexpr int s2_waves(bool ltab) { return ltab ? 16 : 4; }
+constexpr int S2_TAB_WORDS = (1 << 14) + 2; // bucket offsets of a chunk for hash words of up to 7 bases
 constexpr int S2_CAP = 512;            // seeds of one target x one assay chunk held in LDS
 constexpr int S2_ASSAYS = 128;         // assays per chunk (7-bit local index in the key)
 constexpr int S2_SWEEP = 16;           // positions per lane and sweep
@@ -125,17 +130,20 @@ template <int WS> __device__ __forceinline__ bool s2_first_packed(uint32_t W0, u
 	return ((r_lo & b_lo) | (r_hi & b_hi)) == 0u;
 }
 
-template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(Seed2Args a)
+template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), LTAB ? 1 : 4) void seed2_kernel(Seed2Args a)
 {
+	constexpr int S2_WAVES = s2_waves(LTAB), S2_THREADS = 64 * S2_WAVES;
+	static_assert(S2_ASSAYS * 4 >= S2_TGT_WORDS + 4 && S2_CAP >= 3 * MAX_BUCKETS, "the shared arrays hold their lodgers");
 	__shared__ uint32_t s_raw[S2_WAVES][S2_CAP];      // kept seeds (keys) as the dense pass finds them
-	__shared__ uint32_t s_srt[S2_WAVES][S2_CAP];      // candidates of the scan, then the keys grouped by assay
-	__shared__ uint32_t s_tgt[S2_WAVES][S2_TGT_WORDS + 4]; // the packed words of the target (targets of up to 2 048 bases)
+	__shared__ uint32_t s_srt[S2_WAVES][S2_CAP];      // candidates of the scan, then the keys grouped by assay (LTAB: the emission's scratch words live here too)
+	__shared__ uint32_t s_tgt[S2_WAVES][LTAB ? 1 : S2_TGT_WORDS + 4]; // the packed words of the target (targets of up to 2 048 bases); LTAB: inside s_ext
 	__shared__ uint16_t s_hist[S2_WAVES][S2_ASSAYS];  // seeds per assay
 	__shared__ uint16_t s_off[S2_WAVES][S2_ASSAYS];   // scatter cursors, then the END of every assay's segment
 	__shared__ __attribute__((aligned(16))) uint32_t s_ext[S2_WAVES][S2_ASSAYS * 4]; // per assay: smallest key of F-, of R-, largest key of F+, of R+
 	__shared__ uint32_t s_agg[S2_WAVES][S2_ASSAYS];   // per assay: successors on the minus strand | on the plus strand << 10 | valid seeds << 20
 	__shared__ uint32_t s_qh[S2_WAVES][MAX_BUCKETS], s_qcur[S2_WAVES][MAX_BUCKETS], s_qend[S2_WAVES][MAX_BUCKETS];
-	__shared__ uint32_t s_qpos[S2_WAVES][MAX_BUCKETS], s_qsplit[S2_WAVES][MAX_BUCKETS], s_qnew[S2_WAVES][MAX_BUCKETS];
+	__shared__ uint32_t s_qtmp[S2_WAVES][LTAB ? 1 : 3 * MAX_BUCKETS]; // per emission round: first slot, end of the open block, the new block (per bucket)
+	__shared__ uint16_t s_tab[LTAB ? S2_TAB_WORDS : 2]; // LTAB: the chunk's bucket offsets [4^k + 1]
 	__shared__ uint8_t s_af[S2_ASSAYS];               // per assay of the chunk: 1 probe / padlock assay (hash-overload lists), 2 PCR with a probe
 	__shared__ uint32_t s_slot[S2_ASSAYS * 3];        // slot_pack of the chunk's slots
 	__shared__ uint32_t s_qbase[MAX_BUCKETS], s_qcap[MAX_BUCKETS];
@@ -147,7 +155,10 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 	auto cold = [&](int k) __attribute__((always_inline)) { return *(lds_vu64 *)(&s_cold[k]); };
 
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	uint32_t *raw = s_raw[wv], *srt = s_srt[wv], *tgt = s_tgt[wv];
+	// LTAB: the target's words are dead once the dense pass is through (the extreme keys are collected behind it), the candidate
+	// list once the valid seeds sit in `raw` (the emission's scratch words are written and read inside one round)
+	uint32_t *raw = s_raw[wv], *srt = s_srt[wv], *tgt = LTAB ? s_ext[wv] : s_tgt[wv];
+	uint32_t *qpos = LTAB ? s_srt[wv] : s_qtmp[wv], *qsplit = qpos + MAX_BUCKETS, *qnew = qpos + 2 * MAX_BUCKETS;
 	uint16_t *hist = s_hist[wv], *off = s_off[wv];
 	uint32_t *ext = s_ext[wv], *agg = s_agg[wv];
 	const uint32_t wmask = (1u << (2 * a.word_size)) - 1u;
@@ -161,6 +172,9 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 	}
 	for (uint32_t i = threadIdx.x; i < n_chunk * 3u; i += S2_THREADS) s_slot[i] = a.slot_pack[a.assay_begin * 3u + i];
 	if (int(threadIdx.x) < a.n_buckets) s_qbase[threadIdx.x] = a.q_base[threadIdx.x], s_qcap[threadIdx.x] = a.q_cap[threadIdx.x];
+	if (LTAB) // the chunk's bucket offsets, as dwords (the table starts on a dword, tnt_host.hip plan())
+		for (uint32_t i = threadIdx.x; i < ((1u << (2 * a.word_size)) + 2u) / 2u; i += S2_THREADS)
+			reinterpret_cast<uint32_t *>(s_tab)[i] = reinterpret_cast<const uint32_t *>(a.wt_off)[i];
 	if (threadIdx.x == 0) {
 		s_cold[COLD_ITEMS] = (unsigned long long)a.items, s_cold[COLD_GROUPS] = (unsigned long long)a.groups, s_cold[COLD_QUEUE] = (unsigned long long)a.queue;
 		s_cold[COLD_Q_COUNT] = (unsigned long long)a.q_count, s_cold[COLD_BIG] = (unsigned long long)a.big_count, s_cold[COLD_ERR] = (unsigned long long)a.err;
@@ -215,6 +229,7 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 		const uint32_t rec_words = rec_cur.z; // first packed word of the target (the host checks that the packed array stays below 2^32 words)
 		// this unit's words -> LDS; the next unit's words and the record behind it -> in flight
 		tgt[lane] = wc0, tgt[lane + 64] = wc1;
+		if (LTAB && lane < 4) tgt[S2_TGT_WORDS + lane] = 0; // (the slack words were the last unit's extreme keys)
 		rec_cur = rec_next;
 		load_words(rec_next, wc0, wc1);
 		rec_next = load_rec(unit + 2 * stride);
@@ -317,7 +332,8 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 #pragma unroll
 				for (int q = 0; q < S2_SWEEP; q++) {
 					const uint32_t w = uint32_t(v >> (2 * q)) & wmask;
-					const uint32_t two = *reinterpret_cast<const u32_a2 *>(a.wt_off + w);
+					typedef __attribute__((address_space(3))) const u32_a2 lds_u32_a2; // (gfx950 reads a dword at a 2-byte boundary of LDS in one instruction)
+					const uint32_t two = LTAB ? *((lds_u32_a2 *)(s_tab + w)) : *reinterpret_cast<const u32_a2 *>(a.wt_off + w);
 					const uint32_t e0 = two & 0xFFFFu, e1 = two >> 16;
 					const uint32_t n = (p0 + q < npos) ? e1 - e0 : 0u;
 					bnd[q] = e0 | (n << 16);
@@ -354,8 +370,8 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 					if (slow_p < slow_end) {
 						const uint32_t wd = slow_p >> 4, shp = (slow_p & 15u) * 2u;
 						const uint32_t w = uint32_t(((unsigned long long)tw(wd) | ((unsigned long long)tw(wd + 1) << 32)) >> shp) & wmask;
-						e0 = uint32_t(a.wt_off[w]) + slow_done;
-						const uint32_t e1 = a.wt_off[w + 1];
+						e0 = uint32_t(LTAB ? s_tab[w] : a.wt_off[w]) + slow_done;
+						const uint32_t e1 = LTAB ? s_tab[w + 1] : a.wt_off[w + 1];
 						cnt = e1 > e0 ? e1 - e0 : 0u;
 					}
 					uint32_t incl = cnt; // inclusive prefix of cnt over the lanes
@@ -648,16 +664,16 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 					if (h) {
 						uint32_t cur = s_qcur[wv][lane];
 						const uint32_t end = s_qend[wv][lane];
-						s_qpos[wv][lane] = cur;
-						s_qsplit[wv][lane] = end;
+						qpos[lane] = cur;
+						qsplit[lane] = end;
 						if (cur + h > end) { // the block is full: the rest of the round goes to a new one
 							const uint32_t at = __hip_atomic_fetch_add((glb_u32 *)cold(COLD_Q_COUNT) + lane * BUCKET_STRIDE, QUEUE_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							if (at + QUEUE_BLOCK > s_qcap[lane]) {
 								__hip_atomic_fetch_or((glb_u32 *)cold(COLD_ERR), ERR_ITEM_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								s_qnew[wv][lane] = ~0u;
+								qnew[lane] = ~0u;
 							} else {
 								const uint32_t nb = s_qbase[lane] + at;
-								s_qnew[wv][lane] = nb;
+								qnew[lane] = nb;
 								s_qend[wv][lane] = nb + QUEUE_BLOCK;
 								cur = nb - (end - cur); // so that cur + h lands h - (end - cur) slots into the new block
 							}
@@ -668,10 +684,10 @@ template <int WS> __global__ __launch_bounds__(S2_THREADS, 4) void seed2_kernel(
 				}
 				wave_sync();
 				if (bucket != ~0u) {
-					uint32_t pos = s_qpos[wv][bucket] + r;
-					const uint32_t split = s_qsplit[wv][bucket];
+					uint32_t pos = qpos[bucket] + r;
+					const uint32_t split = qsplit[bucket];
 					if (pos >= split) {
-						const uint32_t nb = s_qnew[wv][bucket];
+						const uint32_t nb = qnew[bucket];
 						pos = nb == ~0u ? ~0u : nb + (pos - split);
 					}
 					if (pos != ~0u) g_queue[pos] = fat;
