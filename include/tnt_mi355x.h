@@ -30,17 +30,18 @@ extern "C" {
 
 #define TNT_ABI_VERSION 5
 
-/* Longest oligo the gfx950 bind kernels accept (reference cap: MAX_SEQUENCE_LENGTH
- * 1024, nuc_cruc.h:80).  Up to 64 bases the rows of the alignment live in
- * registers; 65..128 run through an instance that keeps them in scratch memory. */
-#define TNT_MAX_OLIGO 128
+/* Longest oligo (the reference's MAX_SEQUENCE_LENGTH, nuc_cruc.h:80).  Up to 64 bases the rows of the alignment live
+ * in registers, one window per lane; 65..128 run through an instance that keeps them in scratch memory; 129..1024 are
+ * bound by the wavefront-per-window kernel (query rows across the lanes) -- in searches as the probes of probe-only
+ * assays (hybridisation probes; primers and padlock arms of that length: TNT_E_LIMIT), at unit level anywhere.        */
+#define TNT_MAX_OLIGO 1024
 /* NUM_FLANK_BASE, tntblast.h:76 */
 #define TNT_FLANK 4
 /* window = oligo + 2*flank (bind_oligo.cpp:139-142) */
 #define TNT_MAX_WINDOW (TNT_MAX_OLIGO + 2 * TNT_FLANK)
-/* alignment text: 3 lines of "5' " + <=(L+W) columns + " 3'" (nuc_cruc_output.cpp:8-213).  Sized for
- * every alignment of a 64-mer; an alignment of a longer oligo whose text does not fit (more than ~14 gap
- * columns at 128 bases) fails the call with TNT_E_LIMIT instead of being cut. */
+/* alignment text: 3 lines of "5' " + <=(L+W) columns + " 3'" (nuc_cruc_output.cpp:8-213).  The fixed fields hold
+ * every alignment of a 64-mer.  A longer text is kept by the context (until its next search / bind call) and the
+ * field holds a reference to it: read every alignment field through tnt_long_text().                              */
 #define TNT_ALIGN_TEXT 448
 
 /* error codes */
@@ -320,6 +321,11 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
  * Depends on the oligos and options only; computed on the GPU by the unit-level bind kernel instance.   */
 int tnt_oligo_structure(tnt_ctx *ctx, const char *a, const char *b, float ct_a, float ct_b, float *hairpin_a,
                         float *homodimer_a, float *heterodimer_ab);
+
+/* The text of an alignment field (tnt_hit::*_align, tnt_bind::align): the field itself, or -- for an alignment of an oligo
+ * beyond 64 bases that does not fit TNT_ALIGN_TEXT -- the full text the context keeps since its last search / bind call
+ * (the field then holds a 17-character reference that starts with 0x7F).  Returns the length written (without NUL), or < 0. */
+int tnt_long_text(tnt_ctx *ctx, const char *field, char *buf, size_t cap);
 
 /* amplicon / probe text of a hit, copied from the packed targets (amplicon_search.cpp:508-537,
  * probe_search.cpp:138-152): returns length written (without NUL) or <0.                      */

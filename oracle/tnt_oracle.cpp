@@ -1357,6 +1357,10 @@ static void fill_align(char *dst, const std::string &s)
 	dst[n] = 0;
 }
 
+// hybrid_sig keeps its mismatch / gap / clamp counts in int8_t (hybrid_sig.h:121-164): a count beyond 127 -- a probe of
+// several hundred bases -- comes out of the reference wrapped
+static inline int wrap8(unsigned v) { return int(int8_t(uint8_t(v))); }
+
 static tnt_hit blank_hit(const tnt_assay &A, int seq_index)
 {
 	tnt_hit h;
@@ -1464,9 +1468,9 @@ static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const u
 			hit.forward_tm = fo->tm, hit.reverse_tm = ro->tm;
 			hit.forward_dH = fo->dH, hit.reverse_dH = ro->dH;
 			hit.forward_dS = fo->dS, hit.reverse_dS = ro->dS;
-			hit.forward_mm = int(fo->mm), hit.reverse_mm = int(ro->mm);
-			hit.forward_gap = int(fo->gap), hit.reverse_gap = int(ro->gap);
-			hit.forward_primer_clamp = int(fo->a3), hit.reverse_primer_clamp = int(ro->a3);
+			hit.forward_mm = wrap8(fo->mm), hit.reverse_mm = wrap8(ro->mm);
+			hit.forward_gap = wrap8(fo->gap), hit.reverse_gap = wrap8(ro->gap);
+			hit.forward_primer_clamp = wrap8(fo->a3), hit.reverse_primer_clamp = wrap8(ro->a3);
 			fill_align(hit.forward_align, fo->align);
 			fill_align(hit.reverse_align, ro->align);
 
@@ -1484,7 +1488,7 @@ static void amplicon(const Ctx &cx, const tnt_assay &A, const Seeder &h, const u
 					tnt_hit hp = hit;
 					hp.probe_start = p->loc5, hp.probe_stop = p->loc3;
 					hp.probe_tm = p->tm, hp.probe_dH = p->dH, hp.probe_dS = p->dS;
-					hp.probe_mm = int(p->mm), hp.probe_gap = int(p->gap);
+					hp.probe_mm = wrap8(p->mm), hp.probe_gap = wrap8(p->gap);
 					hp.probe_strand = (p->mask & MPLUS) ? TNT_PLUS : TNT_MINUS;
 					fill_align(hp.probe_align, p->align);
 					out.push_back(hp);
@@ -1529,10 +1533,10 @@ static void padlock(const Ctx &cx, const tnt_assay &A, const Seeder &h, const ui
 				hit.forward_tm = d.tm, hit.reverse_tm = u.tm;
 				hit.forward_dH = d.dH, hit.reverse_dH = u.dH;
 				hit.forward_dS = d.dS, hit.reverse_dS = u.dS;
-				hit.forward_mm = int(d.mm), hit.reverse_mm = int(u.mm);
-				hit.forward_gap = int(d.gap), hit.reverse_gap = int(u.gap);
-				hit.forward_primer_clamp = int(d.a3);
-				hit.reverse_primer_clamp = int(u.a5);
+				hit.forward_mm = wrap8(d.mm), hit.reverse_mm = wrap8(u.mm);
+				hit.forward_gap = wrap8(d.gap), hit.reverse_gap = wrap8(u.gap);
+				hit.forward_primer_clamp = wrap8(d.a3);
+				hit.reverse_primer_clamp = wrap8(u.a5);
 				fill_align(hit.forward_align, d.align);
 				fill_align(hit.reverse_align, u.align);
 				out.push_back(hit);
@@ -1557,7 +1561,7 @@ static void hybrid(const Ctx &cx, const tnt_assay &A, const Seeder &h, const uin
 		for (const Info &b : bind) {
 			tnt_hit hit = blank_hit(A, seq_index);
 			hit.probe_tm = b.tm, hit.probe_dH = b.dH, hit.probe_dS = b.dS;
-			hit.probe_mm = int(b.mm), hit.probe_gap = int(b.gap);
+			hit.probe_mm = wrap8(b.mm), hit.probe_gap = wrap8(b.gap);
 			hit.probe_start = b.loc5, hit.probe_stop = b.loc3;
 			hit.probe_strand = minus ? TNT_MINUS : TNT_PLUS;
 			fill_align(hit.probe_align, b.align);
@@ -1809,8 +1813,9 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		double pb1 = -Tk * double(P.bulge_S[1]), pb2 = 1.0e30, pl3 = 1.0e30;
 		// bulges up to the longest window, loops up to 2 x 64 mismatches + the window (entry 512 of both tables is 0 in the
 		// reference, nuc_cruc_santa_lucia.cpp:670,720; no 128-mer reaches it)
-		for (int z = 2; z <= TNT_MAX_WINDOW; z++) pb2 = std::min(pb2, -Tk * double(P.bulge_S[z]));
-		for (int z = 3; z <= 2 * TNT_MAX_OLIGO + TNT_MAX_WINDOW; z++) pl3 = std::min(pl3, -Tk * double(P.loop_S[z]));
+		// (sizes an oligo of up to 128 bases and its window can form: the pre-filter has instances up to 128 rows)
+		for (int z = 2; z <= 128 + 2 * TNT_FLANK; z++) pb2 = std::min(pb2, -Tk * double(P.bulge_S[z]));
+		for (int z = 3; z <= 2 * 128 + 128 + 2 * TNT_FLANK; z++) pl3 = std::min(pl3, -Tk * double(P.loop_S[z]));
 		pl3 += -Tk * double(P.asym_S);
 		const double gap_price = std::min(std::min(pb2, pl3), pb1);
 		for (int prev = 0; prev < NBP; prev++)

@@ -57,3 +57,27 @@ def make(kind, seed, n_targets=60, tl=700):
     wl = synth.Workload("long-%s" % kind, opt, assays, codes, offsets)
     wl.expanded = synth.expand_assays(assays)
     return wl
+
+
+def make_beyond_128(seed, lengths=(150, 220, 400, 1000), n_targets=24, tl=3000):
+    """Probe-only assays with hybridisation probes of more than 128 bases (up to the reference's 1 024): planted sites with
+    substitutions and small indels on either strand, a few IUPAC letters; `-A PROBE`-style rows (probe column only)."""
+    rng = np.random.default_rng([777, seed])
+    codes, offsets = synth._targets(rng, n_targets, tl)
+    opt = abi.options_default(min_primer_tm=45.0, min_probe_tm=50.0)
+    assays = []
+    for a, ln in enumerate(lengths):
+        P = synth._rand_oligo(rng, ln, ln)
+        assays.append(synth.Assay("probe%d" % ln, None, None, P))
+        for _ in range(int(rng.integers(3, 7))):
+            t = int(rng.integers(0, n_targets))
+            s = _edit(rng, P, max(3, ln // 25), 2)
+            if rng.random() < 0.5:
+                s = synth.revcomp(s)
+            pos = int(rng.integers(1, tl - len(s) - 1))
+            synth._put(codes, int(offsets[t]), pos, s)
+    pos = rng.integers(0, n_targets * tl, 30)
+    codes[pos] = rng.integers(5, 16, 30).astype(np.uint8)
+    wl = synth.Workload("beyond-128", opt, assays, codes, offsets)
+    wl.expanded = synth.expand_assays(assays)
+    return wl

@@ -296,8 +296,11 @@ def test_structure_vs_oracle(Engine, oracle):
     for o in ("A" * 65, "AT" * 64, synth._rand_oligo(rng, 100, 128)):  # the long unit-level instance
         got = e.oligo_structure(o, oligos[3], 5e-7, 9e-7)
         assert tuple(tc.f32_bits(v) for v in got) == oracle.structure(opt, o, oligos[3], 5e-7, 9e-7), o
+    for o in (synth._rand_oligo(rng, 129, 129), synth._rand_oligo(rng, 300, 300), "GC" * 100 + "TTTT" + "GC" * 100):  # the wavefront-per-window kernel
+        got = e.oligo_structure(o, oligos[3], 5e-7, 9e-7)
+        assert tuple(tc.f32_bits(v) for v in got) == oracle.structure(opt, o, oligos[3], 5e-7, 9e-7), o
     with pytest.raises(Exception):
-        e.oligo_structure("A" * 129)
+        e.oligo_structure("A" * 1025)
     with pytest.raises(Exception):
         e.oligo_structure("ACGTNACGT")
     e.close()
@@ -1347,3 +1350,76 @@ def test_integration_stub_drops_in(Engine, checkers, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cli_compare.py"), str(tmp_path), "stub"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-500:]
     assert r.stdout.count("identical") >= 20
+
+
+def _bind_record_resolved(e, b):
+    """gu.bind_record with the alignment read through tnt_long_text and cut at the field's size (where the CPU checkers cut theirs)."""
+    rec = gu.bind_record(b) if not bytes(b.align).startswith(b"\x7fLT") else None
+    if rec is None:
+        raw = bytes(b.align)
+        b2 = abi.tnt_bind.from_buffer_copy(b)
+        b2.align = b"?"
+        rec = gu.bind_record(b2)
+        rec[21] = e.long_text(raw)[:abi.TNT_ALIGN_TEXT - 1]
+    return rec
+
+
+def test_g11_oligos_beyond_128_bases_golden(Engine):
+    """G11 (reference-generated): probes of 130, 200 and 1 000 bases through the wavefront-per-window kernel (query rows across
+    the lanes, 4 / 16 rows per lane, trace words in a slab per wavefront) -- its unit-level form on a sample of seeds, the
+    search (seeds in segments of 128 query words, hits of the segments merged), the self-structure values: == the reference.
+    Alignment texts beyond the 448-byte fields are read through tnt_long_text."""
+    g = gu.load("g11_beyond128.json.gz")
+    opt = gu.options_from(g["options"])
+    codes, offsets = gu.pack_targets(g["targets"])
+    ex = synth.expand_assays([synth.Assay(a[0], a[1], a[2], a[3]) for a in g["assays"]])
+    e = Engine(opt, ex)
+    om = {o: i for i, o in enumerate(e.oligos)}
+    db = e.pack(codes, offsets)
+    reqs = tc.make_reqs((r[0], om[g["oligos"][r[1]]], r[2], r[3], r[4], 1, 2.5e-7) for r in g["requests"])
+    out = e.bind_batch(db, reqs)
+    bad = [(i, gu.compare_bind(x, _bind_record_resolved(e, out[i]))) for i, x in enumerate(g["binds"])]
+    assert not [b for b in bad if b[1]], [b for b in bad if b[1]][:2]
+    assert sum(1 for x in g["binds"] if x[0] == 0 and len(x[21]) == abi.TNT_ALIGN_TEXT - 1) > 0  # (texts that fill the field: the long ones)
+    hits = e.search(db)
+    assert [list(k) for k in tc.sorted_hit_keys(hits, text_of=e.long_text)] == g["hits"] and len(g["hits"]) > 5
+    for i, o in enumerate(g["oligos"]):
+        got = e.oligo_structure(o, g["oligos"][(i + 1) % len(g["oligos"])], 2.5e-7, 2.5e-7)
+        assert [tc.f32_bits(v) for v in got] == g["structure"][i]
+    db.close()
+    e.close()
+
+
+@pytest.mark.parametrize("seed,lengths", [(1, (150, 220, 400, 1000)), (2, (129, 135, 300, 640)), (3, (257, 513, 1024))])
+def test_oligos_beyond_128_bases_vs_oracle(Engine, oracle, seed, lengths):
+    """Probe-only assays with probes of 129 to 1 024 bases: search == oracle (== reference, CPU suite), a sample of their
+    seeds through the unit-level route == oracle, full alignment texts through tnt_long_text."""
+    import longwl
+    wl = longwl.make_beyond_128(seed, lengths=lengths, n_targets=12, tl=2600)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    hits = e.search(db)
+    assert tc.sorted_hit_keys(hits, text_of=e.long_text) == want and len(want) >= 6
+    full = [e.long_text(bytes(h.probe_align)) for h in hits]
+    assert max(len(t) for t in full) > 3 * max(lengths)  # three lines of more than the probe's length: far beyond the 448-byte field
+    oligos = sorted({x.probe for x in wl.expanded})
+    seeds = oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    pick = seeds[::max(1, len(seeds) // 120)]
+    om = {o: i for i, o in enumerate(e.oligos)}
+    want_b = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, tc.make_reqs((s[0], s[1], s[2], s[3], s[4], 1, 2.5e-7) for s in pick))
+    got_b = e.bind_batch(db, tc.make_reqs((s[0], om[oligos[s[1]]], s[2], s[3], s[4], 1, 2.5e-7) for s in pick))
+    bad = [(i, gu.compare_bind(gu.bind_record(w), _bind_record_resolved(e, got_b[i]))) for i, w in enumerate(want_b)]
+    assert not [b for b in bad if b[1]], [b for b in bad if b[1]][:2]
+    db.close()
+    e.close()
+
+
+def test_primers_beyond_128_bases_are_refused(Engine):
+    """Oligos of more than 128 bases are searched as the probes of probe-only assays; a PCR primer of that length is refused
+    with TNT_E_LIMIT at context creation, never searched differently."""
+    from thermonucleotideblast_amd.engine import TntError
+    rng = np.random.default_rng(5)
+    F, R = synth._rand_oligo(rng, 140, 140), synth._rand_oligo(rng, 20, 20)
+    with pytest.raises(TntError, match="probe"):
+        Engine(abi.options_default(min_primer_tm=40.0), synth.expand_assays([synth.Assay("a", F, R, None)]))

@@ -158,3 +158,19 @@ def test_g10_long_records(oracle):
         if "first_cull" in case:
             rows = sorted([int(v) for v in r] for r in oracle.first_cull(opt, expanded, codes, offsets))
             assert rows == case["first_cull"] and len(rows) > 2000, case["config"]
+
+
+def test_g11_oligos_beyond_128_bases(oracle):
+    """G11 (reference-generated): hybridisation probes of 130, 200 and 1 000 bases -- NucCruc evaluations of a sample of their
+    seeds, the hit set of hybrid(), hairpin / homodimer / heterodimer Tm: oracle == reference."""
+    g = gu.load("g11_beyond128.json.gz")
+    opt = gu.options_from(g["options"])
+    codes, offsets = gu.pack_targets(g["targets"])
+    reqs = tc.make_reqs((r[0], r[1], r[2], r[3], r[4], 1, 2.5e-7) for r in g["requests"])
+    out = oracle.bind_batch(opt, g["oligos"], codes, offsets, reqs)
+    bad = [(i, gu.compare_bind(x, gu.bind_record(out[i]))) for i, x in enumerate(g["binds"])]
+    assert not [b for b in bad if b[1]], [b for b in bad if b[1]][:2]
+    ex = synth.expand_assays([synth.Assay(a[0], a[1], a[2], a[3]) for a in g["assays"]])
+    assert [list(k) for k in tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets))] == g["hits"]
+    for i, o in enumerate(g["oligos"]):
+        assert list(oracle.structure(opt, o, g["oligos"][(i + 1) % len(g["oligos"])], 2.5e-7, 2.5e-7)) == g["structure"][i]

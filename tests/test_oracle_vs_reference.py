@@ -210,3 +210,26 @@ def test_search_with_bind_cache_conflicts(ref, oracle, kind, seed):
     assert a == b and len(a) > 0
     if kind != "padlock":
         assert b != c  # the memo does change these results
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_oligos_beyond_128_bases(ref, oracle, seed):
+    """Hybridisation probes of 150 to 1 000 bases (the reference's MAX_SEQUENCE_LENGTH is 1 024): seeds, binds, hits and
+    self-structure of the oracle against the reference -- what pins the checker for the wavefront-per-window kernel's
+    own lengths."""
+    import longwl
+    wl = longwl.make_beyond_128(seed, lengths=(150, 1000) if seed == 1 else (130, 260, 520), n_targets=4, tl=1500)
+    oligos = sorted({e.probe for e in wl.expanded})
+    assert max(len(o) for o in oligos) >= 520
+    sa = ref.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    assert sa == oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    pick = sa[::max(1, len(sa) // 40)]
+    reqs = tc.make_reqs((s[0], s[1], s[2], s[3], s[4], 1, 2.5e-7) for s in pick)
+    ra = ref.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    rb = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    bad = [b for b in ((i, tc.bind_compare_fields(ra[i], rb[i])) for i in range(len(reqs))) if b[1]]
+    assert not bad, bad[:3]
+    a = tc.sorted_hit_keys(ref.search(wl.options, wl.expanded, wl.codes, wl.offsets, threads=2))
+    assert a == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets)) and len(a) >= 3
+    for o in oligos[:2]:
+        assert ref.structure(wl.options, o, oligos[-1]) == oracle.structure(wl.options, o, oligos[-1])

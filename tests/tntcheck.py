@@ -78,8 +78,10 @@ def f32_bits(x):
     return int(np.float32(x).view(np.uint32))
 
 
-def hit_key(h, with_text=True):
-    """Canonical, order-independent, bit-exact key of one hit (floats as uint32 bit patterns)."""
+def hit_key(h, with_text=True, text_of=None):
+    """Canonical, order-independent, bit-exact key of one hit (floats as uint32 bit patterns).  text_of: reads an alignment
+    field (Engine.long_text: an alignment of an oligo beyond 64 bases that does not fit the field is kept by the context);
+    texts are compared up to the field's size, where the CPU checkers cut theirs."""
     k = []
     for n, t in abi.tnt_hit._fields_:
         v = getattr(h, n) if not isinstance(h, dict) else h[n]
@@ -87,7 +89,10 @@ def hit_key(h, with_text=True):
             k.append(f32_bits(v))
         elif n.endswith("_align"):
             if with_text:
-                k.append(v.decode() if isinstance(v, bytes) else v)
+                if text_of is not None:
+                    k.append(text_of(v)[:abi.TNT_ALIGN_TEXT - 1])
+                else:
+                    k.append(v.decode() if isinstance(v, bytes) else v)
         else:
             k.append(int(v))
     return tuple(k)
@@ -313,5 +318,5 @@ def make_reqs(rows):
     return arr
 
 
-def sorted_hit_keys(hits, with_text=True):
-    return sorted(hit_key(h, with_text) for h in hits)
+def sorted_hit_keys(hits, with_text=True, text_of=None):
+    return sorted(hit_key(h, with_text, text_of) for h in hits)

@@ -5,7 +5,7 @@ Pure declarations: importing this module loads no native code.
 import ctypes as C
 
 TNT_ABI_VERSION = 5
-TNT_MAX_OLIGO = 128
+TNT_MAX_OLIGO = 1024
 TNT_FLANK = 4
 TNT_ALIGN_TEXT = 448
 

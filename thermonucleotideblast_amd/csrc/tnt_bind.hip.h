@@ -56,7 +56,14 @@ struct BindArgs {
 	uint32_t *n_active;
 	uint32_t *debug;           // experimental builds only (TNT_EXP_STATS)
 	const uint8_t *audit;      // optional (audit mode of the pre-filter): 1 = the filter would have rejected this item
+	// alignment texts that do not fit ALIGN_TEXT (oligos beyond 64 bases): written here, the record's field holds a reference
+	char *ltext;
+	uint32_t ltext_cap;
+	uint32_t *ltext_count;     // bytes handed out
 };
+
+// reference to a text in the long-text arena, as a text field holds it: 0x7F 'L' 'T' + offset (8 hex digits) + length (6 hex digits)
+constexpr int LTEXT_REF_CHARS = 17;
 
 constexpr int TIE_CAP = 256;      // maximal cells of one DP beyond which the kernel reports ERR_TIE_OVERFLOW
 constexpr unsigned long long WC_MASK = // watson_and_crick[], nuc_cruc.cpp:229-238
@@ -870,18 +877,28 @@ __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const ui
 		if (prefix < 0) prefix = 0;
 		int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
 		if (suffix < 0) suffix = 0;
-		// three lines of prefix + columns + suffix and 18 characters of decoration: the field holds every alignment of
-		// a 64-mer; one of a longer oligo that does not fit fails the call (never a cut text)
-		if (LONG_TEXT && 3 * (prefix + (bi.k1 - bi.k0) + suffix) + 18 >= ALIGN_TEXT) {
-			atomicOr(a.err, ERR_TEXT_OVERFLOW);
-			prefix = suffix = 0, bi.k1 = bi.k0;
-		}
+		// three lines of prefix + columns + suffix and 18 characters of decoration: the field holds every alignment of a
+		// 64-mer; one of a longer oligo that does not fit goes to the context's long-text arena and the field gets a reference
+		// to it (tnt_long_text reads through it).  Never a cut text: without room in the arena the call fails.
 		// (written a dword at a time: every lane writes into a record of its own, so a byte store is a memory request)
 		int o = 0;
 		uint32_t acc = 0;
 		static_assert(offsetof(BoundRec, text) % 4 == 0 && offsetof(BindFull, text) % 4 == 0 && sizeof(BoundRec) % 4 == 0 && sizeof(BindFull) % 4 == 0 && ALIGN_TEXT % 4 == 0,
 		              "text fields on 4-byte boundaries");
 		uint32_t *text32 = reinterpret_cast<uint32_t *>(text);
+		const int text_chars = 3 * (prefix + (bi.k1 - bi.k0) + suffix) + 18;
+		uint32_t lref = 0xFFFFFFFFu; // where the text sits in the arena
+		if (LONG_TEXT && text_chars >= ALIGN_TEXT) {
+			const uint32_t need = (uint32_t(text_chars) + 4u) & ~3u;
+			const uint32_t at = a.ltext ? atomicAdd(a.ltext_count, need) : 0xFFFFFFFFu;
+			if (a.ltext && at <= a.ltext_cap && need <= a.ltext_cap - at) {
+				lref = at;
+				text32 = reinterpret_cast<uint32_t *>(a.ltext + at);
+			} else {
+				atomicOr(a.err, ERR_TEXT_OVERFLOW);
+				prefix = suffix = 0, bi.k1 = bi.k0;
+			}
+		}
 		auto put = [&](char ch) __attribute__((always_inline)) {
 			acc |= uint32_t(uint8_t(ch)) << ((o & 3) * 8);
 			o++;
@@ -906,7 +923,17 @@ __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const ui
 		for (int i = 1; i <= suffix; i++) put(base_letter(TARGET(bi.lm_t - i)));
 		put(' '), put('5'), put('\'');
 		text32[o >> 2] = acc; // the rest and the terminating zero (acc holds zeros above the characters written)
-		if (rec) rec->text_len = o;
+		if (rec) rec->text_len = o; // (the text's own length also where the field only refers to it: sort_by_bound_match compares it)
+		if (lref != 0xFFFFFFFFu) { // the field: 0x7F L T, offset, length -- no zero byte inside, one behind
+			uint32_t *f32 = reinterpret_cast<uint32_t *>(text);
+			auto hex = [](uint32_t v, int d) __attribute__((always_inline)) { return uint32_t("0123456789abcdef"[(v >> (4 * d)) & 15u]); };
+			const uint32_t len = uint32_t(o);
+			f32[0] = 0x7Fu | (uint32_t('L') << 8) | (uint32_t('T') << 16) | (hex(lref, 7) << 24);
+			f32[1] = hex(lref, 6) | (hex(lref, 5) << 8) | (hex(lref, 4) << 16) | (hex(lref, 3) << 24);
+			f32[2] = hex(lref, 2) | (hex(lref, 1) << 8) | (hex(lref, 0) << 16) | (hex(len, 5) << 24);
+			f32[3] = hex(len, 4) | (hex(len, 3) << 8) | (hex(len, 2) << 16) | (hex(len, 1) << 24);
+			f32[4] = hex(len, 0);
+		}
 	}
 #ifdef TNT_EXP_STATS
 	{ // wave-level cycle breakdown of the tail (s_memtime ticks / 64, lane 0 of every wave; waves re-converge here)
@@ -1060,7 +1087,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
 		const int L = active ? a.olig_len[slot.oligo] : 0;
 		const bool minus = (it.info & ITEM_MINUS) != 0;
-		const int qloc = int(it.info & 127u);
+		const int qloc = int(it.info & 127u) + slot.qloc_bias;
 		const uint32_t tlen = (FULL && (!active || (it.target >> 29))) ? 0u : a.db.len[it.target]; // no target set behind self-structure requests
 		// bind_oligo.cpp:502-505
 		int start = int(it.tloc) - (qloc + FLANK);
@@ -1361,12 +1388,15 @@ TNT_EXACT_LADDER(X)
 #undef X
 // the wavefront-per-window form (tnt_wbind.hip.h, instances in tnt_wbind_inst.hip): N = query rows per lane, oligos of up
 // to 64 * N bases; `full` = the unit-level form (any request kind, dp_max / n_max reported)
-#define TNT_WBIND_LADDER(X) X(1) X(2)
+#define TNT_WBIND_LADDER(X) X(1) X(2) X(4) X(8) X(16)
 #define X(N) void launch_wbind_##N(const BindArgs &a, int blocks, hipStream_t stream); void launch_wbind_full_##N(const BindArgs &a, int blocks, hipStream_t stream);
 TNT_WBIND_LADDER(X)
 #undef X
 constexpr int wb_waves(int R) { return R == 1 ? 4 : (R == 2 ? 2 : 1); }    // wavefronts (= windows in flight) per workgroup
-constexpr int wb_blocks_per_cu(int R) { return R == 1 ? 3 : (R == 2 ? 2 : 1); } // resident workgroups (LDS: 54 KB / 67 KB each)
+constexpr bool wb_trace_lds(int R) { return R <= 2; }                      // the trace words of a window fit LDS (beyond: a slab per wavefront in HBM)
+constexpr size_t wb_slab_bytes(int R) { return wb_trace_lds(R) ? 0 : size_t(64 * R) * size_t(64 * R + 2 * FLANK); }
+constexpr int wb_rows_per_lane(int rows) { return rows <= 64 ? 1 : (rows <= 128 ? 2 : (rows <= 256 ? 4 : (rows <= 512 ? 8 : 16))); }
+constexpr int wb_blocks_per_cu(int R) { return R == 1 ? 3 : 2; } // resident workgroups (LDS: 54 KB at R = 1, 67 KB at R = 2, 30 to 44 KB beyond: the trace words in HBM)
 
 } // namespace tnt
 #endif

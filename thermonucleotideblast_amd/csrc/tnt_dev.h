@@ -14,10 +14,11 @@ constexpr int NBP = 49;  // NUM_BASE_PAIR
 constexpr int P_AT = bA * NB + bT, P_TA = bT * NB + bA, P_CG = bC * NB + bG, P_GC = bG * NB + bC;
 constexpr int P_GT = bG * NB + bT, P_TG = bT * NB + bG, P_EE = bE * NB + bE, P__ = bGAP * NB + bGAP;
 
-constexpr int MAX_OLIGO = 128;            // TNT_MAX_OLIGO
+constexpr int MAX_OLIGO = 1024;           // TNT_MAX_OLIGO = the reference's MAX_SEQUENCE_LENGTH (nuc_cruc.h:80): stride of the oligo tables
+constexpr int MAX_LANE_OLIGO = 128;       // longest oligo the lane-per-window kernels (bind_kernel, filter_kernel) hold; beyond: wbind_kernel
 constexpr int FLANK = 4;                  // NUM_FLANK_BASE, tntblast.h:76
-constexpr int MAX_WINDOW = MAX_OLIGO + 2 * FLANK;
-constexpr int MAX_COLS = MAX_OLIGO + MAX_WINDOW + 4; // longest traceback path + dangles
+constexpr int MAX_WINDOW = MAX_LANE_OLIGO + 2 * FLANK;
+constexpr int MAX_COLS = MAX_LANE_OLIGO + MAX_WINDOW + 4; // longest traceback path + dangles
 constexpr int ALIGN_TEXT = 448;           // TNT_ALIGN_TEXT
 
 // trace word of one DP cell: one byte, see the bind kernel.  Predecessor states follow nuc_cruc.h:62-64
@@ -87,6 +88,9 @@ struct Slot {
 	int32_t assay;   // expanded assay index (or -1)
 	int32_t bucket;  // length bucket = which bind kernel instance handles this oligo ...
 	int32_t bucket_general; // ... and the one for windows that hold a degenerate target base
+	int32_t qloc_bias; // added to the 7-bit word index of a work item: the seeds of an oligo of more than 134 bases come from
+	                   // segments of 128 query words each (a segment is a slot of its own), and unit-level requests name any word
+	int32_t pad;
 };
 
 // Instances of the bind kernel (rows kept in registers): every oligo length up to 40 has its own (probes of 33 to 40 bases
@@ -103,6 +107,8 @@ struct Slot {
 #define TNT_FILTER_LADDER(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(44) X(48) X(52) X(56) X(60) X(64)
 constexpr int MAX_BUCKETS = 48;
 constexpr int BUCKET_EXACT = 0x100, BUCKET_PLAIN = 0x200; // flags on the instance id kept by the host (lmax | flags)
+constexpr int BUCKET_WAVE = 0x400; // the wavefront-per-window kernel serves the bucket: the low byte holds the query rows per lane (4, 8, 16: oligos of up to 256, 512, 1 024 bases)
+constexpr int bucket_rows(int id) { return (id & BUCKET_WAVE) ? 64 * (id & 0xFF) : (id & 0xFF); }
 
 // Workgroup size of the bind kernel instances.  One lane owns one DP; a lane needs 8 * LMAX + 48 bytes of LDS
 // (window, query, alignment columns, best alignment, trace prefetch) next to the 24 KB of tables every workgroup

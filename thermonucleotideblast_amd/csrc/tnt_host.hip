@@ -297,7 +297,7 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 		// sizes a window of this library can hold (the reference leaves the last entry of both tables at 0,
 		// nuc_cruc_santa_lucia.cpp:670,720: a 512-base loop no 128-mer can form)
 		for (int sz = 2; sz <= MAX_WINDOW; sz++) pb2 = std::min(pb2, -Tk * double(T.bulge_S[sz]));
-		for (int sz = 3; sz <= 2 * MAX_OLIGO + MAX_WINDOW; sz++) pl3 = std::min(pl3, -Tk * double(T.loop_S[sz]));
+		for (int sz = 3; sz <= 2 * MAX_LANE_OLIGO + MAX_WINDOW; sz++) pl3 = std::min(pl3, -Tk * double(T.loop_S[sz]));
 		pl3 += -Tk * double(T.asym_S); // a loop that leaves its diagonal is asymmetric by at least one base
 		const double gap_price = std::min(std::min(pb2, pl3), pb1);
 		// best stack across a single-base bulge into pair c (nuc_cruc.cpp:2105-2120: the flanking stack is kept)
@@ -647,6 +647,15 @@ struct tnt_ctx {
 	PinnedBuf<uint8_t> pin_blob;         // tnt_search_collect_compact: the hits of the last search in wire form
 	// Row a6: assays that hold an oligo used under two strand concentrations / threshold sets go through the replay of the
 	// reference's per-target BindCache (tnt_pair.hip.h, cache_replay_kernel) instead of the ordinary pairing
+	// Oligos of 129 to 1 024 bases (probes of probe-only assays): the 7-bit word index of a work item reaches 128 query words, so
+	// such a probe is seeded in segments of 128 words -- every segment behind the first a VIRTUAL assay of its own (same id /
+	// degen_id, same oligo, Slot::qloc_bias = 128 * segment) appended behind the caller's assays.  Two seeds of one diagonal in
+	// two segments bind the same window; the hits of the segments are merged when a search is collected (merge_long_probe_hits).
+	std::vector<int32_t> h_segment;      // per device assay: segment of its probe's word list (-1: the whole list)
+	size_t n_input_assays = 0;
+	bool long_probes = false;
+	DevBuf<char> ltext;                  // alignment texts beyond TNT_ALIGN_TEXT (tnt_long_text)
+	std::vector<char> h_ltext;           // ... on the host, as of the last collected search / bind call
 	bool cache_replay = false;
 	uint32_t n_cache_assays = 0;
 	DevBuf<unsigned long long> ck_in, ck_out; // sort keys of their groups (target << 32 | assay)
@@ -703,7 +712,8 @@ enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items *
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
        C_BUCKET = C_GROUPS + N_SHARD * SHARD_STRIDE, C_DEBUG = C_BUCKET + MAX_BUCKETS * BUCKET_STRIDE,
-       C_BLOB = C_DEBUG + 16 /* compact hit blob of the search: bytes, hits (enqueue_compaction) */, C_COUNT = C_BLOB + 2 };
+       C_BLOB = C_DEBUG + 16 /* compact hit blob of the search: bytes, hits (enqueue_compaction) */,
+       C_LTEXT = C_BLOB + 2 /* bytes of the long-text arena handed out */, C_COUNT = C_LTEXT + 2 };
 static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
@@ -763,13 +773,21 @@ int pick_lmax(size_t max_len)
 	TNT_LMAX_LADDER(X)
 	TNT_LONG_LADDER(X)
 #undef X
-	return MAX_OLIGO;
+	return BUCKET_WAVE | wb_rows_per_lane(int(max_len)); // beyond 128 bases: the wavefront-per-window kernel (4, 8, 16 rows per lane)
 }
 
 // persistent grid of one bind kernel instance
 // `id` = rows | BUCKET_* flags of an instance (0: the unit-level instance)
-int bind_threads(int id) { return bind_threads_for(id ? (id & 0xFF) : 64, (id & BUCKET_PLAIN) != 0); }
-int bind_grid(const tnt_ctx *c, int id) { return c->n_cu * bind_blocks_per_cu(id & 0xFF, (id & BUCKET_PLAIN) != 0); }
+int bind_threads(int id)
+{
+	if (id & BUCKET_WAVE) return 64 * wb_waves(id & 0xFF);
+	return bind_threads_for(id ? (id & 0xFF) : 64, (id & BUCKET_PLAIN) != 0);
+}
+int bind_grid(const tnt_ctx *c, int id)
+{
+	if (id & BUCKET_WAVE) return c->n_cu * wb_blocks_per_cu(id & 0xFF) * 2;
+	return c->n_cu * bind_blocks_per_cu(id & 0xFF, (id & BUCKET_PLAIN) != 0);
+}
 
 // instance id for plain windows of oligos of length L: the exact instance where there is one, else the ladder
 int pick_instance(size_t L)
@@ -777,8 +795,11 @@ int pick_instance(size_t L)
 #define X(N) if (L == N) return N | BUCKET_EXACT | BUCKET_PLAIN;
 	TNT_EXACT_LADDER(X)
 #undef X
+	if (L > size_t(MAX_LANE_OLIGO)) return pick_lmax(L); // (one instance for every window of such an oligo)
 	return pick_lmax(L) | BUCKET_PLAIN;
 }
+
+void launch_wbind(tnt_ctx *c, const BindArgs &a, int rows, bool full, hipStream_t stream, size_t n_items = 0);
 
 void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_t stream = nullptr, int unit_rows = 0 /* 0: the context's */)
 {
@@ -788,9 +809,15 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 		else hipLaunchKernelGGL((bind_kernel<64, false, false, false, true>), dim3(blocks), dim3(bind_threads(64)), 0, stream, a);
 		return;
 	}
-	if (lmax == 0) { // unit-level API: the 64-row instance, or the long one when an oligo needs it
-		if ((unit_rows ? unit_rows : c->unit_rows) > 64) hipLaunchKernelGGL((bind_kernel<MAX_OLIGO, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
+	if (lmax == 0) { // unit-level API: the 64-row instance, the 128-row one, or the wavefront-per-window kernel when an oligo needs it
+		const int rows = unit_rows ? unit_rows : c->unit_rows;
+		if (rows > MAX_LANE_OLIGO) launch_wbind(c, a, rows, true, stream);
+		else if (rows > 64) hipLaunchKernelGGL((bind_kernel<MAX_LANE_OLIGO, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
 		else hipLaunchKernelGGL((bind_kernel<64, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
+		return;
+	}
+	if (lmax & BUCKET_WAVE) {
+		launch_wbind(c, a, bucket_rows(lmax), false, stream);
 		return;
 	}
 	switch (lmax) {
@@ -810,10 +837,9 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 }
 
 // the wavefront-per-window form of the bind kernel (tnt_wbind.hip.h): rows per lane by the longest oligo of the launch
-int wbind_rows_per_lane(int rows) { return rows <= 64 ? 1 : 2; }
-void launch_wbind(tnt_ctx *c, const BindArgs &a, int rows, bool full, hipStream_t stream, size_t n_items = 0 /* 0: a full queue */)
+void launch_wbind(tnt_ctx *c, const BindArgs &a, int rows, bool full, hipStream_t stream, size_t n_items /* 0: a full queue */)
 {
-	const int R = wbind_rows_per_lane(rows);
+	const int R = wb_rows_per_lane(rows);
 	int blocks = c->n_cu * wb_blocks_per_cu(R) * 2; // persistent grid: 2 x the resident workgroups
 	if (n_items) blocks = int(std::min<size_t>(size_t(blocks), (n_items + size_t(wb_waves(R)) - 1) / size_t(wb_waves(R))));
 	switch (R) {
@@ -935,7 +961,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		const uint32_t queue_cap = direct ? c->h_q_cap[i] : uint32_t(c->item_cap);
 		b.n_items = queue_cap;
 		b.audit = nullptr;
-		if (c->filter_on && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) && ((c->bucket_lmax[i] & 0xFF) <= 64 || c->filter_long) &&
+		if (c->filter_on && !(c->bucket_lmax[i] & BUCKET_WAVE) && ((c->bucket_lmax[i] & BUCKET_PLAIN) || c->filter_general) && ((c->bucket_lmax[i] & 0xFF) <= 64 || c->filter_long) &&
 		    has_filter_instance(c->bucket_lmax[i] & 0xFF, !(c->bucket_lmax[i] & BUCKET_PLAIN))) {
 			// every window first meets the pre-filter: what cannot reach the minimum Tm is rejected there, the rest of the
 			// bucket is compacted into qsurv (same offset) and bound by the full kernel.  (The general buckets -- windows
@@ -975,7 +1001,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.best = c->best.p + size_t(lane) * c->lane_cols;
 		b.stack = c->stack.p + size_t(lane) * c->lane_cols;
 		b.ties = c->ties.p + size_t(lane) * c->lane_ties;
-		if (c->wave_from && (c->bucket_lmax[i] & 0xFF) >= c->wave_from && !c->opt.use_dinkelbach) launch_wbind(c, b, c->bucket_lmax[i] & 0xFF, false, c->lane_stream[lane]);
+		if ((c->bucket_lmax[i] & BUCKET_WAVE) || (c->wave_from && (c->bucket_lmax[i] & 0xFF) >= c->wave_from && !c->opt.use_dinkelbach))
+			launch_wbind(c, b, bucket_rows(c->bucket_lmax[i]), false, c->lane_stream[lane]);
 		else launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
 	}
 	for (int l = 0; l < c->lanes && (l < n_launch || c->split_filter); l++) {
@@ -986,8 +1013,9 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 
 int ensure_scratch(tnt_ctx *c, int need_lmax)
 {
-	if (c->trace.p && c->scratch_lmax >= need_lmax) return TNT_OK;
-	c->scratch_lmax = std::max(c->scratch_lmax, need_lmax);
+	if (need_lmax > MAX_LANE_OLIGO && !(need_lmax & BUCKET_WAVE)) need_lmax = BUCKET_WAVE | wb_rows_per_lane(need_lmax); // (rows of a unit-level request)
+	if (c->trace.p && bucket_rows(c->scratch_lmax) >= bucket_rows(need_lmax)) return TNT_OK;
+	if (bucket_rows(need_lmax) > bucket_rows(c->scratch_lmax)) c->scratch_lmax = need_lmax;
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, c->device), c->err);
 	c->n_cu = prop.multiProcessorCount;
@@ -997,6 +1025,10 @@ int ensure_scratch(tnt_ctx *c, int need_lmax)
 	inst.push_back(c->scratch_lmax);
 	size_t n_trace = 0, n_cols = 0, n_ties = 0;
 	for (int id : inst) {
+		if (id & BUCKET_WAVE) { // one trace slab per wavefront of the persistent grid (rows beyond the LDS budget)
+			n_trace = std::max(n_trace, size_t(bind_grid(c, id)) * size_t(wb_waves(id & 0xFF)) * wb_slab_bytes(id & 0xFF));
+			continue;
+		}
 		const int l = id & 0xFF;
 		const size_t lanes = size_t(bind_grid(c, id)) * size_t(bind_threads(id));
 		const size_t lm = size_t(l), wm = lm + 2 * FLANK, nc = lm + wm + 4;
@@ -1096,7 +1128,21 @@ BindArgs bind_args(tnt_ctx *c, const DbView &v)
 	a.active = c->S().active.p;
 	a.n_active = c->S().counters.p + C_ACTIVE;
 	a.debug = c->G() + C_DEBUG;
+	a.ltext = c->ltext.p;
+	a.ltext_cap = uint32_t(std::min<size_t>(c->ltext.n, 0xFFFFFF00u));
+	a.ltext_count = c->G() + C_LTEXT;
 	return a;
+}
+
+// the long alignment texts of the work just finished -> host (tnt_long_text reads them there)
+int fetch_long_texts(tnt_ctx *c, uint32_t bytes)
+{
+	c->h_ltext.clear();
+	if (!bytes || !c->ltext.p) return TNT_OK;
+	bytes = uint32_t(std::min<size_t>(bytes, c->ltext.n));
+	c->h_ltext.resize(bytes);
+	HIP_TRY(hipMemcpy(c->h_ltext.data(), c->ltext.p, bytes, hipMemcpyDeviceToHost), c->err);
+	return TNT_OK;
 }
 
 const char *err_text(uint32_t e)
@@ -1109,8 +1155,8 @@ const char *err_text(uint32_t e)
 	if (e & ERR_LIST_OVERFLOW) return "more than 512 seeds of one assay inside one seed window";
 	if (e & ERR_STACK_OVERFLOW) return "traceback branch stack overflow";
 	if (e & ERR_TIE_OVERFLOW) return "more than 256 maximal DP cells in one window";
+	if (e & ERR_TEXT_OVERFLOW) return "alignment texts beyond TNT_ALIGN_TEXT do not fit the long-text arena (TNT_MI355X_LTEXT_MB)";
 	if (e & ERR_FILTER_UNSOUND) return "pre-filter audit: the filter would have rejected a window the bind kernel accepts";
-	if (e & ERR_TEXT_OVERFLOW) return "the alignment text of an oligo longer than 64 bases does not fit TNT_ALIGN_TEXT";
 	return "unknown device error";
 }
 
@@ -1159,7 +1205,7 @@ static int calibrate_long_filter(tnt_ctx *c)
 	}
 	std::vector<const Slot *> longs;
 	for (const Slot &sl : c->h_slots)
-		if (sl.oligo >= 0 && c->oligos[size_t(sl.oligo)].size() > 64 && longs.size() < 64) longs.push_back(&sl);
+		if (sl.oligo >= 0 && c->oligos[size_t(sl.oligo)].size() > 64 && c->oligos[size_t(sl.oligo)].size() <= size_t(MAX_LANE_OLIGO) && longs.size() < 64) longs.push_back(&sl);
 	if (longs.empty() || !c->filter_on) return TNT_OK;
 	const size_t N = 2048, TLEN = 320;
 	std::vector<uint8_t> codes(N * TLEN);
@@ -1317,8 +1363,39 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		}
 		c->h_assays.push_back(d);
 	}
+	c->n_input_assays = n_assays;
+	c->h_segment.assign(n_assays, -1);
+	{
+		// oligos beyond 128 bases: probes of probe-only assays only, seeded in segments of 128 query words
+		const size_t k = size_t(opt->hash_word_size);
+		for (size_t i = 0; i < n_assays; i++) {
+			const AssayDev d = c->h_assays[i];
+			const int slots3[3] = {d.slot_f, d.slot_r, d.slot_p};
+			for (int role = 0; role < 3; role++) {
+				if (slots3[role] < 0) continue;
+				const size_t L = c->oligos[size_t(c->h_slots[size_t(slots3[role])].oligo)].size();
+				if (L <= size_t(MAX_LANE_OLIGO)) continue;
+				if (d.kind != 2) FAIL(TNT_E_LIMIT, "oligos of more than 128 bases are searched as the probes of probe-only assays (PCR primers, TaqMan probes and padlock arms: up to 128)");
+				if (opt->use_dinkelbach) FAIL(TNT_E_LIMIT, "--dinkelbach with an oligo longer than 64 bases");
+				const size_t n_words = L >= k ? L - k + 1 : 0, n_seg = (n_words + 127) / 128;
+				c->h_segment[i] = 0;
+				c->long_probes = true;
+				for (size_t sg = 1; sg < n_seg; sg++) {
+					const size_t v = c->h_assays.size();
+					c->h_assays.push_back(d);
+					c->h_segment.push_back(int32_t(sg));
+					c->h_slots.resize((v + 1) * 3, Slot{-1, 0.0f, 0, int(v), 0, 0});
+					Slot sl = c->h_slots[size_t(d.slot_p)];
+					sl.assay = int(v);
+					sl.qloc_bias = int32_t(128 * sg);
+					c->h_slots[v * 3 + 2] = sl;
+					c->h_assays[v].slot_p = int32_t(v * 3 + 2);
+				}
+			}
+		}
+	}
 	for (const std::string &o : c->oligos) {
-		if (o.size() > size_t(TNT_MAX_OLIGO)) FAIL(TNT_E_LIMIT, "oligo longer than TNT_MAX_OLIGO (128) bases");
+		if (o.size() > size_t(TNT_MAX_OLIGO)) FAIL(TNT_E_LIMIT, "oligo longer than TNT_MAX_OLIGO (1024) bases");
 		if (o.empty()) FAIL(TNT_E_ARG, "empty oligo");
 		for (char ch : o)
 			if (char_to_base(ch) < 0) FAIL(TNT_E_ARG, "oligos must be expanded to A/C/G/T/I (expand_degenerate_signatures)");
@@ -1326,11 +1403,11 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	}
 	if (opt->use_dinkelbach && max_L > 64) FAIL(TNT_E_LIMIT, "--dinkelbach with an oligo longer than 64 bases");
 	c->lmax = opt->use_dinkelbach ? 64 : pick_lmax(max_L); // --dinkelbach: one 64-row instance binds everything
-	c->unit_rows = max_L > 64 ? MAX_OLIGO : 64;
+	c->unit_rows = max_L <= 64 ? 64 : (max_L <= size_t(MAX_LANE_OLIGO) ? MAX_LANE_OLIGO : int(max_L)); // unit-level instance: 64 / 128 rows, or the wavefront kernel
 	{
 		// buckets: one per instance in use, in ascending length; the last one is the general instance that
 		// takes the longest oligo (short queues are bound there as a whole)
-		auto by_len = [](int a, int b) { return (a & 0xFF) != (b & 0xFF) ? (a & 0xFF) < (b & 0xFF) : a > b; };
+		auto by_len = [](int a, int b) { return bucket_rows(a) != bucket_rows(b) ? bucket_rows(a) < bucket_rows(b) : a > b; };
 		std::vector<int> used;
 		for (const Slot &sl : c->h_slots)
 			if (sl.oligo >= 0) {
@@ -1391,7 +1468,11 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				// padlock_search.cpp:97,238)
 				if (d.kind != 0 && !(opt->target_strand & (minus ? TNT_STRAND_MINUS : TNT_STRAND_PLUS))) continue;
 				const std::string &o = c->oligos[c->h_slots[slots3[role]].oligo];
-				const std::vector<uint16_t> w = word_list(o, minus == 0, k); // plus strand: find_complement
+				std::vector<uint16_t> w = word_list(o, minus == 0, k); // plus strand: find_complement
+				if (c->h_segment[ai] >= 0) { // a probe of more than 128 bases: this (virtual) assay seeds one segment of its word list
+					const size_t w0 = std::min(w.size(), size_t(128) * size_t(c->h_segment[ai])), w1 = std::min(w.size(), w0 + 128);
+					w = std::vector<uint16_t>(w.begin() + long(w0), w.begin() + long(w1));
+				}
 				// the strand-specific sequence, 2 bits per base (plain A/C/G/T oligos only: word index == base offset)
 				bool plain = o.size() <= 64; // (the packed form holds 64 bases; longer oligos take the word-list test)
 				for (size_t x = 0; x < o.size() && plain; x++) {
@@ -1406,7 +1487,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 					}
 					if (b2 >= 0) wl_seq[li * 2 + (x >> 5)] |= (unsigned long long)b2 << ((x & 31) * 2);
 				}
-				if (w.size() > 127) FAIL(TNT_E_LIMIT, "too many query words");
+				if (w.size() > 128) FAIL(TNT_E_LIMIT, "too many query words");
 				if (ai >= (size_t(1) << (32 - WT_ASSAY_SHIFT))) FAIL(TNT_E_LIMIT, "too many assays");
 				for (size_t wi = 0; wi < w.size(); wi++) {
 					c->assay_entries[ai].push_back(std::make_pair(
@@ -1496,6 +1577,11 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	    (e = c->wl_seq.upload(wl_seq)) != hipSuccess || (c->h_wl_seq = wl_seq, false) ||
 	    (e = c->wlist.upload(wlist)) != hipSuccess)
 		FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
+	if (max_L > 64) { // alignment texts of such oligos may exceed TNT_ALIGN_TEXT: the arena they go to
+		size_t mb = max_L > size_t(MAX_LANE_OLIGO) ? 256 : 32;
+		if (const char *e = getenv("TNT_MI355X_LTEXT_MB")) mb = std::max<size_t>(1, strtoull(e, nullptr, 10));
+		if ((e = c->ltext.alloc(mb << 20)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("long-text arena: ") + hipGetErrorString(e));
+	}
 	if (max_L > 64) {
 		const int crc = calibrate_long_filter(c);
 		if (crc) {
@@ -2318,9 +2404,11 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	const bool direct = c->seed2 && !seeds_only && db->h_word_off[db->n_targets] < (uint64_t(1) << 32);
 	c->batch_direct = direct;
 	if (direct) {
-		// the instance with the chunk's bucket offsets in LDS (hash words of up to 7 bases): one 1024-thread workgroup per CU;
-		// else four 256-thread workgroups per CU that read them through L1 / L2 -- 16 wavefronts per CU either way
-		const bool ltab = c->opt.hash_word_size <= 7 && !getenv("TNT_MI355X_SEED_GLOBAL_TABLE");
+		// four 256-thread workgroups per CU that read the chunk's bucket offsets through L1 / L2; on request the instance that
+		// keeps them in LDS (hash words of up to 7 bases, one 1024-thread workgroup per CU: 16 wavefronts per CU either way) --
+		// built in round 4 and measured SLOWER (config 2: seed 5.9 against 5.3 ms, config 4 per 100 k targets: 50.7 against 37.2 ms;
+		// DESIGN.md 4.1), although the scan on its own runs 3.6 x faster out of LDS (tnt_seed_scan_only)
+		const bool ltab = c->opt.hash_word_size <= 7 && getenv("TNT_MI355X_SEED2_LDS_TABLE");
 		const size_t S2_WAVES = size_t(s2_waves(ltab));
 		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * (ltab ? 1 : 4), tnt_ctx::MAX_REGIONS / S2_WAVES)));
 		const uint32_t regions = blocks * uint32_t(S2_WAVES);
@@ -2704,6 +2792,7 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 {
 	if (!ctx || !ctx->pending) return TNT_E_ARG;
 	if (ctx->pending_db && !ctx->pending_db->h_long_targets.empty()) want_records = true; // (the hits of windowed targets are made on the host)
+	if (ctx->long_probes) want_records = true; // (the hits of a long probe's segments are merged on the host)
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
 	uint32_t cnt[C_COUNT];
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->S().counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
@@ -2801,6 +2890,51 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 			} else {
 				HIP_TRY(hipMemcpy(ctx->hits.p + n, ctx->h_hits + n, extra.size() * sizeof(tnt_hit), hipMemcpyHostToDevice), ctx->err);
 			}
+		}
+	}
+	{ // alignment texts beyond TNT_ALIGN_TEXT (oligos of more than 64 bases) follow their records to the host
+		const int lrc = fetch_long_texts(ctx, cnt[C_LTEXT]);
+		if (lrc) return lrc;
+	}
+	if (ctx->long_probes && n_unique) {
+		// A probe of more than 128 bases is seeded in segments (virtual assays): a site found through two segments is reported
+		// by both.  hybrid() keeps, per strand, one record per footprint -- the one first in oligo_info::operator< order, i.e.
+		// with the highest Tm (bind_oligo.cpp:431-453): the same rule across the segments.
+		std::vector<uint32_t> order(n_unique);
+		for (size_t i = 0; i < n_unique; i++) order[i] = uint32_t(i);
+		const tnt_hit *H = ctx->h_hits;
+		auto key_less = [H](uint32_t x, uint32_t y) {
+			const tnt_hit &a = H[x], &b = H[y];
+			if (a.degen_id != b.degen_id) return a.degen_id < b.degen_id;
+			if (a.seq_index != b.seq_index) return a.seq_index < b.seq_index;
+			if (a.probe_strand != b.probe_strand) return a.probe_strand < b.probe_strand;
+			if (a.probe_start != b.probe_start) return a.probe_start < b.probe_start;
+			if (a.probe_stop != b.probe_stop) return a.probe_stop < b.probe_stop;
+			return a.probe_tm > b.probe_tm;
+		};
+		std::vector<int32_t> long_ids; // degen_id of the assays whose probe is seeded in segments
+		for (size_t ai = 0; ai < ctx->n_input_assays; ai++)
+			if (ctx->h_segment[ai] >= 0) long_ids.push_back(ctx->h_assays[ai].degen_id);
+		std::sort(long_ids.begin(), long_ids.end());
+		auto segmented = [&](const tnt_hit &h) { return !h.has_primers && std::binary_search(long_ids.begin(), long_ids.end(), h.degen_id); };
+		std::stable_sort(order.begin(), order.end(), key_less);
+		std::vector<char> drop(n_unique, 0);
+		size_t n_drop = 0;
+		for (size_t i = 1; i < n_unique; i++) {
+			const tnt_hit &a = H[order[i - 1]], &b = H[order[i]];
+			if (segmented(b) && a.degen_id == b.degen_id && a.seq_index == b.seq_index && a.probe_strand == b.probe_strand && a.probe_start == b.probe_start &&
+			    a.probe_stop == b.probe_stop && !a.has_primers)
+				drop[order[i]] = 1, n_drop++;
+		}
+		if (n_drop) {
+			size_t o = 0;
+			for (size_t i = 0; i < n_unique; i++)
+				if (!drop[i]) {
+					if (o != i) memcpy(&ctx->h_hits[o], &ctx->h_hits[i], sizeof(tnt_hit));
+					o++;
+				}
+			n_unique = o;
+			HIP_TRY(hipMemcpy(ctx->hits.p, ctx->h_hits, n_unique * sizeof(tnt_hit), hipMemcpyHostToDevice), ctx->err); // (the device view and the compact form follow)
 		}
 	}
 	// stage timings
@@ -3397,7 +3531,7 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 	for (size_t i = 0; i < n; i++) {
 		const tnt_bind_req &r = req[i];
 		const size_t t = size_t(r.seq_index) - db->first_seq_index;
-		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc > 127 ||
+		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc >= TNT_MAX_OLIGO ||
 		    r.target_loc < 0 || !(r.ct > 0.0f)) {
 			ctx->err = "bad bind request";
 			return TNT_E_ARG;
@@ -3410,7 +3544,8 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		slots[i].bucket_general = bucket_of(pick_lmax(ctx->oligos[r.oligo].size()));
 		items[i].target = uint32_t(t);
 		items[i].tloc = uint32_t(r.target_loc);
-		items[i].info = uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT);
+		slots[i].qloc_bias = r.query_loc & ~127; // (a work item holds seven bits of the word index)
+		items[i].info = uint32_t(r.query_loc & 127) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT);
 		items[i].group = 0;
 	}
 	DevBuf<Slot> dslots;
@@ -3454,6 +3589,8 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		ctx->err = err_text(cnt[C_ERR]);
 		return TNT_E_LIMIT;
 	}
+	rc = fetch_long_texts(ctx, cnt[C_LTEXT]); // (tnt_bind::align of a long alignment refers to them: tnt_long_text)
+	if (rc) return rc;
 	if (route != TNT_ROUTE_UNIT && route != TNT_ROUTE_WAVE_UNIT) {
 		// what the throughput instances leave behind: a status per request and, for bound ones, the pool record
 		std::vector<int32_t> res(n);
@@ -3525,7 +3662,7 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 	for (size_t i = 0; i < n; i++) {
 		const tnt_bind_req &r = req[i];
 		const size_t t = size_t(r.seq_index) - db->first_seq_index;
-		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc > 127 ||
+		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc >= TNT_MAX_OLIGO ||
 		    r.target_loc < 0 || !(r.ct > 0.0f)) {
 			ctx->err = "bad bind request";
 			return TNT_E_ARG;
@@ -3585,7 +3722,8 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 		return TNT_E_ARG;
 	}
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	const int struct_rows = (strlen(oa) > 64 || (ob && strlen(ob) > 64)) ? MAX_OLIGO : 64; // which unit-level instance
+	const size_t struct_len = std::max(strlen(oa), ob ? strlen(ob) : size_t(0));
+	const int struct_rows = struct_len <= 64 ? 64 : (struct_len <= size_t(MAX_LANE_OLIGO) ? MAX_LANE_OLIGO : int(std::min<size_t>(struct_len, MAX_OLIGO))); // which unit-level instance
 	int rc = ensure_work_buffers(ctx, struct_rows);
 	if (rc) return rc;
 	const char *seqs[2] = {oa, ob};
@@ -3596,7 +3734,7 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	for (int o = 0; o < n_ol; o++) {
 		const size_t L = strlen(seqs[o]);
 		if (L == 0 || L > size_t(TNT_MAX_OLIGO)) {
-			ctx->err = "oligo length must be 1..128";
+			ctx->err = "oligo length must be 1..1024";
 			return TNT_E_LIMIT;
 		}
 		len[o] = int(L);
@@ -3652,6 +3790,31 @@ int tnt_oligo_structure(tnt_ctx *ctx, const char *oa, const char *ob, float ct_a
 	*homodimer_a = full[1].tm;
 	if (ob) *heterodimer_ab = full[2].tm;
 	return TNT_OK;
+}
+
+int tnt_long_text(tnt_ctx *ctx, const char *field, char *buf, size_t cap)
+{
+	if (!field || !buf || cap == 0) return TNT_E_ARG;
+	const char *src = field;
+	size_t n = 0;
+	if (static_cast<unsigned char>(field[0]) == 0x7Fu && field[1] == 'L' && field[2] == 'T') { // a reference into the long-text arena
+		if (!ctx) return TNT_E_ARG;
+		unsigned long off = 0, len = 0;
+		for (int i = 0; i < 8; i++) off = off * 16 + (unsigned long)(field[3 + i] <= '9' ? field[3 + i] - '0' : field[3 + i] - 'a' + 10);
+		for (int i = 0; i < 6; i++) len = len * 16 + (unsigned long)(field[11 + i] <= '9' ? field[11 + i] - '0' : field[11 + i] - 'a' + 10);
+		if (off + len > ctx->h_ltext.size()) {
+			ctx->err = "tnt_long_text: the reference is older than the context's last search / bind call";
+			return TNT_E_ARG;
+		}
+		src = ctx->h_ltext.data() + off;
+		n = len;
+	} else {
+		n = strnlen(field, TNT_ALIGN_TEXT);
+	}
+	if (n + 1 > cap) return TNT_E_LIMIT;
+	memcpy(buf, src, n);
+	buf[n] = 0;
+	return int(n);
 }
 
 int tnt_hit_sequence(tnt_ctx *ctx, tnt_db *db, const tnt_hit *hit, char *buf, size_t cap)

@@ -21,7 +21,8 @@
 // contexts take turns).
 class HostPool
 {
-	std::mutex run_mu, mu;
+	std::mutex run_mu, mu, err_mu;
+	std::string error; // what a worker's job threw during the current run (the first one)
 	std::condition_variable cv_work, cv_done;
 	std::vector<pthread_t> th;
 	const std::function<void(size_t)> *fn = nullptr;
@@ -46,7 +47,17 @@ class HostPool
 			if (stop) return;
 			seen = generation;
 			lk.unlock();
-			for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) (*fn)(i);
+			for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+				try { // (an exception that leaves a thread's start function ends the process: pair_group allocates)
+					(*fn)(i);
+				} catch (const std::exception &e) {
+					std::lock_guard<std::mutex> g(err_mu);
+					if (error.empty()) error = e.what();
+				} catch (...) {
+					std::lock_guard<std::mutex> g(err_mu);
+					if (error.empty()) error = "unknown exception";
+				}
+			}
 			lk.lock();
 			if (--busy == 0) cv_done.notify_all();
 		}
@@ -74,13 +85,18 @@ public:
 		start();
 		return unsigned(th.size());
 	}
-	// false: no worker thread could be started (f needs the large stack, it must not run on the caller's)
-	bool run(size_t count, const std::function<void(size_t)> &f)
+	// false: no worker thread could be started (f needs the large stack, it must not run on the caller's), or a job threw
+	// (*why says what)
+	bool run(size_t count, const std::function<void(size_t)> &f, std::string *why = nullptr)
 	{
 		std::lock_guard<std::mutex> g(run_mu);
 		start();
-		if (th.empty()) return false;
+		if (th.empty()) {
+			if (why) *why = "no worker thread with a list-sized stack could be started";
+			return false;
+		}
 		if (count == 0) return true;
+		error.clear();
 		std::unique_lock<std::mutex> lk(mu);
 		fn = &f;
 		n = count;
@@ -90,6 +106,10 @@ public:
 		cv_work.notify_all();
 		cv_done.wait(lk, [&] { return busy == 0; });
 		fn = nullptr;
+		if (!error.empty()) {
+			if (why) *why = "a pairing job failed: " + error;
+			return false;
+		}
 		return true;
 	}
 
@@ -104,7 +124,10 @@ private:
 		const unsigned want = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
 		pthread_attr_t attr;
 		pthread_attr_init(&attr);
-		pthread_attr_setstacksize(&attr, size_t(512) << 20); // address space, not memory: pages are touched as far as a list reaches
+		// address space, not memory: pages are touched as far as a list reaches.  pair_group<PAIR_HOST> keeps about 190 MB of
+		// lists on its stack at the largest list (a million entries: the list, its order keys, four hash-overload lists and the
+		// scratch copies of cull / bind_step / list_sort): 256 MB per worker, 32 GB of address space for 128 of them
+		pthread_attr_setstacksize(&attr, size_t(256) << 20);
 		for (unsigned w = 0; w < want; w++) {
 			pthread_t t;
 			if (pthread_create(&t, &attr, worker_main, this) == 0) th.push_back(t);
@@ -440,8 +463,9 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		p.unit_target = unit_target.data();
 		p.unit_own_lo = own_lo.data();
 		p.unit_own_hi = own_hi.data();
-		if (!workers.run(groups.size(), [&](size_t g) { pair_group<PAIR_HOST>(p, groups[g]); })) {
-			ctx->err = "could not start a host thread for the lists of long targets";
+		std::string why;
+		if (!workers.run(groups.size(), [&](size_t g) { pair_group<PAIR_HOST>(p, groups[g]); }, &why)) {
+			ctx->err = "the lists of long targets: " + why;
 			return TNT_E_DEVICE;
 		}
 		if ((err & ERR_HIT_OVERFLOW) && hit_cap < UINT32_MAX) {

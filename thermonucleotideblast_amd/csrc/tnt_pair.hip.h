@@ -103,6 +103,10 @@ TNT_HD inline void copy_text(char *dst, const char *src)
 	dst[i] = 0;
 }
 
+// hybrid_sig keeps its mismatch / gap / clamp counts in int8_t (hybrid_sig.h:121-164): a count beyond 127 -- a probe of
+// several hundred bases -- comes out of the reference wrapped, and so out of here
+TNT_HD inline int32_t wrap8(int32_t v) { return int32_t(int8_t(uint8_t(uint32_t(v)))); }
+
 TNT_HD inline void init_hit(Hit &h, const AssayDev &A, int seq_index)
 {
 	// hybrid_sig::init(), hybrid_sig.h:54-110
@@ -730,9 +734,9 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				h.forward_tm = fo.tm, h.reverse_tm = ro.tm;
 				h.forward_dH = fo.dH, h.reverse_dH = ro.dH;
 				h.forward_dS = fo.dS, h.reverse_dS = ro.dS;
-				h.forward_mm = fo.mm, h.reverse_mm = ro.mm;
-				h.forward_gap = fo.gap, h.reverse_gap = ro.gap;
-				h.forward_primer_clamp = fo.a3, h.reverse_primer_clamp = ro.a3;
+				h.forward_mm = wrap8(fo.mm), h.reverse_mm = wrap8(ro.mm);
+				h.forward_gap = wrap8(fo.gap), h.reverse_gap = wrap8(ro.gap);
+				h.forward_primer_clamp = wrap8(fo.a3), h.reverse_primer_clamp = wrap8(ro.a3);
 
 				if (has_probe) {
 					for (int p = f + 1; p < r; p++) {
@@ -750,7 +754,7 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 						*out = h;
 						out->probe_start = P.loc5, out->probe_stop = P.loc3;
 						out->probe_tm = bp.tm, out->probe_dH = bp.dH, out->probe_dS = bp.dS;
-						out->probe_mm = bp.mm, out->probe_gap = bp.gap;
+						out->probe_mm = wrap8(bp.mm), out->probe_gap = wrap8(bp.gap);
 						out->probe_strand = (P.mask & MPLUS) ? 0 : 1;
 						copy_text(out->forward_align, fo.text);
 						copy_text(out->reverse_align, ro.text);
@@ -804,7 +808,7 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				if (!out) return;
 				init_hit(*out, A, seq_index);
 				out->probe_tm = b.tm, out->probe_dH = b.dH, out->probe_dS = b.dS;
-				out->probe_mm = b.mm, out->probe_gap = b.gap;
+				out->probe_mm = wrap8(b.mm), out->probe_gap = wrap8(b.gap);
 				out->probe_start = e.loc5, out->probe_stop = e.loc3;
 				out->probe_strand = pass == 0 ? 1 : 0;
 				copy_text(out->probe_align, b.text);
@@ -837,10 +841,10 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				out->forward_tm = bd.tm, out->reverse_tm = bu.tm;
 				out->forward_dH = bd.dH, out->reverse_dH = bu.dH;
 				out->forward_dS = bd.dS, out->reverse_dS = bu.dS;
-				out->forward_mm = bd.mm, out->reverse_mm = bu.mm;
-				out->forward_gap = bd.gap, out->reverse_gap = bu.gap;
-				out->forward_primer_clamp = bd.a3;
-				out->reverse_primer_clamp = bu.a5;
+				out->forward_mm = wrap8(bd.mm), out->reverse_mm = wrap8(bu.mm);
+				out->forward_gap = wrap8(bd.gap), out->reverse_gap = wrap8(bu.gap);
+				out->forward_primer_clamp = wrap8(bd.a3);
+				out->reverse_primer_clamp = wrap8(bu.a5);
 				copy_text(out->forward_align, bd.text);
 				copy_text(out->reverse_align, bu.text);
 			}

@@ -37,11 +37,14 @@
 
 namespace tnt {
 
-// wavefronts (= targets in flight) per workgroup.  LTAB (round 4): the chunk's bucket offsets sit in LDS (32 KB at k = 7, staged
-// once per launch) and ONE 1024-thread workgroup per CU shares them -- the scan's sixteen gathers per lane and sweep become LDS
-// reads (the scan on its own: 0.28 ms per pass over config 2 against 1.0 ms inside the kernel with the table behind L1 / L2);
-// the same 16 wavefronts per CU fit next to the table because two per-wavefront arrays share their space with others that are
-// dead while they are in use (the target's words with the extreme keys, the emission's scratch words with the candidate list).
+// wavefronts (= targets in flight) per workgroup.  LTAB (round 4, opt-in: TNT_MI355X_SEED2_LDS_TABLE): the chunk's bucket offsets
+// sit in LDS (32 KB at k = 7, staged once per launch) and ONE 1024-thread workgroup per CU shares them -- the scan's sixteen
+// gathers per lane and sweep become LDS reads; the same 16 wavefronts per CU fit next to the table because two per-wavefront
+// arrays share their space with others that are dead while they are in use (the target's words with the extreme keys, the
+// emission's scratch words with the candidate list).  The scan on its own runs 3.6 x faster that way (0.28 ms per pass over
+// config 2, tnt_seed_scan_only) -- the whole kernel runs SLOWER (config 2: 5.9 against 5.3 ms; config 4, sixteen chunk launches
+// per batch: 50.7 against 37.2 ms per 100 k targets): the table reads were hitting L1 anyway, and a 1024-thread workgroup only
+// starts when a whole CU has drained.  Kept as an instance, not used by default.
 constexpr int s2_waves(bool ltab) { return ltab ? 16 : 4; }
 constexpr int S2_TAB_WORDS = (1 << 14) + 2; // bucket offsets of a chunk for hash words of up to 7 bases
 constexpr int S2_CAP = 512;            // seeds of one target x one assay chunk held in LDS

@@ -25,14 +25,12 @@
 namespace tnt {
 
 constexpr int WB_CODE_SHIFT = 11;                                          // a maximal cell is (i << 11) | j: i <= 1024, j <= 1032
-constexpr bool wb_trace_lds(int R) { return R <= 2; }
 constexpr int wb_trace_pitch(int R) // bytes between two rows of the trace array: lanes write R rows apart, (R * pitch - 1) / 4 odd spreads them over the banks
 {
 	int p = 64 * R + 2 * FLANK;
 	if (R == 1) while ((p - 1) % 8 != 4) p++;
 	return p;
 }
-constexpr size_t wb_slab_bytes(int R) { return wb_trace_lds(R) ? 0 : size_t(64 * R) * size_t(64 * R + 2 * FLANK); } // HBM trace per wavefront
 
 // v_mov_b32_dpp wave_shr:1: lane l takes src of lane l - 1, lane 0 keeps `first`
 __device__ __forceinline__ int wave_shr1(int first, int src) { return __builtin_amdgcn_update_dpp(first, src, 0x138, 0xf, 0xf, false); }
@@ -54,7 +52,7 @@ template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void 
 	constexpr int NCOLS = LMAX + WMAX + 4;
 	constexpr bool TLDS = wb_trace_lds(R);
 	constexpr int PITCH = wb_trace_pitch(R);
-	static_assert(LMAX <= MAX_OLIGO || R == 1, "rows beyond TNT_MAX_OLIGO");
+	static_assert(LMAX <= MAX_OLIGO, "rows beyond TNT_MAX_OLIGO");
 
 	// tables: the general planes of bind_kernel (any target base): plane 0 delta_g(prev, cur), plane 1 term(cur), index
 	// ((x' * 7 + x) * 49 + q' * 7 + q); term[] by pair
@@ -129,7 +127,7 @@ template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void 
 		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
 		const int L = a.olig_len[slot.oligo];
 		const bool minus = (it.info & ITEM_MINUS) != 0;
-		const int qloc = int(it.info & 127u);
+		const int qloc = int(it.info & 127u) + slot.qloc_bias;
 		const int xmode = FULL ? int((it.target >> 29) & 3u) : 0; // 0 window of a packed target, 1 heterodimer, 2 homodimer, 3 hairpin
 		const uint32_t tlen = (FULL && xmode) ? 0u : a.db.len[it.target];
 		int start = int(it.tloc) - (qloc + FLANK); // bind_oligo.cpp:502-505

@@ -1,5 +1,6 @@
 // tnt_wbind_inst.hip -- instances of the wavefront-per-window bind kernel (tnt_wbind.hip.h): rows per lane 1 (oligos up to
-// 64 bases), 2 (up to 128); the throughput form and the unit-level form (FULL: any request kind, dp_max / n_max reported).
+// 64 bases), 2 (up to 128), 4 / 8 / 16 (up to 256 / 512 / 1 024: the lengths only this kernel binds); the throughput form
+// and the unit-level form (FULL: any request kind, dp_max / n_max reported).
 #include "tnt_wbind.hip.h"
 
 namespace tnt {

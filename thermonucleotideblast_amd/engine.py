@@ -98,6 +98,7 @@ def load_library():
     lib.tnt_db_ingest_timing.argtypes = [C.c_void_p, P(abi.tnt_ingest_timing)]
     lib.tnt_oligo_structure.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
     lib.tnt_db_skip_targets.argtypes = [C.c_void_p, C.c_void_p, P(C.c_uint8), C.c_size_t]
+    lib.tnt_long_text.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
     lib.tnt_seed_scan_only.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_float), P(C.c_uint64)]
     lib.tnt_search_collect_compact.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t), P(C.c_size_t)]
     lib.tnt_device_count.restype = C.c_int
@@ -123,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "tnt_last_timing", "tnt_seeds", "tnt_first_cull", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
     "tnt_db_create_from_fasta", "tnt_db_load_fasta", "tnt_db_defline", "tnt_db_target_info", "tnt_db_target_codes", "tnt_db_ingest_timing",
     "tnt_fasta_open", "tnt_fasta_next", "tnt_fasta_close",
-    "tnt_seed_scan_only", "tnt_search_collect_compact", "tnt_device_count", "tnt_gang_create", "tnt_gang_destroy", "tnt_gang_transport", "tnt_gang_last_error", "tnt_gang_gather",
+    "tnt_long_text", "tnt_seed_scan_only", "tnt_search_collect_compact", "tnt_device_count", "tnt_gang_create", "tnt_gang_destroy", "tnt_gang_transport", "tnt_gang_last_error", "tnt_gang_gather",
 ]
 
 
@@ -315,6 +316,18 @@ class Engine:
         out = (abi.tnt_hit * n.value)()
         C.memmove(out, view, C.sizeof(abi.tnt_hit) * n.value)
         return out
+
+    def long_text(self, field):
+        """The text of an alignment field (bytes of tnt_hit::*_align / tnt_bind::align): the field itself, or the text the context
+        keeps for an alignment that does not fit TNT_ALIGN_TEXT (tnt_long_text)."""
+        raw = bytes(field)
+        if not raw.startswith(b"\x7fLT"):
+            return raw.split(b"\0", 1)[0].decode("latin-1")
+        buf = C.create_string_buffer(8192)
+        n = self.lib.tnt_long_text(self._h, raw, buf, len(buf))
+        if n < 0:
+            raise TntError("tnt_long_text failed (%d)" % n)
+        return buf.raw[:n].decode("latin-1")
 
     def scan_only(self, batch, repeats=5):
         """(ms per pass, raw candidates per pass) of the seed stage's scan on its own (tnt_seed_scan_only)."""

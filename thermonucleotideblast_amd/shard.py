@@ -239,12 +239,21 @@ def finish_compact(st):
     collective = dist.is_initialized() and (world > 1 or st.padded is not None or st.reqs or st.recv)
     parts = None
     if collective and st.mode == "exact":
-        failed = st.failed
-        for r in st.reqs:
-            try:
-                r.wait()
-            except Exception:
-                failed = True
+        # The ranks first agree on whether every transfer could be POSTED, before any of them waits: a rank whose isend
+        # raised leaves the root's irecv without a partner, and the root would sit in wait() in front of the agreement
+        # (gloo for ever, RCCL until its watchdog).  What this cannot repair: the orphaned irecv stays posted, so a
+        # one-sided failure is only survivable where the backend lets a later collective overtake it (gloo does; with RCCL
+        # point-to-point operations and collectives of a communicator are sequenced and the run ends at the watchdog).  The
+        # padded gather is the default for that reason; the exact form is an option for uniform, healthy fabrics.
+        posted = torch.tensor([1 if st.failed else 0], dtype=torch.int64, device=st.device)
+        dist.all_reduce(posted, op=dist.ReduceOp.MAX)
+        failed = bool(int(posted.item()))
+        if not failed:
+            for r in st.reqs:
+                try:
+                    r.wait()
+                except Exception:
+                    failed = True
         flag = torch.tensor([1 if failed else 0], dtype=torch.int64, device=st.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):  # some rank could not send or receive: every rank repeats the transfer as one padded gather
