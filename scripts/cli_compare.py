@@ -63,6 +63,9 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     ("long_probes", "probe", 60, 6, 31, ["-E", "45"]),
     ("long_padlock_arms", "padlock", 60, 6, 33, ["-A", "PADLOCK", "-E", "45"]),
     ("long_primer", "pcr", 60, 6, 34, ["-e", "45"]),
+    # hybridisation probes of more than 128 bases (tests/longwl.py make_beyond_128): the wavefront-per-window kernel, seeds in
+    # segments, alignment texts far beyond the 448-byte fields of a hit
+    ("probes_beyond_128", "beyond128", 10, 3, 36, ["-A", "PROBE", "-E", "50"]),
     # row a6: the probe of every TaqMan assay is also the forward primer of a PCR assay listed next to it -- one oligo string under
     # two strand concentrations / threshold sets: the reference's per-target BindCache decides (the library replays it)
     ("shared_oligos", 3, 250, 10, 35, ["-e", "45", "-E", "30", "--primer-clamp", "2", "--probe-clamp5", "1"]),
@@ -82,7 +85,10 @@ def closing_lines(stdout):
 
 
 def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False, name=None):
-    wl = longwl.make(cfg, seed, n_targets=nt) if isinstance(cfg, str) else synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
+    if cfg == "beyond128":
+        wl = longwl.make_beyond_128(seed, lengths=(150, 320, 700), n_targets=nt, tl=2200)
+    else:
+        wl = longwl.make(cfg, seed, n_targets=nt) if isinstance(cfg, str) else synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
     offsets = wl.offsets
     if long_target or name in LONG_RECORDS:  # the first records become one
         k = LONG_RECORDS.get(name, 150)

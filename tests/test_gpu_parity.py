@@ -401,7 +401,7 @@ def test_long_oligos_vs_oracle(Engine, oracle, kind, seed, monkeypatch):
         assert not bad, (route, len(bad), bad[:3])
     db.close()
     e.close()
-    too_long = [synth.ExpandedAssay(0, 0, None, None, "ACGT" * 32 + "A")]
+    too_long = [synth.ExpandedAssay(0, 0, None, None, "ACGT" * 256 + "A")]  # beyond the reference's MAX_SEQUENCE_LENGTH too
     with pytest.raises(Exception):
         Engine(wl.options, too_long)
 
@@ -1402,7 +1402,7 @@ def test_oligos_beyond_128_bases_vs_oracle(Engine, oracle, seed, lengths):
     hits = e.search(db)
     assert tc.sorted_hit_keys(hits, text_of=e.long_text) == want and len(want) >= 6
     full = [e.long_text(bytes(h.probe_align)) for h in hits]
-    assert max(len(t) for t in full) > 3 * max(lengths)  # three lines of more than the probe's length: far beyond the 448-byte field
+    assert max(len(t) for t in full) > 2 * abi.TNT_ALIGN_TEXT  # (three lines of hundreds of columns: far beyond the 448-byte field)
     oligos = sorted({x.probe for x in wl.expanded})
     seeds = oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
     pick = seeds[::max(1, len(seeds) // 120)]

@@ -200,8 +200,10 @@ struct AssayDev {
 	int32_t slot_f, slot_r, slot_p; // Slot indices (or -1)
 	int32_t kind;                   // 0 PCR (amplicon), 1 padlock/MIPS, 2 probe (hybrid)
 	int32_t has_probe;
-	int32_t cache_replay;           // 1: one of its oligos is used under another strand concentration / threshold set elsewhere in the
-	                                // context: the assay is paired by the replay of the reference's BindCache (tnt_pair.hip.h, row a6)
+	int32_t cache_replay;           // bit 0: one of its oligos is used under another strand concentration / threshold set elsewhere in the
+	                                // context: the assay is paired by the replay of the reference's BindCache (tnt_pair.hip.h, row a6);
+	                                // bit 1: a probe of more than 128 bases seeded in segments (this assay is one of them): its hits carry
+	                                // the seed's diagonal in amplicon_start until the segments' hits are merged (tnt_host.hip)
 };
 
 // seed-table entry: one query word of one (assay, role, strand)

@@ -1379,10 +1379,10 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				if (opt->use_dinkelbach) FAIL(TNT_E_LIMIT, "--dinkelbach with an oligo longer than 64 bases");
 				const size_t n_words = L >= k ? L - k + 1 : 0, n_seg = (n_words + 127) / 128;
 				c->h_segment[i] = 0;
-				c->long_probes = true;
+				if (n_seg > 1) c->long_probes = true, c->h_assays[i].cache_replay |= 2;
 				for (size_t sg = 1; sg < n_seg; sg++) {
 					const size_t v = c->h_assays.size();
-					c->h_assays.push_back(d);
+					c->h_assays.push_back(c->h_assays[i]);
 					c->h_segment.push_back(int32_t(sg));
 					c->h_slots.resize((v + 1) * 3, Slot{-1, 0.0f, 0, int(v), 0, 0});
 					Slot sl = c->h_slots[size_t(d.slot_p)];
@@ -1547,8 +1547,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		// thresholds to it).  TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 keeps the uncached computation (every use on its own).
 		if (!getenv("TNT_MI355X_UNCACHED_SHARED_OLIGOS"))
 			for (const Slot &sl : c->h_slots)
-				if (sl.oligo >= 0 && shared[size_t(sl.oligo)] && c->h_assays[size_t(sl.assay)].kind != 2 && !c->h_assays[size_t(sl.assay)].cache_replay) {
-					c->h_assays[size_t(sl.assay)].cache_replay = 1;
+				if (sl.oligo >= 0 && shared[size_t(sl.oligo)] && c->h_assays[size_t(sl.assay)].kind != 2 && !(c->h_assays[size_t(sl.assay)].cache_replay & 1)) {
+					c->h_assays[size_t(sl.assay)].cache_replay |= 1;
 					c->n_cache_assays++;
 					c->cache_replay = true;
 				}
@@ -2530,6 +2530,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 	p.result = c->S().result.p;
 	p.pool = c->S().pool.p;
 	p.assays = c->assays.p;
+	p.slots = c->slots.p;
 	p.db = v;
 	p.max_len = c->opt.max_len;
 	p.single_primer_pcr = c->opt.single_primer_pcr;
@@ -2910,11 +2911,12 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 			if (a.probe_strand != b.probe_strand) return a.probe_strand < b.probe_strand;
 			if (a.probe_start != b.probe_start) return a.probe_start < b.probe_start;
 			if (a.probe_stop != b.probe_stop) return a.probe_stop < b.probe_stop;
-			return a.probe_tm > b.probe_tm;
+			if (a.probe_tm != b.probe_tm) return a.probe_tm > b.probe_tm;
+			return a.amplicon_start < b.amplicon_start; // the seed's diagonal (list order of the hash overload, bind_oligo.cpp:157)
 		};
 		std::vector<int32_t> long_ids; // degen_id of the assays whose probe is seeded in segments
 		for (size_t ai = 0; ai < ctx->n_input_assays; ai++)
-			if (ctx->h_segment[ai] >= 0) long_ids.push_back(ctx->h_assays[ai].degen_id);
+			if (ctx->h_assays[ai].cache_replay & 2) long_ids.push_back(ctx->h_assays[ai].degen_id);
 		std::sort(long_ids.begin(), long_ids.end());
 		auto segmented = [&](const tnt_hit &h) { return !h.has_primers && std::binary_search(long_ids.begin(), long_ids.end(), h.degen_id); };
 		std::stable_sort(order.begin(), order.end(), key_less);
@@ -2926,16 +2928,16 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 			    a.probe_stop == b.probe_stop && !a.has_primers)
 				drop[order[i]] = 1, n_drop++;
 		}
-		if (n_drop) {
-			size_t o = 0;
-			for (size_t i = 0; i < n_unique; i++)
-				if (!drop[i]) {
-					if (o != i) memcpy(&ctx->h_hits[o], &ctx->h_hits[i], sizeof(tnt_hit));
-					o++;
-				}
-			n_unique = o;
-			HIP_TRY(hipMemcpy(ctx->hits.p, ctx->h_hits, n_unique * sizeof(tnt_hit), hipMemcpyHostToDevice), ctx->err); // (the device view and the compact form follow)
-		}
+		size_t o = 0;
+		for (size_t i = 0; i < n_unique; i++)
+			if (!drop[i]) {
+				if (o != i) memcpy(&ctx->h_hits[o], &ctx->h_hits[i], sizeof(tnt_hit));
+				if (segmented(ctx->h_hits[o])) ctx->h_hits[o].amplicon_start = 0; // (it carried the seed's diagonal up to here)
+				o++;
+			}
+		n_unique = o;
+		(void)n_drop;
+		HIP_TRY(hipMemcpy(ctx->hits.p, ctx->h_hits, n_unique * sizeof(tnt_hit), hipMemcpyHostToDevice), ctx->err); // (the device view and the compact form follow)
 	}
 	// stage timings
 	tnt_timing &T = ctx->timing;

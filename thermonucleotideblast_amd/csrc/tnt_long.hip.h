@@ -449,6 +449,7 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		p.result = result;
 		p.pool = pool;
 		p.assays = ctx->h_assays.data();
+		p.slots = ctx->h_slots.data();
 		p.db.first_seq_index = db->first_seq_index;
 		p.max_len = ctx->opt.max_len;
 		p.single_primer_pcr = ctx->opt.single_primer_pcr;

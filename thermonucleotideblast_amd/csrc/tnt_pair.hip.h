@@ -574,7 +574,7 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 	const uint32_t n_active = *a.n_active;
 	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS) {
 		const Group G = a.groups[a.active[gi]];
-		if (a.citems && a.assays[G.assay & GROUP_ASSAY_MASK].cache_replay) continue; // paired by cache_replay_kernel
+		if (a.citems && (a.assays[G.assay & GROUP_ASSAY_MASK].cache_replay & 1)) continue; // paired by cache_replay_kernel
 		const uint32_t count = G.count & ~GROUP_ALIVE;
 		// every group is paired by the smallest instance that holds it
 		const int fits = count <= uint32_t(PAIR_SMALL) ? PAIR_SMALL : (count <= uint32_t(PAIR_MAX) ? PAIR_MAX : PAIR_BIG);
@@ -626,6 +626,9 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 		}
 		Entry &e = l.e[i];
 		e.tloc = it.tloc;
+		// a probe seeded in segments (oligos beyond 128 bases): the entry carries its diagonal (query word - target position, over
+		// the whole oligo) to the hit, where the merge of the segments' hits needs it (the hash-overload lists never look at tloc)
+		if (A.kind == 2 && (A.cache_replay & 2)) e.tloc = uint32_t(int32_t(it.info & 127u) + a.slots[it.info >> ITEM_SLOT_SHIFT].qloc_bias - int32_t(it.tloc));
 		e.rec = CACHED ? res : (res >= 0 ? res : -1);
 		e.loc5 = e.loc3 = 0;
 		const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u;
@@ -811,6 +814,7 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				out->probe_mm = wrap8(b.mm), out->probe_gap = wrap8(b.gap);
 				out->probe_start = e.loc5, out->probe_stop = e.loc3;
 				out->probe_strand = pass == 0 ? 1 : 0;
+				if (A.cache_replay & 2) out->amplicon_start = int32_t(e.tloc); // (the diagonal: read and cleared by the merge of the segments' hits)
 				copy_text(out->probe_align, b.text);
 			}
 		}
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void cache_collect_kernel(CacheCollectArgs a)
 			const uint32_t gi = s * a.seg_size + i;
 			const Group G = a.groups[gi];
 			const uint32_t assay = G.assay & GROUP_ASSAY_MASK;
-			if (!a.assays[assay].cache_replay) continue;
+			if (!(a.assays[assay].cache_replay & 1)) continue;
 			const uint32_t count = G.count & ~GROUP_ALIVE;
 			const uint32_t slot = atomicAdd(a.n_groups, 1u);
 			const uint32_t cf = atomicAdd(a.n_items, count);

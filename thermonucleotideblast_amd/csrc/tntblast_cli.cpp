@@ -398,9 +398,28 @@ struct Record { // a hit with what the writer needs beside the tnt_hit payload
 	tnt_hit h;
 	size_t order; // position in the device output (ties keep it: std::list::sort is stable)
 	std::string amplicon, defline; // taken while the batch of targets that produced the hit is still resident
+	std::string long_align[3];     // alignments that do not fit the hit's 448-byte fields (oligos beyond 64 bases), read through tnt_long_text then too
+	const char *align(int which) const // 0 forward, 1 reverse, 2 probe
+	{
+		if (!long_align[which].empty()) return long_align[which].c_str();
+		return which == 0 ? h.forward_align : (which == 1 ? h.reverse_align : h.probe_align);
+	}
 	float min_tm() const { return std::min(h.forward_tm, h.reverse_tm); }
 	float max_tm() const { return std::max(h.forward_tm, h.reverse_tm); }
 };
+
+// an alignment field that only refers to its text (0x7F ...): fetch the text while the context still holds it
+void resolve_long_alignments(tnt_ctx *ctx, Record &rec)
+{
+	const char *field[3] = {rec.h.forward_align, rec.h.reverse_align, rec.h.probe_align};
+	for (int k = 0; k < 3; k++) {
+		if (static_cast<unsigned char>(field[k][0]) != 0x7Fu) continue;
+		std::vector<char> buf(1 << 14);
+		const int n = tnt_long_text(ctx, field[k], buf.data(), buf.size());
+		if (n < 0) fail("tnt_long_text failed");
+		rec.long_align[k].assign(buf.data(), size_t(n));
+	}
+}
 
 bool record_less(const Record &a, const Record &b) // hybrid_sig::operator< for equal ids, hybrid_sig.h:328-357
 {
@@ -502,21 +521,21 @@ template <class LEN> void uniquify_results(std::vector<Record> &m, LEN oligo_len
 					const bool primers_overlap = std::abs(A.h.amplicon_start - B.h.amplicon_start) < fl && std::abs(A.h.amplicon_stop - B.h.amplicon_stop) < rl;
 					if (primers_overlap) {
 						if (A.h.amplicon_start <= B.h.amplicon_start && A.h.amplicon_stop >= B.h.amplicon_stop &&
-						    top_strand(A.h.forward_align).find(top_strand(B.h.forward_align)) != std::string::npos &&
-						    top_strand(A.h.reverse_align).find(top_strand(B.h.reverse_align)) != std::string::npos)
+						    top_strand(A.align(0)).find(top_strand(B.align(0))) != std::string::npos &&
+						    top_strand(A.align(1)).find(top_strand(B.align(1))) != std::string::npos)
 							same = 1;
 						else if (B.h.amplicon_start <= A.h.amplicon_start && B.h.amplicon_stop >= A.h.amplicon_stop &&
-						         top_strand(B.h.forward_align).find(top_strand(A.h.forward_align)) != std::string::npos &&
-						         top_strand(B.h.reverse_align).find(top_strand(A.h.reverse_align)) != std::string::npos)
+						         top_strand(B.align(0)).find(top_strand(A.align(0))) != std::string::npos &&
+						         top_strand(B.align(1)).find(top_strand(A.align(1))) != std::string::npos)
 							same = 2;
 						if (A.h.has_probe && B.h.has_probe && (A.h.probe_start != B.h.probe_start || A.h.probe_stop != B.h.probe_stop)) same = 0;
 					}
 				} else {
 					if (A.h.probe_start <= B.h.probe_start && A.h.probe_stop >= B.h.probe_stop &&
-					    top_strand(A.h.probe_align).find(top_strand(B.h.probe_align)) != std::string::npos)
+					    top_strand(A.align(2)).find(top_strand(B.align(2))) != std::string::npos)
 						same = 1;
 					else if (B.h.probe_start <= A.h.probe_start && B.h.probe_stop >= A.h.probe_stop &&
-					         top_strand(B.h.probe_align).find(top_strand(A.h.probe_align)) != std::string::npos)
+					         top_strand(B.align(2)).find(top_strand(A.align(2))) != std::string::npos)
 						same = 2;
 				}
 				if (same == 0) continue;
@@ -1092,6 +1111,7 @@ int main(int argc, char **argv)
 				for (size_t i = 0; i < n_hits; i++) {
 					if (is_long[size_t(hits[i].seq_index) - first]) continue; // (none: skipped above)
 					Record rec{hits[i], n_seen++, std::string(), std::string()};
+					resolve_long_alignments(ctx, rec);
 					const int na = tnt_hit_sequence(ctx, db, &hits[i], amp.data(), amp.size());
 					if (na < 0) fail("amplicon longer than the sequence buffer");
 					rec.amplicon.assign(amp.data(), size_t(na));
@@ -1150,6 +1170,7 @@ int main(int argc, char **argv)
 							if (F.start != 0 && lo <= 0) continue;
 							if (F.stop != F.max_stop && hi >= int(F.len) - 1) continue;
 							Record rec{fh[i], n_seen++, std::string(), std::string()};
+							resolve_long_alignments(ctx, rec);
 							const int na = tnt_hit_sequence(ctx, fdb, &fh[i], amp.data(), amp.size());
 							if (na < 0) fail("amplicon longer than the sequence buffer");
 							rec.amplicon.assign(amp.data(), size_t(na));
@@ -1381,9 +1402,9 @@ int main(int argc, char **argv)
 					}
 				}
 				if (standard && opt.show_alignments) {
-					write_alignment(*out, fp + " align ", h.forward_align);
-					write_alignment(*out, rp + " align ", h.reverse_align);
-					write_alignment(*out, "probe align ", h.probe_align);
+					write_alignment(*out, fp + " align ", rec.align(0));
+					write_alignment(*out, rp + " align ", rec.align(1));
+					write_alignment(*out, "probe align ", rec.align(2));
 				}
 				if (opt.format & (Options::STANDARD | Options::FASTA)) {
 					*out << '>' << rec.defline;
