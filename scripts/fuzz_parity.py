@@ -29,9 +29,12 @@ def random_case(rng, case, max_code=18, dangle=True):
     if LONG_FRACTION > 0.0:  # (its own stream: the sequence of ordinary cases does not depend on the share)
         lrng = np.random.default_rng([case, 977])
         if lrng.random() < LONG_FRACTION:
-            kind = ("pcr", "probe", "padlock")[int(lrng.integers(0, 3))]
+            kind = ("pcr", "probe", "padlock", "beyond128")[int(lrng.integers(0, 4))]
             cfg = 2 if kind == "pcr" else 5
-            wl = longwl.make(kind, int(lrng.integers(1, 1 << 30)), n_targets=min(nt, 120))
+            if kind == "beyond128":  # probes of 129 to 600 bases: the wavefront-per-window kernel, seeds in segments, long texts
+                wl = longwl.make_beyond_128(int(lrng.integers(1, 1 << 30)), lengths=tuple(int(x) for x in lrng.integers(129, 600, 3)), n_targets=8, tl=1800)
+            else:
+                wl = longwl.make(kind, int(lrng.integers(1, 1 << 30)), n_targets=min(nt, 120))
             nt = wl.n_targets
     o = wl.options
     pick = lambda *v: v[int(rng.integers(0, len(v)))]  # noqa: E731
@@ -64,6 +67,8 @@ def random_case(rng, case, max_code=18, dangle=True):
         o.assay_format = int(pick(abi.ASSAY_PADLOCK, abi.ASSAY_PADLOCK, abi.ASSAY_MIPS))
     codes, offsets = wl.codes, wl.offsets
     shape = int(rng.integers(0, 5))
+    if shape == 2 and nt <= 21:  # (the few targets of a case with probes beyond 128 bases stay as they are)
+        shape = 0
     if shape == 1:   # ragged lengths incl. empty and shorter-than-word targets
         lens = np.minimum(rng.integers(0, 1000, nt), np.diff(offsets).astype(np.int64))
         lens[rng.integers(0, nt, 3)] = [0, 3, 6]
@@ -158,7 +163,7 @@ def main():
             from thermonucleotideblast_amd.engine import Engine
             eng = Engine(wl.options, wl.expanded)
             db = eng.pack(codes, offsets)
-            got = tc.sorted_hit_keys(eng.search(db))
+            got = tc.sorted_hit_keys(eng.search(db), text_of=eng.long_text)  # (alignments beyond the 448-byte fields: cut where the oracle cuts)
             db.close()
             eng.close()
         except Exception as e:
