@@ -6,7 +6,8 @@ import os
 import sys
 
 src = sys.argv[1]
-d = json.load(open(src))["kernels"]
+summary = json.load(open(src))
+d = summary["kernels"]
 stage = [k for k in ("bucket_kernel", "filter_kernel<L>", "bind_kernel<L>") if k in d]
 seed = "seed2_kernel" if "seed2_kernel" in d else "seed_kernel"  # (round 3: tnt_seed2.hip.h)
 fetch = sum(float(d[k]["FETCH_SIZE"]) for k in stage)   # KB per search (= per step of the full-size config)
@@ -16,6 +17,7 @@ dst = os.path.join(os.path.dirname(os.path.abspath(src)), "bind_pmc.json")
 if os.path.exists(dst):
     old = json.load(open(dst))
 out = {
+    "git_head": summary.get("git_head"),  # the build the counters were collected on (scripts/pmc_summarize.py reads .git_head)
     "source": "%s (rocprofv3 --pmc, separate passes, scripts/pmc_collect.sh 2 1000000, bind launches serialised on one stream)" % src,
     "kernel": "bind stage of one step (config 2, 1 000 000 x 1 kb targets): bucket_kernel + filter_kernel<L> + bind_kernel<L> on the survivors",
     "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
