@@ -684,7 +684,7 @@ def test_edge_cases(Engine, oracle):
     assert got == want and len(want) >= 3
     db.close()
     e.close()
-    # the longest oligos of the register-resident instances (64) and of the long ones (128) work, 129 fail loudly
+    # the longest oligos of the register-resident instances (64) and of the long ones (128) work, 1 025 fail loudly
     rng = np.random.default_rng(5)
     for n_long in (64, 128):
         long_o = "".join("ACGT"[i] for i in rng.integers(0, 4, n_long))
@@ -700,9 +700,7 @@ def test_edge_cases(Engine, oracle):
         e.close()
     from thermonucleotideblast_amd.engine import TntError
     with pytest.raises(TntError):
-        Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, long_o + "A")])
-    with pytest.raises(TntError):
-        Engine(abi.options_default(use_dinkelbach=1), [synth.ExpandedAssay(0, 0, None, None, long_o[:65])])
+        Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGT" * 256 + "A")])  # 1 025 bases
     with pytest.raises(TntError):
         Engine(abi.options_default(), [synth.ExpandedAssay(0, 0, None, None, "ACGTNACGTACGTACGT")])
 
@@ -1423,3 +1421,62 @@ def test_primers_beyond_128_bases_are_refused(Engine):
     F, R = synth._rand_oligo(rng, 140, 140), synth._rand_oligo(rng, 20, 20)
     with pytest.raises(TntError, match="probe"):
         Engine(abi.options_default(min_primer_tm=40.0), synth.expand_assays([synth.Assay("a", F, R, None)]))
+
+
+@pytest.mark.parametrize("kind,seed", [("probe", 1), ("padlock", 3), ("pcr", 4), ("beyond", 2)])
+def test_dinkelbach_with_long_oligos_vs_oracle(Engine, oracle, kind, seed):
+    """--dinkelbach with oligos of more than 64 bases: the lane-per-window Dinkelbach instances stop at 64 rows, longer
+    oligos take the wavefront-per-window kernel's Dinkelbach form (passes over the same window with the per-pass scores
+    rebuilt in LDS).  Search and unit-level binds == oracle (== reference, tests/test_oracle_vs_reference.py)."""
+    import longwl
+    wl = longwl.make(kind, seed) if kind != "beyond" else longwl.make_beyond_128(seed, lengths=(129, 200, 520), n_targets=10, tl=2400)
+    wl.options.use_dinkelbach = 1
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    assert tc.sorted_hit_keys(e.search(db), text_of=e.long_text) == want and len(want) >= 5
+    oligos = sorted({o for x in wl.expanded for o in (x.forward, x.reverse, x.probe) if o})
+    seeds = oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    pick = seeds[::max(1, len(seeds) // 300)]
+    om = {o: i for i, o in enumerate(e.oligos)}
+    want_b = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, tc.make_reqs((s[0], s[1], s[2], s[3], s[4], i % 2, 2.5e-7) for i, s in enumerate(pick)))
+    got_b = e.bind_batch(db, tc.make_reqs((s[0], om[oligos[s[1]]], s[2], s[3], s[4], i % 2, 2.5e-7) for i, s in enumerate(pick)))
+    assert sum(1 for w in want_b if w.status == 0) > 3
+    bad = [(i, gu.compare_bind(gu.bind_record(w), _bind_record_resolved(e, got_b[i]))) for i, w in enumerate(want_b)]
+    assert not [b for b in bad if b[1]], [b for b in bad if b[1]][:2]
+    db.close()
+    e.close()
+
+
+def test_cache_replay_of_crowded_targets(Engine, oracle):
+    """Row a6 at its capacity edges: ninety assays that share one primer with the probe of a TaqMan assay (every one of them goes
+    through the cache replay) all find their amplicons on the same targets -- more groups per target than one lane used to
+    hold --, and a low-complexity target gives one of those groups more than 64 items (the replay's instance for crowded
+    groups).  Search == oracle."""
+    rng = np.random.default_rng(2718)
+    F = synth._rand_oligo(rng, 20, 20)
+    Rs = [synth._rand_oligo(rng, 19, 22) for _ in range(90)]
+    P, F2, R2 = synth._rand_oligo(rng, 24, 24), synth._rand_oligo(rng, 20, 20), synth._rand_oligo(rng, 20, 20)
+    assays = [synth.Assay("pcr%d" % i, F, r, None) for i, r in enumerate(Rs[:45])]
+    assays.append(synth.Assay("taq", F2, R2, F))  # F as a probe: another strand concentration, other thresholds
+    assays += [synth.Assay("pcr%d" % (45 + i), F, r, None) for i, r in enumerate(Rs[45:])]
+    ex = synth.expand_assays(assays)
+    opt = abi.options_default(min_primer_tm=40.0, min_probe_tm=30.0, primer_clamp=1, probe_clamp_5=2)
+    filler = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    targets = []
+    for t in range(6):
+        seq = filler(30) + F + filler(40)
+        for r in Rs:
+            seq += synth.revcomp(r if t % 2 == 0 else synth._mutate(rng, r, 1)) + filler(int(rng.integers(5, 30)))
+        seq += F2 + filler(20) + synth.revcomp(F) + filler(25) + synth.revcomp(R2) + filler(10)
+        targets.append(seq)
+    # a crowded group: the shared primer's 3' half over and over (every copy seeds the primer), one reverse site behind them
+    targets.append(filler(20) + (F[8:] + "T") * 80 + filler(30) + synth.revcomp(Rs[0]) + filler(20))
+    codes, offsets = gu.pack_targets(targets)
+    want = tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets))
+    e = Engine(opt, ex)
+    db = e.pack(codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    assert got == want and len(want) > 200
+    db.close()
+    e.close()

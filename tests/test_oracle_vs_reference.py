@@ -233,3 +233,22 @@ def test_oligos_beyond_128_bases(ref, oracle, seed):
     assert a == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets)) and len(a) >= 3
     for o in oligos[:2]:
         assert ref.structure(wl.options, o, oligos[-1]) == oracle.structure(wl.options, o, oligos[-1])
+
+
+@pytest.mark.parametrize("kind,seed", [("probe", 1), ("pcr", 4), ("beyond", 2)])
+def test_dinkelbach_with_long_oligos(ref, oracle, kind, seed):
+    """--dinkelbach with oligos of 65 to 520 bases: binds and hits of the oracle against the reference (pins the checker
+    for the wavefront-per-window kernel's Dinkelbach form)."""
+    import longwl
+    wl = longwl.make(kind, seed) if kind != "beyond" else longwl.make_beyond_128(seed, lengths=(129, 200, 520), n_targets=10, tl=2400)
+    wl.options.use_dinkelbach = 1
+    oligos = sorted({o for e in wl.expanded for o in (e.forward, e.reverse, e.probe) if o})
+    sa = ref.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    pick = sa[::max(1, len(sa) // 300)]
+    reqs = tc.make_reqs((s[0], s[1], s[2], s[3], s[4], i % 2, 2.5e-7) for i, s in enumerate(pick))
+    ra = ref.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    rb = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    bad = [b for b in ((i, tc.bind_compare_fields(ra[i], rb[i])) for i in range(len(reqs))) if b[1]]
+    assert not bad, bad[:3]
+    a = tc.sorted_hit_keys(ref.search(wl.options, wl.expanded, wl.codes, wl.offsets, threads=2))
+    assert a == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets)) and len(a) >= 5

@@ -1389,7 +1389,8 @@ TNT_EXACT_LADDER(X)
 // the wavefront-per-window form (tnt_wbind.hip.h, instances in tnt_wbind_inst.hip): N = query rows per lane, oligos of up
 // to 64 * N bases; `full` = the unit-level form (any request kind, dp_max / n_max reported)
 #define TNT_WBIND_LADDER(X) X(1) X(2) X(4) X(8) X(16)
-#define X(N) void launch_wbind_##N(const BindArgs &a, int blocks, hipStream_t stream); void launch_wbind_full_##N(const BindArgs &a, int blocks, hipStream_t stream);
+#define X(N) void launch_wbind_##N(const BindArgs &a, int blocks, hipStream_t stream); void launch_wbind_full_##N(const BindArgs &a, int blocks, hipStream_t stream); \
+	void launch_wbind_dink_##N(const BindArgs &a, int blocks, bool full, hipStream_t stream);
 TNT_WBIND_LADDER(X)
 #undef X
 constexpr int wb_waves(int R) { return R == 1 ? 4 : (R == 2 ? 2 : 1); }    // wavefronts (= windows in flight) per workgroup

@@ -37,6 +37,9 @@ constexpr int FILT_PLANE = 28 * 64;              // entries per class (>= FILT_E
 constexpr int FILT_CLASSES = 2;                  // threshold sets by minimum Tm: primers, probes
 constexpr int FILT_UNITS = 1000;                 // table units per kcal/mol
 constexpr int FILT_NEG = -16384;                 // "not possible": -16.4 kcal/mol (a price no path that matters can pay) ...
+#ifndef TNT_FILT_UNPACK_MAX
+#define TNT_FILT_UNPACK_MAX 40
+#endif
 constexpr int FILT_SAT = 32767;                  // ... and the value sums saturate at: 32.8 kcal/mol, above every threshold
 
 // host-built tables of one context (tnt_host.hip, fill_filter_tables)
@@ -256,11 +259,14 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 		}
 		// The sweep, two columns per trip: the cells of a column live in one register each, (X, M2) as two 16-bit halves,
 		// and the two columns of a trip write alternate register sets (no copies at the back edge).  Per cell: one
-		// ds_read_b32 and four packed instructions --
+		// ds_read_b32 and three packed instructions --
 		//   a  = entry + (dX, dX)            v_pk_add_i16, saturating    (dX + stack, dX + loop entry)
 		//   m  = max(up, old)                v_pk_max_i16                high half: max(M2 above, M2 to the left)
-		//   n  = max(a, (m.hi, m.hi))        v_pk_max_i16                (X, M2) but for the diagonal's M2 ...
-		//   n  = max(n, diag)                v_pk_max_i16                ... which this adds (X >= dX anyway: stacks are >= 0)
+		//   n  = max(a, (m.hi, m.hi))        v_pk_max_i16                (X, M2)
+		// (the automaton's M2 also takes the diagonal neighbour's M2: that one is never above the M2 of the cell above, which
+		// has it as its left neighbour; round 4 dropped the instruction.  Packed-16 and SDWA forms issue at half the rate of a
+		// plain add, scripts/microbench/valu_rate.hip: the table address is a plain add of an unpacked row constant where the
+		// registers allow.)
 		// The maximum of X over the window needs no instruction per cell: X never decreases along a diagonal (the stack
 		// term is >= 0, also through the padding rows and columns), so it is reached in the last row or the last column.
 		const s2 EDGE = {0, short(FILT_NEG)}; // a cell outside the matrix: X = 0, M2 = none
@@ -272,19 +278,37 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 #pragma unroll
 		for (int i = 0; i < LMAX; i++) PA[i] = EDGE;
 		s2 bestpk = EDGE;
-		auto row_addr = [&](int i) __attribute__((always_inline)) { return int((Rpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 0xFFu); };
+		// short instances keep the row constants one per register (a full-rate add per cell instead of an SDWA byte select)
+		constexpr bool UNPACKED = LMAX <= TNT_FILT_UNPACK_MAX;
+		int Rrow[UNPACKED ? LMAX : 1];
+		if (UNPACKED) {
+#pragma unroll
+			for (int i = 0; i < LMAX; i++) Rrow[UNPACKED ? i : 0] = int((Rpk[i >> 2] >> ((i & 3) * 8)) & 0xFFu);
+		}
+		auto row_addr = [&](int i) __attribute__((always_inline)) {
+			if (UNPACKED) return Rrow[UNPACKED ? i - 1 : 0];
+			return int((Rpk[(i - 1) >> 2] >> (((i - 1) & 3) * 8)) & 0xFFu);
+		};
 		auto column = [&](const s2 *Pin, s2 *Pout, const int colbase) __attribute__((always_inline)) {
 			s2 e[LMAX];
 #pragma unroll
+#ifdef TNT_EXP_FILT_NOLDS
+			for (int i = 1; i <= LMAX; i++) { // timing experiment: the sweep without its table reads
+				const int ad = colbase + row_addr(i);
+				e[i - 1] = (s2){short(ad & 1023), short(ad >> 4)};
+			}
+#else
 			for (int i = 1; i <= LMAX; i++) e[i - 1] = *(lds_cs2 *)(uintptr_t(uint32_t(colbase + row_addr(i))));
+#endif
 			s2 D = EDGE, U = EDGE; // (1, j) sees the edge above it and diagonally
 #pragma unroll
 			for (int i = 1; i <= LMAX; i++) {
 				const s2 O = Pin[i - 1]; // (i, j-1)
 				const s2 sum = __builtin_elementwise_add_sat(e[i - 1], (s2){D.x, D.x});
 				const s2 m = __builtin_elementwise_max(U, O);
-				s2 n = __builtin_elementwise_max(sum, (s2){m.y, m.y});
-				n = __builtin_elementwise_max(n, D);
+				const s2 n = __builtin_elementwise_max(sum, (s2){m.y, m.y});
+				// (no maximum with the diagonal cell: its M2 is already inside U's -- the cell above took it in as ITS left
+				// neighbour --, and its X cannot exceed sum.x, stacks being >= 0)
 				Pout[i - 1] = n;
 				D = O, U = n;
 			}
@@ -294,8 +318,13 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void filter_ke
 		int tp = FILT_NONE;                          // no column before the first
 #pragma unroll 1
 		for (int j = 1; j <= Wwave; j += 2) {
+			if (UNPACKED) {
 #pragma unroll
-			for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
+				for (int i = 0; i < LMAX; i++) asm volatile("" : "+v"(Rrow[UNPACKED ? i : 0])); // (not re-derived from the packed form inside the loop)
+			} else {
+#pragma unroll
+				for (int w = 0; w < (LMAX + 3) / 4; w++) asm volatile("" : "+v"(Rpk[w])); // keep the row constants packed
+			}
 			const int t1 = j < W ? column_base(j + 1) : FILT_NONE;     // column j + 1 (none: behind the window, or padding of an odd width)
 			const int t2 = j + 1 < W ? column_base(j + 2) : FILT_NONE; // column j + 2
 			column(PA, INPLACE ? PA : PB, tab_base + (tp * FILT_X + t) * (NBP * 4));

@@ -804,9 +804,23 @@ void launch_wbind(tnt_ctx *c, const BindArgs &a, int rows, bool full, hipStream_
 void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_t stream = nullptr, int unit_rows = 0 /* 0: the context's */)
 {
 	if (!stream) stream = c->stream;
-	if (c->opt.use_dinkelbach) { // every bind through the 64-row general instances that iterate the temperature
-		if (lmax == 0) hipLaunchKernelGGL((bind_kernel<64, true, false, false, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
-		else hipLaunchKernelGGL((bind_kernel<64, false, false, false, true>), dim3(blocks), dim3(bind_threads(64)), 0, stream, a);
+	if (c->opt.use_dinkelbach) {
+		// every bind through an instance that iterates the temperature: the 64-row general lane instances, or -- oligos beyond 64
+		// bases -- the wavefront-per-window kernel, whose workgroup (one wavefront) rebuilds its delta_g planes per pass
+		const int rows = lmax == 0 ? (unit_rows ? unit_rows : c->unit_rows) : bucket_rows(lmax);
+		if (rows > 64) {
+			const int R = wb_rows_per_lane(rows), wblocks = c->n_cu * 6;
+			switch (R) {
+#define X(N) case N: tnt::launch_wbind_dink_##N(a, wblocks, lmax == 0, stream); break;
+				TNT_WBIND_LADDER(X)
+#undef X
+			default: break;
+			}
+		} else if (lmax == 0) {
+			hipLaunchKernelGGL((bind_kernel<64, true, false, false, true>), dim3(blocks), dim3(bind_threads(0)), 0, stream, a);
+		} else {
+			hipLaunchKernelGGL((bind_kernel<64, false, false, false, true>), dim3(blocks), dim3(bind_threads(64)), 0, stream, a);
+		}
 		return;
 	}
 	if (lmax == 0) { // unit-level API: the 64-row instance, the 128-row one, or the wavefront-per-window kernel when an oligo needs it
@@ -1001,7 +1015,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.best = c->best.p + size_t(lane) * c->lane_cols;
 		b.stack = c->stack.p + size_t(lane) * c->lane_cols;
 		b.ties = c->ties.p + size_t(lane) * c->lane_ties;
-		if ((c->bucket_lmax[i] & BUCKET_WAVE) || (c->wave_from && (c->bucket_lmax[i] & 0xFF) >= c->wave_from && !c->opt.use_dinkelbach))
+		if (!c->opt.use_dinkelbach && ((c->bucket_lmax[i] & BUCKET_WAVE) || (c->wave_from && (c->bucket_lmax[i] & 0xFF) >= c->wave_from)))
 			launch_wbind(c, b, bucket_rows(c->bucket_lmax[i]), false, c->lane_stream[lane]);
 		else launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
 	}
@@ -1376,7 +1390,6 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				const size_t L = c->oligos[size_t(c->h_slots[size_t(slots3[role])].oligo)].size();
 				if (L <= size_t(MAX_LANE_OLIGO)) continue;
 				if (d.kind != 2) FAIL(TNT_E_LIMIT, "oligos of more than 128 bases are searched as the probes of probe-only assays (PCR primers, TaqMan probes and padlock arms: up to 128)");
-				if (opt->use_dinkelbach) FAIL(TNT_E_LIMIT, "--dinkelbach with an oligo longer than 64 bases");
 				const size_t n_words = L >= k ? L - k + 1 : 0, n_seg = (n_words + 127) / 128;
 				c->h_segment[i] = 0;
 				if (n_seg > 1) c->long_probes = true, c->h_assays[i].cache_replay |= 2;
@@ -1401,8 +1414,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 			if (char_to_base(ch) < 0) FAIL(TNT_E_ARG, "oligos must be expanded to A/C/G/T/I (expand_degenerate_signatures)");
 		max_L = std::max(max_L, o.size());
 	}
-	if (opt->use_dinkelbach && max_L > 64) FAIL(TNT_E_LIMIT, "--dinkelbach with an oligo longer than 64 bases");
-	c->lmax = opt->use_dinkelbach ? 64 : pick_lmax(max_L); // --dinkelbach: one 64-row instance binds everything
+	c->lmax = (opt->use_dinkelbach && max_L <= 64) ? 64 : pick_lmax(max_L); // --dinkelbach: ONE instance binds everything (64 lane rows, or the wavefront kernel beyond)
 	c->unit_rows = max_L <= 64 ? 64 : (max_L <= size_t(MAX_LANE_OLIGO) ? MAX_LANE_OLIGO : int(max_L)); // unit-level instance: 64 / 128 rows, or the wavefront kernel
 	{
 		// buckets: one per instance in use, in ascending length; the last one is the general instance that
@@ -2320,6 +2332,7 @@ static int enqueue_cache_replay(tnt_ctx *c, PairArgs p, bool direct, size_t cap_
 	k.citems = c->c_items.p, k.corigin = c->c_origin.p;
 	k.cap_items = uint32_t(cap_items);
 	k.n_items = c->c_counts.p + 1;
+	k.n_big = c->c_counts.p + 3;
 	k.err = p.err;
 	hipLaunchKernelGGL(cache_collect_kernel, dim3(std::min<uint32_t>(k.n_segs, 4096u)), dim3(256), 0, c->stream, k);
 	// every collected item in full: status, Tm, dH, dS, dG, anchors, counts, footprint, text -- whatever its own thresholds say
@@ -2339,7 +2352,9 @@ static int enqueue_cache_replay(tnt_ctx *c, PairArgs p, bool direct, size_t cap_
 	r.p.cpool = c->c_pool.p, r.p.cpool_cap = uint32_t(cap_items), r.p.cpool_count = c->c_counts.p + 2;
 	r.keys = c->ck_out.p, r.vals = c->cv_out.p, r.recs = c->c_recs.p;
 	r.cap_groups = uint32_t(cap_groups);
-	hipLaunchKernelGGL(cache_replay_kernel, dim3(uint32_t(std::min<size_t>(8192, (cap_groups + PAIR_THREADS - 1) / PAIR_THREADS))), dim3(PAIR_THREADS), 0, c->stream, r);
+	r.n_big = c->c_counts.p + 3;
+	hipLaunchKernelGGL(cache_replay_kernel<PAIR_MAX>, dim3(uint32_t(std::min<size_t>(8192, (cap_groups + PAIR_THREADS - 1) / PAIR_THREADS))), dim3(PAIR_THREADS), 0, c->stream, r);
+	hipLaunchKernelGGL(cache_replay_kernel<PAIR_BIG>, dim3(uint32_t(std::min<size_t>(256, (cap_groups + PAIR_THREADS - 1) / PAIR_THREADS))), dim3(PAIR_THREADS), 0, c->stream, r);
 	return TNT_OK;
 }
 

@@ -85,7 +85,6 @@ struct PairArgs {
 struct ConflictRec {
 	uint32_t group, cfirst, count, pad;
 };
-constexpr int CACHE_RUN_MAX = 64; // such groups per target (= assays that share an oligo across classes)
 
 enum : uint8_t { MF = 1, MR = 2, MP = 4, MPLUS = 8, MMINUS = 16, MVALID = 32 }; // oligo_info, tntblast.h:147-154
 
@@ -317,7 +316,13 @@ template <int N> TNT_HD void bind_step(ListT<N> &l, uint8_t want, const BoundRec
 
 struct PairArgs;
 struct ConflictRec;
-template <int N, bool CACHED = false> TNT_HD void pair_group(const PairArgs &a, const Group G, const ConflictRec *run = nullptr, int n_run = 0, uint32_t cfirst = 0);
+// The groups of one target that go through the cache replay, in assay order (a window of the sorted (target, assay) list).
+struct ConflictRun {
+	const uint32_t *vals;
+	const ConflictRec *recs;
+	TNT_HD const ConflictRec &operator[](int g) const { return recs[vals[g]]; }
+};
+template <int N, bool CACHED = false> TNT_HD void pair_group(const PairArgs &a, const Group G, ConflictRun run = ConflictRun{nullptr, nullptr}, int n_run = 0, uint32_t cfirst = 0);
 
 TNT_HD inline Hit *alloc_hit(const PairArgs &a)
 {
@@ -501,7 +506,7 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 // threshold cascade had looked at when it stopped (the rest zero / empty).  A later request applies ITS thresholds to the
 // memo.  `run` = the target's groups of such assays up to and including the current one, in assay order: the citems
 // evaluated so far are found there (corigin != 0xFFFFFFFF).
-TNT_HD inline void cache_resolve(const PairArgs &a, Entry &e, const ConflictRec *run, int n_run)
+TNT_HD inline void cache_resolve(const PairArgs &a, Entry &e, const ConflictRun run, int n_run)
 {
 	if (e.rec >= -1) return;
 	const uint32_t ci = uint32_t(-2 - e.rec);
@@ -588,7 +593,7 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 
 // CACHED: the group belongs to an assay that goes through the replay of the reference's BindCache: its items are
 // a.citems[cfirst ...], nothing is known about them until a bind step asks (cache_resolve), records come from a.cpool.
-template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Group G, const ConflictRec *run, int n_run, uint32_t cfirst)
+template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Group G, const ConflictRun run, int n_run, uint32_t cfirst)
 {
 	const AssayDev A = a.assays[G.assay & GROUP_ASSAY_MASK];
 	const int seq_index = int(a.db.first_seq_index + a.unit_target[G.target]);
@@ -879,6 +884,7 @@ struct CacheCollectArgs {
 	uint32_t *corigin;
 	uint32_t cap_items;
 	uint32_t *n_items;
+	uint32_t *n_big;
 	uint32_t *err;
 };
 
@@ -898,6 +904,7 @@ __global__ __launch_bounds__(256) void cache_collect_kernel(CacheCollectArgs a)
 				atomicOr(a.err, ERR_ITEM_OVERFLOW);
 				continue;
 			}
+			if (count > uint32_t(PAIR_MAX)) atomicAdd(a.n_big, 1u);
 			a.recs[slot] = ConflictRec{gi, cf, count, 0u};
 			a.keys[slot] = ((unsigned long long)G.target << 32) | assay;
 			a.vals[slot] = slot;
@@ -917,28 +924,32 @@ struct CacheReplayArgs {
 	const uint32_t *vals;
 	const ConflictRec *recs;
 	uint32_t cap_groups;
+	const uint32_t *n_big; // collected groups of more than PAIR_MAX items
 };
 
-__global__ __launch_bounds__(PAIR_THREADS) void cache_replay_kernel(CacheReplayArgs a)
+// N = PAIR_MAX: the targets all of whose collected groups hold up to PAIR_MAX items (all of them in practice); N = PAIR_BIG:
+// the targets with a crowded group (the replay of one target is one sequence, so a target goes to one instance whole).
+template <int N> __global__ __launch_bounds__(PAIR_THREADS) void cache_replay_kernel(CacheReplayArgs a)
 {
+	if (N == PAIR_BIG && *a.n_big == 0) return;
 	for (uint32_t i = blockIdx.x * PAIR_THREADS + threadIdx.x; i < a.cap_groups; i += gridDim.x * PAIR_THREADS) {
 		const unsigned long long key = a.keys[i];
 		if (key == ~0ull) continue;
 		if (i > 0 && (a.keys[i - 1] >> 32) == (key >> 32)) continue; // not the first group of its target
-		ConflictRec run[CACHE_RUN_MAX];
-		int n_run = 0;
-		for (uint32_t j = i; j < a.cap_groups && a.keys[j] != ~0ull && (a.keys[j] >> 32) == (key >> 32); j++) {
-			if (n_run == CACHE_RUN_MAX) {
-				atomicOr(a.p.err, ERR_LIST_OVERFLOW);
-				break;
-			}
-			const ConflictRec r = a.recs[a.vals[j]];
-			run[n_run++] = r;
-			if (r.count > uint32_t(PAIR_MAX)) {
+		if (*a.n_big != 0 || N == PAIR_BIG) {
+			uint32_t most = 0;
+			for (uint32_t j = i; j < a.cap_groups && a.keys[j] != ~0ull && (a.keys[j] >> 32) == (key >> 32); j++) most = max(most, a.recs[a.vals[j]].count);
+			if ((most > uint32_t(PAIR_MAX)) != (N == PAIR_BIG)) continue;
+			if (most > uint32_t(PAIR_BIG)) {
 				atomicOr(a.p.err, ERR_LIST_OVERFLOW);
 				continue;
 			}
-			pair_group<PAIR_MAX, true>(a.p, a.p.groups[r.group], run, n_run, r.cfirst);
+		}
+		const ConflictRun run{a.vals + i, a.recs};
+		int n_run = 0;
+		for (uint32_t j = i; j < a.cap_groups && a.keys[j] != ~0ull && (a.keys[j] >> 32) == (key >> 32); j++) {
+			const ConflictRec r = run[n_run++];
+			pair_group<N, true>(a.p, a.p.groups[r.group], run, n_run, r.cfirst);
 		}
 	}
 }

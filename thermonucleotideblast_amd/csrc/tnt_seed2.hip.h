@@ -47,7 +47,10 @@ namespace tnt {
 // starts when a whole CU has drained.  Kept as an instance, not used by default.
 constexpr int s2_waves(bool ltab) { return ltab ? 16 : 4; }
 constexpr int S2_TAB_WORDS = (1 << 14) + 2; // bucket offsets of a chunk for hash words of up to 7 bases
-constexpr int S2_CAP = 512;            // seeds of one target x one assay chunk held in LDS
+#ifndef TNT_S2_CAP
+#define TNT_S2_CAP 512
+#endif
+constexpr int S2_CAP = TNT_S2_CAP;     // seeds of one target x one assay chunk held in LDS
 constexpr int S2_ASSAYS = 128;         // assays per chunk (7-bit local index in the key)
 constexpr int S2_SWEEP = 16;           // positions per lane and sweep
 constexpr int S2_TGT_WORDS = 128;       // packed words of a target parked in LDS (2 048 bases); longer targets are read from HBM
@@ -133,19 +136,26 @@ template <int WS> __device__ __forceinline__ bool s2_first_packed(uint32_t W0, u
 	return ((r_lo & b_lo) | (r_hi & b_hi)) == 0u;
 }
 
-template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), LTAB ? 1 : 4) void seed2_kernel(Seed2Args a)
+#ifndef TNT_EXP_S2_SKIP
+#define TNT_EXP_S2_SKIP 0 // timing experiments (wrong results): 1 no item stores, 2 no queue stores, 4 no group stores, 8 no emission, 16 no cull loop
+#endif
+#ifndef TNT_S2_OCC
+#define TNT_S2_OCC 4 // workgroups per CU the kernel is compiled for (5: registers capped at 96, the aliased LDS arrays of LTAB)
+#endif
+template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), LTAB ? 1 : TNT_S2_OCC) void seed2_kernel(Seed2Args a)
 {
 	constexpr int S2_WAVES = s2_waves(LTAB), S2_THREADS = 64 * S2_WAVES;
+	constexpr bool ALIAS = LTAB || TNT_S2_OCC > 4; // the target's words inside s_ext, the emission's scratch words inside s_srt
 	static_assert(S2_ASSAYS * 4 >= S2_TGT_WORDS + 4 && S2_CAP >= 3 * MAX_BUCKETS, "the shared arrays hold their lodgers");
 	__shared__ uint32_t s_raw[S2_WAVES][S2_CAP];      // kept seeds (keys) as the dense pass finds them
 	__shared__ uint32_t s_srt[S2_WAVES][S2_CAP];      // candidates of the scan, then the keys grouped by assay (LTAB: the emission's scratch words live here too)
-	__shared__ uint32_t s_tgt[S2_WAVES][LTAB ? 1 : S2_TGT_WORDS + 4]; // the packed words of the target (targets of up to 2 048 bases); LTAB: inside s_ext
+	__shared__ uint32_t s_tgt[S2_WAVES][ALIAS ? 1 : S2_TGT_WORDS + 4]; // the packed words of the target (targets of up to 2 048 bases); LTAB: inside s_ext
 	__shared__ uint16_t s_hist[S2_WAVES][S2_ASSAYS];  // seeds per assay
 	__shared__ uint16_t s_off[S2_WAVES][S2_ASSAYS];   // scatter cursors, then the END of every assay's segment
 	__shared__ __attribute__((aligned(16))) uint32_t s_ext[S2_WAVES][S2_ASSAYS * 4]; // per assay: smallest key of F-, of R-, largest key of F+, of R+
 	__shared__ uint32_t s_agg[S2_WAVES][S2_ASSAYS];   // per assay: successors on the minus strand | on the plus strand << 10 | valid seeds << 20
 	__shared__ uint32_t s_qh[S2_WAVES][MAX_BUCKETS], s_qcur[S2_WAVES][MAX_BUCKETS], s_qend[S2_WAVES][MAX_BUCKETS];
-	__shared__ uint32_t s_qtmp[S2_WAVES][LTAB ? 1 : 3 * MAX_BUCKETS]; // per emission round: first slot, end of the open block, the new block (per bucket)
+	__shared__ uint32_t s_qtmp[S2_WAVES][ALIAS ? 1 : 3 * MAX_BUCKETS]; // per emission round: first slot, end of the open block, the new block (per bucket)
 	__shared__ uint16_t s_tab[LTAB ? S2_TAB_WORDS : 2]; // LTAB: the chunk's bucket offsets [4^k + 1]
 	__shared__ uint8_t s_af[S2_ASSAYS];               // per assay of the chunk: 1 probe / padlock assay (hash-overload lists), 2 PCR with a probe
 	__shared__ uint32_t s_slot[S2_ASSAYS * 3];        // slot_pack of the chunk's slots
@@ -160,8 +170,8 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	// LTAB: the target's words are dead once the dense pass is through (the extreme keys are collected behind it), the candidate
 	// list once the valid seeds sit in `raw` (the emission's scratch words are written and read inside one round)
-	uint32_t *raw = s_raw[wv], *srt = s_srt[wv], *tgt = LTAB ? s_ext[wv] : s_tgt[wv];
-	uint32_t *qpos = LTAB ? s_srt[wv] : s_qtmp[wv], *qsplit = qpos + MAX_BUCKETS, *qnew = qpos + 2 * MAX_BUCKETS;
+	uint32_t *raw = s_raw[wv], *srt = s_srt[wv], *tgt = ALIAS ? s_ext[wv] : s_tgt[wv];
+	uint32_t *qpos = ALIAS ? s_srt[wv] : s_qtmp[wv], *qsplit = qpos + MAX_BUCKETS, *qnew = qpos + 2 * MAX_BUCKETS;
 	uint16_t *hist = s_hist[wv], *off = s_off[wv];
 	uint32_t *ext = s_ext[wv], *agg = s_agg[wv];
 	const uint32_t wmask = (1u << (2 * a.word_size)) - 1u;
@@ -232,7 +242,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		const uint32_t rec_words = rec_cur.z; // first packed word of the target (the host checks that the packed array stays below 2^32 words)
 		// this unit's words -> LDS; the next unit's words and the record behind it -> in flight
 		tgt[lane] = wc0, tgt[lane + 64] = wc1;
-		if (LTAB && lane < 4) tgt[S2_TGT_WORDS + lane] = 0; // (the slack words were the last unit's extreme keys)
+		if (ALIAS && lane < 4) tgt[S2_TGT_WORDS + lane] = 0; // (the slack words were the last unit's extreme keys)
 		rec_cur = rec_next;
 		load_words(rec_next, wc0, wc1);
 		rec_next = load_rec(unit + 2 * stride);
@@ -479,7 +489,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		//    the counts decide which strand is bound first (:131).
 		// Probe / padlock lists are bound as a whole (hash overload, bind_oligo.cpp:124-454): every seed is valid.
 		uint32_t n_valid_all = 0; // valid seeds so far (wave-uniform)
-		for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+		for (uint32_t i0 = 0; i0 < ((TNT_EXP_S2_SKIP & 16) ? 0u : n); i0 += 64) {
 			const uint32_t i = i0 + uint32_t(lane);
 			bool valid = false;
 			uint32_t kk = 0;
@@ -598,7 +608,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		glb_u32x4 *const g_queue = (glb_u32x4 *)cold(COLD_QUEUE);
 		glb_u32 *const g_result = (glb_u32 *)cold(COLD_RESULT);
 		uint32_t carry_la = ~0u; // assay of the last seed of the round before
-		for (uint32_t i0 = 0; i0 < n_valid_all; i0 += 64) {
+		for (uint32_t i0 = 0; i0 < ((TNT_EXP_S2_SKIP & 8) ? 0u : n_valid_all); i0 += 64) {
 			const uint32_t i = i0 + uint32_t(lane);
 			const bool valid = i < n_valid_all;
 			const uint32_t n_valid = n_valid_all - i0 < 64u ? n_valid_all - i0 : 64u;
@@ -625,7 +635,9 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			const uint32_t assay = a.assay_begin + la;
 			if (first) {
 				const uint32_t nv = ag >> 20;
+#if !(TNT_EXP_S2_SKIP & 4)
 				g_groups[gidx] = u32x4{unit, assay | (minus_first ? GROUP_MINUS_FIRST : 0u), o, nv}; // Group{target (unit), assay | flags, first, count}
+#endif
 				if (nv > 64u) __hip_atomic_fetch_add((glb_u32 *)cold(COLD_BIG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			uint32_t bucket = ~0u;
@@ -634,8 +646,10 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 				const uint32_t slot = assay * 3u + role; // the Slot table is laid out [assay][role]
 				// Item{target, tloc, info, group}
 				const uint32_t info = wi | (minus ? ITEM_MINUS : 0u) | (pb ? ITEM_PHASE_B : 0u) | (slot << ITEM_SLOT_SHIFT);
+#if !(TNT_EXP_S2_SKIP & 1)
 				g_items[o] = u32x4{t, p, info, gidx};
 				g_result[o] = 0xFFFFFFFFu; // -1: not bound (what the pre-filter's rejection means; a bind overwrites it)
+#endif
 				if (!pb) {
 					const uint32_t sp = s_slot[la * 3u + role];
 					bucket = sp & 0xFFu;
@@ -693,7 +707,9 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 						const uint32_t nb = qnew[bucket];
 						pos = nb == ~0u ? ~0u : nb + (pos - split);
 					}
+#if !(TNT_EXP_S2_SKIP & 2)
 					if (pos != ~0u) g_queue[pos] = fat;
+#endif
 				}
 				n_phase_a += uint32_t(__builtin_popcountll(am));
 			}

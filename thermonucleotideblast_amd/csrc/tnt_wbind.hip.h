@@ -43,9 +43,13 @@ struct RowTrace {
 	__device__ __forceinline__ int get(int li, int lj) const { return int(tr[size_t(li - 1) * size_t(pitch) + size_t(lj - 1)]); }
 };
 
-template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void wbind_kernel(BindArgs a)
+// DINK: --dinkelbach (NucCruc::approximate_tm_heterodimer, nuc_cruc.cpp:2399-2432): the alignment is computed at 0 C, then
+// again and again at the Tm the last pass gave while its free energy there is negative and still rising; every pass has its
+// own delta_g (update_dp_param at that temperature), so a workgroup is ONE wavefront and rebuilds its LDS planes from the
+// (H, S, floor) triples of the entries (Tables::dk_*) in front of every pass.
+template <int R, bool FULL, bool DINK = false> __global__ __launch_bounds__(64 * (DINK ? 1 : wb_waves(R))) void wbind_kernel(BindArgs a)
 {
-	constexpr int WAVES = wb_waves(R);
+	constexpr int WAVES = DINK ? 1 : wb_waves(R);
 	constexpr int THREADS = 64 * WAVES;
 	constexpr int LMAX = 64 * R;
 	constexpr int WMAX = LMAX + 2 * FLANK;
@@ -85,14 +89,25 @@ template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void 
 	}
 	if (uint32_t(blockIdx.x) * uint32_t(WAVES) >= n_items) return; // (before the tables are staged: the grid is sized for full queues)
 
-	for (int i = tid; i < NBP * NBP; i += THREADS) {
-		const int p = i / NBP, cpair = i % NBP; // prev pair (x', q'), current pair (x, q)
-		const int at = ((p / NB) * NB + cpair / NB) * NBP + (p % NB) * NB + cpair % NB;
-		s_dgp[at] = a.tab->dg[i];
-		s_dgp[DG_PLANE + at] = a.tab->term[cpair];
-	}
-	if (tid < NBP) s_term[tid] = a.tab->term[tid];
-	if (tid < 4) s_const[tid] = a.tab->dg_const[tid];
+	// delta_g of entry `src` of Tables::dg at temperature T (update_dp_param, nuc_cruc.cpp:357-486: truncation towards zero, the
+	// clamped classes floored at 0)
+	auto dg_at = [&](int src, float T) __attribute__((always_inline)) {
+		if (src < 0) return 0; // (a class constant without an entry of its own)
+		const int v = int((a.tab->dk_H[src] - T * a.tab->dk_S[src]) * 10000.0f);
+		const int f = a.tab->dk_F[src];
+		return v > f ? v : f;
+	};
+	auto stage_dg = [&](float T, bool at_target_t) __attribute__((always_inline)) { // the planes of one temperature (the whole workgroup)
+		for (int i = tid; i < NBP * NBP; i += THREADS) {
+			const int p = i / NBP, cpair = i % NBP; // prev pair (x', q'), current pair (x, q)
+			const int at = ((p / NB) * NB + cpair / NB) * NBP + (p % NB) * NB + cpair % NB;
+			s_dgp[at] = at_target_t ? a.tab->dg[i] : dg_at(i, T);
+			s_dgp[DG_PLANE + at] = at_target_t ? a.tab->term[cpair] : dg_at(a.tab->term_src[cpair], T);
+		}
+		if (tid < NBP) s_term[tid] = at_target_t ? a.tab->term[tid] : dg_at(a.tab->term_src[tid], T);
+		if (tid < 4) s_const[tid] = at_target_t ? a.tab->dg_const[tid] : dg_at(a.tab->const_src[tid], T);
+	};
+	if (!DINK) stage_dg(0.0f, true);
 	for (int i = tid; i < 18 * 18; i += THREADS) s_lut[i] = a.tab->bbp[i];
 	if (tid < 18) s_rt[tid] = a.tab->rt[tid];
 	for (int i = tid; i < NBP * NBP; i += THREADS) s_hs_map[i] = a.tab->hs_map[i];
@@ -114,7 +129,6 @@ template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void 
 
 	const uint32_t *index = a.index;
 	if (index && a.index_base_dev) index += *a.index_base_dev;
-	const int c_bulge = s_const[0], c_zero = s_const[1], c_forb_m = s_const[2], c_forb_xy = s_const[3];
 	const char *sdg = reinterpret_cast<const char *>(s_dgp);
 	const char *sterm = reinterpret_cast<const char *>(s_term);
 
@@ -209,6 +223,16 @@ template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void 
 		const uint32_t rt_gap = s_rt[bGAP];
 
 		int gmax = -1, nmax = 0, max_ij = 0;
+		// temperature of this pass: the target temperature, or the Dinkelbach sequence 0 C, Tm_1, Tm_2, ...
+		float Tcur = DINK ? 273.15f : s_k.temperature, dk_q = -999999.9f;
+	next_pass:
+		if (DINK) { // this pass's delta_g planes (the workgroup is this wavefront)
+			stage_dg(Tcur, false);
+			if (lane == 0) s_ntie[wv] = 0;
+			wave_sync();
+			gmax = -1, nmax = 0, max_ij = 0;
+		}
+		const int c_bulge = s_const[0], c_zero = s_const[1], c_forb_m = s_const[2], c_forb_xy = s_const[3];
 
 		// ------------------------------------------------------------------ the sweep (align_dimer, nuc_cruc.cpp:492-696)
 		// COLLECT: the second sweep of a window with several maximal cells appends every cell that holds `gmax` to ties[]
@@ -347,11 +371,20 @@ template <int R, bool FULL> __global__ __launch_bounds__(64 * wb_waves(R)) void 
 		wave_sync(); // trace words and ties were written by other lanes
 
 		// ------------------------------------------------------------------ serial tail on lane 0
+		bool again = false;
 		if (lane == 0) {
 			RowTrace tr{trace, PITCH};
-			float Tcur = s_k.temperature, dk_q = -999999.9f;
-			(void)bind_tail<FULL, false, true, (LMAX > 64), 1, WB_CODE_SHIFT, uint32_t>(a, tr, s_lut, s_hs_map, s_hs_val, s_k, win, qry, cols, best, stack, ties, NCOLS, WMAX + 1, idx, it,
-			                                                                          slot, L, W, start, stop, minus, xmode, gmax, nmax, max_ij, Tcur, dk_q);
+			again = bind_tail<FULL, DINK, true, (LMAX > 64), 1, WB_CODE_SHIFT, uint32_t>(a, tr, s_lut, s_hs_map, s_hs_val, s_k, win, qry, cols, best, stack, ties, NCOLS, WMAX + 1, idx, it,
+			                                                                         slot, L, W, start, stop, minus, xmode, gmax, nmax, max_ij, Tcur, dk_q);
+		}
+		if (DINK) { // another pass at the temperature lane 0 found?
+			again = __builtin_amdgcn_readfirstlane(int(again)) != 0;
+			Tcur = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Tcur)));
+			dk_q = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dk_q)));
+			if (again) {
+				wave_sync();
+				goto next_pass;
+			}
 		}
 	}
 }

@@ -13,6 +13,11 @@ namespace tnt {
 	void launch_wbind_full_##N(const BindArgs &a, int blocks, hipStream_t stream)                                        \
 	{                                                                                                                    \
 		hipLaunchKernelGGL((wbind_kernel<N, true>), dim3(blocks), dim3(64 * wb_waves(N)), 0, stream, a);                  \
+	}                                                                                                                    \
+	void launch_wbind_dink_##N(const BindArgs &a, int blocks, bool full, hipStream_t stream) /* --dinkelbach: one wavefront per workgroup */ \
+	{                                                                                                                    \
+		if (full) hipLaunchKernelGGL((wbind_kernel<N, true, true>), dim3(blocks), dim3(64), 0, stream, a);                \
+		else hipLaunchKernelGGL((wbind_kernel<N, false, true>), dim3(blocks), dim3(64), 0, stream, a);                    \
 	}
 TNT_WBIND_LADDER(X)
 #undef X
