@@ -32,6 +32,7 @@
 #include <cstring>
 #include <sstream>
 #include <string>
+#include <new>
 #include <vector>
 #include <list>
 #include <unordered_map>
@@ -352,7 +353,7 @@ int tntref_bind_batch(const tnt_options *opt, const char *const *oligos, int n_o
 
 // a4 at unit level: the head of amplicon() (amplicon_search.cpp:96-129) with the reference's own functions -- match list in
 // assembly order, early exits, cull_oligo_match -- and what is left of the list.  Same records as tntor_first_cull; the
-// seventh field (strand bound first) comes from counts that read one node past the list and is not compared.
+// seventh field (strand bound first) comes from counts that read one node past the list: see the list's block below.
 int tntref_first_cull(const tnt_options *opt, const tnt_assay *assays, size_t n_assays, const uint8_t *codes, const uint64_t *offsets,
                       size_t n_targets, uint32_t first_seq_index, int32_t **out, size_t *n_out)
 {
@@ -366,7 +367,18 @@ int tntref_first_cull(const tnt_options *opt, const tnt_assay *assays, size_t n_
 				for (size_t a = 0; a < n_assays; a++) {
 					const tnt_assay &A = assays[a];
 					if (!(A.forward && A.reverse) || opt->assay_format != TNT_ASSAY_PCR) continue;
-					list<oligo_info> ml;
+					// cull_oligo_match reads the strand bits of the node behind the last element when that one is valid:
+					// the list header itself, i.e. whatever lies behind it in memory.  Here the header sits in a zeroed block, so
+					// that read finds no strand bit ("counts nothing": the deterministic reading the oracle and the product follow);
+					// in the reference binary it is stack contents.
+					alignas(16) unsigned char ml_block[sizeof(list<oligo_info>) + 2 * sizeof(oligo_info) + 64];
+					memset(ml_block, 0, sizeof(ml_block));
+					struct ListHolder {
+						list<oligo_info> *l;
+						explicit ListHolder(void *at) : l(new (at) list<oligo_info>()) {}
+						~ListHolder() { l->~list<oligo_info>(); }
+					} ml_holder(ml_block);
+					list<oligo_info> &ml = *ml_holder.l;
 					match_oligo_to_minus_strand(ml, dbase, A.forward, oligo_info::F);
 					match_oligo_to_minus_strand(ml, dbase, A.reverse, oligo_info::R);
 					const size_t n_minus = ml.size();

@@ -52,7 +52,10 @@ constexpr int S2_TAB_WORDS = (1 << 14) + 2; // bucket offsets of a chunk for has
 #endif
 constexpr int S2_CAP = TNT_S2_CAP;     // seeds of one target x one assay chunk held in LDS
 constexpr int S2_ASSAYS = 128;         // assays per chunk (7-bit local index in the key)
-constexpr int S2_SWEEP = 16;           // positions per lane and sweep
+#ifndef TNT_S2_SWEEP
+#define TNT_S2_SWEEP 16
+#endif
+constexpr int S2_SWEEP = TNT_S2_SWEEP; // positions per lane and sweep (16 or 8)
 constexpr int S2_TGT_WORDS = 128;       // packed words of a target parked in LDS (2 048 bases); longer targets are read from HBM
 constexpr uint32_t QUEUE_BLOCK = 64;   // queue slots handed out at a time (one filter / bind wavefront reads one block)
 constexpr uint32_t QUEUE_HOLE = 0xFFFFFFFFu; // a queue slot without an item
@@ -137,7 +140,7 @@ template <int WS> __device__ __forceinline__ bool s2_first_packed(uint32_t W0, u
 }
 
 #ifndef TNT_EXP_S2_SKIP
-#define TNT_EXP_S2_SKIP 0 // timing experiments (wrong results): 1 no item stores, 2 no queue stores, 4 no group stores, 8 no emission, 16 no cull loop
+#define TNT_EXP_S2_SKIP 0 // timing experiments (wrong results): 1 no item stores, 2 no queue stores, 4 no group stores, 8 no emission, 16 no cull loop, 32 nothing behind the dense pass, 64 no dense pass, 128 candidates counted, not listed
 #endif
 #ifndef TNT_S2_OCC
 #define TNT_S2_OCC 4 // workgroups per CU the kernel is compiled for (5: registers capped at 96, the aliased LDS arrays of LTAB)
@@ -299,7 +302,15 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 				} else if ((x.ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) {
 					const uint32_t w0 = (cp - kmax) >> 4;
 					uint32_t o_lo = x.seq.x, o_hi = x.seq.y;
-					if (kmax != wi) { // the seed sits less than wi bases into the target: the oligo from base wi - kmax on (rare)
+					if (wi + uint32_t(a.word_size) <= 32u) {
+						// every compared base lies in the first 32 of the oligo (x.seq): the oligo from base wi - kmax on is a shift
+						// of those two words -- by nothing unless the seed sits less than wi bases into the target.  (Without a
+						// branch: one lane in a hundred is such a seed, but one wavefront in two holds one, and the branch's load
+						// was a memory round trip of its own.)
+						const uint32_t s2 = (wi - kmax) * 2u;
+						const uint32_t a_lo = __builtin_amdgcn_alignbit(o_hi, o_lo, s2 & 31u), a_hi = o_hi >> (s2 & 31u);
+						o_lo = s2 < 32u ? a_lo : a_hi, o_hi = s2 < 32u ? a_hi : 0u;
+					} else if (kmax != wi) { // a long oligo's seed less than wi bases into the target: the oligo from base wi - kmax on (rare)
 						const uint4 q = a.wt_seq[x.idx];
 						const uint32_t s2 = (wi - kmax) * 2u, word = s2 >> 5, sh2 = s2 & 31u;
 						const uint32_t oa = word == 0 ? q.x : (word == 1 ? q.y : (word == 2 ? q.z : q.w));
@@ -340,6 +351,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 				const uint32_t p0 = base + uint32_t(lane) * S2_SWEEP;
 				unsigned long long v = 0;
 				if (p0 < npos) v = (unsigned long long)tw(p0 >> 4) | ((unsigned long long)tw((p0 >> 4) + 1) << 32);
+				if (S2_SWEEP == 8) v >>= 16 * (lane & 1); // (two lanes share a packed word)
 				uint32_t bnd[S2_SWEEP]; // first entry | count << 16
 				uint32_t mine = 0;
 #pragma unroll
@@ -369,10 +381,12 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 					break; // drain, then take this sweep again (or scan it slowly)
 				}
 				uint32_t o = ncand + incl - mine;
+				if (!(TNT_EXP_S2_SKIP & 128)) {
 #pragma unroll
 				for (int q = 0; q < S2_SWEEP; q++) {
 					uint32_t e = bnd[q] & 0xFFFFu;
 					for (uint32_t n = bnd[q] >> 16; n > 0; n--, e++) cand[o++] = (p0 + q) | (e << 15);
+				}
 				}
 				ncand += total;
 				base += 64 * S2_SWEEP;
@@ -414,7 +428,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			// diagonal) survives
 			wave_sync(); // the list was written by other lanes
 			S2_STAMP(1);
-			for (uint32_t c0 = 0; c0 < ncand; c0 += 256) {
+			for (uint32_t c0 = 0; c0 < ((TNT_EXP_S2_SKIP & 64) ? 0u : ncand); c0 += 256) {
 				const Cand x0 = fetch(c0 + uint32_t(lane), ncand);
 				const Cand x1 = fetch(c0 + 64u + uint32_t(lane), ncand);
 				const Cand x2 = fetch(c0 + 128u + uint32_t(lane), ncand);
@@ -433,7 +447,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			if (lane == 0) atomicOr(a.err, ERR_SEED_OVERFLOW);
 			n = S2_CAP;
 		}
-		if (n == 0) continue;
+		if (n == 0 || (TNT_EXP_S2_SKIP & 32)) continue;
 
 		// ---------------------------------------------------------------- counting sort by assay + extreme keys
 		{
