@@ -1480,3 +1480,22 @@ def test_cache_replay_of_crowded_targets(Engine, oracle):
     assert got == want and len(want) > 200
     db.close()
     e.close()
+
+
+def test_long_alignment_texts_of_windowed_targets(Engine, oracle):
+    """Probes of 150 to 300 bases (alignment texts beyond the 448-byte field: long-text arena) on targets that are seeded in
+    windows (their binds run in passes of their own behind the whole-target part of the search): the arena keeps the texts of
+    the whole search, tnt_long_text resolves the references of either part.  Search == oracle, texts included."""
+    import longwl
+    wl = longwl.make_beyond_128(9, lengths=(150, 220, 300), n_targets=32, tl=3000)
+    # the last twelve targets glued into one record of 36 000 bases (beyond a seed work unit: seeded in windows), the others stay whole
+    offsets = np.concatenate([wl.offsets[:21], wl.offsets[-1:]]).astype(np.uint64)
+    want_glued = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, offsets))
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    hits = e.search(db)
+    assert tc.sorted_hit_keys(hits, text_of=e.long_text) == want_glued and len(want_glued) >= 8
+    assert any(bytes(h.probe_align)[:3] == b"\x7fLT" for h in hits if h.seq_index == 20)  # a reference made by the windowed part
+    assert any(bytes(h.probe_align)[:3] == b"\x7fLT" for h in hits if h.seq_index < 20)
+    db.close()
+    e.close()

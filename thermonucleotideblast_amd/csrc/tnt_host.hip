@@ -2909,6 +2909,8 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 		}
 	}
 	{ // alignment texts beyond TNT_ALIGN_TEXT (oligos of more than 64 bases) follow their records to the host
+		if ((ctx->pending_db && !ctx->pending_db->h_long_targets.empty()) || ctx->S().counters.p != ctx->G()) // (the binds of the windowed targets went on filling the arena; the fill is a search-wide counter)
+			HIP_TRY(hipMemcpy(&cnt[C_LTEXT], ctx->G() + C_LTEXT, sizeof(uint32_t), hipMemcpyDeviceToHost), ctx->err);
 		const int lrc = fetch_long_texts(ctx, cnt[C_LTEXT]);
 		if (lrc) return lrc;
 	}

@@ -172,7 +172,7 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			return TNT_E_LIMIT;
 		}
 		if (cap > ctx->seeds_out.n) HIP_TRY(ctx->seeds_out.alloc(cap), ctx->err); // (kept for the next search)
-		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_LTEXT, ctx->stream), ctx->err); // (not the long-text arena's fill: the texts of the search so far stay)
 		rc = enqueue_batch(ctx, db, u0, u1, true);
 		if (rc) return rc;
 		uint32_t h[C_COUNT];
@@ -399,7 +399,7 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 	size_t chunk = std::min(ctx->item_cap, size_t(1) << 24);
 	for (size_t c0 = 0; c0 < n_bind;) {
 		const size_t nc = std::min(chunk, n_bind - c0);
-		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_COUNT, ctx->stream), ctx->err);
+		HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_LTEXT, ctx->stream), ctx->err); // (not the long-text arena's fill: the texts of the search so far stay)
 		if (host_cull) HIP_TRY(hipMemcpyAsync(ctx->S().items.p, bind_items + c0, nc * sizeof(Item), hipMemcpyHostToDevice, ctx->stream), ctx->err);
 		else HIP_TRY(hipMemcpyAsync(ctx->S().items.p, d_kept + c0, nc * sizeof(Item), hipMemcpyDeviceToDevice, ctx->stream), ctx->err);
 		hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->S().qb.p, uint32_t(nc), cnt + C_QB); // the queue: every item

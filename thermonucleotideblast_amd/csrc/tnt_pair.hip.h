@@ -612,6 +612,8 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 	ListT<N> l;
 	l.n = int(g_count);
 	bool any_bound = false;
+	uint32_t bound_classes = 0; // 1: a minus-strand primer is bound, 2: a plus-strand primer, 4: a probe
+	uint32_t bound_arms = 0;
 	unsigned long long order[N];
 	for (int i = 0; i < l.n; i++) {
 		const Item it = CACHED ? a.citems[cfirst + uint32_t(i)] : a.items[G.first + i];
@@ -638,9 +640,20 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 		e.loc5 = e.loc3 = 0;
 		const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u;
 		e.mask = uint8_t((role == 0 ? MF : (role == 1 ? MR : MP)) | ((it.info & ITEM_MINUS) ? MMINUS : MPLUS));
-		if (res >= 0) any_bound = true;
+		if (res >= 0) {
+			any_bound = true;
+			bound_classes |= uint32_t(role == 2 ? 4u : ((it.info & ITEM_MINUS) ? 1u : 2u));
+			bound_arms |= 1u << (((it.info & ITEM_MINUS) ? 0u : 2u) + (role == 1 ? 0u : 1u)); // the hash overload's lists: minus-up, minus-down, plus-up, plus-down
+		}
 	}
 	if (!any_bound && !CACHED) return;
+	// amplicon() reports a pair of a bound minus-strand primer and a bound plus-strand primer (with a bound probe between them in
+	// a TaqMan assay), amplicon_search.cpp:356-420: a group without one of them ends in one of the early returns below or in an
+	// empty pairing loop -- nine in ten of the groups that arrive here (one strand bound, nothing on the other): they leave
+	// before the list is put in order.
+	if (!CACHED && A.kind == 0 && ((bound_classes & 3u) != 3u || (A.has_probe && !(bound_classes & 4u)))) return;
+	// padlock() pairs an upstream with a downstream arm of the same strand (padlock_search.cpp:62-361)
+	if (!CACHED && A.kind == 1 && (bound_arms & 3u) != 3u && (bound_arms & 12u) != 12u) return;
 #if !defined(__HIP_DEVICE_COMPILE__)
 	bool in_order = true; // (the lists of windowed targets arrive in list order: tnt_sort.hip)
 	for (int i = 1; i < l.n && in_order; i++) in_order = order[i - 1] < order[i];
