@@ -31,6 +31,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_BASE = 0.25      # 2-bit packed targets read once
 VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2.0  # guide: 1 024 SIMDs, one wave-instruction per 2 cycles, 2.4 GHz
+# measured on the same hardware (scripts/ubench_valu.hip, profiles/r04q_ubench_valu.txt, 2+ wavefronts per SIMD): plain add / logic
+# ops sustain 1.07e12 wave-instructions/s, v_max / v_cmp / v_cndmask / v_alignbit / three-operand, SDWA and packed-16 forms 5.95e11
+VALU_RATE_MEASURED = {"full_rate_ops": 1.07e12, "half_rate_ops": 5.95e11}
 PIECES = 8                     # the strong-scaling database is generated in this many pieces
 
 
@@ -437,7 +440,10 @@ def main():
                 if n_valu and bind_ms_step > 0:
                     ach = n_valu / (bind_ms_step * 1e-3)
                     valu = {"achieved": ach, "unit": "VALU wave-instructions/s", "peak_guide": VALU_PEAK_GUIDE,
-                            "frac_guide": ach / VALU_PEAK_GUIDE, "wave_instructions_per_step": n_valu}
+                            "frac_guide": ach / VALU_PEAK_GUIDE, "wave_instructions_per_step": n_valu,
+                            "rate_measured": VALU_RATE_MEASURED,
+                            "note": "the filter's sweep is packed-16 maxima / saturating adds, the fill's v_max3 / v_alignbit / v_sub: mostly "
+                                    "half-rate forms, whose measured rate (scripts/ubench_valu.hip) is 48 % of the guide's peak"}
             except Exception:
                 traffic = None
         # the streaming part of the seed stage alone (SURVEY 8(d) means the HBM roofline for THIS scan): its share of the
