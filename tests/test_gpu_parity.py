@@ -1499,3 +1499,47 @@ def test_long_alignment_texts_of_windowed_targets(Engine, oracle):
     assert any(bytes(h.probe_align)[:3] == b"\x7fLT" for h in hits if h.seq_index < 20)
     db.close()
     e.close()
+
+
+@pytest.mark.parametrize("fmt,max_len", [(abi.ASSAY_PADLOCK, 0), (abi.ASSAY_MIPS, 40)])
+def test_many_bound_arms_on_one_long_record(Engine, oracle, fmt, max_len):
+    """padlock() / the pairing loop of amplicon() on lists with dozens of bound oligos (a 60-kb record that carries eighty
+    ligation sites of two padlock assays, arms side by side or up to 60 bases apart, either strand; and eighty amplicons of a
+    PCR assay in a second context): the pairing walks only the stretch of the list a pair can come from -- the same hits, in
+    the oracle's multiset, as the reference's walk over every pair."""
+    rng = np.random.default_rng(4711 + int(fmt))
+    n, tl = 60, 1000
+    codes, offsets = synth._targets(rng, n, tl)
+    arms = [(synth._rand_oligo(rng, 20, 24), synth._rand_oligo(rng, 20, 24)) for _ in range(2)]
+    for k in range(80):
+        F, R = arms[k % 2]
+        gap = "" if fmt == abi.ASSAY_PADLOCK else "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 60))))
+        site = synth._mutate(rng, F, 1) + gap + synth._mutate(rng, R, 1)
+        if rng.random() < 0.5:
+            site = synth.revcomp(site)
+        synth._put(codes, 0, int(rng.integers(10, n * tl - 200)), site)
+    glued = np.array([0, n * tl], dtype=np.uint64)  # one 60-kb record: seeded in windows, paired whole
+    opt = abi.options_default(min_primer_tm=40.0, min_probe_tm=40.0, assay_format=fmt, max_len=max_len)
+    ex = synth.expand_assays([synth.Assay("pad%d" % i, F, R, None) for i, (F, R) in enumerate(arms)])
+    want = tc.sorted_hit_keys(oracle.search(opt, ex, codes, glued))
+    e = Engine(opt, ex)
+    db = e.pack(codes, glued)
+    assert tc.sorted_hit_keys(e.search(db)) == want and len(want) > 30
+    db.close()
+    e.close()
+    # the same sites as PCR amplicons (forward primer, 0..60 bases, reverse complement of the other arm)
+    opt2 = abi.options_default(min_primer_tm=40.0, max_len=200)
+    codes2, _ = synth._targets(rng, n, tl)
+    for k in range(80):
+        F, R = arms[k % 2]
+        amp = synth._mutate(rng, F, 1) + "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(5, 60)))) + synth.revcomp(synth._mutate(rng, R, 1))
+        if rng.random() < 0.5:
+            amp = synth.revcomp(amp)
+        synth._put(codes2, 0, int(rng.integers(10, n * tl - 200)), amp)
+    ex2 = synth.expand_assays([synth.Assay("pcr%d" % i, F, R, None) for i, (F, R) in enumerate(arms)])
+    want2 = tc.sorted_hit_keys(oracle.search(opt2, ex2, codes2, glued))
+    e = Engine(opt2, ex2)
+    db = e.pack(codes2, glued)
+    assert tc.sorted_hit_keys(e.search(db)) == want2 and len(want2) > 30
+    db.close()
+    e.close()

@@ -465,7 +465,20 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		p.unit_own_lo = own_lo.data();
 		p.unit_own_hi = own_hi.data();
 		std::string why;
-		if (!workers.run(groups.size(), [&](size_t g) { pair_group<PAIR_HOST>(p, groups[g]); }, &why)) {
+		std::vector<double> group_ms(timing ? groups.size() : 0);
+		std::vector<Item> exp_items;
+		std::vector<int32_t> exp_result;
+		std::vector<BoundRec> exp_pool;
+		if (getenv("TNT_EXP_LONG_COPY")) { // experiment: the pairing reads pageable copies instead of the page-locked arrays
+			exp_items.assign(bind_items, bind_items + n_bind), exp_result.assign(result, result + n_bind), exp_pool.assign(pool, pool + n_pool);
+			p.items = exp_items.data(), p.result = exp_result.data(), p.pool = exp_pool.data();
+			lap("experiment: copies");
+		}
+		if (!workers.run(groups.size(), [&](size_t g) {
+			    const auto t0 = std::chrono::steady_clock::now();
+			    pair_group<PAIR_HOST>(p, groups[g]);
+			    if (timing) group_ms[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		    }, &why)) {
 			ctx->err = "the lists of long targets: " + why;
 			return TNT_E_DEVICE;
 		}
@@ -477,6 +490,16 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		if (err) {
 			ctx->err = err_text(err);
 			return TNT_E_LIMIT;
+		}
+		if (timing && !groups.empty()) {
+			std::vector<double> d = group_ms;
+			std::sort(d.begin(), d.end());
+			double sum = 0;
+			for (double x : d) sum += x;
+			size_t big = 0;
+			for (const Group &g : groups) big = std::max<size_t>(big, g.count & ~GROUP_ALIVE);
+			fprintf(stderr, "long targets: %zu lists (longest %zu seeds, %zu items, %zu bound): per list min %.2f median %.2f max %.2f ms, sum %.1f ms\n", groups.size(), big, n_bind, n_pool,
+			        d.front(), d[d.size() / 2], d.back(), sum);
 		}
 		lap("pairing");
 		// The workers took the groups as they came: put the hits back into the order one thread produces -- groups by

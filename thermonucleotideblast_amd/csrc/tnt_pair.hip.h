@@ -20,6 +20,7 @@
 #include "tnt_dev.h"
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <algorithm>
+#include <vector>
 #endif
 
 namespace tnt {
@@ -203,12 +204,18 @@ template <class Less> TNT_HD void merge_runs(Entry *e, Entry *tmp, int lo, int m
 // the head of the right run: the loop of merge_runs takes the whole left run first, then the right one) is skipped.
 // 96 lists of 165 000 entries (a 250-Mb record against config 2) otherwise stream 1 GB each through every core's memory
 // channel: 0.8 s.
-template <class Less> void sort_block(Entry *e, Entry *tmp, int lo, int size, Less less)
+// `plain` (optional, oligo_loc_less only): plain[i + 1] - plain[lo + 1] counts, over (lo, i], the entries that are bound or lie
+// before their left neighbour in target_loc.  A block without any, whose first entry is unbound too, holds unbound entries in
+// ascending target_loc order: there sort_by_oligo_loc is a strict weak order (it compares target_loc) and every merge inside the
+// block hands back its input -- the whole subtree is skipped.  The lists of a windowed target arrive in target_loc order and the bind
+// steps append what they bound at the end, so nearly all of a 700 000-entry list is such blocks.
+template <class Less> void sort_block(Entry *e, Entry *tmp, int lo, int size, Less less, const int *plain = nullptr)
 {
 	if (size < 2) return;
+	if (plain && plain[lo + size] - plain[lo + 1] == 0 && !(e[lo].loc5 + e[lo].loc3)) return;
 	const int half = size / 2;
-	sort_block(e, tmp, lo, half, less);
-	sort_block(e, tmp, lo + half, half, less);
+	sort_block(e, tmp, lo, half, less, plain);
+	sort_block(e, tmp, lo + half, half, less, plain);
 	const Entry &head = e[lo + half];
 	int a = lo;
 	while (a < lo + half && !less(head, e[a])) a++;
@@ -216,16 +223,28 @@ template <class Less> void sort_block(Entry *e, Entry *tmp, int lo, int size, Le
 }
 #endif
 
-template <class Less> TNT_HD void list_sort(Entry *e, Entry *tmp, int n, Less less)
+template <class Less> TNT_HD void list_sort(Entry *e, Entry *tmp, int n, Less less, bool by_oligo_loc = false)
 {
 	if (n < 2) return;
+#if !defined(__HIP_DEVICE_COMPILE__)
+	std::vector<int> plain_prefix;
+#ifndef TNT_EXP_NO_PLAIN_SKIP
+	if (by_oligo_loc && n >= 4096) {
+		plain_prefix.resize(size_t(n) + 1);
+		plain_prefix[0] = 0;
+		for (int i = 0; i < n; i++)
+			plain_prefix[i + 1] = plain_prefix[i] + (((e[i].loc5 + e[i].loc3) != 0 || (i > 0 && e[i].tloc < e[i - 1].tloc)) ? 1 : 0);
+	}
+#endif
+	const int *plain = plain_prefix.empty() ? nullptr : plain_prefix.data();
+#endif
 	// blocks by the binary digits of n, most significant first; each sorted bottom-up in aligned halves
 	int start = 0;
 	for (int bit = 30; bit >= 0; bit--) {
 		const int size = 1 << bit;
 		if (!(n & size)) continue;
 #if !defined(__HIP_DEVICE_COMPILE__)
-		sort_block(e, tmp, start, size, less);
+		sort_block(e, tmp, start, size, less, plain);
 #else
 		for (int width = 1; width < size; width <<= 1)
 			for (int lo = start; lo < start + size; lo += 2 * width) merge_runs(e, tmp, lo, lo + width, lo + 2 * width, less);
@@ -251,8 +270,9 @@ template <int N> TNT_HD void cull(ListT<N> &l, int max_len, bool has_probe, bool
 {
 	const uint32_t threshold = uint32_t(max_len) + 50u;
 	Entry tmp[N];
-	list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); });
-	for (int i = 0; i < l.n; i++) l.e[i].mask &= uint8_t(~MVALID);
+	list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }, true);
+	// (no entry carries MVALID here: the flag is taken off again where the survivors are compacted below -- one pass over a
+	// 700 000-entry list of a windowed target less)
 	for (int f = 0; f < l.n; f++) {
 		if (l.e[f].mask & (MPLUS | MP)) continue;
 		for (int r = f + 1; r < l.n; r++) {
@@ -275,15 +295,16 @@ template <int N> TNT_HD void cull(ListT<N> &l, int max_len, bool has_probe, bool
 	cnt_minus = cnt_plus = 0;
 	// The reference advances the iterator first and then reads ->mask, i.e. it looks at the element that
 	// FOLLOWS each valid one in the list as it stands (invalid successors are still present at that time).
+	int o = 0;
 	for (int i = 0; i < l.n; i++) {
-		if ((l.e[i].mask & MVALID) && i + 1 < l.n) {
+		if (!(l.e[i].mask & MVALID)) continue;
+		if (i + 1 < l.n) { // (the successor is read before the compaction can have written it: o <= i)
 			cnt_minus += (l.e[i + 1].mask & MMINUS) ? 1 : 0;
 			cnt_plus += (l.e[i + 1].mask & MPLUS) ? 1 : 0;
 		}
+		l.e[o] = l.e[i];
+		l.e[o++].mask &= uint8_t(~MVALID);
 	}
-	int o = 0;
-	for (int i = 0; i < l.n; i++)
-		if (l.e[i].mask & MVALID) l.e[o++] = l.e[i];
 	l.n = o;
 }
 
@@ -298,7 +319,11 @@ template <int N> TNT_HD void bind_step(ListT<N> &l, uint8_t want, const BoundRec
 			l.e[o++] = l.e[i];
 			continue;
 		}
-		if (l.e[i].rec >= 0) cur[nc++] = l.e[i]; // bound; unbound seeds are dropped (curr_oligo.pop_front)
+		if (l.e[i].rec >= 0) { // bound (unbound seeds are dropped: curr_oligo.pop_front); a bound entry takes its coordinates from the bind result
+			cur[nc] = l.e[i];
+			cur[nc].loc5 = pool[l.e[i].rec].loc5;
+			cur[nc++].loc3 = pool[l.e[i].rec].loc3;
+		}
 	}
 	l.n = o;
 	if (nc == 0) return;
@@ -691,16 +716,10 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 		for (int s = 0; s < 4; s++) {
 			const bool fwd = (s % 2) == 0;
 			const bool minus = minus_first ? (s < 2) : (s >= 2);
-			// a bound entry takes its coordinates from the bind result
 			const uint8_t want = uint8_t((fwd ? MF : MR) | (minus ? MMINUS : MPLUS));
 			if (CACHED) // the entries of this oligo and strand meet the memo in list order (bind_oligo.cpp:476-512)
 				for (int i = 0; i < l.n; i++)
 					if ((l.e[i].mask & want) == want) cache_resolve(a, l.e[i], run, n_run);
-			for (int i = 0; i < l.n; i++)
-				if ((l.e[i].mask & want) == want && l.e[i].rec >= 0) {
-					l.e[i].loc5 = pool[l.e[i].rec].loc5;
-					l.e[i].loc3 = pool[l.e[i].rec].loc3;
-				}
 			bind_step(l, want, pool);
 			if (s < 3) {
 				cull(l, a.max_len, has_probe, single, d0, d1);
@@ -715,26 +734,34 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				if (CACHED)
 					for (int i = 0; i < l.n; i++)
 						if ((l.e[i].mask & want) == want) cache_resolve(a, l.e[i], run, n_run);
-				for (int i = 0; i < l.n; i++)
-					if ((l.e[i].mask & want) == want && l.e[i].rec >= 0) {
-						l.e[i].loc5 = pool[l.e[i].rec].loc5;
-						l.e[i].loc3 = pool[l.e[i].rec].loc3;
-					}
 				bind_step(l, want, pool);
 			}
 		}
 		{
 			Entry tmp[N];
-			list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }); // :356
+			list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }, true); // :356
 		}
 
 		const bool apply_mm = a.min_max_primer_clamp >= 0;
 		const uint32_t min_max_clamp = apply_mm ? uint32_t(a.min_max_primer_clamp) : 0u;
+		// The reference walks every pair of the list (amplicon_search.cpp:356-420: `continue` on an amplicon beyond max_len, no
+		// break): quadratic in the bound oligos, 0.3 s for one list of a 250-Mb record.  Where the list is in ascending loc5
+		// order -- it is, behind the sort above, unless a footprint's coordinates sum to zero and sort_by_oligo_loc falls back to
+		// target_loc -- every R behind the first one whose loc5 already puts the amplicon beyond max_len does so too:
+		// R.loc3 >= R.loc5 - slack with slack = the largest (loc5 - loc3) of the list, so the walk stops there.  Same pairs, same order.
+		bool ascending = true;
+		long slack = -(1l << 40);
+		for (int i = 0; i < l.n; i++) {
+			if (i > 0 && l.e[i].loc5 < l.e[i - 1].loc5) ascending = false;
+			const long d = long(l.e[i].loc5) - long(l.e[i].loc3);
+			slack = d > slack ? d : slack;
+		}
 		for (int f = 0; f < l.n; f++) {
 			const Entry &F = l.e[f];
 			if (F.mask & (MPLUS | MP)) continue;
 			for (int r = f + 1; r < l.n; r++) {
 				const Entry &R = l.e[r];
+				if (ascending && long(R.loc5) - slack - long(F.loc5) + 1 > long(a.max_len)) break;
 				if (R.mask & (MMINUS | MP)) continue;
 				if (!single && ((F.mask & (MR | MF)) == (R.mask & (MR | MF)))) continue;
 				if (F.loc3 >= R.loc5) continue;
@@ -844,9 +871,34 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 	for (int pass = 0; pass < 2; pass++) {
 		const bool minus = pass == 0;
 		const int up = minus ? 0 : 2, down = up + 1;
-		for (int u = 0; u < ln[up]; u++)
-			for (int d = 0; d < ln[down]; d++) {
-				const Entry &U = lists[up][u], &D = lists[down][d];
+		// The reference tries every (upstream, downstream) pair (padlock_search.cpp:230-361): quadratic in the bound arms of a
+		// long record.  The downstream list is in ascending loc5 order (oligo_info::operator< is a strict weak order with loc5
+		// first), and a pair needs  0 <= len <= max_len  with len = U.loc5 - D.loc3 - 1 (minus) or D.loc5 - U.loc3 - 1 (plus):
+		// that bounds D.loc5 from both sides -- through the smallest and largest footprint (loc3 - loc5) of the list on the minus
+		// strand -- so only the stretch of the list between those bounds is walked: the same pairs in the same order.
+		long span_lo = 0, span_hi = 0;
+		for (int d = 0; d < ln[down]; d++) {
+			const long sp = long(lists[down][d].loc3) - long(lists[down][d].loc5);
+			span_lo = (d == 0 || sp < span_lo) ? sp : span_lo;
+			span_hi = (d == 0 || sp > span_hi) ? sp : span_hi;
+		}
+		for (int u = 0; u < ln[up]; u++) {
+			const Entry &U = lists[up][u];
+			const long d5_lo = minus ? long(U.loc5) - 1 - long(max_len) - span_hi : long(U.loc3) + 1;
+			const long d5_hi = minus ? long(U.loc5) - 1 - span_lo : long(U.loc3) + 1 + long(max_len);
+			int d = 0;
+			if (ln[down] > 16) { // first entry with loc5 >= d5_lo
+				int lo = 0, hi = ln[down];
+				while (lo < hi) {
+					const int mid = (lo + hi) >> 1;
+					if (long(lists[down][mid].loc5) < d5_lo) lo = mid + 1;
+					else hi = mid;
+				}
+				d = lo;
+			}
+			for (; d < ln[down]; d++) {
+				const Entry &D = lists[down][d];
+				if (long(D.loc5) > d5_hi) break;
 				const int len = minus ? (U.loc5 - D.loc3 - 1) : (D.loc5 - U.loc3 - 1);
 				if (len < 0 || len > max_len) continue;
 				{
@@ -870,6 +922,7 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				copy_text(out->forward_align, bd.text);
 				copy_text(out->reverse_align, bu.text);
 			}
+		}
 	}
 }
 
