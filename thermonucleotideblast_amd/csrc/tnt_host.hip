@@ -608,6 +608,7 @@ struct tnt_ctx {
 		DevBuf<int32_t> result;
 		DevBuf<Group> groups;
 		DevBuf<uint32_t> active, qa, qb;
+		DevBuf<uint32_t> pairable; // the groups of `active` that can report a hit (pair_select_kernel)
 		DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
 		DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
 		DevBuf<uint4> qfat;       // phase-A queues of the round-3 seed kernel: self-contained entries (FilterArgs2::fat)
@@ -707,7 +708,7 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_FILTERED /* windows rejected by the pre-filter (whole search) */, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS,
+enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_FILTERED /* windows rejected by the pre-filter (whole search) */, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS, C_PAIRABLE /* groups handed to the pair kernels */,
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
@@ -1066,6 +1067,7 @@ int alloc_set(tnt_ctx *c, int k)
 	HIP_TRY(W.result.alloc(c->item_cap), c->err);
 	HIP_TRY(W.groups.alloc(c->group_cap), c->err);
 	HIP_TRY(W.active.alloc(c->group_cap), c->err);
+	HIP_TRY(W.pairable.alloc(c->group_cap), c->err);
 	HIP_TRY(W.qa.alloc(c->item_cap), c->err);
 	HIP_TRY(W.qb.alloc(c->item_cap), c->err);
 	HIP_TRY(W.qbucket.alloc(c->item_cap), c->err);
@@ -2573,6 +2575,16 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		const int crc = ensure_cache_buffers(c, u1 - u0, cache_groups, cache_items, cache_tmp);
 		if (crc) return crc;
 		p.citems = c->c_items.p;
+	}
+	{ // the pair kernels only see the groups that can report something (tnt_pair.hip.h, pair_select_kernel)
+		HIP_TRY(hipMemsetAsync(cnt + C_PAIRABLE, 0, sizeof(uint32_t), c->stream), c->err);
+		PairSelectArgs ps;
+		ps.p = p;
+		ps.selected = c->S().pairable.p;
+		ps.n_selected = cnt + C_PAIRABLE;
+		hipLaunchKernelGGL(pair_select_kernel, dim3(2048), dim3(256), 0, c->stream, ps);
+		p.active = c->S().pairable.p;
+		p.n_active = cnt + C_PAIRABLE;
 	}
 	hipLaunchKernelGGL(pair_kernel<PAIR_SMALL>, dim3(8192), dim3(PAIR_THREADS), 0, c->stream, p);
 	hipLaunchKernelGGL(pair_kernel<PAIR_MAX>, dim3(2048), dim3(PAIR_THREADS), 0, c->stream, p);

@@ -926,6 +926,58 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 	}
 }
 
+// Which of the groups that bound something can report anything at all?  amplicon() needs a bound primer on either strand (and a
+// bound probe in a TaqMan assay), padlock() an upstream and a downstream arm on one strand (the early returns of pair_group):
+// nine in ten of the groups the bind stage leaves alive hold one bound strand and nothing else.  One cheap lane per group looks
+// at the results of its items and hands the pair kernels -- 97 registers and 1.8 KB of scratch memory per lane -- only the
+// groups that need them.  Groups of the cache replay are left out (their results are not known yet), crowded groups are passed
+// on unseen (the pair kernels decide which instance takes them).
+struct PairSelectArgs {
+	PairArgs p;
+	uint32_t *selected;   // out: group indices, in place of PairArgs::active
+	uint32_t *n_selected; // device counter, zeroed before the launch
+};
+
+__global__ __launch_bounds__(256) void pair_select_kernel(PairSelectArgs a)
+{
+	const uint32_t n_active = *a.p.n_active;
+	for (uint32_t base = blockIdx.x * 256u; base < n_active; base += gridDim.x * 256u) {
+		const uint32_t gi = base + threadIdx.x;
+		bool keep = false;
+		uint32_t g = 0;
+		if (gi < n_active) {
+			g = a.p.active[gi];
+			const Group G = a.p.groups[g];
+			const AssayDev A = a.p.assays[G.assay & GROUP_ASSAY_MASK];
+			const uint32_t count = G.count & ~GROUP_ALIVE;
+			if (a.p.citems && (A.cache_replay & 1)) {
+				keep = false;
+			} else if (count > uint32_t(PAIR_MAX) || A.kind == 2) {
+				keep = true;
+			} else {
+				uint32_t classes = 0, arms = 0;
+				for (uint32_t i = 0; i < count; i++) {
+					if (a.p.result[G.first + i] < 0) continue;
+					const uint32_t info = a.p.items[G.first + i].info;
+					const uint32_t role = (info >> ITEM_SLOT_SHIFT) % 3u;
+					classes |= role == 2 ? 4u : ((info & ITEM_MINUS) ? 1u : 2u);
+					arms |= 1u << (((info & ITEM_MINUS) ? 0u : 2u) + (role == 1 ? 0u : 1u));
+				}
+				if (A.kind == 0) keep = (classes & 3u) == 3u && (!A.has_probe || (classes & 4u));
+				else keep = (arms & 3u) == 3u || (arms & 12u) == 12u;
+			}
+		}
+		const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+		if (m) {
+			const int lane = threadIdx.x & 63;
+			uint32_t at = 0;
+			if (lane == __builtin_ctzll(m)) at = atomicAdd(a.n_selected, uint32_t(__builtin_popcountll(m)));
+			at = uint32_t(__shfl(int(at), __builtin_ctzll(m)));
+			if (keep) a.selected[at + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = g;
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Row a6, the reference's per-target BindCache where it changes results: an oligo string used under two strand
 // concentrations / threshold sets among the PCR / padlock assays of a context.  The assays that hold such an oligo are
