@@ -63,7 +63,6 @@ struct BindArgs {
 };
 
 // reference to a text in the long-text arena, as a text field holds it: 0x7F 'L' 'T' + offset (8 hex digits) + length (6 hex digits)
-constexpr int LTEXT_REF_CHARS = 17;
 
 constexpr int TIE_CAP = 256;      // maximal cells of one DP beyond which the kernel reports ERR_TIE_OVERFLOW
 constexpr unsigned long long WC_MASK = // watson_and_crick[], nuc_cruc.cpp:229-238

@@ -134,6 +134,8 @@ constexpr uint32_t ITEM_MINUS = 1u << 7;
 constexpr uint32_t ITEM_PHASE_B = 1u << 8; // bound only if a phase-A item of its group bound (second strand / probe)
 constexpr int ITEM_SLOT_SHIFT = 9;
 
+constexpr int LTEXT_REF_CHARS = 17; // a text field that refers to the long-text arena: 0x7F 'L' 'T', 8 hex digits of offset, 6 of length
+
 // result of one bind; pool record only exists for bound items
 struct BoundRec {
 	int32_t loc5, loc3;

@@ -317,9 +317,10 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 				return;
 			}
 			// amplicon(): the assembled match list (already in the order the cull's stable sort by target_loc leaves it in)
-			static thread_local std::unique_ptr<ListT<PAIR_HOST>> scratch;
-			if (!scratch) scratch.reset(new ListT<PAIR_HOST>);
-			ListT<PAIR_HOST> &l = *scratch;
+			static thread_local std::unique_ptr<Entry[]> store; // the list and the working space of its sort
+			if (!store) store.reset(new Entry[2 * size_t(PAIR_HOST)]);
+			ListT<PAIR_HOST> l;
+			l.e = store.get(), l.scratch = store.get() + PAIR_HOST;
 			l.n = int(e - b);
 			for (uint32_t i = b; i < e; i++) {
 				Entry &en = l.e[i - b];

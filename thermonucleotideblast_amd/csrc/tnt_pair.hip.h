@@ -96,11 +96,26 @@ struct Entry {
 	uint8_t mask;
 };
 
-TNT_HD inline void copy_text(char *dst, const char *src)
+#ifndef TNT_EXP_PAIR_SKIP
+#define TNT_EXP_PAIR_SKIP 0 // timing experiments (wrong results): 1 no alignment texts in the hits, 2 no hit records at all, 4 nothing behind the gather of a group
+#endif
+// The alignment text of a bound record into a hit.  Both fields start on a 4-byte boundary and the bind kernel writes its
+// text a dword at a time with zeros behind the last character (tnt_bind.hip.h): the copy moves whole dwords, as many as the
+// record's text length says -- known up front, so the loads do not wait for each other (a byte loop that stops at the zero
+// byte cost the pair kernel half of its time: 0.29 of 0.63 ms per config-2 step).  A text that lives in the long-text arena
+// is LTEXT_REF_CHARS characters of reference in the field, whatever its own length.
+TNT_HD inline void copy_text(char *dst, const BoundRec &rec)
 {
-	int i = 0;
-	for (; i < ALIGN_TEXT - 1 && src[i]; i++) dst[i] = src[i];
-	dst[i] = 0;
+	if (TNT_EXP_PAIR_SKIP & 1) {
+		dst[0] = 0;
+		return;
+	}
+	int chars = rec.text_len < ALIGN_TEXT ? rec.text_len : LTEXT_REF_CHARS;
+	chars = chars < 0 ? 0 : (chars > ALIGN_TEXT - 1 ? ALIGN_TEXT - 1 : chars);
+	const uint32_t *s = reinterpret_cast<const uint32_t *>(rec.text);
+	uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+	const int words = chars / 4 + 1; // the characters and the zero behind them
+	for (int i = 0; i < words; i++) d[i] = s[i];
 }
 
 // hybrid_sig keeps its mismatch / gap / clamp counts in int8_t (hybrid_sig.h:121-164): a count beyond 127 -- a probe of
@@ -153,8 +168,12 @@ TNT_HD inline bool info_less(const Entry &x, const Entry &y, const BoundRec *poo
 	return pool[x.rec].tm > pool[y.rec].tm;
 }
 
+// A (target, assay) list and the working space of its sorts and bind steps: N entries each, in storage the caller owns -- arrays
+// of the function's own (scratch memory on the device, the worker's stack on the host) or, for the common instance of the pair
+// kernel, the workgroup's LDS (a lane's chain of dependent accesses runs at LDS latency instead of scratch-memory latency).
 template <int N> struct ListT {
-	Entry e[N];
+	Entry *e;
+	Entry *scratch;
 	int n;
 };
 
@@ -269,7 +288,7 @@ template <class Less> TNT_HD void list_sort(Entry *e, Entry *tmp, int n, Less le
 template <int N> TNT_HD void cull(ListT<N> &l, int max_len, bool has_probe, bool single_primer, int &cnt_minus, int &cnt_plus)
 {
 	const uint32_t threshold = uint32_t(max_len) + 50u;
-	Entry tmp[N];
+	Entry *const tmp = l.scratch;
 	list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }, true);
 	// (no entry carries MVALID here: the flag is taken off again where the survivors are compacted below -- one pass over a
 	// 700 000-entry list of a windowed target less)
@@ -311,7 +330,7 @@ template <int N> TNT_HD void cull(ListT<N> &l, int max_len, bool has_probe, bool
 // bind_oligo_to_{minus,plus}_strand, mask overload: list surgery of bind_oligo.cpp:476-500,806-826
 template <int N> TNT_HD void bind_step(ListT<N> &l, uint8_t want, const BoundRec *pool)
 {
-	Entry cur[N];
+	Entry *const cur = l.scratch;
 	int nc = 0;
 	int o = 0;
 	for (int i = 0; i < l.n; i++) {
@@ -347,12 +366,22 @@ struct ConflictRun {
 	const ConflictRec *recs;
 	TNT_HD const ConflictRec &operator[](int g) const { return recs[vals[g]]; }
 };
-template <int N, bool CACHED = false> TNT_HD void pair_group(const PairArgs &a, const Group G, ConflictRun run = ConflictRun{nullptr, nullptr}, int n_run = 0, uint32_t cfirst = 0);
+template <int N, bool CACHED = false, bool WORK = false> TNT_HD void pair_group(const PairArgs &a, const Group G, ConflictRun run = ConflictRun{nullptr, nullptr}, int n_run = 0, uint32_t cfirst = 0, Entry *work = nullptr);
 
 TNT_HD inline Hit *alloc_hit(const PairArgs &a)
 {
+	if (TNT_EXP_PAIR_SKIP & 2) return nullptr;
 #if defined(__HIP_DEVICE_COMPILE__)
-	const uint32_t o = atomicAdd(a.hit_count, 1u);
+	// One atomic for all the lanes of the wavefront that stand here together: 32 000 hits per step on one counter is 0.4 ms of
+	// serialised atomics otherwise (a hot word takes some 90 of them per microsecond), and behind pair_select_kernel most lanes of
+	// a wavefront do report a hit.
+	const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+	const int leader = __builtin_ctzll(here);
+	const int lane = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+	uint32_t first = 0;
+	if (lane == leader) first = atomicAdd(a.hit_count, uint32_t(__builtin_popcountll(here)));
+	first = uint32_t(__builtin_amdgcn_readlane(int(first), leader));
+	const uint32_t o = first + uint32_t(__builtin_popcountll(here & ((1ull << lane) - 1ull)));
 #else
 	const uint32_t o = __atomic_fetch_add(a.hit_count, 1u, __ATOMIC_RELAXED); // (the host replay runs on several threads)
 #endif
@@ -590,7 +619,7 @@ TNT_HD inline void cache_resolve(const PairArgs &a, Entry &e, const ConflictRun 
 	int n = 0;
 	if (full)
 		for (; n < ALIGN_TEXT - 1 && U.text[n]; n++) r.text[n] = U.text[n];
-	r.text[n] = 0;
+	for (int z = n; z < (n / 4 + 1) * 4; z++) r.text[z] = 0; // (zeros to the end of the dword, as the bind kernel leaves its texts: copy_text moves dwords)
 	r.text_len = n;
 	e.rec = int32_t(at);
 	e.loc5 = r.loc5, e.loc3 = r.loc3;
@@ -598,8 +627,11 @@ TNT_HD inline void cache_resolve(const PairArgs &a, Entry &e, const ConflictRun 
 
 // N = PAIR_MAX: the groups of up to PAIR_MAX items (all of them in practice); N = PAIR_BIG: the crowded rest.  The
 // per-lane lists live in scratch memory, so the common instance keeps them small.
+constexpr int PAIR_WORK_STRIDE = 2 * PAIR_SMALL * int(sizeof(Entry) / 4) + 1; // dwords per lane: an odd stride, so that the lanes' entries of one index fall on different banks
 template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(PairArgs a)
 {
+	static_assert(sizeof(Entry) % 4 == 0 && alignof(Entry) <= 4, "entries are whole dwords");
+	__shared__ uint32_t s_work[N == PAIR_SMALL ? PAIR_THREADS * PAIR_WORK_STRIDE : 1];
 	if (N == PAIR_BIG && *a.n_big == 0) return;
 	const uint32_t n_active = *a.n_active;
 	for (uint32_t gi = blockIdx.x * PAIR_THREADS + threadIdx.x; gi < n_active; gi += gridDim.x * PAIR_THREADS) {
@@ -612,13 +644,18 @@ template <int N> __global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(Pai
 			if (N == PAIR_MAX && fits == PAIR_BIG && !a.big_enabled) atomicOr(a.err, ERR_LIST_OVERFLOW);
 			continue;
 		}
-		pair_group<N>(a, G);
+#ifndef TNT_PAIR_NO_LDS
+		if constexpr (N == PAIR_SMALL) pair_group<N, false, true>(a, G, ConflictRun{nullptr, nullptr}, 0, 0, reinterpret_cast<Entry *>(s_work + threadIdx.x * PAIR_WORK_STRIDE));
+		else
+#endif
+			pair_group<N>(a, G);
 	}
 }
 
 // CACHED: the group belongs to an assay that goes through the replay of the reference's BindCache: its items are
 // a.citems[cfirst ...], nothing is known about them until a bind step asks (cache_resolve), records come from a.cpool.
-template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Group G, const ConflictRun run, int n_run, uint32_t cfirst)
+// WORK: the list and its working space live in `work` (2 * N entries handed in by the caller: the LDS of pair_kernel<PAIR_SMALL>).
+template <int N, bool CACHED, bool WORK> TNT_HD void pair_group(const PairArgs &a, const Group G, const ConflictRun run, int n_run, uint32_t cfirst, Entry *work)
 {
 	const AssayDev A = a.assays[G.assay & GROUP_ASSAY_MASK];
 	const int seq_index = int(a.db.first_seq_index + a.unit_target[G.target]);
@@ -634,7 +671,10 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 	// The seed kernel emits the items of a group in arbitrary order; the reference's list order (the order of the
 	// seed keys: target_loc, assembly group, word index for amplicon(); list, diagonal, word index for the hash
 	// overload) is restored here, where only the groups that bound something arrive.
+	Entry own[WORK ? 1 : 2 * N];
 	ListT<N> l;
+	l.e = WORK ? work : own;
+	l.scratch = l.e + N;
 	l.n = int(g_count);
 	bool any_bound = false;
 	uint32_t bound_classes = 0; // 1: a minus-strand primer is bound, 2: a plus-strand primer, 4: a probe
@@ -679,6 +719,7 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 	if (!CACHED && A.kind == 0 && ((bound_classes & 3u) != 3u || (A.has_probe && !(bound_classes & 4u)))) return;
 	// padlock() pairs an upstream with a downstream arm of the same strand (padlock_search.cpp:62-361)
 	if (!CACHED && A.kind == 1 && (bound_arms & 3u) != 3u && (bound_arms & 12u) != 12u) return;
+	if (TNT_EXP_PAIR_SKIP & 4) return;
 #if !defined(__HIP_DEVICE_COMPILE__)
 	bool in_order = true; // (the lists of windowed targets arrive in list order: tnt_sort.hip)
 	for (int i = 1; i < l.n && in_order; i++) in_order = order[i - 1] < order[i];
@@ -737,10 +778,7 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				bind_step(l, want, pool);
 			}
 		}
-		{
-			Entry tmp[N];
-			list_sort(l.e, tmp, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }, true); // :356
-		}
+		list_sort(l.e, l.scratch, l.n, [](const Entry &x, const Entry &y) { return oligo_loc_less(x, y); }, true); // :356
 
 		const bool apply_mm = a.min_max_primer_clamp >= 0;
 		const uint32_t min_max_clamp = apply_mm ? uint32_t(a.min_max_primer_clamp) : 0u;
@@ -804,16 +842,16 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 						out->probe_tm = bp.tm, out->probe_dH = bp.dH, out->probe_dS = bp.dS;
 						out->probe_mm = wrap8(bp.mm), out->probe_gap = wrap8(bp.gap);
 						out->probe_strand = (P.mask & MPLUS) ? 0 : 1;
-						copy_text(out->forward_align, fo.text);
-						copy_text(out->reverse_align, ro.text);
-						copy_text(out->probe_align, bp.text);
+						copy_text(out->forward_align, fo);
+						copy_text(out->reverse_align, ro);
+						copy_text(out->probe_align, bp);
 					}
 				} else {
 					Hit *out = alloc_hit(a);
 					if (!out) return;
 					*out = h;
-					copy_text(out->forward_align, fo.text);
-					copy_text(out->reverse_align, ro.text);
+					copy_text(out->forward_align, fo);
+					copy_text(out->reverse_align, ro);
 				}
 			}
 		}
@@ -860,7 +898,7 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				out->probe_start = e.loc5, out->probe_stop = e.loc3;
 				out->probe_strand = pass == 0 ? 1 : 0;
 				if (A.cache_replay & 2) out->amplicon_start = int32_t(e.tloc); // (the diagonal: read and cleared by the merge of the segments' hits)
-				copy_text(out->probe_align, b.text);
+				copy_text(out->probe_align, b);
 			}
 		}
 		return;
@@ -919,8 +957,8 @@ template <int N, bool CACHED> TNT_HD void pair_group(const PairArgs &a, const Gr
 				out->forward_gap = wrap8(bd.gap), out->reverse_gap = wrap8(bu.gap);
 				out->forward_primer_clamp = wrap8(bd.a3);
 				out->reverse_primer_clamp = wrap8(bu.a5);
-				copy_text(out->forward_align, bd.text);
-				copy_text(out->reverse_align, bu.text);
+				copy_text(out->forward_align, bd);
+				copy_text(out->reverse_align, bu);
 			}
 		}
 	}
