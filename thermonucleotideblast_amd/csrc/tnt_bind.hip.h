@@ -762,9 +762,24 @@ __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const ui
 	return false;
 #endif
 	int a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0, loc5 = 0, loc3 = 0;
+	// The columns of the best alignment sit in `best` -- HBM for the instances whose LDS is taken by other things (every plain
+	// instance of 23 rows and more) -- and the counts below and the alignment text read them one at a time, each read waiting for
+	// the one before it (a rolled loop; the text's stores in between may alias them as far as the compiler knows): some hundred
+	// memory round trips per record, 100 000 of the 509 000 cycles a wavefront spent on 64 windows (TNT_EXP_STATS: thresholds
+	// 37 000, output 84 000).  `cols` (LDS) is free once the enumeration is through: the columns move there eight loads at a time.
 	if (best_valid && (FULL || status == 0)) {
-		const int front_q = col_q(best[bi.k0 * STRIDE]), front_t = col_t(best[bi.k0 * STRIDE]);
-		const int back_q = col_q(best[(bi.k1 - 1) * STRIDE]), back_t = col_t(best[(bi.k1 - 1) * STRIDE]);
+		for (int k = bi.k0; k < bi.k1; k += 8) {
+			uint8_t v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = k + u < bi.k1 ? best[(k + u) * STRIDE] : uint8_t(0);
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				if (k + u < bi.k1) cols[(k + u) * STRIDE] = v[u];
+		}
+	}
+	if (best_valid && (FULL || status == 0)) {
+		const int front_q = col_q(cols[bi.k0 * STRIDE]), front_t = col_t(cols[bi.k0 * STRIDE]);
+		const int back_q = col_q(cols[(bi.k1 - 1) * STRIDE]), back_t = col_t(cols[(bi.k1 - 1) * STRIDE]);
 		{ // anchor5_query, nuc_cruc_anchor.cpp:143-192
 			int qi = 0, ti = bi.fm_q + bi.fm_t;
 			bool go = !(front_t == bE);
@@ -790,7 +805,7 @@ __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const ui
 		{ // num_mismatch_by_query / num_gap / max_contiguous_target_degen, nuc_cruc.h:389-483
 			int aligned = 0, run = 0;
 			for (int k = bi.k0; k < bi.k1; k++) {
-				const uint8_t cw = best[k * STRIDE];
+				const uint8_t cw = cols[k * STRIDE];
 				const int q = col_q(cw), t = col_t(cw);
 				if (!is_virtual(q)) {
 					if (!is_virtual(t) && !is_complementary(q, t)) mm++;
@@ -905,20 +920,20 @@ __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const ui
 		};
 		put('5'), put('\''), put(' ');
 		for (int i = 0; i < prefix; i++) put(base_letter(QUERY(bi.fm_q - prefix + i)));
-		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_q(best[k * STRIDE])));
+		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_q(cols[k * STRIDE])));
 		for (int i = 0; i < suffix; i++) put(base_letter(QUERY(bi.lm_q + 1 + i)));
 		put(' '), put('3'), put('\''), put('\n');
 		put(' '), put(' '), put(' ');
 		for (int i = 0; i < prefix; i++) put(is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ');
 		for (int k = bi.k0; k < bi.k1; k++) {
-			const uint8_t cw = best[k * STRIDE];
+			const uint8_t cw = cols[k * STRIDE];
 			put(is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ');
 		}
 		for (int i = 0; i < suffix; i++) put(is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ');
 		put('\n');
 		put('3'), put('\''), put(' ');
 		for (int i = prefix; i > 0; i--) put(base_letter(TARGET(bi.fm_t + i)));
-		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_t(best[k * STRIDE])));
+		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_t(cols[k * STRIDE])));
 		for (int i = 1; i <= suffix; i++) put(base_letter(TARGET(bi.lm_t - i)));
 		put(' '), put('5'), put('\'');
 		text32[o >> 2] = acc; // the rest and the terminating zero (acc holds zeros above the characters written)
