@@ -799,7 +799,9 @@ template <int N, bool CACHED, bool WORK> TNT_HD void pair_group(const PairArgs &
 			if (F.mask & (MPLUS | MP)) continue;
 			for (int r = f + 1; r < l.n; r++) {
 				const Entry &R = l.e[r];
+#ifndef TNT_EXP_FULL_WALK // (tests/native/host_pair_walk_check.hip holds the bounded walks against the reference's walk over every pair)
 				if (ascending && long(R.loc5) - slack - long(F.loc5) + 1 > long(a.max_len)) break;
+#endif
 				if (R.mask & (MMINUS | MP)) continue;
 				if (!single && ((F.mask & (MR | MF)) == (R.mask & (MR | MF)))) continue;
 				if (F.loc3 >= R.loc5) continue;
@@ -925,6 +927,7 @@ template <int N, bool CACHED, bool WORK> TNT_HD void pair_group(const PairArgs &
 			const long d5_lo = minus ? long(U.loc5) - 1 - long(max_len) - span_hi : long(U.loc3) + 1;
 			const long d5_hi = minus ? long(U.loc5) - 1 - span_lo : long(U.loc3) + 1 + long(max_len);
 			int d = 0;
+#ifndef TNT_EXP_FULL_WALK
 			if (ln[down] > 16) { // first entry with loc5 >= d5_lo
 				int lo = 0, hi = ln[down];
 				while (lo < hi) {
@@ -934,9 +937,12 @@ template <int N, bool CACHED, bool WORK> TNT_HD void pair_group(const PairArgs &
 				}
 				d = lo;
 			}
+#endif
 			for (; d < ln[down]; d++) {
 				const Entry &D = lists[down][d];
+#ifndef TNT_EXP_FULL_WALK
 				if (long(D.loc5) > d5_hi) break;
+#endif
 				const int len = minus ? (U.loc5 - D.loc3 - 1) : (D.loc5 - U.loc3 - 1);
 				if (len < 0 || len > max_len) continue;
 				{
