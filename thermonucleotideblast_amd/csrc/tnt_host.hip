@@ -810,7 +810,8 @@ void launch_bind(tnt_ctx *c, const BindArgs &a, int blocks, int lmax, hipStream_
 		// bases -- the wavefront-per-window kernel, whose workgroup (one wavefront) rebuilds its delta_g planes per pass
 		const int rows = lmax == 0 ? (unit_rows ? unit_rows : c->unit_rows) : bucket_rows(lmax);
 		if (rows > 64) {
-			const int R = wb_rows_per_lane(rows), wblocks = c->n_cu * 6;
+			// one wavefront per workgroup, one trace slab per wavefront: the grid is what ensure_scratch sized a lane's slabs for
+			const int R = wb_rows_per_lane(rows), wblocks = bind_grid(c, BUCKET_WAVE | R) * wb_waves(R);
 			switch (R) {
 #define X(N) case N: tnt::launch_wbind_dink_##N(a, wblocks, lmax == 0, stream); break;
 				TNT_WBIND_LADDER(X)
@@ -2802,7 +2803,9 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	if (start) (void)hipEventDestroy(start);
 	if (rc) return rc;
 	ctx->blob_cap_hits = 0, ctx->blob_hits = 0, ctx->blob_bytes = 0;
-	if (ctx->compact_in_search && db->h_long_targets.empty()) { // (the hits of windowed targets join the list on the host, at collect time)
+	// (the hits of windowed targets join the list on the host, at collect time; the segments' hits of probes beyond 128 bases are
+	// merged there too -- amplicon_start carries the seed's diagonal until then -- so the blob is packed from the merged records)
+	if (ctx->compact_in_search && db->h_long_targets.empty() && !ctx->long_probes) {
 		const size_t cap_hits = std::min<size_t>(ctx->hit_cap, std::max<size_t>(4 * ctx->dev_hits_n, size_t(1) << 16));
 		rc = enqueue_compaction(ctx, cap_hits, ctx->G() + C_HITS);
 		if (rc) return rc;
@@ -3563,7 +3566,7 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
 		const tnt_bind_req &r = req[i];
 		const size_t t = size_t(r.seq_index) - db->first_seq_index;
 		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc >= TNT_MAX_OLIGO ||
-		    r.target_loc < 0 || !(r.ct > 0.0f)) {
+		    size_t(r.query_loc) >= ctx->oligos[size_t(r.oligo)].size() || r.target_loc < 0 || !(r.ct > 0.0f)) {
 			ctx->err = "bad bind request";
 			return TNT_E_ARG;
 		}
@@ -3693,12 +3696,18 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 	for (size_t i = 0; i < n; i++) {
 		const tnt_bind_req &r = req[i];
 		const size_t t = size_t(r.seq_index) - db->first_seq_index;
-		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc >= TNT_MAX_OLIGO ||
-		    r.target_loc < 0 || !(r.ct > 0.0f)) {
+		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 ||
+		    size_t(r.query_loc) >= ctx->oligos[size_t(r.oligo)].size() || r.target_loc < 0 || !(r.ct > 0.0f)) {
 			ctx->err = "bad bind request";
 			return TNT_E_ARG;
 		}
 		const int L = int(ctx->oligos[r.oligo].size());
+		// the pre-filter is a lane-per-window kernel: oligos of up to MAX_LANE_OLIGO bases, whose word index fits the seven bits
+		// of a work item (longer oligos are bound by the wavefront kernel, which has no pre-filter in front of it)
+		if (L > MAX_LANE_OLIGO || r.query_loc > 127) {
+			ctx->err = "tnt_filter_bound: the pre-filter serves oligos of up to 128 bases";
+			return TNT_E_LIMIT;
+		}
 		slots[i] = Slot{r.oligo, logf((r.ct - 0.5f * 0.0f) * 1.0f), r.role == 1 ? 1 : 0, -1, 0, 0};
 		items[i] = Item{uint32_t(t), uint32_t(r.target_loc), uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT), 0};
 		// windows with a non-ACGT code meet the filter instance of the general buckets

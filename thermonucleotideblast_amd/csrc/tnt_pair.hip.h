@@ -35,7 +35,7 @@ namespace tnt {
 #endif
 
 constexpr int PAIR_THREADS = 64;
-constexpr int PAIR_HOST = 1 << 20; // entries of one (target, assay) list in the host replay (arrays on 512-MB thread stacks: only the pages a list touches exist)
+constexpr int PAIR_HOST = 1 << 20; // entries of one (target, assay) list in the host replay (arrays on 256-MB thread stacks: only the pages a list touches exist)
 #ifndef TNT_PAIR_SMALL
 #define TNT_PAIR_SMALL 16
 #endif
@@ -621,6 +621,16 @@ TNT_HD inline void cache_resolve(const PairArgs &a, Entry &e, const ConflictRun 
 		for (; n < ALIGN_TEXT - 1 && U.text[n]; n++) r.text[n] = U.text[n];
 	for (int z = n; z < (n / 4 + 1) * 4; z++) r.text[z] = 0; // (zeros to the end of the dword, as the bind kernel leaves its texts: copy_text moves dwords)
 	r.text_len = n;
+	// a text that lives in the long-text arena: the field holds 0x7F 'L' 'T', eight hex digits of offset, six of length (bind_tail).
+	// sort_by_bound_match compares the text's OWN length where Tm and the mismatch count tie (bound_less), so take it from there
+	if (n == LTEXT_REF_CHARS && uint8_t(r.text[0]) == 0x7Fu && r.text[1] == 'L' && r.text[2] == 'T') {
+		int len = 0;
+		for (int d = 0; d < 6; d++) {
+			const int ch = r.text[11 + d];
+			len = len * 16 + (ch >= 'a' ? ch - 'a' + 10 : ch - '0');
+		}
+		r.text_len = len;
+	}
 	e.rec = int32_t(at);
 	e.loc5 = r.loc5, e.loc3 = r.loc3;
 }

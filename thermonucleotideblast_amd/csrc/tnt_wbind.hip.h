@@ -270,7 +270,7 @@ template <int R, bool FULL, bool DINK = false> __global__ __launch_bounds__(64 *
 				const bool colvalid = uint32_t(j - 1) < uint32_t(W);
 				const bool firstcol = j == 1;
 				const uint32_t rtw_next = uint32_t(wave_shr1(int(rt_ahead), int(rtw)));
-				rt_ahead = rtc[s + 2];
+				rt_ahead = rtc[s + 2 < WMAX + 3 ? s + 2 : WMAX + 3]; // (steps run to nl + W - 1: behind the window every column reads the GAP word at the array's end)
 				int nx[R], ny[R], nt[R];
 				tables(rtw_next, rtw, nx, ny, nt);
 				// the row above: (i-1, j) as the lane above left it one step ago; the border row for lane 0
