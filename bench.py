@@ -10,9 +10,10 @@ there is no data-path collective, and the hit records of every step are gathered
 
 A step = one pass of the hot path (seed -> cull -> bind -> pair) over targets that are already packed and
 resident in HBM.
-  --scaling weak   (default) every rank owns an independent shard of the per-GPU size of the configuration
+  --scaling weak   every rank owns an independent shard of the per-GPU size of the configuration (default)
   --scaling strong one database of the configuration's full size (configs 4 / 5 as BASELINE.json words them: 10 M x
-                   2 kb / 5 M x 1 kb), generated in 8 pieces and dealt to the ranks in contiguous runs
+                   2 kb / 5 M x 1 kb), generated in 8 pieces and dealt to the ranks in contiguous runs (default for
+                   --config 4 / 5 with --gpus > 1)
 Workload at N = 1: BASELINE.json configs[1], "96 PCR primer pairs vs 1M x 1kb synthetic targets".
 Prints ONE JSON line on rank 0.
 """
@@ -34,6 +35,7 @@ VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2.0  # guide: 1 024 SIMDs, one wave-instruction
 # measured on the same hardware (scripts/ubench_valu.hip, profiles/r04q_ubench_valu.txt, 2+ wavefronts per SIMD): plain add / logic
 # ops sustain 1.07e12 wave-instructions/s, v_max / v_cmp / v_cndmask / v_alignbit / three-operand, SDWA and packed-16 forms 5.95e11
 VALU_RATE_MEASURED = {"full_rate_ops": 1.07e12, "half_rate_ops": 5.95e11}
+INT32_LANE_OPS_PEAK = VALU_PEAK_GUIDE * 64  # the same issue rate in lane operations: 7.86e13 int32 lane-ops/s
 PIECES = 8                     # the strong-scaling database is generated in this many pieces
 
 
@@ -45,7 +47,8 @@ def parse():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config 1..5 (default 2)")
     ap.add_argument("--targets", type=int, default=None, help="override targets per GPU (weak) / in total (strong)")
     ap.add_argument("--assays", type=int, default=None)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: strong for configs 4 / 5 on more than one GPU (BASELINE.json words them as ONE database sharded over the GPUs), else weak")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the bounded CPU baseline sample")
     ap.add_argument("--parity-targets", type=int, default=65536, help="cap of the parity sample (targets checked against the CPU checkers)")
     ap.add_argument("--gather", choices=("padded", "exact"), default="padded",
@@ -56,7 +59,23 @@ def parse():
                     help="single GPU: run the multi-GPU step (RCCL process group of one rank, staged gather) instead of the plain one")
     ap.add_argument("--launch-only", action="store_true",
                     help="no GPU: start the ranks (gloo), count them, run the hit gather on made-up records and print the line")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if (args.config in (4, 5) and args.gpus > 1) else "weak"
+    return args
+
+
+def csrc_hash():
+    """sha256 over the kernel / host sources the library is built from (thermonucleotideblast_amd/csrc, sorted by name), 16 hex
+    digits: what a PMC file must carry (profiles/bind_pmc.json: csrc_sha16) for its counters to describe THIS build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "thermonucleotideblast_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def free_port():
@@ -263,7 +282,7 @@ def launch_only(args, rank, world):
         sys.exit(1)
 
 
-def roofline_of_bind_stage(hbm_achieved, traffic, valu, n_binds, bind_ms_step):
+def roofline_of_bind_stage(hbm_achieved, traffic, valu, n_binds, bind_ms_step, n_cells=0, pmc_state=None):
     """The dominant stage (pre-filter + bind kernels).  What bounds it is VALU issue (integer DP: DESIGN.md 4.2, 4.2a), so where
     the instruction counts of the workload are on file (profiles/bind_pmc.json, config 2 at full size) the line prices it against
     the VALU issue peak of the guide; the algorithmic-bytes figure against HBM (tiny by construction) stays beside it."""
@@ -273,14 +292,26 @@ def roofline_of_bind_stage(hbm_achieved, traffic, valu, n_binds, bind_ms_step):
     src = ("profiles/bind_pmc.json: rocprofv3 --pmc passes of this workload in a run of their own (scripts/pmc_collect.sh), not measured by this process"
            if traffic is not None else None)
     dps = n_binds / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0
+    # SURVEY 8(d) asks for ALGORITHMIC work over the measured time: the windows this run handed to the bind stage (counted on the
+    # device: tnt_timing.n_cells = sum of oligo length x window width) x the three states align_dimer updates per cell
+    # (nuc_cruc.cpp:492-696), against the int32 lane-operation rate of the chip (one lane-op per state update at the very least)
+    su = 3.0 * n_cells / (bind_ms_step * 1e-3) if bind_ms_step > 0 else 0.0
+    algorithmic = {"state_updates_per_s": su, "peak_int32_lane_ops": INT32_LANE_OPS_PEAK, "frac": su / INT32_LANE_OPS_PEAK,
+                   "dp_per_step": n_binds, "cells_per_step": n_cells,
+                   "note": "3 x DP cells of this run's windows (device counter) / bind-stage time (HIP events) / (1 024 SIMDs x 2.4 GHz / 2 x 64 lanes); "
+                           "the pre-filter decides 94 % of the windows with 2 states per cell, so the work actually executed is less than this"}
     if valu:
-        return {"bound": "valu", "kernel": kernel, "achieved": valu["achieved"], "peak": valu["peak_guide"], "unit": valu["unit"], "frac": valu["frac_guide"],
-                "traffic": traffic, "traffic_source": src, "dp_per_s": dps, "hbm": hbm, "valu_issue": valu,
-                "note": "bound by VALU issue, not by HBM: achieved = VALU wave-instructions per step (PMC SQ_INSTS_VALU of this workload, "
-                        "profiles/bind_pmc.json) over this run's stage time (HIP events); peak = 1 024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction "
-                        "(the guide's wave64 rate for full-rate ops; half of this stage's instructions are half-rate packed / three-operand forms); "
-                        "traffic = PMC 2*FETCH_SIZE + WRITE_SIZE per step"}
-    return dict({"bound": "hbm", "kernel": kernel, "traffic": traffic, "traffic_source": src, "dp_per_s": dps, "valu_issue": None}, **hbm)
+        return {"bound": "valu", "kernel": kernel, "achieved": su, "peak": INT32_LANE_OPS_PEAK, "unit": "DP state updates/s vs int32 lane-ops/s", "frac": su / INT32_LANE_OPS_PEAK,
+                "algorithmic": algorithmic, "pmc": pmc_state,
+                "traffic": traffic, "traffic_source": src, "dp_per_s": dps, "hbm": hbm, "valu_issue": dict(valu, frac=valu["frac_guide"]),
+                "note": "bound by VALU issue, not by HBM: achieved / frac = ALGORITHMIC DP state updates of this run (3 x cells, device counter) over "
+                        "the stage time (HIP events) against 7.86e13 int32 lane-ops/s (1 024 SIMDs x 2.4 GHz / 2 x 64 lanes); valu_issue = the pipe's "
+                        "utilisation (PMC SQ_INSTS_VALU of this workload and build, profiles/bind_pmc.json, over this run's time: it credits every "
+                        "instruction issued); traffic = PMC 2*FETCH_SIZE + WRITE_SIZE per step"}
+    return {"bound": "valu", "kernel": kernel, "achieved": su, "peak": INT32_LANE_OPS_PEAK, "unit": "DP state updates/s vs int32 lane-ops/s", "frac": su / INT32_LANE_OPS_PEAK,
+            "algorithmic": algorithmic, "pmc": pmc_state, "traffic": traffic, "traffic_source": src, "dp_per_s": dps, "hbm": hbm, "valu_issue": None,
+            "note": "bound by VALU issue, not by HBM (integer DP); achieved = algorithmic DP state updates of this run over the stage time (HIP events); "
+                    "no PMC file for this build and workload: traffic and issue utilisation not reported"}
 
 
 def main():
@@ -349,12 +380,12 @@ def main():
         device memory, page-locked receive buffer on rank 0; the same code runs on gloo in tests/test_distributed_cpu.py).
         The gather of one search travels while the next search runs; every search and every gather of the n steps is
         complete when this returns."""
-        acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_hits": 0, "gather_bytes": 0, "gather_mode": None}
+        acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_cells": 0, "n_hits": 0, "gather_bytes": 0, "gather_mode": None}
         if n <= 0:
             return acc
         todo = [db for _ in range(n) for db in dbs]
         eng.enqueue(todo[0])
-        step_hits = step_binds = 0
+        step_hits = step_binds = step_cells = 0
         for i, db in enumerate(todo):
             if world == 1 and not selftest:
                 # the hits reach the host in compact form (9 MB per search of config 2 instead of 47 MB of 1 464-byte records)
@@ -381,9 +412,10 @@ def main():
             acc["pair"] += tm.pair_ms
             step_hits += nh
             step_binds += tm.n_binds
+            step_cells += tm.n_cells
             if (i + 1) % len(dbs) == 0:
-                acc["n_hits"], acc["n_binds"] = step_hits, step_binds  # of the last step
-                step_hits = step_binds = 0
+                acc["n_hits"], acc["n_binds"], acc["n_cells"] = step_hits, step_binds, step_cells  # of the last step
+                step_hits = step_binds = step_cells = 0
         return acc
 
     run(args.warmup)
@@ -422,9 +454,15 @@ def main():
         valu = None
         seed_issue = None
         pmc = os.path.join(ROOT, "profiles", "bind_pmc.json")
+        pmc_state = None
         if os.path.exists(pmc) and args.config == 2 and per_piece == full and args.scaling == "weak":  # measured for this workload only
             try:
                 rec = json.load(open(pmc))
+                # counters from a file describe the build they were collected on: used only when the file carries the hash of
+                # the sources this library was built from
+                pmc_state = "current" if rec.get("csrc_sha16") == csrc_hash() else "stale"
+                if pmc_state == "stale":
+                    raise ValueError("profiles/bind_pmc.json was collected on another build")
                 traffic = rec.get("hbm_bytes_per_step")
                 # What bounds these kernels is instruction issue and LDS bank conflicts, not HBM:
                 # VALU wave-instructions per step from the same PMC file over this run's bind time, against the guide's plain
@@ -480,7 +518,7 @@ def main():
             "gather_bytes_per_search": acc["gather_bytes"],
             "pack_and_h2d_s": pack_s,
             "stage_ms_per_step": {"seed": seed_ms_step, "bind": bind_ms_step, "pair": pair_ms / steps},
-            "roofline": roofline_of_bind_stage(achieved, traffic, valu, n_binds, bind_ms_step),
+            "roofline": roofline_of_bind_stage(achieved, traffic, valu, n_binds, bind_ms_step, acc["n_cells"], pmc_state),
             # the streaming stage, for which SURVEY 8(d) means the HBM roofline: the seed kernels of a step (scan + cull)
             "roofline_seed": {"bound": "hbm", "kernel": "seed stage: seed2_kernel (scan + diagonal de-duplication + first cull + emission into the buckets' queues)", "achieved": seed_achieved,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": seed_achieved / HBM_PEAK_GBS,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNT_ABI_VERSION 5
+#define TNT_ABI_VERSION 6
 
 /* Longest oligo (the reference's MAX_SEQUENCE_LENGTH, nuc_cruc.h:80).  Up to 64 bases the rows of the alignment live
  * in registers, one window per lane; 65..128 run through an instance that keeps them in scratch memory; 129..1024 are
@@ -165,6 +165,12 @@ int tnt_abi_version(void);
 int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_assays, int device, tnt_ctx **out);
 void tnt_ctx_destroy(tnt_ctx *ctx);
 const char *tnt_last_error(const tnt_ctx *ctx); /* ctx may be NULL: last creation error */
+/* Warnings about the context's options, "" when there are none (ABI v6).  One today: thresholds in the regime of SURVEY
+ * Q11 -- a class of oligos whose thresholds accept Tm = 0 and dG = 0.  For a window without any valid alignment the reference
+ * evaluates the first / last match its NucCruc object kept from the previous valid window (alignment::clear() leaves them,
+ * nuc_cruc.h:360-371,386-387) and may report it as a hit with Tm = 0 (bind_oligo.cpp:600-624); which ones depends on the order
+ * its threads met the windows.  This library reports such windows as not bound: under these options it can list fewer hits. */
+const char *tnt_ctx_warnings(const tnt_ctx *ctx);
 
 /* unique-oligo table of the context (assay oligos de-duplicated by string) */
 int tnt_ctx_num_oligos(const tnt_ctx *ctx);
@@ -276,6 +282,8 @@ typedef struct tnt_timing {
 	float seed_ms, bind_ms, pair_ms, total_ms;
 	uint64_t n_seeds, n_binds, n_bound, n_hits;
 	uint64_t n_filtered; /* of n_binds: windows the pre-filter rejected before the full bind kernel (their Tm cannot reach the minimum) */
+	uint64_t n_cells;    /* DP cells of the n_binds windows: sum of oligo length x window width (align_dimer fills three states per cell,
+	                        nuc_cruc.cpp:492-696): the algorithmic work of the bind stage (ABI v6) */
 } tnt_timing;
 int tnt_last_timing(tnt_ctx *ctx, tnt_timing *out);
 

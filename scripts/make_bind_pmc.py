@@ -8,7 +8,7 @@ import sys
 src = sys.argv[1]
 summary = json.load(open(src))
 d = summary["kernels"]
-stage = [k for k in ("bucket_kernel", "filter_kernel<L>", "bind_kernel<L>") if k in d]
+stage = [k for k in ("bucket_kernel", "regroup_count_kernel", "regroup_scan_kernel", "regroup_scatter_kernel", "ufilter_kernel<L>", "filter_kernel<L>", "bind_kernel<L>") if k in d]
 seed = "seed2_kernel" if "seed2_kernel" in d else "seed_kernel"  # (round 3: tnt_seed2.hip.h)
 fetch = sum(float(d[k]["FETCH_SIZE"]) for k in stage)   # KB per search (= per step of the full-size config)
 write = sum(float(d[k]["WRITE_SIZE"]) for k in stage)
@@ -17,15 +17,17 @@ dst = os.path.join(os.path.dirname(os.path.abspath(src)), "bind_pmc.json")
 if os.path.exists(dst):
     old = json.load(open(dst))
 out = {
-    "git_head": summary.get("git_head"),  # the build the counters were collected on (scripts/pmc_summarize.py reads .git_head)
+    "git_head": summary.get("git_head"),
+    "csrc_sha16": summary.get("csrc_sha16"),  # bench.py uses the counters only for a library built from these sources  # the build the counters were collected on (scripts/pmc_summarize.py reads .git_head)
     "source": "%s (rocprofv3 --pmc, separate passes, scripts/pmc_collect.sh 2 1000000, bind launches serialised on one stream)" % src,
-    "kernel": "bind stage of one step (config 2, 1 000 000 x 1 kb targets): bucket_kernel + filter_kernel<L> + bind_kernel<L> on the survivors",
+    "kernel": "bind stage of one step (config 2, 1 000 000 x 1 kb targets): regroup kernels + ufilter_kernel<L> (phase A) / bucket_kernel + filter_kernel<L> (phase B) + bind_kernel<L> on the survivors",
     "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
     "per_kernel_KB": {k: {"FETCH_SIZE": float(v["FETCH_SIZE"]), "WRITE_SIZE": float(v["WRITE_SIZE"])}
                       for k, v in d.items() if k in stage + [seed, "pair_kernel"]},
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_step": int((2.0 * fetch + write) * 1024),
     "SQ_INSTS_VALU_per_step": sum(float(d[k]["SQ_INSTS_VALU"]) for k in stage),
+    "lds": {k: {c: float(d[k][c]) for c in ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") if c in d[k]} for k in stage},
     # the seed stage's instruction counts (wave-instructions per step): what bounds it is issue, not the 250 MB it streams
     "seed_kernel_insts_per_step": {k: float(d[seed][k]) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")},
     "history": (old.get("history") or ([{"hbm_bytes_per_step": old["round1"]["hbm_bytes_per_step"], "SQ_INSTS_VALU_per_step": old["round1"]["SQ_INSTS_VALU_per_step"], "state": "round 1 (r01k)"}] if "round1" in old else []))

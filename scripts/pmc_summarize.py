@@ -21,6 +21,8 @@ def short(name):
     m = re.search(r"(bind_kernel)<(\d+), *(true|false)", name)
     if m:
         return "bind_kernel<%s>" % ("unit" if m.group(3) == "true" else "L")
+    if "ufilter_kernel<" in name:  # the pre-filter on queues regrouped by oligo (round 5)
+        return "ufilter_kernel<L>"
     if "filter_kernel<" in name:
         return "filter_kernel<L>"
     m = re.search(r"(\w+_kernel)\b", name)
@@ -47,13 +49,17 @@ def main():
             m = re.search(r"bind_kernel<(\d+), *false", r["Kernel_Name"])
             if m:
                 per_inst[int(m.group(1))].append(d)
-            m = re.search(r"filter_kernel<(\d+)>", r["Kernel_Name"])
+            m = re.search(r"filter_kernel<(\d+)", r["Kernel_Name"])
             if m:
                 per_filt[int(m.group(1))].append(d)
     out = {"searches": searches, "kernels": {}}
     head = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".git_head")  # written before the snapshot leaves for the GPU box
     if os.path.exists(head):
         out["git_head"] = open(head).read().strip()
+    # the hash of the sources the measured library was built from: bench.py only uses counters that carry its own build's hash
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["csrc_sha16"] = bench.csrc_hash()
     for k in sorted(set(counters) | set(dur)):
         e = {c: v / searches for c, v in sorted(counters[k].items())}
         if dur[k]:

@@ -29,7 +29,7 @@ def _oligo_set(expanded):
 def test_native_library_is_loaded(Engine):
     from thermonucleotideblast_amd import engine
     lib = engine.load_library()
-    assert lib.tnt_abi_version() == 5
+    assert lib.tnt_abi_version() == 6
     assert any("libtnt_mi355x.so" in line for line in open("/proc/self/maps"))
 
 
@@ -152,11 +152,18 @@ def test_random_windows_production_vs_oracle(Engine, oracle, seed, kw):
     e.close()
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 8, 9, 11, 100, 102])
-def test_filter_kernel_equals_its_checker(Engine, oracle, k):
-    """The pre-filter kernel (every row-count instance the oligo lengths pick) against the oracle-side restatement whose
-    soundness tests/test_filter_bound.py checks: same bound, same threshold, for every window."""
+@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 8, 9, 11, 100, 102, 1000, 1001, 1004, 1006, 1009])
+def test_filter_kernel_equals_its_checker(Engine, oracle, k, monkeypatch):
+    """The pre-filter kernels (every row-count instance the oligo lengths pick) against the oracle-side restatement whose
+    soundness tests/test_filter_bound.py checks: same bound, same threshold, for every window.  Plain windows of oligos of up
+    to 64 bases go through the regrouping and ufilter_kernel (what a search does with them); k >= 1000: the same sets
+    with TNT_MI355X_NO_REGROUP=1, i.e. filter_kernel on the queue as it is."""
     import test_filter_bound as fbt
+    if k >= 1000:
+        monkeypatch.setenv("TNT_MI355X_NO_REGROUP", "1")
+        k -= 1000
+    else:
+        monkeypatch.delenv("TNT_MI355X_NO_REGROUP", raising=False)
     long_oligos = k >= 100  # (100, 102: a Tm and a dG set for oligos of 65 to 128 bases -- the 128-row instances)
     k %= 100
     name, kw = fbt.LONG_OLIGO_SETS[k] if long_oligos else fbt.OPTION_SETS[k]
@@ -1446,6 +1453,77 @@ def test_dinkelbach_with_long_oligos_vs_oracle(Engine, oracle, kind, seed):
     assert not [b for b in bad if b[1]], [b for b in bad if b[1]][:2]
     db.close()
     e.close()
+
+
+def test_dinkelbach_many_windows_of_long_probes(Engine, oracle):
+    """--dinkelbach with probes of 200 and 300 bases on enough targets that each of the two buckets holds thousands of windows:
+    the Dinkelbach form of the wavefront kernel runs one wavefront per workgroup with a trace slab per wavefront, and its
+    grid must stay inside the slabs its lane stream owns while the other bucket's launch runs beside it (the round-4
+    advisor's finding: a grid of 6 workgroups per CU against slabs for 4)."""
+    import longwl
+    wl = longwl.make_beyond_128(11, lengths=(200, 300), n_targets=48, tl=2400)
+    wl.options.use_dinkelbach = 1
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    for _ in range(2):
+        assert tc.sorted_hit_keys(e.search(db), text_of=e.long_text) == want and len(want) >= 4
+    assert e.timing().n_binds > 4 * 4 * 256, e.timing().n_binds  # more windows than either grid has wavefronts
+    db.close()
+    e.close()
+
+
+def test_q11_regime_is_reported(Engine):
+    """Thresholds that accept Tm = 0 and dG = 0 (no -e / -E, no negative -g / -G) put a context in the regime of SURVEY Q11, where
+    the reference can report hits built from stale alignment state (nuc_cruc.h:360-371): tnt_ctx_warnings says so; with a
+    minimum Tm above 0 C it is silent."""
+    wl = synth.make_workload(3, n_targets=16, n_assays=4, seed=5)
+    e = Engine(wl.options, wl.expanded)
+    assert e.warnings() == ""
+    e.close()
+    wl.options.min_probe_tm = 0.0
+    e = Engine(wl.options, wl.expanded)
+    w = e.warnings()
+    assert "probe thresholds" in w and "nuc_cruc.h:360-371" in w and "primer and" not in w
+    e.close()
+    wl.options.min_primer_tm = 0.0
+    e = Engine(wl.options, wl.expanded)
+    assert "primer and probe thresholds" in e.warnings()
+    e.close()
+    wl.options.max_primer_dg = -5.0
+    wl.options.max_probe_dg = -5.0
+    e = Engine(wl.options, wl.expanded)
+    assert e.warnings() == ""
+    e.close()
+
+
+def test_standalone_front_end_gathers_over_rccl(tmp_path):
+    """tntblast-mi355x --gpus 1 with TNT_MI355X_GATHER=rccl: the C++ front end, no torch in the process, has to find librccl
+    by itself (tnt_gang_create: dlopen by name, then /opt/rocm/lib, then ROCM_PATH) and says which transport it uses; the run
+    fails instead of falling back when RCCL is asked for and missing.  Also: the Q11 warning on stderr."""
+    import os
+    import subprocess
+    import __graft_entry__ as g
+    wl = synth.make_workload(2, n_targets=300, n_assays=8, seed=77)
+    fa, assay = tmp_path / "db.fna", tmp_path / "assays.txt"
+    with open(fa, "w") as f:
+        for t in range(wl.n_targets):
+            f.write(">t%d\n%s\n" % (t, synth.decode(wl.codes[int(wl.offsets[t]):int(wl.offsets[t + 1])])))
+    with open(assay, "w") as f:
+        for a in wl.assays:
+            f.write("%s\t%s\t%s\n" % (a.name, a.forward, a.reverse))
+    env = dict(os.environ, TNT_MI355X_GATHER="rccl", TNT_MI355X_VERBOSE_GANG="1")
+    env.pop("LD_PRELOAD", None)
+    out = tmp_path / "out.txt"
+    r = subprocess.run([g.CLI, "-i", str(assay), "-d", str(fa), "-o", str(out), "-e", "40", "--gpus", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    assert "1 device context(s), gather over rccl" in r.stderr, r.stderr
+    assert "warning" not in r.stderr
+    assert open(out).read().count("amplicon range") > 3
+    # no minimum Tm, no maximum dG: the Q11 regime is named once on stderr
+    r = subprocess.run([g.CLI, "-i", str(assay), "-d", str(fa), "-o", str(tmp_path / "out2.txt"), "-z", "-40", "--gpus", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    assert r.stderr.count("warning: the primer thresholds accept Tm = 0") == 1, r.stderr
 
 
 def test_cache_replay_of_crowded_targets(Engine, oracle):

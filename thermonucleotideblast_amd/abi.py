@@ -4,7 +4,7 @@ Pure declarations: importing this module loads no native code.
 """
 import ctypes as C
 
-TNT_ABI_VERSION = 5
+TNT_ABI_VERSION = 6
 TNT_MAX_OLIGO = 1024
 TNT_FLANK = 4
 TNT_ALIGN_TEXT = 448
@@ -123,7 +123,7 @@ class tnt_bind_req(C.Structure):
 class tnt_timing(C.Structure):
     _fields_ = [("seed_ms", C.c_float), ("bind_ms", C.c_float), ("pair_ms", C.c_float),
                 ("total_ms", C.c_float), ("n_seeds", C.c_uint64), ("n_binds", C.c_uint64),
-                ("n_bound", C.c_uint64), ("n_hits", C.c_uint64), ("n_filtered", C.c_uint64)]
+                ("n_bound", C.c_uint64), ("n_hits", C.c_uint64), ("n_filtered", C.c_uint64), ("n_cells", C.c_uint64)]
 
 
 class tnt_ingest_timing(C.Structure):

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <deque>
 #include <memory>
 #include <string>
 #include <thread>
@@ -31,6 +32,8 @@
 #include "tnt_seed2.hip.h"
 #include "tnt_bind.hip.h"
 #include "tnt_filter.hip.h"
+#define TNT_REGROUP_KERNELS
+#include "tnt_ufilter.hip.h"
 #include "tnt_pair.hip.h"
 #include "tnt_ingest.hip.h"
 #include <zlib.h>
@@ -546,6 +549,7 @@ struct tnt_ctx {
 	hipEvent_t phase_ready = nullptr;
 	size_t lane_trace = 0, lane_cols = 0, lane_ties = 0; // scratch elements per lane
 
+	std::string warnings; // what a caller should know about this context's options (tnt_ctx_warnings): the Q11 regime
 	std::vector<std::string> oligos;
 	std::vector<AssayDev> h_assays;
 	std::vector<Slot> h_slots;
@@ -585,6 +589,13 @@ struct tnt_ctx {
 	int pipeline_batches = 1;        // batches a large search is cut into on two buffer sets (TNT_MI355X_PIPELINE; 1: one batch after the other on one stream -- measured faster)
 	static constexpr uint32_t MAX_REGIONS = 8192;
 	DevBuf<uint32_t> slot_pack;      // [slot] bucket | bucket_general << 8 | oligo length << 16
+	// Round 5: the phase-A queue of a plain length bucket is regrouped by (oligo, threshold class) in front of its pre-filter
+	// (tnt_ufilter.hip.h): slot -> rank of its (oligo, class) inside its bucket, the buckets' shares of the histogram / cursor
+	// arrays and of the regrouped queue (every run is padded to whole blocks: 64 slots per bin on top of the bucket's region)
+	bool regroup = false;
+	DevBuf<uint32_t> slot_bin;
+	std::vector<uint32_t> h_slot_bin, rg_bins, rg_bin_base; // [slot]; [bucket] bins, first bin
+	uint32_t rg_total_bins = 0;
 	DevBuf<uint32_t> q_base, q_cap;  // [bucket] region of every phase-A queue inside `qa`
 	std::vector<uint32_t> h_q_base, h_q_cap;
 	bool q_planned_exceptions = false;
@@ -612,6 +623,8 @@ struct tnt_ctx {
 		DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
 		DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
 		DevBuf<uint4> qfat;       // phase-A queues of the round-3 seed kernel: self-contained entries (FilterArgs2::fat)
+		DevBuf<uint4> qsort;      // ... regrouped by (oligo, class): bucket i at q_base[i] + 64 * rg_bin_base[i] (UFilterArgs::fat)
+		DevBuf<uint32_t> rg_hist, rg_cursor; // [rg_total_bins] entries per bin of the batch, next free slot of its run
 		DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
 		DevBuf<uint32_t> item_rep;
 		DevBuf<BoundRec> pool;
@@ -709,13 +722,14 @@ struct tnt_ctx {
 namespace {
 
 enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_FILTERED /* windows rejected by the pre-filter (whole search) */, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS, C_PAIRABLE /* groups handed to the pair kernels */,
+       C_TOT_CELLS_LO = 18, C_TOT_CELLS_HI /* DP cells of the windows handed to the bind stage, sum of L x W (whole search, 64 bits) */,
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
        // per length bucket: entries of the current phase queue
        C_BUCKET = C_GROUPS + N_SHARD * SHARD_STRIDE, C_DEBUG = C_BUCKET + MAX_BUCKETS * BUCKET_STRIDE,
        C_BLOB = C_DEBUG + 16 /* compact hit blob of the search: bytes, hits (enqueue_compaction) */,
        C_LTEXT = C_BLOB + 2 /* bytes of the long-text arena handed out */, C_COUNT = C_LTEXT + 2 };
-static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0, "64-bit totals must be 8-byte aligned");
+static_assert(C_TOT_ITEMS_LO % 2 == 0 && C_TOT_GROUPS_LO % 2 == 0 && C_TOT_BINDS_LO % 2 == 0 && C_TOT_CELLS_LO % 2 == 0 && C_TOT_CELLS_HI < 32, "64-bit totals must be 8-byte aligned");
 
 // per-batch counters -> running totals of the whole search (the per-batch ones restart every batch)
 __global__ void accumulate_kernel(uint32_t *cnt, uint32_t *g) // cnt: the batch's counters, g: the search-wide ones
@@ -908,6 +922,48 @@ void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t strea
 	}
 }
 
+// the pre-filter on a queue regrouped by oligo (tnt_ufilter.hip.h): instances of up to 64 rows
+bool has_ufilter_instance(int rows)
+{
+	switch (rows) {
+#define X(N) case N: return N <= 64;
+		TNT_FILTER_LADDER(X)
+#undef X
+	default: return false;
+	}
+}
+
+void launch_ufilter(const UFilterArgs &a, int blocks, int rows, hipStream_t stream)
+{
+	switch (rows) {
+#define X(N) case N: tnt::launch_ufilter_##N(a, blocks, stream); break;
+		TNT_FILTER_LADDER(X)
+#undef X
+	default: break;
+	}
+}
+
+// Regroups one bucket's phase-A queue by (oligo, threshold class) -- count, scan, scatter -- and runs the pre-filter on the
+// regrouped queue.  `n_sorted` / `next_block`: two zeroed device words of the launch.
+void launch_regrouped_filter(tnt_ctx *c, const uint4 *src, const uint32_t *n_src_dev, uint32_t src_cap, const uint32_t *slot_bin, uint32_t n_bins,
+                             uint32_t *hist, uint32_t *cursor, uint4 *dst, uint32_t *n_sorted, uint32_t *next_block, UFilterArgs u, int rows, hipStream_t stream)
+{
+	RegroupArgs r;
+	memset(&r, 0, sizeof(r));
+	r.src = src, r.n_src_dev = n_src_dev, r.src_cap = src_cap;
+	r.slot_bin = slot_bin, r.n_bins = n_bins;
+	r.hist = hist, r.cursor = cursor;
+	r.dst = dst, r.n_dst_dev = n_sorted;
+	hipLaunchKernelGGL(regroup_count_kernel, dim3(c->n_cu * 4), dim3(RG_THREADS), 0, stream, r);
+	hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(1024), 0, stream, r);
+	hipLaunchKernelGGL(regroup_scatter_kernel, dim3(c->n_cu * 4), dim3(RG_THREADS), 0, stream, r);
+	u.fat = dst;
+	u.n_items_dev = n_sorted;
+	u.n_items = src_cap + uint32_t(UF_BLOCK) * n_bins;
+	u.next_block = next_block;
+	launch_ufilter(u, c->n_cu * 8, rows, stream);
+}
+
 template <bool LDS_TABLES> void launch_seed(const SeedArgs &s, int mode, int blocks, int threads, hipStream_t stream)
 {
 	if (mode == SEED_LIST) hipLaunchKernelGGL((seed_kernel<LDS_TABLES, SEED_LIST>), dim3(blocks), dim3(threads), 0, stream, s);
@@ -949,6 +1005,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		if (merge_mode == 3) k.merge_below *= 8;
 		k.err = gcnt + C_ERR;
 		k.item_rep = (c->dedupe && shard_counts) ? c->S().item_rep.p : nullptr; // phase A only: phase-B items are never duplicates
+		k.cells = reinterpret_cast<unsigned long long *>(gcnt + C_TOT_CELLS_LO);
 		hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 		hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	}
@@ -1002,7 +1059,20 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.n_rejected = gcnt + C_FILTERED;
 			f.audit = c->filter_audit ? c->S().audit.p : nullptr;
 			f.status_exact = c->filter_status_exact ? 1 : 0;
-			launch_filter(f, c->n_cu * 8, c->bucket_lmax[i] & 0xFF, c->lane_stream[split ? 0 : lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
+			const int rows = c->bucket_lmax[i] & 0xFF;
+			if (direct && c->regroup && (c->bucket_lmax[i] & BUCKET_PLAIN) && has_ufilter_instance(rows) && c->rg_bins[i] > 0 && c->rg_bins[i] <= uint32_t(RG_MAX_BINS) && c->S().qsort.p) {
+				// the windows of one oligo side by side: the table reads of a wavefront fall on different banks (tnt_ufilter.hip.h)
+				UFilterArgs u;
+				memset(&u, 0, sizeof(u));
+				u.tab = f.tab, u.packed = v.packed, u.olig_q4 = f.olig_q4, u.olig_len = f.olig_len, u.slots = f.slots;
+				u.survivors = f.survivors, u.n_survivors = f.n_survivors, u.n_rejected = f.n_rejected;
+				u.audit = f.audit, u.status_exact = f.status_exact;
+				launch_regrouped_filter(c, f.fat, f.n_items_dev, queue_cap, c->slot_bin.p, c->rg_bins[i], c->S().rg_hist.p + c->rg_bin_base[i], c->S().rg_cursor.p + c->rg_bin_base[i],
+				                        c->S().qsort.p + c->h_q_base[i] + size_t(UF_BLOCK) * c->rg_bin_base[i], cnt + C_BUCKET + i * BUCKET_STRIDE + 4, cnt + C_BUCKET + i * BUCKET_STRIDE + 5,
+				                        u, rows, c->lane_stream[split ? 0 : lane]);
+			} else {
+				launch_filter(f, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
+			}
 			if (split) { // the filter kernels, each of which fills the device, queue up on lane 0; the bind launches follow theirs on the other lanes
 				if (!c->filtered[i]) (void)hipEventCreateWithFlags(&c->filtered[i], hipEventDisableTiming);
 				(void)hipEventRecord(c->filtered[i], c->lane_stream[0]);
@@ -1074,6 +1144,11 @@ int alloc_set(tnt_ctx *c, int k)
 	HIP_TRY(W.qbucket.alloc(c->item_cap), c->err);
 	if (c->filter_on) HIP_TRY(W.qsurv.alloc(c->item_cap), c->err);
 	if (c->seed2) HIP_TRY(W.qfat.alloc(c->item_cap), c->err);
+	if (c->seed2 && c->regroup) {
+		HIP_TRY(W.qsort.alloc(c->item_cap + size_t(UF_BLOCK) * c->rg_total_bins), c->err);
+		HIP_TRY(W.rg_hist.alloc(std::max<size_t>(1, c->rg_total_bins)), c->err);
+		HIP_TRY(W.rg_cursor.alloc(std::max<size_t>(1, c->rg_total_bins)), c->err);
+	}
 	if (c->filter_audit) HIP_TRY(W.audit.alloc(c->item_cap), c->err);
 	if (c->dedupe) HIP_TRY(W.item_rep.alloc(c->item_cap), c->err);
 	HIP_TRY(W.pool.alloc(POOL_CAP), c->err);
@@ -1207,6 +1282,7 @@ void tnt_options_default(tnt_options *o) // options.h:85-170, tntblast.h:19-76
 }
 
 const char *tnt_last_error(const tnt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *tnt_ctx_warnings(const tnt_ctx *ctx) { return ctx ? ctx->warnings.c_str() : ""; }
 
 // The pre-filter of oligos of 65 to 128 bases costs a fifth of the bind it spares (5 ns against 22 ns per window), and whether it
 // spares any hangs on the thresholds: against -E 40 an unrelated 120-base window already reaches the bound (0.7 % rejected: the
@@ -1568,6 +1644,21 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 					c->cache_replay = true;
 				}
 	}
+	{ // Q11: thresholds under which the reference reports hits this library does not
+		bool primers = false, probes = false;
+		for (const Slot &sl : c->h_slots)
+			if (sl.oligo >= 0) (sl.thresh == 0 ? primers : probes) = true;
+		auto open_class = [](float min_tm, float max_tm, float min_dg, float max_dg) { return min_tm <= 0.0f && max_tm >= 0.0f && min_dg <= 0.0f && max_dg >= 0.0f; };
+		const bool qp = primers && open_class(opt->min_primer_tm, opt->max_primer_tm, opt->min_primer_dg, opt->max_primer_dg);
+		const bool qb = probes && open_class(opt->min_probe_tm, opt->max_probe_tm, opt->min_probe_dg, opt->max_probe_dg);
+		if (qp || qb)
+			c->warnings = std::string("the ") + (qp && qb ? "primer and probe" : (qp ? "primer" : "probe")) +
+			              " thresholds accept Tm = 0 and dG = 0 (no minimum Tm above 0 C, no maximum dG below 0): for a window without any valid "
+			              "alignment the reference scores the first / last match its NucCruc object kept from an earlier window (alignment::clear() "
+			              "does not reset them, nuc_cruc.h:360-371,386-387; bind_oligo.cpp:600-624) and can report it as a hit with Tm = 0 -- which "
+			              "hits depends on its thread schedule; this library reports such a window as not bound, so it may list fewer hits than "
+			              "tntblast does under these options";
+	}
 	// the round-3 seed kernel serves every search but those that mark shared oligos in the seed kernel
 	c->seed2 = !c->dedupe && !getenv("TNT_MI355X_SEED_V2");
 	if (const char *pe = getenv("TNT_MI355X_PIPELINE")) c->pipeline_batches = std::max(1, std::min(64, atoi(pe)));
@@ -1582,6 +1673,24 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	if (c->bucket_lmax.size() > size_t(MAX_BUCKETS)) FAIL(TNT_E_LIMIT, "too many oligo length classes");
 	hipError_t e = hipSuccess;
 	if ((e = c->slot_pack.upload(slot_pack)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
+	{ // bins of the regrouping: the distinct (oligo, threshold class) pairs of every length bucket, in order of appearance
+		c->h_slot_bin.assign(std::max<size_t>(1, c->h_slots.size()), 0u);
+		c->rg_bins.assign(c->bucket_lmax.size(), 0u);
+		std::map<std::tuple<int32_t, int32_t, int>, uint32_t> seen;
+		for (size_t si = 0; si < c->h_slots.size(); si++) {
+			const Slot &sl = c->h_slots[si];
+			if (sl.oligo < 0) continue;
+			const int32_t b = int32_t(slot_pack[si] & 0xFFu);
+			const auto it = seen.emplace(std::make_tuple(b, sl.oligo, sl.thresh == 0 ? 0 : 1), c->rg_bins[size_t(b)]);
+			if (it.second) c->rg_bins[size_t(b)]++;
+			c->h_slot_bin[si] = it.first->second;
+		}
+		c->rg_bin_base.assign(c->bucket_lmax.size(), 0u);
+		c->rg_total_bins = 0;
+		for (size_t b = 0; b < c->bucket_lmax.size(); b++) c->rg_bin_base[b] = c->rg_total_bins, c->rg_total_bins += c->rg_bins[b];
+		c->regroup = c->filter_on && !opt->use_dinkelbach && !getenv("TNT_MI355X_NO_REGROUP");
+		if ((e = c->slot_bin.upload(c->h_slot_bin)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
+	}
 	std::vector<Tables> tv(1, c->h_tab);
 	std::vector<FilterTables> fv(1, c->h_ftab);
 	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->ftab.upload(fv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
@@ -2434,6 +2543,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		HIP_TRY(hipMemsetAsync(c->S().region_counts.p, 0, sizeof(uint32_t) * 2 * regions, seed_stream), c->err);
 		HIP_TRY(hipMemsetAsync(c->S().q_state.p, 0, sizeof(uint32_t) * size_t(regions) * MAX_BUCKETS * 2, seed_stream), c->err);
 		HIP_TRY(hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, seed_stream), c->err);
+		if (c->regroup && c->rg_total_bins) HIP_TRY(hipMemsetAsync(c->S().rg_hist.p, 0, sizeof(uint32_t) * c->rg_total_bins, seed_stream), c->err);
 		Seed2Args q;
 		memset(&q, 0, sizeof(q));
 		q.db = v;
@@ -2457,6 +2567,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		q.n_buckets = int(c->bucket_lmax.size());
 		q.stat_items = cnt + C_ITEMS, q.stat_groups = cnt + C_GROUPS, q.stat_phase_a = cnt + C_QA;
 		q.big_count = cnt + C_BIG;
+		q.stat_cells = reinterpret_cast<unsigned long long *>(gcnt + C_TOT_CELLS_LO);
 		q.err = gcnt + C_ERR;
 		q.debug = gcnt + C_DEBUG + 8;
 		const size_t n_words2 = size_t(1) << (2 * c->opt.hash_word_size);
@@ -2991,6 +3102,7 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 	T.n_bound = cnt[C_TOT_BOUND];
 	T.n_hits = n_unique;
 	T.n_filtered = cnt[C_FILTERED];
+	T.n_cells = (uint64_t(cnt[C_TOT_CELLS_HI]) << 32) | cnt[C_TOT_CELLS_LO];
 	ctx->dev_hits_valid = true; // (the hits of long targets, paired on the host, were copied behind the device's own)
 	ctx->dev_hits_n = n_unique;
 	if (ctx->blob_cap_hits && n_unique <= ctx->blob_cap_hits && cnt[C_BLOB + 1] == n_unique) ctx->blob_hits = n_unique, ctx->blob_bytes = cnt[C_BLOB];
@@ -3186,8 +3298,11 @@ int tnt_gang_create(tnt_ctx *const *ctx, int n, tnt_gang **out)
 	std::string why;
 	if (!distinct) why = "two contexts share a device";
 	if (want_rccl && distinct) {
-		for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
-			if ((g->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+		std::vector<std::string> names = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+		if (const char *rp = getenv("ROCM_PATH")) names.push_back(std::string(rp) + "/lib/librccl.so.1"), names.push_back(std::string(rp) + "/lib/librccl.so");
+		if (const char *lp = getenv("TNT_MI355X_RCCL_LIB")) names.insert(names.begin(), lp);
+		for (const std::string &name : names)
+			if ((g->lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
 		if (!g->lib) why = "librccl not found";
 		if (g->lib) {
 			g->p_init = reinterpret_cast<decltype(g->p_init)>(dlsym(g->lib, "ncclCommInitAll"));
@@ -3741,10 +3856,52 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 	f.result = ctx->S().result.p;
 	f.score_out = dscore.p;
 	size_t at = 0;
+	// plain windows of oligos of up to 64 bases go the way a search sends them: regrouped by (oligo, class), then the pre-filter
+	// on the regrouped queue (tnt_ufilter.hip.h; TNT_MI355X_NO_REGROUP=1: filter_kernel on the queue as it is)
+	std::deque<DevBuf<uint4>> keep_fat;     // (a deque: growing it leaves the buffers where they are)
+	std::deque<DevBuf<uint32_t>> keep_words;
 	for (const auto &kv : by_rows) {
-		f.index = dindex.p + at;
-		f.n_items = uint32_t(kv.second.size());
-		launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), kv.first % 1000, ctx->stream, kv.first >= 1000);
+		const int rows = kv.first % 1000;
+		bool regrouped = false;
+		if (ctx->regroup && kv.first < 1000 && has_ufilter_instance(rows) && db->h_word_off[db->n_targets] < (uint64_t(1) << 32)) {
+			std::map<std::pair<int32_t, int32_t>, uint32_t> bins;
+			std::vector<uint32_t> slot_bin(n, 0u);
+			std::vector<uint4> fat(kv.second.size());
+			for (size_t x = 0; x < kv.second.size(); x++) {
+				const uint32_t i = kv.second[x];
+				const tnt_bind_req &r = req[i];
+				const size_t t = size_t(r.seq_index) - db->first_seq_index;
+				const int L = int(ctx->oligos[r.oligo].size());
+				const int start = std::max(0, r.target_loc - (r.query_loc + FLANK));
+				const uint32_t stop = std::min<uint32_t>(uint32_t(start + L + 2 * FLANK), db->h_len[t]);
+				slot_bin[i] = bins.emplace(std::make_pair(int32_t(r.oligo), int32_t(slots[i].thresh)), uint32_t(bins.size())).first->second;
+				fat[x] = make_uint4(i, uint32_t(db->h_word_off[t] + uint64_t(start >> 4)), uint32_t(start & 15) | ((stop - uint32_t(start)) << 4) | (uint32_t(L) << 12), items[i].info);
+			}
+			if (bins.size() <= size_t(RG_MAX_BINS)) {
+				const uint32_t n_bins = uint32_t(bins.size());
+				keep_fat.emplace_back(), keep_fat.emplace_back();
+				keep_words.emplace_back(), keep_words.emplace_back();
+				DevBuf<uint4> &dfat = keep_fat[keep_fat.size() - 2], &dsorted = keep_fat.back();
+				DevBuf<uint32_t> &dbin = keep_words[keep_words.size() - 2], &dwork = keep_words.back();
+				HIP_TRY(dfat.upload(fat), ctx->err);
+				HIP_TRY(dsorted.alloc(fat.size() + size_t(UF_BLOCK) * n_bins), ctx->err);
+				HIP_TRY(dbin.upload(slot_bin), ctx->err);
+				std::vector<uint32_t> work(3 + 2 * size_t(n_bins), 0u); // entries, regrouped entries, work counter; histogram; cursors
+				work[0] = uint32_t(fat.size());
+				HIP_TRY(dwork.upload(work), ctx->err);
+				UFilterArgs u;
+				memset(&u, 0, sizeof(u));
+				u.tab = f.tab, u.packed = f.db.packed, u.olig_q4 = f.olig_q4, u.olig_len = f.olig_len, u.slots = f.slots;
+				u.score_out = f.score_out;
+				launch_regrouped_filter(ctx, dfat.p, dwork.p, uint32_t(fat.size()), dbin.p, n_bins, dwork.p + 3, dwork.p + 3 + n_bins, dsorted.p, dwork.p + 1, dwork.p + 2, u, rows, ctx->stream);
+				regrouped = true;
+			}
+		}
+		if (!regrouped) {
+			f.index = dindex.p + at;
+			f.n_items = uint32_t(kv.second.size());
+			launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), rows, ctx->stream, kv.first >= 1000);
+		}
 		at += kv.second.size();
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);

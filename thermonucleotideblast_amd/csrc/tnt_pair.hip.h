@@ -486,6 +486,7 @@ struct BucketArgs {
 	                              // with padding rows beats one under-filled launch per bucket
 	uint32_t *err;
 	const uint32_t *item_rep;     // optional: items that take the result of another item are not queued (see SeedArgs)
+	unsigned long long *cells;    // optional statistics: DP cells (rows x window columns) of the queued items, added by the scatter pass
 };
 
 constexpr int BUCKET_PER_THREAD = 16; // (one global atomic per bucket and 4 096 items: a hot counter sustains only ~88 atomics per microsecond)
@@ -509,6 +510,7 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 	const uint32_t n = n_all < a.cap ? n_all : a.cap;
 	if (n_all > a.cap && blockIdx.x == 0 && tid == 0) atomicOr(a.err, ERR_ITEM_OVERFLOW);
 	constexpr uint32_t STEP = 256 * BUCKET_PER_THREAD;
+	unsigned long long my_cells = 0;
 	for (uint32_t base = blockIdx.x * STEP; base < n; base += gridDim.x * STEP) {
 		if (tid < MAX_BUCKETS) s_cnt[tid] = 0;
 		__syncthreads();
@@ -540,6 +542,15 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 				}
 				bkt[m] = n < a.merge_below ? uint32_t(a.n_buckets - 1) : uint32_t(degenerate ? sl.bucket_general : sl.bucket);
 				pos[m] = atomicAdd(&s_cnt[bkt[m]], 1u);
+				if (SCATTER && a.cells) { // rows x columns of the window, bind_oligo.cpp:502-505
+					const int L = a.olig_len[sl.oligo];
+					int start = int(it.tloc) - (int(it.info & 127u) + sl.qloc_bias + FLANK);
+					if (start < 0) start = 0;
+					int stop = start + L + 2 * FLANK;
+					const int tlen = int(a.db.len[it.target]);
+					if (stop > tlen) stop = tlen;
+					my_cells += (unsigned long long)(L) * (unsigned long long)(stop > start ? stop - start : 0);
+				}
 			}
 		}
 		__syncthreads();
@@ -551,6 +562,11 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 				if (bkt[m] != 0xFFFFFFFFu) a.dst[s_first[bkt[m]] + s_base[bkt[m]] + pos[m]] = idx[m];
 			__syncthreads();
 		}
+	}
+	if (SCATTER && a.cells) { // one atomic per wavefront
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) my_cells += (unsigned long long)__shfl_xor((long long)my_cells, o);
+		if ((tid & 63) == 0 && my_cells) atomicAdd(a.cells, my_cells);
 	}
 }
 

@@ -91,6 +91,7 @@ struct Seed2Args {
 	int last_chunk;              // the last launch of the batch marks the unused slots of the open blocks
 	int n_buckets;
 	uint32_t *stat_items, *stat_groups, *stat_phase_a; // statistics (one add per wavefront and launch)
+	unsigned long long *stat_cells; // ... DP cells (rows x window columns) of the phase-A windows
 	uint32_t *big_count;         // groups of more than 64 items
 	uint32_t *err;
 	uint32_t *debug;             // experimental builds only (TNT_EXP_STATS): cycles per phase
@@ -211,6 +212,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 	uint32_t item_cur = item_lo + a.region_counts[2 * region], group_cur = group_lo + a.region_counts[2 * region + 1];
 	const uint32_t item_first = item_cur, group_first = group_cur;
 	uint32_t n_phase_a = 0;
+	uint32_t cells_acc = 0; // rows x columns of this lane's phase-A windows (below 2^32 per lane and launch: a lane emits at most 2^20 windows of at most 128 x 136 cells)
 
 	// Software pipeline over the wavefront's units: the record of unit i + 2 (one scalar load) and the packed words of
 	// unit i + 1 (two dwords per lane) are in flight while unit i is processed.
@@ -673,6 +675,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 					uint32_t stop = uint32_t(start) + (sp >> 16) + 2u * FLANK;
 					if (stop > len) stop = len;
 					fat = u32x4{o, uint32_t(rec_words + uint32_t(start >> 4)), uint32_t(start & 15) | ((stop - uint32_t(start)) << 4) | ((sp >> 16) << 12), info};
+					cells_acc += (sp >> 16) * (stop - uint32_t(start));
 					if (exc1 > exc0) { // windows with a degenerate target base go to the general instance of their length
 						uint32_t lo = exc0, hi = exc1;
 						while (lo < hi) {
@@ -757,6 +760,12 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		if (item_cur != item_first) atomicAdd(a.stat_items + shard * SHARD_STRIDE, item_cur - item_first);
 		if (group_cur != group_first) atomicAdd(a.stat_groups + shard * SHARD_STRIDE, group_cur - group_first);
 		if (n_phase_a) atomicAdd(a.stat_phase_a + shard * SHARD_STRIDE, n_phase_a);
+	}
+	{
+		unsigned long long c = cells_acc;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) c += (unsigned long long)__shfl_xor((long long)c, o);
+		if (lane == 0 && c && a.stat_cells) atomicAdd(a.stat_cells, c);
 	}
 }
 

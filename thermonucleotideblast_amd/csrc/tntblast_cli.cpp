@@ -999,7 +999,11 @@ int main(int argc, char **argv)
 			}
 			ctx = ctxs[0];
 			if (tnt_gang_create(ctxs.data(), n, &gang) != TNT_OK) fail(tnt_gang_last_error(nullptr));
-			if (getenv("TNT_MI355X_VERBOSE_GANG")) std::cerr << "tntblast-mi355x: " << n << " device context(s), gather over " << tnt_gang_transport(gang) << std::endl;
+			// the transport: on request, and always when RCCL was wanted and the gather fell back to host copies
+			const std::string transport = tnt_gang_transport(gang);
+			if (getenv("TNT_MI355X_VERBOSE_GANG") || (n > 1 && transport.rfind("host (", 0) == 0))
+				std::cerr << "tntblast-mi355x: " << n << " device context(s), gather over " << transport << std::endl;
+			if (const char *w = tnt_ctx_warnings(ctx); w && *w) std::cerr << "tntblast-mi355x: warning: " << w << std::endl;
 		}
 		const size_t n_rank = ctxs.size();
 		if (opt.verbose) std::cout << "Reading sequence database: " << opt.dbase << std::endl;
