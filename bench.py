@@ -380,12 +380,12 @@ def main():
         device memory, page-locked receive buffer on rank 0; the same code runs on gloo in tests/test_distributed_cpu.py).
         The gather of one search travels while the next search runs; every search and every gather of the n steps is
         complete when this returns."""
-        acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_cells": 0, "n_hits": 0, "gather_bytes": 0, "gather_mode": None}
+        acc = {"seed": 0.0, "bind": 0.0, "pair": 0.0, "n_binds": 0, "n_cells": 0, "n_filtered": 0, "n_bound": 0, "n_hits": 0, "gather_bytes": 0, "gather_mode": None}
         if n <= 0:
             return acc
         todo = [db for _ in range(n) for db in dbs]
         eng.enqueue(todo[0])
-        step_hits = step_binds = step_cells = 0
+        step_hits = step_binds = step_cells = step_filtered = step_bound = 0
         for i, db in enumerate(todo):
             if world == 1 and not selftest:
                 # the hits reach the host in compact form (9 MB per search of config 2 instead of 47 MB of 1 464-byte records)
@@ -413,9 +413,12 @@ def main():
             step_hits += nh
             step_binds += tm.n_binds
             step_cells += tm.n_cells
+            step_filtered += tm.n_filtered
+            step_bound += tm.n_bound
             if (i + 1) % len(dbs) == 0:
                 acc["n_hits"], acc["n_binds"], acc["n_cells"] = step_hits, step_binds, step_cells  # of the last step
-                step_hits = step_binds = step_cells = 0
+                acc["n_filtered"], acc["n_bound"] = step_filtered, step_bound
+                step_hits = step_binds = step_cells = step_filtered = step_bound = 0
         return acc
 
     run(args.warmup)
@@ -515,6 +518,7 @@ def main():
                        "thresholds": "-e 40 -E 40, all other options default"},
             "targets_per_s": n_targets_all * args.steps / elapsed,
             "hits_per_step": n_hits,
+            "windows_per_step": {"handed_to_the_bind_stage": n_binds, "rejected_by_the_pre_filter": acc["n_filtered"], "bound": acc["n_bound"]},
             "gather_bytes_per_search": acc["gather_bytes"],
             "pack_and_h2d_s": pack_s,
             "stage_ms_per_step": {"seed": seed_ms_step, "bind": bind_ms_step, "pair": pair_ms / steps},

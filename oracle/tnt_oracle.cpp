@@ -1583,6 +1583,8 @@ const char *tntor_last_error(void) { return g_err.c_str(); }
 // The reference's per-target BindCache (a6) on (default) or off: off, every use of an oligo is evaluated on its own -- what the
 // library computes for contexts it accepts, where the two agree (same strand concentration and thresholds for every use).
 void tntor_set_bind_cache(int on) { g_bind_cache = on != 0; }
+static int g_filter_tier = 1; // tntor_set_filter_tier: which bound tntor_filter_bound restates (1: the pre-filter's automaton, 2: the second tier's)
+void tntor_set_filter_tier(int tier) { g_filter_tier = tier == 2 ? 2 : 1; }
 
 int tntor_tables(const tnt_options *opt, int32_t *delta_g, float *param_H, float *param_S, float *loop_S, float *bulge_S,
                  float *hairpin_S, float *scalars)
@@ -1792,6 +1794,7 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		bool on;
 		float tk, theta0, ct_scale;
 		std::vector<int> fpos, close; // [prev pair * 49 + cur pair] in evaluate order
+		std::vector<int> fcur, fprev; // second tier: the stack as it is (no clamp at zero) where the CURRENT / the PREVIOUS column is Watson-Crick, else "not possible"
 	} cls[2];
 	const double min_tm[2] = {double(opt->min_primer_tm), double(opt->min_probe_tm)};
 	const double max_dg[2] = {double(opt->max_primer_dg), double(opt->max_probe_dg)};
@@ -1807,6 +1810,8 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		C.on = ok && (by_tm || by_dg);
 		C.fpos.assign(NBP * NBP, 0);
 		C.close.assign(NBP * NBP, NEG);
+		C.fcur.assign(NBP * NBP, NEG);
+		C.fprev.assign(NBP * NBP, NEG);
 		if (!C.on) continue;
 		const double sc = double(P.salt) * log_na;
 		auto phi = [&](int prev, int cur) { return -(double(P.H[prev * NBP + cur]) - Tk * (double(P.S[prev * NBP + cur]) + sc)); };
@@ -1823,6 +1828,8 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 				if (prev / NB > I || prev % NB > I || cur / NB > I || cur % NB > I) continue;
 				const double f = phi(prev, cur);
 				C.fpos[prev * NBP + cur] = units((P.wc[prev] || P.wc[cur]) ? std::max(f, 0.0) : 0.0);
+				if (P.wc[cur]) C.fcur[prev * NBP + cur] = units(f);
+				if (P.wc[prev]) C.fprev[prev * NBP + cur] = units(f);
 				if (!P.wc[cur]) continue; // a loop / bulge closes on a Watson-Crick column
 				double u1 = -1.0e30;
 				for (int pm = 0; pm < NBP; pm++)
@@ -1902,6 +1909,34 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 				for (int y = (tc == ANY ? int(A) : tc); y <= (tc == ANY ? int(I) : tc); y++) m = std::max(m, tab[(qp * NB + x) * NBP + qc * NB + y]);
 			return m;
 		};
+		if (g_filter_tier == 2) {
+			// Second tier: the same decomposition of an alignment at its Watson-Crick columns, but a terminal
+			// stack is charged as it is -- the first tier drops every unfavourable stack on a diagonal, which makes mismatches
+			// free.  Two states per cell on its diagonal: H = the cell is a counted (Watson-Crick) column, S = the cell lies inside
+			// a region of mismatch / gap columns that stays on (or returns to) this diagonal: entered from H with the stack
+			// [H cell -> next cell] (the terminal stack at the region's first column), crossed for nothing (stacks inside a loop
+			// are not credited; a region that returns to its diagonal may cost nothing at all: loop_S[2] = 0, symmetric gaps),
+			// left into H with the stack [previous cell -> H cell].  LP as in the first tier, entered from H or S.
+			std::vector<int> H(size_t(L + 1) * (W + 1), 0), S(size_t(L + 1) * (W + 1), 0);
+			std::fill(LP.begin(), LP.end(), NEG);
+			auto sat = [&](int v) { return std::max(NEG, std::min(SAT, v)); };
+			for (int a = 1; a <= L; a++)
+				for (int b = 1; b <= W; b++) {
+					int h = 0, sv = 0, lp = NEG;
+					if (a > 1 && b > 1) {
+						const int y = std::max(H[at(a - 1, b - 1)], S[at(a - 1, b - 1)]);
+						h = std::max(h, sat(y + entry(C.fcur, qb[a - 2], tg[b - 2], qb[a - 1], tg[b - 1])));
+						h = std::max(h, sat(LP[at(a - 1, b - 1)] + entry(C.close, qb[a - 2], tg[b - 2], qb[a - 1], tg[b - 1])));
+						sv = std::max(S[at(a - 1, b - 1)], sat(H[at(a - 1, b - 1)] + entry(C.fprev, qb[a - 2], tg[b - 2], qb[a - 1], tg[b - 1])));
+						sv = std::max(sv, 0);
+						lp = LP[at(a - 1, b - 1)];
+					}
+					lp = std::max(lp, std::max(LP[at(a - 1, b)], LP[at(a, b - 1)]));
+					lp = std::max(lp, std::max(std::max(H[at(a - 1, b)], S[at(a - 1, b)]), std::max(H[at(a, b - 1)], S[at(a, b - 1)])));
+					H[at(a, b)] = h, S[at(a, b)] = sv, LP[at(a, b)] = lp;
+					best = std::max(best, h);
+				}
+		} else
 		for (int a = 1; a <= L; a++)
 			for (int b = 1; b <= W; b++) {
 				int x = 0, lp = NEG;

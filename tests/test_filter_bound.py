@@ -82,7 +82,7 @@ def make_windows(rng, n, lo=12, hi=40, degen=0.3, inosine=0.04):
     return oligos, targets, rows
 
 
-def check_option_set(oracle, name, kw, n, seed, **window_kw):
+def check_option_set(oracle, name, kw, n, seed, tier=1, **window_kw):
     rng = np.random.default_rng([2024, seed])
     opt = abi.options_default(**kw)
     oligos, targets, rows = make_windows(rng, n, **window_kw)
@@ -91,7 +91,7 @@ def check_option_set(oracle, name, kw, n, seed, **window_kw):
     offsets = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
     reqs = tc.make_reqs(rows)
     out = oracle.bind_batch(opt, oligos, codes, offsets, reqs)
-    fb = oracle.filter_bound(opt, oligos, codes, offsets, reqs)
+    fb = oracle.filter_bound(opt, oligos, codes, offsets, reqs, tier=tier)
     role = np.array([r[5] for r in rows])
     min_tm = np.where(role == 1, opt.min_probe_tm, opt.min_primer_tm).astype(np.float64)
     max_dg = np.where(role == 1, opt.max_probe_dg, opt.max_primer_dg).astype(np.float64)
@@ -132,6 +132,22 @@ def test_filter_never_rejects_an_accepted_window(oracle, k):
     name, kw = OPTION_SETS[k]
     res = check_option_set(oracle, name, kw, n, k)
     assert res["rejected_by_filter"] > 0  # the filter does something
+
+
+@pytest.mark.parametrize("k", [0, 3, 5])
+def test_second_tier_candidate_is_sound_and_gains_little(oracle, k):
+    """Round 5 tried a second tier on the pre-filter's survivors: the same decomposition of an alignment at its Watson-Crick columns,
+    but a terminal stack charged AS IT IS instead of dropped when unfavourable (two states per diagonal cell: counted column /
+    inside a region; restated in tntor_filter_bound under tntor_set_filter_tier(2)).  It is sound by the first tier's argument and
+    never above the first tier's bound -- and rejects almost nothing more: an unfavourable terminal stack is dodged by counting
+    the helix one pair short, which is what evaluate_alignment itself would do for an alignment that leaves the pair unpaired
+    (a symmetric loop with one mismatch costs nothing, loop_S[2] = 0).  Not built as a kernel; the measurement is kept."""
+    n = int(os.environ.get("TNT_FILTER_PROPERTY_N", "40000")) // 2
+    name, kw = OPTION_SETS[k]
+    one = check_option_set(oracle, name, kw, n, 300 + k, tier=1)
+    two = check_option_set(oracle, name + " (second tier)", kw, n, 300 + k, tier=2)  # asserts "accepted => not rejected" and the stronger bound
+    assert two["rejected_by_filter"] >= one["rejected_by_filter"]
+    assert two["reject_rate_of_non_accepted"] - one["reject_rate_of_non_accepted"] < 0.05
 
 
 @pytest.mark.parametrize("k", [0, 5, 9])

@@ -194,8 +194,15 @@ class _CpuImpl:
         assert rc == 0, self.error()
         return out
 
-    def filter_bound(self, opt, oligos, codes, offsets, reqs, first=0):
-        """Checker of the bind pre-filter (oracle only): (n, 2) int32 array of [bound, threshold] per request."""
+    def filter_bound(self, opt, oligos, codes, offsets, reqs, first=0, tier=1):
+        """Checker of the bind pre-filter (oracle only): (n, 2) int32 array of [bound, threshold] per request.
+        tier=2: the second tier's bound (terminal stacks charged as they are) against the same threshold."""
+        if tier != 1:
+            self.lib.tntor_set_filter_tier(int(tier))
+            try:
+                return self.filter_bound(opt, oligos, codes, offsets, reqs, first)
+            finally:
+                self.lib.tntor_set_filter_tier(1)
         codes, pc = as_u8(codes)
         offsets, po = as_u64(offsets)
         out = np.zeros((len(reqs), 2), dtype=np.int32)

@@ -1,14 +1,14 @@
 // tnt_bind_inst.hip -- the throughput instances of the bind kernel, one per oligo-length bucket.
 //
 // The build compiles this file several times with -DTNT_INST_LIST="G(36) P(36) E(22) ..." (a share of the
-// instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows, F / D = pre-filter for plain / any windows, U = pre-filter on queues regrouped by oligo) so they build
+// instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows, F / D = pre-filter for plain / any windows, U / V = pre-filter on queues regrouped by oligo, plain / any windows) so they build
 // in parallel; compiled once without the macro it provides all of them.
 #include "tnt_bind.hip.h"
 #include "tnt_filter.hip.h"
 #include "tnt_ufilter.hip.h"
 
 #ifndef TNT_INST_LIST
-#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_LONG_LADDER(G) TNT_LONG_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F) TNT_LMAX_LADDER(D) TNT_LONG_LADDER(F) TNT_LONG_LADDER(D) TNT_FILTER_LADDER(U)
+#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_LONG_LADDER(G) TNT_LONG_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F) TNT_LMAX_LADDER(D) TNT_LONG_LADDER(F) TNT_LONG_LADDER(D) TNT_FILTER_LADDER(U) TNT_LMAX_LADDER(V)
 #endif
 
 namespace tnt {
@@ -31,7 +31,12 @@ namespace tnt {
 #define U(N)                                                                                                         \
 	void launch_ufilter_##N(const UFilterArgs &a, int blocks, hipStream_t stream)                                    \
 	{                                                                                                                \
-		hipLaunchKernelGGL((ufilter_kernel<N>), dim3(blocks), dim3(256), 0, stream, a);                               \
+		hipLaunchKernelGGL((ufilter_kernel<N, false>), dim3(blocks), dim3(256), 0, stream, a);                        \
+	}
+#define V(N)                                                                                                         \
+	void launch_ufilter_degen_##N(const UFilterArgs &a, int blocks, hipStream_t stream)                              \
+	{                                                                                                                \
+		hipLaunchKernelGGL((ufilter_kernel<N, true>), dim3(blocks), dim3(256), 0, stream, a);                         \
 	}
 #define G(N) TNT_LAUNCHER(launch_bind_##N, N, false, false)
 #define P(N) TNT_LAUNCHER(launch_bind_plain_##N, N, false, true)
@@ -43,5 +48,6 @@ TNT_INST_LIST
 #undef F
 #undef D
 #undef U
+#undef V
 
 } // namespace tnt

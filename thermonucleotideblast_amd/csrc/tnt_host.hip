@@ -593,9 +593,14 @@ struct tnt_ctx {
 	// (tnt_ufilter.hip.h): slot -> rank of its (oligo, class) inside its bucket, the buckets' shares of the histogram / cursor
 	// arrays and of the regrouped queue (every run is padded to whole blocks: 64 slots per bin on top of the bucket's region)
 	bool regroup = false;
-	DevBuf<uint32_t> slot_bin;
-	std::vector<uint32_t> h_slot_bin, rg_bins, rg_bin_base; // [slot]; [bucket] bins, first bin
+	DevBuf<uint32_t> slot_bin;       // [slot][2]: inside its plain bucket, inside its general bucket
+	std::vector<uint32_t> h_slot_bin, rg_bins, rg_bin_base; // [slot][2]; [bucket] bins, first bin
 	uint32_t rg_total_bins = 0;
+	std::vector<RegroupBucket> h_rg_desc; // the buckets of a batch that are regrouped (planned with the queue regions)
+	std::vector<int> rg_desc_of;          // [bucket] -> its descriptor, or -1
+	DevBuf<RegroupBucket> rg_desc;
+	DevBuf<uint32_t> rg_bin_base_dev; // [bucket] first group of the bucket (the seed kernel counts the entries per group where the groups fit its LDS histogram)
+	bool rg_seed_counts = false;      // ... so the regrouping runs without its counting pass
 	DevBuf<uint32_t> q_base, q_cap;  // [bucket] region of every phase-A queue inside `qa`
 	std::vector<uint32_t> h_q_base, h_q_cap;
 	bool q_planned_exceptions = false;
@@ -923,8 +928,16 @@ void launch_filter(const FilterArgs2 &a, int blocks, int rows, hipStream_t strea
 }
 
 // the pre-filter on a queue regrouped by oligo (tnt_ufilter.hip.h): instances of up to 64 rows
-bool has_ufilter_instance(int rows)
+bool has_ufilter_instance(int rows, bool degen)
 {
+	if (degen) {
+		switch (rows) {
+#define X(N) case N: return true;
+			TNT_LMAX_LADDER(X)
+#undef X
+		default: return false;
+		}
+	}
 	switch (rows) {
 #define X(N) case N: return N <= 64;
 		TNT_FILTER_LADDER(X)
@@ -933,8 +946,17 @@ bool has_ufilter_instance(int rows)
 	}
 }
 
-void launch_ufilter(const UFilterArgs &a, int blocks, int rows, hipStream_t stream)
+void launch_ufilter(const UFilterArgs &a, int blocks, int rows, hipStream_t stream, bool degen)
 {
+	if (degen) {
+		switch (rows) {
+#define X(N) case N: tnt::launch_ufilter_degen_##N(a, blocks, stream); break;
+			TNT_LMAX_LADDER(X)
+#undef X
+		default: break;
+		}
+		return;
+	}
 	switch (rows) {
 #define X(N) case N: tnt::launch_ufilter_##N(a, blocks, stream); break;
 		TNT_FILTER_LADDER(X)
@@ -943,25 +965,19 @@ void launch_ufilter(const UFilterArgs &a, int blocks, int rows, hipStream_t stre
 	}
 }
 
-// Regroups one bucket's phase-A queue by (oligo, threshold class) -- count, scan, scatter -- and runs the pre-filter on the
-// regrouped queue.  `n_sorted` / `next_block`: two zeroed device words of the launch.
-void launch_regrouped_filter(tnt_ctx *c, const uint4 *src, const uint32_t *n_src_dev, uint32_t src_cap, const uint32_t *slot_bin, uint32_t n_bins,
-                             uint32_t *hist, uint32_t *cursor, uint4 *dst, uint32_t *n_sorted, uint32_t *next_block, UFilterArgs u, int rows, hipStream_t stream)
+// The regrouping of a batch's phase-A queues by (oligo, threshold class): count, scan, scatter, each ONE launch over all the
+// buckets of `desc` (device array of n_desc descriptors).
+void launch_regroup(tnt_ctx *c, const RegroupBucket *desc, uint32_t n_desc, const uint4 *src, uint4 *dst, uint32_t *counters, const uint32_t *slot_bin,
+                    uint32_t *hist, uint32_t *cursor, hipStream_t stream, bool counted = false /* the histogram is filled already (by the seed kernel) */)
 {
 	RegroupArgs r;
 	memset(&r, 0, sizeof(r));
-	r.src = src, r.n_src_dev = n_src_dev, r.src_cap = src_cap;
-	r.slot_bin = slot_bin, r.n_bins = n_bins;
-	r.hist = hist, r.cursor = cursor;
-	r.dst = dst, r.n_dst_dev = n_sorted;
-	hipLaunchKernelGGL(regroup_count_kernel, dim3(c->n_cu * 4), dim3(RG_THREADS), 0, stream, r);
-	hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(1024), 0, stream, r);
-	hipLaunchKernelGGL(regroup_scatter_kernel, dim3(c->n_cu * 4), dim3(RG_THREADS), 0, stream, r);
-	u.fat = dst;
-	u.n_items_dev = n_sorted;
-	u.n_items = src_cap + uint32_t(UF_BLOCK) * n_bins;
-	u.next_block = next_block;
-	launch_ufilter(u, c->n_cu * 8, rows, stream);
+	r.buckets = desc, r.n_buckets = n_desc;
+	r.src = src, r.dst = dst, r.counters = counters;
+	r.slot_bin = slot_bin, r.hist = hist, r.cursor = cursor;
+	if (!counted) hipLaunchKernelGGL(regroup_count_kernel, dim3(c->n_cu * 8), dim3(RG_THREADS), 0, stream, r);
+	hipLaunchKernelGGL(regroup_scan_kernel, dim3(n_desc), dim3(1024), 0, stream, r);
+	hipLaunchKernelGGL(regroup_scatter_kernel, dim3(c->n_cu * 8), dim3(RG_THREADS), 0, stream, r);
 }
 
 template <bool LDS_TABLES> void launch_seed(const SeedArgs &s, int mode, int blocks, int threads, hipStream_t stream)
@@ -1009,6 +1025,9 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 		hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	}
+	const bool regrouped = direct && c->regroup && c->filter_on && !c->h_rg_desc.empty() && c->S().qsort.p;
+	if (regrouped) // the phase-A queues of the batch, windows of one oligo side by side (tnt_ufilter.hip.h)
+		launch_regroup(c, c->rg_desc.p, uint32_t(c->h_rg_desc.size()), c->S().qfat.p, c->S().qsort.p, cnt + C_BUCKET, c->slot_bin.p, c->S().rg_hist.p, c->S().rg_cursor.p, c->stream, c->rg_seed_counts);
 	(void)hipEventRecord(c->phase_ready, c->stream);
 	for (int l = 0; l < c->lanes; l++) (void)hipStreamWaitEvent(c->lane_stream[l], c->phase_ready, 0);
 	int n_launch = 0;
@@ -1060,18 +1079,22 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.audit = c->filter_audit ? c->S().audit.p : nullptr;
 			f.status_exact = c->filter_status_exact ? 1 : 0;
 			const int rows = c->bucket_lmax[i] & 0xFF;
-			if (direct && c->regroup && (c->bucket_lmax[i] & BUCKET_PLAIN) && has_ufilter_instance(rows) && c->rg_bins[i] > 0 && c->rg_bins[i] <= uint32_t(RG_MAX_BINS) && c->S().qsort.p) {
-				// the windows of one oligo side by side: the table reads of a wavefront fall on different banks (tnt_ufilter.hip.h)
+			const bool degen = !(c->bucket_lmax[i] & BUCKET_PLAIN);
+			if (regrouped && c->rg_desc_of[i] >= 0) {
+				const RegroupBucket &B = c->h_rg_desc[size_t(c->rg_desc_of[i])];
 				UFilterArgs u;
 				memset(&u, 0, sizeof(u));
 				u.tab = f.tab, u.packed = v.packed, u.olig_q4 = f.olig_q4, u.olig_len = f.olig_len, u.slots = f.slots;
+				u.db = v, u.items = f.items;
+				u.fat = c->S().qsort.p + B.dst_base;
+				u.n_items_dev = cnt + C_BUCKET + B.counter + 4;
+				u.n_items = B.src_cap + uint32_t(UF_BLOCK) * B.n_bins;
+				u.next_block = cnt + C_BUCKET + B.counter + 5;
 				u.survivors = f.survivors, u.n_survivors = f.n_survivors, u.n_rejected = f.n_rejected;
 				u.audit = f.audit, u.status_exact = f.status_exact;
-				launch_regrouped_filter(c, f.fat, f.n_items_dev, queue_cap, c->slot_bin.p, c->rg_bins[i], c->S().rg_hist.p + c->rg_bin_base[i], c->S().rg_cursor.p + c->rg_bin_base[i],
-				                        c->S().qsort.p + c->h_q_base[i] + size_t(UF_BLOCK) * c->rg_bin_base[i], cnt + C_BUCKET + i * BUCKET_STRIDE + 4, cnt + C_BUCKET + i * BUCKET_STRIDE + 5,
-				                        u, rows, c->lane_stream[split ? 0 : lane]);
+				launch_ufilter(u, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], degen);
 			} else {
-				launch_filter(f, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], !(c->bucket_lmax[i] & BUCKET_PLAIN));
+				launch_filter(f, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], degen);
 			}
 			if (split) { // the filter kernels, each of which fills the device, queue up on lane 0; the bind launches follow theirs on the other lanes
 				if (!c->filtered[i]) (void)hipEventCreateWithFlags(&c->filtered[i], hipEventDisableTiming);
@@ -1674,22 +1697,25 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	hipError_t e = hipSuccess;
 	if ((e = c->slot_pack.upload(slot_pack)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
 	{ // bins of the regrouping: the distinct (oligo, threshold class) pairs of every length bucket, in order of appearance
-		c->h_slot_bin.assign(std::max<size_t>(1, c->h_slots.size()), 0u);
+		c->h_slot_bin.assign(2 * std::max<size_t>(1, c->h_slots.size()), 0u);
 		c->rg_bins.assign(c->bucket_lmax.size(), 0u);
 		std::map<std::tuple<int32_t, int32_t, int>, uint32_t> seen;
 		for (size_t si = 0; si < c->h_slots.size(); si++) {
 			const Slot &sl = c->h_slots[si];
 			if (sl.oligo < 0) continue;
-			const int32_t b = int32_t(slot_pack[si] & 0xFFu);
-			const auto it = seen.emplace(std::make_tuple(b, sl.oligo, sl.thresh == 0 ? 0 : 1), c->rg_bins[size_t(b)]);
-			if (it.second) c->rg_bins[size_t(b)]++;
-			c->h_slot_bin[si] = it.first->second;
+			for (int g = 0; g < 2; g++) { // the slot's plain bucket, its general bucket (one bucket is never both)
+				const int32_t b = int32_t((slot_pack[si] >> (8 * g)) & 0xFFu);
+				const auto it = seen.emplace(std::make_tuple(b, sl.oligo, sl.thresh == 0 ? 0 : 1), c->rg_bins[size_t(b)]);
+				if (it.second) c->rg_bins[size_t(b)]++;
+				c->h_slot_bin[2 * si + size_t(g)] = it.first->second;
+			}
 		}
 		c->rg_bin_base.assign(c->bucket_lmax.size(), 0u);
 		c->rg_total_bins = 0;
 		for (size_t b = 0; b < c->bucket_lmax.size(); b++) c->rg_bin_base[b] = c->rg_total_bins, c->rg_total_bins += c->rg_bins[b];
 		c->regroup = c->filter_on && !opt->use_dinkelbach && !getenv("TNT_MI355X_NO_REGROUP");
-		if ((e = c->slot_bin.upload(c->h_slot_bin)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
+		if ((e = c->slot_bin.upload(c->h_slot_bin)) != hipSuccess || (e = c->rg_bin_base_dev.upload(c->rg_bin_base)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
+		c->rg_seed_counts = c->regroup && c->rg_total_bins > 0 && c->rg_total_bins <= uint32_t(S2_BINS) && !getenv("TNT_MI355X_REGROUP_COUNT_PASS");
 	}
 	std::vector<Tables> tv(1, c->h_tab);
 	std::vector<FilterTables> fv(1, c->h_ftab);
@@ -2568,6 +2594,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		q.stat_items = cnt + C_ITEMS, q.stat_groups = cnt + C_GROUPS, q.stat_phase_a = cnt + C_QA;
 		q.big_count = cnt + C_BIG;
 		q.stat_cells = reinterpret_cast<unsigned long long *>(gcnt + C_TOT_CELLS_LO);
+		if (c->rg_seed_counts && c->S().rg_hist.p) // the entries per (oligo, class) group, counted as they are written
+			q.slot_bin = c->slot_bin.p, q.bin_base = c->rg_bin_base_dev.p, q.bin_hist = c->S().rg_hist.p, q.n_bins = c->rg_total_bins;
 		q.err = gcnt + C_ERR;
 		q.debug = gcnt + C_DEBUG + 8;
 		const size_t n_words2 = size_t(1) << (2 * c->opt.hash_word_size);
@@ -2857,6 +2885,26 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 		HIP_TRY(c->q_base.upload(c->h_q_base), c->err);
 		HIP_TRY(c->q_cap.upload(c->h_q_cap), c->err);
 		c->q_planned_exceptions = exc;
+		// the buckets whose queue is regrouped by oligo in front of the pre-filter: those the filter serves (launch_bind_phase),
+		// with an instance of ufilter_kernel and a histogram that fits LDS
+		c->h_rg_desc.clear();
+		c->rg_desc_of.assign(nb, -1);
+		for (size_t b = 0; b < nb && c->regroup; b++) {
+			const int id = c->bucket_lmax[b], rows = id & 0xFF;
+			const bool plain = (id & BUCKET_PLAIN) != 0;
+			if (c->h_q_cap[b] == 0 || (id & BUCKET_WAVE) || rows > 64 || !(plain || c->filter_general) || !has_filter_instance(rows, !plain) || !has_ufilter_instance(rows, !plain)) continue;
+			if (c->rg_bins[b] == 0 || c->rg_bins[b] > uint32_t(RG_MAX_BINS)) continue;
+			RegroupBucket B;
+			memset(&B, 0, sizeof(B));
+			B.src_base = c->h_q_base[b], B.src_cap = c->h_q_cap[b];
+			B.dst_base = c->h_q_base[b] + uint32_t(UF_BLOCK) * c->rg_bin_base[b];
+			B.bin_base = c->rg_bin_base[b], B.n_bins = c->rg_bins[b];
+			B.general = plain ? 0u : 1u;
+			B.counter = uint32_t(b) * BUCKET_STRIDE;
+			c->rg_desc_of[b] = int(c->h_rg_desc.size());
+			c->h_rg_desc.push_back(B);
+		}
+		if (!c->h_rg_desc.empty()) HIP_TRY(c->rg_desc.upload(c->h_rg_desc), c->err);
 	}
 	return TNT_OK;
 }
@@ -3860,12 +3908,14 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 	// on the regrouped queue (tnt_ufilter.hip.h; TNT_MI355X_NO_REGROUP=1: filter_kernel on the queue as it is)
 	std::deque<DevBuf<uint4>> keep_fat;     // (a deque: growing it leaves the buffers where they are)
 	std::deque<DevBuf<uint32_t>> keep_words;
+	std::deque<DevBuf<RegroupBucket>> keep_desc;
 	for (const auto &kv : by_rows) {
 		const int rows = kv.first % 1000;
+		const bool degen = kv.first >= 1000;
 		bool regrouped = false;
-		if (ctx->regroup && kv.first < 1000 && has_ufilter_instance(rows) && db->h_word_off[db->n_targets] < (uint64_t(1) << 32)) {
+		if (ctx->regroup && has_ufilter_instance(rows, degen) && db->h_word_off[db->n_targets] < (uint64_t(1) << 32)) {
 			std::map<std::pair<int32_t, int32_t>, uint32_t> bins;
-			std::vector<uint32_t> slot_bin(n, 0u);
+			std::vector<uint32_t> slot_bin(2 * n, 0u);
 			std::vector<uint4> fat(kv.second.size());
 			for (size_t x = 0; x < kv.second.size(); x++) {
 				const uint32_t i = kv.second[x];
@@ -3874,33 +3924,41 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 				const int L = int(ctx->oligos[r.oligo].size());
 				const int start = std::max(0, r.target_loc - (r.query_loc + FLANK));
 				const uint32_t stop = std::min<uint32_t>(uint32_t(start + L + 2 * FLANK), db->h_len[t]);
-				slot_bin[i] = bins.emplace(std::make_pair(int32_t(r.oligo), int32_t(slots[i].thresh)), uint32_t(bins.size())).first->second;
+				slot_bin[2 * i] = slot_bin[2 * i + 1] = bins.emplace(std::make_pair(int32_t(r.oligo), int32_t(slots[i].thresh)), uint32_t(bins.size())).first->second;
 				fat[x] = make_uint4(i, uint32_t(db->h_word_off[t] + uint64_t(start >> 4)), uint32_t(start & 15) | ((stop - uint32_t(start)) << 4) | (uint32_t(L) << 12), items[i].info);
 			}
 			if (bins.size() <= size_t(RG_MAX_BINS)) {
 				const uint32_t n_bins = uint32_t(bins.size());
 				keep_fat.emplace_back(), keep_fat.emplace_back();
 				keep_words.emplace_back(), keep_words.emplace_back();
+				keep_desc.emplace_back();
 				DevBuf<uint4> &dfat = keep_fat[keep_fat.size() - 2], &dsorted = keep_fat.back();
 				DevBuf<uint32_t> &dbin = keep_words[keep_words.size() - 2], &dwork = keep_words.back();
 				HIP_TRY(dfat.upload(fat), ctx->err);
 				HIP_TRY(dsorted.alloc(fat.size() + size_t(UF_BLOCK) * n_bins), ctx->err);
 				HIP_TRY(dbin.upload(slot_bin), ctx->err);
-				std::vector<uint32_t> work(3 + 2 * size_t(n_bins), 0u); // entries, regrouped entries, work counter; histogram; cursors
+				std::vector<uint32_t> work(8 + 2 * size_t(n_bins), 0u); // a counter line ([0] entries, [4] regrouped entries, [5] work counter); histogram; cursors
 				work[0] = uint32_t(fat.size());
 				HIP_TRY(dwork.upload(work), ctx->err);
+				RegroupBucket B;
+				memset(&B, 0, sizeof(B));
+				B.src_cap = uint32_t(fat.size()), B.n_bins = n_bins, B.general = degen ? 1u : 0u;
+				HIP_TRY(keep_desc.back().upload(std::vector<RegroupBucket>(1, B)), ctx->err);
+				launch_regroup(ctx, keep_desc.back().p, 1, dfat.p, dsorted.p, dwork.p, dbin.p, dwork.p + 8, dwork.p + 8 + n_bins, ctx->stream);
 				UFilterArgs u;
 				memset(&u, 0, sizeof(u));
 				u.tab = f.tab, u.packed = f.db.packed, u.olig_q4 = f.olig_q4, u.olig_len = f.olig_len, u.slots = f.slots;
+				u.db = f.db, u.items = f.items;
 				u.score_out = f.score_out;
-				launch_regrouped_filter(ctx, dfat.p, dwork.p, uint32_t(fat.size()), dbin.p, n_bins, dwork.p + 3, dwork.p + 3 + n_bins, dsorted.p, dwork.p + 1, dwork.p + 2, u, rows, ctx->stream);
+				u.fat = dsorted.p, u.n_items_dev = dwork.p + 4, u.n_items = uint32_t(fat.size()) + uint32_t(UF_BLOCK) * n_bins, u.next_block = dwork.p + 5;
+				launch_ufilter(u, ctx->n_cu * 8, rows, ctx->stream, degen);
 				regrouped = true;
 			}
 		}
 		if (!regrouped) {
 			f.index = dindex.p + at;
 			f.n_items = uint32_t(kv.second.size());
-			launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), rows, ctx->stream, kv.first >= 1000);
+			launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), rows, ctx->stream, degen);
 		}
 		at += kv.second.size();
 	}

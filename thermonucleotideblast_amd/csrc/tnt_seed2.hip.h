@@ -59,6 +59,7 @@ constexpr int S2_SWEEP = TNT_S2_SWEEP; // positions per lane and sweep (16 or 8)
 constexpr int S2_TGT_WORDS = 128;       // packed words of a target parked in LDS (2 048 bases); longer targets are read from HBM
 constexpr uint32_t QUEUE_BLOCK = 64;   // queue slots handed out at a time (one filter / bind wavefront reads one block)
 constexpr uint32_t QUEUE_HOLE = 0xFFFFFFFFu; // a queue slot without an item
+constexpr int S2_BINS = 448;              // (oligo, threshold class) groups a workgroup counts in LDS (what is left of a quarter of a CU's 160 KB next to the other arrays)
 
 struct Seed2Args {
 	DbView db;
@@ -92,6 +93,13 @@ struct Seed2Args {
 	int n_buckets;
 	uint32_t *stat_items, *stat_groups, *stat_phase_a; // statistics (one add per wavefront and launch)
 	unsigned long long *stat_cells; // ... DP cells (rows x window columns) of the phase-A windows
+	// Round 5: the pre-filter reads its queues regrouped by (oligo, threshold class) (tnt_ufilter.hip.h); the entries per group
+	// are counted here, as the entries are written -- an LDS histogram per workgroup, flushed once per launch -- which spares the
+	// regrouping its counting pass over the queues.  Null: not counted (more groups than S2_BINS: the counting pass runs).
+	const uint32_t *slot_bin;    // [slot][2] group of the slot inside its plain / its general bucket
+	const uint32_t *bin_base;    // [bucket] first group of the bucket in bin_hist
+	uint32_t *bin_hist;          // [groups of all buckets] entries per group (zeroed per batch)
+	uint32_t n_bins;
 	uint32_t *big_count;         // groups of more than 64 items
 	uint32_t *err;
 	uint32_t *debug;             // experimental builds only (TNT_EXP_STATS): cycles per phase
@@ -164,6 +172,9 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 	__shared__ uint8_t s_af[S2_ASSAYS];               // per assay of the chunk: 1 probe / padlock assay (hash-overload lists), 2 PCR with a probe
 	__shared__ uint32_t s_slot[S2_ASSAYS * 3];        // slot_pack of the chunk's slots
 	__shared__ uint32_t s_qbase[MAX_BUCKETS], s_qcap[MAX_BUCKETS];
+	__shared__ uint32_t s_cells[S2_WAVES];            // DP cells of the windows this wavefront queued (statistics)
+	__shared__ uint32_t s_bhist[S2_BINS];             // entries per (oligo, class) group written by this workgroup (Seed2Args::bin_hist)
+	__shared__ uint32_t s_bin[S2_ASSAYS * 3];         // per slot of the chunk: group in bin_hist of its plain bucket | of its general bucket << 16
 	// pointers the emission needs: read from LDS where they are used (kept in registers they spill to scratch memory,
 	// and a scratch reload is a vector-memory load -- see the emission)
 	enum { COLD_ITEMS = 0, COLD_GROUPS, COLD_QUEUE, COLD_Q_COUNT, COLD_BIG, COLD_ERR, COLD_RESULT, COLD_N };
@@ -189,6 +200,13 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 	}
 	for (uint32_t i = threadIdx.x; i < n_chunk * 3u; i += S2_THREADS) s_slot[i] = a.slot_pack[a.assay_begin * 3u + i];
 	if (int(threadIdx.x) < a.n_buckets) s_qbase[threadIdx.x] = a.q_base[threadIdx.x], s_qcap[threadIdx.x] = a.q_cap[threadIdx.x];
+	if (a.bin_hist) {
+		for (uint32_t i = threadIdx.x; i < uint32_t(S2_BINS); i += S2_THREADS) s_bhist[i] = 0;
+		for (uint32_t i = threadIdx.x; i < n_chunk * 3u; i += S2_THREADS) {
+			const uint32_t sp = a.slot_pack[a.assay_begin * 3u + i], sl = a.assay_begin * 3u + i;
+			s_bin[i] = (a.bin_base[sp & 0xFFu] + a.slot_bin[2u * sl]) | ((a.bin_base[(sp >> 8) & 0xFFu] + a.slot_bin[2u * sl + 1u]) << 16);
+		}
+	}
 	if (LTAB) // the chunk's bucket offsets, as dwords (the table starts on a dword, tnt_host.hip plan())
 		for (uint32_t i = threadIdx.x; i < ((1u << (2 * a.word_size)) + 2u) / 2u; i += S2_THREADS)
 			reinterpret_cast<uint32_t *>(s_tab)[i] = reinterpret_cast<const uint32_t *>(a.wt_off)[i];
@@ -206,13 +224,13 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		s_qend[wv][lane] = a.q_state[(region * MAX_BUCKETS + lane) * 2 + 1];
 	}
 	if (lane < 4) tgt[S2_TGT_WORDS + lane] = 0; // (slack behind the last word: the scan and the diagonal test read ahead)
+	if (lane == 0) s_cells[wv] = 0;
 	__syncthreads();
 
 	const uint32_t item_lo = region * a.item_region, group_lo = region * a.group_region;
 	uint32_t item_cur = item_lo + a.region_counts[2 * region], group_cur = group_lo + a.region_counts[2 * region + 1];
 	const uint32_t item_first = item_cur, group_first = group_cur;
 	uint32_t n_phase_a = 0;
-	uint32_t cells_acc = 0; // rows x columns of this lane's phase-A windows (below 2^32 per lane and launch: a lane emits at most 2^20 windows of at most 128 x 136 cells)
 
 	// Software pipeline over the wavefront's units: the record of unit i + 2 (one scalar load) and the packed words of
 	// unit i + 1 (two dwords per lane) are in flight while unit i is processed.
@@ -675,7 +693,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 					uint32_t stop = uint32_t(start) + (sp >> 16) + 2u * FLANK;
 					if (stop > len) stop = len;
 					fat = u32x4{o, uint32_t(rec_words + uint32_t(start >> 4)), uint32_t(start & 15) | ((stop - uint32_t(start)) << 4) | ((sp >> 16) << 12), info};
-					cells_acc += (sp >> 16) * (stop - uint32_t(start));
+					atomicAdd(&s_cells[wv], (sp >> 16) * (stop - uint32_t(start))); // rows x columns of the window (statistics; below 2^32 per wavefront and launch)
 					if (exc1 > exc0) { // windows with a degenerate target base go to the general instance of their length
 						uint32_t lo = exc0, hi = exc1;
 						while (lo < hi) {
@@ -727,6 +745,10 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 #if !(TNT_EXP_S2_SKIP & 2)
 					if (pos != ~0u) g_queue[pos] = fat;
 #endif
+					if (a.bin_hist && pos != ~0u) { // one LDS add per entry written: the regrouping's histogram, by the bucket the entry went to
+						const uint32_t sb = s_bin[la * 3u + role];
+						atomicAdd(&s_bhist[bucket != (s_slot[la * 3u + role] & 0xFFu) ? (sb >> 16) : (sb & 0xFFFFu)], 1u);
+					}
 				}
 				n_phase_a += uint32_t(__builtin_popcountll(am));
 			}
@@ -761,12 +783,13 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		if (group_cur != group_first) atomicAdd(a.stat_groups + shard * SHARD_STRIDE, group_cur - group_first);
 		if (n_phase_a) atomicAdd(a.stat_phase_a + shard * SHARD_STRIDE, n_phase_a);
 	}
-	{
-		unsigned long long c = cells_acc;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) c += (unsigned long long)__shfl_xor((long long)c, o);
-		if (lane == 0 && c && a.stat_cells) atomicAdd(a.stat_cells, c);
+	if (a.bin_hist) { // the workgroup's counts -> the batch's histogram
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < a.n_bins; i += S2_THREADS)
+			if (s_bhist[i]) atomicAdd(a.bin_hist + i, s_bhist[i]);
 	}
+	wave_sync();
+	if (lane == 0 && s_cells[wv] && a.stat_cells) atomicAdd(a.stat_cells, (unsigned long long)s_cells[wv]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -46,49 +46,93 @@ constexpr int uf_stride(int lmax)
 	return 2 * h;
 }
 
+// One length bucket of a regrouping launch (the launch serves all buckets of a phase at once: three launches per batch
+// instead of three per bucket, each of which had a start-up and a tail of its own)
+struct RegroupBucket {
+	uint32_t src_base, src_cap;  // the bucket's region of the phase-A queue as the seed kernel filled it (blocks with holes)
+	uint32_t dst_base;           // ... of the regrouped queue: src_cap + UF_BLOCK * n_bins slots
+	uint32_t bin_base, n_bins;   // its share of the histogram / cursor arrays
+	uint32_t general;            // 1: a general bucket (windows with a degenerate target base): bins by Slot::bucket_general
+	uint32_t counter;            // word offset of its counter line: [0] slots handed out, [4] out: regrouped entries, [5] work counter of its filter launch
+	uint32_t pad;
+};
+
 struct RegroupArgs {
-	const uint4 *src;            // queue region of one length bucket as the seed kernel filled it (blocks with holes)
-	const uint32_t *n_src_dev;   // slots handed out in it
-	uint32_t src_cap;            // ... capped at the region
-	const uint32_t *slot_bin;    // [slot] rank of the slot's (oligo, threshold class) inside its bucket
-	uint32_t n_bins;
-	uint32_t *hist;              // [n_bins] entries per bin (zeroed per batch)
-	uint32_t *cursor;            // [n_bins] next free slot of the bin's run
-	uint4 *dst;                  // the regrouped queue: per bin a run of whole blocks
-	uint32_t *n_dst_dev;         // its length (a multiple of UF_BLOCK)
+	const RegroupBucket *buckets;
+	uint32_t n_buckets;
+	const uint4 *src;            // phase-A queue buffer
+	uint4 *dst;                  // regrouped queue buffer
+	uint32_t *counters;          // bucket counter lines of the batch
+	const uint32_t *slot_bin;    // [slot][2] rank of the slot's (oligo, threshold class) inside its plain / its general bucket
+	uint32_t *hist;              // [bins of all buckets] entries per bin (zeroed per batch)
+	uint32_t *cursor;            // next free slot of every bin's run
 };
 
 #ifdef TNT_REGROUP_KERNELS // (the three regrouping kernels are compiled once, in tnt_host.hip's translation unit)
+// chunk c of a launch -> (bucket, first entry): the buckets' chunk counts are prefix-summed by every workgroup (a few dozen words)
+struct RegroupMap {
+	uint32_t first[MAX_BUCKETS + 1]; // first chunk of every bucket
+	uint32_t n[MAX_BUCKETS];         // entries of every bucket
+};
+__device__ __forceinline__ void regroup_map(const RegroupArgs &a, uint32_t chunk, RegroupMap &m)
+{
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (uint32_t b = 0; b < a.n_buckets; b++) {
+			uint32_t n = a.counters[a.buckets[b].counter];
+			n = n < a.buckets[b].src_cap ? n : a.buckets[b].src_cap;
+			m.first[b] = run, m.n[b] = n;
+			run += (n + chunk - 1) / chunk;
+		}
+		m.first[a.n_buckets] = run;
+	}
+	__syncthreads();
+}
+__device__ __forceinline__ uint32_t regroup_bucket_of(const RegroupMap &m, uint32_t n_buckets, uint32_t c)
+{
+	uint32_t b = 0;
+	while (b + 1 < n_buckets && m.first[b + 1] <= c) b++;
+	return b;
+}
+
 // pass 1: entries per bin
+constexpr uint32_t RG_COUNT_CHUNK = 64 * RG_THREADS;
 __global__ __launch_bounds__(RG_THREADS) void regroup_count_kernel(RegroupArgs a)
 {
 	__shared__ uint32_t s_hist[RG_MAX_BINS];
-	uint32_t n = *a.n_src_dev;
-	n = n < a.src_cap ? n : a.src_cap;
-	const uint32_t per = ((n + gridDim.x - 1) / gridDim.x + RG_THREADS - 1) / RG_THREADS * RG_THREADS; // a contiguous stretch per workgroup
-	const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-	if (lo >= n) return;
-	for (uint32_t b = threadIdx.x; b < a.n_bins; b += RG_THREADS) s_hist[b] = 0;
-	__syncthreads();
-	for (uint32_t i = lo + threadIdx.x; i < hi; i += RG_THREADS) {
-		const uint4 e = a.src[i];
-		if (e.x != RG_HOLE) atomicAdd(&s_hist[a.slot_bin[e.w >> ITEM_SLOT_SHIFT]], 1u);
+	__shared__ RegroupMap s_map;
+	regroup_map(a, RG_COUNT_CHUNK, s_map);
+	const uint32_t n_chunks = s_map.first[a.n_buckets];
+	for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+		const uint32_t b = regroup_bucket_of(s_map, a.n_buckets, c);
+		const RegroupBucket B = a.buckets[b];
+		const uint32_t lo = (c - s_map.first[b]) * RG_COUNT_CHUNK, hi = lo + RG_COUNT_CHUNK < s_map.n[b] ? lo + RG_COUNT_CHUNK : s_map.n[b];
+		for (uint32_t x = threadIdx.x; x < B.n_bins; x += RG_THREADS) s_hist[x] = 0;
+		__syncthreads();
+		const uint4 *src = a.src + B.src_base;
+		for (uint32_t i = lo + threadIdx.x; i < hi; i += RG_THREADS) {
+			const uint4 e = src[i];
+			if (e.x != RG_HOLE) atomicAdd(&s_hist[a.slot_bin[2u * (e.w >> ITEM_SLOT_SHIFT) + B.general]], 1u);
+		}
+		__syncthreads();
+		for (uint32_t x = threadIdx.x; x < B.n_bins; x += RG_THREADS)
+			if (s_hist[x]) atomicAdd(a.hist + B.bin_base + x, s_hist[x]);
+		__syncthreads();
 	}
-	__syncthreads();
-	for (uint32_t b = threadIdx.x; b < a.n_bins; b += RG_THREADS)
-		if (s_hist[b]) atomicAdd(a.hist + b, s_hist[b]);
 }
 
-// pass 2 (one workgroup): the runs -- every bin's count rounded up to whole blocks --, their padding, the total
+// pass 2 (one workgroup per bucket): the runs -- every bin's count rounded up to whole blocks --, their padding, the total
 __global__ __launch_bounds__(1024) void regroup_scan_kernel(RegroupArgs a)
 {
 	__shared__ uint32_t s_part[1024];
 	__shared__ uint32_t s_carry;
+	const RegroupBucket B = a.buckets[blockIdx.x];
+	uint4 *dst = a.dst + B.dst_base;
 	if (threadIdx.x == 0) s_carry = 0;
 	__syncthreads();
-	for (uint32_t b0 = 0; b0 < a.n_bins; b0 += 1024) {
+	for (uint32_t b0 = 0; b0 < B.n_bins; b0 += 1024) {
 		const uint32_t b = b0 + threadIdx.x;
-		const uint32_t cnt = b < a.n_bins ? a.hist[b] : 0u;
+		const uint32_t cnt = b < B.n_bins ? a.hist[B.bin_base + b] : 0u;
 		const uint32_t padded = (cnt + UF_BLOCK - 1) & ~(UF_BLOCK - 1);
 		s_part[threadIdx.x] = padded;
 		__syncthreads();
@@ -99,15 +143,15 @@ __global__ __launch_bounds__(1024) void regroup_scan_kernel(RegroupArgs a)
 			__syncthreads();
 		}
 		const uint32_t start = s_carry + s_part[threadIdx.x] - padded;
-		if (b < a.n_bins) {
-			a.cursor[b] = start;
-			for (uint32_t x = cnt; x < padded; x++) a.dst[start + x] = make_uint4(RG_HOLE, 0, 0, 0);
+		if (b < B.n_bins) {
+			a.cursor[B.bin_base + b] = start;
+			for (uint32_t x = cnt; x < padded; x++) dst[start + x] = make_uint4(RG_HOLE, 0, 0, 0);
 		}
 		__syncthreads();
 		if (threadIdx.x == 1023) s_carry += s_part[1023];
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) *a.n_dst_dev = s_carry;
+	if (threadIdx.x == 0) a.counters[B.counter + 4] = s_carry;
 }
 
 // pass 3: every entry to its bin's run.  A workgroup ranks a tile of entries per bin in LDS, reserves the tile's share of
@@ -116,36 +160,42 @@ __global__ __launch_bounds__(1024) void regroup_scan_kernel(RegroupArgs a)
 __global__ __launch_bounds__(RG_THREADS) void regroup_scatter_kernel(RegroupArgs a)
 {
 	__shared__ uint32_t s_cnt[RG_MAX_BINS], s_base[RG_MAX_BINS];
-	uint32_t n = *a.n_src_dev;
-	n = n < a.src_cap ? n : a.src_cap;
-	for (uint32_t b = threadIdx.x; b < a.n_bins; b += RG_THREADS) s_cnt[b] = 0;
+	__shared__ RegroupMap s_map;
+	regroup_map(a, RG_TILE, s_map);
+	const uint32_t n_chunks = s_map.first[a.n_buckets];
+	for (uint32_t x = threadIdx.x; x < RG_MAX_BINS; x += RG_THREADS) s_cnt[x] = 0;
 	__syncthreads();
-	for (uint32_t t0 = blockIdx.x * RG_TILE; t0 < n; t0 += gridDim.x * RG_TILE) {
+	for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+		const uint32_t b = regroup_bucket_of(s_map, a.n_buckets, c);
+		const RegroupBucket B = a.buckets[b];
+		const uint32_t t0 = (c - s_map.first[b]) * RG_TILE, n = s_map.n[b];
+		const uint4 *src = a.src + B.src_base;
+		uint4 *dst = a.dst + B.dst_base;
 		constexpr int PER = RG_TILE / RG_THREADS;
 		uint4 e[PER];
 		uint32_t br[PER]; // bin | rank << 12
 #pragma unroll
 		for (int r = 0; r < PER; r++) {
 			const uint32_t i = t0 + r * RG_THREADS + threadIdx.x;
-			e[r] = i < n ? a.src[i] : make_uint4(RG_HOLE, 0, 0, 0);
+			e[r] = i < n ? src[i] : make_uint4(RG_HOLE, 0, 0, 0);
 		}
 #pragma unroll
 		for (int r = 0; r < PER; r++) {
 			br[r] = ~0u;
 			if (e[r].x != RG_HOLE) {
-				const uint32_t bin = a.slot_bin[e[r].w >> ITEM_SLOT_SHIFT];
+				const uint32_t bin = a.slot_bin[2u * (e[r].w >> ITEM_SLOT_SHIFT) + B.general];
 				br[r] = bin | (atomicAdd(&s_cnt[bin], 1u) << 12);
 			}
 		}
 		__syncthreads();
-		for (uint32_t b = threadIdx.x; b < a.n_bins; b += RG_THREADS) {
-			const uint32_t c = s_cnt[b];
-			if (c) s_base[b] = atomicAdd(a.cursor + b, c), s_cnt[b] = 0;
+		for (uint32_t x = threadIdx.x; x < B.n_bins; x += RG_THREADS) {
+			const uint32_t k = s_cnt[x];
+			if (k) s_base[x] = atomicAdd(a.cursor + B.bin_base + x, k), s_cnt[x] = 0;
 		}
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < PER; r++)
-			if (br[r] != ~0u) a.dst[s_base[br[r] & 4095u] + (br[r] >> 12)] = e[r];
+			if (br[r] != ~0u) dst[s_base[br[r] & 4095u] + (br[r] >> 12)] = e[r];
 		__syncthreads();
 	}
 }
@@ -168,17 +218,24 @@ struct UFilterArgs {
 	uint8_t *audit;               // optional: audit mode marks what the filter would reject and lets everything through
 	int32_t *score_out;           // optional (unit-level entry): bound and threshold per item, [2 * idx]
 	int32_t status_exact;         // reject only where the status is certain (bounds against the minimum Tm)
+	// the instance for the general buckets (windows that hold a non-ACGT target code): the exception lists go by target and position
+	DbView db;
+	const Item *items;
 };
 
-template <int LMAX> __global__ __launch_bounds__(256) void ufilter_kernel(UFilterArgs a)
+// DEGEN: the instance for the general buckets -- windows with a non-ACGT target code.  As in filter_kernel<L, true>: an IUPAC code
+// or an inosine is the column value ANY (entry by entry the maximum over the bases it can stand for), a code the window loader
+// skips (gap, unknown: the window shrinks, Q6) makes the window pass unfiltered.
+template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void ufilter_kernel(UFilterArgs a)
 {
 	static_assert(LMAX <= 64, "the 128-row instances update one register set in place: filter_kernel");
+	constexpr int UF_KK = DEGEN ? FILT_X * FILT_X : UF_K; // target dinucleotides: ANY joins A C G T NONE
 	constexpr int THREADS = 256, WAVES = THREADS / 64;
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NW = (WMAX + 15) / 16; // packed words of a window in column order
 	constexpr int S = uf_stride(LMAX);
-	static_assert(UF_K <= 32 && (S % 2) == 0 && ((S / 2) % 2) == 1 && S >= LMAX, "table pitch");
-	__shared__ __attribute__((aligned(16))) uint32_t s_row[WAVES][UF_K * S];
+	static_assert(UF_K <= 32 && (S % 2) == 0 && ((S / 2) % 2) == 1 && S >= LMAX, "table pitch"); // (ANY columns reach k = 35: k and k - 32 share a bank pair)
+	__shared__ __attribute__((aligned(16))) uint32_t s_row[WAVES][UF_KK * S];
 	__shared__ uint32_t s_keep[WAVES][128]; // survivors of a wavefront on their way to the list
 	__shared__ uint32_t s_wcount[WAVES], s_wbase;
 	typedef short s2 __attribute__((ext_vector_type(2))); // (X, M2) of a cell, or (stack, loop entry) of a table entry: one register
@@ -221,7 +278,7 @@ template <int LMAX> __global__ __launch_bounds__(256) void ufilter_kernel(UFilte
 				filt_wave_sync(); // (the lanes' reads of the last block's table are through)
 				const uint32_t *plane = a.tab->plane[cls];
 				const uint32_t *q4 = a.olig_q4 + size_t(oligo) * (MAX_OLIGO / 4);
-				for (int e = lane; e < UF_K * S; e += 64) {
+				for (int e = lane; e < UF_KK * S; e += 64) {
 					const int k = e / S, i = e - k * S;
 					uint32_t q = bGAP, qp = bGAP;
 					if (i < L) q = (q4[i >> 2] >> ((i & 3) * 8 + 2)) & 7u;
@@ -238,6 +295,8 @@ template <int LMAX> __global__ __launch_bounds__(256) void ufilter_kernel(UFilte
 			// The window in column order, 2 bits per column, column j at bits 2 (j - 1): plus-strand binding reads the bases as
 			// they lie (bind_oligo.cpp:1227-1276), minus-strand binding the complement of base W - j (:524-573)
 			uint32_t ov[NW];
+			uint32_t om[DEGEN ? NW : 1]; // DEGEN: bit 2 (j - 1) set: column j holds an IUPAC code or an inosine
+			bool unfilterable = false;
 			{
 				const uint32_t *pk = a.packed + fe.y;
 				uint32_t raw[NW + 1];
@@ -246,33 +305,59 @@ template <int LMAX> __global__ __launch_bounds__(256) void ufilter_kernel(UFilte
 				const uint32_t sh = (fe.z & 15u) * 2u;
 #pragma unroll
 				for (int k = 0; k < NW; k++) ov[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
-				if (__builtin_amdgcn_ballot_w64(minus) != 0) {
-					// reversed and complemented: bit-reverse every word and swap the words, put the two bits of a base back in order,
-					// shift the 16 * NW - W bases of slack out, complement
-					uint32_t rv[NW + 1];
+				if (DEGEN) {
+					// the window's non-ACGT codes from the target's exception list (window: bind_oligo.cpp:502-505)
 #pragma unroll
-					for (int k = 0; k < NW; k++) {
-						const uint32_t r = __builtin_bitreverse32(ov[NW - 1 - k]);
-						rv[k] = ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
-					}
-					rv[NW] = 0;
-					const uint32_t slack = uint32_t(16 * NW - W) * 2u; // bits; below 32 * NW
-					// whole words first (NW <= 5: a short chain of selects), then the bits
+					for (int k = 0; k < NW; k++) om[DEGEN ? k : 0] = 0u;
+					if (active) {
+						const Item it = a.items[idx];
+						int start = int(it.tloc) - (int(fe.w & 127u) + FLANK);
+						if (start < 0) start = 0;
+						const int stop = start + W;
+						const uint32_t e0 = a.db.exc_off[it.target], e1 = a.db.exc_off[it.target + 1];
+						uint32_t lo = e0, hi = e1;
+						while (lo < hi) {
+							const uint32_t mid = (lo + hi) >> 1;
+							if (a.db.exc_pos[mid] < uint32_t(start)) lo = mid + 1;
+							else hi = mid;
+						}
+						for (uint32_t x = lo; x < e1 && a.db.exc_pos[x] < uint32_t(stop); x++) {
+							if (a.db.exc_code[x] > 15) unfilterable = true; // skipped codes; inosine (4) and the IUPAC codes read as ANY
+							const int r = int(a.db.exc_pos[x]) - start;
 #pragma unroll
-					for (int step = NW - 1; step >= 1; step--) { // words to drop: at most NW - 1 when W >= 1
-						const bool drop = (slack >> 5) >= uint32_t(step);
-						// (applied cumulatively: each pass drops one word where `slack >> 5` still asks for it)
-						if (drop) {
-#pragma unroll
-							for (int k = 0; k < NW; k++) rv[k] = rv[k + 1];
+							for (int k = 0; k < NW; k++)
+								if ((r >> 4) == k) om[DEGEN ? k : 0] |= 1u << ((r & 15) * 2);
 						}
 					}
-					const uint32_t bits = slack & 31u;
+				}
+				if (__builtin_amdgcn_ballot_w64(minus) != 0) {
+					// reversed (and, the bases, complemented): bit-reverse every word and swap the words, put the two bits of a base
+					// back in order, shift the 16 * NW - W bases of slack out
+					auto reversed = [&](uint32_t *x, const uint32_t flip) __attribute__((always_inline)) {
+						uint32_t rv[NW + 1];
 #pragma unroll
-					for (int k = 0; k < NW; k++) {
-						const uint32_t v = __builtin_amdgcn_alignbit(rv[k + 1], rv[k], bits);
-						ov[k] = minus ? v : ov[k];
-					}
+						for (int k = 0; k < NW; k++) {
+							const uint32_t r = __builtin_bitreverse32(x[NW - 1 - k]);
+							rv[k] = ((((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u))) ^ flip;
+						}
+						rv[NW] = 0;
+						const uint32_t slack = uint32_t(16 * NW - W) * 2u; // bits; below 32 * NW for a window of at least one base
+						// whole words first (NW <= 5: each pass drops one word where `slack >> 5` still asks for it), then the bits
+#pragma unroll
+						for (int step = NW - 1; step >= 1; step--) {
+							const bool drop = (slack >> 5) >= uint32_t(step);
+#pragma unroll
+							for (int k = 0; k < NW; k++) rv[k] = drop ? rv[k + 1] : rv[k];
+						}
+						const uint32_t bits = slack & 31u;
+#pragma unroll
+						for (int k = 0; k < NW; k++) {
+							const uint32_t v = __builtin_amdgcn_alignbit(rv[k + 1], rv[k], bits);
+							x[k] = minus ? v : x[k];
+						}
+					};
+					reversed(ov, ~0u);
+					if (DEGEN) reversed(om, 0u);
 				}
 			}
 
@@ -330,6 +415,10 @@ template <int LMAX> __global__ __launch_bounds__(256) void ufilter_kernel(UFilte
 					for (int c = 0; c < ncol; c += 2) {
 						int t0 = int(__builtin_amdgcn_ubfe(word, uint32_t(2 * c), 2u));
 						int t1 = int(__builtin_amdgcn_ubfe(word, uint32_t(2 * c + 2), 2u));
+						if (DEGEN) {
+							t0 = ((om[DEGEN ? w : 0] >> (2 * c)) & 1u) ? FILT_ANY : t0;
+							t1 = ((om[DEGEN ? w : 0] >> (2 * c + 2)) & 1u) ? FILT_ANY : t1;
+						}
 						if (RAGGED) {
 							t0 = j0 + c + 1 <= W ? t0 : FILT_NONE;
 							t1 = j0 + c + 2 <= W ? t1 : FILT_NONE;
@@ -357,6 +446,7 @@ template <int LMAX> __global__ __launch_bounds__(256) void ufilter_kernel(UFilte
 				theta = int(floorf(th * float(FILT_UNITS))) - 1;
 				pass = best >= theta || best >= FILT_SAT || (a.status_exact && a.tab->enabled[cls] != FILT_BY_TM);
 			}
+			if (DEGEN && unfilterable) pass = true, best = INT32_MAX, theta = INT32_MIN;
 			if (a.score_out && active) a.score_out[2 * idx] = best, a.score_out[2 * idx + 1] = theta;
 			if (a.audit) {
 				if (active) a.audit[idx] = pass ? 0 : 1;
@@ -405,6 +495,9 @@ template <int LMAX> __global__ __launch_bounds__(256) void ufilter_kernel(UFilte
 // host-side launchers, defined in tnt_bind_inst.hip next to the filter instances of the same lengths (TNT_FILTER_LADDER)
 #define X(N) void launch_ufilter_##N(const UFilterArgs &a, int blocks, hipStream_t stream);
 TNT_FILTER_LADDER(X)
+#undef X
+#define X(N) void launch_ufilter_degen_##N(const UFilterArgs &a, int blocks, hipStream_t stream);
+TNT_LMAX_LADDER(X)
 #undef X
 
 } // namespace tnt
