@@ -1473,6 +1473,43 @@ def test_dinkelbach_many_windows_of_long_probes(Engine, oracle):
     e.close()
 
 
+def test_deferred_finish_changes_no_result(Engine, oracle, monkeypatch):
+    """TNT_MI355X_DEFER=1: the throughput bind instances park the windows that pass the Tm / dG tests and bind_finish_kernel
+    writes their records and alignment texts (built and measured in round 5, no gain, opt-in): same hits as the default path
+    and as the oracle -- PCR, TaqMan, padlock + probes on targets with IUPAC codes -- and the same statuses / records through
+    the production instances of the unit-level route."""
+    for cfg, nt, na in [(2, 20000, 96), (3, 12000, 48), (5, 4000, 120)]:
+        wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=77)
+        res = {}
+        for mode in ("default", "deferred"):
+            monkeypatch.delenv("TNT_MI355X_DEFER", raising=False)
+            if mode == "deferred":
+                monkeypatch.setenv("TNT_MI355X_DEFER", "1")
+            e = Engine(wl.options, wl.expanded)
+            db = e.pack(wl.codes, wl.offsets)
+            res[mode] = tc.sorted_hit_keys(e.search(db))
+            if mode == "deferred" and cfg == 2:
+                oligos = sorted({o for x in wl.expanded for o in (x.forward, x.reverse, x.probe) if o})
+                seeds = oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
+                pick = seeds[::max(1, len(seeds) // 4000)]
+                om = {o: i for i, o in enumerate(e.oligos)}
+                want_b = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, tc.make_reqs((s[0], s[1], s[2], s[3], s[4], 0, 9.0e-7) for s in pick))
+                got_b = e.bind_batch(db, tc.make_reqs((s[0], om[oligos[s[1]]], s[2], s[3], s[4], 0, 9.0e-7) for s in pick), route=1)
+                bad = []
+                for i, w in enumerate(want_b):
+                    x, got = gu.bind_record(w), gu.bind_record(got_b[i])
+                    d = [(k, x[k], got[k]) for k in ([0] + (ROUTED_FIELDS if x[0] == 0 else [])) if x[k] != got[k]]
+                    if d:
+                        bad.append((i, d))
+                assert not bad, bad[:2]
+                assert sum(1 for w in want_b if w.status == 0) > 10
+            db.close()
+            e.close()
+        assert res["default"] == res["deferred"] and len(res["default"]) > 0
+        if cfg != 5:
+            assert res["default"] == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+
+
 def test_q11_regime_is_reported(Engine):
     """Thresholds that accept Tm = 0 and dG = 0 (no -e / -E, no negative -g / -G) put a context in the regime of SURVEY Q11, where
     the reference can report hits built from stale alignment state (nuc_cruc.h:360-371): tnt_ctx_warnings says so; with a

@@ -60,7 +60,30 @@ struct BindArgs {
 	char *ltext;
 	uint32_t ltext_cap;
 	uint32_t *ltext_count;     // bytes handed out
+	// Round 5 (opt-in, TNT_MI355X_DEFER=1: measured, no gain -- DESIGN.md 4.2): the throughput instances of up to 64 rows can
+	// leave what lies behind the Tm / dG tests of the cascade -- anchors, counts, the other thresholds, footprint, record and
+	// alignment text -- to bind_finish_kernel: one window in five gets that far, so inside the bind kernel that code runs with
+	// a fifth of the lanes.  A window that passes the two tests parks its state here.  Null (the default): everything inside
+	// the bind kernel.
+	struct PendingRec *pending;
+	uint32_t pending_cap;
+	uint32_t *n_pending;
 };
+
+// state of a window behind the Tm / dG tests (bind_oligo.cpp:600-624): what bind_finish needs of it
+constexpr int PENDING_WIN = 64 + 2 * FLANK; // window bases of an oligo of up to 64 bases
+constexpr int PENDING_COLS = 64 + PENDING_WIN + 4 + 4; // alignment columns (rounded up to dwords)
+struct PendingRec {
+	uint32_t idx, group;
+	int32_t start, stop;
+	float tm, dH, dS;
+	uint32_t slot;
+	int16_t n_cols, fm_q, fm_t, lm_q, lm_t, pad0;
+	uint8_t L, W, minus, pad1;
+	uint8_t win[PENDING_WIN];   // TARGET(k)
+	uint8_t cols[PENDING_COLS]; // columns k0 .. k1 - 1 of the best alignment
+};
+static_assert(sizeof(PendingRec) % 4 == 0 && offsetof(PendingRec, win) % 4 == 0 && offsetof(PendingRec, cols) % 4 == 0, "records are moved as dwords");
 
 // reference to a text in the long-text arena, as a text field holds it: 0x7F 'L' 'T' + offset (8 hex digits) + length (6 hex digits)
 
@@ -449,6 +472,207 @@ template <int LMAX, int STRIDE, int PF> struct SlabTrace {
 };
 
 // The serial tail of one (oligo, window): everything behind the DP fill -- tm_dimer's loop over the maximal cells,
+// The back of the serial tail: what bind_oligo_to_*_strand does with a window once Tm and dG passed (bind_oligo.cpp:626-748) --
+// anchors and counts (nuc_cruc_anchor.cpp, nuc_cruc.h:389-483), the other thresholds, alignment_range, the bound record and the
+// alignment text (operator<<, nuc_cruc_output.cpp:74-205).  Called at the end of bind_tail (unit-level instance, oligos beyond 64
+// bases, --dinkelbach) or, for the windows the throughput instances parked, by bind_finish_kernel.
+//   win / cols / best: per-lane slices with stride STRIDE; qry (QRY_LDS) the oligo in row order, else `query` 5'->3' in memory.
+#define QUERY(K) (QRY_LDS ? int(qry[(L - 1 - (K)) * STRIDE]) : int(query[(K)]))
+#define TARGET(K) int(win[(K) * STRIDE])
+template <bool FULL, bool QRY_LDS, bool LONG_TEXT, int STRIDE>
+__device__ __forceinline__ void bind_finish(const BindArgs &a, const uint8_t *win, const uint8_t *qry, const uint8_t *query, uint8_t *cols, const uint8_t *best, AlignInfo bi,
+                                            const bool best_valid, int status, const Thresh &th, const float tm, const float best_dH, const float best_dS, const float dg,
+                                            const uint32_t idx, const Item &it, const int L, const int W, const int start, const int stop, const bool minus, const int gmax, const int nmax)
+{
+	int a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0, loc5 = 0, loc3 = 0;
+	// The columns of the best alignment sit in `best` -- HBM for the instances whose LDS is taken by other things (every plain
+	// instance of 23 rows and more) -- and the counts below and the alignment text read them one at a time, each read waiting for
+	// the one before it (a rolled loop; the text's stores in between may alias them as far as the compiler knows): some hundred
+	// memory round trips per record, 100 000 of the 509 000 cycles a wavefront spent on 64 windows (TNT_EXP_STATS: thresholds
+	// 37 000, output 84 000).  `cols` (LDS) is free once the enumeration is through: the columns move there eight loads at a time.
+	if (best_valid && (FULL || status == 0)) {
+		for (int k = bi.k0; k < bi.k1; k += 8) {
+			uint8_t v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = k + u < bi.k1 ? best[(k + u) * STRIDE] : uint8_t(0);
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				if (k + u < bi.k1) cols[(k + u) * STRIDE] = v[u];
+		}
+	}
+	if (best_valid && (FULL || status == 0)) {
+		const int front_q = col_q(cols[bi.k0 * STRIDE]), front_t = col_t(cols[bi.k0 * STRIDE]);
+		const int back_q = col_q(cols[(bi.k1 - 1) * STRIDE]), back_t = col_t(cols[(bi.k1 - 1) * STRIDE]);
+		{ // anchor5_query, nuc_cruc_anchor.cpp:143-192
+			int qi = 0, ti = bi.fm_q + bi.fm_t;
+			bool go = !(front_t == bE);
+			if (front_q == bE) ti--;
+			if (ti >= W) go = false;
+			while (go) {
+				if (qi >= L || ti < 0) break;
+				if (!is_complementary(QUERY(qi), TARGET(ti))) break;
+				a5++, qi++, ti--;
+			}
+		}
+		{ // anchor3_query, nuc_cruc_anchor.cpp:249-298
+			int qi = L - 1, ti = (bi.lm_q + bi.lm_t + 1) - L;
+			bool go = !(back_t == bE);
+			if (back_q == bE) ti++;
+			if (ti >= W || ti < 0) go = false;
+			while (go) {
+				if (qi < 0 || ti >= W) break;
+				if (!is_complementary(QUERY(qi), TARGET(ti))) break;
+				a3++, qi--, ti++;
+			}
+		}
+		{ // num_mismatch_by_query / num_gap / max_contiguous_target_degen, nuc_cruc.h:389-483
+			int aligned = 0, run = 0;
+			for (int k = bi.k0; k < bi.k1; k++) {
+				const uint8_t cw = cols[k * STRIDE];
+				const int q = col_q(cw), t = col_t(cw);
+				if (!is_virtual(q)) {
+					if (!is_virtual(t) && !is_complementary(q, t)) mm++;
+					aligned++;
+				}
+				gap += (q == bGAP) + (t == bGAP);
+				if (t >= bM && t <= bN) {
+					run++;
+					if (run > poly) poly = run;
+				} else {
+					run = 0;
+				}
+			}
+			mm += L - aligned;
+		}
+		if (!status) {
+			if (a5 < th.clamp5) status = 3;
+			else if (a3 < th.clamp3) status = 4;
+			else if (mm > th.max_mm) status = 5;
+			else if (gap > th.max_gap) status = 6;
+			else if (poly > th.max_poly) status = 7;
+		}
+		// alignment_range (nuc_cruc_anchor.cpp:379-396) -> plus-strand footprint
+		const int qf = bi.fm_q, ql = bi.lm_q, tf = bi.lm_t, tl = bi.fm_t;
+		loc5 = loc3 = start;
+		if (minus) { // bind_oligo.cpp:721-731
+			loc5 += (stop - start - 1) - tl;
+			loc3 += (stop - start - 1) - tf;
+			loc5 -= qf;
+			loc3 += (L - 1) - ql;
+		} else { // bind_oligo.cpp:1424-1434
+			loc5 += tf;
+			loc3 += tl;
+			loc3 += qf;
+			loc5 -= (L - 1) - ql;
+		}
+	} else if (!best_valid && !status) {
+		status = 8; // SURVEY Q11 fence: no alignment is never a bind
+	}
+
+	// ------------------------------------------------------------------ output
+	char *text = nullptr;
+	int32_t res = -status;
+	BoundRec *rec = nullptr;
+	if (!FULL && status == 0 && a.audit && a.audit[idx]) atomicOr(a.err, ERR_FILTER_UNSOUND);
+	if (status == 0 && !FULL) {
+		const uint32_t slotp = atomicAdd(a.pool_count, 1u);
+		if (slotp < a.pool_cap) {
+			rec = a.pool + slotp;
+			rec->loc5 = loc5, rec->loc3 = loc3;
+			rec->tm = tm, rec->dH = best_dH, rec->dS = best_dS;
+			rec->a5 = a5, rec->a3 = a3, rec->mm = mm, rec->gap = gap;
+			text = rec->text;
+			res = int32_t(slotp);
+			if (a.groups && !(atomicOr(&a.groups[it.group].count, GROUP_ALIVE) & GROUP_ALIVE))
+				a.active[atomicAdd(a.n_active, 1u)] = it.group;
+		} else {
+			atomicOr(a.err, ERR_POOL_OVERFLOW);
+			res = -100;
+		}
+	}
+	if (FULL) {
+		BindFull &f = a.full[idx];
+		f.status = status, f.target_start = start, f.target_stop = stop;
+		f.tm = tm, f.dH = best_dH, f.dS = best_dS, f.dg = dg;
+		f.a5 = a5, f.a3 = a3, f.mm = mm, f.gap = gap, f.poly = poly;
+		f.loc5 = loc5, f.loc3 = loc3;
+		f.q_first = bi.fm_q, f.q_last = bi.lm_q, f.t_first = bi.lm_t, f.t_last = bi.fm_t;
+		f.valid = best_valid ? 1 : 0;
+		f.dp_max = gmax;
+		f.n_max = nmax;
+		f.text[0] = 0;
+		if (best_valid) text = f.text;
+	} else {
+		a.result[idx] = res;
+	}
+
+	if (text) { // operator<<(ostream&, NucCruc), nuc_cruc_output.cpp:74-205
+		int prefix = bi.fm_q < (W - 1 - bi.fm_t) ? bi.fm_q : (W - 1 - bi.fm_t);
+		if (prefix < 0) prefix = 0;
+		int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
+		if (suffix < 0) suffix = 0;
+		// three lines of prefix + columns + suffix and 18 characters of decoration: the field holds every alignment of a
+		// 64-mer; one of a longer oligo that does not fit goes to the context's long-text arena and the field gets a reference
+		// to it (tnt_long_text reads through it).  Never a cut text: without room in the arena the call fails.
+		// (written a dword at a time: every lane writes into a record of its own, so a byte store is a memory request)
+		int o = 0;
+		uint32_t acc = 0;
+		static_assert(offsetof(BoundRec, text) % 4 == 0 && offsetof(BindFull, text) % 4 == 0 && sizeof(BoundRec) % 4 == 0 && sizeof(BindFull) % 4 == 0 && ALIGN_TEXT % 4 == 0,
+		              "text fields on 4-byte boundaries");
+		uint32_t *text32 = reinterpret_cast<uint32_t *>(text);
+		const int text_chars = 3 * (prefix + (bi.k1 - bi.k0) + suffix) + 18;
+		uint32_t lref = 0xFFFFFFFFu; // where the text sits in the arena
+		if (LONG_TEXT && text_chars >= ALIGN_TEXT) {
+			const uint32_t need = (uint32_t(text_chars) + 4u) & ~3u;
+			const uint32_t at = a.ltext ? atomicAdd(a.ltext_count, need) : 0xFFFFFFFFu;
+			if (a.ltext && at <= a.ltext_cap && need <= a.ltext_cap - at) {
+				lref = at;
+				text32 = reinterpret_cast<uint32_t *>(a.ltext + at);
+			} else {
+				atomicOr(a.err, ERR_TEXT_OVERFLOW);
+				prefix = suffix = 0, bi.k1 = bi.k0;
+			}
+		}
+		auto put = [&](char ch) __attribute__((always_inline)) {
+			acc |= uint32_t(uint8_t(ch)) << ((o & 3) * 8);
+			o++;
+			if ((o & 3) == 0) text32[(o >> 2) - 1] = acc, acc = 0;
+		};
+		put('5'), put('\''), put(' ');
+		for (int i = 0; i < prefix; i++) put(base_letter(QUERY(bi.fm_q - prefix + i)));
+		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_q(cols[k * STRIDE])));
+		for (int i = 0; i < suffix; i++) put(base_letter(QUERY(bi.lm_q + 1 + i)));
+		put(' '), put('3'), put('\''), put('\n');
+		put(' '), put(' '), put(' ');
+		for (int i = 0; i < prefix; i++) put(is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ');
+		for (int k = bi.k0; k < bi.k1; k++) {
+			const uint8_t cw = cols[k * STRIDE];
+			put(is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ');
+		}
+		for (int i = 0; i < suffix; i++) put(is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ');
+		put('\n');
+		put('3'), put('\''), put(' ');
+		for (int i = prefix; i > 0; i--) put(base_letter(TARGET(bi.fm_t + i)));
+		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_t(cols[k * STRIDE])));
+		for (int i = 1; i <= suffix; i++) put(base_letter(TARGET(bi.lm_t - i)));
+		put(' '), put('5'), put('\'');
+		text32[o >> 2] = acc; // the rest and the terminating zero (acc holds zeros above the characters written)
+		if (rec) rec->text_len = o; // (the text's own length also where the field only refers to it: sort_by_bound_match compares it)
+		if (lref != 0xFFFFFFFFu) { // the field: 0x7F L T, offset, length -- no zero byte inside, one behind
+			uint32_t *f32 = reinterpret_cast<uint32_t *>(text);
+			auto hex = [](uint32_t v, int d) __attribute__((always_inline)) { return uint32_t("0123456789abcdef"[(v >> (4 * d)) & 15u]); };
+			const uint32_t len = uint32_t(o);
+			f32[0] = 0x7Fu | (uint32_t('L') << 8) | (uint32_t('T') << 16) | (hex(lref, 7) << 24);
+			f32[1] = hex(lref, 6) | (hex(lref, 5) << 8) | (hex(lref, 4) << 16) | (hex(lref, 3) << 24);
+			f32[2] = hex(lref, 2) | (hex(lref, 1) << 8) | (hex(lref, 0) << 16) | (hex(len, 5) << 24);
+			f32[3] = hex(len, 4) | (hex(len, 3) << 8) | (hex(len, 2) << 16) | (hex(len, 1) << 24);
+			f32[4] = hex(len, 0);
+		}
+	}
+}
+#undef QUERY
+#undef TARGET
+
 // enumerate_dimer_alignments + trace_back, evaluate_alignment, the threshold cascade, anchors and counts, footprint, record
 // and alignment text.  Shared by the lane-per-window kernel (bind_kernel, below: STRIDE = workgroup size, per-lane slices of
 // LDS / scratch arrays) and the wavefront-per-window kernel (tnt_wbind.hip.h: STRIDE = 1, one lane runs it).
@@ -457,7 +681,8 @@ template <int LMAX, int STRIDE, int PF> struct SlabTrace {
 //   A maximal cell is (i << CODE_SHIFT) | j; cells are numbered li * wstride + lj for the branch-cursor stack, whose entries
 //   are  key (cell * 4 + state, 24 bits) | trace mask << 24 | cursor << 28.
 // Returns true when a Dinkelbach pass has to follow (Tcur updated).
-template <bool FULL, bool DINK, bool QRY_LDS, bool LONG_TEXT, int STRIDE, int CODE_SHIFT, typename TIE_T, class TRACE>
+//   DEFER: the instance may park a window behind the Tm / dG tests for bind_finish_kernel (BindArgs::pending).
+template <bool FULL, bool DINK, bool QRY_LDS, bool LONG_TEXT, int STRIDE, int CODE_SHIFT, typename TIE_T, class TRACE, bool DEFER = false>
 __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const uint8_t *s_lut, const uint8_t *s_hs_map, const float2 *s_hs_val, const TailConst &s_k,
                                           const uint8_t *win, const uint8_t *qry, uint8_t *cols, uint8_t *best, uint32_t *stack, TIE_T *ties, int ncols, int wstride,
                                           uint32_t idx, const Item &it, const Slot &slot, int L, int W, int start, int stop, bool minus, int xmode, int gmax, int nmax,
@@ -761,193 +986,46 @@ __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const ui
 	a.result[idx] = -1 - (status & 1);
 	return false;
 #endif
-	int a5 = 0, a3 = 0, mm = 0, gap = 0, poly = 0, loc5 = 0, loc3 = 0;
-	// The columns of the best alignment sit in `best` -- HBM for the instances whose LDS is taken by other things (every plain
-	// instance of 23 rows and more) -- and the counts below and the alignment text read them one at a time, each read waiting for
-	// the one before it (a rolled loop; the text's stores in between may alias them as far as the compiler knows): some hundred
-	// memory round trips per record, 100 000 of the 509 000 cycles a wavefront spent on 64 windows (TNT_EXP_STATS: thresholds
-	// 37 000, output 84 000).  `cols` (LDS) is free once the enumeration is through: the columns move there eight loads at a time.
-	if (best_valid && (FULL || status == 0)) {
-		for (int k = bi.k0; k < bi.k1; k += 8) {
-			uint8_t v[8];
-#pragma unroll
-			for (int u = 0; u < 8; u++) v[u] = k + u < bi.k1 ? best[(k + u) * STRIDE] : uint8_t(0);
-#pragma unroll
-			for (int u = 0; u < 8; u++)
-				if (k + u < bi.k1) cols[(k + u) * STRIDE] = v[u];
-		}
-	}
-	if (best_valid && (FULL || status == 0)) {
-		const int front_q = col_q(cols[bi.k0 * STRIDE]), front_t = col_t(cols[bi.k0 * STRIDE]);
-		const int back_q = col_q(cols[(bi.k1 - 1) * STRIDE]), back_t = col_t(cols[(bi.k1 - 1) * STRIDE]);
-		{ // anchor5_query, nuc_cruc_anchor.cpp:143-192
-			int qi = 0, ti = bi.fm_q + bi.fm_t;
-			bool go = !(front_t == bE);
-			if (front_q == bE) ti--;
-			if (ti >= W) go = false;
-			while (go) {
-				if (qi >= L || ti < 0) break;
-				if (!is_complementary(QUERY(qi), TARGET(ti))) break;
-				a5++, qi++, ti--;
-			}
-		}
-		{ // anchor3_query, nuc_cruc_anchor.cpp:249-298
-			int qi = L - 1, ti = (bi.lm_q + bi.lm_t + 1) - L;
-			bool go = !(back_t == bE);
-			if (back_q == bE) ti++;
-			if (ti >= W || ti < 0) go = false;
-			while (go) {
-				if (qi < 0 || ti >= W) break;
-				if (!is_complementary(QUERY(qi), TARGET(ti))) break;
-				a3++, qi--, ti++;
-			}
-		}
-		{ // num_mismatch_by_query / num_gap / max_contiguous_target_degen, nuc_cruc.h:389-483
-			int aligned = 0, run = 0;
-			for (int k = bi.k0; k < bi.k1; k++) {
-				const uint8_t cw = cols[k * STRIDE];
-				const int q = col_q(cw), t = col_t(cw);
-				if (!is_virtual(q)) {
-					if (!is_virtual(t) && !is_complementary(q, t)) mm++;
-					aligned++;
-				}
-				gap += (q == bGAP) + (t == bGAP);
-				if (t >= bM && t <= bN) {
-					run++;
-					if (run > poly) poly = run;
-				} else {
-					run = 0;
-				}
-			}
-			mm += L - aligned;
-		}
-		if (!status) {
-			if (a5 < th.clamp5) status = 3;
-			else if (a3 < th.clamp3) status = 4;
-			else if (mm > th.max_mm) status = 5;
-			else if (gap > th.max_gap) status = 6;
-			else if (poly > th.max_poly) status = 7;
-		}
-		// alignment_range (nuc_cruc_anchor.cpp:379-396) -> plus-strand footprint
-		const int qf = bi.fm_q, ql = bi.lm_q, tf = bi.lm_t, tl = bi.fm_t;
-		loc5 = loc3 = start;
-		if (minus) { // bind_oligo.cpp:721-731
-			loc5 += (stop - start - 1) - tl;
-			loc3 += (stop - start - 1) - tf;
-			loc5 -= qf;
-			loc3 += (L - 1) - ql;
-		} else { // bind_oligo.cpp:1424-1434
-			loc5 += tf;
-			loc3 += tl;
-			loc3 += qf;
-			loc5 -= (L - 1) - ql;
-		}
-	} else if (!best_valid && !status) {
-		status = 8; // SURVEY Q11 fence: no alignment is never a bind
-	}
-
-#ifdef TNT_EXP_STATS
-	const long long st_out0 = __builtin_readcyclecounter();
-#endif
-	// ------------------------------------------------------------------ output
-	char *text = nullptr;
-	int32_t res = -status;
-	BoundRec *rec = nullptr;
-	if (!FULL && status == 0 && a.audit && a.audit[idx]) atomicOr(a.err, ERR_FILTER_UNSOUND);
-	if (status == 0 && !FULL) {
-		const uint32_t slotp = atomicAdd(a.pool_count, 1u);
-		if (slotp < a.pool_cap) {
-			rec = a.pool + slotp;
-			rec->loc5 = loc5, rec->loc3 = loc3;
-			rec->tm = tm, rec->dH = best_dH, rec->dS = best_dS;
-			rec->a5 = a5, rec->a3 = a3, rec->mm = mm, rec->gap = gap;
-			text = rec->text;
-			res = int32_t(slotp);
-			if (a.groups && !(atomicOr(&a.groups[it.group].count, GROUP_ALIVE) & GROUP_ALIVE))
-				a.active[atomicAdd(a.n_active, 1u)] = it.group;
+	if (DEFER && a.pending) {
+		// What is left runs for the windows that passed both tests only (one in five on config 2): their state goes to the queue of
+		// bind_finish_kernel, lanes of a wavefront share one atomic; the others have their status.
+		const bool park = status == 0 && best_valid;
+		if (!park) {
+			a.result[idx] = -(status ? status : 8); // (no valid alignment under thresholds that accept Tm = 0: the Q11 fence)
 		} else {
-			atomicOr(a.err, ERR_POOL_OVERFLOW);
-			res = -100;
-		}
-	}
-	if (FULL) {
-		BindFull &f = a.full[idx];
-		f.status = status, f.target_start = start, f.target_stop = stop;
-		f.tm = tm, f.dH = best_dH, f.dS = best_dS, f.dg = dg;
-		f.a5 = a5, f.a3 = a3, f.mm = mm, f.gap = gap, f.poly = poly;
-		f.loc5 = loc5, f.loc3 = loc3;
-		f.q_first = bi.fm_q, f.q_last = bi.lm_q, f.t_first = bi.lm_t, f.t_last = bi.fm_t;
-		f.valid = best_valid ? 1 : 0;
-		f.dp_max = gmax;
-		f.n_max = nmax;
-		f.text[0] = 0;
-		if (best_valid) text = f.text;
-	} else {
-		a.result[idx] = res;
-	}
-
-	if (text) { // operator<<(ostream&, NucCruc), nuc_cruc_output.cpp:74-205
-		int prefix = bi.fm_q < (W - 1 - bi.fm_t) ? bi.fm_q : (W - 1 - bi.fm_t);
-		if (prefix < 0) prefix = 0;
-		int suffix = (L - 1 - bi.lm_q) < bi.lm_t ? (L - 1 - bi.lm_q) : bi.lm_t;
-		if (suffix < 0) suffix = 0;
-		// three lines of prefix + columns + suffix and 18 characters of decoration: the field holds every alignment of a
-		// 64-mer; one of a longer oligo that does not fit goes to the context's long-text arena and the field gets a reference
-		// to it (tnt_long_text reads through it).  Never a cut text: without room in the arena the call fails.
-		// (written a dword at a time: every lane writes into a record of its own, so a byte store is a memory request)
-		int o = 0;
-		uint32_t acc = 0;
-		static_assert(offsetof(BoundRec, text) % 4 == 0 && offsetof(BindFull, text) % 4 == 0 && sizeof(BoundRec) % 4 == 0 && sizeof(BindFull) % 4 == 0 && ALIGN_TEXT % 4 == 0,
-		              "text fields on 4-byte boundaries");
-		uint32_t *text32 = reinterpret_cast<uint32_t *>(text);
-		const int text_chars = 3 * (prefix + (bi.k1 - bi.k0) + suffix) + 18;
-		uint32_t lref = 0xFFFFFFFFu; // where the text sits in the arena
-		if (LONG_TEXT && text_chars >= ALIGN_TEXT) {
-			const uint32_t need = (uint32_t(text_chars) + 4u) & ~3u;
-			const uint32_t at = a.ltext ? atomicAdd(a.ltext_count, need) : 0xFFFFFFFFu;
-			if (a.ltext && at <= a.ltext_cap && need <= a.ltext_cap - at) {
-				lref = at;
-				text32 = reinterpret_cast<uint32_t *>(a.ltext + at);
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(true); // the lanes that park
+			const int me = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)));
+			uint32_t at = 0;
+			if (me == 0) at = atomicAdd(a.n_pending, uint32_t(__builtin_popcountll(m)));
+			at = uint32_t(__shfl(int(at), __builtin_ctzll(m))) + uint32_t(me);
+			if (at >= a.pending_cap) {
+				atomicOr(a.err, ERR_POOL_OVERFLOW);
+				a.result[idx] = -100;
 			} else {
-				atomicOr(a.err, ERR_TEXT_OVERFLOW);
-				prefix = suffix = 0, bi.k1 = bi.k0;
+				PendingRec &p = a.pending[at];
+				p.idx = idx, p.group = it.group, p.start = start, p.stop = stop;
+				p.tm = tm, p.dH = best_dH, p.dS = best_dS;
+				p.slot = it.info >> ITEM_SLOT_SHIFT;
+				p.n_cols = int16_t(bi.k1 - bi.k0), p.fm_q = int16_t(bi.fm_q), p.fm_t = int16_t(bi.fm_t), p.lm_q = int16_t(bi.lm_q), p.lm_t = int16_t(bi.lm_t), p.pad0 = 0;
+				p.L = uint8_t(L), p.W = uint8_t(W), p.minus = minus ? 1 : 0, p.pad1 = 0;
+				uint32_t *pw = reinterpret_cast<uint32_t *>(p.win), *pc = reinterpret_cast<uint32_t *>(p.cols);
+				for (int k = 0; k < W; k += 4) {
+					uint32_t v = 0;
+#pragma unroll
+					for (int u = 0; u < 4; u++) v |= (k + u < W ? uint32_t(win[(k + u) * STRIDE]) : 0u) << (8 * u);
+					pw[k >> 2] = v;
+				}
+				const int nc = bi.k1 - bi.k0;
+				for (int k = 0; k < nc; k += 4) {
+					uint32_t v = 0;
+#pragma unroll
+					for (int u = 0; u < 4; u++) v |= (k + u < nc ? uint32_t(best[(bi.k0 + k + u) * STRIDE]) : 0u) << (8 * u);
+					pc[k >> 2] = v;
+				}
 			}
 		}
-		auto put = [&](char ch) __attribute__((always_inline)) {
-			acc |= uint32_t(uint8_t(ch)) << ((o & 3) * 8);
-			o++;
-			if ((o & 3) == 0) text32[(o >> 2) - 1] = acc, acc = 0;
-		};
-		put('5'), put('\''), put(' ');
-		for (int i = 0; i < prefix; i++) put(base_letter(QUERY(bi.fm_q - prefix + i)));
-		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_q(cols[k * STRIDE])));
-		for (int i = 0; i < suffix; i++) put(base_letter(QUERY(bi.lm_q + 1 + i)));
-		put(' '), put('3'), put('\''), put('\n');
-		put(' '), put(' '), put(' ');
-		for (int i = 0; i < prefix; i++) put(is_complementary(QUERY(bi.fm_q - prefix + i), TARGET(bi.fm_t + prefix - i)) ? ':' : ' ');
-		for (int k = bi.k0; k < bi.k1; k++) {
-			const uint8_t cw = cols[k * STRIDE];
-			put(is_complementary(col_t(cw), col_q(cw)) ? '|' : ' ');
-		}
-		for (int i = 0; i < suffix; i++) put(is_complementary(QUERY(bi.lm_q + 1 + i), TARGET(bi.lm_t - i - 1)) ? ':' : ' ');
-		put('\n');
-		put('3'), put('\''), put(' ');
-		for (int i = prefix; i > 0; i--) put(base_letter(TARGET(bi.fm_t + i)));
-		for (int k = bi.k0; k < bi.k1; k++) put(base_letter(col_t(cols[k * STRIDE])));
-		for (int i = 1; i <= suffix; i++) put(base_letter(TARGET(bi.lm_t - i)));
-		put(' '), put('5'), put('\'');
-		text32[o >> 2] = acc; // the rest and the terminating zero (acc holds zeros above the characters written)
-		if (rec) rec->text_len = o; // (the text's own length also where the field only refers to it: sort_by_bound_match compares it)
-		if (lref != 0xFFFFFFFFu) { // the field: 0x7F L T, offset, length -- no zero byte inside, one behind
-			uint32_t *f32 = reinterpret_cast<uint32_t *>(text);
-			auto hex = [](uint32_t v, int d) __attribute__((always_inline)) { return uint32_t("0123456789abcdef"[(v >> (4 * d)) & 15u]); };
-			const uint32_t len = uint32_t(o);
-			f32[0] = 0x7Fu | (uint32_t('L') << 8) | (uint32_t('T') << 16) | (hex(lref, 7) << 24);
-			f32[1] = hex(lref, 6) | (hex(lref, 5) << 8) | (hex(lref, 4) << 16) | (hex(lref, 3) << 24);
-			f32[2] = hex(lref, 2) | (hex(lref, 1) << 8) | (hex(lref, 0) << 16) | (hex(len, 5) << 24);
-			f32[3] = hex(len, 4) | (hex(len, 3) << 8) | (hex(len, 2) << 16) | (hex(len, 1) << 24);
-			f32[4] = hex(len, 0);
-		}
+	} else {
+		bind_finish<FULL, QRY_LDS, LONG_TEXT, STRIDE>(a, win, qry, c.query, cols, best, bi, best_valid, status, th, tm, best_dH, best_dS, dg, idx, it, L, W, start, stop, minus, gmax, nmax);
 	}
 #ifdef TNT_EXP_STATS
 	{ // wave-level cycle breakdown of the tail (s_memtime ticks / 64, lane 0 of every wave; waves re-converge here)
@@ -958,8 +1036,7 @@ __device__ __forceinline__ bool bind_tail(const BindArgs &a, TRACE &tr, const ui
 			atomicAdd(a.debug + 2, uint32_t(st_trim >> 6));
 			atomicAdd(a.debug + 3, uint32_t(st_eval >> 6));
 			atomicAdd(a.debug + 4, uint32_t((st_thr0 - st_tail0 - st_trace - st_trim - st_eval) >> 6));
-			atomicAdd(a.debug + 5, uint32_t((st_out0 - st_thr0) >> 6));
-			atomicAdd(a.debug + 6, uint32_t((st_end - st_out0) >> 6));
+			atomicAdd(a.debug + 5, uint32_t((st_end - st_thr0) >> 6)); // thresholds + output
 			atomicAdd(a.debug + 7, 1u);
 		}
 	}
@@ -1377,7 +1454,7 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 
 		{
 			SlabTrace<LMAX, BIND_THREADS, PF> tr{trace, s_pf + tid, -1, -1};
-			if (bind_tail<FULL, DINK, QRY_LDS, (LMAX > 64), BIND_THREADS, 8, uint16_t>(a, tr, s_lut, s_hs_map, s_hs_val, s_k, win, qry, cols, best, stack, ties, NCOLS, WMAX + 1, idx, it,
+			if (bind_tail<FULL, DINK, QRY_LDS, (LMAX > 64), BIND_THREADS, 8, uint16_t, SlabTrace<LMAX, BIND_THREADS, PF>, (!FULL && !DINK && LMAX <= 64)>(a, tr, s_lut, s_hs_map, s_hs_val, s_k, win, qry, cols, best, stack, ties, NCOLS, WMAX + 1, idx, it,
 			                                                                           slot, L, W, start, stop, minus, xmode, gmax, nmax, max_ij, Tcur, dk_q
 #ifdef TNT_EXP_STATS
 			                                                                           , st_fill0
@@ -1387,6 +1464,47 @@ __global__ __launch_bounds__(bind_threads_for(LMAX, PLAIN), (bind_threads_for(LM
 		}
 	}
 }
+
+// The windows the throughput instances parked behind the Tm / dG tests (BindArgs::pending), one lane each: anchors, counts,
+// the other thresholds, footprint, bound record, alignment text -- bind_finish, with every lane at work.  One launch per bind
+// phase, whatever the oligo lengths (a record carries its own).  Compiled once, in tnt_host.hip's translation unit.
+constexpr int FIN_THREADS = 256;
+#ifdef TNT_FINISH_KERNEL
+__global__ __launch_bounds__(FIN_THREADS) void bind_finish_kernel(BindArgs a)
+{
+	__shared__ uint8_t s_win[PENDING_WIN * FIN_THREADS];   // [k][thread]: the layout bind_finish reads
+	__shared__ uint8_t s_cols[PENDING_COLS * FIN_THREADS];
+	const int tid = threadIdx.x;
+	uint32_t n = *a.n_pending;
+	n = n < a.pending_cap ? n : a.pending_cap;
+	for (uint32_t base = blockIdx.x * FIN_THREADS; base < n; base += gridDim.x * FIN_THREADS) {
+		const uint32_t i = base + uint32_t(tid);
+		if (i >= n) continue; // (no barrier below: every lane works on slices of its own)
+		const PendingRec &p = a.pending[i];
+		const int L = p.L, W = p.W, nc = p.n_cols;
+		const uint32_t *pw = reinterpret_cast<const uint32_t *>(p.win), *pc = reinterpret_cast<const uint32_t *>(p.cols);
+		for (int k = 0; k < W; k += 4) {
+			const uint32_t v = pw[k >> 2];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (k + u < PENDING_WIN) s_win[(k + u) * FIN_THREADS + tid] = uint8_t(v >> (8 * u));
+		}
+		for (int k = 0; k < nc; k += 4) {
+			const uint32_t v = pc[k >> 2];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (k + u < PENDING_COLS) s_cols[(k + u) * FIN_THREADS + tid] = uint8_t(v >> (8 * u));
+		}
+		const Slot slot = a.slots[p.slot];
+		const Thresh th = a.thresh[slot.thresh];
+		Item it = Item{0, 0, p.slot << ITEM_SLOT_SHIFT, p.group};
+		const AlignInfo bi = {0, nc, p.fm_q, p.fm_t, p.lm_q, p.lm_t};
+		const float dg = p.dH - a.tab->temperature * p.dS; // delta_G(), nuc_cruc.h:1217
+		bind_finish<false, false, false, FIN_THREADS>(a, s_win + tid, nullptr, a.olig_base + size_t(slot.oligo) * MAX_OLIGO, s_cols + tid, s_cols + tid, bi, true, 0, th, p.tm, p.dH,
+		                                              p.dS, dg, p.idx, it, L, W, p.start, p.stop, p.minus != 0, 0, 0);
+	}
+}
+#endif
 
 // host-side launchers of the throughput instances, defined in tnt_bind_inst.hip
 #define X(N) void launch_bind_##N(const BindArgs &a, int blocks, hipStream_t stream);

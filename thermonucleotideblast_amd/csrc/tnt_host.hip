@@ -30,6 +30,7 @@
 #include "tnt_arena.h"
 #include "tnt_seed.hip.h"
 #include "tnt_seed2.hip.h"
+#define TNT_FINISH_KERNEL
 #include "tnt_bind.hip.h"
 #include "tnt_filter.hip.h"
 #define TNT_REGROUP_KERNELS
@@ -592,6 +593,7 @@ struct tnt_ctx {
 	// Round 5: the phase-A queue of a plain length bucket is regrouped by (oligo, threshold class) in front of its pre-filter
 	// (tnt_ufilter.hip.h): slot -> rank of its (oligo, class) inside its bucket, the buckets' shares of the histogram / cursor
 	// arrays and of the regrouped queue (every run is padded to whole blocks: 64 slots per bin on top of the bucket's region)
+	bool defer_finish = false; // the throughput bind instances park the windows that pass Tm / dG for bind_finish_kernel (tnt_bind.hip.h)
 	bool regroup = false;
 	DevBuf<uint32_t> slot_bin;       // [slot][2]: inside its plain bucket, inside its general bucket
 	std::vector<uint32_t> h_slot_bin, rg_bins, rg_bin_base; // [slot][2]; [bucket] bins, first bin
@@ -633,6 +635,7 @@ struct tnt_ctx {
 		DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
 		DevBuf<uint32_t> item_rep;
 		DevBuf<BoundRec> pool;
+		DevBuf<PendingRec> pending; // windows behind the Tm / dG tests, waiting for bind_finish_kernel
 		DevBuf<uint32_t> counters;       // per-batch counters; the search-wide ones (hits, error word, totals) live in set 0's
 		DevBuf<uint32_t> region_counts;  // [2 * MAX_REGIONS] items, groups of every region
 		DevBuf<uint32_t> q_state;        // [MAX_REGIONS][MAX_BUCKETS][2]
@@ -726,7 +729,7 @@ struct tnt_ctx {
 
 namespace {
 
-enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_FILTERED /* windows rejected by the pre-filter (whole search) */, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS, C_PAIRABLE /* groups handed to the pair kernels */,
+enum { C_POOL = 0, C_ACTIVE, C_QB, C_BIG /* groups of more than PAIR_MAX items */, C_HITS, C_ERR, C_DUPS /* phase-A items bound through a representative */, C_FILTERED /* windows rejected by the pre-filter (whole search) */, C_TOT_ITEMS_LO, C_TOT_ITEMS_HI, C_TOT_GROUPS_LO, C_TOT_GROUPS_HI, C_TOT_BINDS_LO, C_TOT_BINDS_HI, C_TOT_BOUND, C_SEEDS, C_PAIRABLE /* groups handed to the pair kernels */, C_PENDING /* windows parked for bind_finish_kernel (per bind phase) */,
        C_TOT_CELLS_LO = 18, C_TOT_CELLS_HI /* DP cells of the windows handed to the bind stage, sum of L x W (whole search, 64 bits) */,
        // sharded counters of the seed kernel (N_SHARD * SHARD_STRIDE words each)
        C_ITEMS = 32, C_QA = C_ITEMS + N_SHARD * SHARD_STRIDE, C_GROUPS = C_QA + N_SHARD * SHARD_STRIDE,
@@ -1025,6 +1028,13 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		hipLaunchKernelGGL(bucket_kernel<false>, dim3(1024), dim3(256), 0, c->stream, k);
 		hipLaunchKernelGGL(bucket_kernel<true>, dim3(1024), dim3(256), 0, c->stream, k);
 	}
+	const bool deferred = c->defer_finish && c->S().pending.p;
+	if (deferred) {
+		(void)hipMemsetAsync(cnt + C_PENDING, 0, sizeof(uint32_t), c->stream);
+		b.pending = c->S().pending.p, b.pending_cap = uint32_t(c->S().pending.n), b.n_pending = cnt + C_PENDING;
+	} else {
+		b.pending = nullptr, b.pending_cap = 0, b.n_pending = nullptr;
+	}
 	const bool regrouped = direct && c->regroup && c->filter_on && !c->h_rg_desc.empty() && c->S().qsort.p;
 	if (regrouped) // the phase-A queues of the batch, windows of one oligo side by side (tnt_ufilter.hip.h)
 		launch_regroup(c, c->rg_desc.p, uint32_t(c->h_rg_desc.size()), c->S().qfat.p, c->S().qsort.p, cnt + C_BUCKET, c->slot_bin.p, c->S().rg_hist.p, c->S().rg_cursor.p, c->stream, c->rg_seed_counts);
@@ -1118,6 +1128,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		(void)hipEventRecord(c->lane_done[l], c->lane_stream[l]);
 		(void)hipStreamWaitEvent(c->stream, c->lane_done[l], 0);
 	}
+	if (deferred) hipLaunchKernelGGL(bind_finish_kernel, dim3(c->n_cu * 4), dim3(FIN_THREADS), 0, c->stream, b); // what the instances parked: records and texts
 }
 
 int ensure_scratch(tnt_ctx *c, int need_lmax)
@@ -1175,6 +1186,7 @@ int alloc_set(tnt_ctx *c, int k)
 	if (c->filter_audit) HIP_TRY(W.audit.alloc(c->item_cap), c->err);
 	if (c->dedupe) HIP_TRY(W.item_rep.alloc(c->item_cap), c->err);
 	HIP_TRY(W.pool.alloc(POOL_CAP), c->err);
+	if (c->defer_finish) HIP_TRY(W.pending.alloc(POOL_CAP), c->err);
 	HIP_TRY(W.counters.alloc(C_COUNT), c->err);
 	HIP_TRY(W.region_counts.alloc(2 * tnt_ctx::MAX_REGIONS), c->err);
 	HIP_TRY(W.q_state.alloc(size_t(tnt_ctx::MAX_REGIONS) * MAX_BUCKETS * 2), c->err);
@@ -1714,6 +1726,10 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 		c->rg_total_bins = 0;
 		for (size_t b = 0; b < c->bucket_lmax.size(); b++) c->rg_bin_base[b] = c->rg_total_bins, c->rg_total_bins += c->rg_bins[b];
 		c->regroup = c->filter_on && !opt->use_dinkelbach && !getenv("TNT_MI355X_NO_REGROUP");
+		// built and measured in round 5: bind stage 8.74 ms with it against 8.72 without on config 2, 532 against 543 ms on config 5 --
+		// what the bind kernels lose in lane-starved tail code the extra launch per phase (which the next phase waits for) takes
+		// back.  Opt-in (TNT_MI355X_DEFER=1), like the other measured-and-dropped variants.
+		c->defer_finish = !opt->use_dinkelbach && getenv("TNT_MI355X_DEFER") != nullptr;
 		if ((e = c->slot_bin.upload(c->h_slot_bin)) != hipSuccess || (e = c->rg_bin_base_dev.upload(c->rg_bin_base)) != hipSuccess) FAIL(TNT_E_DEVICE, std::string("table upload: ") + hipGetErrorString(e));
 		c->rg_seed_counts = c->regroup && c->rg_total_bins > 0 && c->rg_total_bins <= uint32_t(S2_BINS) && !getenv("TNT_MI355X_REGROUP_COUNT_PASS");
 	}
