@@ -970,13 +970,13 @@ void launch_ufilter(const UFilterArgs &a, int blocks, int rows, hipStream_t stre
 
 // The regrouping of a batch's phase-A queues by (oligo, threshold class): count, scan, scatter, each ONE launch over all the
 // buckets of `desc` (device array of n_desc descriptors).
-void launch_regroup(tnt_ctx *c, const RegroupBucket *desc, uint32_t n_desc, const uint4 *src, uint4 *dst, const uint32_t *packed, uint32_t *counters, const uint32_t *slot_bin,
+void launch_regroup(tnt_ctx *c, const RegroupBucket *desc, uint32_t n_desc, const uint4 *src, uint4 *dst, uint32_t *counters, const uint32_t *slot_bin,
                     uint32_t *hist, uint32_t *cursor, hipStream_t stream, bool counted = false /* the histogram is filled already (by the seed kernel) */)
 {
 	RegroupArgs r;
 	memset(&r, 0, sizeof(r));
 	r.buckets = desc, r.n_buckets = n_desc;
-	r.src = src, r.dst = dst, r.packed = packed, r.counters = counters;
+	r.src = src, r.dst = dst, r.counters = counters;
 	r.slot_bin = slot_bin, r.hist = hist, r.cursor = cursor;
 	if (!counted) hipLaunchKernelGGL(regroup_count_kernel, dim3(c->n_cu * 8), dim3(RG_THREADS), 0, stream, r);
 	hipLaunchKernelGGL(regroup_scan_kernel, dim3(n_desc), dim3(1024), 0, stream, r);
@@ -1037,7 +1037,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 	}
 	const bool regrouped = direct && c->regroup && c->filter_on && !c->h_rg_desc.empty() && c->S().qsort.p;
 	if (regrouped) // the phase-A queues of the batch, windows of one oligo side by side (tnt_ufilter.hip.h)
-		launch_regroup(c, c->rg_desc.p, uint32_t(c->h_rg_desc.size()), c->S().qfat.p, c->S().qsort.p, v.packed, cnt + C_BUCKET, c->slot_bin.p, c->S().rg_hist.p, c->S().rg_cursor.p, c->stream, c->rg_seed_counts);
+		launch_regroup(c, c->rg_desc.p, uint32_t(c->h_rg_desc.size()), c->S().qfat.p, c->S().qsort.p, cnt + C_BUCKET, c->slot_bin.p, c->S().rg_hist.p, c->S().rg_cursor.p, c->stream, c->rg_seed_counts);
 	(void)hipEventRecord(c->phase_ready, c->stream);
 	for (int l = 0; l < c->lanes; l++) (void)hipStreamWaitEvent(c->lane_stream[l], c->phase_ready, 0);
 	int n_launch = 0;
@@ -1096,7 +1096,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 				memset(&u, 0, sizeof(u));
 				u.tab = f.tab, u.packed = v.packed, u.olig_q4 = f.olig_q4, u.olig_len = f.olig_len, u.slots = f.slots;
 				u.db = v, u.items = f.items;
-				u.fat = c->S().qsort.p + size_t(B.dst_base) * UF_ENTRY;
+				u.fat = c->S().qsort.p + B.dst_base;
 				u.n_items_dev = cnt + C_BUCKET + B.counter + 4;
 				u.n_items = B.src_cap + uint32_t(UF_BLOCK) * B.n_bins;
 				u.next_block = cnt + C_BUCKET + B.counter + 5;
@@ -1179,7 +1179,7 @@ int alloc_set(tnt_ctx *c, int k)
 	if (c->filter_on) HIP_TRY(W.qsurv.alloc(c->item_cap), c->err);
 	if (c->seed2) HIP_TRY(W.qfat.alloc(c->item_cap), c->err);
 	if (c->seed2 && c->regroup) {
-		HIP_TRY(W.qsort.alloc((c->item_cap + size_t(UF_BLOCK) * c->rg_total_bins) * UF_ENTRY), c->err); // (entries of UF_ENTRY uint4: the window's packed words travel with them)
+		HIP_TRY(W.qsort.alloc(c->item_cap + size_t(UF_BLOCK) * c->rg_total_bins), c->err);
 		HIP_TRY(W.rg_hist.alloc(std::max<size_t>(1, c->rg_total_bins)), c->err);
 		HIP_TRY(W.rg_cursor.alloc(std::max<size_t>(1, c->rg_total_bins)), c->err);
 	}
@@ -3951,7 +3951,7 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 				DevBuf<uint4> &dfat = keep_fat[keep_fat.size() - 2], &dsorted = keep_fat.back();
 				DevBuf<uint32_t> &dbin = keep_words[keep_words.size() - 2], &dwork = keep_words.back();
 				HIP_TRY(dfat.upload(fat), ctx->err);
-				HIP_TRY(dsorted.alloc((fat.size() + size_t(UF_BLOCK) * n_bins) * UF_ENTRY), ctx->err);
+				HIP_TRY(dsorted.alloc(fat.size() + size_t(UF_BLOCK) * n_bins), ctx->err);
 				HIP_TRY(dbin.upload(slot_bin), ctx->err);
 				std::vector<uint32_t> work(8 + 2 * size_t(n_bins), 0u); // a counter line ([0] entries, [4] regrouped entries, [5] work counter); histogram; cursors
 				work[0] = uint32_t(fat.size());
@@ -3960,7 +3960,7 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 				memset(&B, 0, sizeof(B));
 				B.src_cap = uint32_t(fat.size()), B.n_bins = n_bins, B.general = degen ? 1u : 0u;
 				HIP_TRY(keep_desc.back().upload(std::vector<RegroupBucket>(1, B)), ctx->err);
-				launch_regroup(ctx, keep_desc.back().p, 1, dfat.p, dsorted.p, f.db.packed, dwork.p, dbin.p, dwork.p + 8, dwork.p + 8 + n_bins, ctx->stream);
+				launch_regroup(ctx, keep_desc.back().p, 1, dfat.p, dsorted.p, dwork.p, dbin.p, dwork.p + 8, dwork.p + 8 + n_bins, ctx->stream);
 				UFilterArgs u;
 				memset(&u, 0, sizeof(u));
 				u.tab = f.tab, u.packed = f.db.packed, u.olig_q4 = f.olig_q4, u.olig_len = f.olig_len, u.slots = f.slots;

@@ -16,11 +16,6 @@
 //    ds_read_b64, and lanes with different k fall on different bank pairs (S / 2 odd), lanes with the same k broadcast.
 //  * The window is put in column order once per window (minus-strand lanes: reversed and complemented), so the target
 //    base of column j is a bit field at a wave-uniform position.
-//  * With the windows of one oligo side by side, neighbours in the queue no longer share a target: a lane's read of its
-//    window's packed words would be a 64-byte sector of its own (3.3 GB of fetches per step of config 2).  The regrouping's
-//    scatter pass, which still walks the queue in target order, reads those words -- neighbours share their lines there --
-//    and stores them behind the entry: a regrouped entry is 32 bytes, {entry, the window's first four packed words}, enough for
-//    windows of up to 48 bases (instances of up to 40 rows; longer ones read the packed targets as before).
 //
 // The result per window -- bound, threshold, pass / reject -- is the old kernel's, integer by integer
 // (tests/test_gpu_parity.py::test_filter_kernel_equals_its_checker runs both against the oracle-side checker); windows
@@ -39,8 +34,6 @@ constexpr int RG_THREADS = 256;
 constexpr int RG_TILE = 8 * RG_THREADS;     // entries a workgroup of the scatter pass ranks at a time
 constexpr uint32_t UF_BLOCK = 64;           // windows of one (oligo, class) a wavefront takes at a time
 constexpr uint32_t UF_CHUNK = 8;            // blocks a wavefront grabs per atomic
-constexpr uint32_t UF_ENTRY = 2;            // uint4 per regrouped entry: the seed kernel's 16 bytes + the window's first four packed words
-constexpr int UF_WORDS_ROWS = 40;           // instances of up to this many rows find their window in the entry (NW + 1 <= 4 words)
 
 // target dinucleotides of a plain window: k = x' * FILT_X + x with x', x in A C G T NONE
 constexpr int UF_K = FILT_NONE * FILT_X + FILT_NONE + 1;
@@ -57,7 +50,7 @@ constexpr int uf_stride(int lmax)
 // instead of three per bucket, each of which had a start-up and a tail of its own)
 struct RegroupBucket {
 	uint32_t src_base, src_cap;  // the bucket's region of the phase-A queue as the seed kernel filled it (blocks with holes)
-	uint32_t dst_base;           // ... of the regrouped queue, in entries (of UF_ENTRY uint4 each): src_cap + UF_BLOCK * n_bins slots
+	uint32_t dst_base;           // ... of the regrouped queue: src_cap + UF_BLOCK * n_bins slots
 	uint32_t bin_base, n_bins;   // its share of the histogram / cursor arrays
 	uint32_t general;            // 1: a general bucket (windows with a degenerate target base): bins by Slot::bucket_general
 	uint32_t counter;            // word offset of its counter line: [0] slots handed out, [4] out: regrouped entries, [5] work counter of its filter launch
@@ -68,8 +61,7 @@ struct RegroupArgs {
 	const RegroupBucket *buckets;
 	uint32_t n_buckets;
 	const uint4 *src;            // phase-A queue buffer
-	uint4 *dst;                  // regrouped queue buffer (UF_ENTRY uint4 per entry)
-	const uint32_t *packed;      // DbView::packed: the scatter pass copies every window's first four words behind its entry
+	uint4 *dst;                  // regrouped queue buffer
 	uint32_t *counters;          // bucket counter lines of the batch
 	const uint32_t *slot_bin;    // [slot][2] rank of the slot's (oligo, threshold class) inside its plain / its general bucket
 	uint32_t *hist;              // [bins of all buckets] entries per bin (zeroed per batch)
@@ -135,7 +127,7 @@ __global__ __launch_bounds__(1024) void regroup_scan_kernel(RegroupArgs a)
 	__shared__ uint32_t s_part[1024];
 	__shared__ uint32_t s_carry;
 	const RegroupBucket B = a.buckets[blockIdx.x];
-	uint4 *dst = a.dst + size_t(B.dst_base) * UF_ENTRY;
+	uint4 *dst = a.dst + B.dst_base;
 	if (threadIdx.x == 0) s_carry = 0;
 	__syncthreads();
 	for (uint32_t b0 = 0; b0 < B.n_bins; b0 += 1024) {
@@ -153,7 +145,7 @@ __global__ __launch_bounds__(1024) void regroup_scan_kernel(RegroupArgs a)
 		const uint32_t start = s_carry + s_part[threadIdx.x] - padded;
 		if (b < B.n_bins) {
 			a.cursor[B.bin_base + b] = start;
-			for (uint32_t x = cnt; x < padded; x++) dst[size_t(start + x) * UF_ENTRY] = make_uint4(RG_HOLE, 0, 0, 0);
+			for (uint32_t x = cnt; x < padded; x++) dst[start + x] = make_uint4(RG_HOLE, 0, 0, 0);
 		}
 		__syncthreads();
 		if (threadIdx.x == 1023) s_carry += s_part[1023];
@@ -178,7 +170,7 @@ __global__ __launch_bounds__(RG_THREADS) void regroup_scatter_kernel(RegroupArgs
 		const RegroupBucket B = a.buckets[b];
 		const uint32_t t0 = (c - s_map.first[b]) * RG_TILE, n = s_map.n[b];
 		const uint4 *src = a.src + B.src_base;
-		uint4 *dst = a.dst + size_t(B.dst_base) * UF_ENTRY;
+		uint4 *dst = a.dst + B.dst_base;
 		constexpr int PER = RG_TILE / RG_THREADS;
 		uint4 e[PER];
 		uint32_t br[PER]; // bin | rank << 12
@@ -203,13 +195,7 @@ __global__ __launch_bounds__(RG_THREADS) void regroup_scatter_kernel(RegroupArgs
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < PER; r++)
-			if (br[r] != ~0u) {
-				// (the tile's entries lie in target order: the windows of one target read the same few lines)
-				const uint32_t *pk = a.packed + e[r].y;
-				uint4 *to = dst + size_t(s_base[br[r] & 4095u] + (br[r] >> 12)) * UF_ENTRY;
-				to[0] = e[r];
-				to[1] = make_uint4(pk[0], pk[1], pk[2], pk[3]); // (rows are padded and the array has sixteen words of slack behind its end)
-			}
+			if (br[r] != ~0u) dst[s_base[br[r] & 4095u] + (br[r] >> 12)] = e[r];
 		__syncthreads();
 	}
 }
@@ -222,7 +208,7 @@ struct UFilterArgs {
 	const uint32_t *olig_q4;      // [n][MAX_OLIGO / 4] reversed oligo, one byte per row = 4 * base code
 	const int32_t *olig_len;
 	const Slot *slots;
-	const uint4 *fat;             // the regrouped queue (UF_ENTRY uint4 per entry): blocks of UF_BLOCK entries of one (oligo, class), holes behind a run's last entry
+	const uint4 *fat;             // the regrouped queue: blocks of UF_BLOCK entries of one (oligo, class), holes behind a run's last entry
 	const uint32_t *n_items_dev;  // its length
 	uint32_t n_items;             // ... capped at the region
 	uint32_t *next_block;         // work counter of the launch (zeroed per batch)
@@ -275,8 +261,7 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void ufilter_k
 		if (c0 >= n_blocks) break;
 		const uint32_t c1 = c0 + UF_CHUNK < n_blocks ? c0 + UF_CHUNK : n_blocks;
 		for (uint32_t blk = c0; blk < c1; blk++) {
-			const uint4 *ent = a.fat + size_t(blk * UF_BLOCK + uint32_t(lane)) * UF_ENTRY;
-			const uint4 fe = ent[0];
+			const uint4 fe = a.fat[blk * UF_BLOCK + uint32_t(lane)];
 			const uint32_t idx = fe.x;
 			const bool active = idx != RG_HOLE;
 			const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
@@ -313,18 +298,10 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void ufilter_k
 			uint32_t om[DEGEN ? NW : 1]; // DEGEN: bit 2 (j - 1) set: column j holds an IUPAC code or an inosine
 			bool unfilterable = false;
 			{
+				const uint32_t *pk = a.packed + fe.y;
 				uint32_t raw[NW + 1];
-				if (LMAX <= UF_WORDS_ROWS) { // the window's words travel with the entry
-					static_assert(LMAX > UF_WORDS_ROWS || NW + 1 <= 4, "four words behind the entry");
-					const uint4 w4 = ent[1];
-					const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-					for (int k = 0; k <= NW; k++) raw[k] = active ? w[k < 4 ? k : 3] : 0u;
-				} else {
-					const uint32_t *pk = a.packed + fe.y;
-#pragma unroll
-					for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u; // (rows are padded and the array has sixteen words of slack behind its end)
-				}
+				for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u; // (rows are padded and the array has sixteen words of slack behind its end)
 				const uint32_t sh = (fe.z & 15u) * 2u;
 #pragma unroll
 				for (int k = 0; k < NW; k++) ov[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
