@@ -322,6 +322,12 @@ int tnt_bind_batch_routed(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, siz
  * with inosine or a skipped code gives INT32_MAX / INT32_MIN (never rejected); oligos beyond 64 bases have no filter
  * instance: -1 / -1.  bind_oligo_to_*_strand rejects what stays below on Tm (bind_oligo.cpp:600-606).           */
 int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, int32_t *score);
+/* The pre-filter's SECOND tier for the same requests (ABI v6; tnt_sbound.hip.h): a trace-free fill of align_dimer's recurrence
+ * (nuc_cruc.cpp:492-696) whose states carry, next to the score, the credit the first tier's argument grants the path: score[2 i]
+ * = the credit of the maximal-score paths in 1e-3 kcal/mol (INT32_MAX: above 20.48 kcal/mol, or a window this tier does not
+ * serve -- IUPAC codes in the window, oligos beyond 40 bases), score[2 i + 1] = the first tier's threshold (INT32_MIN: not
+ * served / class never rejected).  A window is rejected iff score[2 i] < score[2 i + 1]. */
+int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, int32_t *score);
 
 /* Oligo self-structure printed with every hit (tntblast_local.cpp:656-686): hairpin and homodimer Tm of oligo
  * `a` at strand(ct_a, ct_a), and, when `b` is given, the heterodimer Tm of query a / target b at

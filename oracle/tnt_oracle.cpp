@@ -394,6 +394,7 @@ private:
 	std::vector<Cell> dp;
 	int stride = 0;
 
+public: // (the fill and its score table are read by the restatement of the pre-filter's DP-score tier, tntor_filter_bound)
 	int g(int prev, int curp) const { return dg[prev * NBP + curp]; }
 
 	// nuc_cruc.cpp:492-696
@@ -473,6 +474,7 @@ private:
 		}
 	}
 
+private:
 	// nuc_cruc.cpp:1409-1618
 	void trace_back(int cell, std::deque<Branch> &stack, int &zero_count, Alignment &al)
 	{
@@ -1584,7 +1586,7 @@ const char *tntor_last_error(void) { return g_err.c_str(); }
 // library computes for contexts it accepts, where the two agree (same strand concentration and thresholds for every use).
 void tntor_set_bind_cache(int on) { g_bind_cache = on != 0; }
 static int g_filter_tier = 1; // tntor_set_filter_tier: which bound tntor_filter_bound restates (1: the pre-filter's automaton, 2: the second tier's)
-void tntor_set_filter_tier(int tier) { g_filter_tier = tier == 2 ? 2 : 1; }
+void tntor_set_filter_tier(int tier) { g_filter_tier = (tier == 2 || tier == 3 || tier == 30) ? tier : 1; }
 
 int tntor_tables(const tnt_options *opt, int32_t *delta_g, float *param_H, float *param_S, float *loop_S, float *bulge_S,
                  float *hairpin_S, float *scalars)
@@ -1795,6 +1797,7 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		float tk, theta0, ct_scale;
 		std::vector<int> fpos, close; // [prev pair * 49 + cur pair] in evaluate order
 		std::vector<int> fcur, fprev; // second tier: the stack as it is (no clamp at zero) where the CURRENT / the PREVIOUS column is Watson-Crick, else "not possible"
+		std::vector<int> b_step, b_gap; // tier 3 (units of 1e-4 kcal/mol, rounded up): the credit of a diagonal step / of the aligned column at either end of a gap run
 	} cls[2];
 	const double min_tm[2] = {double(opt->min_primer_tm), double(opt->min_probe_tm)};
 	const double max_dg[2] = {double(opt->max_primer_dg), double(opt->max_probe_dg)};
@@ -1812,6 +1815,8 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 		C.close.assign(NBP * NBP, NEG);
 		C.fcur.assign(NBP * NBP, NEG);
 		C.fprev.assign(NBP * NBP, NEG);
+		C.b_step.assign(NBP * NBP, 0);
+		C.b_gap.assign(NBP * NBP, 0);
 		if (!C.on) continue;
 		const double sc = double(P.salt) * log_na;
 		auto phi = [&](int prev, int cur) { return -(double(P.H[prev * NBP + cur]) - Tk * (double(P.S[prev * NBP + cur]) + sc)); };
@@ -1830,6 +1835,14 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 				C.fpos[prev * NBP + cur] = units((P.wc[prev] || P.wc[cur]) ? std::max(f, 0.0) : 0.0);
 				if (P.wc[cur]) C.fcur[prev * NBP + cur] = units(f);
 				if (P.wc[prev]) C.fprev[prev * NBP + cur] = units(f);
+				C.b_step[prev * NBP + cur] = int(std::ceil(((P.wc[prev] || P.wc[cur]) ? std::max(f, 0.0) : 0.0) * 1.0e4));
+				{ // an aligned column next to a gap run: its terminal stack (with the diagonally adjacent cell), or the stack across a single-base bulge
+					double best = (P.wc[prev] || P.wc[cur]) ? std::max(f, 0.0) : 0.0;
+					if (P.wc[cur] || P.wc[prev])
+						for (int pm = 0; pm < NBP; pm++)
+							if (P.wc[pm] && pm / NB <= I && pm % NB <= I) best = std::max(best, std::max(phi(pm, cur), phi(prev, pm)) - pb1);
+					C.b_gap[prev * NBP + cur] = int(std::ceil(best * 1.0e4));
+				}
 				if (!P.wc[cur]) continue; // a loop / bulge closes on a Watson-Crick column
 				double u1 = -1.0e30;
 				for (int pm = 0; pm < NBP; pm++)
@@ -1909,6 +1922,95 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 				for (int y = (tc == ANY ? int(A) : tc); y <= (tc == ANY ? int(I) : tc); y++) m = std::max(m, tab[(qp * NB + x) * NBP + qc * NB + y]);
 			return m;
 		};
+		if (g_filter_tier == 3 || g_filter_tier == 30) {
+			// Tier 3 (tnt_sbound.hip.h): NucCruc scores the MAXIMAL-SCORE paths of align_dimer (nuc_cruc.cpp:492-696, :2533-2537,
+			// :1409-1618).  credit(A) = what the first tier's argument grants an alignment along its own path (non-negative: a
+			// diagonal step's stack when one of its columns is Watson-Crick; at an aligned column next to a gap run the stack with its
+			// diagonally adjacent cell, or the stack across a single-base bulge).  One integer per DP state, V = score << 11 | credit
+			// (score exact, credit in units of 0.02 kcal/mol rounded up): the fill's own recurrence over these picks the higher score
+			// and, among equal scores, the higher credit.  The credit of the window's maximal V bounds Phi - const of whatever
+			// NucCruc scores.  Bit 10 of the credit field is a guard: set in any state, the window passes.  Plain windows, oligos of
+			// up to 40 bases; the restatement runs the kernel's table-driven loops.
+			bool plain = true;
+			for (int b = 0; b < W; b++) plain = plain && tg[b] != ANY;
+			int credit3 = INT32_MAX; // (not served by this tier: passes)
+			if (plain && C.on && L <= 40 && W >= 1) {
+				Melt m(opt->target_t, opt->salt, false, false);
+				m.set_query(q);
+				m.target.clear();
+				for (int b = W - 1; b >= 0; b--) m.target.push_back(Base(tg[b])); // (tg was reversed into pairing order above)
+				const int K = 1 << 11, NEG3 = -(1 << 30);
+				auto cl = [&](long long v) { return int(std::max<long long>(v, NEG3)); };
+				auto up50 = [&](double kcal) { return int(std::ceil(kcal * 50.0)); };
+				auto dgv = [&](int prev, int cur) { return m.g(prev, cur); };
+				auto term = [&](int c) { // Tables::term (tnt_host.hip fill_tables): g((x,GAP), c) for real pairs, FORB_XY for (GAP, x)
+					if (c / NB == GAP) return dgv(GAP * NB + A, A * NB + GAP);
+					return dgv(A * NB + GAP, c);
+				};
+				const int GG = GAP * NB + GAP;
+				const int c_bulge = dgv(A * NB + GAP, A * NB + GAP) * K, c_zero = dgv(GG, A * NB + GAP) * K;
+				const int c_forb_m = cl(-(long long)dgv(GG, A * NB + A) * K), c_forb_xy = cl(-(long long)dgv(GAP * NB + A, A * NB + GAP) * K);
+				// credits in the tables' convention: pair = query base * 7 + target base, phi(first = the later cell, second = its diagonal predecessor)
+				const double sc = double(P.salt) * log_na, Tk3 = double(C.tk), pb1 = -Tk3 * double(P.bulge_S[1]);
+				auto phi = [&](int prev, int cur) { return -(double(P.H[prev * NBP + cur]) - Tk3 * (double(P.S[prev * NBP + cur]) + sc)); };
+				auto b_step = [&](int first, int second) { return (P.wc[first] || P.wc[second]) ? std::max(phi(first, second), 0.0) : 0.0; };
+				auto b_gap = [&](int first, int second) {
+					double best = b_step(first, second);
+					if (P.wc[first] || P.wc[second])
+						for (int pm = 0; pm < NBP; pm++)
+							if (P.wc[pm] && pm / NB <= I && pm % NB <= I) best = std::max(best, std::max(phi(pm, second), phi(first, pm)) - pb1);
+					return best;
+				};
+				// plane values for (x', x, q', q): x', x in A C G T none(4); q', q base codes 0..6
+				auto planes = [&](int xp5, int x5, int qp, int qq, int out[4]) {
+					const int xpB = xp5 == 4 ? int(GAP) : xp5, xB = x5 == 4 ? int(GAP) : x5;
+					const bool v1 = qq <= I && x5 < 4, v2 = qp <= I && xp5 < 4;
+					const int first = qq * NB + x5, second = qp * NB + xp5;
+					const int cpair = xB * NB + qq, ppair = xpB * NB + qp;
+					const int cs = (v1 && v2) ? up50(b_step(first, second)) : 0;
+					const int cg = (v1 && v2) ? up50(b_gap(first, second)) : (v1 ? up50(b_gap(first, first)) : 0);
+					const int cc = v2 ? ((v1) ? up50(b_gap(first, second)) : up50(b_gap(second, second))) : 0;
+					out[0] = x5 == 4 ? NEG3 : cl(-(long long)dgv(ppair, cpair) * K + cs);
+					out[1] = x5 == 4 ? NEG3 : cl(-(long long)term(cpair) * K + cg);
+					out[2] = xp5 == 4 ? c_forb_m : out[1];
+					out[3] = cl(-(long long)term(xpB * NB + qp) * K + cc);
+				};
+				std::vector<int> oM(L, 0), oQ(L, 0), oT(L, 0), qrow(L + 2, int(GAP));
+				for (int i = 1; i <= L; i++) qrow[i] = int(m.query[L - i]); // row i = query[L - i]; row 0 and row L + 1: none
+				int vmax = 0, sticky = 0;
+				auto tbase = [&](int j) { return (j >= 1 && j <= W) ? int(m.target[j - 1]) : 4; };
+				for (int j = 1; j <= W; j++) {
+					const int tp = tbase(j - 1), t = tbase(j), tn = tbase(j + 1);
+					const bool firstcol = j == 1;
+					const int v5 = firstcol ? c_zero : c_bulge;
+					int dM = 0, dQ = 0, dT = 0, uM = 0, uT = 0;
+					for (int i = 1; i <= L; i++) {
+						int pa[4], pn[4], p4[4];
+						planes(tp, t, qrow[i - 1], qrow[i], pa);
+						planes(tp, t, qrow[i], qrow[i + 1], pn); // the next row's constant
+						planes(t, tn, qrow[i - 1], qrow[i], p4);
+						const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
+						const int d1 = dM + pa[0], d2 = dQ + pa[2], d3 = dT + (i == 1 ? c_forb_m : pa[1]);
+						const int M = std::max(d1, std::max(d2, d3));
+						const int Iq = std::max(cM + pn[3], cQ - v5);
+						const int It = std::max(uM + (i == 1 ? c_forb_xy : p4[3]), uT - (i == 1 ? c_zero : c_bulge));
+						const int Mz = std::max(M, 0), Iqz = std::max(Iq, 0), Itz = std::max(It, 0);
+						vmax = std::max(vmax, Mz);
+						sticky |= Mz | Iqz | Itz;
+						dM = cM, dQ = cQ, dT = cT;
+						uM = Mz, uT = Itz;
+						oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
+					}
+				}
+				credit3 = (sticky & (1 << 10)) ? INT32_MAX : (vmax & (K - 1)) * 20;
+				if (getenv("TNTOR_TIER3_CHECK_SCORE")) { // development check: the fill's maximal score (positive maxima only)
+					m.align_dimer();
+					if (!(sticky & (1 << 10)) && std::max(m.max_score, 0) != (vmax >> 11)) fprintf(stderr, "tier 3: score %d vs fill %d\n", vmax >> 11, m.max_score);
+				}
+			}
+			// (the first tier's bound follows; the smaller of the two stands)
+			score[2 * k] = credit3;
+		}
 		if (g_filter_tier == 2) {
 			// Second tier: the same decomposition of an alignment at its Watson-Crick columns, but a terminal
 			// stack is charged as it is -- the first tier drops every unfavourable stack on a diagonal, which makes mismatches
@@ -1952,6 +2054,8 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 				LP[at(a, b)] = lp;
 				best = std::max(best, x);
 			}
+		if (g_filter_tier == 3) best = std::min(best, score[2 * k]);
+		if (g_filter_tier == 30) best = score[2 * k]; // (the tier's own figure: what the kernel's unit-level entry reports)
 		score[2 * k] = std::min(best, SAT);
 		if (C.on) {
 			const float log_ct = logf((r.ct - 0.5f * 0.0f) * 1.0f);

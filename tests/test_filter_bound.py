@@ -134,6 +134,18 @@ def test_filter_never_rejects_an_accepted_window(oracle, k):
     assert res["rejected_by_filter"] > 0  # the filter does something
 
 
+@pytest.mark.parametrize("k", range(len(OPTION_SETS)))
+def test_second_tier_never_rejects_an_accepted_window(oracle, k):
+    """The pre-filter's second tier (tnt_sbound.hip.h; restated in tntor_filter_bound under tier 3 = the smaller of both tiers'
+    bounds): the credit of align_dimer's maximal-score paths is an upper bound of Phi - const of the alignment NucCruc scores,
+    for every window that has one -- and it rejects more than the first tier does."""
+    n = int(os.environ.get("TNT_FILTER_PROPERTY_N", "40000")) // 2
+    name, kw = OPTION_SETS[k]
+    one = check_option_set(oracle, name, kw, n, 400 + k, tier=1)
+    two = check_option_set(oracle, name + " (both tiers)", kw, n, 400 + k, tier=3)  # asserts "accepted => not rejected" and bound >= Phi
+    assert two["rejected_by_filter"] > one["rejected_by_filter"]
+
+
 @pytest.mark.parametrize("k", [0, 3, 5])
 def test_second_tier_candidate_is_sound_and_gains_little(oracle, k):
     """Round 5 tried a second tier on the pre-filter's survivors: the same decomposition of an alignment at its Watson-Crick columns,

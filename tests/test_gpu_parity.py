@@ -190,6 +190,34 @@ def test_filter_kernel_equals_its_checker(Engine, oracle, k, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("k", [0, 1, 3, 5, 8, 9])
+def test_second_tier_kernel_equals_its_checker(Engine, oracle, k):
+    """sbound_kernel (the pre-filter's second tier: a trace-free fill of align_dimer's recurrence, V = score << 11 | credit) against
+    its oracle-side restatement, integer by integer: the credit of the maximal-score paths, INT32_MAX -> 32 767 where the guard
+    bit fired or the window is not served (IUPAC codes, oligos beyond 40 bases).  Minimum-Tm, dG-only and dangling-end sets."""
+    import test_filter_bound as fbt
+    name, kw = fbt.OPTION_SETS[k]
+    rng = np.random.default_rng([77, k])
+    opt = abi.options_default(**kw)
+    oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=48, degen=0.15)
+    rows = [r[:6] + ((opt.probe_strand if r[5] else opt.primer_strand),) for r in rows]
+    codes, offsets = gu.pack_targets(targets)
+    e = Engine(opt, [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(oligos)])
+    om = {o: i for i, o in enumerate(e.oligos)}
+    db = e.pack(codes, offsets)
+    got = e.filter_bound_tier2(db, tc.make_reqs((r[0], om[oligos[r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in rows))
+    want = oracle.filter_bound(opt, oligos, codes, offsets, tc.make_reqs(rows), tier=30)
+    served = got[:, 1] != np.iinfo(np.int32).min
+    assert served.sum() > 3000 and (~served).sum() > 300
+    g0 = np.minimum(got[:, 0], 32767)
+    bad = np.nonzero(g0 != want[:, 0])[0]
+    assert len(bad) == 0, "%s: %d of %d differ, first %r got %r want %r" % (name, len(bad), len(rows), rows[bad[0]], got[bad[0]], want[bad[0]])
+    assert (got[served, 1] == want[served, 1]).all()
+    assert (g0[served] < got[served, 1]).sum() > 300  # the tier rejects windows
+    db.close()
+    e.close()
+
+
 def test_filter_changes_no_result(Engine, oracle, monkeypatch):
     """The same searches with the pre-filter on, off and in audit mode (everything is bound and the bind kernel raises an
     error if it accepts a window the filter marked): identical hits, and the filter does reject most windows."""
@@ -212,9 +240,12 @@ def test_filter_changes_no_result(Engine, oracle, monkeypatch):
         for k_, v_ in kw.items():
             setattr(wl.options, k_, v_)
         res = {}
-        for mode in ("on", "off", "audit"):
+        for mode in ("on", "off", "audit", "tier1"):
             monkeypatch.delenv("TNT_MI355X_NO_FILTER", raising=False)
             monkeypatch.delenv("TNT_MI355X_FILTER_AUDIT", raising=False)
+            monkeypatch.delenv("TNT_MI355X_NO_TIER2", raising=False)
+            if mode == "tier1":  # (the first tier alone: TNT_MI355X_NO_TIER2)
+                monkeypatch.setenv("TNT_MI355X_NO_TIER2", "1")
             if mode == "off":
                 monkeypatch.setenv("TNT_MI355X_NO_FILTER", "1")
             if mode == "audit":
@@ -223,13 +254,15 @@ def test_filter_changes_no_result(Engine, oracle, monkeypatch):
             db = e.pack(wl.codes, wl.offsets)
             res[mode] = tc.sorted_hit_keys(e.search(db))
             tm = e.timing()
-            if mode == "on":
+            if mode in ("on", "tier1"):
                 assert tm.n_filtered > tm.n_binds // (2 if set(kw) <= {"min_primer_tm", "min_probe_tm"} else 5), (cfg, tm.n_filtered, tm.n_binds)  # (dG / dangle sets: looser bounds)
+                res[mode + "_filtered"] = tm.n_filtered
             else:
                 assert tm.n_filtered == 0
             db.close()
             e.close()
-        assert res["on"] == res["off"] == res["audit"] and len(res["on"]) > 0
+        assert res["on"] == res["off"] == res["audit"] == res["tier1"] and len(res["on"]) > 0
+        assert res["on_filtered"] > res["tier1_filtered"]  # the second tier rejects windows the first lets through
         if cfg == 2 or inosine:
             assert res["on"] == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
 

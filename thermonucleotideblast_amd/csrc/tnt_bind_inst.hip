@@ -1,14 +1,15 @@
 // tnt_bind_inst.hip -- the throughput instances of the bind kernel, one per oligo-length bucket.
 //
 // The build compiles this file several times with -DTNT_INST_LIST="G(36) P(36) E(22) ..." (a share of the
-// instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows, F / D = pre-filter for plain / any windows, U / V = pre-filter on queues regrouped by oligo, plain / any windows) so they build
+// instances each: G = general ladder, P = plain-window ladder, E = exact length + plain windows, F / D = pre-filter for plain / any windows, U / V = pre-filter on queues regrouped by oligo, plain / any windows, S = the pre-filter's second tier) so they build
 // in parallel; compiled once without the macro it provides all of them.
 #include "tnt_bind.hip.h"
 #include "tnt_filter.hip.h"
 #include "tnt_ufilter.hip.h"
+#include "tnt_sbound.hip.h"
 
 #ifndef TNT_INST_LIST
-#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_LONG_LADDER(G) TNT_LONG_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F) TNT_LMAX_LADDER(D) TNT_LONG_LADDER(F) TNT_LONG_LADDER(D) TNT_FILTER_LADDER(U) TNT_LMAX_LADDER(V)
+#define TNT_INST_LIST TNT_LMAX_LADDER(G) TNT_LMAX_LADDER(P) TNT_LONG_LADDER(G) TNT_LONG_LADDER(P) TNT_EXACT_LADDER(E) TNT_FILTER_LADDER(F) TNT_LMAX_LADDER(D) TNT_LONG_LADDER(F) TNT_LONG_LADDER(D) TNT_FILTER_LADDER(U) TNT_LMAX_LADDER(V) TNT_SBOUND_LADDER(S)
 #endif
 
 namespace tnt {
@@ -38,6 +39,11 @@ namespace tnt {
 	{                                                                                                                \
 		hipLaunchKernelGGL((ufilter_kernel<N, true>), dim3(blocks), dim3(256), 0, stream, a);                         \
 	}
+#define S(N)                                                                                                         \
+	void launch_sbound_##N(const SBoundArgs &a, int blocks, hipStream_t stream)                                      \
+	{                                                                                                                \
+		hipLaunchKernelGGL((sbound_kernel<N>), dim3(blocks), dim3(256), 0, stream, a);                                \
+	}
 #define G(N) TNT_LAUNCHER(launch_bind_##N, N, false, false)
 #define P(N) TNT_LAUNCHER(launch_bind_plain_##N, N, false, true)
 #define E(N) TNT_LAUNCHER(launch_bind_exact_##N, N, true, true)
@@ -49,5 +55,6 @@ TNT_INST_LIST
 #undef D
 #undef U
 #undef V
+#undef S
 
 } // namespace tnt

@@ -35,6 +35,7 @@
 #include "tnt_filter.hip.h"
 #define TNT_REGROUP_KERNELS
 #include "tnt_ufilter.hip.h"
+#include "tnt_sbound.hip.h"
 #include "tnt_pair.hip.h"
 #include "tnt_ingest.hip.h"
 #include <zlib.h>
@@ -377,6 +378,67 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 	}
 }
 
+// Tables of the pre-filter's second tier (tnt_sbound.hip.h): per threshold class four planes over (x', x, q', q) -- the diagonal
+// predecessor's and the cell's target base (A C G T, 4 = none) and query base -- holding (-delta_g) << 11 | credit for the four
+// transitions of align_dimer that read the tables: diagonal step; into an aligned column from a gap state; the same in the first
+// column; from an aligned column into a gap state (read at the NEXT row's / the NEXT column's index: the credit is the closing
+// column's stack with its diagonally adjacent later cell).  Credits follow fill_filter_tables (pair = query base * 7 + target
+// base, phi(later cell, its diagonal predecessor)), in units of 0.02 kcal/mol rounded up.
+void fill_sbound_tables(SBoundTables &S, const FilterTables &F, const Tables &T, const tnt_options &opt)
+{
+	memset(&S, 0, sizeof(S));
+	bool wc[NBP];
+	memset(wc, 0, sizeof(wc));
+	wc[P_AT] = wc[P_TA] = wc[P_CG] = wc[P_GC] = true;
+	for (int b = bA; b <= bI; b++) wc[b * NB + bI] = wc[bI * NB + b] = true;
+	const long long K = 1ll << SB_SHIFT;
+	auto cl = [](long long v) { return int32_t(std::max<long long>(v, SB_NEG)); };
+	auto up = [](double kcal) { return int(std::ceil(kcal * double(SB_UNITS))); };
+	S.bulge = int32_t(T.dg_const[0] * K), S.zero = int32_t(T.dg_const[1] * K);
+	S.forb_m = cl(-(long long)T.dg_const[2] * K), S.forb_xy = cl(-(long long)T.dg_const[3] * K);
+	// the largest gain of a column: the score of a window of SB_MAX_ROWS + 8 columns has to stay below 2^20 units
+	long long gain = 0;
+	for (int p = 0; p < NBP; p++)
+		for (int c = 0; c < NBP; c++)
+			if (p / NB <= bI && p % NB <= bI && c / NB <= bI && c % NB <= bI) gain = std::max<long long>(gain, -(long long)T.dg[p * NBP + c]);
+	const bool fits = gain * (SB_MAX_ROWS + 2 * FLANK) < (1ll << 20) && std::abs((long long)T.dg_const[0]) < (1ll << 19) && std::abs((long long)T.dg_const[1]) < (1ll << 19);
+	for (int cls = 0; cls < FILT_CLASSES; cls++) {
+		for (int pl = 0; pl < SB_PLANES; pl++)
+			for (int i = 0; i < SB_PLANE; i++) S.plane[cls][pl][i] = SB_NEG;
+		S.enabled[cls] = (F.enabled[cls] && fits && !opt.use_dinkelbach && !getenv("TNT_MI355X_NO_TIER2")) ? 1 : 0;
+		if (!F.enabled[cls]) continue;
+		const double Tk = double(F.tk[cls]);
+		const double sc = double(T.salt) * double(T.log_na);
+		auto phi = [&](int prev, int cur) { return -(double(T.H[prev * NBP + cur]) - Tk * (double(T.S[prev * NBP + cur]) + sc)); };
+		const double pb1 = -Tk * double(T.bulge_S[1]);
+		auto b_step = [&](int first, int second) { return (wc[first] || wc[second]) ? std::max(phi(first, second), 0.0) : 0.0; };
+		auto b_gap = [&](int first, int second) {
+			double best = b_step(first, second);
+			if (wc[first] || wc[second])
+				for (int pm = 0; pm < NBP; pm++)
+					if (wc[pm] && pm / NB <= bI && pm % NB <= bI) best = std::max(best, std::max(phi(pm, second), phi(first, pm)) - pb1);
+			return best;
+		};
+		for (int xp5 = 0; xp5 < SB_X; xp5++)
+			for (int x5 = 0; x5 < SB_X; x5++)
+				for (int qp = 0; qp < NB; qp++)
+					for (int q = 0; q < NB; q++) {
+						const int at = (xp5 * SB_X + x5) * NBP + qp * NB + q;
+						const int xpB = xp5 == 4 ? int(bGAP) : xp5, xB = x5 == 4 ? int(bGAP) : x5;
+						const bool v1 = q <= bI && x5 < 4, v2 = qp <= bI && xp5 < 4;
+						const int first = q * NB + x5, second = qp * NB + xp5; // (read only where valid)
+						const int cpair = xB * NB + q, ppair = xpB * NB + qp;
+						const int cs = (v1 && v2) ? up(b_step(first, second)) : 0;
+						const int cg = (v1 && v2) ? up(b_gap(first, second)) : (v1 ? up(b_gap(first, first)) : 0);
+						const int cc = v2 ? (v1 ? up(b_gap(first, second)) : up(b_gap(second, second))) : 0;
+						S.plane[cls][0][at] = x5 == 4 ? SB_NEG : cl(-(long long)T.dg[ppair * NBP + cpair] * K + cs);
+						S.plane[cls][1][at] = x5 == 4 ? SB_NEG : cl(-(long long)T.term[cpair] * K + cg);
+						S.plane[cls][2][at] = xp5 == 4 ? S.forb_m : S.plane[cls][1][at];
+						S.plane[cls][3][at] = cl(-(long long)T.term[xpB * NB + qp] * K + cc);
+					}
+	}
+}
+
 // build_word_list<std::string>, seq_hash.h:287-374, in the packed stream's little-endian word convention
 // (first base of the k-mer in the lowest two bits)
 std::vector<uint16_t> word_list(const std::string &oligo, bool complement, int k)
@@ -593,6 +655,10 @@ struct tnt_ctx {
 	// Round 5: the phase-A queue of a plain length bucket is regrouped by (oligo, threshold class) in front of its pre-filter
 	// (tnt_ufilter.hip.h): slot -> rank of its (oligo, class) inside its bucket, the buckets' shares of the histogram / cursor
 	// arrays and of the regrouped queue (every run is padded to whole blocks: 64 slots per bin on top of the bucket's region)
+	// second tier of the pre-filter (tnt_sbound.hip.h): the credit of the fill's maximal-score paths
+	SBoundTables h_stab;
+	DevBuf<SBoundTables> stab;
+	bool tier2 = false;
 	bool defer_finish = false; // the throughput bind instances park the windows that pass Tm / dG for bind_finish_kernel (tnt_bind.hip.h)
 	bool regroup = false;
 	DevBuf<uint32_t> slot_bin;       // [slot][2]: inside its plain bucket, inside its general bucket
@@ -629,6 +695,7 @@ struct tnt_ctx {
 		DevBuf<uint32_t> pairable; // the groups of `active` that can report a hit (pair_select_kernel)
 		DevBuf<uint32_t> qbucket; // the phase queue regrouped by oligo length, bucket after bucket
 		DevBuf<uint32_t> qsurv;   // the bucket queue after the filter, bucket by bucket at the same offsets
+		DevBuf<uint32_t> qsurv2;  // ... after the filter's second tier
 		DevBuf<uint4> qfat;       // phase-A queues of the round-3 seed kernel: self-contained entries (FilterArgs2::fat)
 		DevBuf<uint4> qsort;      // ... regrouped by (oligo, class): bucket i at q_base[i] + 64 * rg_bin_base[i] (UFilterArgs::fat)
 		DevBuf<uint32_t> rg_hist, rg_cursor; // [rg_total_bins] entries per bin of the batch, next free slot of its run
@@ -968,6 +1035,26 @@ void launch_ufilter(const UFilterArgs &a, int blocks, int rows, hipStream_t stre
 	}
 }
 
+bool has_sbound_instance(int rows)
+{
+	switch (rows) {
+#define X(N) case N: return true;
+		TNT_SBOUND_LADDER(X)
+#undef X
+	default: return false;
+	}
+}
+
+void launch_sbound(const SBoundArgs &a, int blocks, int rows, hipStream_t stream)
+{
+	switch (rows) {
+#define X(N) case N: tnt::launch_sbound_##N(a, blocks, stream); break;
+		TNT_SBOUND_LADDER(X)
+#undef X
+	default: break;
+	}
+}
+
 // The regrouping of a batch's phase-A queues by (oligo, threshold class): count, scan, scatter, each ONE launch over all the
 // buckets of `desc` (device array of n_desc descriptors).
 void launch_regroup(tnt_ctx *c, const RegroupBucket *desc, uint32_t n_desc, const uint4 *src, uint4 *dst, uint32_t *counters, const uint32_t *slot_bin,
@@ -1115,6 +1202,22 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			b.index_stride = 1;
 			b.n_items_dev = f.n_survivors;
 			b.audit = f.audit;
+			// Second tier on the survivors (tnt_sbound.hip.h): plain windows of oligos of up to 40 bases -- a trace-free fill of
+			// align_dimer's own recurrence whose maximum carries the credit of the maximal-score paths.  (Not where the caller
+			// reports statuses: a window this tier rejects against the maximum dG may fail the Tm range first.)
+			if (c->tier2 && c->S().qsurv2.p && (c->bucket_lmax[i] & BUCKET_PLAIN) && has_sbound_instance(rows) && !c->filter_status_exact && !split) {
+				SBoundArgs sb;
+				memset(&sb, 0, sizeof(sb));
+				sb.tab = c->stab.p, sb.ftab = c->ftab.p, sb.db = v;
+				sb.olig_q4 = b.olig_q4, sb.olig_len = b.olig_len, sb.slots = b.slots, sb.items = b.items;
+				sb.index = survivors, sb.index_base_dev = b.index_base_dev, sb.n_items_dev = f.n_survivors, sb.n_items = queue_cap;
+				sb.survivors = c->S().qsurv2.p + (direct ? c->h_q_base[i] : 0u);
+				sb.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 7;
+				sb.result = b.result, sb.n_rejected = gcnt + C_FILTERED, sb.audit = f.audit;
+				launch_sbound(sb, c->n_cu * 4, rows, c->lane_stream[lane]);
+				b.index = sb.survivors;
+				b.n_items_dev = sb.n_survivors;
+			}
 		}
 		b.trace = c->trace.p + size_t(lane) * c->lane_trace;
 		b.best = c->best.p + size_t(lane) * c->lane_cols;
@@ -1177,6 +1280,7 @@ int alloc_set(tnt_ctx *c, int k)
 	HIP_TRY(W.qb.alloc(c->item_cap), c->err);
 	HIP_TRY(W.qbucket.alloc(c->item_cap), c->err);
 	if (c->filter_on) HIP_TRY(W.qsurv.alloc(c->item_cap), c->err);
+	if (c->tier2) HIP_TRY(W.qsurv2.alloc(c->item_cap), c->err);
 	if (c->seed2) HIP_TRY(W.qfat.alloc(c->item_cap), c->err);
 	if (c->seed2 && c->regroup) {
 		HIP_TRY(W.qsort.alloc(c->item_cap + size_t(UF_BLOCK) * c->rg_total_bins), c->err);
@@ -1555,9 +1659,11 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	// ---- tables
 	if (!fill_tables(c->h_tab, *opt)) FAIL(TNT_E_UNSUPPORTED, "delta_g table lacks the class structure the bind kernel relies on");
 	fill_filter_tables(c->h_ftab, c->h_tab, *opt);
+	fill_sbound_tables(c->h_stab, c->h_ftab, c->h_tab, *opt);
 	c->filter_on = (c->h_ftab.enabled[0] || c->h_ftab.enabled[1]) && !getenv("TNT_MI355X_NO_FILTER");
 	c->filter_audit = c->filter_on && getenv("TNT_MI355X_FILTER_AUDIT");
 	c->filter_general = c->filter_on && !getenv("TNT_MI355X_NO_FILTER_GENERAL");
+	c->tier2 = c->filter_on && (c->h_stab.enabled[0] || c->h_stab.enabled[1]);
 	c->serial_bind = getenv("TNT_MI355X_SERIAL_BIND") != nullptr;
 	if (const char *e = getenv("TNT_MI355X_WAVE_BIND")) c->wave_from = std::max(0, atoi(e)); // A/B switch: 1 = every bucket, 33 = oligos of 33 bases and more, ...
 	std::vector<uint8_t> ob(std::max<size_t>(1, c->oligos.size()) * MAX_OLIGO, 0);
@@ -1735,7 +1841,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	}
 	std::vector<Tables> tv(1, c->h_tab);
 	std::vector<FilterTables> fv(1, c->h_ftab);
-	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->ftab.upload(fv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
+	std::vector<SBoundTables> sv(1, c->h_stab);
+	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->ftab.upload(fv)) != hipSuccess || (e = c->stab.upload(sv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
 	    (e = c->olig_q4.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
 	    (e = c->slot_canon.upload(c->h_slot_canon)) != hipSuccess || (e = c->slot_next.upload(c->h_slot_next)) != hipSuccess ||
@@ -3976,6 +4083,73 @@ int tnt_filter_bound(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n
 			f.n_items = uint32_t(kv.second.size());
 			launch_filter(f, int(std::min<size_t>(size_t(ctx->n_cu) * 8, (kv.second.size() + 255) / 256)), rows, ctx->stream, degen);
 		}
+		at += kv.second.size();
+	}
+	HIP_TRY(hipGetLastError(), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpy(score, dscore.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost), ctx->err);
+	return TNT_OK;
+}
+
+int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, size_t n, int32_t *score)
+{
+	if (!ctx || !db || db->ctx != ctx || (!req && n) || (!score && n)) return TNT_E_ARG;
+	if (ctx->pending) {
+		ctx->err = "a search is pending on this context: collect it first";
+		return TNT_E_ARG;
+	}
+	if (n == 0) return TNT_OK;
+	if (n > ITEM_CAP_MAX || n > (size_t(1) << (32 - ITEM_SLOT_SHIFT))) return TNT_E_LIMIT;
+	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
+	int rc = ensure_work_buffers(ctx, 64, nullptr, n);
+	if (rc) return rc;
+	if (!db->host_copy) {
+		ctx->err = "tnt_filter_bound_tier2 needs a database packed from codes (tnt_db_create)";
+		return TNT_E_UNSUPPORTED;
+	}
+	std::vector<Slot> slots(n);
+	std::vector<Item> items(n);
+	std::map<int, std::vector<uint32_t>> by_rows; // instance (rows) -> requests it serves
+	for (size_t i = 0; i < n; i++) {
+		const tnt_bind_req &r = req[i];
+		const size_t t = size_t(r.seq_index) - db->first_seq_index;
+		if (t >= db->n_targets || r.oligo < 0 || r.oligo >= int(ctx->oligos.size()) || r.query_loc < 0 || r.query_loc > 127 ||
+		    size_t(r.query_loc) >= ctx->oligos[size_t(r.oligo)].size() || r.target_loc < 0 || !(r.ct > 0.0f)) {
+			ctx->err = "bad bind request";
+			return TNT_E_ARG;
+		}
+		const int L = int(ctx->oligos[r.oligo].size());
+		slots[i] = Slot{r.oligo, logf((r.ct - 0.5f * 0.0f) * 1.0f), r.role == 1 ? 1 : 0, -1, 0, 0};
+		items[i] = Item{uint32_t(t), uint32_t(r.target_loc), uint32_t(r.query_loc) | (r.strand == TNT_MINUS ? ITEM_MINUS : 0u) | (uint32_t(i) << ITEM_SLOT_SHIFT), 0};
+		score[2 * i] = INT32_MAX, score[2 * i + 1] = INT32_MIN; // (not served: passes)
+		const int start = std::max(0, r.target_loc - (r.query_loc + FLANK));
+		const uint32_t stop = std::min<uint32_t>(uint32_t(start + L + 2 * FLANK), db->h_len[t]);
+		const uint32_t *eb = db->h_exc_pos.data() + db->h_exc_off[t], *ee = db->h_exc_pos.data() + db->h_exc_off[t + 1];
+		const uint32_t *it = std::lower_bound(eb, ee, uint32_t(start));
+		const int rows = pick_instance(size_t(L)) & 0xFF;
+		if ((it == ee || *it >= stop) && L <= SB_MAX_ROWS && has_sbound_instance(rows)) by_rows[rows].push_back(uint32_t(i)); // plain windows of oligos of up to 40 bases
+	}
+	DevBuf<Slot> dslots;
+	DevBuf<int32_t> dscore;
+	DevBuf<uint32_t> dindex;
+	HIP_TRY(dslots.upload(slots), ctx->err);
+	HIP_TRY(dscore.alloc(2 * n), ctx->err);
+	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+	HIP_TRY(hipMemcpy(ctx->S().items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
+	HIP_TRY(hipMemcpy(dscore.p, score, 2 * n * sizeof(int32_t), hipMemcpyHostToDevice), ctx->err);
+	std::vector<uint32_t> order;
+	for (const auto &kv : by_rows) order.insert(order.end(), kv.second.begin(), kv.second.end());
+	HIP_TRY(dindex.upload(order), ctx->err);
+	SBoundArgs sb;
+	memset(&sb, 0, sizeof(sb));
+	sb.tab = ctx->stab.p, sb.ftab = ctx->ftab.p, sb.db = make_view(db, 0, db->n_targets);
+	sb.olig_q4 = ctx->olig_q4.p, sb.olig_len = ctx->olig_len.p, sb.slots = dslots.p, sb.items = ctx->S().items.p;
+	sb.score_out = dscore.p;
+	size_t at = 0;
+	for (const auto &kv : by_rows) {
+		sb.index = dindex.p + at;
+		sb.n_items = uint32_t(kv.second.size());
+		launch_sbound(sb, int(std::min<size_t>(size_t(ctx->n_cu) * 4, (kv.second.size() + 255) / 256)), kv.first, ctx->stream);
 		at += kv.second.size();
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);

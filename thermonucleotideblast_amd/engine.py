@@ -86,6 +86,7 @@ def load_library():
     lib.tnt_bind_batch.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind)]
     lib.tnt_bind_batch_routed.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(abi.tnt_bind), C.c_int]
     lib.tnt_filter_bound.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(C.c_int32)]
+    lib.tnt_filter_bound_tier2.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_bind_req), C.c_size_t, P(C.c_int32)]
     lib.tnt_hit_sequence.argtypes = [C.c_void_p, C.c_void_p, P(abi.tnt_hit), C.c_char_p, C.c_size_t]
     lib.tnt_db_create_from_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, P(C.c_void_p)]
     lib.tnt_db_load_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, P(C.c_void_p)]
@@ -120,7 +121,7 @@ def load_library():
 
 # every symbol include/tnt_mi355x.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
-    "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error", "tnt_ctx_warnings",
+    "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error", "tnt_ctx_warnings", "tnt_filter_bound_tier2",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_skip_targets", "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device", "tnt_search_hits_compact", "tnt_hits_unpack",
     "tnt_last_timing", "tnt_seeds", "tnt_first_cull", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
@@ -418,6 +419,12 @@ class Engine:
         """(n, 2) int32 array [bound, threshold] of the bind stage's pre-filter for every request (tnt_filter_bound)."""
         out = np.zeros((len(reqs), 2), dtype=np.int32)
         self._check(self.lib.tnt_filter_bound(self._h, batch._h, reqs, len(reqs), out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def filter_bound_tier2(self, batch, reqs):
+        """(n, 2) int32 array [credit of the maximal-score paths, threshold] of the pre-filter's second tier (tnt_filter_bound_tier2)."""
+        out = np.zeros((len(reqs), 2), dtype=np.int32)
+        self._check(self.lib.tnt_filter_bound_tier2(self._h, batch._h, reqs, len(reqs), out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
     def oligo_structure(self, a, b=None, ct_a=9.0e-7, ct_b=9.0e-7):
