@@ -378,11 +378,11 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 	}
 }
 
-// Tables of the pre-filter's second tier (tnt_sbound.hip.h): per threshold class four planes over (x', x, q', q) -- the diagonal
-// predecessor's and the cell's target base (A C G T, 4 = none) and query base -- holding (-delta_g) << 11 | credit for the four
-// transitions of align_dimer that read the tables: diagonal step; into an aligned column from a gap state; the same in the first
-// column; from an aligned column into a gap state (read at the NEXT row's / the NEXT column's index: the credit is the closing
-// column's stack with its diagonally adjacent later cell).  Credits follow fill_filter_tables (pair = query base * 7 + target
+// Tables of the pre-filter's second tier (tnt_sbound.hip.h): per threshold class one entry per (x', x, q', q) -- the diagonal
+// predecessor's and the cell's target base (A C G T, 4 = none) and query base -- holding (-delta_g) << 11 | credit for the three
+// transitions of align_dimer that read the tables: diagonal step; into an aligned column from a gap state; from an aligned
+// column into a gap state (read at the NEXT row's / the NEXT column's index: the credit is the closing column's stack with its
+// diagonally adjacent later cell).  Credits follow fill_filter_tables (pair = query base * 7 + target
 // base, phi(later cell, its diagonal predecessor)), in units of 0.02 kcal/mol rounded up.
 void fill_sbound_tables(SBoundTables &S, const FilterTables &F, const Tables &T, const tnt_options &opt)
 {
@@ -403,8 +403,7 @@ void fill_sbound_tables(SBoundTables &S, const FilterTables &F, const Tables &T,
 			if (p / NB <= bI && p % NB <= bI && c / NB <= bI && c % NB <= bI) gain = std::max<long long>(gain, -(long long)T.dg[p * NBP + c]);
 	const bool fits = gain * (SB_MAX_ROWS + 2 * FLANK) < (1ll << 20) && std::abs((long long)T.dg_const[0]) < (1ll << 19) && std::abs((long long)T.dg_const[1]) < (1ll << 19);
 	for (int cls = 0; cls < FILT_CLASSES; cls++) {
-		for (int pl = 0; pl < SB_PLANES; pl++)
-			for (int i = 0; i < SB_PLANE; i++) S.plane[cls][pl][i] = SB_NEG;
+		for (int i = 0; i < SB_ENTRIES; i++) S.entry[cls][i][0] = S.entry[cls][i][1] = S.entry[cls][i][2] = SB_NEG, S.entry[cls][i][3] = 0;
 		S.enabled[cls] = (F.enabled[cls] && fits && !opt.use_dinkelbach && !getenv("TNT_MI355X_NO_TIER2")) ? 1 : 0;
 		if (!F.enabled[cls]) continue;
 		const double Tk = double(F.tk[cls]);
@@ -431,10 +430,9 @@ void fill_sbound_tables(SBoundTables &S, const FilterTables &F, const Tables &T,
 						const int cs = (v1 && v2) ? up(b_step(first, second)) : 0;
 						const int cg = (v1 && v2) ? up(b_gap(first, second)) : (v1 ? up(b_gap(first, first)) : 0);
 						const int cc = v2 ? (v1 ? up(b_gap(first, second)) : up(b_gap(second, second))) : 0;
-						S.plane[cls][0][at] = x5 == 4 ? SB_NEG : cl(-(long long)T.dg[ppair * NBP + cpair] * K + cs);
-						S.plane[cls][1][at] = x5 == 4 ? SB_NEG : cl(-(long long)T.term[cpair] * K + cg);
-						S.plane[cls][2][at] = xp5 == 4 ? S.forb_m : S.plane[cls][1][at];
-						S.plane[cls][3][at] = cl(-(long long)T.term[xpB * NB + qp] * K + cc);
+						S.entry[cls][at][0] = x5 == 4 ? SB_NEG : cl(-(long long)T.dg[ppair * NBP + cpair] * K + cs);
+						S.entry[cls][at][1] = x5 == 4 ? SB_NEG : cl(-(long long)T.term[cpair] * K + cg); // (first column: the kernel forbids the step out of a gap state itself)
+						S.entry[cls][at][2] = cl(-(long long)T.term[xpB * NB + qp] * K + cc);
 					}
 	}
 }
@@ -1205,7 +1203,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			// Second tier on the survivors (tnt_sbound.hip.h): plain windows of oligos of up to 40 bases -- a trace-free fill of
 			// align_dimer's own recurrence whose maximum carries the credit of the maximal-score paths.  (Not where the caller
 			// reports statuses: a window this tier rejects against the maximum dG may fail the Tm range first.)
-			if (c->tier2 && c->S().qsurv2.p && (c->bucket_lmax[i] & BUCKET_PLAIN) && has_sbound_instance(rows) && !c->filter_status_exact && !split) {
+			if (c->tier2 && c->S().qsurv2.p && (c->bucket_lmax[i] & BUCKET_PLAIN) && has_sbound_instance(rows) && (rows < 17 || (c->bucket_lmax[i] & BUCKET_EXACT)) &&
+			    !c->filter_status_exact && !split) {
 				SBoundArgs sb;
 				memset(&sb, 0, sizeof(sb));
 				sb.tab = c->stab.p, sb.ftab = c->ftab.p, sb.db = v;
@@ -1214,7 +1213,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 				sb.survivors = c->S().qsurv2.p + (direct ? c->h_q_base[i] : 0u);
 				sb.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 7;
 				sb.result = b.result, sb.n_rejected = gcnt + C_FILTERED, sb.audit = f.audit;
-				launch_sbound(sb, c->n_cu * 4, rows, c->lane_stream[lane]);
+				launch_sbound(sb, c->n_cu * (sb_threads(rows) == 512 ? 2 : 3), rows, c->lane_stream[lane]);
 				b.index = sb.survivors;
 				b.n_items_dev = sb.n_survivors;
 			}
@@ -4149,7 +4148,7 @@ int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, si
 	for (const auto &kv : by_rows) {
 		sb.index = dindex.p + at;
 		sb.n_items = uint32_t(kv.second.size());
-		launch_sbound(sb, int(std::min<size_t>(size_t(ctx->n_cu) * 4, (kv.second.size() + 255) / 256)), kv.first, ctx->stream);
+		launch_sbound(sb, int(std::min<size_t>(size_t(ctx->n_cu) * 2, (kv.second.size() + 255) / 256)), kv.first, ctx->stream);
 		at += kv.second.size();
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);

@@ -23,7 +23,7 @@
 // than 2^10 units, so bit 10 of the credit field is a guard: once it is set in any state the window passes (20.48 kcal/mol is
 // above every threshold this tier is enabled for) and what the sums do afterwards is ignored.
 //
-// No trace words, no traceback, no scoring: 20 instructions per cell against the fill's 36 and nothing behind them.  Plain
+// No trace words, no traceback, no scoring: 17 instructions and two LDS reads per cell against the fill's 36 and nothing behind them.  Plain
 // windows (A/C/G/T targets) of oligos of up to 40 bases; everything else goes from the first tier straight to the bind kernel.
 // tests: tests/test_filter_bound.py (soundness of the oracle-side restatement, tier 3), tests/test_gpu_parity.py
 // (kernel == restatement; searches with the tier on / off / in audit mode).
@@ -43,13 +43,17 @@ constexpr int SB_GUARD = 1 << (SB_SHIFT - 1); // credit >= 20.48 kcal/mol: the w
 constexpr int SB_UNITS = 50;                 // credit units per kcal/mol (0.02 kcal/mol each)
 constexpr int SB_X = 5;                      // target base of a column: A C G T, 4 = none (before the first / behind the last column)
 constexpr int SB_ENTRIES = SB_X * SB_X * NBP; // index ((x' * 5 + x) * 49 + q' * 7 + q): diagonal predecessor (x', q'), cell (x, q)
-constexpr int SB_PLANE = 20 * 64;            // ints per plane (>= SB_ENTRIES)
-constexpr int SB_PLANES = 4;                 // diagonal step; from a gap state; the same in the first column; into a gap state
 constexpr int SB_MAX_ROWS = 40;              // instances (score < 2^20 units for oligos of up to 40 bases: the host checks the table)
 constexpr int SB_NEG = -(1 << 30);           // a forbidden transition
+// Workgroup size per instance: the tables take 39 KB of LDS per workgroup, the states 3 registers per row.  Up to 22 rows fit 128
+// registers (4 wavefronts per SIMD: two workgroups of 8); beyond that 3 or 2 per SIMD, reached with workgroups of 4.
+constexpr int sb_threads(int lmax) { return lmax <= 22 ? 512 : 256; }
+constexpr int sb_waves_per_simd(int lmax) { return lmax <= 22 ? 4 : (lmax <= 32 ? 3 : 2); }
 
+// One 16-byte entry per (x', x, q', q), read with ONE ds_read_b128: [0] the diagonal step, [1] into an aligned column from a gap
+// state, [2] from an aligned column into a gap state (read at the NEXT row's / the NEXT column's entry), [3] unused.
 struct SBoundTables {
-	int32_t plane[FILT_CLASSES][SB_PLANES][SB_PLANE];
+	int32_t entry[FILT_CLASSES][SB_ENTRIES][4];
 	int32_t bulge, zero, forb_m, forb_xy;    // the fill's class constants (Tables::dg_const), times 2^11
 	int32_t enabled[FILT_CLASSES];           // the class's bound is taken by this tier too (thresholds below the guard, scores that fit)
 };
@@ -75,16 +79,21 @@ struct SBoundArgs {
 	int32_t *dp_out;              // optional (unit-level entry): [idx] the maximal score of the fill
 };
 
-template <int LMAX> __global__ __launch_bounds__(256) void sbound_kernel(SBoundArgs a)
+// EXACT: every oligo of the launch has exactly LMAX bases (the exact-length buckets; the instance of 16 rows serves shorter ones).
+template <int LMAX, bool EXACT> __global__ __launch_bounds__(sb_threads(LMAX), sb_waves_per_simd(LMAX)) void sbound_kernel(SBoundArgs a)
 {
-	static_assert(LMAX <= SB_MAX_ROWS && SB_ENTRIES <= SB_PLANE, "instances of up to 40 rows");
-	constexpr int THREADS = 256;
+	static_assert(LMAX <= SB_MAX_ROWS, "instances of up to 40 rows");
+	constexpr int THREADS = sb_threads(LMAX);
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NW = (WMAX + 15) / 16;
-	__shared__ int32_t s_tab[FILT_CLASSES * SB_PLANES * SB_PLANE];
+	constexpr int NR = (LMAX + 1 + 3) / 4;   // row constants, four to a register
+	constexpr int CLS_BYTES = SB_ENTRIES * 16;
+	typedef int32_t i32x4 __attribute__((ext_vector_type(3))); // (three of the entry's four words: a dead fourth register would be reused before the read lands)
+	__shared__ __attribute__((aligned(16))) int32_t s_tab[FILT_CLASSES * SB_ENTRIES * 4];
 	__shared__ uint32_t s_keep[THREADS / 64][128];
 	__shared__ uint32_t s_wcount[THREADS / 64], s_wbase;
 	typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+	typedef __attribute__((address_space(3))) const i32x4 lds_ci32x4;
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint32_t n_items = a.n_items;
@@ -92,8 +101,8 @@ template <int LMAX> __global__ __launch_bounds__(256) void sbound_kernel(SBoundA
 		const uint32_t n_dev = *a.n_items_dev;
 		n_items = n_dev < n_items ? n_dev : n_items;
 	}
-	if (uint32_t(blockIdx.x) * uint32_t(THREADS) >= n_items) return; // (nothing to do: leave before staging 40 KB of tables)
-	for (int i = tid; i < FILT_CLASSES * SB_PLANES * SB_PLANE; i += THREADS) s_tab[i] = (&a.tab->plane[0][0][0])[i];
+	if (uint32_t(blockIdx.x) * uint32_t(THREADS) >= n_items) return; // (nothing to do: leave before staging 39 KB of tables)
+	for (int i = tid; i < FILT_CLASSES * SB_ENTRIES * 4; i += THREADS) s_tab[i] = (&a.tab->entry[0][0][0])[i];
 	__syncthreads();
 	const int c_bulge = a.tab->bulge, c_zero = a.tab->zero, c_forb_m = a.tab->forb_m, c_forb_xy = a.tab->forb_xy;
 	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
@@ -105,7 +114,7 @@ template <int LMAX> __global__ __launch_bounds__(256) void sbound_kernel(SBoundA
 		const bool active = idx != 0xFFFFFFFFu;
 		const Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
 		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
-		const int L = active ? a.olig_len[slot.oligo] : 0;
+		const int L = active ? (EXACT ? LMAX : a.olig_len[slot.oligo]) : 0;
 		const bool minus = (it.info & ITEM_MINUS) != 0;
 		// the window, bind_oligo.cpp:502-505 (plain windows only: no exception inside)
 		int start = int(it.tloc) - (int(it.info & 127u) + slot.qloc_bias + FLANK);
@@ -147,10 +156,12 @@ template <int LMAX> __global__ __launch_bounds__(256) void sbound_kernel(SBoundA
 				}
 			}
 		}
-		// row constants 4 * (7 * q' + q) of rows 1 .. LMAX + 1 (q' the base of the row above, none above the first; rows behind the
-		// oligo hold "none": the row behind the last one is read for the credit of a gap opened in the last row)
-		int Rrow[LMAX + 1];
+		// row constants 7 * q' + q of rows 1 .. LMAX + 1, a byte each (q' the base of the row above, none above the first; rows
+		// behind the oligo hold "none": the row behind the last one is read for the credit of a gap opened in the last row)
+		uint32_t Rp[NR];
 		{
+#pragma unroll
+			for (int k = 0; k < NR; k++) Rp[k] = 0;
 			uint32_t qprev = bGAP;
 #pragma unroll
 			for (int i = 0; i <= LMAX; i++) {
@@ -158,15 +169,17 @@ template <int LMAX> __global__ __launch_bounds__(256) void sbound_kernel(SBoundA
 				if (i < LMAX) {
 					const uint32_t q4w = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + (i >> 2)] : 0u;
 					q = (q4w >> ((i & 3) * 8 + 2)) & 7u;
-					if (i >= L) q = bGAP;
+					if (!EXACT && i >= L) q = bGAP;
 				}
-				Rrow[i] = int(4u * (7u * qprev + q));
+				Rp[i >> 2] |= (7u * qprev + q) << ((i & 3) * 8);
 				qprev = q;
 			}
 		}
 		const int cls = filter_class(slot.thresh);
-		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * (SB_PLANES * SB_PLANE * 4);
+		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * CLS_BYTES;
+		auto rd4 = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32x4 *)(uintptr_t(uint32_t(addr))); };
 		auto rd = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32 *)(uintptr_t(uint32_t(addr))); };
+		auto rowc = [&](int i) __attribute__((always_inline)) { return int((Rp[i >> 2] >> ((i & 3) * 8)) & 0xFFu) * 16; }; // byte offset of row i + 1's entry
 
 		int Wwave = W;
 #pragma unroll
@@ -194,23 +207,29 @@ template <int LMAX> __global__ __launch_bounds__(256) void sbound_kernel(SBoundA
 			const int tn = base_of(j + 1);
 			const bool colok = j <= W;
 			const bool firstcol = j == 1;
-			const int colA = tab_base + (tp * SB_X + t) * (NBP * 4);  // (x', x) = (previous column, this column)
-			const int colN = tab_base + (t * SB_X + tn) * (NBP * 4);  // (this column, next column): the credit of a gap opened in the target strand
+			const int colA = tab_base + (tp * SB_X + t) * (NBP * 16);     // (x', x) = (previous column, this column)
+			const int colN = tab_base + (t * SB_X + tn) * (NBP * 16) + 8; // (this column, next column): the credit of a gap opened in the target strand
 			const int v5 = firstcol ? c_zero : c_bulge;
+			const int q_first = firstcol ? SB_NEG / 2 : 0;                // (no aligned column before the first: nothing closes a gap state there)
 #pragma unroll
-			for (int i = 0; i <= LMAX; i++) asm volatile("" : "+v"(Rrow[i])); // (kept in registers, not re-derived per column)
+			for (int k = 0; k < NR; k++) asm volatile("" : "+v"(Rp[k])); // (kept in registers, not re-derived per column)
 			int dM = 0, dQ = 0, dT = 0; // (i - 1, j - 1): the border row
 			int uM = 0, uT = 0;         // (i - 1, j), new values
+			int colmax = 0, colst = 0;
+			// the entries of rows i and i + 1 are in flight while row i - 1 is computed
+			i32x4 e0 = rd4(colA + rowc(0)), e1 = rd4(colA + rowc(1));
+			int g0 = rd(colN + rowc(0));
 #pragma unroll
 			for (int i = 1; i <= LMAX; i++) {
-				const int ea = colA + Rrow[i - 1];
-				const int p1 = rd(ea), p2 = rd(ea + SB_PLANE * 4), p2f = rd(ea + 2 * SB_PLANE * 4);
-				const int p3 = rd(colA + Rrow[i] + 3 * SB_PLANE * 4);   // read at the NEXT row's constant: (q_i, q_i+1)
-				const int p4 = rd(colN + Rrow[i - 1] + 3 * SB_PLANE * 4);
+				const i32x4 e2 = i + 1 <= LMAX ? rd4(colA + rowc(i + 1 <= LMAX ? i + 1 : LMAX)) : e1;
+				const int g1 = i < LMAX ? rd(colN + rowc(i < LMAX ? i : 0)) : 0;
+				const int p1 = e0.x, p2 = e0.y;
+				const int p3 = e1.z;  // the NEXT row's entry: (q_i, q_i+1)
+				const int p4 = g0;
 				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // (i, j - 1)
 				// align_dimer, nuc_cruc.cpp:536-666, every table value = (-delta_g) << 11 | credit
 				const int d1 = dM + p1;
-				const int d2 = dQ + (firstcol ? c_forb_m : p2f);
+				const int d2 = dQ + p2 + q_first;
 				const int d3 = dT + (i == 1 ? c_forb_m : p2);
 				int M = d1 > d2 ? d1 : d2;
 				M = M > d3 ? M : d3;
@@ -219,13 +238,21 @@ template <int LMAX> __global__ __launch_bounds__(256) void sbound_kernel(SBoundA
 				const int ti = uM + (i == 1 ? c_forb_xy : p4), te = uT - (i == 1 ? c_zero : c_bulge);
 				const int It = ti > te ? ti : te;
 				const int Mz = M > 0 ? M : 0, Iqz = Iq > 0 ? Iq : 0, Itz = It > 0 ? It : 0;
-				const bool valid = colok && i <= L;
-				vmax = (valid && Mz > vmax) ? Mz : vmax;
-				sticky |= valid ? (Mz | Iqz | Itz) : 0;
+				if (EXACT) {
+					colmax = Mz > colmax ? Mz : colmax;
+					colst |= Mz | Iqz | Itz;
+				} else {
+					const bool valid = i <= L;
+					colmax = (valid && Mz > colmax) ? Mz : colmax;
+					colst |= valid ? (Mz | Iqz | Itz) : 0;
+				}
 				dM = cM, dQ = cQ, dT = cT;
 				uM = Mz, uT = Itz;
 				oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
+				e0 = e1, e1 = e2, g0 = g1;
 			}
+			vmax = (colok && colmax > vmax) ? colmax : vmax;
+			sticky |= colok ? colst : 0;
 			tp = t, t = tn;
 		}
 		// the verdict: the credit of the best maximal-score path against the first tier's threshold (same constants, same units)
