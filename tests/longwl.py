@@ -81,3 +81,50 @@ def make_beyond_128(seed, lengths=(150, 220, 400, 1000), n_targets=24, tl=3000):
     wl = synth.Workload("beyond-128", opt, assays, codes, offsets)
     wl.expanded = synth.expand_assays(assays)
     return wl
+
+
+def make_primers_beyond_128(kind, seed, n_targets=10, tl=2600, every=2):
+    """kind: 'pcr' (primer pairs, one or both primers of 129..520 bases), 'taqman' (a probe of more than 128 bases between
+    ordinary primers, or a long primer next to an ordinary probe), 'padlock' (arms of more than 128 bases).  Planted sites with
+    substitutions and small indels on either strand, a few IUPAC letters.  The reference takes oligos of up to 1 024 bases in
+    every role (nuc_cruc.h:80)."""
+    rng = np.random.default_rng([991, seed, {"pcr": 0, "taqman": 1, "padlock": 2}[kind]])
+    codes, offsets = synth._targets(rng, n_targets, tl)
+    opt = abi.options_default(min_primer_tm=45.0, min_probe_tm=45.0)
+    if kind == "padlock":
+        opt.assay_format = abi.ASSAY_PADLOCK
+    assays = []
+    shapes = {"pcr": [(129, 22), (300, 24), (20, 260), (150, 135), (520, 21)],
+              "taqman": [(21, 23, 160), (140, 22, 30), (24, 20, 300), (200, 180, 150)],
+              "padlock": [(129, 40), (30, 200), (150, 150), (260, 25)]}[kind]
+    shapes = shapes[seed % every::every]  # (a long oligo costs the reference a second per seed: a few shapes per case)
+    for a, shape in enumerate(shapes):
+        if kind == "pcr":
+            F, R = synth._rand_oligo(rng, shape[0], shape[0]), synth._rand_oligo(rng, shape[1], shape[1])
+            assays.append(synth.Assay("long%d" % a, F, R, None))
+            amp = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(20, 150))))
+            site = F + amp + synth.revcomp(R)
+        elif kind == "taqman":
+            F, R, P = (synth._rand_oligo(rng, n, n) for n in shape)
+            assays.append(synth.Assay("long%d" % a, F, R, P))
+            g1 = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(5, 60))))
+            g2 = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(5, 60))))
+            site = F + g1 + (P if rng.random() < 0.5 else synth.revcomp(P)) + g2 + synth.revcomp(R)
+        else:
+            F, R = synth._rand_oligo(rng, shape[0], shape[0]), synth._rand_oligo(rng, shape[1], shape[1])
+            assays.append(synth.Assay("long%d" % a, F, R, None))
+            site = F + R
+        for _ in range(int(rng.integers(3, 6))):
+            t = int(rng.integers(0, n_targets))
+            s = _edit(rng, site, max(3, len(site) // 40), 2)
+            if rng.random() < 0.5:
+                s = synth.revcomp(s)
+            if len(s) + 2 >= tl:
+                continue
+            pos = int(rng.integers(1, tl - len(s) - 1))
+            synth._put(codes, int(offsets[t]), pos, s)
+    pos = rng.integers(0, n_targets * tl, 30)
+    codes[pos] = rng.integers(5, 16, 30).astype(np.uint8)
+    wl = synth.Workload("beyond-128-%s" % kind, opt, assays, codes, offsets)
+    wl.expanded = synth.expand_assays(assays)
+    return wl

@@ -1453,14 +1453,57 @@ def test_oligos_beyond_128_bases_vs_oracle(Engine, oracle, seed, lengths):
     e.close()
 
 
-def test_primers_beyond_128_bases_are_refused(Engine):
-    """Oligos of more than 128 bases are searched as the probes of probe-only assays; a PCR primer of that length is refused
-    with TNT_E_LIMIT at context creation, never searched differently."""
-    from thermonucleotideblast_amd.engine import TntError
-    rng = np.random.default_rng(5)
-    F, R = synth._rand_oligo(rng, 140, 140), synth._rand_oligo(rng, 20, 20)
-    with pytest.raises(TntError, match="probe"):
-        Engine(abi.options_default(min_primer_tm=40.0), synth.expand_assays([synth.Assay("a", F, R, None)]))
+@pytest.mark.parametrize("kind,seed,kw", [("pcr", 0, {}), ("pcr", 1, {}), ("pcr", 6, {"every": 1, "n_targets": 16}), ("taqman", 2, {}), ("taqman", 3, {}), ("padlock", 4, {}),
+                                          ("padlock", 5, {})])
+def test_primers_beyond_128_bases_vs_oracle(Engine, oracle, kind, seed, kw):
+    """PCR primers, TaqMan probes and padlock arms of 129 to 1 000 bases (the reference takes 1 024 in every role,
+    nuc_cruc.h:80): seeded in segments of 128 query words whose seeds join ONE list per (target, assay) -- assembled on the
+    host, seeds that two segments found on one diagonal reduced to the first -- then culled, bound (wavefront-per-window
+    kernel) and paired as the lists of targets that are seeded in windows are.  Search and first cull == oracle (== reference:
+    tests/test_oracle_vs_reference.py::test_primers_beyond_128_bases)."""
+    import longwl
+    wl = longwl.make_primers_beyond_128(kind, seed, **kw)
+    if seed == 6:  # one primer of a thousand bases among them
+        rng = np.random.default_rng(66)
+        F, R = synth._rand_oligo(rng, 1000, 1000), synth._rand_oligo(rng, 22, 22)
+        wl.assays.append(synth.Assay("kilo", F, R, None))
+        site = longwl._edit(rng, F + "ACGTTGCAAGGCTTAACCGGTTAAGC" + synth.revcomp(R), 30, 2)
+        synth._put(wl.codes, int(wl.offsets[3]), 200, site)
+        synth._put(wl.codes, int(wl.offsets[5]), 700, synth.revcomp(site))
+        wl.expanded = synth.expand_assays(wl.assays)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, wl.offsets)
+    hits = e.search(db)
+    assert tc.sorted_hit_keys(hits, text_of=e.long_text) == want and len(want) >= 4
+    if kind != "padlock":
+        got = e.first_cull(db)
+        wantc = oracle.first_cull(wl.options, wl.expanded, wl.codes, wl.offsets)
+        assert sorted(map(tuple, got)) == sorted(map(tuple, wantc)) and len(wantc) > 10
+    db.close()
+    e.close()
+
+
+def test_primers_beyond_128_bases_beside_ordinary_assays(Engine, oracle):
+    """Long primer pairs among ordinary assays (and a probe-only assay with a long probe): every assay of the context takes
+    the route of the windowed targets then; same hits as the oracle."""
+    import longwl
+    wl = longwl.make_primers_beyond_128("pcr", 1)
+    base = synth.make_workload(2, n_targets=10, n_assays=12, seed=5)
+    rng = np.random.default_rng(8)
+    codes = np.concatenate([wl.codes, base.codes])
+    offsets = np.concatenate([wl.offsets, base.offsets[1:] + wl.offsets[-1]]).astype(np.uint64)
+    P = synth._rand_oligo(rng, 180, 180)
+    synth._put(codes, int(offsets[2]), 900, longwl._edit(rng, P, 6, 1))
+    assays = list(wl.assays) + list(base.assays) + [synth.Assay("longprobe", None, None, P)]
+    ex = synth.expand_assays(assays)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, ex, codes, offsets))
+    e = Engine(wl.options, ex)
+    db = e.pack(codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db), text_of=e.long_text)
+    assert got == want and len(want) > 20
+    db.close()
+    e.close()
 
 
 @pytest.mark.parametrize("kind,seed", [("probe", 1), ("padlock", 3), ("pcr", 4), ("beyond", 2)])

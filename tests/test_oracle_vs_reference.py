@@ -128,6 +128,28 @@ def test_long_oligos(ref, oracle, kind, seed):
         assert ref.structure(wl.options, o, oligos[0]) == oracle.structure(wl.options, o, oligos[0])
 
 
+@pytest.mark.parametrize("kind,seed", [("pcr", 0), ("pcr", 1), ("taqman", 2), ("taqman", 3), ("padlock", 4), ("padlock", 5)])
+def test_primers_beyond_128_bases(ref, oracle, kind, seed):
+    """PCR primers, TaqMan probes and padlock arms of 129..1 024 bases (nuc_cruc.h:80: every role may be that long): seeds,
+    binds and hits of the oracle against the reference."""
+    import longwl
+    wl = longwl.make_primers_beyond_128(kind, seed)
+    oligos = sorted({o for e in wl.expanded for o in (e.forward, e.reverse, e.probe) if o})
+    assert max(len(o) for o in oligos) > 128
+    sa = ref.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    assert sa == oracle.seeds(wl.options, oligos, wl.codes, wl.offsets)
+    reqs = tc.make_reqs((s[0], s[1], s[2], s[3], s[4], i % 2, 9e-7 if i % 3 else 2.5e-7) for i, s in enumerate(sa[::max(1, len(sa) // 1500)]))
+    ra = ref.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    rb = oracle.bind_batch(wl.options, oligos, wl.codes, wl.offsets, reqs)
+    bad = [b for b in ((i, tc.bind_compare_fields(ra[i], rb[i])) for i in range(len(reqs))) if b[1]]
+    assert not bad, bad[:3]
+    a = tc.sorted_hit_keys(ref.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+    assert a == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets)) and len(a) >= 4
+    if kind != "padlock":
+        ca, cb = ref.first_cull(wl.options, wl.expanded, wl.codes, wl.offsets), oracle.first_cull(wl.options, wl.expanded, wl.codes, wl.offsets)
+        assert np.array_equal(np.asarray(ca), np.asarray(cb))
+
+
 @pytest.mark.parametrize("kw", [{}, {"allow_dangle_5": 1, "allow_dangle_3": 1}, {"salt": 1.0, "target_t": 300.0}])
 def test_oligo_structure(ref, oracle, kw):
     """hairpin / homodimer / heterodimer Tm of oligos (tntblast_local.cpp:656-686) on fresh random + designed oligos."""

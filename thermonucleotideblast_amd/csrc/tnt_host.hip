@@ -739,6 +739,8 @@ struct tnt_ctx {
 	// degen_id, same oligo, Slot::qloc_bias = 128 * segment) appended behind the caller's assays.  Two seeds of one diagonal in
 	// two segments bind the same window; the hits of the segments are merged when a search is collected (merge_long_probe_hits).
 	std::vector<int32_t> h_segment;      // per device assay: segment of its probe's word list (-1: the whole list)
+	std::vector<uint32_t> h_assay_base;  // per device assay: the assay whose lists its seeds join (itself; the first segment's assay for the segments of long primers)
+	bool long_primers = false;           // a primer, TaqMan probe or padlock arm of more than 128 bases: every target is seeded in windows and its lists are assembled, culled and paired whole on the host (tnt_long.hip.h)
 	size_t n_input_assays = 0;
 	bool long_probes = false;
 	DevBuf<char> ltext;                  // alignment texts beyond TNT_ALIGN_TEXT (tnt_long_text)
@@ -1597,29 +1599,49 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	c->n_input_assays = n_assays;
 	c->h_segment.assign(n_assays, -1);
 	{
-		// oligos beyond 128 bases: probes of probe-only assays only, seeded in segments of 128 query words
+		// Oligos beyond 128 bases are seeded in segments of 128 query words, one (virtual) assay per segment.  The probe of a
+		// probe-only assay: every seed is bound on its own, the segments' hits are merged at collect time.  A primer, a TaqMan
+		// probe or a padlock arm (nuc_cruc.h:80: every role may have 1 024 bases): the culls and the pairing act on the lists of
+		// the whole oligo, so the segments' seeds join ONE list per (target, assay) -- assembled on the host, where seeds that
+		// two segments found on one diagonal are reduced to the first (bind_oligo.cpp:98-99) -- and every target takes the path
+		// of the targets that are seeded in windows (tnt_long.hip.h).
 		const size_t k = size_t(opt->hash_word_size);
+		c->h_assay_base.resize(n_assays);
+		for (size_t i = 0; i < n_assays; i++) c->h_assay_base[i] = uint32_t(i);
 		for (size_t i = 0; i < n_assays; i++) {
 			const AssayDev d = c->h_assays[i];
 			const int slots3[3] = {d.slot_f, d.slot_r, d.slot_p};
+			size_t seg_of[3] = {0, 0, 0}, n_seg = 0; // segments of the role's word list (0: the role has no oligo of more than 128 bases)
 			for (int role = 0; role < 3; role++) {
 				if (slots3[role] < 0) continue;
 				const size_t L = c->oligos[size_t(c->h_slots[size_t(slots3[role])].oligo)].size();
 				if (L <= size_t(MAX_LANE_OLIGO)) continue;
-				if (d.kind != 2) FAIL(TNT_E_LIMIT, "oligos of more than 128 bases are searched as the probes of probe-only assays (PCR primers, TaqMan probes and padlock arms: up to 128)");
-				const size_t n_words = L >= k ? L - k + 1 : 0, n_seg = (n_words + 127) / 128;
-				c->h_segment[i] = 0;
+				const size_t n_words = L >= k ? L - k + 1 : 0;
+				seg_of[role] = std::max<size_t>(1, (n_words + 127) / 128);
+				n_seg = std::max(n_seg, seg_of[role]);
+			}
+			if (n_seg == 0) continue;
+			c->h_segment[i] = 0;
+			if (d.kind == 2) {
 				if (n_seg > 1) c->long_probes = true, c->h_assays[i].cache_replay |= 2;
-				for (size_t sg = 1; sg < n_seg; sg++) {
-					const size_t v = c->h_assays.size();
-					c->h_assays.push_back(c->h_assays[i]);
-					c->h_segment.push_back(int32_t(sg));
-					c->h_slots.resize((v + 1) * 3, Slot{-1, 0.0f, 0, int(v), 0, 0});
-					Slot sl = c->h_slots[size_t(d.slot_p)];
+			} else {
+				c->long_primers = true;
+			}
+			for (size_t sg = 1; sg < n_seg; sg++) {
+				const size_t v = c->h_assays.size();
+				c->h_assays.push_back(c->h_assays[i]);
+				c->h_segment.push_back(int32_t(sg));
+				c->h_assay_base.push_back(uint32_t(i));
+				c->h_slots.resize((v + 1) * 3, Slot{-1, 0.0f, 0, int(v), 0, 0});
+				int32_t *const vslot[3] = {&c->h_assays[v].slot_f, &c->h_assays[v].slot_r, &c->h_assays[v].slot_p};
+				for (int role = 0; role < 3; role++) {
+					*vslot[role] = -1; // (a role whose word list ends before this segment seeds nothing here)
+					if (slots3[role] < 0 || sg >= seg_of[role]) continue;
+					Slot sl = c->h_slots[size_t(slots3[role])];
 					sl.assay = int(v);
 					sl.qloc_bias = int32_t(128 * sg);
-					c->h_slots[v * 3 + 2] = sl;
-					c->h_assays[v].slot_p = int32_t(v * 3 + 2);
+					c->h_slots[v * 3 + size_t(role)] = sl;
+					*vslot[role] = int32_t(v * 3 + size_t(role));
 				}
 			}
 		}
@@ -1700,7 +1722,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 				if (d.kind != 0 && !(opt->target_strand & (minus ? TNT_STRAND_MINUS : TNT_STRAND_PLUS))) continue;
 				const std::string &o = c->oligos[c->h_slots[slots3[role]].oligo];
 				std::vector<uint16_t> w = word_list(o, minus == 0, k); // plus strand: find_complement
-				if (c->h_segment[ai] >= 0) { // a probe of more than 128 bases: this (virtual) assay seeds one segment of its word list
+				if (c->h_segment[ai] >= 0 && o.size() > size_t(MAX_LANE_OLIGO)) { // an oligo of more than 128 bases: this (virtual) assay seeds one segment of its word list
 					const size_t w0 = std::min(w.size(), size_t(128) * size_t(c->h_segment[ai])), w1 = std::min(w.size(), w0 + 128);
 					w = std::vector<uint16_t>(w.begin() + long(w0), w.begin() + long(w1));
 				}
@@ -1923,7 +1945,7 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 		const uint32_t len = db->h_len[t];
 		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
 		const double expect = double(npos) * double(max_ent) / double(size_t(1) << (2 * k));
-		return !(expect <= 256.0 && npos <= 32768u) || db->all_long;
+		return !(expect <= 256.0 && npos <= 32768u) || db->all_long || ctx->long_primers;
 	};
 	auto skipped = [&](size_t t) { return t < db->h_skip.size() && db->h_skip[t] != 0; };
 	for (size_t t = 0; t < db->n_targets; t++) {

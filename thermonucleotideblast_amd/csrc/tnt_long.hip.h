@@ -228,7 +228,7 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 	// The lists are assembled AND culled on the device (tnt_sort.hip): only the seeds the first cull keeps, and one group
 	// record per list, come back.  TNT_MI355X_LONG_HOST_CULL=1 keeps round 2's route (every seed to the host, cull_oligo_match
 	// replayed per list on the worker threads) as the cross-check of the device cull.
-	const bool host_cull = getenv("TNT_MI355X_LONG_HOST_CULL") != nullptr;
+	const bool host_cull = getenv("TNT_MI355X_LONG_HOST_CULL") != nullptr || ctx->long_primers; // (the segments of primers beyond 128 bases: their seeds join one list on the host, below)
 	HostPool &workers = HostPool::get();
 	// (all device arrays of this path come out of one allocation the context keeps: tnt_arena.h)
 	DeviceArena &arena = ctx->long_arena;
@@ -293,6 +293,58 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		HIP_TRY(hipMemcpyAsync(sorted, d_items, n_raw * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipMemcpyAsync(list_of, d_list, n_raw * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		if (ctx->long_primers) {
+			// Primers, TaqMan probes and padlock arms of more than 128 bases were seeded in segments of 128 query words, one
+			// virtual assay per segment (tnt_ctx_create): their seeds join the list of the assay they belong to, in the order of
+			// the whole oligo's word indices (the keys of tnt_sort.hip with the segment's offset added), and of the seeds two
+			// segments found on one diagonal of one (oligo, strand) only the first stays -- match_oligo_to_*_strand sorts by
+			// diagonal and keeps the smallest word index (bind_oligo.cpp:98-99); inside a segment the seed kernel did that.
+			struct Row {
+				uint32_t list;
+				unsigned long long key;
+				uint32_t at;
+			};
+			struct Dup {
+				uint32_t list, who; // who: role | strand << 2
+				long long diag;
+				uint32_t qloc, row;
+			};
+			std::vector<Row> rows(n_raw);
+			std::vector<Dup> dups;
+			for (size_t i = 0; i < n_raw; i++) {
+				const Item &it = sorted[i];
+				const uint32_t slot = it.info >> ITEM_SLOT_SHIFT, role = slot % 3u, minus = (it.info & ITEM_MINUS) ? 1u : 0u;
+				const uint32_t rank = uint32_t(list_of[i] / n_assays_all), assay = uint32_t(list_of[i] % n_assays_all), base = ctx->h_assay_base[assay];
+				const unsigned long long qloc = (unsigned long long)(int64_t(it.info & 127u) + int64_t(ctx->h_slots[slot].qloc_bias));
+				unsigned long long key;
+				if (ctx->h_assays[base].kind == 0) {
+					const unsigned long long grp = role == 2 ? (minus ? 4u : 5u) : ((minus ? 0u : 2u) + role);
+					key = ((unsigned long long)it.tloc << 14) | (grp << 11) | qloc;
+				} else {
+					const unsigned long long listid = (minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
+					key = (listid << 46) | ((unsigned long long)(int64_t(qloc) - int64_t(it.tloc) + (int64_t(1) << 33)) << 11) | qloc;
+				}
+				rows[i] = Row{uint32_t(size_t(rank) * n_assays_all + base), key, uint32_t(i)};
+				if (ctx->h_segment[base] >= 0) dups.push_back(Dup{rows[i].list, role | (minus << 2), int64_t(qloc) - int64_t(it.tloc), uint32_t(qloc), uint32_t(i)});
+			}
+			std::vector<uint8_t> dropped(n_raw, 0);
+			std::sort(dups.begin(), dups.end(), [](const Dup &a, const Dup &b) {
+				if (a.list != b.list) return a.list < b.list;
+				if (a.who != b.who) return a.who < b.who;
+				if (a.diag != b.diag) return a.diag < b.diag;
+				return a.qloc < b.qloc;
+			});
+			for (size_t i = 1; i < dups.size(); i++)
+				if (dups[i].list == dups[i - 1].list && dups[i].who == dups[i - 1].who && dups[i].diag == dups[i - 1].diag) dropped[dups[i].row] = 1;
+			std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.list != b.list ? a.list < b.list : (a.key != b.key ? a.key < b.key : a.at < b.at); });
+			std::vector<Item> merged;
+			std::vector<uint32_t> merged_list;
+			merged.reserve(n_raw), merged_list.reserve(n_raw);
+			for (const Row &r : rows)
+				if (!dropped[r.at]) merged.push_back(sorted[r.at]), merged_list.push_back(r.list);
+			n_raw = merged.size();
+			if (n_raw) memcpy(sorted, merged.data(), n_raw * sizeof(Item)), memcpy(list_of, merged_list.data(), n_raw * sizeof(uint32_t));
+		}
 		std::vector<uint32_t> seg_begin, seg_assay;
 		for (size_t i = 0; i < n_raw; i++)
 			if (i == 0 || list_of[i] != list_of[i - 1]) {
@@ -383,7 +435,7 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 				const Item &it = bind_items[i];
 				const uint32_t slot = it.info >> ITEM_SLOT_SHIFT;
 				const int32_t row[7] = {int32_t(db->first_seq_index + it.target), int32_t(assay), int32_t(slot % 3u), (it.info & ITEM_MINUS) ? TNT_MINUS : TNT_PLUS,
-				                        int32_t(it.info & 127u), int32_t(it.tloc), (g.assay & GROUP_MINUS_FIRST) ? 1 : 0};
+				                        int32_t(it.info & 127u) + ctx->h_slots[slot].qloc_bias, int32_t(it.tloc), (g.assay & GROUP_MINUS_FIRST) ? 1 : 0};
 				cull_rows->insert(cull_rows->end(), row, row + 7);
 			}
 		}

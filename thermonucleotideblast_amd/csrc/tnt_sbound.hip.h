@@ -45,10 +45,10 @@ constexpr int SB_X = 5;                      // target base of a column: A C G T
 constexpr int SB_ENTRIES = SB_X * SB_X * NBP; // index ((x' * 5 + x) * 49 + q' * 7 + q): diagonal predecessor (x', q'), cell (x, q)
 constexpr int SB_MAX_ROWS = 40;              // instances (score < 2^20 units for oligos of up to 40 bases: the host checks the table)
 constexpr int SB_NEG = -(1 << 30);           // a forbidden transition
-// Workgroup size per instance: the tables take 39 KB of LDS per workgroup, the states 3 registers per row.  Up to 22 rows fit 128
+// Workgroup size per instance: the tables take 39 KB of LDS per workgroup, the states 3 registers per row.  Up to 25 rows fit 128
 // registers (4 wavefronts per SIMD: two workgroups of 8); beyond that 3 or 2 per SIMD, reached with workgroups of 4.
-constexpr int sb_threads(int lmax) { return lmax <= 22 ? 512 : 256; }
-constexpr int sb_waves_per_simd(int lmax) { return lmax <= 22 ? 4 : (lmax <= 32 ? 3 : 2); }
+constexpr int sb_threads(int lmax) { return lmax <= 25 ? 512 : 256; }
+constexpr int sb_waves_per_simd(int lmax) { return lmax <= 25 ? 4 : (lmax <= 37 ? 3 : 2); }
 
 // One 16-byte entry per (x', x, q', q), read with ONE ds_read_b128: [0] the diagonal step, [1] into an aligned column from a gap
 // state, [2] from an aligned column into a gap state (read at the NEXT row's / the NEXT column's entry), [3] unused.
@@ -213,29 +213,28 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(sb_threads(LMAX), s
 			const int q_first = firstcol ? SB_NEG / 2 : 0;                // (no aligned column before the first: nothing closes a gap state there)
 #pragma unroll
 			for (int k = 0; k < NR; k++) asm volatile("" : "+v"(Rp[k])); // (kept in registers, not re-derived per column)
-			int dM = 0, dQ = 0, dT = 0; // (i - 1, j - 1): the border row
 			int uM = 0, uT = 0;         // (i - 1, j), new values
 			int colmax = 0, colst = 0;
 			// the entries of rows i and i + 1 are in flight while row i - 1 is computed
 			i32x4 e0 = rd4(colA + rowc(0)), e1 = rd4(colA + rowc(1));
 			int g0 = rd(colN + rowc(0));
+			// Row i also forms the diagonal candidates of row i + 1 (the bind kernel's arrangement): they need the old states of
+			// row i, which die there, so the new states take their registers and nothing is copied at the loop's back edge.
+			int dg1 = e0.x, dg2 = e0.y + q_first, dg3 = c_forb_m; // row 1: the border row above holds 0, 0, 0
 #pragma unroll
 			for (int i = 1; i <= LMAX; i++) {
 				const i32x4 e2 = i + 1 <= LMAX ? rd4(colA + rowc(i + 1 <= LMAX ? i + 1 : LMAX)) : e1;
 				const int g1 = i < LMAX ? rd(colN + rowc(i < LMAX ? i : 0)) : 0;
-				const int p1 = e0.x, p2 = e0.y;
-				const int p3 = e1.z;  // the NEXT row's entry: (q_i, q_i+1)
-				const int p4 = g0;
 				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // (i, j - 1)
 				// align_dimer, nuc_cruc.cpp:536-666, every table value = (-delta_g) << 11 | credit
-				const int d1 = dM + p1;
-				const int d2 = dQ + p2 + q_first;
-				const int d3 = dT + (i == 1 ? c_forb_m : p2);
-				int M = d1 > d2 ? d1 : d2;
-				M = M > d3 ? M : d3;
-				const int qi = cM + p3, qe = cQ - v5;
+				int dn1 = 0, dn2 = 0, dn3 = 0;
+				if (i < LMAX) dn1 = cM + e1.x, dn2 = cQ + e1.y + q_first, dn3 = cT + e1.y; // e1: the NEXT row's entry, (q_i, q_i+1)
+				int qi = cM + e1.z, qe = cQ - v5;
+				asm volatile("" : "+v"(dn1), "+v"(dn2), "+v"(dn3), "+v"(qi), "+v"(qe), "+v"(dg1)); // the old states of this row are dead from here on
+				int M = dg1 > dg2 ? dg1 : dg2;
+				M = M > dg3 ? M : dg3;
 				const int Iq = qi > qe ? qi : qe;
-				const int ti = uM + (i == 1 ? c_forb_xy : p4), te = uT - (i == 1 ? c_zero : c_bulge);
+				const int ti = uM + (i == 1 ? c_forb_xy : g0), te = uT - (i == 1 ? c_zero : c_bulge);
 				const int It = ti > te ? ti : te;
 				const int Mz = M > 0 ? M : 0, Iqz = Iq > 0 ? Iq : 0, Itz = It > 0 ? It : 0;
 				if (EXACT) {
@@ -246,9 +245,9 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(sb_threads(LMAX), s
 					colmax = (valid && Mz > colmax) ? Mz : colmax;
 					colst |= valid ? (Mz | Iqz | Itz) : 0;
 				}
-				dM = cM, dQ = cQ, dT = cT;
 				uM = Mz, uT = Itz;
 				oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
+				dg1 = dn1, dg2 = dn2, dg3 = dn3;
 				e0 = e1, e1 = e2, g0 = g1;
 			}
 			vmax = (colok && colmax > vmax) ? colmax : vmax;
