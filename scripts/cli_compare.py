@@ -66,6 +66,11 @@ CASES = [  # (name, config, targets, assays, seed, extra flags)
     # hybridisation probes of more than 128 bases (tests/longwl.py make_beyond_128): the wavefront-per-window kernel, seeds in
     # segments, alignment texts far beyond the 448-byte fields of a hit
     ("probes_beyond_128", "beyond128", 10, 3, 36, ["-A", "PROBE", "-E", "50"]),
+    # PCR primers, TaqMan probes and padlock arms of more than 128 bases (tests/longwl.py make_primers_beyond_128): segments of one
+    # oligo's word list feed one list per (target, assay)
+    ("primers_beyond_128", "pcr>128", 10, 3, 1, ["-e", "45"]),
+    ("taqman_beyond_128", "taqman>128", 10, 3, 2, ["-e", "45", "-E", "45"]),
+    ("padlock_arms_beyond_128", "padlock>128", 10, 3, 4, ["-A", "PADLOCK", "-E", "45"]),
     # row a6: the probe of every TaqMan assay is also the forward primer of a PCR assay listed next to it -- one oligo string under
     # two strand concentrations / threshold sets: the reference's per-target BindCache decides (the library replays it)
     ("shared_oligos", 3, 250, 10, 35, ["-e", "45", "-E", "30", "--primer-clamp", "2", "--probe-clamp5", "1"]),
@@ -87,6 +92,8 @@ def closing_lines(stdout):
 def write_case(d, cfg, nt, na, seed, long_target=False, fastq=False, name=None):
     if cfg == "beyond128":
         wl = longwl.make_beyond_128(seed, lengths=(150, 320, 700), n_targets=nt, tl=2200)
+    elif isinstance(cfg, str) and cfg.endswith(">128"):
+        wl = longwl.make_primers_beyond_128(cfg[:-4], seed, n_targets=nt)
     else:
         wl = longwl.make(cfg, seed, n_targets=nt) if isinstance(cfg, str) else synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=seed)
     offsets = wl.offsets

@@ -30,9 +30,11 @@ def random_case(rng, case, max_code=18, dangle=True):
     if LONG_FRACTION > 0.0:  # (its own stream: the sequence of ordinary cases does not depend on the share)
         lrng = np.random.default_rng([case, 977])
         if lrng.random() < LONG_FRACTION:
-            kind = ("pcr", "probe", "padlock", "beyond128")[int(lrng.integers(0, 4))]
-            cfg = 2 if kind == "pcr" else 5
-            if kind == "beyond128":  # probes of 129 to 600 bases: the wavefront-per-window kernel, seeds in segments, long texts
+            kind = ("pcr", "probe", "padlock", "beyond128", "pcr>128", "taqman>128", "padlock>128")[int(lrng.integers(0, 7))]
+            cfg = 2 if kind.startswith("pcr") else (3 if kind.startswith("taqman") else 5)
+            if kind.endswith(">128"):  # primers, TaqMan probes, padlock arms of more than 128 bases: segments that feed one list
+                wl = longwl.make_primers_beyond_128(kind[:-4], int(lrng.integers(1, 1 << 30)), n_targets=8, tl=2200)
+            elif kind == "beyond128":  # probes of 129 to 600 bases: the wavefront-per-window kernel, seeds in segments, long texts
                 wl = longwl.make_beyond_128(int(lrng.integers(1, 1 << 30)), lengths=tuple(int(x) for x in lrng.integers(129, 600, 3)), n_targets=8, tl=1800)
             else:
                 wl = longwl.make(kind, int(lrng.integers(1, 1 << 30)), n_targets=min(nt, 120))
