@@ -633,6 +633,29 @@ def test_shared_oligos_across_classes_follow_the_bind_cache(Engine, oracle, kind
     e.close()
 
 
+@pytest.mark.parametrize("kind,seed,per", [("taqman", 61, 100), ("taqman", 65, 300), ("degenerate", 63, 50), ("padlock", 64, 100)])
+def test_bind_cache_on_windowed_targets(Engine, oracle, kind, seed, per):
+    """Row a6 on targets that are seeded in windows (records of 50 to 300 kb made of the targets of the cases above): the
+    reference's memo is per target whatever its length (tntblast_local.cpp:503-506).  The groups of the assays that share an
+    oligo are bound in full by the unit-level instance and replayed per target in assay order on a host thread (pair_group<N,
+    true>, the memo as a map); the other assays' lists are paired the ordinary way beside them.  == oracle (== reference:
+    tests/test_oracle_vs_reference.py::test_bind_cache_on_a_long_record)."""
+    wl, ex = _shared_oligo_workload(kind, seed)
+    offsets = np.concatenate([wl.offsets[:-1:per], wl.offsets[-1:]]).astype(np.uint64)
+    assert int(np.diff(offsets.astype(np.int64)).max()) > 40000
+    want = tc.sorted_hit_keys(oracle.search(wl.options, ex, wl.codes, offsets))
+    uncached = tc.sorted_hit_keys(oracle.search(wl.options, ex, wl.codes, offsets, bind_cache=False))
+    e = Engine(wl.options, ex)
+    db = e.pack(wl.codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    assert got == want and len(want) > 20
+    assert got == tc.sorted_hit_keys(e.search(db))  # (again: nothing of the replay is left over)
+    if kind == "taqman":
+        assert want != uncached  # the memo decides hits here
+    db.close()
+    e.close()
+
+
 def test_g5_readme_example(Engine):
     fx = gu.load("g5_readme.json.gz")
     ex = synth.expand_assays([synth.Assay("gibb-marburg", *fx["assay"])])

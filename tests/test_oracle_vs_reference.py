@@ -243,6 +243,21 @@ def test_search_with_bind_cache_conflicts(ref, oracle, kind, seed):
         assert b != c  # the memo does change these results
 
 
+def test_bind_cache_on_a_long_record(ref, oracle):
+    """Row a6 on records of 100 kb (the library seeds them in windows): the memo is per target whatever its length
+    (tntblast_local.cpp:503-506) -- oracle == reference on the TaqMan / PCR assay set that shares its probes with primers."""
+    wl, ex = _conflict_workload("taqman", 61)
+    offsets = np.concatenate([wl.offsets[:-1:100], wl.offsets[-1:]]).astype(np.uint64)
+    b = tc.sorted_hit_keys(oracle.search(wl.options, ex, wl.codes, offsets))
+    a = None
+    for attempt in range(8):  # (SURVEY Q4: the reference's strand choice is not deterministic, see above)
+        a = tc.sorted_hit_keys(ref.search(wl.options, ex, wl.codes, offsets, threads=1))
+        if a == b:
+            break
+    assert a == b and len(a) > 20
+    assert b != tc.sorted_hit_keys(oracle.search(wl.options, ex, wl.codes, offsets, bind_cache=False))
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_oligos_beyond_128_bases(ref, oracle, seed):
     """Hybridisation probes of 150 to 1 000 bases (the reference's MAX_SEQUENCE_LENGTH is 1 024): seeds, binds, hits and

@@ -673,6 +673,7 @@ struct tnt_ctx {
 	uint32_t batch_regions = 0;      // regions (wavefronts) of the batch that ran last
 	bool batch_direct = false;       // ... and whether it went through seed2_kernel (per-wavefront regions) or the round-2 kernel (32 shards)
 	DevBuf<Thresh> thresh;
+	std::vector<Thresh> h_thresh;       // (host copy: the cache replay of windowed targets runs on host threads)
 	DevBuf<AssayDev> assays;
 	DevBuf<uint32_t> wt_ent, wl_off;
 	DevBuf<unsigned long long> wl_seq;
@@ -1550,6 +1551,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	th[1] = mk(opt->min_probe_tm, opt->max_probe_tm, opt->min_probe_dg, opt->max_probe_dg, opt->probe_clamp_5, opt->probe_clamp_3);
 	th[2] = mk(opt->min_probe_tm, opt->max_probe_tm, opt->min_probe_dg, opt->max_probe_dg, opt->probe_clamp_5, 0); // padlock upstream
 	th[3] = mk(opt->min_probe_tm, opt->max_probe_tm, opt->min_probe_dg, opt->max_probe_dg, 0, opt->probe_clamp_3); // padlock downstream
+	c->h_thresh = th;
 
 	const float fwd_strand = opt->asymmetric_strand_ratio * opt->primer_strand; // tntblast_local.cpp:232-234
 	const float rev_strand = opt->primer_strand;
@@ -3062,11 +3064,6 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	if (ctx) ctx->dev_hits_valid = false;
 	if (!ctx || !db || db->ctx != ctx) return TNT_E_ARG;
 	HIP_TRY(hipSetDevice(ctx->device), ctx->err);
-	if (ctx->cache_replay && !db->h_long_targets.empty()) {
-		ctx->err = "an oligo is used under two strand concentrations or threshold sets (the reference's bind cache decides such assays) and the database holds a "
-		           "target that is seeded in windows: the cache replay pairs whole-target work units only (TNT_MI355X_UNCACHED_SHARED_OLIGOS=1 searches without the memo)";
-		return TNT_E_UNSUPPORTED;
-	}
 	int rc = ensure_work_buffers(ctx, ctx->cache_replay ? std::max(ctx->lmax, ctx->unit_rows) : ctx->lmax, db); // (the replay binds through the unit-level instance)
 	if (rc) return rc;
 	for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);

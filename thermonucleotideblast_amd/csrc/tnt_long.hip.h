@@ -490,6 +490,62 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 	const BoundRec *const pool = ctx->pin_pool.p;
 
 	lap("bind on the device");
+	// ---- row a6 on these targets: the groups of the assays that share an oligo across strand concentrations / threshold sets are
+	// decided by the reference's per-target BindCache (tntblast_local.cpp:503-506, bind_oligo.cpp:506-512).  As on whole-target work
+	// units (enqueue_cache_replay): every one of their seeds is bound in full by the unit-level instance, then the groups of a
+	// target are replayed in assay order through pair_group<N, true> -- here on a host thread per target, the memo as a map.
+	std::vector<ConflictRec> crecs;
+	std::vector<uint32_t> cvals;
+	std::vector<std::pair<uint32_t, uint32_t>> cruns; // per target with such groups: its records [first, end)
+	std::vector<Item> citems;
+	std::vector<BindFull> cfull;
+	if (ctx->cache_replay) {
+		for (size_t g = 0; g < groups.size(); g++) {
+			const Group &G = groups[g];
+			if (!(ctx->h_assays[G.assay & GROUP_ASSAY_MASK].cache_replay & 1)) continue;
+			const uint32_t count = G.count & ~GROUP_ALIVE;
+			if (citems.size() + count >= (size_t(1) << 31) - 2) {
+				ctx->err = "more than 2^31 seeds of assays that share an oligo on the long targets of this batch";
+				return TNT_E_LIMIT;
+			}
+			if (cruns.empty() || groups[crecs[cruns.back().first].group].target != G.target) cruns.push_back({uint32_t(crecs.size()), uint32_t(crecs.size())});
+			cvals.push_back(uint32_t(crecs.size()));
+			crecs.push_back(ConflictRec{uint32_t(g), uint32_t(citems.size()), count, 0u});
+			cruns.back().second = uint32_t(crecs.size());
+			for (uint32_t k2 = 0; k2 < count; k2++) {
+				Item it = bind_items[G.first + k2];
+				it.info &= ~ITEM_PHASE_B;
+				citems.push_back(it);
+			}
+		}
+		cfull.resize(citems.size());
+		DevBuf<BindFull> d_full;
+		const size_t step = std::min(ctx->item_cap, size_t(1) << 20);
+		if (!citems.empty()) HIP_TRY(d_full.alloc(std::min(step, citems.size())), ctx->err);
+		for (size_t c0 = 0; c0 < citems.size(); c0 += step) {
+			const size_t nc = std::min(step, citems.size() - c0);
+			HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * C_LTEXT, ctx->stream), ctx->err);
+			HIP_TRY(hipMemcpyAsync(ctx->S().items.p, citems.data() + c0, nc * sizeof(Item), hipMemcpyHostToDevice, ctx->stream), ctx->err);
+			BindArgs b = bind_args(ctx, v);
+			b.groups = nullptr, b.index = nullptr;
+			b.n_items = uint32_t(nc), b.n_items_dev = nullptr;
+			b.full = d_full.p;
+			launch_bind(ctx, b, ctx->bind_blocks, 0); // status, Tm, dH, dS, dG, anchors, counts, footprint, text -- whatever its own thresholds say
+			uint32_t h[C_COUNT];
+			HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+			HIP_TRY(hipMemcpyAsync(cfull.data() + c0, d_full.p, nc * sizeof(BindFull), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+			HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+			HIP_TRY(hipGetLastError(), ctx->err);
+			if (h[C_ERR]) {
+				ctx->err = err_text(h[C_ERR]);
+				return TNT_E_LIMIT;
+			}
+		}
+		lap("cache replay: full binds");
+	}
+	std::vector<uint32_t> corigin(citems.size());
+	std::vector<BoundRec> cpool(citems.size());
+	auto replayed = [&](const Group &G) { return ctx->cache_replay && (ctx->h_assays[G.assay & GROUP_ASSAY_MASK].cache_replay & 1) != 0; };
 	// ---- the bind / cull sequence and the pairing loops on the whole lists (pair_group, compiled for the host)
 	size_t hit_cap = std::max<size_t>(1024, n_pool);
 	std::unique_ptr<Hit[]> hits(new Hit[hit_cap]); // (not initialised: a record is 1.4 kB, pages are touched as hits arrive)
@@ -528,12 +584,36 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			lap("experiment: copies");
 		}
 		if (!workers.run(groups.size(), [&](size_t g) {
+			    if (replayed(groups[g])) return; // (below)
 			    const auto t0 = std::chrono::steady_clock::now();
 			    pair_group<PAIR_HOST>(p, groups[g]);
 			    if (timing) group_ms[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 		    }, &why)) {
 			ctx->err = "the lists of long targets: " + why;
 			return TNT_E_DEVICE;
+		}
+		if (!cruns.empty()) {
+			std::fill(corigin.begin(), corigin.end(), 0xFFFFFFFFu);
+			uint32_t n_cpool = 0;
+			PairArgs pc = p;
+			pc.thresh = ctx->h_thresh.data();
+			pc.citems = citems.data(), pc.cfull = cfull.data(), pc.corigin = corigin.data();
+			pc.cpool = cpool.data(), pc.cpool_cap = uint32_t(cpool.size()), pc.cpool_count = &n_cpool;
+			if (!workers.run(cruns.size(), [&](size_t t) {
+				    CacheMemo memo; // the target's BindCache: (oligo, strand, window) -> the seed evaluated first
+				    PairArgs mine = pc;
+				    mine.cmemo = &memo;
+				    const ConflictRun run{cvals.data() + cruns[t].first, crecs.data()};
+				    int n_run = 0;
+				    for (uint32_t j = cruns[t].first; j < cruns[t].second; j++) {
+					    const ConflictRec r = run[n_run++];
+					    pair_group<PAIR_HOST, true>(mine, groups[r.group], run, n_run, r.cfirst);
+				    }
+			    }, &why)) {
+				ctx->err = "the cache replay on long targets: " + why;
+				return TNT_E_DEVICE;
+			}
+			lap("cache replay");
 		}
 		if ((err & ERR_HIT_OVERFLOW) && hit_cap < UINT32_MAX) {
 			hit_cap *= 4;

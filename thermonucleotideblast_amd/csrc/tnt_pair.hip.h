@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 #include "tnt_dev.h"
+#include <map>
+#include <utility>
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <algorithm>
 #include <vector>
@@ -80,6 +82,7 @@ struct PairArgs {
 	BoundRec *cpool;            // bound records as the memo hands them out
 	uint32_t cpool_cap;
 	uint32_t *cpool_count;
+	void *cmemo;                // host replay of windowed targets (tnt_long.hip.h): the target's memo as a map, CacheMemo * (the lists hold 10^5 entries there; null: the evaluated citems of the run are searched)
 };
 
 // one group of an assay that goes through the cache replay: where its items were copied to
@@ -570,6 +573,7 @@ template <bool SCATTER> __global__ __launch_bounds__(256) void bucket_kernel(Buc
 	}
 }
 
+typedef std::map<std::pair<unsigned long long, unsigned long long>, uint32_t> CacheMemo; // host replay: (oligo, strand), window -> the citem evaluated first
 // One request to the reference's BindCache (tntblast.h:247-324; bind_oligo.cpp:508-512 miss, :750-803 / :396-428 hit).  The
 // entry stands for citem ci = -2 - rec.  Its key is (oligo string, window, strand); the memo of a key is the FIRST
 // evaluation of it on this target -- whatever strand concentration and threshold set asked --, holding what that caller's
@@ -584,6 +588,14 @@ TNT_HD inline void cache_resolve(const PairArgs &a, Entry &e, const ConflictRun 
 	const Slot sl = a.slots[it.info >> ITEM_SLOT_SHIFT];
 	const BindFull &own = a.cfull[ci];
 	uint32_t origin = ci;
+#if !defined(__HIP_DEVICE_COMPILE__)
+	if (a.cmemo) { // every evaluated citem of a key has the key's first evaluation as its origin: the map holds exactly that
+		CacheMemo &memo = *static_cast<CacheMemo *>(a.cmemo);
+		const std::pair<unsigned long long, unsigned long long> key((unsigned long long)(uint32_t(sl.oligo)) << 1 | ((it.info & ITEM_MINUS) ? 1u : 0u),
+		                                                             ((unsigned long long)uint32_t(own.target_start) << 32) | uint32_t(own.target_stop));
+		origin = memo.emplace(key, ci).first->second;
+	} else
+#endif
 	for (int g = 0; g < n_run && origin == ci; g++)
 		for (uint32_t x = run[g].cfirst; x < run[g].cfirst + run[g].count; x++) {
 			if (x == ci || a.corigin[x] == 0xFFFFFFFFu) continue;
@@ -710,15 +722,16 @@ template <int N, bool CACHED, bool WORK> TNT_HD void pair_group(const PairArgs &
 		const Item it = CACHED ? a.citems[cfirst + uint32_t(i)] : a.items[G.first + i];
 		const int32_t res = CACHED ? -2 - int32_t(cfirst + uint32_t(i)) : a.result[G.first + i];
 		{
-			const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u, wi = it.info & 127u;
+			// (word index over the whole oligo: the seeds of an oligo beyond 128 bases come from segments of 128 words, Slot::qloc_bias)
+			const uint32_t role = (it.info >> ITEM_SLOT_SHIFT) % 3u, wi = uint32_t(int32_t(it.info & 127u) + a.slots[it.info >> ITEM_SLOT_SHIFT].qloc_bias);
 			const bool minus = (it.info & ITEM_MINUS) != 0;
 			unsigned long long key;
 			if (A.kind == 0) {
 				const unsigned long long rank = role == 2 ? (minus ? 4u : 5u) : ((minus ? 0u : 2u) + role); // F-, R-, F+, R+, P-, P+
-				key = ((unsigned long long)it.tloc << 24) | (rank << 21) | ((unsigned long long)wi << 14);
+				key = ((unsigned long long)it.tloc << 28) | (rank << 25) | ((unsigned long long)wi << 14);
 			} else {
 				const unsigned long long listid = (minus ? 0u : 2u) + (role == 1 ? 0u : 1u);
-				key = (listid << 54) | ((unsigned long long)(long(wi) - long(it.tloc) + (1l << 33)) << 20) | ((unsigned long long)wi << 13);
+				key = (listid << 58) | ((unsigned long long)(long(wi) - long(it.tloc) + (1l << 33)) << 24) | ((unsigned long long)wi << 13);
 			}
 			order[i] = key;
 		}
