@@ -32,8 +32,8 @@ extern "C" {
 
 /* Longest oligo (the reference's MAX_SEQUENCE_LENGTH, nuc_cruc.h:80).  Up to 64 bases the rows of the alignment live
  * in registers, one window per lane; 65..128 run through an instance that keeps them in scratch memory; 129..1024 are
- * bound by the wavefront-per-window kernel (query rows across the lanes) -- in searches as the probes of probe-only
- * assays (hybridisation probes; primers and padlock arms of that length: TNT_E_LIMIT), at unit level anywhere.        */
+ * bound by the wavefront-per-window kernel (query rows across the lanes), in every role (a context with a primer, TaqMan
+ * probe or padlock arm of that length searches every target by the route of the targets that are seeded in windows).   */
 #define TNT_MAX_OLIGO 1024
 /* NUM_FLANK_BASE, tntblast.h:76 */
 #define TNT_FLANK 4
