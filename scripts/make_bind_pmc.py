@@ -8,7 +8,7 @@ import sys
 src = sys.argv[1]
 summary = json.load(open(src))
 d = summary["kernels"]
-stage = [k for k in ("bucket_kernel", "regroup_count_kernel", "regroup_scan_kernel", "regroup_scatter_kernel", "ufilter_kernel<L>", "filter_kernel<L>", "bind_kernel<L>") if k in d]
+stage = [k for k in ("bucket_kernel", "regroup_count_kernel", "regroup_scan_kernel", "regroup_scatter_kernel", "ufilter_kernel<L>", "filter_kernel<L>", "sbound_kernel", "bind_kernel<L>") if k in d]
 seed = "seed2_kernel" if "seed2_kernel" in d else "seed_kernel"  # (round 3: tnt_seed2.hip.h)
 fetch = sum(float(d[k]["FETCH_SIZE"]) for k in stage)   # KB per search (= per step of the full-size config)
 write = sum(float(d[k]["WRITE_SIZE"]) for k in stage)
@@ -20,7 +20,7 @@ out = {
     "git_head": summary.get("git_head"),
     "csrc_sha16": summary.get("csrc_sha16"),  # bench.py uses the counters only for a library built from these sources  # the build the counters were collected on (scripts/pmc_summarize.py reads .git_head)
     "source": "%s (rocprofv3 --pmc, separate passes, scripts/pmc_collect.sh 2 1000000, bind launches serialised on one stream)" % src,
-    "kernel": "bind stage of one step (config 2, 1 000 000 x 1 kb targets): regroup kernels + ufilter_kernel<L> (phase A) / bucket_kernel + filter_kernel<L> (phase B) + bind_kernel<L> on the survivors",
+    "kernel": "bind stage of one step (config 2, 1 000 000 x 1 kb targets): regroup kernels + ufilter_kernel<L> + sbound_kernel<L> (phase A) / bucket_kernel + filter_kernel<L> (phase B) + bind_kernel<L> on the survivors",
     "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
     "per_kernel_KB": {k: {"FETCH_SIZE": float(v["FETCH_SIZE"]), "WRITE_SIZE": float(v["WRITE_SIZE"])}
                       for k, v in d.items() if k in stage + [seed, "pair_kernel"]},
