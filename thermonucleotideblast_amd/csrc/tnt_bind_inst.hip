@@ -42,7 +42,7 @@ namespace tnt {
 #define S(N)                                                                                                         \
 	void launch_sbound_##N(const SBoundArgs &a, int blocks, hipStream_t stream)                                      \
 	{                                                                                                                \
-		hipLaunchKernelGGL((sbound_kernel<N, (N >= 17)>), dim3(blocks), dim3(sb_threads(N)), 0, stream, a);                                \
+		hipLaunchKernelGGL((sbound_kernel<N, (N >= 17)>), dim3(blocks), dim3(SB_THREADS), 0, stream, a);                                \
 	}
 #define G(N) TNT_LAUNCHER(launch_bind_##N, N, false, false)
 #define P(N) TNT_LAUNCHER(launch_bind_plain_##N, N, false, true)

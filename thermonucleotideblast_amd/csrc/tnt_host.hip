@@ -698,6 +698,7 @@ struct tnt_ctx {
 		DevBuf<uint4> qfat;       // phase-A queues of the round-3 seed kernel: self-contained entries (FilterArgs2::fat)
 		DevBuf<uint4> qsort;      // ... regrouped by (oligo, class): bucket i at q_base[i] + 64 * rg_bin_base[i] (UFilterArgs::fat)
 		DevBuf<uint32_t> rg_hist, rg_cursor; // [rg_total_bins] entries per bin of the batch, next free slot of its run
+		DevBuf<uint32_t> rg_fill;            // ... survivors of the pre-filter's first tier handed to the second (by group: tnt_sbound.hip.h)
 		DevBuf<uint8_t> audit;    // audit mode: 1 = the filter would reject this item
 		DevBuf<uint32_t> item_rep;
 		DevBuf<BoundRec> pool;
@@ -1178,6 +1179,12 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			f.status_exact = c->filter_status_exact ? 1 : 0;
 			const int rows = c->bucket_lmax[i] & 0xFF;
 			const bool degen = !(c->bucket_lmax[i] & BUCKET_PLAIN);
+			// Second tier on the survivors (tnt_sbound.hip.h): plain windows of oligos of up to 40 bases in a regrouped bucket -- a
+			// trace-free fill of align_dimer's own recurrence whose maximum carries the credit of the maximal-score paths; the first
+			// tier hands its survivors over group by group, so that a wavefront of the second holds one oligo as well.  (Not where the
+			// caller reports statuses: a window this tier rejects against the maximum dG may fail the Tm range first.)
+			const bool second = regrouped && c->rg_desc_of[i] >= 0 && c->tier2 && c->S().qsurv2.p && c->S().rg_fill.p && (c->bucket_lmax[i] & BUCKET_PLAIN) && has_sbound_instance(rows) &&
+			                    (rows < 17 || (c->bucket_lmax[i] & BUCKET_EXACT)) && c->h_rg_desc[size_t(c->rg_desc_of[i])].n_bins <= uint32_t(SB_MAX_BINS) && !c->filter_status_exact && !split;
 			if (regrouped && c->rg_desc_of[i] >= 0) {
 				const RegroupBucket &B = c->h_rg_desc[size_t(c->rg_desc_of[i])];
 				UFilterArgs u;
@@ -1190,7 +1197,25 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 				u.next_block = cnt + C_BUCKET + B.counter + 5;
 				u.survivors = f.survivors, u.n_survivors = f.n_survivors, u.n_rejected = f.n_rejected;
 				u.audit = f.audit, u.status_exact = f.status_exact;
+				if (second) { // survivors by group, in the regrouped queue's own geometry
+					u.survivors = c->S().qsurv.p + B.dst_base;
+					u.slot_bin = c->slot_bin.p, u.general = B.general;
+					u.bin_end = c->S().rg_cursor.p + B.bin_base, u.bin_count = c->S().rg_hist.p + B.bin_base, u.bin_fill = c->S().rg_fill.p + B.bin_base;
+				}
 				launch_ufilter(u, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], degen);
+				if (second) {
+					SBoundArgs sb;
+					memset(&sb, 0, sizeof(sb));
+					sb.tab = c->stab.p, sb.ftab = c->ftab.p, sb.db = v;
+					sb.olig_q4 = b.olig_q4, sb.olig_len = b.olig_len, sb.slots = b.slots, sb.items = b.items;
+					sb.index = u.survivors, sb.bin_end = u.bin_end, sb.bin_count = u.bin_count, sb.bin_fill = u.bin_fill, sb.n_bins = B.n_bins;
+					sb.next_work = cnt + C_BUCKET + B.counter + 6;
+					sb.survivors = c->S().qsurv2.p + c->h_q_base[i];
+					sb.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 7;
+					sb.result = b.result, sb.n_rejected = gcnt + C_FILTERED, sb.audit = f.audit;
+					launch_sbound(sb, c->n_cu * 3, rows, c->lane_stream[lane]);
+					f.survivors = sb.survivors, f.n_survivors = sb.n_survivors; // what the bind kernel takes
+				}
 			} else {
 				launch_filter(f, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], degen);
 			}
@@ -1199,27 +1224,10 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 				(void)hipEventRecord(c->filtered[i], c->lane_stream[0]);
 				(void)hipStreamWaitEvent(c->lane_stream[lane], c->filtered[i], 0);
 			}
-			b.index = survivors;
+			b.index = f.survivors;
 			b.index_stride = 1;
 			b.n_items_dev = f.n_survivors;
 			b.audit = f.audit;
-			// Second tier on the survivors (tnt_sbound.hip.h): plain windows of oligos of up to 40 bases -- a trace-free fill of
-			// align_dimer's own recurrence whose maximum carries the credit of the maximal-score paths.  (Not where the caller
-			// reports statuses: a window this tier rejects against the maximum dG may fail the Tm range first.)
-			if (c->tier2 && c->S().qsurv2.p && (c->bucket_lmax[i] & BUCKET_PLAIN) && has_sbound_instance(rows) && (rows < 17 || (c->bucket_lmax[i] & BUCKET_EXACT)) &&
-			    !c->filter_status_exact && !split) {
-				SBoundArgs sb;
-				memset(&sb, 0, sizeof(sb));
-				sb.tab = c->stab.p, sb.ftab = c->ftab.p, sb.db = v;
-				sb.olig_q4 = b.olig_q4, sb.olig_len = b.olig_len, sb.slots = b.slots, sb.items = b.items;
-				sb.index = survivors, sb.index_base_dev = b.index_base_dev, sb.n_items_dev = f.n_survivors, sb.n_items = queue_cap;
-				sb.survivors = c->S().qsurv2.p + (direct ? c->h_q_base[i] : 0u);
-				sb.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 7;
-				sb.result = b.result, sb.n_rejected = gcnt + C_FILTERED, sb.audit = f.audit;
-				launch_sbound(sb, c->n_cu * (sb_threads(rows) == 512 ? 2 : 3), rows, c->lane_stream[lane]);
-				b.index = sb.survivors;
-				b.n_items_dev = sb.n_survivors;
-			}
 		}
 		b.trace = c->trace.p + size_t(lane) * c->lane_trace;
 		b.best = c->best.p + size_t(lane) * c->lane_cols;
@@ -1281,13 +1289,14 @@ int alloc_set(tnt_ctx *c, int k)
 	HIP_TRY(W.qa.alloc(c->item_cap), c->err);
 	HIP_TRY(W.qb.alloc(c->item_cap), c->err);
 	HIP_TRY(W.qbucket.alloc(c->item_cap), c->err);
-	if (c->filter_on) HIP_TRY(W.qsurv.alloc(c->item_cap), c->err);
+	if (c->filter_on) HIP_TRY(W.qsurv.alloc(c->item_cap + size_t(UF_BLOCK) * c->rg_total_bins), c->err); // (a regrouped bucket's survivors keep the regrouped queue's geometry)
 	if (c->tier2) HIP_TRY(W.qsurv2.alloc(c->item_cap), c->err);
 	if (c->seed2) HIP_TRY(W.qfat.alloc(c->item_cap), c->err);
 	if (c->seed2 && c->regroup) {
 		HIP_TRY(W.qsort.alloc(c->item_cap + size_t(UF_BLOCK) * c->rg_total_bins), c->err);
 		HIP_TRY(W.rg_hist.alloc(std::max<size_t>(1, c->rg_total_bins)), c->err);
 		HIP_TRY(W.rg_cursor.alloc(std::max<size_t>(1, c->rg_total_bins)), c->err);
+		HIP_TRY(W.rg_fill.alloc(std::max<size_t>(1, c->rg_total_bins)), c->err);
 	}
 	if (c->filter_audit) HIP_TRY(W.audit.alloc(c->item_cap), c->err);
 	if (c->dedupe) HIP_TRY(W.item_rep.alloc(c->item_cap), c->err);
@@ -2716,6 +2725,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		HIP_TRY(hipMemsetAsync(c->S().q_state.p, 0, sizeof(uint32_t) * size_t(regions) * MAX_BUCKETS * 2, seed_stream), c->err);
 		HIP_TRY(hipMemsetAsync(cnt + C_BUCKET, 0, sizeof(uint32_t) * MAX_BUCKETS * BUCKET_STRIDE, seed_stream), c->err);
 		if (c->regroup && c->rg_total_bins) HIP_TRY(hipMemsetAsync(c->S().rg_hist.p, 0, sizeof(uint32_t) * c->rg_total_bins, seed_stream), c->err);
+		if (c->regroup && c->rg_total_bins && c->S().rg_fill.p) HIP_TRY(hipMemsetAsync(c->S().rg_fill.p, 0, sizeof(uint32_t) * c->rg_total_bins, seed_stream), c->err);
 		Seed2Args q;
 		memset(&q, 0, sizeof(q));
 		q.db = v;
@@ -4127,7 +4137,7 @@ int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, si
 	}
 	std::vector<Slot> slots(n);
 	std::vector<Item> items(n);
-	std::map<int, std::vector<uint32_t>> by_rows; // instance (rows) -> requests it serves
+	std::map<std::tuple<int, int, int>, std::vector<uint32_t>> by_group; // (instance rows, oligo, threshold class) -> requests: the kernel takes one oligo per wavefront
 	for (size_t i = 0; i < n; i++) {
 		const tnt_bind_req &r = req[i];
 		const size_t t = size_t(r.seq_index) - db->first_seq_index;
@@ -4145,30 +4155,47 @@ int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, si
 		const uint32_t *eb = db->h_exc_pos.data() + db->h_exc_off[t], *ee = db->h_exc_pos.data() + db->h_exc_off[t + 1];
 		const uint32_t *it = std::lower_bound(eb, ee, uint32_t(start));
 		const int rows = pick_instance(size_t(L)) & 0xFF;
-		if ((it == ee || *it >= stop) && L <= SB_MAX_ROWS && has_sbound_instance(rows)) by_rows[rows].push_back(uint32_t(i)); // plain windows of oligos of up to 40 bases
+		if ((it == ee || *it >= stop) && L <= SB_MAX_ROWS && has_sbound_instance(rows)) by_group[std::make_tuple(rows, r.oligo, r.role == 1 ? 1 : 0)].push_back(uint32_t(i)); // plain windows of oligos of up to 40 bases
 	}
 	DevBuf<Slot> dslots;
 	DevBuf<int32_t> dscore;
-	DevBuf<uint32_t> dindex;
+	DevBuf<uint32_t> dindex, dfirst, dfill, dwork;
 	HIP_TRY(dslots.upload(slots), ctx->err);
 	HIP_TRY(dscore.alloc(2 * n), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	HIP_TRY(hipMemcpy(ctx->S().items.p, items.data(), n * sizeof(Item), hipMemcpyHostToDevice), ctx->err);
 	HIP_TRY(hipMemcpy(dscore.p, score, 2 * n * sizeof(int32_t), hipMemcpyHostToDevice), ctx->err);
-	std::vector<uint32_t> order;
-	for (const auto &kv : by_rows) order.insert(order.end(), kv.second.begin(), kv.second.end());
+	// the groups side by side, a launch per instance and SB_MAX_BINS groups
+	struct Launch {
+		int rows;
+		uint32_t g0, n_groups;
+	};
+	std::vector<uint32_t> order, first, fill;
+	std::vector<Launch> launches;
+	for (const auto &kv : by_group) {
+		const int rows = std::get<0>(kv.first);
+		if (launches.empty() || launches.back().rows != rows || launches.back().n_groups == uint32_t(SB_MAX_BINS)) launches.push_back(Launch{rows, uint32_t(first.size()), 0u});
+		launches.back().n_groups++;
+		first.push_back(uint32_t(order.size())), fill.push_back(uint32_t(kv.second.size()));
+		order.insert(order.end(), kv.second.begin(), kv.second.end());
+	}
+	if (order.empty()) return TNT_OK;
 	HIP_TRY(dindex.upload(order), ctx->err);
+	HIP_TRY(dfirst.upload(first), ctx->err);
+	HIP_TRY(dfill.upload(fill), ctx->err);
+	HIP_TRY(dwork.upload(std::vector<uint32_t>(launches.size(), 0u)), ctx->err);
 	SBoundArgs sb;
 	memset(&sb, 0, sizeof(sb));
 	sb.tab = ctx->stab.p, sb.ftab = ctx->ftab.p, sb.db = make_view(db, 0, db->n_targets);
 	sb.olig_q4 = ctx->olig_q4.p, sb.olig_len = ctx->olig_len.p, sb.slots = dslots.p, sb.items = ctx->S().items.p;
 	sb.score_out = dscore.p;
-	size_t at = 0;
-	for (const auto &kv : by_rows) {
-		sb.index = dindex.p + at;
-		sb.n_items = uint32_t(kv.second.size());
-		launch_sbound(sb, int(std::min<size_t>(size_t(ctx->n_cu) * 2, (kv.second.size() + 255) / 256)), kv.first, ctx->stream);
-		at += kv.second.size();
+	sb.index = dindex.p;
+	for (size_t l = 0; l < launches.size(); l++) {
+		sb.bin_end = dfirst.p + launches[l].g0, sb.bin_count = nullptr, sb.bin_fill = dfill.p + launches[l].g0, sb.n_bins = launches[l].n_groups;
+		sb.next_work = dwork.p + l;
+		size_t blocks = 0;
+		for (uint32_t g = 0; g < launches[l].n_groups; g++) blocks += (fill[launches[l].g0 + g] + SB_BLOCK - 1) / SB_BLOCK;
+		launch_sbound(sb, int(std::min<size_t>(size_t(ctx->n_cu) * 3, (blocks + SB_WAVES - 1) / SB_WAVES)), launches[l].rows, ctx->stream);
 	}
 	HIP_TRY(hipGetLastError(), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);

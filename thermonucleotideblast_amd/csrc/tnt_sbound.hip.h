@@ -23,7 +23,8 @@
 // than 2^10 units, so bit 10 of the credit field is a guard: once it is set in any state the window passes (20.48 kcal/mol is
 // above every threshold this tier is enabled for) and what the sums do afterwards is ignored.
 //
-// No trace words, no traceback, no scoring: 17 instructions and two LDS reads per cell against the fill's 36 and nothing behind them.  Plain
+// No trace words, no traceback, no scoring: 14 instructions and two LDS reads at immediate offsets per cell against the fill's 36
+// and nothing behind them; the first tier hands its survivors over group by group, so a wavefront holds ONE oligo's table.  Plain
 // windows (A/C/G/T targets) of oligos of up to 40 bases; everything else goes from the first tier straight to the bind kernel.
 // tests: tests/test_filter_bound.py (soundness of the oracle-side restatement, tier 3), tests/test_gpu_parity.py
 // (kernel == restatement; searches with the tier on / off / in audit mode).
@@ -45,12 +46,19 @@ constexpr int SB_X = 5;                      // target base of a column: A C G T
 constexpr int SB_ENTRIES = SB_X * SB_X * NBP; // index ((x' * 5 + x) * 49 + q' * 7 + q): diagonal predecessor (x', q'), cell (x, q)
 constexpr int SB_MAX_ROWS = 40;              // instances (score < 2^20 units for oligos of up to 40 bases: the host checks the table)
 constexpr int SB_NEG = -(1 << 30);           // a forbidden transition
-// Workgroup size per instance: the tables take 39 KB of LDS per workgroup, the states 3 registers per row.  Up to 25 rows fit 128
-// registers (4 wavefronts per SIMD: two workgroups of 8); beyond that 3 or 2 per SIMD, reached with workgroups of 4.
-constexpr int sb_threads(int lmax) { return lmax <= 25 ? 512 : 256; }
-constexpr int sb_waves_per_simd(int lmax) { return lmax <= 25 ? 4 : (lmax <= 37 ? 3 : 2); }
+constexpr int SB_THREADS = 256, SB_WAVES = SB_THREADS / 64;
+constexpr int SB_MAX_BINS = 1024;            // groups of one launch (their block counts are prefix-summed in LDS)
+constexpr uint32_t SB_BLOCK = 64;            // survivors of one group a wavefront takes at a time
+constexpr uint32_t SB_CHUNK = 1;             // blocks a wavefront grabs per atomic (a bucket has a few thousand blocks for the device's three thousand wavefronts: taken one at a time)
+constexpr uint32_t SB_HOLE = 0xFFFFFFFFu;
+// column index of (x', x): the sixteen pairs of real bases first, so that the lanes of a wavefront -- which differ in nothing but
+// their column -- read sixteen different bank groups (the pitch of a column is an odd number of 16-byte entries)
+constexpr int SB_COLS = SB_X * SB_X;
+__host__ __device__ constexpr int sb_col(int xp, int x) { return (xp < 4 && x < 4) ? xp * 4 + x : (xp == 4 ? 16 + x : 21 + xp); }
+constexpr int sb_pitch(int lmax) { return (((lmax + 1) | 1)) * 16; } // bytes between two columns of the per-oligo table
+constexpr int sb_waves_per_simd(int lmax) { return lmax <= 25 ? 3 : 2; } // (LDS: four per-oligo tables per workgroup)
 
-// One 16-byte entry per (x', x, q', q), read with ONE ds_read_b128: [0] the diagonal step, [1] into an aligned column from a gap
+// One 16-byte entry per (x', x, q', q), read with ONE ds_read_b96: [0] the diagonal step, [1] into an aligned column from a gap
 // state, [2] from an aligned column into a gap state (read at the NEXT row's / the NEXT column's entry), [3] unused.
 struct SBoundTables {
 	int32_t entry[FILT_CLASSES][SB_ENTRIES][4];
@@ -66,11 +74,14 @@ struct SBoundArgs {
 	const int32_t *olig_len;
 	const Slot *slots;
 	const Item *items;
-	const uint32_t *index;        // the first tier's survivors (item indices), from index[*index_base_dev]
-	const uint32_t *index_base_dev;
-	const uint32_t *n_items_dev;
-	uint32_t n_items;             // cap on the device count
-	uint32_t *survivors;          // out: the windows that go on to the bind kernel, from survivors[*index_base_dev]
+	// The first tier's survivors BY GROUP (one oligo and threshold class each): the survivors of group g are
+	// index[bin_end[g] - bin_count[g] ...], bin_fill[g] of them (ufilter_kernel wrote them to the front of the group's run of the
+	// regrouped queue; bin_count null: bin_end holds the first index itself).
+	const uint32_t *index;
+	const uint32_t *bin_end, *bin_count, *bin_fill;
+	uint32_t n_bins;
+	uint32_t *next_work;          // work counter of the launch (zeroed per batch)
+	uint32_t *survivors;          // out: the windows that go on to the bind kernel (one dense list)
 	uint32_t *n_survivors;
 	int32_t *result;              // rejected windows: -1 (Tm below the minimum, bind_oligo.cpp:600-606)
 	uint32_t *n_rejected;         // statistics
@@ -79,224 +90,278 @@ struct SBoundArgs {
 	int32_t *dp_out;              // optional (unit-level entry): [idx] the maximal score of the fill
 };
 
+// One wavefront = 64 survivors of ONE oligo (as in ufilter_kernel): its table sits in LDS as T[column (x', x)][row], an entry per
+// row -- the read of a cell is an immediate offset on the column's base register, and the lanes differ in the column only.
 // EXACT: every oligo of the launch has exactly LMAX bases (the exact-length buckets; the instance of 16 rows serves shorter ones).
-template <int LMAX, bool EXACT> __global__ __launch_bounds__(sb_threads(LMAX), sb_waves_per_simd(LMAX)) void sbound_kernel(SBoundArgs a)
+template <int LMAX, bool EXACT> __global__ __launch_bounds__(SB_THREADS, sb_waves_per_simd(LMAX)) void sbound_kernel(SBoundArgs a)
 {
 	static_assert(LMAX <= SB_MAX_ROWS, "instances of up to 40 rows");
-	constexpr int THREADS = sb_threads(LMAX);
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NW = (WMAX + 15) / 16;
-	constexpr int NR = (LMAX + 1 + 3) / 4;   // row constants, four to a register
-	constexpr int CLS_BYTES = SB_ENTRIES * 16;
-	typedef int32_t i32x4 __attribute__((ext_vector_type(3))); // (three of the entry's four words: a dead fourth register would be reused before the read lands)
-	__shared__ __attribute__((aligned(16))) int32_t s_tab[FILT_CLASSES * SB_ENTRIES * 4];
-	__shared__ uint32_t s_keep[THREADS / 64][128];
-	__shared__ uint32_t s_wcount[THREADS / 64], s_wbase;
+	constexpr int PITCH = sb_pitch(LMAX);    // bytes
+	typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+	typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+	__shared__ __attribute__((aligned(16))) int32_t s_tab[SB_WAVES][SB_COLS * PITCH / 4];
+	__shared__ uint32_t s_pref[SB_MAX_BINS + 1];  // blocks of the groups before group g
+	__shared__ uint32_t s_part[SB_THREADS];
+	__shared__ uint32_t s_keep[SB_WAVES][128];
+	__shared__ uint32_t s_wcount[SB_WAVES], s_wbase;
 	typedef __attribute__((address_space(3))) const int32_t lds_ci32;
-	typedef __attribute__((address_space(3))) const i32x4 lds_ci32x4;
+	typedef __attribute__((address_space(3))) const i32x3 lds_ci32x3;
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint32_t n_items = a.n_items;
-	if (a.n_items_dev) {
-		const uint32_t n_dev = *a.n_items_dev;
-		n_items = n_dev < n_items ? n_dev : n_items;
+	// ---- the launch's work: blocks of 64 survivors, group after group
+	{
+		const uint32_t n_bins = a.n_bins < uint32_t(SB_MAX_BINS) ? a.n_bins : uint32_t(SB_MAX_BINS);
+		constexpr uint32_t PER = SB_MAX_BINS / SB_THREADS;
+		uint32_t mine[PER], sum = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < PER; k++) {
+			const uint32_t g = uint32_t(tid) * PER + k;
+			mine[k] = g < n_bins ? (a.bin_fill[g] + SB_BLOCK - 1) / SB_BLOCK : 0u;
+			sum += mine[k];
+		}
+		s_part[tid] = sum;
+		__syncthreads();
+		for (int d = 1; d < SB_THREADS; d <<= 1) { // inclusive scan
+			const uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+			__syncthreads();
+			s_part[tid] += v;
+			__syncthreads();
+		}
+		uint32_t run = s_part[tid] - sum;
+#pragma unroll
+		for (uint32_t k = 0; k < PER; k++) {
+			s_pref[uint32_t(tid) * PER + k] = run;
+			run += mine[k];
+		}
+		if (tid == SB_THREADS - 1) s_pref[SB_MAX_BINS] = run;
+		__syncthreads();
 	}
-	if (uint32_t(blockIdx.x) * uint32_t(THREADS) >= n_items) return; // (nothing to do: leave before staging 39 KB of tables)
-	for (int i = tid; i < FILT_CLASSES * SB_ENTRIES * 4; i += THREADS) s_tab[i] = (&a.tab->entry[0][0][0])[i];
-	__syncthreads();
+	const uint32_t n_work = s_pref[SB_MAX_BINS];
 	const int c_bulge = a.tab->bulge, c_zero = a.tab->zero, c_forb_m = a.tab->forb_m, c_forb_xy = a.tab->forb_xy;
-	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
-	uint32_t *surv = a.survivors ? a.survivors + (a.index_base_dev ? *a.index_base_dev : 0u) : nullptr;
 	uint32_t n_rej = 0, n_keep = 0;
+	int cur_oligo = -1, cur_cls = -1;
+	int32_t *tabw = s_tab[wave];
+	const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)tabw)));
+	auto rd3 = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32x3 *)(uintptr_t(uint32_t(addr))); };
+	auto rd = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32 *)(uintptr_t(uint32_t(addr))); };
 
-	for (uint32_t base = blockIdx.x * THREADS; base < n_items; base += gridDim.x * THREADS) {
-		const uint32_t idx = base + tid < n_items ? index[base + tid] : 0xFFFFFFFFu;
-		const bool active = idx != 0xFFFFFFFFu;
-		const Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
-		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
-		const int L = active ? (EXACT ? LMAX : a.olig_len[slot.oligo]) : 0;
-		const bool minus = (it.info & ITEM_MINUS) != 0;
-		// the window, bind_oligo.cpp:502-505 (plain windows only: no exception inside)
-		int start = int(it.tloc) - (int(it.info & 127u) + slot.qloc_bias + FLANK);
-		if (start < 0) start = 0;
-		int stop = start + L + 2 * FLANK;
-		const int tlen = active ? int(a.db.len[it.target]) : 0;
-		if (stop > tlen) stop = tlen;
-		const int W = active ? stop - start : 0;
-		// ... in column order, 2 bits per column (ufilter_kernel's form): column j = target[j - 1] as NucCruc holds it
-		uint32_t ov[NW];
+	for (;;) {
+		uint32_t w0 = 0;
+		if (lane == 0) w0 = atomicAdd(a.next_work, SB_CHUNK);
+		w0 = uint32_t(__builtin_amdgcn_readfirstlane(int(w0)));
+		if (w0 >= n_work) break;
+		const uint32_t w1 = w0 + SB_CHUNK < n_work ? w0 + SB_CHUNK : n_work;
+		// the group of block w0: the last one whose first block is not behind it
+		uint32_t g = 0;
 		{
-			const uint32_t *pk = a.db.packed + (active ? a.db.word_off[it.target] : 0ull) + uint32_t(start >> 4);
-			uint32_t raw[NW + 1];
-#pragma unroll
-			for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u;
-			const uint32_t sh = uint32_t(start & 15) * 2u;
-#pragma unroll
-			for (int k = 0; k < NW; k++) ov[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
-			if (__builtin_amdgcn_ballot_w64(minus) != 0) {
-				uint32_t rv[NW + 1];
-#pragma unroll
-				for (int k = 0; k < NW; k++) {
-					const uint32_t r = __builtin_bitreverse32(ov[NW - 1 - k]);
-					rv[k] = ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+			uint32_t lo = 0, hi = a.n_bins < uint32_t(SB_MAX_BINS) ? a.n_bins : uint32_t(SB_MAX_BINS);
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_pref[mid] <= w0) lo = mid;
+				else hi = mid;
+			}
+			g = lo;
+		}
+		for (uint32_t w = w0; w < w1; w++) {
+			while (s_pref[g + 1] <= w) g++; // (groups without survivors have no block)
+			const uint32_t fill = a.bin_fill[g], first = a.bin_end[g] - (a.bin_count ? a.bin_count[g] : 0u);
+			const uint32_t at = (w - s_pref[g]) * SB_BLOCK + uint32_t(lane);
+			const uint32_t idx = at < fill ? a.index[first + at] : SB_HOLE;
+			const bool active = idx != SB_HOLE;
+			const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+			if (am == 0) continue;
+			const Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
+			// the block's oligo and threshold class: those of its first survivor (a group holds one (oligo, class))
+			const int lead = __builtin_ctzll(am);
+			const uint32_t lead_slot = uint32_t(__builtin_amdgcn_readlane(int(it.info), lead)) >> ITEM_SLOT_SHIFT;
+			const Slot ls = a.slots[lead_slot];
+			const int oligo = __builtin_amdgcn_readfirstlane(ls.oligo), cls = __builtin_amdgcn_readfirstlane(filter_class(ls.thresh));
+			const int L = EXACT ? LMAX : __builtin_amdgcn_readfirstlane(a.olig_len[oligo]);
+			if (oligo != cur_oligo || cls != cur_cls) {
+				// T[column][i] = entry[cls][(x' * 5 + x) * 49 + 7 * q' + q] for i = 0 .. LMAX: q the base of row i + 1 (none behind the
+				// oligo: the row behind the last one is read for the credit of a gap opened in the last row), q' the base of the row above
+				// (none above the first)
+				filt_wave_sync(); // (the lanes' reads of the last block's table are through)
+				const i32x4 *src = reinterpret_cast<const i32x4 *>(&a.tab->entry[cls][0][0]);
+				const uint32_t *q4 = a.olig_q4 + size_t(oligo) * (MAX_OLIGO / 4);
+#pragma unroll 4
+				for (int e0 = 0; e0 < SB_COLS * (LMAX + 1); e0 += 64) { // (unrolled by four: the reads of four rounds are in flight together)
+					const int e = e0 + lane;
+					if (e >= SB_COLS * (LMAX + 1)) break;
+					const int xx = e / (LMAX + 1), i = e - xx * (LMAX + 1);
+					const int xp = xx / SB_X, x = xx - xp * SB_X;
+					uint32_t q = bGAP, qp = bGAP;
+					if (i < L) q = (q4[i >> 2] >> ((i & 3) * 8 + 2)) & 7u;
+					if (i >= 1 && i - 1 < L) qp = (q4[(i - 1) >> 2] >> (((i - 1) & 3) * 8 + 2)) & 7u;
+					*reinterpret_cast<i32x4 *>(reinterpret_cast<char *>(tabw) + sb_col(xp, x) * PITCH + i * 16) = src[xx * NBP + int(7u * qp + q)];
 				}
-				rv[NW] = 0;
-				const uint32_t slack = uint32_t(16 * NW - W) * 2u;
+				cur_oligo = oligo, cur_cls = cls;
+				filt_wave_sync();
+			}
+			const Slot slot = a.slots[active ? it.info >> ITEM_SLOT_SHIFT : lead_slot];
+			const bool minus = (it.info & ITEM_MINUS) != 0;
+			// the window, bind_oligo.cpp:502-505 (plain windows only: no exception inside)
+			int start = int(it.tloc) - (int(it.info & 127u) + slot.qloc_bias + FLANK);
+			if (start < 0) start = 0;
+			int stop = start + L + 2 * FLANK;
+			const int tlen = active ? int(a.db.len[it.target]) : 0;
+			if (stop > tlen) stop = tlen;
+			const int W = active ? stop - start : 0;
+			// ... in column order, 2 bits per column (ufilter_kernel's form): column j = target[j - 1] as NucCruc holds it
+			uint32_t ov[NW];
+			{
+				const uint32_t *pk = a.db.packed + (active ? a.db.word_off[it.target] : 0ull) + uint32_t(start >> 4);
+				uint32_t raw[NW + 1];
 #pragma unroll
-				for (int step = NW - 1; step >= 1; step--) {
-					const bool drop = (slack >> 5) >= uint32_t(step);
+				for (int k = 0; k <= NW; k++) raw[k] = active ? pk[k] : 0u;
+				const uint32_t sh = uint32_t(start & 15) * 2u;
 #pragma unroll
-					for (int k = 0; k < NW; k++) rv[k] = drop ? rv[k + 1] : rv[k];
-				}
-				const uint32_t bits = slack & 31u;
+				for (int k = 0; k < NW; k++) ov[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
+				if (__builtin_amdgcn_ballot_w64(minus) != 0) {
+					uint32_t rv[NW + 1];
 #pragma unroll
-				for (int k = 0; k < NW; k++) {
-					const uint32_t v = __builtin_amdgcn_alignbit(rv[k + 1], rv[k], bits);
-					ov[k] = minus ? v : ov[k];
+					for (int k = 0; k < NW; k++) {
+						const uint32_t r = __builtin_bitreverse32(ov[NW - 1 - k]);
+						rv[k] = ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+					}
+					rv[NW] = 0;
+					const uint32_t slack = uint32_t(16 * NW - W) * 2u;
+#pragma unroll
+					for (int step = NW - 1; step >= 1; step--) {
+						const bool drop = (slack >> 5) >= uint32_t(step);
+#pragma unroll
+						for (int k = 0; k < NW; k++) rv[k] = drop ? rv[k + 1] : rv[k];
+					}
+					const uint32_t bits = slack & 31u;
+#pragma unroll
+					for (int k = 0; k < NW; k++) {
+						const uint32_t v = __builtin_amdgcn_alignbit(rv[k + 1], rv[k], bits);
+						ov[k] = minus ? v : ov[k];
+					}
 				}
 			}
-		}
-		// row constants 7 * q' + q of rows 1 .. LMAX + 1, a byte each (q' the base of the row above, none above the first; rows
-		// behind the oligo hold "none": the row behind the last one is read for the credit of a gap opened in the last row)
-		uint32_t Rp[NR];
-		{
+
+			int Wwave = W;
 #pragma unroll
-			for (int k = 0; k < NR; k++) Rp[k] = 0;
-			uint32_t qprev = bGAP;
-#pragma unroll
-			for (int i = 0; i <= LMAX; i++) {
-				uint32_t q = bGAP;
-				if (i < LMAX) {
-					const uint32_t q4w = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + (i >> 2)] : 0u;
-					q = (q4w >> ((i & 3) * 8 + 2)) & 7u;
-					if (!EXACT && i >= L) q = bGAP;
-				}
-				Rp[i >> 2] |= (7u * qprev + q) << ((i & 3) * 8);
-				qprev = q;
+			for (int o = 32; o > 0; o >>= 1) {
+				const int other = __shfl_xor(Wwave, o);
+				Wwave = other > Wwave ? other : Wwave;
 			}
-		}
-		const int cls = filter_class(slot.thresh);
-		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * CLS_BYTES;
-		auto rd4 = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32x4 *)(uintptr_t(uint32_t(addr))); };
-		auto rd = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32 *)(uintptr_t(uint32_t(addr))); };
-		auto rowc = [&](int i) __attribute__((always_inline)) { return int((Rp[i >> 2] >> ((i & 3) * 8)) & 0xFFu) * 16; }; // byte offset of row i + 1's entry
+			Wwave = __builtin_amdgcn_readfirstlane(Wwave);
 
-		int Wwave = W;
+			// states of the previous column, clamped at zero (what the next column reads; the border holds -1: zero)
+			int oM[LMAX], oQ[LMAX], oT[LMAX];
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
-			const int other = __shfl_xor(Wwave, o);
-			Wwave = other > Wwave ? other : Wwave;
-		}
-		Wwave = __builtin_amdgcn_readfirstlane(Wwave);
-
-		// states of the previous column, clamped at zero (what the next column reads; the border holds -1: zero)
-		int oM[LMAX], oQ[LMAX], oT[LMAX];
+			for (int i = 0; i < LMAX; i++) oM[i] = oQ[i] = oT[i] = 0;
+			int vmax = 0, sticky = 0;
+			auto base_of = [&](int j) __attribute__((always_inline)) { // target base of column j (1-based), SB_X - 1 outside the window
+				uint32_t wd = ov[0];
 #pragma unroll
-		for (int i = 0; i < LMAX; i++) oM[i] = oQ[i] = oT[i] = 0;
-		int vmax = 0, sticky = 0;
-		auto base_of = [&](int j) __attribute__((always_inline)) { // target base of column j (1-based), SB_X - 1 outside the window
-			uint32_t w = ov[0];
-#pragma unroll
-			for (int k = 1; k < NW; k++) w = ((j - 1) >> 4) == k ? ov[k] : w;
-			const int b = int((w >> (((j - 1) & 15) * 2)) & 3u);
-			return (j >= 1 && j <= W) ? b : SB_X - 1;
-		};
-		int tp = SB_X - 1, t = base_of(1);
+				for (int k = 1; k < NW; k++) wd = ((j - 1) >> 4) == k ? ov[k] : wd;
+				const int b = int((wd >> (((j - 1) & 15) * 2)) & 3u);
+				return (j >= 1 && j <= W) ? b : SB_X - 1;
+			};
+			auto col_of = [&](int xp, int x) __attribute__((always_inline)) { // sb_col, with selects
+				const int inner = xp * 4 + x, edge = xp == 4 ? 16 + x : 21 + xp;
+				return (xp < 4 && x < 4) ? inner : edge;
+			};
+			int tp = SB_X - 1, t = base_of(1);
 #pragma unroll 1
-		for (int j = 1; j <= Wwave; j++) {
-			const int tn = base_of(j + 1);
-			const bool colok = j <= W;
-			const bool firstcol = j == 1;
-			const int colA = tab_base + (tp * SB_X + t) * (NBP * 16);     // (x', x) = (previous column, this column)
-			const int colN = tab_base + (t * SB_X + tn) * (NBP * 16) + 8; // (this column, next column): the credit of a gap opened in the target strand
-			const int v5 = firstcol ? c_zero : c_bulge;
-			const int q_first = firstcol ? SB_NEG / 2 : 0;                // (no aligned column before the first: nothing closes a gap state there)
+			for (int j = 1; j <= Wwave; j++) {
+				const int tn = base_of(j + 1);
+				const bool colok = j <= W;
+				const bool firstcol = j == 1;
+				const int colA = tab_base + col_of(tp, t) * PITCH;     // (x', x) = (previous column, this column)
+				const int colN = tab_base + col_of(t, tn) * PITCH + 8; // (this column, next column): the credit of a gap opened in the target strand
+				const int v5 = firstcol ? c_zero : c_bulge;
+				const int q_first = firstcol ? SB_NEG / 2 : 0;         // (no aligned column before the first: nothing closes a gap state there)
+				int uM = 0, uT = 0;         // (i - 1, j), new values
+				int colmax = 0, colst = 0;
+				// the entries of rows i and i + 1 are in flight while row i - 1 is computed
+				i32x3 e0 = rd3(colA), e1 = rd3(colA + 16);
+				int g0 = rd(colN);
+				// Row i also forms the diagonal candidates of row i + 1 (the bind kernel's arrangement): they need the old states of
+				// row i, which die there, so the new states take their registers and nothing is copied at the loop's back edge.
+				int dg1 = e0.x, dg2 = e0.y + q_first, dg3 = c_forb_m; // row 1: the border row above holds 0, 0, 0
 #pragma unroll
-			for (int k = 0; k < NR; k++) asm volatile("" : "+v"(Rp[k])); // (kept in registers, not re-derived per column)
-			int uM = 0, uT = 0;         // (i - 1, j), new values
-			int colmax = 0, colst = 0;
-			// the entries of rows i and i + 1 are in flight while row i - 1 is computed
-			i32x4 e0 = rd4(colA + rowc(0)), e1 = rd4(colA + rowc(1));
-			int g0 = rd(colN + rowc(0));
-			// Row i also forms the diagonal candidates of row i + 1 (the bind kernel's arrangement): they need the old states of
-			// row i, which die there, so the new states take their registers and nothing is copied at the loop's back edge.
-			int dg1 = e0.x, dg2 = e0.y + q_first, dg3 = c_forb_m; // row 1: the border row above holds 0, 0, 0
-#pragma unroll
-			for (int i = 1; i <= LMAX; i++) {
-				const i32x4 e2 = i + 1 <= LMAX ? rd4(colA + rowc(i + 1 <= LMAX ? i + 1 : LMAX)) : e1;
-				const int g1 = i < LMAX ? rd(colN + rowc(i < LMAX ? i : 0)) : 0;
-				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // (i, j - 1)
-				// align_dimer, nuc_cruc.cpp:536-666, every table value = (-delta_g) << 11 | credit
-				int dn1 = 0, dn2 = 0, dn3 = 0;
-				if (i < LMAX) dn1 = cM + e1.x, dn2 = cQ + e1.y + q_first, dn3 = cT + e1.y; // e1: the NEXT row's entry, (q_i, q_i+1)
-				int qi = cM + e1.z, qe = cQ - v5;
-				asm volatile("" : "+v"(dn1), "+v"(dn2), "+v"(dn3), "+v"(qi), "+v"(qe), "+v"(dg1)); // the old states of this row are dead from here on
-				int M = dg1 > dg2 ? dg1 : dg2;
-				M = M > dg3 ? M : dg3;
-				const int Iq = qi > qe ? qi : qe;
-				const int ti = uM + (i == 1 ? c_forb_xy : g0), te = uT - (i == 1 ? c_zero : c_bulge);
-				const int It = ti > te ? ti : te;
-				const int Mz = M > 0 ? M : 0, Iqz = Iq > 0 ? Iq : 0, Itz = It > 0 ? It : 0;
-				if (EXACT) {
-					colmax = Mz > colmax ? Mz : colmax;
-					colst |= Mz | Iqz | Itz;
-				} else {
-					const bool valid = i <= L;
-					colmax = (valid && Mz > colmax) ? Mz : colmax;
-					colst |= valid ? (Mz | Iqz | Itz) : 0;
+				for (int i = 1; i <= LMAX; i++) {
+					const i32x3 e2 = i + 1 <= LMAX ? rd3(colA + 16 * (i + 1 <= LMAX ? i + 1 : LMAX)) : e1;
+					const int g1 = i < LMAX ? rd(colN + 16 * (i < LMAX ? i : 0)) : 0;
+					const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // (i, j - 1)
+					// align_dimer, nuc_cruc.cpp:536-666, every table value = (-delta_g) << 11 | credit
+					int dn1 = 0, dn2 = 0, dn3 = 0;
+					if (i < LMAX) dn1 = cM + e1.x, dn2 = cQ + e1.y + q_first, dn3 = cT + e1.y; // e1: the NEXT row's entry, (q_i, q_i+1)
+					int qi = cM + e1.z, qe = cQ - v5;
+					asm volatile("" : "+v"(dn1), "+v"(dn2), "+v"(dn3), "+v"(qi), "+v"(qe), "+v"(dg1)); // the old states of this row are dead from here on
+					int M = dg1 > dg2 ? dg1 : dg2;
+					M = M > dg3 ? M : dg3;
+					const int Iq = qi > qe ? qi : qe;
+					const int ti = uM + (i == 1 ? c_forb_xy : g0), te = uT - (i == 1 ? c_zero : c_bulge);
+					const int It = ti > te ? ti : te;
+					const int Mz = M > 0 ? M : 0, Iqz = Iq > 0 ? Iq : 0, Itz = It > 0 ? It : 0;
+					if (EXACT) {
+						colmax = Mz > colmax ? Mz : colmax;
+						colst |= Mz | Iqz | Itz;
+					} else {
+						const bool valid = i <= L; // (wave-uniform)
+						colmax = (valid && Mz > colmax) ? Mz : colmax;
+						colst |= valid ? (Mz | Iqz | Itz) : 0;
+					}
+					uM = Mz, uT = Itz;
+					oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
+					dg1 = dn1, dg2 = dn2, dg3 = dn3;
+					e0 = e1, e1 = e2, g0 = g1;
 				}
-				uM = Mz, uT = Itz;
-				oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
-				dg1 = dn1, dg2 = dn2, dg3 = dn3;
-				e0 = e1, e1 = e2, g0 = g1;
+				vmax = (colok && colmax > vmax) ? colmax : vmax;
+				sticky |= colok ? colst : 0;
+				tp = t, t = tn;
 			}
-			vmax = (colok && colmax > vmax) ? colmax : vmax;
-			sticky |= colok ? colst : 0;
-			tp = t, t = tn;
-		}
-		// the verdict: the credit of the best maximal-score path against the first tier's threshold (same constants, same units)
-		const int credit = (vmax & SB_CREDIT_MASK) * (FILT_UNITS / SB_UNITS); // 1e-3 kcal/mol
-		const bool guard = (sticky & SB_GUARD) != 0;
-		bool pass = true;
-		int theta = INT32_MIN;
-		if (a.tab->enabled[cls] && a.ftab->enabled[cls]) {
-			const float th = a.ftab->theta0[cls] - a.ftab->ct_scale[cls] * (a.ftab->tk[cls] * (1.9872e-3f * slot.log_ct));
-			theta = int(floorf(th * float(FILT_UNITS))) - 1;
-			pass = guard || credit >= theta;
-		}
-		if (a.score_out && active) a.score_out[2 * idx] = guard ? INT32_MAX : credit, a.score_out[2 * idx + 1] = theta;
-		if (a.dp_out && active) a.dp_out[idx] = vmax >> SB_SHIFT;
-		if (a.audit) {
-			if (active && !pass) a.audit[idx] = 1;
-			pass = true;
-		}
-		if (active && !pass && a.result) a.result[idx] = -1;
-		if (surv) { // as in the first tier: survivors leave a per-wavefront LDS buffer 64 at a time
-			const unsigned long long m = __builtin_amdgcn_ballot_w64(active && pass);
-			n_rej += uint32_t(__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && !pass)));
-			if (active && pass) s_keep[wave][n_keep + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
-			n_keep += uint32_t(__builtin_popcountll(m));
-			if (n_keep >= 64u) {
-				filt_wave_sync();
-				uint32_t at = 0;
-				if (lane == 0) at = atomicAdd(a.n_survivors, 64u);
-				at = uint32_t(__builtin_amdgcn_readfirstlane(int(at)));
-				surv[at + lane] = s_keep[wave][lane];
-				const uint32_t rest = n_keep - 64u;
-				const uint32_t moved = uint32_t(lane) < rest ? s_keep[wave][64 + lane] : 0u;
-				filt_wave_sync();
-				if (uint32_t(lane) < rest) s_keep[wave][lane] = moved;
-				n_keep = rest;
+			// the verdict: the credit of the best maximal-score path against the first tier's threshold (same constants, same units)
+			const int credit = (vmax & SB_CREDIT_MASK) * (FILT_UNITS / SB_UNITS); // 1e-3 kcal/mol
+			const bool guard = (sticky & SB_GUARD) != 0;
+			bool pass = true;
+			int theta = INT32_MIN;
+			if (a.tab->enabled[cls] && a.ftab->enabled[cls]) {
+				const float th = a.ftab->theta0[cls] - a.ftab->ct_scale[cls] * (a.ftab->tk[cls] * (1.9872e-3f * slot.log_ct));
+				theta = int(floorf(th * float(FILT_UNITS))) - 1;
+				pass = guard || credit >= theta;
 			}
-			filt_wave_sync();
+			if (a.score_out && active) a.score_out[2 * idx] = guard ? INT32_MAX : credit, a.score_out[2 * idx + 1] = theta;
+			if (a.dp_out && active) a.dp_out[idx] = vmax >> SB_SHIFT;
+			if (a.audit) {
+				if (active && !pass) a.audit[idx] = 1;
+				pass = true;
+			}
+			if (active && !pass && a.result) a.result[idx] = -1;
+			if (a.survivors) { // as in the first tier: survivors leave a per-wavefront LDS buffer 64 at a time
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(active && pass);
+				n_rej += uint32_t(__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && !pass)));
+				if (active && pass) s_keep[wave][n_keep + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
+				n_keep += uint32_t(__builtin_popcountll(m));
+				if (n_keep >= 64u) {
+					filt_wave_sync();
+					uint32_t at2 = 0;
+					if (lane == 0) at2 = atomicAdd(a.n_survivors, 64u);
+					at2 = uint32_t(__builtin_amdgcn_readfirstlane(int(at2)));
+					a.survivors[at2 + lane] = s_keep[wave][lane];
+					const uint32_t rest = n_keep - 64u;
+					const uint32_t moved = uint32_t(lane) < rest ? s_keep[wave][64 + lane] : 0u;
+					filt_wave_sync();
+					if (uint32_t(lane) < rest) s_keep[wave][lane] = moved;
+					n_keep = rest;
+				}
+				filt_wave_sync();
+			}
 		}
 	}
-	if (surv) {
+	if (a.survivors) {
 		if (lane == 0) s_wcount[wave] = n_keep;
 		__syncthreads();
 		if (tid == 0) {
 			uint32_t run = 0;
-			for (int w = 0; w < THREADS / 64; w++) {
+			for (int w = 0; w < SB_WAVES; w++) {
 				const uint32_t c = s_wcount[w];
 				s_wcount[w] = run;
 				run += c;
@@ -304,7 +369,7 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(sb_threads(LMAX), s
 			s_wbase = run ? atomicAdd(a.n_survivors, run) : 0u;
 		}
 		__syncthreads();
-		if (uint32_t(lane) < n_keep) surv[s_wbase + s_wcount[wave] + lane] = s_keep[wave][lane];
+		if (uint32_t(lane) < n_keep) a.survivors[s_wbase + s_wcount[wave] + lane] = s_keep[wave][lane];
 	}
 	if (a.n_rejected && lane == 0 && n_rej) atomicAdd(a.n_rejected, n_rej);
 }

@@ -221,6 +221,14 @@ struct UFilterArgs {
 	// the instance for the general buckets (windows that hold a non-ACGT target code): the exception lists go by target and position
 	DbView db;
 	const Item *items;
+	// Survivors BY GROUP (for the second tier, tnt_sbound.hip.h, whose wavefronts want one oligo each as this kernel's do): set,
+	// `survivors` has the regrouped queue's geometry and the survivors of a group go to the front of the group's own run --
+	// survivors[bin_end[g] - bin_count[g] + (position handed out by bin_fill[g])].  Null: one dense list behind n_survivors.
+	const uint32_t *slot_bin;     // [slot][2] group of the slot inside its plain / its general bucket
+	const uint32_t *bin_end;      // [groups of the bucket] end of the group's entries in the regrouped queue (the scatter pass's cursor)
+	const uint32_t *bin_count;    // ... their number (the histogram)
+	uint32_t *bin_fill;           // ... survivors so far (zeroed per batch)
+	uint32_t general;
 };
 
 // DEGEN: the instance for the general buckets -- windows with a non-ACGT target code.  As in filter_kernel<L, true>: an IUPAC code
@@ -250,7 +258,22 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void ufilter_k
 	n_items = n_items < a.n_items ? n_items : a.n_items;
 	const uint32_t n_blocks = n_items / UF_BLOCK;
 	uint32_t n_rej = 0, n_keep = 0; // windows this wavefront rejected / holds in s_keep (wave-uniform)
+	uint32_t keep_bin = 0;          // a.bin_fill: the group the held survivors belong to
 	int cur_oligo = -1, cur_cls = -1;
+	// the held survivors (n of them, the first ones) to their group's run / to the dense list
+	auto flush = [&](const uint32_t n) __attribute__((always_inline)) {
+		filt_wave_sync();
+		uint32_t at = 0;
+		if (lane == 0) at = a.bin_fill ? a.bin_end[keep_bin] - a.bin_count[keep_bin] + atomicAdd(a.bin_fill + keep_bin, n) : atomicAdd(a.n_survivors, n);
+		at = uint32_t(__builtin_amdgcn_readfirstlane(int(at)));
+		if (uint32_t(lane) < n) a.survivors[at + uint32_t(lane)] = s_keep[wave][lane];
+		const uint32_t rest = n_keep - n; // < 64
+		const uint32_t moved = uint32_t(lane) < rest ? s_keep[wave][n + uint32_t(lane)] : 0u;
+		filt_wave_sync();
+		if (uint32_t(lane) < rest) s_keep[wave][lane] = moved;
+		n_keep = rest;
+		filt_wave_sync();
+	};
 	uint32_t *row = s_row[wave];
 	const int row_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)row)));
 
@@ -272,6 +295,11 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void ufilter_k
 			const Slot ls = a.slots[lead_slot];
 			const int oligo = __builtin_amdgcn_readfirstlane(ls.oligo), cls = __builtin_amdgcn_readfirstlane(filter_class(ls.thresh));
 			const int L = __builtin_amdgcn_readfirstlane(a.olig_len[oligo]);
+			if (a.bin_fill) { // the survivors held so far belong to another group: out with them
+				const uint32_t bin = uint32_t(__builtin_amdgcn_readfirstlane(int(a.slot_bin[2u * lead_slot + a.general])));
+				if (bin != keep_bin && n_keep) flush(n_keep);
+				keep_bin = bin;
+			}
 			if (oligo != cur_oligo || cls != cur_cls) {
 				// T[k][i] = plane[cls][k * 49 + 7 * q' + q]: q the base of row i (none behind the oligo: such rows add nothing and
 				// open nothing), q' the base of the row above (none above the first)
@@ -458,23 +486,14 @@ template <int LMAX, bool DEGEN> __global__ __launch_bounds__(256) void ufilter_k
 				n_rej += uint32_t(__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && !pass)));
 				if (active && pass) s_keep[wave][n_keep + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
 				n_keep += uint32_t(__builtin_popcountll(m));
-				if (n_keep >= 64u) {
-					filt_wave_sync();
-					uint32_t at = 0;
-					if (lane == 0) at = atomicAdd(a.n_survivors, 64u);
-					at = uint32_t(__builtin_amdgcn_readfirstlane(int(at)));
-					a.survivors[at + lane] = s_keep[wave][lane];
-					const uint32_t rest = n_keep - 64u; // < 64
-					const uint32_t moved = uint32_t(lane) < rest ? s_keep[wave][64 + lane] : 0u;
-					filt_wave_sync();
-					if (uint32_t(lane) < rest) s_keep[wave][lane] = moved;
-					n_keep = rest;
-				}
+				if (n_keep >= 64u) flush(64u);
 				filt_wave_sync();
 			}
 		}
 	}
-	if (a.survivors) { // what is left in the buffers: one atomic per workgroup
+	if (a.survivors && a.bin_fill) {
+		if (n_keep) flush(n_keep);
+	} else if (a.survivors) { // what is left in the buffers: one atomic per workgroup
 		if (lane == 0) s_wcount[wave] = n_keep;
 		__syncthreads();
 		if (threadIdx.x == 0) {
