@@ -1931,15 +1931,17 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 			// and, among equal scores, the higher credit.  The credit of the window's maximal V bounds Phi - const of whatever
 			// NucCruc scores.  Bit 10 of the credit field is a guard: set in any state, the window passes.  Plain windows, oligos of
 			// up to 40 bases; the restatement runs the kernel's table-driven loops.
-			bool plain = true;
-			for (int b = 0; b < W; b++) plain = plain && tg[b] != ANY;
+			// Windows with IUPAC codes or inosine in the target: align_dimer resolves the target base of a cell against the query base
+			// it is paired with (bbp, nuc_cruc.cpp:203-213; against "none" where the partner is a gap), so the table entry of a
+			// transition is that of the RESOLVED bases -- the kernel's general instance (sbound_kernel<L, false, true>) indexes its
+			// shared table that way, this restatement calls the same resolve().
 			int credit3 = INT32_MAX; // (not served by this tier: passes)
-			if (plain && C.on && L <= 40 && W >= 1) {
+			if (C.on && L <= 40 && W >= 1) {
 				Melt m(opt->target_t, opt->salt, false, false);
 				m.set_query(q);
-				m.target.clear();
-				for (int b = W - 1; b >= 0; b--) m.target.push_back(Base(tg[b])); // (tg was reversed into pairing order above)
+				load_window(m, seq, start, stop, r.strand == TNT_MINUS);
 				const int K = 1 << 11, NEG3 = -(1 << 30);
+				const int NONE = 5; // target base of a column: A C G T I, 5 = none (before the first / behind the last column)
 				auto cl = [&](long long v) { return int(std::max<long long>(v, NEG3)); };
 				auto up50 = [&](double kcal) { return int(std::ceil(kcal * 50.0)); };
 				auto dgv = [&](int prev, int cur) { return m.g(prev, cur); };
@@ -1961,34 +1963,36 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 							if (P.wc[pm] && pm / NB <= I && pm % NB <= I) best = std::max(best, std::max(phi(pm, second), phi(first, pm)) - pb1);
 					return best;
 				};
-				// plane values for (x', x, q', q): x', x in A C G T none(4); q', q base codes 0..6
-				auto planes = [&](int xp5, int x5, int qp, int qq, int out[4]) {
-					const int xpB = xp5 == 4 ? int(GAP) : xp5, xB = x5 == 4 ? int(GAP) : x5;
-					const bool v1 = qq <= I && x5 < 4, v2 = qp <= I && xp5 < 4;
-					const int first = qq * NB + x5, second = qp * NB + xp5;
+				// entry values for (x', x, q', q): x', x in A C G T I none(5); q', q base codes 0..6
+				auto planes = [&](int xp, int x, int qp, int qq, int out[4]) {
+					const int xpB = xp == NONE ? int(GAP) : xp, xB = x == NONE ? int(GAP) : x;
+					const bool v1 = qq <= I && x != NONE, v2 = qp <= I && xp != NONE;
+					const int first = qq * NB + x, second = qp * NB + xp; // (read only where valid)
 					const int cpair = xB * NB + qq, ppair = xpB * NB + qp;
 					const int cs = (v1 && v2) ? up50(b_step(first, second)) : 0;
 					const int cg = (v1 && v2) ? up50(b_gap(first, second)) : (v1 ? up50(b_gap(first, first)) : 0);
 					const int cc = v2 ? ((v1) ? up50(b_gap(first, second)) : up50(b_gap(second, second))) : 0;
-					out[0] = x5 == 4 ? NEG3 : cl(-(long long)dgv(ppair, cpair) * K + cs);
-					out[1] = x5 == 4 ? NEG3 : cl(-(long long)term(cpair) * K + cg);
-					out[2] = xp5 == 4 ? c_forb_m : out[1];
+					out[0] = x == NONE ? NEG3 : cl(-(long long)dgv(ppair, cpair) * K + cs);
+					out[1] = x == NONE ? NEG3 : cl(-(long long)term(cpair) * K + cg);
+					out[2] = xp == NONE ? c_forb_m : out[1];
 					out[3] = cl(-(long long)term(xpB * NB + qp) * K + cc);
 				};
 				std::vector<int> oM(L, 0), oQ(L, 0), oT(L, 0), qrow(L + 2, int(GAP));
 				for (int i = 1; i <= L; i++) qrow[i] = int(m.query[L - i]); // row i = query[L - i]; row 0 and row L + 1: none
+				const int Wt = int(m.target.size()); // (codes the window loader skips are not in it: such windows are not served)
+				bool served = Wt == W;
 				int vmax = 0, sticky = 0;
-				auto tbase = [&](int j) { return (j >= 1 && j <= W) ? int(m.target[j - 1]) : 4; };
-				for (int j = 1; j <= W; j++) {
-					const int tp = tbase(j - 1), t = tbase(j), tn = tbase(j + 1);
+				// the base of column j as the cell of row i sees it
+				auto rx = [&](int j, int i) { return (j >= 1 && j <= Wt) ? int(resolve(m.target[j - 1], Base(qrow[i]))) : NONE; };
+				for (int j = 1; j <= Wt && served; j++) {
 					const bool firstcol = j == 1;
 					const int v5 = firstcol ? c_zero : c_bulge;
 					int dM = 0, dQ = 0, dT = 0, uM = 0, uT = 0;
 					for (int i = 1; i <= L; i++) {
 						int pa[4], pn[4], p4[4];
-						planes(tp, t, qrow[i - 1], qrow[i], pa);
-						planes(tp, t, qrow[i], qrow[i + 1], pn); // the next row's constant
-						planes(t, tn, qrow[i - 1], qrow[i], p4);
+						planes(rx(j - 1, i - 1), rx(j, i), qrow[i - 1], qrow[i], pa);
+						planes(rx(j - 1, i), rx(j, i + 1), qrow[i], qrow[i + 1], pn); // the next row's entry
+						planes(rx(j, i - 1), rx(j + 1, i), qrow[i - 1], qrow[i], p4);
 						const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1];
 						const int d1 = dM + pa[0], d2 = dQ + pa[2], d3 = dT + (i == 1 ? c_forb_m : pa[1]);
 						const int M = std::max(d1, std::max(d2, d3));
@@ -2002,8 +2006,8 @@ int tntor_filter_bound(const tnt_options *opt, const char *const *oligos, int n_
 						oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
 					}
 				}
-				credit3 = (sticky & (1 << 10)) ? INT32_MAX : (vmax & (K - 1)) * 20;
-				if (getenv("TNTOR_TIER3_CHECK_SCORE")) { // development check: the fill's maximal score (positive maxima only)
+				if (served) credit3 = (sticky & (1 << 10)) ? INT32_MAX : (vmax & (K - 1)) * 20;
+				if (served && getenv("TNTOR_TIER3_CHECK_SCORE")) { // development check: the fill's maximal score (positive maxima only)
 					m.align_dimer();
 					if (!(sticky & (1 << 10)) && std::max(m.max_score, 0) != (vmax >> 11)) fprintf(stderr, "tier 3: score %d vs fill %d\n", vmax >> 11, m.max_score);
 				}

@@ -192,14 +192,15 @@ def test_filter_kernel_equals_its_checker(Engine, oracle, k, monkeypatch):
 
 @pytest.mark.parametrize("k", [0, 1, 3, 5, 8, 9])
 def test_second_tier_kernel_equals_its_checker(Engine, oracle, k):
-    """sbound_kernel (the pre-filter's second tier: a trace-free fill of align_dimer's recurrence, V = score << 11 | credit) against
-    its oracle-side restatement, integer by integer: the credit of the maximal-score paths, INT32_MAX -> 32 767 where the guard
-    bit fired or the window is not served (IUPAC codes, oligos beyond 40 bases).  Minimum-Tm, dG-only and dangling-end sets."""
+    """sbound_kernel / sbound_degen_kernel (the pre-filter's second tier: a trace-free fill of align_dimer's recurrence, V = score << 11 |
+    credit; the second for windows that hold an IUPAC code or an inosine: a column's code resolved against the query base of every
+    row) against the oracle-side restatement, integer by integer: the credit of the maximal-score paths, INT32_MAX -> 32 767 where
+    the guard bit fired or the window is not served (oligos beyond 40 bases).  Minimum-Tm, dG-only and dangling-end sets."""
     import test_filter_bound as fbt
     name, kw = fbt.OPTION_SETS[k]
     rng = np.random.default_rng([77, k])
     opt = abi.options_default(**kw)
-    oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=48, degen=0.15)
+    oligos, targets, rows = fbt.make_windows(rng, 6000, lo=12, hi=48, degen=0.3, inosine=0.15)
     rows = [r[:6] + ((opt.probe_strand if r[5] else opt.primer_strand),) for r in rows]
     codes, offsets = gu.pack_targets(targets)
     e = Engine(opt, [synth.ExpandedAssay(i, i, None, None, o) for i, o in enumerate(oligos)])
@@ -208,7 +209,8 @@ def test_second_tier_kernel_equals_its_checker(Engine, oracle, k):
     got = e.filter_bound_tier2(db, tc.make_reqs((r[0], om[oligos[r[1]]], r[2], r[3], r[4], r[5], r[6]) for r in rows))
     want = oracle.filter_bound(opt, oligos, codes, offsets, tc.make_reqs(rows), tier=30)
     served = got[:, 1] != np.iinfo(np.int32).min
-    assert served.sum() > 3000 and (~served).sum() > 300
+    degenerate = np.array([any(ch not in "ACGT" for ch in targets[r[0]]) for r in rows])
+    assert served.sum() > 3000 and (~served).sum() > 300 and (served & degenerate).sum() > 800
     g0 = np.minimum(got[:, 0], 32767)
     bad = np.nonzero(g0 != want[:, 0])[0]
     assert len(bad) == 0, "%s: %d of %d differ, first %r got %r want %r" % (name, len(bad), len(rows), rows[bad[0]], got[bad[0]], want[bad[0]])
@@ -1692,6 +1694,30 @@ def test_cache_replay_of_crowded_targets(Engine, oracle):
     db = e.pack(codes, offsets)
     got = tc.sorted_hit_keys(e.search(db))
     assert got == want and len(want) > 200
+    db.close()
+    e.close()
+
+
+def test_cache_replay_of_a_list_beyond_512_seeds(Engine, oracle):
+    """Row a6 with more than 512 seeds of one assay on one target (the capacity of the device replay's crowded-group instance and of
+    a work unit's seed list): the target is seeded in windows and its lists -- up to 2^20 entries -- are replayed on a host
+    thread with the memo as a map.  Round 4 refused this input (TNT_E_LIMIT / TNT_E_UNSUPPORTED).  Search == oracle."""
+    rng = np.random.default_rng(31415)
+    F = synth._rand_oligo(rng, 20, 20)
+    R, R1 = synth._rand_oligo(rng, 21, 21), synth._rand_oligo(rng, 20, 20)
+    P, F2, R2 = synth._rand_oligo(rng, 24, 24), synth._rand_oligo(rng, 20, 20), synth._rand_oligo(rng, 20, 20)
+    assays = [synth.Assay("pcr0", F, R, None), synth.Assay("taq", F2, R2, F), synth.Assay("pcr1", F, R1, None)]
+    ex = synth.expand_assays(assays)
+    opt = abi.options_default(min_primer_tm=40.0, min_probe_tm=30.0, primer_clamp=1, probe_clamp_5=2)
+    filler = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    crowded = filler(20) + (F[8:] + "T") * 700 + filler(30) + synth.revcomp(R) + filler(20) + F2 + filler(15) + synth.revcomp(F) + filler(20) + synth.revcomp(R2) + filler(10)
+    plain = filler(40) + F + filler(60) + synth.revcomp(R1) + filler(30) + F2 + filler(20) + F + filler(25) + synth.revcomp(R2) + filler(10)
+    codes, offsets = gu.pack_targets([plain, crowded, plain[::-1]])
+    want = tc.sorted_hit_keys(oracle.search(opt, ex, codes, offsets))
+    e = Engine(opt, ex)
+    db = e.pack(codes, offsets)
+    got = tc.sorted_hit_keys(e.search(db))
+    assert got == want and len(want) > 3
     db.close()
     e.close()
 

@@ -384,9 +384,11 @@ void fill_filter_tables(FilterTables &F, const Tables &T, const tnt_options &opt
 // column into a gap state (read at the NEXT row's / the NEXT column's index: the credit is the closing column's stack with its
 // diagonally adjacent later cell).  Credits follow fill_filter_tables (pair = query base * 7 + target
 // base, phi(later cell, its diagonal predecessor)), in units of 0.02 kcal/mol rounded up.
-void fill_sbound_tables(SBoundTables &S, const FilterTables &F, const Tables &T, const tnt_options &opt)
+// X = 5: target bases A C G T none (plain windows); X = 6: A C G T I none (the general instance: a column's code resolved against
+// the query base, tnt_sbound.hip.h) into `entry` [FILT_CLASSES][X * X * 49][4].
+template <int X> void fill_sbound_entries(int32_t (*entry)[X * X * NBP][4], const FilterTables &F, const Tables &T)
 {
-	memset(&S, 0, sizeof(S));
+	constexpr int NONE = X - 1;
 	bool wc[NBP];
 	memset(wc, 0, sizeof(wc));
 	wc[P_AT] = wc[P_TA] = wc[P_CG] = wc[P_GC] = true;
@@ -394,17 +396,8 @@ void fill_sbound_tables(SBoundTables &S, const FilterTables &F, const Tables &T,
 	const long long K = 1ll << SB_SHIFT;
 	auto cl = [](long long v) { return int32_t(std::max<long long>(v, SB_NEG)); };
 	auto up = [](double kcal) { return int(std::ceil(kcal * double(SB_UNITS))); };
-	S.bulge = int32_t(T.dg_const[0] * K), S.zero = int32_t(T.dg_const[1] * K);
-	S.forb_m = cl(-(long long)T.dg_const[2] * K), S.forb_xy = cl(-(long long)T.dg_const[3] * K);
-	// the largest gain of a column: the score of a window of SB_MAX_ROWS + 8 columns has to stay below 2^20 units
-	long long gain = 0;
-	for (int p = 0; p < NBP; p++)
-		for (int c = 0; c < NBP; c++)
-			if (p / NB <= bI && p % NB <= bI && c / NB <= bI && c % NB <= bI) gain = std::max<long long>(gain, -(long long)T.dg[p * NBP + c]);
-	const bool fits = gain * (SB_MAX_ROWS + 2 * FLANK) < (1ll << 20) && std::abs((long long)T.dg_const[0]) < (1ll << 19) && std::abs((long long)T.dg_const[1]) < (1ll << 19);
 	for (int cls = 0; cls < FILT_CLASSES; cls++) {
-		for (int i = 0; i < SB_ENTRIES; i++) S.entry[cls][i][0] = S.entry[cls][i][1] = S.entry[cls][i][2] = SB_NEG, S.entry[cls][i][3] = 0;
-		S.enabled[cls] = (F.enabled[cls] && fits && !opt.use_dinkelbach && !getenv("TNT_MI355X_NO_TIER2")) ? 1 : 0;
+		for (int i = 0; i < X * X * NBP; i++) entry[cls][i][0] = entry[cls][i][1] = entry[cls][i][2] = SB_NEG, entry[cls][i][3] = 0;
 		if (!F.enabled[cls]) continue;
 		const double Tk = double(F.tk[cls]);
 		const double sc = double(T.salt) * double(T.log_na);
@@ -418,23 +411,43 @@ void fill_sbound_tables(SBoundTables &S, const FilterTables &F, const Tables &T,
 					if (wc[pm] && pm / NB <= bI && pm % NB <= bI) best = std::max(best, std::max(phi(pm, second), phi(first, pm)) - pb1);
 			return best;
 		};
-		for (int xp5 = 0; xp5 < SB_X; xp5++)
-			for (int x5 = 0; x5 < SB_X; x5++)
+		for (int xp = 0; xp < X; xp++)
+			for (int x = 0; x < X; x++)
 				for (int qp = 0; qp < NB; qp++)
 					for (int q = 0; q < NB; q++) {
-						const int at = (xp5 * SB_X + x5) * NBP + qp * NB + q;
-						const int xpB = xp5 == 4 ? int(bGAP) : xp5, xB = x5 == 4 ? int(bGAP) : x5;
-						const bool v1 = q <= bI && x5 < 4, v2 = qp <= bI && xp5 < 4;
-						const int first = q * NB + x5, second = qp * NB + xp5; // (read only where valid)
+						const int at = (xp * X + x) * NBP + qp * NB + q;
+						const int xpB = xp == NONE ? int(bGAP) : xp, xB = x == NONE ? int(bGAP) : x;
+						const bool v1 = q <= bI && x != NONE, v2 = qp <= bI && xp != NONE;
+						const int first = q * NB + x, second = qp * NB + xp; // (read only where valid)
 						const int cpair = xB * NB + q, ppair = xpB * NB + qp;
 						const int cs = (v1 && v2) ? up(b_step(first, second)) : 0;
 						const int cg = (v1 && v2) ? up(b_gap(first, second)) : (v1 ? up(b_gap(first, first)) : 0);
 						const int cc = v2 ? (v1 ? up(b_gap(first, second)) : up(b_gap(second, second))) : 0;
-						S.entry[cls][at][0] = x5 == 4 ? SB_NEG : cl(-(long long)T.dg[ppair * NBP + cpair] * K + cs);
-						S.entry[cls][at][1] = x5 == 4 ? SB_NEG : cl(-(long long)T.term[cpair] * K + cg); // (first column: the kernel forbids the step out of a gap state itself)
-						S.entry[cls][at][2] = cl(-(long long)T.term[xpB * NB + qp] * K + cc);
+						entry[cls][at][0] = x == NONE ? SB_NEG : cl(-(long long)T.dg[ppair * NBP + cpair] * K + cs);
+						entry[cls][at][1] = x == NONE ? SB_NEG : cl(-(long long)T.term[cpair] * K + cg); // (first column: the kernel forbids the step out of a gap state itself)
+						entry[cls][at][2] = cl(-(long long)T.term[xpB * NB + qp] * K + cc);
 					}
 	}
+}
+
+void fill_sbound_tables(SBoundTables &S, SBoundTablesD &D, const FilterTables &F, const Tables &T, const tnt_options &opt)
+{
+	memset(&S, 0, sizeof(S));
+	memset(&D, 0, sizeof(D));
+	const long long K = 1ll << SB_SHIFT;
+	auto cl = [](long long v) { return int32_t(std::max<long long>(v, SB_NEG)); };
+	S.bulge = int32_t(T.dg_const[0] * K), S.zero = int32_t(T.dg_const[1] * K);
+	S.forb_m = cl(-(long long)T.dg_const[2] * K), S.forb_xy = cl(-(long long)T.dg_const[3] * K);
+	// the largest gain of a column: the score of a window of SB_MAX_ROWS + 8 columns has to stay below 2^20 units
+	long long gain = 0;
+	for (int p = 0; p < NBP; p++)
+		for (int c = 0; c < NBP; c++)
+			if (p / NB <= bI && p % NB <= bI && c / NB <= bI && c % NB <= bI) gain = std::max<long long>(gain, -(long long)T.dg[p * NBP + c]);
+	const bool fits = gain * (SB_MAX_ROWS + 2 * FLANK) < (1ll << 20) && std::abs((long long)T.dg_const[0]) < (1ll << 19) && std::abs((long long)T.dg_const[1]) < (1ll << 19);
+	for (int cls = 0; cls < FILT_CLASSES; cls++)
+		S.enabled[cls] = (F.enabled[cls] && fits && !opt.use_dinkelbach && !getenv("TNT_MI355X_NO_TIER2")) ? 1 : 0;
+	fill_sbound_entries<SB_X>(S.entry, F, T);
+	fill_sbound_entries<SBD_X>(D.entry, F, T);
 }
 
 // build_word_list<std::string>, seq_hash.h:287-374, in the packed stream's little-endian word convention
@@ -656,6 +669,8 @@ struct tnt_ctx {
 	// second tier of the pre-filter (tnt_sbound.hip.h): the credit of the fill's maximal-score paths
 	SBoundTables h_stab;
 	DevBuf<SBoundTables> stab;
+	std::unique_ptr<SBoundTablesD> h_dstab; // ... of the general instance (a column's code resolved against the query base)
+	DevBuf<SBoundTablesD> dstab;
 	bool tier2 = false;
 	bool defer_finish = false; // the throughput bind instances park the windows that pass Tm / dG for bind_finish_kernel (tnt_bind.hip.h)
 	bool regroup = false;
@@ -1057,6 +1072,26 @@ void launch_sbound(const SBoundArgs &a, int blocks, int rows, hipStream_t stream
 	}
 }
 
+bool has_sbound_degen_instance(int rows)
+{
+	switch (rows) {
+#define X(N) case N: return true;
+		TNT_SBOUND_DEGEN_LADDER(X)
+#undef X
+	default: return false;
+	}
+}
+
+void launch_sbound_degen(const SBoundDegenArgs &a, int blocks, int rows, hipStream_t stream)
+{
+	switch (rows) {
+#define X(N) case N: tnt::launch_sbound_degen_##N(a, blocks, stream); break;
+		TNT_SBOUND_DEGEN_LADDER(X)
+#undef X
+	default: break;
+	}
+}
+
 // The regrouping of a batch's phase-A queues by (oligo, threshold class): count, scan, scatter, each ONE launch over all the
 // buckets of `desc` (device array of n_desc descriptors).
 void launch_regroup(tnt_ctx *c, const RegroupBucket *desc, uint32_t n_desc, const uint4 *src, uint4 *dst, uint32_t *counters, const uint32_t *slot_bin,
@@ -1141,7 +1176,9 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		if (c->serial_bind) n_launch = 1;
 		// (direct: the queue holds 16-byte entries whose first word is the item index)
 		const uint32_t *queue = direct ? reinterpret_cast<const uint32_t *>(c->S().qfat.p + c->h_q_base[i]) : c->S().qbucket.p;
-		uint32_t *survivors = c->S().qsurv.p ? c->S().qsurv.p + (direct ? c->h_q_base[i] : 0u) : nullptr;
+		// (survivor lists keep the regrouped queues' geometry: bucket i at q_base[i] + 64 * rg_bin_base[i], so that a bucket whose
+		// survivors go by group -- in place of its regrouped entries -- does not reach into its neighbour's list)
+		uint32_t *survivors = c->S().qsurv.p ? c->S().qsurv.p + (direct ? c->h_q_base[i] + uint32_t(UF_BLOCK) * (i < c->rg_bin_base.size() ? c->rg_bin_base[i] : 0u) : 0u) : nullptr;
 		b.index = queue;
 		b.index_stride = direct ? 4 : 1;
 		b.index_base_dev = direct ? nullptr : cnt + C_BUCKET + i * BUCKET_STRIDE + 2;
@@ -1223,6 +1260,23 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 				if (!c->filtered[i]) (void)hipEventCreateWithFlags(&c->filtered[i], hipEventDisableTiming);
 				(void)hipEventRecord(c->filtered[i], c->lane_stream[0]);
 				(void)hipStreamWaitEvent(c->lane_stream[lane], c->filtered[i], 0);
+			}
+			// ... and of the general buckets of phase A (windows with IUPAC codes or inosine): the instance that resolves a column's
+			// code against the query base of every row, on the first tier's dense list.  (Not in phase B: its few thousand windows are
+			// one short chain of launches, and one more launch costs config 2 and 3 0.1 ms for nothing.)
+			if (degen && direct && c->tier2 && c->S().qsurv2.p && has_sbound_degen_instance(rows) && !c->filter_status_exact && !split && !getenv("TNT_MI355X_NO_TIER2_GENERAL")) {
+				SBoundDegenArgs sd;
+				memset(&sd, 0, sizeof(sd));
+				sd.tab = c->stab.p, sd.dtab = c->dstab.p, sd.ftab = c->ftab.p;
+				sd.rt = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(c->tab.p) + offsetof(Tables, rt));
+				sd.db = v;
+				sd.olig_q4 = b.olig_q4, sd.olig_len = b.olig_len, sd.slots = b.slots, sd.items = b.items;
+				sd.index = f.survivors, sd.index_base_dev = b.index_base_dev, sd.n_items_dev = f.n_survivors, sd.n_items = queue_cap;
+				sd.survivors = c->S().qsurv2.p + (direct ? c->h_q_base[i] : 0u);
+				sd.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 7;
+				sd.result = b.result, sd.n_rejected = gcnt + C_FILTERED, sd.audit = f.audit;
+				launch_sbound_degen(sd, c->n_cu * 2, rows, c->lane_stream[lane]);
+				f.survivors = sd.survivors, f.n_survivors = sd.n_survivors;
 			}
 			b.index = f.survivors;
 			b.index_stride = 1;
@@ -1691,7 +1745,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	// ---- tables
 	if (!fill_tables(c->h_tab, *opt)) FAIL(TNT_E_UNSUPPORTED, "delta_g table lacks the class structure the bind kernel relies on");
 	fill_filter_tables(c->h_ftab, c->h_tab, *opt);
-	fill_sbound_tables(c->h_stab, c->h_ftab, c->h_tab, *opt);
+	c->h_dstab.reset(new SBoundTablesD);
+	fill_sbound_tables(c->h_stab, *c->h_dstab, c->h_ftab, c->h_tab, *opt);
 	c->filter_on = (c->h_ftab.enabled[0] || c->h_ftab.enabled[1]) && !getenv("TNT_MI355X_NO_FILTER");
 	c->filter_audit = c->filter_on && getenv("TNT_MI355X_FILTER_AUDIT");
 	c->filter_general = c->filter_on && !getenv("TNT_MI355X_NO_FILTER_GENERAL");
@@ -1874,7 +1929,8 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	std::vector<Tables> tv(1, c->h_tab);
 	std::vector<FilterTables> fv(1, c->h_ftab);
 	std::vector<SBoundTables> sv(1, c->h_stab);
-	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->ftab.upload(fv)) != hipSuccess || (e = c->stab.upload(sv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
+	std::vector<SBoundTablesD> dv(1, *c->h_dstab);
+	if ((e = c->tab.upload(tv)) != hipSuccess || (e = c->ftab.upload(fv)) != hipSuccess || (e = c->stab.upload(sv)) != hipSuccess || (e = c->dstab.upload(dv)) != hipSuccess || (e = c->olig_base.upload(ob)) != hipSuccess ||
 	    (e = c->olig_q4.upload(orv)) != hipSuccess || (e = c->olig_len.upload(ol)) != hipSuccess ||
 	    (e = c->slots.upload(c->h_slots)) != hipSuccess || (e = c->thresh.upload(th)) != hipSuccess ||
 	    (e = c->slot_canon.upload(c->h_slot_canon)) != hipSuccess || (e = c->slot_next.upload(c->h_slot_next)) != hipSuccess ||
@@ -3155,8 +3211,11 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 #endif
 	// Capacity overflows are repaired and the search repeated: the hit buffer grows to what the pair kernel counted,
 	// the per-batch lists (work items, groups, bound records) get smaller batches.
+	// (a (target, assay) list beyond the crowded-group instance's 512 entries: the whole database takes the route of the targets that
+	// are seeded in windows, whose lists -- up to 2^20 entries -- are culled and paired on host threads)
+	const bool lists_to_host = ctx->force_big && ctx->pending_db && !ctx->pending_db->all_long && !ctx->long_primers;
 	const uint32_t repairable = ERR_HIT_OVERFLOW | ERR_ITEM_OVERFLOW | ERR_GROUP_OVERFLOW | ERR_POOL_OVERFLOW | ERR_SEED_OVERFLOW |
-	                            (ctx->force_big ? 0u : ERR_LIST_OVERFLOW);
+	                            ((!ctx->force_big || lists_to_host) ? ERR_LIST_OVERFLOW : 0u);
 	if (cnt[C_ERR] & repairable) {
 		const uint32_t fatal = cnt[C_ERR] & ~repairable;
 		if (!fatal && ctx->retries < 16 && ctx->pending_db) {
@@ -3178,7 +3237,13 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 					HIP_TRY(build_units(ctx, ctx->pending_db), ctx->err);
 				}
 			}
-			if (cnt[C_ERR] & ERR_LIST_OVERFLOW) ctx->force_big = true;
+			if (cnt[C_ERR] & ERR_LIST_OVERFLOW) {
+				if (lists_to_host) {
+					ctx->pending_db->all_long = true;
+					HIP_TRY(build_units(ctx, ctx->pending_db), ctx->err);
+				}
+				ctx->force_big = true;
+			}
 			const int rc = tnt_search_enqueue(ctx, ctx->pending_db);
 			if (rc) return rc;
 			return collect_search(ctx, want_records, hits, n_hits);
@@ -4138,6 +4203,7 @@ int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, si
 	std::vector<Slot> slots(n);
 	std::vector<Item> items(n);
 	std::map<std::tuple<int, int, int>, std::vector<uint32_t>> by_group; // (instance rows, oligo, threshold class) -> requests: the kernel takes one oligo per wavefront
+	std::map<int, std::vector<uint32_t>> by_rows_degen; // general instance (rows) -> requests
 	for (size_t i = 0; i < n; i++) {
 		const tnt_bind_req &r = req[i];
 		const size_t t = size_t(r.seq_index) - db->first_seq_index;
@@ -4156,6 +4222,7 @@ int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, si
 		const uint32_t *it = std::lower_bound(eb, ee, uint32_t(start));
 		const int rows = pick_instance(size_t(L)) & 0xFF;
 		if ((it == ee || *it >= stop) && L <= SB_MAX_ROWS && has_sbound_instance(rows)) by_group[std::make_tuple(rows, r.oligo, r.role == 1 ? 1 : 0)].push_back(uint32_t(i)); // plain windows of oligos of up to 40 bases
+		else if (it != ee && *it < stop && L <= SB_MAX_ROWS && has_sbound_degen_instance(pick_lmax(size_t(L)) & 0xFF)) by_rows_degen[pick_lmax(size_t(L)) & 0xFF].push_back(uint32_t(i)); // windows with an IUPAC code or an inosine: the general instance
 	}
 	DevBuf<Slot> dslots;
 	DevBuf<int32_t> dscore;
@@ -4179,11 +4246,33 @@ int tnt_filter_bound_tier2(tnt_ctx *ctx, tnt_db *db, const tnt_bind_req *req, si
 		first.push_back(uint32_t(order.size())), fill.push_back(uint32_t(kv.second.size()));
 		order.insert(order.end(), kv.second.begin(), kv.second.end());
 	}
-	if (order.empty()) return TNT_OK;
-	HIP_TRY(dindex.upload(order), ctx->err);
-	HIP_TRY(dfirst.upload(first), ctx->err);
-	HIP_TRY(dfill.upload(fill), ctx->err);
-	HIP_TRY(dwork.upload(std::vector<uint32_t>(launches.size(), 0u)), ctx->err);
+	DevBuf<uint32_t> dindex_d;
+	if (!by_rows_degen.empty()) {
+		std::vector<uint32_t> order_d;
+		for (const auto &kv : by_rows_degen) order_d.insert(order_d.end(), kv.second.begin(), kv.second.end());
+		HIP_TRY(dindex_d.upload(order_d), ctx->err);
+		SBoundDegenArgs sd;
+		memset(&sd, 0, sizeof(sd));
+		sd.tab = ctx->stab.p, sd.dtab = ctx->dstab.p, sd.ftab = ctx->ftab.p;
+		sd.rt = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ctx->tab.p) + offsetof(Tables, rt));
+		sd.db = make_view(db, 0, db->n_targets);
+		sd.olig_q4 = ctx->olig_q4.p, sd.olig_len = ctx->olig_len.p, sd.slots = dslots.p, sd.items = ctx->S().items.p;
+		sd.score_out = dscore.p;
+		size_t at = 0;
+		for (const auto &kv : by_rows_degen) {
+			sd.index = dindex_d.p + at;
+			sd.n_items = uint32_t(kv.second.size());
+			launch_sbound_degen(sd, int(std::min<size_t>(size_t(ctx->n_cu) * 2, (kv.second.size() + SBD_THREADS - 1) / SBD_THREADS)), kv.first, ctx->stream);
+			at += kv.second.size();
+		}
+	}
+	if (order.empty() && by_rows_degen.empty()) return TNT_OK;
+	if (!order.empty()) HIP_TRY(dindex.upload(order), ctx->err);
+	if (!order.empty()) {
+		HIP_TRY(dfirst.upload(first), ctx->err);
+		HIP_TRY(dfill.upload(fill), ctx->err);
+		HIP_TRY(dwork.upload(std::vector<uint32_t>(launches.size(), 0u)), ctx->err);
+	}
 	SBoundArgs sb;
 	memset(&sb, 0, sizeof(sb));
 	sb.tab = ctx->stab.p, sb.ftab = ctx->ftab.p, sb.db = make_view(db, 0, db->n_targets);

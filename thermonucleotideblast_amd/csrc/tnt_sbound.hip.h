@@ -374,10 +374,261 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(SB_THREADS, sb_wave
 	if (a.n_rejected && lane == 0 && n_rej) atomicAdd(a.n_rejected, n_rej);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The instance for the GENERAL buckets: windows that hold an IUPAC code or an inosine (the exception lists of the target).
+// align_dimer resolves the target base of a cell against the query base it is paired with (nuc_cruc.cpp:14-213; against "none"
+// where the partner is a gap), so the column part of a transition's table index changes from row to row: one table for all
+// oligos, indexed by the RESOLVED bases (A C G T I none), the address formed per cell.  One lane per survivor of the first
+// tier's general instance (a dense list); rows beyond the oligo are masked (the buckets of the general ladder hold several
+// lengths).  Windows with a code the window loader skips (gap, unknown: the window shrinks, Q6) pass.
+constexpr int SBD_X = 6;                                  // A C G T I none
+constexpr int SBD_ENTRIES = SBD_X * SBD_X * NBP;
+constexpr int SBD_THREADS = 256;
+struct SBoundTablesD {
+	int32_t entry[FILT_CLASSES][SBD_ENTRIES][4];
+};
+struct SBoundDegenArgs {
+	const SBoundTables *tab;      // constants, enabled[]
+	const SBoundTablesD *dtab;
+	const FilterTables *ftab;
+	const uint32_t *rt;           // Tables::rt: rt[x] nibble q = the base x resolves to against partner q
+	DbView db;
+	const uint32_t *olig_q4;
+	const int32_t *olig_len;
+	const Slot *slots;
+	const Item *items;
+	const uint32_t *index;        // the first tier's survivors, from index[*index_base_dev]
+	const uint32_t *index_base_dev;
+	const uint32_t *n_items_dev;
+	uint32_t n_items;
+	uint32_t *survivors;
+	uint32_t *n_survivors;
+	int32_t *result;
+	uint32_t *n_rejected;
+	uint8_t *audit;
+	int32_t *score_out;
+};
+
+template <int LMAX> __global__ __launch_bounds__(SBD_THREADS, 2) void sbound_degen_kernel(SBoundDegenArgs a)
+{
+	static_assert(LMAX <= SB_MAX_ROWS, "instances of up to 40 rows");
+	constexpr int THREADS = SBD_THREADS;
+	constexpr int WMAX = LMAX + 2 * FLANK;
+	constexpr int NQ = (LMAX + 2 + 3) / 4;   // 4 * base code of rows 0 .. LMAX + 1, four to a register
+	constexpr int CLS_BYTES = SBD_ENTRIES * 16;
+	typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+	__shared__ __attribute__((aligned(16))) int32_t s_tab[FILT_CLASSES * SBD_ENTRIES * 4];
+	__shared__ uint8_t s_win[WMAX * THREADS];           // the window's base codes, column j of lane l at (j - 1) * THREADS + l
+	__shared__ uint32_t s_rt[18];
+	__shared__ uint32_t s_keep[THREADS / 64][128];
+	__shared__ uint32_t s_wcount[THREADS / 64], s_wbase;
+	typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+	typedef __attribute__((address_space(3))) const i32x3 lds_ci32x3;
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint32_t n_items = a.n_items;
+	if (a.n_items_dev) {
+		const uint32_t n_dev = *a.n_items_dev;
+		n_items = n_dev < n_items ? n_dev : n_items;
+	}
+	if (uint32_t(blockIdx.x) * uint32_t(THREADS) >= n_items) return; // (nothing to do: leave before staging 56 KB of tables)
+	for (int i = tid; i < FILT_CLASSES * SBD_ENTRIES * 4; i += THREADS) s_tab[i] = (&a.dtab->entry[0][0][0])[i];
+	if (tid < 18) s_rt[tid] = a.rt[tid];
+	__syncthreads();
+	const int c_bulge = a.tab->bulge, c_zero = a.tab->zero, c_forb_m = a.tab->forb_m, c_forb_xy = a.tab->forb_xy;
+	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
+	uint32_t *surv = a.survivors ? a.survivors + (a.index_base_dev ? *a.index_base_dev : 0u) : nullptr;
+	uint32_t n_rej = 0, n_keep = 0;
+	uint8_t *win = s_win + tid;
+	auto rd3 = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32x3 *)(uintptr_t(uint32_t(addr))); };
+	auto rd = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32 *)(uintptr_t(uint32_t(addr))); };
+
+	for (uint32_t base = blockIdx.x * THREADS; base < n_items; base += gridDim.x * THREADS) {
+		const uint32_t idx = base + tid < n_items ? index[base + tid] : 0xFFFFFFFFu;
+		const bool active = idx != 0xFFFFFFFFu;
+		const Item it = active ? a.items[idx] : Item{0, 0, 0, 0};
+		const Slot slot = a.slots[it.info >> ITEM_SLOT_SHIFT];
+		const int L = active ? a.olig_len[slot.oligo] : 0;
+		const bool minus = (it.info & ITEM_MINUS) != 0;
+		// the window, bind_oligo.cpp:502-505, with the codes of its exception list; a skipped code: not served
+		int start = int(it.tloc) - (int(it.info & 127u) + slot.qloc_bias + FLANK);
+		if (start < 0) start = 0;
+		int stop = start + L + 2 * FLANK;
+		const int tlen = active ? int(a.db.len[it.target]) : 0;
+		if (stop > tlen) stop = tlen;
+		const int W = active ? stop - start : 0;
+		bool served = active && L <= LMAX;
+		if (active) {
+			const uint32_t *pk = a.db.packed + a.db.word_off[it.target];
+			const uint32_t e0 = a.db.exc_off[it.target], e1 = a.db.exc_off[it.target + 1];
+			uint32_t lo = e0, hi = e1;
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (a.db.exc_pos[mid] < uint32_t(start)) lo = mid + 1;
+				else hi = mid;
+			}
+			uint32_t e = lo;
+			for (int pos = start; pos < stop; pos++) {
+				int code = int((pk[pos >> 4] >> ((pos & 15) * 2)) & 3u);
+				if (e < e1 && a.db.exc_pos[e] == uint32_t(pos)) code = a.db.exc_code[e++];
+				if (code > 15) served = false, code = 0;
+				const int r = pos - start;
+				if (minus) win[(W - 1 - r) * THREADS] = uint8_t(db_comp(code));
+				else win[r * THREADS] = uint8_t(db_same(code));
+			}
+		}
+		// 4 * base code of rows 0 .. LMAX + 1 (none above the first row and behind the oligo), and the rows' part of the table index
+		uint32_t q4p[NQ];
+#pragma unroll
+		for (int k = 0; k < NQ; k++) q4p[k] = 0;
+#pragma unroll
+		for (int i = 0; i <= LMAX + 1; i++) {
+			uint32_t q4 = 4u * bGAP;
+			if (i >= 1 && i <= LMAX) {
+				const uint32_t q4w = active ? a.olig_q4[slot.oligo * (MAX_OLIGO / 4) + ((i - 1) >> 2)] : 0u;
+				q4 = (q4w >> (((i - 1) & 3) * 8)) & 255u;
+				if (i > L) q4 = 4u * bGAP;
+			}
+			q4p[i >> 2] |= q4 << ((i & 3) * 8);
+		}
+		auto q4_of = [&](int i) __attribute__((always_inline)) { return (q4p[i >> 2] >> ((i & 3) * 8)) & 255u; }; // 4 * base code of row i
+		const int cls = filter_class(slot.thresh);
+		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * CLS_BYTES;
+		// the base a column's code resolves to against the query base of row i, as a table coordinate (5: none)
+		auto rx = [&](uint32_t rtw, uint32_t q4) __attribute__((always_inline)) {
+			const uint32_t v = __builtin_amdgcn_ubfe(rtw, q4, 4u);
+			return v < 5u ? v : 5u;
+		};
+
+		int Wwave = W;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const int other = __shfl_xor(Wwave, o);
+			Wwave = other > Wwave ? other : Wwave;
+		}
+		Wwave = __builtin_amdgcn_readfirstlane(Wwave);
+
+		int oM[LMAX], oQ[LMAX], oT[LMAX];
+#pragma unroll
+		for (int i = 0; i < LMAX; i++) oM[i] = oQ[i] = oT[i] = 0;
+		int vmax = 0, sticky = 0;
+		auto code_of = [&](int j) __attribute__((always_inline)) { return (j >= 1 && j <= W) ? int(win[(j - 1) * THREADS]) : int(bGAP); };
+		uint32_t prtw = s_rt[bGAP], rtw = s_rt[code_of(1)];
+#pragma unroll 1
+		for (int j = 1; j <= Wwave; j++) {
+			const uint32_t nrtw = s_rt[code_of(j + 1)];
+			const bool colok = j <= W;
+			const bool firstcol = j == 1;
+			const int v5 = firstcol ? c_zero : c_bulge;
+			const int q_first = firstcol ? SB_NEG / 2 : 0;
+#pragma unroll
+			for (int k = 0; k < NQ; k++) asm volatile("" : "+v"(q4p[k])); // (kept in registers, not re-derived per column)
+			// entry of row i: (x', x) = (previous column against row i - 1, this column against row i), rows (q_i-1, q_i);
+			// the gap-opening credit of row i: (this column against row i - 1, next column against row i)
+			auto entry_at = [&](int i) __attribute__((always_inline)) {
+				const uint32_t qa = q4_of(i - 1), qb = q4_of(i);
+				const uint32_t col = rx(prtw, qa) * uint32_t(SBD_X) + rx(rtw, qb);
+				return tab_base + int((col * uint32_t(NBP) + (7u * qa + qb) / 4u) * 16u);
+			};
+			auto gap_at = [&](int i) __attribute__((always_inline)) {
+				const uint32_t qa = q4_of(i - 1), qb = q4_of(i);
+				const uint32_t col = rx(rtw, qa) * uint32_t(SBD_X) + rx(nrtw, qb);
+				return tab_base + int((col * uint32_t(NBP) + (7u * qa + qb) / 4u) * 16u) + 8;
+			};
+			int uM = 0, uT = 0;
+			int colmax = 0, colst = 0;
+			i32x3 e0 = rd3(entry_at(1)), e1 = rd3(entry_at(2));
+			int g0 = rd(gap_at(1));
+			int dg1 = e0.x, dg2 = e0.y + q_first, dg3 = c_forb_m; // row 1: the border row above holds 0, 0, 0
+#pragma unroll
+			for (int i = 1; i <= LMAX; i++) {
+				const i32x3 e2 = i + 1 <= LMAX ? rd3(entry_at(i + 2 <= LMAX + 1 ? i + 2 : LMAX + 1)) : e1;
+				const int g1 = i < LMAX ? rd(gap_at(i + 1 <= LMAX ? i + 1 : 1)) : 0;
+				const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // (i, j - 1)
+				int dn1 = 0, dn2 = 0, dn3 = 0;
+				if (i < LMAX) dn1 = cM + e1.x, dn2 = cQ + e1.y + q_first, dn3 = cT + e1.y; // e1: the NEXT row's entry
+				int qi = cM + e1.z, qe = cQ - v5;
+				asm volatile("" : "+v"(dn1), "+v"(dn2), "+v"(dn3), "+v"(qi), "+v"(qe), "+v"(dg1));
+				int M = dg1 > dg2 ? dg1 : dg2;
+				M = M > dg3 ? M : dg3;
+				const int Iq = qi > qe ? qi : qe;
+				const int ti = uM + (i == 1 ? c_forb_xy : g0), te = uT - (i == 1 ? c_zero : c_bulge);
+				const int It = ti > te ? ti : te;
+				const int Mz = M > 0 ? M : 0, Iqz = Iq > 0 ? Iq : 0, Itz = It > 0 ? It : 0;
+				const bool valid = i <= L;
+				colmax = (valid && Mz > colmax) ? Mz : colmax;
+				colst |= valid ? (Mz | Iqz | Itz) : 0;
+				uM = Mz, uT = Itz;
+				oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
+				dg1 = dn1, dg2 = dn2, dg3 = dn3;
+				e0 = e1, e1 = e2, g0 = g1;
+			}
+			vmax = (colok && colmax > vmax) ? colmax : vmax;
+			sticky |= colok ? colst : 0;
+			prtw = rtw, rtw = nrtw;
+		}
+		const int credit = (vmax & SB_CREDIT_MASK) * (FILT_UNITS / SB_UNITS); // 1e-3 kcal/mol
+		const bool guard = (sticky & SB_GUARD) != 0;
+		bool pass = true;
+		int theta = INT32_MIN;
+		if (served && a.tab->enabled[cls] && a.ftab->enabled[cls]) {
+			const float th = a.ftab->theta0[cls] - a.ftab->ct_scale[cls] * (a.ftab->tk[cls] * (1.9872e-3f * slot.log_ct));
+			theta = int(floorf(th * float(FILT_UNITS))) - 1;
+			pass = guard || credit >= theta;
+		}
+		if (a.score_out && active) a.score_out[2 * idx] = (guard || !served) ? INT32_MAX : credit, a.score_out[2 * idx + 1] = theta;
+		if (a.audit) {
+			if (active && !pass) a.audit[idx] = 1;
+			pass = true;
+		}
+		if (active && !pass && a.result) a.result[idx] = -1;
+		if (surv) {
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(active && pass);
+			n_rej += uint32_t(__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && !pass)));
+			if (active && pass) s_keep[wave][n_keep + uint32_t(__builtin_popcountll(m & ((1ull << lane) - 1ull)))] = idx;
+			n_keep += uint32_t(__builtin_popcountll(m));
+			if (n_keep >= 64u) {
+				filt_wave_sync();
+				uint32_t at = 0;
+				if (lane == 0) at = atomicAdd(a.n_survivors, 64u);
+				at = uint32_t(__builtin_amdgcn_readfirstlane(int(at)));
+				surv[at + lane] = s_keep[wave][lane];
+				const uint32_t rest = n_keep - 64u;
+				const uint32_t moved = uint32_t(lane) < rest ? s_keep[wave][64 + lane] : 0u;
+				filt_wave_sync();
+				if (uint32_t(lane) < rest) s_keep[wave][lane] = moved;
+				n_keep = rest;
+			}
+			filt_wave_sync();
+		}
+	}
+	if (surv) {
+		if (lane == 0) s_wcount[wave] = n_keep;
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t run = 0;
+			for (int w = 0; w < THREADS / 64; w++) {
+				const uint32_t c = s_wcount[w];
+				s_wcount[w] = run;
+				run += c;
+			}
+			s_wbase = run ? atomicAdd(a.n_survivors, run) : 0u;
+		}
+		__syncthreads();
+		if (uint32_t(lane) < n_keep) surv[s_wbase + s_wcount[wave] + lane] = s_keep[wave][lane];
+	}
+	if (a.n_rejected && lane == 0 && n_rej) atomicAdd(a.n_rejected, n_rej);
+}
+
 // host-side launchers, defined in tnt_bind_inst.hip (TNT_SBOUND_LADDER: the plain instances of up to 40 rows)
 #define TNT_SBOUND_LADDER(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40)
 #define X(N) void launch_sbound_##N(const SBoundArgs &a, int blocks, hipStream_t stream);
 TNT_SBOUND_LADDER(X)
+#undef X
+// ... and of the general buckets (ladder instances of up to 40 rows)
+#define TNT_SBOUND_DEGEN_LADDER(X) X(16) X(20) X(24) X(28) X(32) X(36) X(40)
+#define X(N) void launch_sbound_degen_##N(const SBoundDegenArgs &a, int blocks, hipStream_t stream);
+TNT_SBOUND_DEGEN_LADDER(X)
 #undef X
 
 } // namespace tnt

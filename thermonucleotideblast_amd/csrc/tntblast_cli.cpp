@@ -353,7 +353,11 @@ std::string primer_heuristics(const std::string &p)
 	int status = 0;
 	if (toupper(p.back()) == 'T') status |= NO_3_T;
 	unsigned tc = 0, ag = 0, g = 0, cc = 0, max_tc = 0, max_ag = 0, n_gc = 0, index = 0;
-	for (char ch : p) {
+	// The reference packs the primer into a CircleBuffer of MAX_PCR_LENGTH = 128 slots (primer.h:92, primer.cpp:330-370) whose
+	// push_back wraps without moving the head (circle_buffer.h:106-111): of an oligo of 128 bases or more the checks see the
+	// last `length mod 128` bases only.  Reproduced, so that the report of a long primer reads as the reference's does.
+	const std::string seen = p.size() >= 128 && p.size() % 128 ? p.substr(p.size() - p.size() % 128) : p;
+	for (char ch : seen) {
 		switch (toupper(ch)) {
 		case 'A': ag++, tc = 0, g = 0, cc = 0; break;
 		case 'T': tc++, ag = 0, g = 0, cc = 0; break;
