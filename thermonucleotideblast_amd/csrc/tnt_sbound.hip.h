@@ -55,8 +55,13 @@ constexpr uint32_t SB_HOLE = 0xFFFFFFFFu;
 // their column -- read sixteen different bank groups (the pitch of a column is an odd number of 16-byte entries)
 constexpr int SB_COLS = SB_X * SB_X;
 __host__ __device__ constexpr int sb_col(int xp, int x) { return (xp < 4 && x < 4) ? xp * 4 + x : (xp == 4 ? 16 + x : 21 + xp); }
-constexpr int sb_pitch(int lmax) { return (((lmax + 1) | 1)) * 16; } // bytes between two columns of the per-oligo table
-constexpr int sb_waves_per_simd(int lmax) { return lmax <= 25 ? 3 : 2; } // (LDS: four per-oligo tables per workgroup)
+// Per-oligo table of a wavefront, two arrays: T12[column][row] = {diagonal step, gap state -> aligned column} (8 bytes, one
+// ds_read_b64: banks modulo 64 in pairs, column pitch an odd number of pairs) and T3[column][row] = {aligned column -> gap state}
+// (4 bytes, ds_read_b32: banks modulo 32, column pitch twice an odd number of dwords): the sixteen columns of real base pairs
+// fall on sixteen different bank pairs / even banks, whatever the row.
+constexpr int sb_pitch12(int lmax) { return ((lmax + 1) | 1) * 8; }                          // bytes
+constexpr int sb_pitch3(int lmax) { return (((lmax + 1 + 1) / 2) | 1) * 2 * 4; }             // bytes
+constexpr int sb_waves_per_simd(int lmax) { return lmax <= 25 ? 4 : (lmax <= 37 ? 3 : 2); } // (registers: three per row; LDS: four per-oligo tables per workgroup)
 
 // One 16-byte entry per (x', x, q', q), read with ONE ds_read_b96: [0] the diagonal step, [1] into an aligned column from a gap
 // state, [2] from an aligned column into a gap state (read at the NEXT row's / the NEXT column's entry), [3] unused.
@@ -98,16 +103,17 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(SB_THREADS, sb_wave
 	static_assert(LMAX <= SB_MAX_ROWS, "instances of up to 40 rows");
 	constexpr int WMAX = LMAX + 2 * FLANK;
 	constexpr int NW = (WMAX + 15) / 16;
-	constexpr int PITCH = sb_pitch(LMAX);    // bytes
-	typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+	constexpr int PITCH12 = sb_pitch12(LMAX), PITCH3 = sb_pitch3(LMAX); // bytes
+	static_assert(PITCH12 >= (LMAX + 1) * 8 && PITCH3 >= (LMAX + 1) * 4 && ((PITCH12 / 8) & 1) && ((PITCH3 / 8) & 1), "column pitches");
+	typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
 	typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-	__shared__ __attribute__((aligned(16))) int32_t s_tab[SB_WAVES][SB_COLS * PITCH / 4];
+	__shared__ __attribute__((aligned(16))) int32_t s_tab[SB_WAVES][SB_COLS * (PITCH12 + PITCH3) / 4];
 	__shared__ uint32_t s_pref[SB_MAX_BINS + 1];  // blocks of the groups before group g
 	__shared__ uint32_t s_part[SB_THREADS];
 	__shared__ uint32_t s_keep[SB_WAVES][128];
 	__shared__ uint32_t s_wcount[SB_WAVES], s_wbase;
 	typedef __attribute__((address_space(3))) const int32_t lds_ci32;
-	typedef __attribute__((address_space(3))) const i32x3 lds_ci32x3;
+	typedef __attribute__((address_space(3))) const volatile i32x2 lds_ci32x2; // (volatile: not merged into ds_read2_b64, which banks modulo 32)
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	// ---- the launch's work: blocks of 64 survivors, group after group
@@ -144,7 +150,11 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(SB_THREADS, sb_wave
 	int cur_oligo = -1, cur_cls = -1;
 	int32_t *tabw = s_tab[wave];
 	const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)tabw)));
-	auto rd3 = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32x3 *)(uintptr_t(uint32_t(addr))); };
+	const int tab3_base = tab_base + SB_COLS * PITCH12;
+	auto rd2 = [&](int addr) __attribute__((always_inline)) {
+		const i32x2 v = *(lds_ci32x2 *)(uintptr_t(uint32_t(addr)));
+		return v;
+	};
 	auto rd = [&](int addr) __attribute__((always_inline)) { return *(lds_ci32 *)(uintptr_t(uint32_t(addr))); };
 
 	for (;;) {
@@ -195,7 +205,10 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(SB_THREADS, sb_wave
 					uint32_t q = bGAP, qp = bGAP;
 					if (i < L) q = (q4[i >> 2] >> ((i & 3) * 8 + 2)) & 7u;
 					if (i >= 1 && i - 1 < L) qp = (q4[(i - 1) >> 2] >> (((i - 1) & 3) * 8 + 2)) & 7u;
-					*reinterpret_cast<i32x4 *>(reinterpret_cast<char *>(tabw) + sb_col(xp, x) * PITCH + i * 16) = src[xx * NBP + int(7u * qp + q)];
+					const i32x4 v = src[xx * NBP + int(7u * qp + q)];
+					const int cc = sb_col(xp, x);
+					*reinterpret_cast<i32x2 *>(reinterpret_cast<char *>(tabw) + cc * PITCH12 + i * 8) = i32x2{v.x, v.y};
+					*reinterpret_cast<int32_t *>(reinterpret_cast<char *>(tabw) + SB_COLS * PITCH12 + cc * PITCH3 + i * 4) = v.z;
 				}
 				cur_oligo = oligo, cur_cls = cls;
 				filt_wave_sync();
@@ -273,27 +286,30 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(SB_THREADS, sb_wave
 				const int tn = base_of(j + 1);
 				const bool colok = j <= W;
 				const bool firstcol = j == 1;
-				const int colA = tab_base + col_of(tp, t) * PITCH;     // (x', x) = (previous column, this column)
-				const int colN = tab_base + col_of(t, tn) * PITCH + 8; // (this column, next column): the credit of a gap opened in the target strand
+				const int cA = col_of(tp, t);                          // (x', x) = (previous column, this column)
+				const int colA = tab_base + cA * PITCH12, colA3 = tab3_base + cA * PITCH3;
+				const int colN3 = tab3_base + col_of(t, tn) * PITCH3;  // (this column, next column): the credit of a gap opened in the target strand
 				const int v5 = firstcol ? c_zero : c_bulge;
 				const int q_first = firstcol ? SB_NEG / 2 : 0;         // (no aligned column before the first: nothing closes a gap state there)
 				int uM = 0, uT = 0;         // (i - 1, j), new values
 				int colmax = 0, colst = 0;
 				// the entries of rows i and i + 1 are in flight while row i - 1 is computed
-				i32x3 e0 = rd3(colA), e1 = rd3(colA + 16);
-				int g0 = rd(colN);
+				i32x2 e0 = rd2(colA), e1 = rd2(colA + 8);
+				int z1 = rd(colA3 + 4); // (the NEXT row's entry: what row 1 pays to open a gap in the query strand)
+				int g0 = rd(colN3);
 				// Row i also forms the diagonal candidates of row i + 1 (the bind kernel's arrangement): they need the old states of
 				// row i, which die there, so the new states take their registers and nothing is copied at the loop's back edge.
 				int dg1 = e0.x, dg2 = e0.y + q_first, dg3 = c_forb_m; // row 1: the border row above holds 0, 0, 0
 #pragma unroll
 				for (int i = 1; i <= LMAX; i++) {
-					const i32x3 e2 = i + 1 <= LMAX ? rd3(colA + 16 * (i + 1 <= LMAX ? i + 1 : LMAX)) : e1;
-					const int g1 = i < LMAX ? rd(colN + 16 * (i < LMAX ? i : 0)) : 0;
+					const i32x2 e2 = i + 1 <= LMAX ? rd2(colA + 8 * (i + 1 <= LMAX ? i + 1 : LMAX)) : e1;
+					const int z2 = i + 1 <= LMAX ? rd(colA3 + 4 * (i + 1 <= LMAX ? i + 1 : LMAX)) : 0;
+					const int g1 = i < LMAX ? rd(colN3 + 4 * (i < LMAX ? i : 0)) : 0;
 					const int cM = oM[i - 1], cQ = oQ[i - 1], cT = oT[i - 1]; // (i, j - 1)
 					// align_dimer, nuc_cruc.cpp:536-666, every table value = (-delta_g) << 11 | credit
 					int dn1 = 0, dn2 = 0, dn3 = 0;
 					if (i < LMAX) dn1 = cM + e1.x, dn2 = cQ + e1.y + q_first, dn3 = cT + e1.y; // e1: the NEXT row's entry, (q_i, q_i+1)
-					int qi = cM + e1.z, qe = cQ - v5;
+					int qi = cM + z1, qe = cQ - v5;
 					asm volatile("" : "+v"(dn1), "+v"(dn2), "+v"(dn3), "+v"(qi), "+v"(qe), "+v"(dg1)); // the old states of this row are dead from here on
 					int M = dg1 > dg2 ? dg1 : dg2;
 					M = M > dg3 ? M : dg3;
@@ -312,7 +328,7 @@ template <int LMAX, bool EXACT> __global__ __launch_bounds__(SB_THREADS, sb_wave
 					uM = Mz, uT = Itz;
 					oM[i - 1] = Mz, oQ[i - 1] = Iqz, oT[i - 1] = Itz;
 					dg1 = dn1, dg2 = dn2, dg3 = dn3;
-					e0 = e1, e1 = e2, g0 = g1;
+					e0 = e1, e1 = e2, z1 = z2, g0 = g1;
 				}
 				vmax = (colok && colmax > vmax) ? colmax : vmax;
 				sticky |= colok ? colst : 0;
