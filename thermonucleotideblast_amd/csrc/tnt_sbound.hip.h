@@ -449,7 +449,15 @@ template <int LMAX> __global__ __launch_bounds__(SBD_THREADS, 2) void sbound_deg
 	}
 	if (uint32_t(blockIdx.x) * uint32_t(THREADS) >= n_items) return; // (nothing to do: leave before staging 56 KB of tables)
 	for (int i = tid; i < FILT_CLASSES * SBD_ENTRIES * 4; i += THREADS) s_tab[i] = (&a.dtab->entry[0][0][0])[i];
-	if (tid < 18) s_rt[tid] = a.rt[tid];
+	if (tid < 18) { // the resolution words as table coordinates: nibble q = min(base, 5) (5: none)
+		const uint32_t w = a.rt[tid];
+		uint32_t v = 0;
+		for (int q = 0; q < 8; q++) {
+			const uint32_t x = (w >> (4 * q)) & 15u;
+			v |= (x < 5u ? x : 5u) << (4 * q);
+		}
+		s_rt[tid] = v;
+	}
 	__syncthreads();
 	const int c_bulge = a.tab->bulge, c_zero = a.tab->zero, c_forb_m = a.tab->forb_m, c_forb_xy = a.tab->forb_xy;
 	const uint32_t *index = a.index + (a.index_base_dev ? *a.index_base_dev : 0u);
@@ -510,11 +518,16 @@ template <int LMAX> __global__ __launch_bounds__(SBD_THREADS, 2) void sbound_deg
 		auto q4_of = [&](int i) __attribute__((always_inline)) { return (q4p[i >> 2] >> ((i & 3) * 8)) & 255u; }; // 4 * base code of row i
 		const int cls = filter_class(slot.thresh);
 		const int tab_base = int(uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)s_tab))) + cls * CLS_BYTES;
-		// the base a column's code resolves to against the query base of row i, as a table coordinate (5: none)
-		auto rx = [&](uint32_t rtw, uint32_t q4) __attribute__((always_inline)) {
-			const uint32_t v = __builtin_amdgcn_ubfe(rtw, q4, 4u);
-			return v < 5u ? v : 5u;
-		};
+		// the rows' part of an entry's address, with the table's base: tab_base + 16 * (7 q_i-1 + q_i) for i = 1 .. LMAX + 1, two to a register
+		constexpr int NRT = (LMAX + 2 + 1) / 2;
+		uint32_t rtab[NRT];
+#pragma unroll
+		for (int k = 0; k < NRT; k++) rtab[k] = 0;
+#pragma unroll
+		for (int i = 1; i <= LMAX + 1; i++) rtab[i >> 1] |= (uint32_t(tab_base) + (7u * q4_of(i - 1) + q4_of(i)) * 4u) << ((i & 1) * 16);
+		auto rtab_of = [&](int i) __attribute__((always_inline)) { return (rtab[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu; };
+		// the base a column's code resolves to against the query base of row i, as a table coordinate (5: none; s_rt holds them clamped)
+		auto rx = [&](uint32_t rtw, uint32_t q4) __attribute__((always_inline)) { return __builtin_amdgcn_ubfe(rtw, q4, 4u); };
 
 		int Wwave = W;
 #pragma unroll
@@ -539,17 +552,17 @@ template <int LMAX> __global__ __launch_bounds__(SBD_THREADS, 2) void sbound_deg
 			const int q_first = firstcol ? SB_NEG / 2 : 0;
 #pragma unroll
 			for (int k = 0; k < NQ; k++) asm volatile("" : "+v"(q4p[k])); // (kept in registers, not re-derived per column)
+#pragma unroll
+			for (int k = 0; k < NRT; k++) asm volatile("" : "+v"(rtab[k]));
 			// entry of row i: (x', x) = (previous column against row i - 1, this column against row i), rows (q_i-1, q_i);
 			// the gap-opening credit of row i: (this column against row i - 1, next column against row i)
 			auto entry_at = [&](int i) __attribute__((always_inline)) {
-				const uint32_t qa = q4_of(i - 1), qb = q4_of(i);
-				const uint32_t col = rx(prtw, qa) * uint32_t(SBD_X) + rx(rtw, qb);
-				return tab_base + int((col * uint32_t(NBP) + (7u * qa + qb) / 4u) * 16u);
+				const uint32_t col = rx(prtw, q4_of(i - 1)) * uint32_t(SBD_X) + rx(rtw, q4_of(i));
+				return int(col * uint32_t(NBP * 16) + rtab_of(i));
 			};
 			auto gap_at = [&](int i) __attribute__((always_inline)) {
-				const uint32_t qa = q4_of(i - 1), qb = q4_of(i);
-				const uint32_t col = rx(rtw, qa) * uint32_t(SBD_X) + rx(nrtw, qb);
-				return tab_base + int((col * uint32_t(NBP) + (7u * qa + qb) / 4u) * 16u) + 8;
+				const uint32_t col = rx(rtw, q4_of(i - 1)) * uint32_t(SBD_X) + rx(nrtw, q4_of(i));
+				return int(col * uint32_t(NBP * 16) + rtab_of(i)) + 8;
 			};
 			int uM = 0, uT = 0;
 			int colmax = 0, colst = 0;
