@@ -23,11 +23,13 @@
 // than 2^10 units, so bit 10 of the credit field is a guard: once it is set in any state the window passes (20.48 kcal/mol is
 // above every threshold this tier is enabled for) and what the sums do afterwards is ignored.
 //
-// No trace words, no traceback, no scoring: 14 instructions and two LDS reads at immediate offsets per cell against the fill's 36
-// and nothing behind them; the first tier hands its survivors over group by group, so a wavefront holds ONE oligo's table.  Plain
-// windows (A/C/G/T targets) of oligos of up to 40 bases; everything else goes from the first tier straight to the bind kernel.
+// No trace words, no traceback, no scoring: 13 VALU instructions and three LDS reads at immediate offsets per cell against the
+// fill's 36 and nothing behind them; the first tier hands its survivors over group by group, so a wavefront holds ONE oligo's
+// table (sbound_kernel: plain windows -- A/C/G/T targets -- of oligos of up to 40 bases in the regrouped buckets).  Windows with an
+// IUPAC code or an inosine take sbound_degen_kernel (the general buckets of phase A: a column's code resolved against the query
+// base of every row, one table for all oligos); everything else goes from the first tier straight to the bind kernel.
 // tests: tests/test_filter_bound.py (soundness of the oracle-side restatement, tier 3), tests/test_gpu_parity.py
-// (kernel == restatement; searches with the tier on / off / in audit mode).
+// (kernels == restatement; searches with the tier on / off / in audit mode).
 #ifndef TNT_SBOUND_HIP_H
 #define TNT_SBOUND_HIP_H
 

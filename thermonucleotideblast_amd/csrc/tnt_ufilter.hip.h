@@ -18,8 +18,10 @@
 //    base of column j is a bit field at a wave-uniform position.
 //
 // The result per window -- bound, threshold, pass / reject -- is the old kernel's, integer by integer
-// (tests/test_gpu_parity.py::test_filter_kernel_equals_its_checker runs both against the oracle-side checker); windows
-// with a degenerate target base, phase B, oligos beyond 64 bases and the unit-level routes stay with filter_kernel.
+// (tests/test_gpu_parity.py::test_filter_kernel_equals_its_checker runs both against the oracle-side checker); the general
+// buckets (windows with a degenerate target base) take the DEGEN instance below; phase B, oligos beyond 64 bases and the
+// unit-level routes stay with filter_kernel.  Survivors leave as one dense list per bucket or -- for the second tier,
+// tnt_sbound.hip.h -- group by group (UFilterArgs::bin_fill).
 #ifndef TNT_UFILTER_HIP_H
 #define TNT_UFILTER_HIP_H
 
