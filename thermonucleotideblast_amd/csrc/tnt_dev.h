@@ -230,6 +230,21 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Inclusive prefix sum over the 64 lanes of a wavefront in the VALU's data-parallel-primitive forms: four row_shr steps scan
+// every row of 16 lanes, row_bcast:15 carries a row's total into the next row, row_bcast:31 the first half's into the second
+// (gfx9 controls; lanes without a source take 0).  Six v_add_u32_dpp -- the shuffle form is six LDS crossbar reads
+// (ds_bpermute_b32) each followed by a compare, a select and an add.
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x)
+{
+	x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false)); // row_shr:1
+	x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false)); // row_shr:2
+	x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false)); // row_shr:4
+	x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false)); // row_shr:8
+	x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false)); // row_bcast:15 into rows 1 and 3
+	x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false)); // row_bcast:31 into rows 2 and 3
+	return x;
+}
+__device__ __forceinline__ uint32_t wave_last(uint32_t x) { return uint32_t(__builtin_amdgcn_readlane(int(x), 63)); }
 __device__ __forceinline__ uint32_t shard_locate(const uint32_t *pre, uint32_t lin, uint32_t region)
 {
 	uint32_t r = 0;

@@ -588,6 +588,7 @@ struct tnt_db {
 	DevBuf<uint4> unit_rec;         // whole-target units: {target, bases, first packed word (64 bits)}: one scalar load per unit
 	DevBuf<int32_t> unit_own_lo, unit_own_hi;
 	uint32_t max_unit_len = 0;
+	uint32_t max_short_len = 0; // longest target that is searched as one work unit (the units the round-3 seed kernel sees)
 	size_t n_short_units = 0;       // units [0, n_short_units) are whole targets, the rest windows of long targets
 	std::vector<uint32_t> h_long_targets; // targets that are seeded in windows and paired on the host
 	bool split = false;             // some target is cut into windows
@@ -693,6 +694,7 @@ struct tnt_ctx {
 	DevBuf<uint32_t> wt_ent, wl_off;
 	DevBuf<unsigned long long> wl_seq;
 	std::vector<unsigned long long> h_wl_seq; // host copy: the per-entry copies of a chunk's table are made from it (plan)
+	DevBuf<uint4> wt_rec;                     // [entry] {entry, first 32 bases of its oligo, 0}: the dense pass's one load per candidate
 	DevBuf<unsigned long long> wt_seq;        // [entry][2] the packed oligo of every table entry (the round-3 seed kernel reads entry and oligo with one index)
 	DevBuf<uint16_t> wt_off, wlist;
 	std::vector<std::vector<std::pair<uint16_t, uint32_t>>> assay_entries; // per assay: (word, entry bits)
@@ -2001,7 +2003,7 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 	db->h_unit_target.clear(), db->h_unit_begin.clear(), db->h_unit_end.clear();
 	db->h_unit_own_lo.clear(), db->h_unit_own_hi.clear();
 	db->h_long_targets.clear();
-	db->max_unit_len = 0;
+	db->max_unit_len = 0, db->max_short_len = 0;
 	db->split = false;
 	// Whole targets first: they go through the device pipeline (seed -> bind -> pair per work unit).  A target is searched
 	// whole whenever it can be: the reference's culls and pairing act on the lists of the whole target.  It is cut into
@@ -2021,7 +2023,7 @@ hipError_t build_units(tnt_ctx *ctx, tnt_db *db)
 		const uint32_t npos = len >= uint32_t(k) ? len - uint32_t(k) + 1u : 0u;
 		db->h_unit_target.push_back(uint32_t(t)), db->h_unit_begin.push_back(0), db->h_unit_end.push_back(npos);
 		db->h_unit_own_lo.push_back(INT32_MIN), db->h_unit_own_hi.push_back(INT32_MAX);
-		db->max_unit_len = std::max(db->max_unit_len, len);
+		db->max_unit_len = std::max(db->max_unit_len, len), db->max_short_len = std::max(db->max_short_len, len);
 	}
 	db->n_short_units = db->h_unit_target.size();
 	for (size_t t = 0; t < db->n_targets; t++) {
@@ -2774,7 +2776,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		// DESIGN.md 4.1), although the scan on its own runs 3.6 x faster out of LDS (tnt_seed_scan_only)
 		const bool ltab = c->opt.hash_word_size <= 7 && getenv("TNT_MI355X_SEED2_LDS_TABLE");
 		const size_t S2_WAVES = size_t(s2_waves(ltab));
-		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * (ltab ? 1 : 4), tnt_ctx::MAX_REGIONS / S2_WAVES)));
+		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * (ltab ? 1 : TNT_S2_OCC), tnt_ctx::MAX_REGIONS / S2_WAVES)));
 		const uint32_t regions = blocks * uint32_t(S2_WAVES);
 		c->batch_regions = regions;
 		HIP_TRY(hipMemsetAsync(c->S().region_counts.p, 0, sizeof(uint32_t) * 2 * regions, seed_stream), c->err);
@@ -2810,6 +2812,8 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 			q.slot_bin = c->slot_bin.p, q.bin_base = c->rg_bin_base_dev.p, q.bin_hist = c->S().rg_hist.p, q.n_bins = c->rg_total_bins;
 		q.err = gcnt + C_ERR;
 		q.debug = gcnt + C_DEBUG + 8;
+		const bool units_short = !getenv("TNT_MI355X_SEED2_GENERAL") && db->max_short_len <= size_t(S2_TGT_WORDS) * 16 && c->opt.max_len >= 0 &&
+		                         size_t(db->max_short_len) <= size_t(c->opt.max_len) + 50 + size_t(c->opt.hash_word_size);
 		const size_t n_words2 = size_t(1) << (2 * c->opt.hash_word_size);
 		const size_t off_stride2 = (n_words2 + 1 + 1) & ~size_t(1);
 		for (size_t ch = 0; ch + 1 < c->chunk_begin.size(); ch++) {
@@ -2818,15 +2822,19 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 			q.wt_off = c->wt_off.p + ch * off_stride2;
 			q.wt_ent = c->wt_ent.p + c->chunk_ent_base[ch];
 			q.wt_seq = reinterpret_cast<const uint4 *>(c->wt_seq.p) + c->chunk_ent_base[ch];
+			q.wt_rec = c->wt_rec.p + c->chunk_ent_base[ch];
 			q.chunk_has_probe = 0;
 			for (uint32_t ai = q.assay_begin; ai < q.assay_end; ai++)
 				if (c->h_assays[ai].kind == 0 && c->h_assays[ai].has_probe) q.chunk_has_probe = 1;
 			q.last_chunk = ch + 2 == c->chunk_begin.size() ? 1 : 0;
 			// (an instance compiled for the default word size -W 7, one that takes it at run time)
-			if (q.word_size == 7 && ltab) hipLaunchKernelGGL((seed2_kernel<7, true>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
-			else if (q.word_size == 7) hipLaunchKernelGGL((seed2_kernel<7, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
-			else if (ltab) hipLaunchKernelGGL((seed2_kernel<0, true>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
-			else hipLaunchKernelGGL((seed2_kernel<0, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
+			// ... and one for databases of short targets (SHORT: every unit in LDS and within the first cull's reach as a whole)
+			if (q.word_size == 7 && ltab) hipLaunchKernelGGL((seed2_kernel<7, true, false>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
+			else if (q.word_size == 7 && units_short) hipLaunchKernelGGL((seed2_kernel<7, false, true>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
+			else if (q.word_size == 7) hipLaunchKernelGGL((seed2_kernel<7, false, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
+			else if (ltab) hipLaunchKernelGGL((seed2_kernel<0, true, false>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
+			else if (units_short) hipLaunchKernelGGL((seed2_kernel<0, false, true>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
+			else hipLaunchKernelGGL((seed2_kernel<0, false, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
 		}
 	}
 	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
@@ -2969,7 +2977,8 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	// word: mean = len * sum(m_w) / 4^k, variance = len * sum(m_w^2) / 4^k (expanded degenerate assays share words, so
 	// their seeds come in bursts).  A chunk grows while mean + 6 sigma stays below the list size; a target that
 	// overflows it anyway makes tnt_search_collect halve chunk_scale and repeat the search.
-	const double cap = double(SEED_CAP) * c->chunk_scale;
+	const bool s2_ltab = c->opt.hash_word_size <= 7 && getenv("TNT_MI355X_SEED2_LDS_TABLE");
+	const double cap = double(c->seed2 ? s2_cap(s2_ltab) : SEED_CAP) * c->chunk_scale;
 	// the streaming seed kernel keeps a chunk's table in LDS: hash words up to 7 bases, at most SEED_LDS_ENT entries
 	// (measured slower than the instance reading them through L2 at twice the occupancy: opt-in until the stages behind
 	// the scan are split off into their own launch)
@@ -3031,6 +3040,10 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 				es[2 * i] = c->h_wl_seq[2 * li], es[2 * i + 1] = c->h_wl_seq[2 * li + 1];
 			}
 			HIP_TRY(c->wt_seq.upload(es), c->err);
+			// the dense pass of the round-3 seed kernel reads an entry and the first 32 bases of its oligo as one record
+			std::vector<uint4> rec(ent.size() + 1, make_uint4(0, 0, 0, 0));
+			for (size_t i = 0; i < ent.size(); i++) rec[i] = make_uint4(ent[i], uint32_t(es[2 * i]), uint32_t(es[2 * i] >> 32), 0u);
+			HIP_TRY(c->wt_rec.upload(rec), c->err);
 		}
 		c->planned_chunks = chunk_begin;
 	}

@@ -45,12 +45,17 @@ namespace tnt {
 // config 2, tnt_seed_scan_only) -- the whole kernel runs SLOWER (config 2: 5.9 against 5.3 ms; config 4, sixteen chunk launches
 // per batch: 50.7 against 37.2 ms per 100 k targets): the table reads were hitting L1 anyway, and a 1024-thread workgroup only
 // starts when a whole CU has drained.  Kept as an instance, not used by default.
-constexpr int s2_waves(bool ltab) { return ltab ? 16 : 4; }
+#ifndef TNT_S2_WAVES
+#define TNT_S2_WAVES 4
+#endif
+constexpr int s2_waves(bool ltab) { return ltab ? 16 : TNT_S2_WAVES; }
 constexpr int S2_TAB_WORDS = (1 << 14) + 2; // bucket offsets of a chunk for hash words of up to 7 bases
 #ifndef TNT_S2_CAP
 #define TNT_S2_CAP 512
 #endif
 constexpr int S2_CAP = TNT_S2_CAP;     // seeds of one target x one assay chunk held in LDS
+constexpr int S2_CAP_LTAB = 512;       // ... by the instance that also keeps the chunk's bucket offsets there (sixteen wavefronts per workgroup)
+constexpr int s2_cap(bool ltab) { return ltab ? S2_CAP_LTAB : S2_CAP; }
 constexpr int S2_ASSAYS = 128;         // assays per chunk (7-bit local index in the key)
 #ifndef TNT_S2_SWEEP
 #define TNT_S2_SWEEP 16
@@ -59,6 +64,10 @@ constexpr int S2_SWEEP = TNT_S2_SWEEP; // positions per lane and sweep (16 or 8)
 constexpr int S2_TGT_WORDS = 128;       // packed words of a target parked in LDS (2 048 bases); longer targets are read from HBM
 constexpr uint32_t QUEUE_BLOCK = 64;   // queue slots handed out at a time (one filter / bind wavefront reads one block)
 constexpr uint32_t QUEUE_HOLE = 0xFFFFFFFFu; // a queue slot without an item
+#ifndef TNT_S2_FLIGHT
+#define TNT_S2_FLIGHT 6
+#endif
+constexpr int S2_FLIGHT = TNT_S2_FLIGHT; // candidates per lane whose table records are in flight together in the dense pass
 constexpr int S2_BINS = 448;              // (oligo, threshold class) groups a workgroup counts in LDS (what is left of a quarter of a CU's 160 KB next to the other arrays)
 
 struct Seed2Args {
@@ -71,6 +80,7 @@ struct Seed2Args {
 	const uint16_t *wlist;       // concatenated word lists
 	const uint32_t *wl_off;      // [((assay * 3 + role) * 2 + minus)] -> first word
 	const uint4 *wt_seq;         // [entry] the strand-specific oligo of the entry's list, 2 bits per base, base 0 in the low bits
+	const uint4 *wt_rec;         // [entry] {the entry, the first 32 bases of that oligo, 0}: what the dense pass reads per candidate, as one load
 	uint32_t assay_begin, assay_end;
 	const AssayDev *assays;
 	int chunk_has_probe;         // some PCR assay of the chunk has a probe (TaqMan)
@@ -154,9 +164,13 @@ template <int WS> __device__ __forceinline__ bool s2_first_packed(uint32_t W0, u
 #ifndef TNT_S2_OCC
 #define TNT_S2_OCC 4 // workgroups per CU the kernel is compiled for (5: registers capped at 96, the aliased LDS arrays of LTAB)
 #endif
-template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), LTAB ? 1 : TNT_S2_OCC) void seed2_kernel(Seed2Args a)
+// SHORT: the host vouches that every unit of the launch fits the LDS copy of a target (S2_TGT_WORDS packed words) and lies within
+// the first cull's reach as a whole (bases - k <= max_len + 50): the tests per unit, the reads of target words from HBM and the
+// cull's general loop are compiled out (1-kb and 2-kb targets against the default -l 2000: every BASELINE configuration).
+template <int WS, bool LTAB, bool SHORT> __global__ __launch_bounds__(64 * s2_waves(LTAB), LTAB ? 1 : TNT_S2_OCC) void seed2_kernel(Seed2Args a)
 {
 	constexpr int S2_WAVES = s2_waves(LTAB), S2_THREADS = 64 * S2_WAVES;
+	constexpr int S2_CAP = s2_cap(LTAB); // (the instance's list capacity: shadows the namespace constant)
 	constexpr bool ALIAS = LTAB || TNT_S2_OCC > 4; // the target's words inside s_ext, the emission's scratch words inside s_srt
 	static_assert(S2_ASSAYS * 4 >= S2_TGT_WORDS + 4 && S2_CAP >= 3 * MAX_BUCKETS, "the shared arrays hold their lodgers");
 	__shared__ uint32_t s_raw[S2_WAVES][S2_CAP];      // kept seeds (keys) as the dense pass finds them
@@ -172,7 +186,6 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 	__shared__ uint8_t s_af[S2_ASSAYS];               // per assay of the chunk: 1 probe / padlock assay (hash-overload lists), 2 PCR with a probe
 	__shared__ uint32_t s_slot[S2_ASSAYS * 3];        // slot_pack of the chunk's slots
 	__shared__ uint32_t s_qbase[MAX_BUCKETS], s_qcap[MAX_BUCKETS];
-	__shared__ uint32_t s_cells[S2_WAVES];            // DP cells of the windows this wavefront queued (statistics)
 	__shared__ uint32_t s_bhist[S2_BINS];             // entries per (oligo, class) group written by this workgroup (Seed2Args::bin_hist)
 	__shared__ uint32_t s_bin[S2_ASSAYS * 3];         // per slot of the chunk: group in bin_hist of its plain bucket | of its general bucket << 16
 	// pointers the emission needs: read from LDS where they are used (kept in registers they spill to scratch memory,
@@ -224,13 +237,13 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		s_qend[wv][lane] = a.q_state[(region * MAX_BUCKETS + lane) * 2 + 1];
 	}
 	if (lane < 4) tgt[S2_TGT_WORDS + lane] = 0; // (slack behind the last word: the scan and the diagonal test read ahead)
-	if (lane == 0) s_cells[wv] = 0;
 	__syncthreads();
 
 	const uint32_t item_lo = region * a.item_region, group_lo = region * a.group_region;
 	uint32_t item_cur = item_lo + a.region_counts[2 * region], group_cur = group_lo + a.region_counts[2 * region + 1];
 	const uint32_t item_first = item_cur, group_first = group_cur;
 	uint32_t n_phase_a = 0;
+	uint32_t my_cells = 0; // DP cells of the windows this lane queued (statistics)
 
 	// Software pipeline over the wavefront's units: the record of unit i + 2 (one scalar load) and the packed words of
 	// unit i + 1 (two dwords per lane) are in flight while unit i is processed.
@@ -239,8 +252,8 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 	auto load_words = [&](const uint4 rec, uint32_t &w0, uint32_t &w1) __attribute__((always_inline)) {
 		const uint32_t nw = (rec.y + 15u) >> 4; // words of the target
 		const uint32_t *pk = a.db.packed + (uint64_t(rec.z) | (uint64_t(rec.w) << 32));
-		w0 = uint32_t(lane) < nw && nw <= uint32_t(S2_TGT_WORDS) ? pk[lane] : 0u;
-		w1 = uint32_t(lane) + 64u < nw && nw <= uint32_t(S2_TGT_WORDS) ? pk[lane + 64] : 0u;
+		w0 = uint32_t(lane) < nw && (SHORT || nw <= uint32_t(S2_TGT_WORDS)) ? pk[lane] : 0u;
+		w1 = uint32_t(lane) + 64u < nw && (SHORT || nw <= uint32_t(S2_TGT_WORDS)) ? pk[lane + 64] : 0u;
 	};
 #ifdef TNT_EXP_STATS
 	long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
@@ -261,7 +274,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 	for (; unit < a.unit1; unit += stride) {
 		const uint32_t t = rec_cur.x, len = rec_cur.y;
 		const uint32_t *pk = a.db.packed + (uint64_t(rec_cur.z) | (uint64_t(rec_cur.w) << 32));
-		const bool in_lds = ((len + 15u) >> 4) <= uint32_t(S2_TGT_WORDS);
+		const bool in_lds = SHORT ? true : ((len + 15u) >> 4) <= uint32_t(S2_TGT_WORDS);
 		const uint32_t rec_words = rec_cur.z; // first packed word of the target (the host checks that the packed array stays below 2^32 words)
 		// this unit's words -> LDS; the next unit's words and the record behind it -> in flight
 		tgt[lane] = wc0, tgt[lane + 64] = wc1;
@@ -272,7 +285,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 		if (len < uint32_t(a.word_size)) continue; // tntblast_local.cpp:513
 		const uint32_t npos = len - a.word_size + 1;
 		// the first cull's reach covers the whole target: "a partner within max_len + 50" is "a partner" (see the head)
-		const bool in_reach = npos - 1u <= threshold;
+		const bool in_reach = SHORT ? true : npos - 1u <= threshold;
 		for (uint32_t i = lane; i < (n_chunk + 1u) / 2u; i += 64) reinterpret_cast<uint32_t *>(hist)[i] = 0;
 		uint32_t nkept = 0; // kept seeds so far (wave-uniform)
 		wave_sync();
@@ -290,62 +303,65 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 
 		// ---------------------------------------------------------------- scan + diagonal de-duplication
 		uint32_t *cand = srt; // position | entry index << 15
-		// One candidate: its table entry and the oligo the entry belongs to come with the same index (two loads, one
-		// round trip); the target words come from LDS.
+		// One candidate: its table entry and the first 32 bases of the oligo the entry belongs to come as one 16-byte record
+		// (Seed2Args::wt_rec), S2_FLIGHT candidates per lane in flight; the target words come from LDS.
 		struct Cand {
-			uint32_t cp, ent, idx;
-			uint2 seq; // the first 32 bases of the entry's oligo
-			bool live;
+			uint32_t cv;  // position | entry index << 15
+			uint32_t ent;
+			uint2 seq;    // the first 32 bases of the entry's oligo
 		};
 		auto fetch = [&](uint32_t c, uint32_t ncand) __attribute__((always_inline)) {
 			Cand x;
-			x.live = c < ncand;
-			x.cp = 0, x.ent = 0, x.idx = 0, x.seq = make_uint2(0, 0);
-			if (x.live) {
-				const uint32_t cv = cand[c];
-				x.cp = cv & 0x7FFFu;
-				x.idx = cv >> 15;
-				x.ent = a.wt_ent[x.idx];
-				x.seq = *reinterpret_cast<const uint2 *>(a.wt_seq + x.idx);
+			x.cv = 0, x.ent = 0, x.seq = make_uint2(0, 0);
+			if (c < ncand) {
+				x.cv = cand[c];
+				const uint4 r = a.wt_rec[x.cv >> 15];
+				x.ent = r.x, x.seq = make_uint2(r.y, r.z);
 			}
 			return x;
 		};
-		auto settle = [&](const Cand &x) __attribute__((always_inline)) {
-			bool first = false;
-			uint32_t key = 0, la = 0;
-			if (x.live) {
-				const uint32_t wi = x.ent & 127u, cp = x.cp;
-				const uint32_t assay = x.ent >> WT_ASSAY_SHIFT;
-				const uint32_t kmax = wi < cp ? wi : cp;
-				if (kmax == 0u) {
-					first = true;
-				} else if ((x.ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) {
-					const uint32_t w0 = (cp - kmax) >> 4;
-					uint32_t o_lo = x.seq.x, o_hi = x.seq.y;
-					if (wi + uint32_t(a.word_size) <= 32u) {
-						// every compared base lies in the first 32 of the oligo (x.seq): the oligo from base wi - kmax on is a shift
-						// of those two words -- by nothing unless the seed sits less than wi bases into the target.  (Without a
-						// branch: one lane in a hundred is such a seed, but one wavefront in two holds one, and the branch's load
-						// was a memory round trip of its own.)
-						const uint32_t s2 = (wi - kmax) * 2u;
-						const uint32_t a_lo = __builtin_amdgcn_alignbit(o_hi, o_lo, s2 & 31u), a_hi = o_hi >> (s2 & 31u);
-						o_lo = s2 < 32u ? a_lo : a_hi, o_hi = s2 < 32u ? a_hi : 0u;
-					} else if (kmax != wi) { // a long oligo's seed less than wi bases into the target: the oligo from base wi - kmax on (rare)
-						const uint4 q = a.wt_seq[x.idx];
+		// The common case -- a plain A/C/G/T oligo whose compared stretch lies in its first 32 bases -- is straight-line code for
+		// every lane (selects, no branches: the candidates of a trip interleave in the instruction stream); the others (oligos
+		// with inosine or IUPAC codes, more than 25 bases before the seed) take a branch the wavefront seldom meets.
+		auto settle = [&](uint32_t c, uint32_t ncand, const Cand &x) __attribute__((always_inline)) {
+			const bool live = c < ncand;
+			const uint32_t wi = x.ent & 127u, cp = x.cv & 0x7FFFu;
+			const uint32_t assay = x.ent >> WT_ASSAY_SHIFT;
+			const uint32_t kmax = wi < cp ? wi : cp;
+			// (the compared stretch -- kmax bases and the word -- fits 32 bases, and starts at base 0 of the oligo or lies in its first 32)
+			const bool packed = (x.ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u && (kmax == wi || wi + uint32_t(a.word_size) <= 32u);
+			bool first;
+			{
+				// every compared base lies in the first 32 of the oligo (x.seq): the oligo from base wi - kmax on is a shift of
+				// those two words -- by nothing unless the seed sits less than wi bases into the target.  kmax == 0 (the first
+				// word of the oligo, or the first position of the target): nothing lies before the seed, the test says "first".
+				const uint32_t w0 = (cp - kmax) >> 4;
+				const uint32_t s2 = (wi - kmax) * 2u;
+				const uint32_t a_lo = __builtin_amdgcn_alignbit(x.seq.y, x.seq.x, s2 & 31u), a_hi = x.seq.y >> (s2 & 31u);
+				const uint32_t o_lo = s2 < 32u ? a_lo : a_hi, o_hi = s2 < 32u ? a_hi : 0u;
+				first = s2_first_packed<WS>(tw(w0), tw(w0 + 1), tw(w0 + 2), o_lo, o_hi, cp, kmax, a.word_size);
+			}
+			const bool other = live && !packed && kmax != 0u;
+			if (__builtin_amdgcn_ballot_w64(other) != 0ull) {
+				if (other) {
+					if ((x.ent & WT_PLAIN) && kmax + uint32_t(a.word_size) <= 32u) {
+						// a long oligo's seed less than wi bases into the target: the oligo from base wi - kmax on
+						const uint4 q = a.wt_seq[x.cv >> 15];
+						const uint32_t w0 = (cp - kmax) >> 4;
 						const uint32_t s2 = (wi - kmax) * 2u, word = s2 >> 5, sh2 = s2 & 31u;
 						const uint32_t oa = word == 0 ? q.x : (word == 1 ? q.y : (word == 2 ? q.z : q.w));
 						const uint32_t ob = word == 0 ? q.y : (word == 1 ? q.z : (word == 2 ? q.w : 0u));
 						const uint32_t oc = word == 0 ? q.z : (word == 1 ? q.w : 0u);
-						o_lo = __builtin_amdgcn_alignbit(ob, oa, sh2), o_hi = __builtin_amdgcn_alignbit(oc, ob, sh2);
+						first = s2_first_packed<WS>(tw(w0), tw(w0 + 1), tw(w0 + 2), __builtin_amdgcn_alignbit(ob, oa, sh2), __builtin_amdgcn_alignbit(oc, ob, sh2), cp, kmax, a.word_size);
+					} else {
+						const uint32_t li = (assay * 3u + ((x.ent >> 8) & 3u)) * 2u + ((x.ent & WT_MINUS) ? 1u : 0u);
+						first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
 					}
-					first = s2_first_packed<WS>(tw(w0), tw(w0 + 1), tw(w0 + 2), o_lo, o_hi, cp, kmax, a.word_size);
-				} else {
-					const uint32_t li = (assay * 3u + ((x.ent >> 8) & 3u)) * 2u + ((x.ent & WT_MINUS) ? 1u : 0u);
-					first = first_on_diagonal_words(pk, a.wlist + a.wl_off[li], wi, cp, wmask);
 				}
-				la = assay - a.assay_begin;
-				key = s2_key(la, x.ent, cp);
 			}
+			first = first && live;
+			const uint32_t la = assay - a.assay_begin;
+			const uint32_t key = s2_key(la, x.ent, cp);
 			const unsigned long long m = __builtin_amdgcn_ballot_w64(first);
 			if (first) {
 				const uint32_t slot = nkept + s2_rank(m);
@@ -384,13 +400,8 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 					bnd[q] = e0 | (n << 16);
 					mine += n;
 				}
-				uint32_t incl = mine;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-					const uint32_t y = __shfl_up(incl, d);
-					if (lane >= d) incl += y;
-				}
-				const uint32_t total = __shfl(incl, 63);
+				const uint32_t incl = wave_prefix_sum(mine);
+				const uint32_t total = wave_last(incl);
 				if (ncand + total > uint32_t(S2_CAP)) {
 					if (ncand == 0) { // a burst: position by position
 						slow = true;
@@ -421,12 +432,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 						const uint32_t e1 = LTAB ? s_tab[w + 1] : a.wt_off[w + 1];
 						cnt = e1 > e0 ? e1 - e0 : 0u;
 					}
-					uint32_t incl = cnt; // inclusive prefix of cnt over the lanes
-#pragma unroll
-					for (int d = 1; d < 64; d <<= 1) {
-						const uint32_t y = __shfl_up(incl, d);
-						if (lane >= d) incl += y;
-					}
+					const uint32_t incl = wave_prefix_sum(cnt); // inclusive prefix of cnt over the lanes
 					const uint32_t at = ncand + incl - cnt;
 					const uint32_t fit = at < uint32_t(S2_CAP) ? (cnt < uint32_t(S2_CAP) - at ? cnt : uint32_t(S2_CAP) - at) : 0u;
 					for (uint32_t x = 0; x < fit; x++) cand[at + x] = slow_p | ((e0 + x) << 15);
@@ -435,7 +441,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 						if (fit == cnt) slow_p += 64, slow_done = 0;
 						else slow_done += fit, over = true;
 					}
-					const uint32_t total = __shfl(incl, 63);
+					const uint32_t total = wave_last(incl);
 					ncand = ncand + total < uint32_t(S2_CAP) ? ncand + total : uint32_t(S2_CAP);
 					if (__builtin_amdgcn_ballot_w64(over) != 0) break;
 					if (__builtin_amdgcn_ballot_w64(slow_p < slow_end) == 0) {
@@ -444,19 +450,17 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 					}
 				}
 			}
-			// dense pass over the candidate list, four rounds of 64 in flight: the first seed of every (oligo, strand,
+			// dense pass over the candidate list, S2_FLIGHT rounds of 64 in flight: the first seed of every (oligo, strand,
 			// diagonal) survives
 			wave_sync(); // the list was written by other lanes
 			S2_STAMP(1);
-			for (uint32_t c0 = 0; c0 < ((TNT_EXP_S2_SKIP & 64) ? 0u : ncand); c0 += 256) {
-				const Cand x0 = fetch(c0 + uint32_t(lane), ncand);
-				const Cand x1 = fetch(c0 + 64u + uint32_t(lane), ncand);
-				const Cand x2 = fetch(c0 + 128u + uint32_t(lane), ncand);
-				const Cand x3 = fetch(c0 + 192u + uint32_t(lane), ncand);
-				settle(x0);
-				if (c0 + 64u < ncand) settle(x1);
-				if (c0 + 128u < ncand) settle(x2);
-				if (c0 + 192u < ncand) settle(x3);
+			for (uint32_t c0 = 0; c0 < ((TNT_EXP_S2_SKIP & 64) ? 0u : ncand); c0 += 64 * S2_FLIGHT) {
+				Cand x[S2_FLIGHT];
+#pragma unroll
+				for (int f = 0; f < S2_FLIGHT; f++) x[f] = fetch(c0 + 64u * uint32_t(f) + uint32_t(lane), ncand);
+#pragma unroll
+				for (int f = 0; f < S2_FLIGHT; f++)
+					if (f == 0 || c0 + 64u * uint32_t(f) < ncand) settle(c0 + 64u * uint32_t(f) + uint32_t(lane), ncand, x[f]);
 			}
 			wave_sync();
 			S2_STAMP(2);
@@ -479,13 +483,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 				c[m] = la < n_chunk ? hist[la] : 0u;
 				sum += c[m];
 			}
-			uint32_t incl = sum;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t y = __shfl_up(incl, d);
-				if (lane >= d) incl += y;
-			}
-			uint32_t run = incl - sum;
+			uint32_t run = wave_prefix_sum(sum) - sum;
 #pragma unroll
 			for (int m = 0; m < PER; m++) {
 				const uint32_t la = uint32_t(lane) * PER + m;
@@ -498,14 +496,31 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			}
 		}
 		wave_sync();
-		for (uint32_t i = lane; i < n; i += 64) {
-			const uint32_t k = raw[i];
-			const uint32_t la = k >> 25, g = (k >> 7) & 7u;
-			const uint32_t old = atomicAdd(reinterpret_cast<unsigned int *>(off) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
-			srt[(la & 1u) ? (old >> 16) : (old & 0xFFFFu)] = k;
-			if (in_reach && g < 4u) { // primers: the extreme key of every (strand, role)
-				if (g < 2u) atomicMin(ext + 4 * la + g, k);
-				else atomicMax(ext + 4 * la + g, k);
+		// (four rounds of 64 keys at a time: their reads, then their returning adds, are in flight together -- a round on its own
+		// is a chain of two LDS latencies)
+		for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+			uint32_t k4[4], old4[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t i = i0 + 64u * uint32_t(u) + uint32_t(lane);
+				k4[u] = i < n ? raw[i] : ~0u; // (no key has all bits set: group 7 does not exist)
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t la = k4[u] >> 25;
+				old4[u] = 0;
+				if (k4[u] != ~0u) old4[u] = atomicAdd(reinterpret_cast<unsigned int *>(off) + (la >> 1), (la & 1u) ? 0x10000u : 1u);
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t k = k4[u], la = k >> 25, g = (k >> 7) & 7u;
+				if (k != ~0u) {
+					srt[(la & 1u) ? (old4[u] >> 16) : (old4[u] & 0xFFFFu)] = k;
+					if (in_reach && g < 4u) { // primers: the extreme key of every (strand, role)
+						if (g < 2u) atomicMin(ext + 4 * la + g, k);
+						else atomicMax(ext + 4 * la + g, k);
+					}
+				}
 			}
 		}
 		wave_sync();
@@ -546,18 +561,23 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 					uint32_t far_d = 0;     // distance to the farthest partner within reach (0: none)
 					uint32_t pn_d = ~0u;    // distance to the nearest probe on the partner's side
 					if (in_reach) {
-						// successor (and nearest probe): two (five) instructions per key of the segment
-						if (a.chunk_has_probe) {
-							for (uint32_t x = 0; x < cnt; x++) {
-								const uint32_t o = srt[s0 + x];
-								const uint32_t d = o - k;
-								next_d = min(next_d, d - 1u);
-								const uint32_t dir = (d ^ sm) - sm; // > 0 as a signed number: on the partner's side
-								const bool op = ((o >> 7) & 7u) >= 4u && int32_t(dir) > 0;
-								pn_d = min(pn_d, op ? dir : ~0u);
+						// Validity comes from the extreme keys; only a primer of an assay with a probe has to walk its segment (the nearest
+						// probe on the partner's side).  The list successor, which only a VALID seed needs, is found behind the
+						// compaction below -- one round over the valid seeds instead of one walk per seed of the target.
+						if ((af & 2u) && !probe_me) {
+							// (four keys per trip, their reads in flight together: a trip costs one LDS latency; the last key repeats
+							// where the segment ends -- a minimum does not mind)
+							for (uint32_t x = 0; x < cnt; x += 4) {
+								uint32_t o4[4];
+#pragma unroll
+								for (int u = 0; u < 4; u++) o4[u] = srt[s0 + min(x + uint32_t(u), cnt - 1u)];
+#pragma unroll
+								for (int u = 0; u < 4; u++) {
+									const uint32_t dir = ((o4[u] - k) ^ sm) - sm; // > 0 as a signed number: on the partner's side
+									const bool op = ((o4[u] >> 7) & 7u) >= 4u && int32_t(dir) > 0;
+									pn_d = min(pn_d, op ? dir : ~0u);
+								}
 							}
-						} else {
-							for (uint32_t x = 0; x < cnt; x++) next_d = min(next_d, srt[s0 + x] - k - 1u);
 						}
 						const uint4 e = *reinterpret_cast<const uint4 *>(ext + 4 * la);
 						if (!probe_me) {
@@ -608,7 +628,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 									if ((single || rf != rr) && fmax[rf] != 0u && rmin[rr] != ~0u && rmin[rr] - (fmax[rf] - 1u) <= threshold) valid = true;
 						}
 					}
-					if (valid) {
+					if (valid && !in_reach) {
 						// one LDS add per valid seed: its assay's count, and the strand of its successor
 						uint32_t add = 1u << 20;
 						if (int32_t(next_d) >= 0) add += // (keys below this one leave huge values behind, not ~0: a successor is less than 2^25 away)
@@ -616,7 +636,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 						atomicAdd(agg + la, add);
 					}
 				}
-				if (valid && (af & 1u)) atomicAdd(agg + la, 1u << 20);
+				if (valid && (af & 1u) && !in_reach) atomicAdd(agg + la, 1u << 20);
 			}
 			// the valid seeds, still grouped by assay, move to `raw` (dead since the counting sort): the emission works on them only
 			const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
@@ -624,6 +644,32 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			n_valid_all += uint32_t(__builtin_popcountll(vm));
 		}
 		wave_sync();
+		if (in_reach) {
+			// The valid seeds' counts: one per assay, and the strand of every valid PCR seed's list successor -- the smallest key of
+			// its assay's segment above its own (the minimum over all keys of (key - k - 1) as an unsigned number).
+			for (uint32_t i0 = 0; i0 < n_valid_all; i0 += 64) {
+				const uint32_t i = i0 + uint32_t(lane);
+				if (i < n_valid_all) {
+					const uint32_t k = raw[i];
+					const uint32_t la = k >> 25;
+					uint32_t add = 1u << 20;
+					if (!(s_af[la] & 1u)) {
+						const uint32_t cnt = hist[la], s0 = uint32_t(off[la]) - cnt;
+						uint32_t next_d = ~0u;
+						for (uint32_t x = 0; x < cnt; x += 4) {
+							uint32_t o4[4];
+#pragma unroll
+							for (int u = 0; u < 4; u++) o4[u] = srt[s0 + min(x + uint32_t(u), cnt - 1u)];
+							next_d = min(min(next_d, min(o4[0] - k - 1u, o4[1] - k - 1u)), min(o4[2] - k - 1u, o4[3] - k - 1u));
+						}
+						if (int32_t(next_d) >= 0) add += // (keys below this one leave huge values behind, not ~0: a successor is less than 2^25 away)
+							 ((0x13u >> (((k + next_d + 1u) >> 7) & 7u)) & 1u) ? 1u : (1u << 10);
+					}
+					atomicAdd(agg + la, add);
+				}
+			}
+			wave_sync();
+		}
 
 		S2_STAMP(4);
 		// ---------------------------------------------------------------- emission: items, groups, phase-A queues
@@ -655,8 +701,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			const bool nonpcr = valid && (s_af[la] & 1u);
 			const bool pb = valid && !nonpcr && (role == 2u || minus != minus_first);
 			// the first seed of every assay opens the group
-			uint32_t la_prev = uint32_t(__shfl_up(int(la), 1));
-			if (lane == 0) la_prev = carry_la;
+			const uint32_t la_prev = uint32_t(__builtin_amdgcn_update_dpp(int(carry_la), int(la), 0x138, 0xF, 0xF, false)); // wave_shr:1; lane 0 keeps the carry
 			const bool first = valid && la_prev != la;
 			const unsigned long long fm = __builtin_amdgcn_ballot_w64(first);
 			const uint32_t n_first = uint32_t(__builtin_popcountll(fm));
@@ -693,7 +738,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 					uint32_t stop = uint32_t(start) + (sp >> 16) + 2u * FLANK;
 					if (stop > len) stop = len;
 					fat = u32x4{o, uint32_t(rec_words + uint32_t(start >> 4)), uint32_t(start & 15) | ((stop - uint32_t(start)) << 4) | ((sp >> 16) << 12), info};
-					atomicAdd(&s_cells[wv], (sp >> 16) * (stop - uint32_t(start))); // rows x columns of the window (statistics; below 2^32 per wavefront and launch)
+					my_cells += (sp >> 16) * (stop - uint32_t(start)); // rows x columns of the window (statistics; below 2^32 per lane and launch)
 					if (exc1 > exc0) { // windows with a degenerate target base go to the general instance of their length
 						uint32_t lo = exc0, hi = exc1;
 						while (lo < hi) {
@@ -754,7 +799,7 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			}
 			item_cur += n_valid;
 			group_cur += n_first;
-			carry_la = uint32_t(__shfl(int(la), int(n_valid) - 1));
+			carry_la = uint32_t(__builtin_amdgcn_readlane(int(la), __builtin_amdgcn_readfirstlane(int(n_valid) - 1)));
 		}
 		wave_sync();
 		S2_STAMP(5);
@@ -789,7 +834,12 @@ template <int WS, bool LTAB> __global__ __launch_bounds__(64 * s2_waves(LTAB), L
 			if (s_bhist[i]) atomicAdd(a.bin_hist + i, s_bhist[i]);
 	}
 	wave_sync();
-	if (lane == 0 && s_cells[wv] && a.stat_cells) atomicAdd(a.stat_cells, (unsigned long long)s_cells[wv]);
+	if (a.stat_cells) { // DP cells of the windows this wavefront queued (statistics): one add per wavefront and launch
+		unsigned long long cells = my_cells;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) cells += (unsigned long long)__shfl_xor((long long)cells, o);
+		if (lane == 0 && cells) atomicAdd(a.stat_cells, cells);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
