@@ -60,6 +60,10 @@ hipError_t sort_pairs_u64_u32(void *tmp, size_t &tmp_bytes, const unsigned long 
                               size_t n, hipStream_t stream);
 hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *target_rank, const AssayDev *assays, uint32_t n_assays,
                            uint32_t n_buckets, Item *items, uint32_t *bucket, DeviceArena &arena, hipStream_t stream);
+size_t long_pair_bytes(size_t n);
+hipError_t long_pair_device(const Item *kept, uint32_t n_kept, const Group *h_groups, uint32_t n_groups, const uint8_t *h_take, const int32_t *result, const BoundRec *pool,
+                            const AssayDev *assays, const AssayDev *h_assays, const uint32_t *h_unit_target, uint32_t first_seq_index, int max_len, int single_primer,
+                            int min_max_primer_clamp, std::vector<Hit> &hits_out, std::vector<uint8_t> &h_flagged, DeviceArena &arena, hipStream_t stream);
 }
 
 static_assert(sizeof(Hit) == sizeof(tnt_hit), "device Hit must mirror tnt_hit");
@@ -742,6 +746,8 @@ struct tnt_ctx {
 	DevBuf<uint32_t> stack;
 	DevBuf<SeedOut> seeds_out;
 	DeviceArena long_arena; // device arrays of the long-target path (lists, scans, kept seeds)
+	DeviceArena long_pair_arena; // ... of the device pairing of its PCR lists (tnt_sort.hip, long_pair_device)
+	DevBuf<BoundRec> long_pool;  // the bound records of all bind passes of a long-target search, for the device pairing
 	int bind_blocks = 0; // grid of the 256-thread instances
 	int n_cu = 0;
 
@@ -843,6 +849,14 @@ __global__ void accumulate_kernel(uint32_t *cnt, uint32_t *g) // cnt: the batch'
 }
 
 // q[i] = i for i < n, *count = n: the queue of a bind phase over every item of a buffer (long-target path)
+// results of one bind pass of the long-target path -> the array over all passes (pool indices counted from the first pass)
+__global__ void rebase_kernel(const int32_t *res, uint32_t n, int32_t base, int32_t *out)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int32_t r = res[i];
+		out[i] = r >= 0 ? r + base : r;
+	}
+}
 __global__ void iota_kernel(uint32_t *q, uint32_t n, uint32_t *count)
 {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = i;
@@ -3283,8 +3297,10 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 		std::vector<tnt_hit> extra;
 		const int rc = search_long_targets(ctx, ctx->pending_db, extra);
 		// (its device arrays are kept for the next search -- allocating 17 GB for a 250-Mb record takes 0.4 s -- up to 48 GB)
-		if (ctx->long_arena.cap + ctx->seeds_out.n * sizeof(SeedOut) > (size_t(48) << 30)) {
+		if (ctx->long_arena.cap + ctx->long_pair_arena.cap + ctx->seeds_out.n * sizeof(SeedOut) > (size_t(48) << 30)) {
 			ctx->long_arena.release();
+			ctx->long_pair_arena.release();
+			ctx->long_pool.release();
 			ctx->seeds_out.release();
 		}
 		if (rc) return rc;

@@ -253,6 +253,9 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 
 	Item *bind_items = nullptr; // the kept seeds, list after list (pinned host copy: the pairing reads it)
 	size_t n_bind = 0;
+	bool dev_pair = false;       // the PCR lists are sequenced and paired on the device
+	bool host_copies = false;    // the host threads need the kept seeds, their results and the bound records
+	std::vector<uint8_t> take;   // [group] the device takes the list
 	std::vector<Group> groups;
 	std::vector<uint32_t> unit_target;
 	std::vector<int32_t> own_lo, own_hi;
@@ -280,12 +283,29 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		own_lo.assign(unit_target.size(), INT32_MIN);
 		own_hi.assign(unit_target.size(), INT32_MAX);
 		lap("first cull (device)");
-		if (n_bind) {
+		// The bind / cull sequence and the pairing of the PCR lists run on the device (tnt_sort.hip, long_pair_device) unless a switch
+		// or the context says otherwise: the lists of probe / padlock assays (one pass over their bound seeds) and of the assays that
+		// go through the cache replay stay with the host threads below, and so does a list the device hands back (flagged).
+		dev_pair = n_bind != 0 && !cull_rows && !getenv("TNT_MI355X_LONG_HOST_PAIR");
+		if (dev_pair) {
+			take.assign(groups.size(), 0);
+			bool any = false;
+			for (size_t g = 0; g < groups.size(); g++) {
+				const AssayDev &A = ctx->h_assays[groups[g].assay & GROUP_ASSAY_MASK];
+				take[g] = (A.kind == 0 && !(ctx->cache_replay && (A.cache_replay & 1))) ? 1 : 0;
+				any = any || take[g];
+				host_copies = host_copies || !take[g];
+			}
+			dev_pair = any;
+		}
+		if (!dev_pair) host_copies = true;
+		if (n_bind && host_copies) {
 			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
 			bind_items = ctx->pin_bind.p;
 			HIP_TRY(hipMemcpyAsync(bind_items, d_kept, n_bind * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err); // (done by the first sync of the bind loop)
 		}
 	} else {
+		host_copies = true;
 		HIP_TRY(ctx->pin_items.ensure(n_raw), ctx->err);
 		HIP_TRY(ctx->pin_list.ensure(n_raw), ctx->err);
 		Item *const sorted = ctx->pin_items.p;
@@ -445,8 +465,25 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 	lap("work items");
 	// ---- bind them on the device, a million at a time: bucket -> pre-filter -> bind, as a search phase does
 	const DbView v = make_view(db, 0, db->n_targets);
-	HIP_TRY(ctx->pin_result.ensure(n_bind), ctx->err);
-	int32_t *const result = ctx->pin_result.p;
+	if (host_copies) HIP_TRY(ctx->pin_result.ensure(n_bind), ctx->err);
+	int32_t *result = host_copies ? ctx->pin_result.p : nullptr;
+	// device pairing: the results of all passes side by side (pool indices over all passes), the bound records of all passes
+	DeviceArena &pair_arena = ctx->long_pair_arena;
+	int32_t *d_result_all = nullptr;
+	if (dev_pair) {
+		if (pair_arena.reserve(long_pair_bytes(n_bind) + n_bind * sizeof(int32_t) + 4096) != hipSuccess || !(d_result_all = pair_arena.take<int32_t>(n_bind))) {
+			(void)hipGetLastError();
+			dev_pair = false; // (no room: the host threads take everything)
+			if (!host_copies) {
+				host_copies = true;
+				HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
+				bind_items = ctx->pin_bind.p;
+				HIP_TRY(hipMemcpyAsync(bind_items, d_kept, n_bind * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+				HIP_TRY(ctx->pin_result.ensure(n_bind), ctx->err);
+				result = ctx->pin_result.p;
+			}
+		}
+	}
 	// (up to 16 M items per pass; a pass that binds more records than the device pool holds is repeated with half as many)
 	size_t n_pool = 0;
 	size_t chunk = std::min(ctx->item_cap, size_t(1) << 24);
@@ -460,8 +497,8 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		b.groups = nullptr;
 		launch_bind_phase(ctx, b, v, db->n_exceptions != 0, ctx->S().qb.p, cnt + C_QB, nullptr);
 		uint32_t h[C_COUNT];
-		int32_t *const res = result + c0;
-		HIP_TRY(hipMemcpyAsync(res, ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+		int32_t *const res = host_copies ? result + c0 : nullptr;
+		if (host_copies) HIP_TRY(hipMemcpyAsync(res, ctx->S().result.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 		HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 		HIP_TRY(hipGetLastError(), ctx->err);
@@ -478,18 +515,70 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			ctx->err = "more than 2^31 bound oligos on the long targets of this batch";
 			return TNT_E_LIMIT;
 		}
-		HIP_TRY(ctx->pin_pool.ensure_keep(base + np, base), ctx->err);
-		if (np) HIP_TRY(hipMemcpy(ctx->pin_pool.p + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		if (host_copies) {
+			HIP_TRY(ctx->pin_pool.ensure_keep(base + np, base), ctx->err);
+			if (np) HIP_TRY(hipMemcpy(ctx->pin_pool.p + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToHost), ctx->err);
+		}
+		if (dev_pair) {
+			if (base + np > ctx->long_pool.n) { // grow, keeping the records of the passes so far
+				DevBuf<BoundRec> bigger;
+				HIP_TRY(bigger.alloc(std::max<size_t>((base + np) * 2, size_t(1) << 16)), ctx->err);
+				if (base) HIP_TRY(hipMemcpy(bigger.p, ctx->long_pool.p, base * sizeof(BoundRec), hipMemcpyDeviceToDevice), ctx->err);
+				std::swap(bigger.p, ctx->long_pool.p), std::swap(bigger.n, ctx->long_pool.n);
+			}
+			if (np) HIP_TRY(hipMemcpyAsync(ctx->long_pool.p + base, ctx->S().pool.p, np * sizeof(BoundRec), hipMemcpyDeviceToDevice, ctx->stream), ctx->err);
+			hipLaunchKernelGGL(rebase_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->S().result.p, uint32_t(nc), int32_t(base), d_result_all + c0);
+			HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err); // (the next pass overwrites the batch's arrays)
+		}
 		n_pool += np;
-		if (base)
+		if (base && host_copies)
 			for (size_t i = 0; i < nc; i++)
 				if (res[i] >= 0) res[i] = int32_t(base + size_t(res[i]));
 		ctx->acc_items += nc;
 		c0 += nc;
 	}
+	lap("bind on the device");
+	// ---- the PCR lists on the device: bind / cull sequence, last sort, pairing loops (amplicon_search.cpp:131-674)
+	std::vector<Hit> dev_hits;
+	std::vector<uint8_t> flagged;
+	if (dev_pair) {
+		const hipError_t pe = long_pair_device(d_kept, uint32_t(n_bind), groups.data(), uint32_t(groups.size()), take.data(), d_result_all, ctx->long_pool.p, ctx->assays.p,
+		                                       ctx->h_assays.data(), unit_target.data(), db->first_seq_index, ctx->opt.max_len, ctx->opt.single_primer_pcr,
+		                                       ctx->opt.min_max_primer_clamp, dev_hits, flagged, pair_arena, ctx->stream);
+		if (pe == hipErrorOutOfMemory) { // (more bound seeds than the reservation expects: the host threads take the lists)
+			(void)hipGetLastError();
+			dev_hits.clear();
+			flagged.assign(groups.size(), 1);
+		} else if (pe != hipSuccess) {
+			ctx->err = std::string("pairing the lists of long targets on the device: ") + hipGetErrorString(pe);
+			return TNT_E_DEVICE;
+		}
+		size_t n_back = 0;
+		for (size_t g = 0; g < groups.size(); g++) n_back += (take[g] && flagged[g]) ? 1 : 0;
+		if (timing) fprintf(stderr, "long targets: %zu lists on the device, %zu of them handed back (sort_by_oligo_loc not a strict weak order on them), %zu hits\n",
+		                    size_t(std::count(take.begin(), take.end(), uint8_t(1))), n_back, dev_hits.size());
+		if (n_back && !host_copies) { // the host threads need the seeds, results and records after all
+			host_copies = true;
+			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
+			bind_items = ctx->pin_bind.p;
+			HIP_TRY(ctx->pin_result.ensure(n_bind), ctx->err);
+			result = ctx->pin_result.p;
+			HIP_TRY(ctx->pin_pool.ensure(n_pool), ctx->err);
+			// (the seeds and results of the lists that came back, at their places in the arrays; the bound records of the pass)
+			for (size_t g = 0; g < groups.size(); g++) {
+				if (!(take[g] && flagged[g])) continue;
+				const size_t first = groups[g].first, count = groups[g].count & ~GROUP_ALIVE;
+				HIP_TRY(hipMemcpyAsync(bind_items + first, d_kept + first, count * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+				HIP_TRY(hipMemcpyAsync(result + first, d_result_all + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+			}
+			if (n_pool) HIP_TRY(hipMemcpyAsync(ctx->pin_pool.p, ctx->long_pool.p, n_pool * sizeof(BoundRec), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
+			HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
+		}
+		lap("PCR lists (device)");
+	}
+	auto on_device = [&](size_t g) { return dev_pair && take[g] && !flagged[g]; };
 	const BoundRec *const pool = ctx->pin_pool.p;
 
-	lap("bind on the device");
 	// ---- row a6 on these targets: the groups of the assays that share an oligo across strand concentrations / threshold sets are
 	// decided by the reference's per-target BindCache (tntblast_local.cpp:503-506, bind_oligo.cpp:506-512).  As on whole-target work
 	// units (enqueue_cache_replay): every one of their seeds is bound in full by the unit-level instance, then the groups of a
@@ -584,7 +673,7 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			lap("experiment: copies");
 		}
 		if (!workers.run(groups.size(), [&](size_t g) {
-			    if (replayed(groups[g])) return; // (below)
+			    if (replayed(groups[g]) || on_device(g)) return; // (below / done above)
 			    const auto t0 = std::chrono::steady_clock::now();
 			    pair_group<PAIR_HOST>(p, groups[g]);
 			    if (timing) group_ms[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -635,6 +724,16 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			        d.front(), d[d.size() / 2], d.back(), sum);
 		}
 		lap("pairing");
+		if (!dev_hits.empty()) { // the device's hits behind the host threads': a list's hits come from one side, in the order of its loops
+			if (size_t(n_hits) + dev_hits.size() > hit_cap) {
+				std::unique_ptr<Hit[]> bigger(new Hit[size_t(n_hits) + dev_hits.size()]);
+				if (n_hits) memcpy(bigger.get(), hits.get(), size_t(n_hits) * sizeof(Hit));
+				hits = std::move(bigger);
+				hit_cap = size_t(n_hits) + dev_hits.size();
+			}
+			memcpy(hits.get() + n_hits, dev_hits.data(), dev_hits.size() * sizeof(Hit));
+			n_hits += uint32_t(dev_hits.size());
+		}
 		// The workers took the groups as they came: put the hits back into the order one thread produces -- groups by
 		// (target, assay position), the hits of a group in the order its worker wrote them (a worker's slots ascend) --, so
 		// that the output does not depend on the scheduling.
