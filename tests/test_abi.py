@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol(hip_lib):
     assert sorted(engine.EXPORTED_SYMBOLS) == syms
     for s in syms:
         assert hasattr(hip_lib, s), s
-    assert hip_lib.tnt_abi_version() == 6
+    assert hip_lib.tnt_abi_version() == 7
 
 
 def test_struct_layouts_match_header(hip_lib):

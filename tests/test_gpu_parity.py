@@ -29,7 +29,7 @@ def _oligo_set(expanded):
 def test_native_library_is_loaded(Engine):
     from thermonucleotideblast_amd import engine
     lib = engine.load_library()
-    assert lib.tnt_abi_version() == 6
+    assert lib.tnt_abi_version() == 7
     assert any("libtnt_mi355x.so" in line for line in open("/proc/self/maps"))
 
 
@@ -838,6 +838,75 @@ def test_genome_sized_target(Engine, oracle):
     e = Engine(wl.options, wl.expanded)
     db = e.pack(wl.codes, offsets)
     assert tc.sorted_hit_keys(e.search(db)) == want
+    db.close()
+    e.close()
+
+
+@pytest.mark.parametrize("cfg,kw", [(2, {}), (3, {}), (2, {"single_primer_pcr": 1}), (2, {"max_len": 300}), (4, {})])
+def test_pcr_lists_of_windowed_targets_are_paired_on_the_device(Engine, oracle, cfg, kw, monkeypatch):
+    """Row (f)-4: the bind / cull sequence and the pairing loops of the PCR lists of a windowed target run on the device
+    (tnt_sort.hip, long_pair_device); TNT_MI355X_LONG_HOST_PAIR=1 leaves them to the host threads' replay of the reference's
+    list surgery.  Same hits in the same order either way, equal to the oracle's; tnt_long_pair_stats says who did what."""
+    wl = synth.make_workload(cfg, n_targets=900, n_assays=14, seed=71 + cfg)
+    for k, v in kw.items():
+        setattr(wl.options, k, v)
+    lens = np.diff(wl.offsets.astype(np.int64))
+    cut = len(lens) - 3  # the first `cut` targets become one long record, three short ones stay
+    offsets = np.array([0, int(lens[:cut].sum())] + [int(lens[:cut + i + 1].sum()) for i in range(3)], dtype=np.uint64)
+    want = tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, offsets))
+    e = Engine(wl.options, wl.expanded)
+    db = e.pack(wl.codes, offsets)
+    got = [tc.hit_key(h) for h in e.search(db)]
+    on_device, handed_back, host_lists, device_hits = e.long_pair_stats()
+    monkeypatch.setenv("TNT_MI355X_LONG_HOST_PAIR", "1")
+    host = [tc.hit_key(h) for h in e.search(db)]
+    assert e.long_pair_stats()[0] == 0 and e.long_pair_stats()[3] == 0
+    monkeypatch.delenv("TNT_MI355X_LONG_HOST_PAIR")
+    assert len(want) > 5
+    assert got == host
+    assert sorted(got) == want
+    assert on_device > 0 and device_hits > 0
+    assert on_device + handed_back + host_lists >= 1
+    db.close()
+    e.close()
+
+
+def test_lists_whose_footprints_cross_go_back_to_the_host_threads(Engine, oracle):
+    """sort_by_oligo_loc (amplicon_search.cpp:12-26) orders two bound entries by their footprints and any other pair by
+    target_loc: where the two disagree on a list, what std::list::sort leaves depends on its merge tree, which only the host
+    replay restates.  Here the two primers of an assay overlap (R = X[0:22], F = X[2:24]) and every planted site carries a
+    mismatch that puts both seeds on one target position with different footprints: the device flags the list, the host
+    threads pair it, the hits equal the oracle's."""
+    rng = np.random.default_rng(9173)
+    n, tl = 300, 1000
+    codes, offsets = synth._targets(rng, n, tl)
+    X = synth._rand_oligo(rng, 26, 26)
+    R, F = X[0:22], X[2:24]
+    other = [(synth._rand_oligo(rng, 20, 24), synth._rand_oligo(rng, 20, 24)) for _ in range(3)]
+    for k in range(60):
+        site = list(X)
+        site[3] = "ACGT"[("ACGT".index(site[3]) + 1 + int(rng.integers(0, 3))) % 4]  # base 3 of R = base 1 of F
+        site = "".join(site)
+        amp = site + "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(20, 120)))) + synth.revcomp(X)
+        if rng.random() < 0.5:
+            amp = synth.revcomp(amp)
+        synth._put(codes, 0, int(rng.integers(10, n * tl - 400)), amp)
+    for k in range(40):  # ordinary amplicons of the other assays: their lists stay on the device
+        A, B = other[k % 3]
+        amp = synth._mutate(rng, A, 1) + "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(20, 120)))) + synth.revcomp(synth._mutate(rng, B, 1))
+        if rng.random() < 0.5:
+            amp = synth.revcomp(amp)
+        synth._put(codes, 0, int(rng.integers(10, n * tl - 400)), amp)
+    glued = np.array([0, n * tl], dtype=np.uint64)  # one 300-kb record: seeded in windows
+    opt = abi.options_default(min_primer_tm=40.0, max_len=400, single_primer_pcr=1)
+    ex = synth.expand_assays([synth.Assay("overlap", F, R, None)] + [synth.Assay("pcr%d" % i, A, B, None) for i, (A, B) in enumerate(other)])
+    want = tc.sorted_hit_keys(oracle.search(opt, ex, codes, glued))
+    e = Engine(opt, ex)
+    db = e.pack(codes, glued)
+    got = tc.sorted_hit_keys(e.search(db))
+    on_device, handed_back, host_lists, device_hits = e.long_pair_stats()
+    assert got == want and len(want) > 30
+    assert handed_back >= 1 and on_device >= 1, (on_device, handed_back, host_lists)
     db.close()
     e.close()
 

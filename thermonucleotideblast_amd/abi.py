@@ -4,7 +4,7 @@ Pure declarations: importing this module loads no native code.
 """
 import ctypes as C
 
-TNT_ABI_VERSION = 6
+TNT_ABI_VERSION = 7
 TNT_MAX_OLIGO = 1024
 TNT_FLANK = 4
 TNT_ALIGN_TEXT = 448

@@ -628,6 +628,7 @@ struct tnt_ctx {
 	hipEvent_t phase_ready = nullptr;
 	size_t lane_trace = 0, lane_cols = 0, lane_ties = 0; // scratch elements per lane
 
+	uint64_t long_pair_stats[4] = {0, 0, 0, 0}; // tnt_long_pair_stats: the lists of windowed targets in the last search
 	std::string warnings; // what a caller should know about this context's options (tnt_ctx_warnings): the Q11 regime
 	std::vector<std::string> oligos;
 	std::vector<AssayDev> h_assays;
@@ -1503,6 +1504,12 @@ void tnt_options_default(tnt_options *o) // options.h:85-170, tntblast.h:19-76
 
 const char *tnt_last_error(const tnt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 const char *tnt_ctx_warnings(const tnt_ctx *ctx) { return ctx ? ctx->warnings.c_str() : ""; }
+int tnt_long_pair_stats(const tnt_ctx *ctx, uint64_t out[4])
+{
+	if (!ctx || !out) return TNT_E_ARG;
+	for (int i = 0; i < 4; i++) out[i] = ctx->long_pair_stats[i];
+	return TNT_OK;
+}
 
 // The pre-filter of oligos of 65 to 128 bases costs a fifth of the bind it spares (5 ns against 22 ns per window), and whether it
 // spares any hangs on the thresholds: against -E 40 an unrelated 120-base window already reaches the bound (0.7 % rejected: the
@@ -3292,6 +3299,7 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 	}
 	if (n && want_records) HIP_TRY(hipMemcpy(ctx->h_hits, ctx->hits.p, n * sizeof(tnt_hit), hipMemcpyDeviceToHost), ctx->err);
 	size_t n_unique = n;
+	for (int i = 0; i < 4; i++) ctx->long_pair_stats[i] = 0;
 	if (ctx->pending_db && !ctx->pending_db->h_long_targets.empty()) {
 		// targets seeded in windows: lists merged per (target, assay), culled and paired whole on the host
 		std::vector<tnt_hit> extra;

@@ -577,6 +577,8 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		lap("PCR lists (device)");
 	}
 	auto on_device = [&](size_t g) { return dev_pair && take[g] && !flagged[g]; };
+	for (size_t g = 0; g < groups.size(); g++) ctx->long_pair_stats[on_device(g) ? 0 : ((dev_pair && take[g]) ? 1 : 2)]++;
+	ctx->long_pair_stats[3] += dev_hits.size();
 	const BoundRec *const pool = ctx->pin_pool.p;
 
 	// ---- row a6 on these targets: the groups of the assays that share an oligo across strand concentrations / threshold sets are
@@ -763,6 +765,7 @@ static int search_long_targets(tnt_ctx *ctx, tnt_db *db, std::vector<tnt_hit> &o
 	if (const char *e = getenv("TNT_MI355X_LONG_PASS_SEEDS")) cap = std::max(1.0, atof(e));
 	for (;;) {
 		out.clear();
+		for (int i = 0; i < 4; i++) ctx->long_pair_stats[i] = 0;
 		if (cull_rows) cull_rows->resize(rows0);
 		const size_t u0 = db->n_short_units, u1 = db->h_unit_target.size();
 		const double per_position = double(ctx->n_entries) / double(size_t(1) << (2 * ctx->opt.hash_word_size));

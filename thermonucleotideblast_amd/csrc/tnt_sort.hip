@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void lp_foot_scatter_kernel(const Item *items,
 		foot[pos[j]] = LpFoot{bucket[j], it.tloc, r.loc5, r.loc3};
 	}
 }
-__global__ __launch_bounds__(256) void lp_foot_check_kernel(const LpFoot *foot, uint32_t n, uint32_t *list_flag)
+__global__ __launch_bounds__(256) void lp_foot_check_kernel(const LpFoot *foot, uint32_t n, uint32_t *list_flag, uint32_t *debug_count = nullptr)
 {
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k + 1u < n; k += gridDim.x * blockDim.x) {
 		const LpFoot a = foot[k], b = foot[k + 1u];
@@ -514,7 +514,11 @@ __global__ __launch_bounds__(256) void lp_foot_check_kernel(const LpFoot *foot, 
 		const bool loc_less = a.loc5 != b.loc5 ? a.loc5 < b.loc5 : a.loc3 < b.loc3;
 		const bool loc_same = a.loc5 == b.loc5 && a.loc3 == b.loc3;
 		const bool ok = (a.tloc < b.tloc && loc_less) || (a.tloc == b.tloc && loc_same);
-		if (!ok) atomicOr(list_flag + a.bucket, 2u);
+		if (!ok) {
+			atomicOr(list_flag + a.bucket, 2u);
+			if (debug_count && atomicAdd(debug_count, 1u) < 12u)
+				printf("long_pair_device: list %u: target_loc %u footprint [%d, %d] before target_loc %u footprint [%d, %d]\n", a.bucket, a.tloc, a.loc5, a.loc3, b.tloc, b.loc5, b.loc3);
+		}
 	}
 }
 
@@ -762,6 +766,7 @@ hipError_t long_pair_device(const Item *kept, uint32_t n_kept, const Group *h_gr
 	LP_TRY(hipMemcpyAsync(d_glist, g_list.data(), sizeof(uint32_t) * n_groups, hipMemcpyHostToDevice, stream));
 	LP_TRY(hipMemcpyAsync(d_lists, lists.data(), sizeof(LpList) * n_lists, hipMemcpyHostToDevice, stream));
 	LP_TRY(hipMemsetAsync(d_list_flag, 0, sizeof(uint32_t) * n_lists, stream));
+	LP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * 4, stream));
 	auto grid = [](size_t m) { return dim3(unsigned(std::min<size_t>(8192, std::max<size_t>(1, (m + 255) / 256)))); };
 	hipLaunchKernelGGL(lp_init_kernel, grid(n_kept), dim3(256), 0, stream, kept, n_kept, d_gfirst, d_gdst, d_glist, n_groups, itm[0], bkt[0]);
 	int cur = 0;
@@ -884,7 +889,7 @@ hipError_t long_pair_device(const Item *kept, uint32_t n_kept, const Group *h_gr
 			LpFoot *const foot = arena.take<LpFoot>(n_foot);
 			if (!foot) return hipErrorOutOfMemory;
 			hipLaunchKernelGGL(lp_foot_scatter_kernel, grid(n_cur), dim3(256), 0, stream, itm[cur], bkt[cur], n_cur, d_flag32, d_pos32, result, pool, foot);
-			hipLaunchKernelGGL(lp_foot_check_kernel, grid(n_foot), dim3(256), 0, stream, foot, n_foot, d_list_flag);
+			hipLaunchKernelGGL(lp_foot_check_kernel, grid(n_foot), dim3(256), 0, stream, foot, n_foot, d_list_flag, debug ? d_cnt : nullptr);
 			stage("bind step: consistency", n_foot, step);
 		}
 		return hipGetLastError();

@@ -60,6 +60,8 @@ def load_library():
     lib.tnt_abi_version.restype = C.c_int
     lib.tnt_ctx_warnings.argtypes = [C.c_void_p]
     lib.tnt_ctx_warnings.restype = C.c_char_p
+    lib.tnt_long_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.tnt_long_pair_stats.restype = C.c_int
     lib.tnt_options_default.argtypes = [P(abi.tnt_options)]
     lib.tnt_last_error.restype = C.c_char_p
     lib.tnt_last_error.argtypes = [C.c_void_p]
@@ -121,7 +123,7 @@ def load_library():
 
 # every symbol include/tnt_mi355x.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
-    "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error", "tnt_ctx_warnings", "tnt_filter_bound_tier2",
+    "tnt_options_default", "tnt_abi_version", "tnt_ctx_create", "tnt_ctx_destroy", "tnt_last_error", "tnt_ctx_warnings", "tnt_long_pair_stats", "tnt_filter_bound_tier2",
     "tnt_ctx_num_oligos", "tnt_ctx_oligo", "tnt_ctx_delta_g", "tnt_db_create", "tnt_db_destroy",
     "tnt_db_skip_targets", "tnt_db_num_targets", "tnt_db_num_bases", "tnt_search", "tnt_search_enqueue", "tnt_search_collect", "tnt_search_hits_device", "tnt_search_hits_compact", "tnt_hits_unpack",
     "tnt_last_timing", "tnt_seeds", "tnt_first_cull", "tnt_bind_batch", "tnt_bind_batch_routed", "tnt_filter_bound", "tnt_hit_sequence", "tnt_oligo_structure",
@@ -384,6 +386,13 @@ class Engine:
     def warnings(self):
         """tnt_ctx_warnings: "" or what the caller should know about the options (the Q11 regime)."""
         return (self.lib.tnt_ctx_warnings(self._h) or b"").decode()
+
+    def long_pair_stats(self):
+        """tnt_long_pair_stats: the lists of windowed targets in the last search -- (PCR lists on the device, PCR lists handed back
+        to the host threads, lists of the host threads from the start, hits the device reported)."""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.tnt_long_pair_stats(self._h, out))
+        return tuple(int(x) for x in out)
 
     def timing(self):
         t = abi.tnt_timing()
