@@ -871,6 +871,55 @@ def test_pcr_lists_of_windowed_targets_are_paired_on_the_device(Engine, oracle, 
     e.close()
 
 
+def test_a_list_beyond_the_host_replay_s_million_entries_is_paired_on_the_device(Engine, monkeypatch):
+    """The host replay keeps a (target, assay) list in arrays of 1 048 576 entries; the device pairing has no such bound.  A
+    40-Mb record against one primer pair at -W 5 leaves some 2.8 million seeds behind the first cull: the search succeeds with
+    the list on the device (and is refused with the host threads forced).  Without an oracle run of that size, the hits are held
+    against the two halves of the record searched as records of their own: a hit needs its two primers bound within reach of
+    each other, whatever else the list holds, so every hit of a half is a hit of the whole record."""
+    rng = np.random.default_rng(20261)
+    n_bases = 40_000_000
+    codes = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
+    F, R = synth._rand_oligo(rng, 22, 22), synth._rand_oligo(rng, 22, 22)
+    planted = []
+    for k in range(120):
+        amp = synth._mutate(rng, F, 1) + "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(30, 300)))) + synth.revcomp(synth._mutate(rng, R, 1))
+        if rng.random() < 0.5:
+            amp = synth.revcomp(amp)
+        pos = int(rng.integers(1000, n_bases - 1000))
+        if abs(pos - n_bases // 2) < 5000:
+            continue  # (not across the cut)
+        synth._put(codes, 0, pos, amp)
+        planted.append(pos)
+    opt = abi.options_default(min_primer_tm=45.0, hash_word_size=5)
+    ex = synth.expand_assays([synth.Assay("pair", F, R, None)])
+    e = Engine(opt, ex)
+    whole = e.pack(codes, np.array([0, n_bases], dtype=np.uint64))
+    hits = e.search(whole)
+    on_device, handed_back, host_lists, device_hits = e.long_pair_stats()
+    assert on_device == 1 and handed_back == 0 and device_hits == len(hits) and len(hits) >= 60
+    monkeypatch.setenv("TNT_MI355X_LONG_HOST_PAIR", "1")
+    with pytest.raises(Exception, match="1048576"):
+        e.search(whole)
+    monkeypatch.delenv("TNT_MI355X_LONG_HOST_PAIR")
+    whole.close()
+    halves = e.pack(codes, np.array([0, n_bases // 2, n_bases], dtype=np.uint64))
+    part = e.search(halves)
+
+    def place(h, shift):
+        k = list(tc.hit_key(h))
+        names = [n for n, _ in abi.tnt_hit._fields_]
+        for n in ("amplicon_start", "amplicon_stop"):
+            k[names.index(n)] += shift
+        k[names.index("seq_index")] = 0
+        return tuple(k)
+    got = set(tc.hit_key(h) for h in hits)
+    moved = [place(h, (n_bases // 2) * int(h.seq_index if not isinstance(h, dict) else h["seq_index"])) for h in part]
+    assert len(moved) >= 60 and all(m in got for m in moved)
+    halves.close()
+    e.close()
+
+
 def test_lists_whose_footprints_cross_go_back_to_the_host_threads(Engine, oracle):
     """sort_by_oligo_loc (amplicon_search.cpp:12-26) orders two bound entries by their footprints and any other pair by
     target_loc: where the two disagree on a list, what std::list::sort leaves depends on its merge tree, which only the host

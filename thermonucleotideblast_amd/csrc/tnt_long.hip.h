@@ -272,11 +272,7 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		n_bind = n_kept;
 		for (const Group &g : all) {
 			if (g.count == 0) continue;
-			if (g.count > uint32_t(PAIR_HOST)) {
-				ctx->err = "more than 1048576 seeds of one assay on one target after the first cull";
-				return TNT_E_LIMIT;
-			}
-			groups.push_back(g);
+			groups.push_back(g); // (a list beyond the host replay's 1 048 576 entries has to be one the device takes and keeps: below)
 		}
 		// (Group::target = rank of the target among the windowed ones)
 		unit_target = long_targets;
@@ -299,6 +295,11 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			dev_pair = any;
 		}
 		if (!dev_pair) host_copies = true;
+		for (size_t g = 0; g < groups.size(); g++)
+			if (groups[g].count > uint32_t(PAIR_HOST) && !(dev_pair && take[g])) {
+				ctx->err = "more than 1048576 seeds of one assay on one target after the first cull (a list the host threads would have to pair)";
+				return TNT_E_LIMIT;
+			}
 		if (n_bind && host_copies) {
 			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
 			bind_items = ctx->pin_bind.p;
@@ -554,7 +555,13 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			return TNT_E_DEVICE;
 		}
 		size_t n_back = 0;
-		for (size_t g = 0; g < groups.size(); g++) n_back += (take[g] && flagged[g]) ? 1 : 0;
+		for (size_t g = 0; g < groups.size(); g++) {
+			n_back += (take[g] && flagged[g]) ? 1 : 0;
+			if (take[g] && flagged[g] && groups[g].count > uint32_t(PAIR_HOST)) {
+				ctx->err = "more than 1048576 seeds of one assay on one target after the first cull, in a list the device handed back";
+				return TNT_E_LIMIT;
+			}
+		}
 		if (timing) fprintf(stderr, "long targets: %zu lists on the device, %zu of them handed back (sort_by_oligo_loc not a strict weak order on them), %zu hits\n",
 		                    size_t(std::count(take.begin(), take.end(), uint8_t(1))), n_back, dev_hits.size());
 		if (n_back && !host_copies) { // the host threads need the seeds, results and records after all
