@@ -666,6 +666,8 @@ struct tnt_ctx {
 	// items straight into the queue of their length bucket
 	bool seed2 = false;
 	size_t item_cap = 0, group_cap = 0; // capacities of the work buffers (ensure_work_buffers)
+	bool seed2_big = false;          // the assay set needs many chunks: the seed kernel's instances with the large lists (S2_CAP_BIG, plan())
+	int seed2_wgs = TNT_S2_OCC;      // workgroups of the round-3 seed kernel per CU (persistent grid; TNT_MI355X_SEED2_WGS: fewer leave LDS and registers to the bind stage of the batch before, with TNT_MI355X_PIPELINE)
 	int pipeline_batches = 1;        // batches a large search is cut into on two buffer sets (TNT_MI355X_PIPELINE; 1: one batch after the other on one stream -- measured faster)
 	static constexpr uint32_t MAX_REGIONS = 8192;
 	DevBuf<uint32_t> slot_pack;      // [slot] bucket | bucket_general << 8 | oligo length << 16
@@ -1913,6 +1915,7 @@ int tnt_ctx_create(const tnt_options *opt, const tnt_assay *assays, size_t n_ass
 	// the round-3 seed kernel serves every search but those that mark shared oligos in the seed kernel
 	c->seed2 = !c->dedupe && !getenv("TNT_MI355X_SEED_V2");
 	if (const char *pe = getenv("TNT_MI355X_PIPELINE")) c->pipeline_batches = std::max(1, std::min(64, atoi(pe)));
+	if (const char *pe = getenv("TNT_MI355X_SEED2_WGS")) c->seed2_wgs = std::max(1, std::min(TNT_S2_OCC, atoi(pe)));
 	std::vector<uint32_t> slot_pack(std::max<size_t>(1, c->h_slots.size()), 0u);
 	for (size_t si = 0; si < c->h_slots.size(); si++) {
 		const Slot &sl = c->h_slots[si];
@@ -2797,7 +2800,9 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 		// DESIGN.md 4.1), although the scan on its own runs 3.6 x faster out of LDS (tnt_seed_scan_only)
 		const bool ltab = c->opt.hash_word_size <= 7 && getenv("TNT_MI355X_SEED2_LDS_TABLE");
 		const size_t S2_WAVES = size_t(s2_waves(ltab));
-		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES, std::min<size_t>(size_t(c->n_cu) * (ltab ? 1 : TNT_S2_OCC), tnt_ctx::MAX_REGIONS / S2_WAVES)));
+		const bool big = c->seed2_big && !ltab;
+		const uint32_t blocks = uint32_t(std::min<size_t>((u1 - u0 + S2_WAVES - 1) / S2_WAVES,
+		                                                   std::min<size_t>(size_t(c->n_cu) * (ltab ? 1 : size_t(big ? std::min(c->seed2_wgs, S2_OCC_BIG) : c->seed2_wgs)), tnt_ctx::MAX_REGIONS / S2_WAVES)));
 		const uint32_t regions = blocks * uint32_t(S2_WAVES);
 		c->batch_regions = regions;
 		HIP_TRY(hipMemsetAsync(c->S().region_counts.p, 0, sizeof(uint32_t) * 2 * regions, seed_stream), c->err);
@@ -2850,12 +2855,18 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 			q.last_chunk = ch + 2 == c->chunk_begin.size() ? 1 : 0;
 			// (an instance compiled for the default word size -W 7, one that takes it at run time)
 			// ... and one for databases of short targets (SHORT: every unit in LDS and within the first cull's reach as a whole)
+			// ... and the ones with the large seed lists for assay sets of many chunks (BIG, plan())
+			const dim3 g2(blocks), b2(64 * s2_waves(false));
 			if (q.word_size == 7 && ltab) hipLaunchKernelGGL((seed2_kernel<7, true, false>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
-			else if (q.word_size == 7 && units_short) hipLaunchKernelGGL((seed2_kernel<7, false, true>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
-			else if (q.word_size == 7) hipLaunchKernelGGL((seed2_kernel<7, false, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
 			else if (ltab) hipLaunchKernelGGL((seed2_kernel<0, true, false>), dim3(blocks), dim3(64 * s2_waves(true)), 0, seed_stream, q);
-			else if (units_short) hipLaunchKernelGGL((seed2_kernel<0, false, true>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
-			else hipLaunchKernelGGL((seed2_kernel<0, false, false>), dim3(blocks), dim3(64 * s2_waves(false)), 0, seed_stream, q);
+			else if (q.word_size == 7 && units_short && big) hipLaunchKernelGGL((seed2_kernel<7, false, true, true>), g2, b2, 0, seed_stream, q);
+			else if (q.word_size == 7 && units_short) hipLaunchKernelGGL((seed2_kernel<7, false, true, false>), g2, b2, 0, seed_stream, q);
+			else if (q.word_size == 7 && big) hipLaunchKernelGGL((seed2_kernel<7, false, false, true>), g2, b2, 0, seed_stream, q);
+			else if (q.word_size == 7) hipLaunchKernelGGL((seed2_kernel<7, false, false, false>), g2, b2, 0, seed_stream, q);
+			else if (units_short && big) hipLaunchKernelGGL((seed2_kernel<0, false, true, true>), g2, b2, 0, seed_stream, q);
+			else if (units_short) hipLaunchKernelGGL((seed2_kernel<0, false, true, false>), g2, b2, 0, seed_stream, q);
+			else if (big) hipLaunchKernelGGL((seed2_kernel<0, false, false, true>), g2, b2, 0, seed_stream, q);
+			else hipLaunchKernelGGL((seed2_kernel<0, false, false, false>), g2, b2, 0, seed_stream, q);
 		}
 	}
 	const int seed_blocks = int(std::min<size_t>((u1 - u0 + SEED_WAVES - 1) / SEED_WAVES, size_t(c->bind_blocks) * 4));
@@ -2986,7 +2997,7 @@ static int enqueue_batch(tnt_ctx *c, tnt_db *db, size_t u0, size_t u1, bool seed
 
 // Assay chunks for the seed kernel and target batches sized so the expected number of seeds fits.
 // Every chunk gets its own bucket table (16-bit offsets, < 65536 entries) so it can sit in LDS.
-static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
+static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch, bool for_search = false)
 {
 	const size_t n_words = size_t(1) << (2 * c->opt.hash_word_size);
 	const double words = double(n_words);
@@ -3005,27 +3016,41 @@ static int plan(tnt_ctx *c, const tnt_db *db, size_t &targets_per_batch)
 	// the scan are split off into their own launch)
 	c->seed_lds = c->opt.hash_word_size <= SEED_LDS_WORD_SIZE && getenv("TNT_MI355X_SEED_LDS_TABLES");
 	const size_t ent_cap = c->seed_lds ? size_t(SEED_LDS_ENT) : size_t(65535);
-	std::vector<uint32_t> chunk_begin;
 	std::vector<uint32_t> mult(n_words);
-	size_t a0 = 0;
-	while (a0 < n_assays) {
-		size_t a1 = a0, ent = 0;
-		double sum_sq = 0.0;
-		std::fill(mult.begin(), mult.end(), 0u);
-		while (a1 < n_assays && a1 - a0 < size_t(c->seed2 ? S2_ASSAYS : SEED_MAX_ASSAYS)) {
-			const auto &ae = c->assay_entries[a1];
-			double add_sq = 0.0;
-			for (const auto &we : ae) add_sq += 2.0 * double(mult[we.first]++) + 1.0;
-			const double mean = maxlen * double(ent + ae.size()) / words, sigma = sqrt(maxlen * (sum_sq + add_sq) / words);
-			if (a1 > a0 && (mean + 6.0 * sigma > cap || ent + ae.size() > ent_cap)) break;
-			ent += ae.size();
-			sum_sq += add_sq;
-			a1++;
+	auto cut = [&](const double list_cap) {
+		std::vector<uint32_t> begin;
+		size_t a0 = 0;
+		while (a0 < n_assays) {
+			size_t a1 = a0, ent = 0;
+			double sum_sq = 0.0;
+			std::fill(mult.begin(), mult.end(), 0u);
+			while (a1 < n_assays && a1 - a0 < size_t(c->seed2 ? S2_ASSAYS : SEED_MAX_ASSAYS)) {
+				const auto &ae = c->assay_entries[a1];
+				double add_sq = 0.0;
+				for (const auto &we : ae) add_sq += 2.0 * double(mult[we.first]++) + 1.0;
+				const double mean = maxlen * double(ent + ae.size()) / words, sigma = sqrt(maxlen * (sum_sq + add_sq) / words);
+				if (a1 > a0 && (mean + 6.0 * sigma > list_cap || ent + ae.size() > ent_cap)) break;
+				ent += ae.size();
+				sum_sq += add_sq;
+				a1++;
+			}
+			begin.push_back(uint32_t(a0));
+			a0 = a1;
 		}
-		chunk_begin.push_back(uint32_t(a0));
-		a0 = a1;
+		begin.push_back(uint32_t(n_assays));
+		return begin;
+	};
+	std::vector<uint32_t> chunk_begin = cut(cap);
+	// Every chunk launch of the round-3 seed kernel scans the database again: an assay set that fills six chunks or more takes
+	// the instances with the large seed lists when that spares three chunks in ten (three workgroups per CU instead of four;
+	// tnt_seed2.hip.h, S2_CAP_BIG).  Only where every unit goes through that kernel: the windows of long targets are seeded by
+	// the round-2 kernel, whose lists hold SEED_CAP.
+	c->seed2_big = false;
+	if (for_search && c->seed2 && !s2_ltab && !getenv("TNT_MI355X_SEED2_STD_LISTS") && db->h_long_targets.empty() && db->h_word_off[db->n_targets] < (uint64_t(1) << 32) &&
+	    chunk_begin.size() - 1 >= 6) {
+		std::vector<uint32_t> big = cut(double(S2_CAP_BIG) * c->chunk_scale);
+		if ((big.size() - 1) * 10 <= (chunk_begin.size() - 1) * 7) chunk_begin.swap(big), c->seed2_big = true;
 	}
-	chunk_begin.push_back(uint32_t(n_assays));
 	if (chunk_begin != c->planned_chunks) {
 		std::vector<uint16_t> off;
 		std::vector<uint32_t> ent;
@@ -3170,7 +3195,7 @@ int tnt_search_enqueue(tnt_ctx *ctx, tnt_db *db)
 	ctx->events.clear();
 	ctx->cur = 0;
 	size_t tpb = 1;
-	rc = plan(ctx, db, tpb);
+	rc = plan(ctx, db, tpb, true); // (the search may take the seed kernel's large-list instances)
 	if (rc) return rc;
 	tpb = std::max<size_t>(1, size_t(double(tpb) * ctx->batch_scale));
 	ctx->n_batches = 0;

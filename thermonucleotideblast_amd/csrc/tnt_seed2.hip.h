@@ -55,7 +55,12 @@ constexpr int S2_TAB_WORDS = (1 << 14) + 2; // bucket offsets of a chunk for has
 #endif
 constexpr int S2_CAP = TNT_S2_CAP;     // seeds of one target x one assay chunk held in LDS
 constexpr int S2_CAP_LTAB = 512;       // ... by the instance that also keeps the chunk's bucket offsets there (sixteen wavefronts per workgroup)
-constexpr int s2_cap(bool ltab) { return ltab ? S2_CAP_LTAB : S2_CAP; }
+// ... by the instances for assay sets that need many chunks (BIG): every chunk launch scans the database again, so a context
+// whose assays fill six chunks or more at 512 seeds takes lists of 896 -- three workgroups per CU instead of four, but four
+// chunks in ten fewer (config 4, sixteen chunks -> nine: seed stage -16 %; config 5, three chunks: +10 %, so it keeps 512)
+constexpr int S2_CAP_BIG = 896;
+constexpr int s2_cap(bool ltab, bool big = false) { return ltab ? S2_CAP_LTAB : (big ? S2_CAP_BIG : S2_CAP); }
+constexpr int S2_OCC_BIG = 3;          // workgroups per CU of the BIG instances (LDS: 53 KB per workgroup)
 constexpr int S2_ASSAYS = 128;         // assays per chunk (7-bit local index in the key)
 #ifndef TNT_S2_SWEEP
 #define TNT_S2_SWEEP 16
@@ -167,10 +172,11 @@ template <int WS> __device__ __forceinline__ bool s2_first_packed(uint32_t W0, u
 // SHORT: the host vouches that every unit of the launch fits the LDS copy of a target (S2_TGT_WORDS packed words) and lies within
 // the first cull's reach as a whole (bases - k <= max_len + 50): the tests per unit, the reads of target words from HBM and the
 // cull's general loop are compiled out (1-kb and 2-kb targets against the default -l 2000: every BASELINE configuration).
-template <int WS, bool LTAB, bool SHORT> __global__ __launch_bounds__(64 * s2_waves(LTAB), LTAB ? 1 : TNT_S2_OCC) void seed2_kernel(Seed2Args a)
+template <int WS, bool LTAB, bool SHORT, bool BIG = false> __global__ __launch_bounds__(64 * s2_waves(LTAB), LTAB ? 1 : (BIG ? S2_OCC_BIG : TNT_S2_OCC)) void seed2_kernel(Seed2Args a)
 {
 	constexpr int S2_WAVES = s2_waves(LTAB), S2_THREADS = 64 * S2_WAVES;
-	constexpr int S2_CAP = s2_cap(LTAB); // (the instance's list capacity: shadows the namespace constant)
+	constexpr int S2_CAP = s2_cap(LTAB, BIG); // (the instance's list capacity: shadows the namespace constant)
+	static_assert(!(LTAB && BIG), "the large lists do not fit beside the bucket offsets");
 	constexpr bool ALIAS = LTAB || TNT_S2_OCC > 4; // the target's words inside s_ext, the emission's scratch words inside s_srt
 	static_assert(S2_ASSAYS * 4 >= S2_TGT_WORDS + 4 && S2_CAP >= 3 * MAX_BUCKETS, "the shared arrays hold their lodgers");
 	__shared__ uint32_t s_raw[S2_WAVES][S2_CAP];      // kept seeds (keys) as the dense pass finds them
