@@ -10,11 +10,16 @@
 // choice of the strand that is bound first and its pairing loops act on the lists of the WHOLE target
 // (amplicon_search.cpp:96-674, padlock_search.cpp, probe_search.cpp), and the first cull's outcome is not local
 // (cull_oligo_match counts the strands of list successors, sort_by_oligo_loc is not a strict weak order: SURVEY Q4, Q5).
-// So such a target is only SEEDED (windows of k-mer positions, every position once) and BOUND (every seed the first cull
-// keeps, through the same bucket -> pre-filter -> bind kernels as everything else) on the device; its seed lists are
-// merged per (target, assay) on the host, where the first cull, the bind / cull sequence and the pairing loops run on the
-// complete lists with the code the pair kernel runs (tnt_pair.hip.h is compiled for both sides).
-// The host workers of this path: a process-wide pool of threads with 512-MB stacks (pair_group<PAIR_HOST> keeps its lists
+// So such a target is SEEDED in windows of k-mer positions (every position once), its seeds are put into per-(target, assay)
+// lists and culled once on the device (tnt_sort.hip), every seed the first cull keeps is BOUND through the same bucket ->
+// pre-filter -> bind kernels as everything else, and since round 6 the bind / cull sequence and the pairing loops of the PCR
+// lists run on the device as well, for all lists of a pass together (tnt_sort.hip, long_pair_device).  What is left to the host
+// threads below -- which run the code the pair kernel runs, tnt_pair.hip.h being compiled for both sides --: the lists of probe /
+// padlock assays (no culls: one pass over their bound seeds), the lists of the assays under the cache replay, the lists of
+// contexts with primers beyond 128 bases (assembled from segments on the host), and a PCR list the device hands back because
+// sort_by_oligo_loc is not a strict weak order on its entries (the outcome of std::list::sort then hangs on its merge tree,
+// which list_sort restates).
+// The host workers of this path: a process-wide pool of threads with 256-MB stacks (pair_group<PAIR_HOST> keeps its lists
 // on the stack), started at the first long-target search and parked on a condition variable between runs -- starting 64
 // or 128 threads with such stacks costs 2-3 ms every time, as much as the culls and the pairing they are started for.
 // run(n, f): f(0) .. f(n - 1), the workers take the indices one at a time; one run at a time (searches of several

@@ -28,6 +28,15 @@
 //  * phase-A items go STRAIGHT into the queue of the length bucket that binds them (blocks of 64 slots handed out per
 //    bucket, unused slots hold QUEUE_HOLE): the bucket pass over the phase-A queue (two passes over 52 M entries on
 //    config 2) is gone and the pre-filter reads the windows of one target back to back.
+// Round 6 (the stage is a chain of dependent steps per target that four wavefronts per SIMD do not hide: shorter chains):
+//  * wave prefix sums and neighbour reads in the VALU's DPP forms (row_shr / row_bcast, wave_shr) instead of LDS crossbar
+//    shuffles; the first cull's walk to the list successor only for the seeds that turned out valid (one round per target
+//    instead of one per 64 seeds), four keys per trip; the counting sort four rounds at a time;
+//  * the dense pass: one 16-byte record per candidate (table entry + the first 32 bases of its oligo), six candidates per
+//    lane in flight, the common case as straight-line code (selects), the rare cases behind one wave-uniform branch;
+//  * instances for databases of short targets (SHORT: every unit in LDS and within the cull's reach, the per-unit tests
+//    and the general loops compiled out) and for assay sets of many chunks (BIG: lists of 896 seeds, three workgroups per CU).
+// Config 2: 5.29 -> 4.57 ms per step; config 4 (sixteen chunks -> nine): 472 -> 369 ms.
 #ifndef TNT_SEED2_HIP_H
 #define TNT_SEED2_HIP_H
 

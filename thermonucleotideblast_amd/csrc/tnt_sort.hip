@@ -1,5 +1,6 @@
-// tnt_sort.hip -- device side of the long-target path's list assembly: the seeds of all windows of the targets that
-// are seeded in windows, ordered into per-(target, assay) lists in the reference's list order.
+// tnt_sort.hip -- device side of the long-target path: the seeds of all windows of the targets that are seeded in windows,
+// ordered into per-(target, assay) lists in the reference's list order (long_sort_seeds), their first cull (long_first_cull)
+// and, behind the bind kernels, the bind / cull sequence and the pairing loops of the PCR lists (long_pair_device, round 6).
 //
 // The reference keeps one std::list per (target, assay) and sorts it by target_loc before the first cull
 // (match_oligo_to_*_strand + cull_oligo_match, bind_oligo.cpp:84-122, amplicon_search.cpp:688; the hash-overload lists by
