@@ -13,7 +13,7 @@ for kv in filter(None, os.environ.get("OPTS", "").split(",")):  # option overrid
 eng = Engine(wl.options, wl.expanded)
 db = eng.pack(wl.codes, wl.offsets)
 seed = []
-for rep in range(int(os.environ.get("REPS", "6"))):
+for rep in range(int(os.environ.get("REPS", "3"))):
     t = time.perf_counter(); hits = eng.search(db); dt = time.perf_counter() - t
     tm = eng.timing()
     seed.append(tm.seed_ms)

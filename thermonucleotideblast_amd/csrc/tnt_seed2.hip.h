@@ -36,7 +36,7 @@
 //    lane in flight, the common case as straight-line code (selects), the rare cases behind one wave-uniform branch;
 //  * instances for databases of short targets (SHORT: every unit in LDS and within the cull's reach, the per-unit tests
 //    and the general loops compiled out) and for assay sets of many chunks (BIG: lists of 896 seeds, three workgroups per CU).
-// Config 2: 5.29 -> 4.57 ms per step; config 4 (sixteen chunks -> nine): 472 -> 369 ms.
+// Config 2: 5.29 -> 4.6 ms per step; config 4 (54 chunk launches per batch -> 28): 472 -> 369 ms per shard.
 #ifndef TNT_SEED2_HIP_H
 #define TNT_SEED2_HIP_H
 
@@ -66,7 +66,7 @@ constexpr int S2_CAP = TNT_S2_CAP;     // seeds of one target x one assay chunk 
 constexpr int S2_CAP_LTAB = 512;       // ... by the instance that also keeps the chunk's bucket offsets there (sixteen wavefronts per workgroup)
 // ... by the instances for assay sets that need many chunks (BIG): every chunk launch scans the database again, so a context
 // whose assays fill six chunks or more at 512 seeds takes lists of 896 -- three workgroups per CU instead of four, but four
-// chunks in ten fewer (config 4, sixteen chunks -> nine: seed stage -16 %; config 5, three chunks: +10 %, so it keeps 512)
+// chunks in ten fewer (config 4, 54 chunks -> 28: seed stage -16 % and more; config 5, ten chunks -> eight at +10 %, so it keeps 512)
 constexpr int S2_CAP_BIG = 896;
 constexpr int s2_cap(bool ltab, bool big = false) { return ltab ? S2_CAP_LTAB : (big ? S2_CAP_BIG : S2_CAP); }
 constexpr int S2_OCC_BIG = 3;          // workgroups per CU of the BIG instances (LDS: 53 KB per workgroup)
