@@ -618,9 +618,12 @@ struct tnt_ctx {
 	tnt_options opt;
 	hipStream_t stream = nullptr;
 	// The length buckets of a phase are independent launches: they run on BIND_LANES side streams (each with its
-	// own scratch slabs) so that the drain of one launch overlaps the ramp-up of the next.
-	static constexpr int BIND_LANES = 8; // at most; `lanes` of them are used (TNT_MI355X_BIND_LANES, default 4)
-	int lanes = 4;
+	// own scratch slabs) so that the drain of one launch overlaps the ramp-up of the next.  Three by default: the runtime maps a
+	// process's streams onto four hardware queues, the context's own stream holds one, and two streams on one queue run one after
+	// the other -- a fourth side stream was sharing a queue with the first (profiles/r06s_timeline_config2.txt: four of config 2's
+	// eight bucket chains on one queue, the other queues idle for the last quarter of the phase).
+	static constexpr int BIND_LANES = 8; // at most; `lanes` of them are used (TNT_MI355X_BIND_LANES, default 3)
+	int lanes = 3;
 	hipStream_t lane_stream[BIND_LANES] = {};
 	hipEvent_t lane_done[BIND_LANES] = {};
 	bool split_filter = false;                 // all pre-filter launches on lane 0, the bind launches behind them on the other lanes (TNT_MI355X_SPLIT_FILTER)
@@ -1182,16 +1185,54 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 	if (regrouped) // the phase-A queues of the batch, windows of one oligo side by side (tnt_ufilter.hip.h)
 		launch_regroup(c, c->rg_desc.p, uint32_t(c->h_rg_desc.size()), c->S().qfat.p, c->S().qsort.p, cnt + C_BUCKET, c->slot_bin.p, c->S().rg_hist.p, c->S().rg_cursor.p, c->stream, c->rg_seed_counts);
 	(void)hipEventRecord(c->phase_ready, c->stream);
+	auto LS = [&](int l) { return c->lane_stream[l]; };
 	for (int l = 0; l < c->lanes; l++) (void)hipStreamWaitEvent(c->lane_stream[l], c->phase_ready, 0);
 	int n_launch = 0;
+	// Which side stream takes which bucket.  The chains of the buckets (pre-filter -> second tier -> bind) run beside each other
+	// and fill each other's tails -- as long as the streams end together: the phase waits for the last one.  Round 6: the buckets
+	// are dealt by expected work (oligo slots of the bucket x rows x columns; the windows per oligo are alike), longest first to
+	// the least loaded stream, instead of round robin (which left one stream with four of config 2's eight buckets and the
+	// others idle for the last quarter of the phase: profiles/r06s_timeline_config2.txt).
+	auto launches = [&](size_t i) {
+		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) return false; // general instances other than the last (merge) bucket only see windows with degenerate bases
+		if (direct && c->h_q_cap[i] == 0) return false; // no slot routes its items here
+		return true;
+	};
+	std::vector<int> lane_of(c->bucket_lmax.size(), 0);
+	if (!c->serial_bind && c->lanes > 1 && !getenv("TNT_MI355X_LANES_ROUND_ROBIN")) {
+		std::vector<double> weight(c->bucket_lmax.size(), 0.0), load(size_t(c->lanes), 0.0);
+		for (const Slot &sl : c->h_slots) {
+			if (sl.oligo < 0) continue;
+			const size_t bk = size_t(has_exceptions ? sl.bucket_general : sl.bucket); // (the plain buckets carry nearly all windows of a database without exceptions)
+			const double rows = double(c->oligos[size_t(sl.oligo)].size());
+			if (size_t(sl.bucket) < weight.size()) weight[size_t(sl.bucket)] += rows * (rows + 2.0 * FLANK);
+			if (has_exceptions && bk < weight.size() && bk != size_t(sl.bucket)) weight[bk] += 0.1 * rows * (rows + 2.0 * FLANK);
+		}
+		std::vector<size_t> order;
+		for (size_t i = 0; i < c->bucket_lmax.size(); i++)
+			if (launches(i)) order.push_back(i);
+		std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return weight[x] > weight[y]; });
+		const int first_lane = (c->split_filter && c->lanes >= 2) ? 1 : 0;
+		for (size_t i : order) {
+			int best = first_lane;
+			for (int l = first_lane; l < c->lanes; l++)
+				if (load[size_t(l)] < load[size_t(best)]) best = l;
+			lane_of[i] = best;
+			load[size_t(best)] += weight[i] + 1.0;
+		}
+	} else {
+		int n = 0;
+		const bool split_rr = c->split_filter && !c->serial_bind && c->lanes >= 2;
+		for (size_t k = c->bucket_lmax.size(); k-- > 0;)
+			if (launches(k)) lane_of[k] = c->serial_bind ? 0 : (split_rr ? 1 + n++ % (c->lanes - 1) : n++ % c->lanes);
+	}
 	// longest buckets first: they take the longest per item, the short ones fill the gaps
 	for (size_t k = c->bucket_lmax.size(); k-- > 0;) {
 		const size_t i = k;
-		// general instances other than the last (merge) bucket only see windows with degenerate bases
-		if (!has_exceptions && !(c->bucket_lmax[i] & BUCKET_PLAIN) && i + 1 < c->bucket_lmax.size()) continue;
-		if (direct && c->h_q_cap[i] == 0) continue; // no slot routes its items here
+		if (!launches(i)) continue;
 		const bool split = c->split_filter && !c->serial_bind && c->lanes >= 2;
-		const int lane = c->serial_bind ? 0 : (split ? 1 + n_launch++ % (c->lanes - 1) : n_launch++ % c->lanes);
+		const int lane = lane_of[i];
+		n_launch++;
 		if (c->serial_bind) n_launch = 1;
 		// (direct: the queue holds 16-byte entries whose first word is the item index)
 		const uint32_t *queue = direct ? reinterpret_cast<const uint32_t *>(c->S().qfat.p + c->h_q_base[i]) : c->S().qbucket.p;
@@ -1258,7 +1299,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 					u.slot_bin = c->slot_bin.p, u.general = B.general;
 					u.bin_end = c->S().rg_cursor.p + B.bin_base, u.bin_count = c->S().rg_hist.p + B.bin_base, u.bin_fill = c->S().rg_fill.p + B.bin_base;
 				}
-				launch_ufilter(u, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], degen);
+				launch_ufilter(u, c->n_cu * 8, rows, LS(split ? 0 : lane), degen);
 				if (second) {
 					SBoundArgs sb;
 					memset(&sb, 0, sizeof(sb));
@@ -1269,16 +1310,16 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 					sb.survivors = c->S().qsurv2.p + c->h_q_base[i];
 					sb.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 7;
 					sb.result = b.result, sb.n_rejected = gcnt + C_FILTERED, sb.audit = f.audit;
-					launch_sbound(sb, c->n_cu * 3, rows, c->lane_stream[lane]);
+					launch_sbound(sb, c->n_cu * 3, rows, LS(lane));
 					f.survivors = sb.survivors, f.n_survivors = sb.n_survivors; // what the bind kernel takes
 				}
 			} else {
-				launch_filter(f, c->n_cu * 8, rows, c->lane_stream[split ? 0 : lane], degen);
+				launch_filter(f, c->n_cu * 8, rows, LS(split ? 0 : lane), degen);
 			}
 			if (split) { // the filter kernels, each of which fills the device, queue up on lane 0; the bind launches follow theirs on the other lanes
 				if (!c->filtered[i]) (void)hipEventCreateWithFlags(&c->filtered[i], hipEventDisableTiming);
-				(void)hipEventRecord(c->filtered[i], c->lane_stream[0]);
-				(void)hipStreamWaitEvent(c->lane_stream[lane], c->filtered[i], 0);
+				(void)hipEventRecord(c->filtered[i], LS(0));
+				(void)hipStreamWaitEvent(LS(lane), c->filtered[i], 0);
 			}
 			// ... and of the general buckets of phase A (windows with IUPAC codes or inosine): the instance that resolves a column's
 			// code against the query base of every row, on the first tier's dense list.  (Not in phase B: its few thousand windows are
@@ -1294,7 +1335,7 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 				sd.survivors = c->S().qsurv2.p + (direct ? c->h_q_base[i] : 0u);
 				sd.n_survivors = cnt + C_BUCKET + i * BUCKET_STRIDE + 7;
 				sd.result = b.result, sd.n_rejected = gcnt + C_FILTERED, sd.audit = f.audit;
-				launch_sbound_degen(sd, c->n_cu * 2, rows, c->lane_stream[lane]);
+				launch_sbound_degen(sd, c->n_cu * 2, rows, LS(lane));
 				f.survivors = sd.survivors, f.n_survivors = sd.n_survivors;
 			}
 			b.index = f.survivors;
@@ -1307,8 +1348,8 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		b.stack = c->stack.p + size_t(lane) * c->lane_cols;
 		b.ties = c->ties.p + size_t(lane) * c->lane_ties;
 		if (!c->opt.use_dinkelbach && ((c->bucket_lmax[i] & BUCKET_WAVE) || (c->wave_from && (c->bucket_lmax[i] & 0xFF) >= c->wave_from)))
-			launch_wbind(c, b, bucket_rows(c->bucket_lmax[i]), false, c->lane_stream[lane]);
-		else launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], c->lane_stream[lane]);
+			launch_wbind(c, b, bucket_rows(c->bucket_lmax[i]), false, LS(lane));
+		else launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], LS(lane));
 	}
 	for (int l = 0; l < c->lanes && (l < n_launch || c->split_filter); l++) {
 		(void)hipEventRecord(c->lane_done[l], c->lane_stream[l]);
