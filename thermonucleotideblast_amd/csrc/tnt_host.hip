@@ -629,6 +629,11 @@ struct tnt_ctx {
 	bool split_filter = false;                 // all pre-filter launches on lane 0, the bind launches behind them on the other lanes (TNT_MI355X_SPLIT_FILTER)
 	hipEvent_t filtered[MAX_BUCKETS] = {};      // split_filter: bucket i has met its pre-filter
 	hipEvent_t phase_ready = nullptr;
+	// how long the launch chain of every bucket took in phase A of the last batch (events around the chain on its side stream):
+	// the next batch deals its buckets to the streams by these (launch_bind_phase)
+	hipEvent_t chain_ev[MAX_BUCKETS][2] = {};
+	bool chain_timed[MAX_BUCKETS] = {};
+	double chain_ms[MAX_BUCKETS] = {};
 	size_t lane_trace = 0, lane_cols = 0, lane_ties = 0; // scratch elements per lane
 
 	uint64_t long_pair_stats[4] = {0, 0, 0, 0}; // tnt_long_pair_stats: the lists of windowed targets in the last search
@@ -816,6 +821,9 @@ struct tnt_ctx {
 			if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
 		}
 		if (phase_ready) (void)hipEventDestroy(phase_ready);
+		for (auto &pair : chain_ev)
+			for (hipEvent_t ev : pair)
+				if (ev) (void)hipEventDestroy(ev);
 		for (BatchSet &W : set) {
 			if (W.seeded) (void)hipEventDestroy(W.seeded);
 			if (W.released) (void)hipEventDestroy(W.released);
@@ -1208,6 +1216,13 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 			if (size_t(sl.bucket) < weight.size()) weight[size_t(sl.bucket)] += rows * (rows + 2.0 * FLANK);
 			if (has_exceptions && bk < weight.size() && bk != size_t(sl.bucket)) weight[bk] += 0.1 * rows * (rows + 2.0 * FLANK);
 		}
+		// (phase A of a search whose context has met such a batch before: the chains' own times, under the same sharing of the device)
+		double measured = 0.0;
+		if (shard_counts)
+			for (size_t i = 0; i < c->bucket_lmax.size() && i < size_t(MAX_BUCKETS); i++)
+				if (launches(i)) measured += c->chain_ms[i];
+		if (measured > 0.0 && !getenv("TNT_MI355X_LANES_STATIC"))
+			for (size_t i = 0; i < c->bucket_lmax.size() && i < size_t(MAX_BUCKETS); i++) weight[i] = c->chain_ms[i] * 1.0e6;
 		std::vector<size_t> order;
 		for (size_t i = 0; i < c->bucket_lmax.size(); i++)
 			if (launches(i)) order.push_back(i);
@@ -1234,6 +1249,12 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		const int lane = lane_of[i];
 		n_launch++;
 		if (c->serial_bind) n_launch = 1;
+		const bool time_chain = shard_counts && !c->serial_bind && !split && i < size_t(MAX_BUCKETS);
+		if (time_chain) {
+			for (int e = 0; e < 2; e++)
+				if (!c->chain_ev[i][e]) (void)hipEventCreate(&c->chain_ev[i][e]);
+			(void)hipEventRecord(c->chain_ev[i][0], LS(lane));
+		}
 		// (direct: the queue holds 16-byte entries whose first word is the item index)
 		const uint32_t *queue = direct ? reinterpret_cast<const uint32_t *>(c->S().qfat.p + c->h_q_base[i]) : c->S().qbucket.p;
 		// (survivor lists keep the regrouped queues' geometry: bucket i at q_base[i] + 64 * rg_bin_base[i], so that a bucket whose
@@ -1350,6 +1371,10 @@ void launch_bind_phase(tnt_ctx *c, BindArgs b, const DbView &v, bool has_excepti
 		if (!c->opt.use_dinkelbach && ((c->bucket_lmax[i] & BUCKET_WAVE) || (c->wave_from && (c->bucket_lmax[i] & 0xFF) >= c->wave_from)))
 			launch_wbind(c, b, bucket_rows(c->bucket_lmax[i]), false, LS(lane));
 		else launch_bind(c, b, bind_grid(c, c->bucket_lmax[i]), c->bucket_lmax[i], LS(lane));
+		if (time_chain) {
+			(void)hipEventRecord(c->chain_ev[i][1], LS(lane));
+			c->chain_timed[i] = true;
+		}
 	}
 	for (int l = 0; l < c->lanes && (l < n_launch || c->split_filter); l++) {
 		(void)hipEventRecord(c->lane_done[l], c->lane_stream[l]);
@@ -3295,6 +3320,13 @@ static int collect_search(tnt_ctx *ctx, bool want_records, const tnt_hit **hits,
 	HIP_TRY(hipMemcpyAsync(cnt, ctx->S().counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 	HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 	ctx->pending = false;
+	for (int i = 0; i < MAX_BUCKETS; i++) { // how long the buckets' chains of the last batch took: the next search deals them by these
+		if (!ctx->chain_timed[i]) continue;
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, ctx->chain_ev[i][0], ctx->chain_ev[i][1]) == hipSuccess && ms > 0.0f) ctx->chain_ms[i] = double(ms);
+		else (void)hipGetLastError();
+		ctx->chain_timed[i] = false;
+	}
 #ifdef TNT_EXP_STATS
 	{
 		const uint32_t *d = cnt + C_DEBUG;
