@@ -172,12 +172,13 @@ const char *tnt_last_error(const tnt_ctx *ctx); /* ctx may be NULL: last creatio
  * its threads met the windows.  This library reports such windows as not bound: under these options it can list fewer hits. */
 const char *tnt_ctx_warnings(const tnt_ctx *ctx);
 /* Where the lists of the targets that are seeded in windows (records beyond one seed work unit: genomes, chromosomes) were
- * sequenced and paired during the context's last search (ABI v7) -- the bind / cull sequence and the pairing loops of
- * amplicon() (amplicon_search.cpp:131-674) per (target, assay) list: out[0] = PCR lists done on the device, out[1] = PCR lists
- * the device handed back to the host threads because sort_by_oligo_loc (amplicon_search.cpp:12-26) is not a strict weak order
- * on their entries, out[2] = lists that were the host threads' from the start (probe / padlock assays, assays under the
- * BindCache replay, contexts with primers beyond 128 bases), out[3] = hits the device reported.  All zero when the search met
- * no such target. */
+ * sequenced and paired during the context's last search (ABI v7) -- per (target, assay) list the bind / cull sequence and the
+ * pairing loops of amplicon() (amplicon_search.cpp:131-674), or the list sorts and pairing of hybrid() / padlock()
+ * (probe_search.cpp:67-230, padlock_search.cpp:62-361): out[0] = lists done on the device, out[1] = PCR lists the device handed
+ * back to the host threads because sort_by_oligo_loc (amplicon_search.cpp:12-26) is not a strict weak order on their entries,
+ * out[2] = lists that were the host threads' from the start (assays under the BindCache replay, the segments of probes beyond
+ * 128 bases, contexts with primers beyond 128 bases), out[3] = hits the device reported.  All zero when the search met no such
+ * target. */
 int tnt_long_pair_stats(const tnt_ctx *ctx, uint64_t out[4]);
 
 /* unique-oligo table of the context (assay oligos de-duplicated by string) */

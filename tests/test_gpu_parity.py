@@ -871,6 +871,49 @@ def test_pcr_lists_of_windowed_targets_are_paired_on_the_device(Engine, oracle, 
     e.close()
 
 
+@pytest.mark.parametrize("fmt,max_len", [(abi.ASSAY_PADLOCK, 0), (abi.ASSAY_MIPS, 40), (None, 0)])
+def test_probe_and_padlock_lists_of_windowed_targets_on_the_device(Engine, oracle, fmt, max_len, monkeypatch):
+    """The lists of probe / padlock assays of a windowed target -- the hash overload's lists: the bound seeds by (strand, arm),
+    sorted by oligo_info::operator<, one per footprint, then hybrid()'s / padlock()'s loops -- run on the device
+    (tnt_sort.hip, long_hash_device); TNT_MI355X_LONG_HOST_HASH_LISTS=1 leaves them to the host threads.  Same hits in the same
+    order either way, equal to the oracle's.  fmt None: config 5's mix of padlock and hybridisation-probe assays."""
+    if fmt is None:
+        wl = synth.make_workload(5, n_targets=700, n_assays=14, seed=83)
+        opt, ex, codes = wl.options, wl.expanded, wl.codes
+        glued = np.array([0, int(wl.offsets[-1])], dtype=np.uint64)
+    else:
+        rng = np.random.default_rng(5150 + int(fmt))
+        n, tl = 90, 1000
+        codes, _ = synth._targets(rng, n, tl)
+        arms = [(synth._rand_oligo(rng, 20, 24), synth._rand_oligo(rng, 20, 24)) for _ in range(3)]
+        for k in range(150):
+            F, R = arms[k % 3]
+            gap = "" if fmt == abi.ASSAY_PADLOCK else "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 60))))
+            site = synth._mutate(rng, F, 1) + gap + synth._mutate(rng, R, 1)
+            if rng.random() < 0.5:
+                site = synth.revcomp(site)
+            synth._put(codes, 0, int(rng.integers(10, n * tl - 200)), site)
+        glued = np.array([0, n * tl], dtype=np.uint64)
+        opt = abi.options_default(min_primer_tm=40.0, min_probe_tm=40.0, assay_format=fmt, max_len=max_len)
+        ex = synth.expand_assays([synth.Assay("pad%d" % i, F, R, None) for i, (F, R) in enumerate(arms)])
+    want = tc.sorted_hit_keys(oracle.search(opt, ex, codes, glued))
+    e = Engine(opt, ex)
+    db = e.pack(codes, glued)
+    got = [tc.hit_key(h) for h in e.search(db)]
+    on_device, handed_back, host_lists, device_hits = e.long_pair_stats()
+    monkeypatch.setenv("TNT_MI355X_LONG_HOST_HASH_LISTS", "1")
+    host = [tc.hit_key(h) for h in e.search(db)]
+    stats_host = e.long_pair_stats()
+    monkeypatch.delenv("TNT_MI355X_LONG_HOST_HASH_LISTS")
+    assert len(want) > 20
+    assert got == host
+    assert sorted(got) == want
+    assert on_device > 0 and device_hits == len(got) and handed_back == 0 and host_lists == 0
+    assert stats_host[0] == 0 and stats_host[2] == on_device
+    db.close()
+    e.close()
+
+
 def test_a_list_beyond_the_host_replay_s_million_entries_is_paired_on_the_device(Engine, monkeypatch):
     """The host replay keeps a (target, assay) list in arrays of 1 048 576 entries; the device pairing has no such bound.  A
     40-Mb record against one primer pair at -W 5 leaves some 2.8 million seeds behind the first cull: the search succeeds with

@@ -61,6 +61,10 @@ hipError_t sort_pairs_u64_u32(void *tmp, size_t &tmp_bytes, const unsigned long 
 hipError_t long_sort_seeds(const SeedOut *seeds, uint32_t n, const uint32_t *target_rank, const AssayDev *assays, uint32_t n_assays,
                            uint32_t n_buckets, Item *items, uint32_t *bucket, DeviceArena &arena, hipStream_t stream);
 size_t long_pair_bytes(size_t n);
+size_t long_hash_bytes(size_t n_kept, size_t n_bound, size_t n_lists);
+hipError_t long_hash_device(const Item *kept, uint32_t n_kept, const Group *h_groups, uint32_t n_groups, const uint8_t *h_take, const int32_t *result, const BoundRec *pool,
+                            const AssayDev *assays, const AssayDev *h_assays, const uint32_t *h_unit_target, uint32_t first_seq_index, int pair_max_len, std::vector<Hit> &hits_out,
+                            DeviceArena &arena, hipStream_t stream);
 hipError_t long_pair_device(const Item *kept, uint32_t n_kept, const Group *h_groups, uint32_t n_groups, const uint8_t *h_take, const int32_t *result, const BoundRec *pool,
                             const AssayDev *assays, const AssayDev *h_assays, const uint32_t *h_unit_target, uint32_t first_seq_index, int max_len, int single_primer,
                             int min_max_primer_clamp, std::vector<Hit> &hits_out, std::vector<uint8_t> &h_flagged, DeviceArena &arena, hipStream_t stream);

@@ -13,10 +13,11 @@
 // So such a target is SEEDED in windows of k-mer positions (every position once), its seeds are put into per-(target, assay)
 // lists and culled once on the device (tnt_sort.hip), every seed the first cull keeps is BOUND through the same bucket ->
 // pre-filter -> bind kernels as everything else, and since round 6 the bind / cull sequence and the pairing loops of the PCR
-// lists run on the device as well, for all lists of a pass together (tnt_sort.hip, long_pair_device).  What is left to the host
-// threads below -- which run the code the pair kernel runs, tnt_pair.hip.h being compiled for both sides --: the lists of probe /
-// padlock assays (no culls: one pass over their bound seeds), the lists of the assays under the cache replay, the lists of
-// contexts with primers beyond 128 bases (assembled from segments on the host), and a PCR list the device hands back because
+// lists and the sorts and pairing of the probe / padlock lists run on the device as well, for all lists of a pass together
+// (tnt_sort.hip, long_pair_device / long_hash_device).  What is left to the host threads below -- which run the code the pair
+// kernel runs, tnt_pair.hip.h being compiled for both sides --: the lists of the assays under the cache replay, the segments of
+// probes beyond 128 bases, the lists of contexts with primers beyond 128 bases (assembled from segments on the host), and a PCR
+// list the device hands back because
 // sort_by_oligo_loc is not a strict weak order on its entries (the outcome of std::list::sort then hangs on its merge tree,
 // which list_sort restates).
 // The host workers of this path: a process-wide pool of threads with 256-MB stacks (pair_group<PAIR_HOST> keeps its lists
@@ -291,9 +292,13 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		if (dev_pair) {
 			take.assign(groups.size(), 0);
 			bool any = false;
+			const bool hash_lists = !getenv("TNT_MI355X_LONG_HOST_HASH_LISTS");
 			for (size_t g = 0; g < groups.size(); g++) {
 				const AssayDev &A = ctx->h_assays[groups[g].assay & GROUP_ASSAY_MASK];
-				take[g] = (A.kind == 0 && !(ctx->cache_replay && (A.cache_replay & 1))) ? 1 : 0;
+				const bool replayed_here = ctx->cache_replay && (A.cache_replay & 1);
+				// 1: a PCR list (long_pair_device); 2: a probe / padlock list (long_hash_device; not the segments of a probe beyond 128
+				// bases, whose hits carry their diagonal to the merge); 0: the host threads'
+				take[g] = replayed_here ? 0 : (A.kind == 0 ? 1 : ((hash_lists && !(A.cache_replay & 2)) ? 2 : 0));
 				any = any || take[g];
 				host_copies = host_copies || !take[g];
 			}
@@ -477,7 +482,8 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 	DeviceArena &pair_arena = ctx->long_pair_arena;
 	int32_t *d_result_all = nullptr;
 	if (dev_pair) {
-		if (pair_arena.reserve(long_pair_bytes(n_bind) + n_bind * sizeof(int32_t) + 4096) != hipSuccess || !(d_result_all = pair_arena.take<int32_t>(n_bind))) {
+		if (pair_arena.reserve(std::max(long_pair_bytes(n_bind), long_hash_bytes(n_bind, n_bind / 2 + 65536, groups.size())) + n_bind * sizeof(int32_t) + 4096) != hipSuccess ||
+		    !(d_result_all = pair_arena.take<int32_t>(n_bind))) {
 			(void)hipGetLastError();
 			dev_pair = false; // (no room: the host threads take everything)
 			if (!host_copies) {
@@ -544,11 +550,31 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 		c0 += nc;
 	}
 	lap("bind on the device");
-	// ---- the PCR lists on the device: bind / cull sequence, last sort, pairing loops (amplicon_search.cpp:131-674)
+	// ---- the lists on the device: the PCR lists' bind / cull sequence, last sort and pairing loops (amplicon_search.cpp:131-674),
+	// the probe / padlock lists' sorts and pairing (probe_search.cpp:67-230, padlock_search.cpp:62-361)
 	std::vector<Hit> dev_hits;
 	std::vector<uint8_t> flagged;
+	std::vector<Hit> dev_hash_hits; // the probe / padlock lists' (long_hash_device)
+	bool hash_done = false;
 	if (dev_pair) {
-		const hipError_t pe = long_pair_device(d_kept, uint32_t(n_bind), groups.data(), uint32_t(groups.size()), take.data(), d_result_all, ctx->long_pool.p, ctx->assays.p,
+		std::vector<uint8_t> take_pcr(groups.size()), take_hash(groups.size());
+		bool any_hash = false;
+		for (size_t g = 0; g < groups.size(); g++) take_pcr[g] = take[g] == 1, take_hash[g] = take[g] == 2, any_hash = any_hash || take[g] == 2;
+		if (any_hash) {
+			const int pair_max_len = ctx->opt.assay_format == TNT_ASSAY_MIPS ? ctx->opt.max_len : 0; // tntblast_local.cpp:592,606
+			const hipError_t he = long_hash_device(d_kept, uint32_t(n_bind), groups.data(), uint32_t(groups.size()), take_hash.data(), d_result_all, ctx->long_pool.p, ctx->assays.p,
+			                                       ctx->h_assays.data(), unit_target.data(), db->first_seq_index, pair_max_len, dev_hash_hits, pair_arena, ctx->stream);
+			if (he == hipSuccess) {
+				hash_done = true;
+			} else if (he == hipErrorOutOfMemory) { // (more bound seeds than the reservation expects: the host threads take these lists)
+				(void)hipGetLastError();
+				dev_hash_hits.clear();
+			} else {
+				ctx->err = std::string("the probe / padlock lists of long targets on the device: ") + hipGetErrorString(he);
+				return TNT_E_DEVICE;
+			}
+		}
+		const hipError_t pe = long_pair_device(d_kept, uint32_t(n_bind), groups.data(), uint32_t(groups.size()), take_pcr.data(), d_result_all, ctx->long_pool.p, ctx->assays.p,
 		                                       ctx->h_assays.data(), unit_target.data(), db->first_seq_index, ctx->opt.max_len, ctx->opt.single_primer_pcr,
 		                                       ctx->opt.min_max_primer_clamp, dev_hits, flagged, pair_arena, ctx->stream);
 		if (pe == hipErrorOutOfMemory) { // (more bound seeds than the reservation expects: the host threads take the lists)
@@ -559,6 +585,9 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			ctx->err = std::string("pairing the lists of long targets on the device: ") + hipGetErrorString(pe);
 			return TNT_E_DEVICE;
 		}
+		if (!hash_done)
+			for (size_t g = 0; g < groups.size(); g++)
+				if (take[g] == 2) flagged[g] = 1; // (no room for them on the device: the host threads take them)
 		size_t n_back = 0;
 		for (size_t g = 0; g < groups.size(); g++) {
 			n_back += (take[g] && flagged[g]) ? 1 : 0;
@@ -567,8 +596,8 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 				return TNT_E_LIMIT;
 			}
 		}
-		if (timing) fprintf(stderr, "long targets: %zu lists on the device, %zu of them handed back (sort_by_oligo_loc not a strict weak order on them), %zu hits\n",
-		                    size_t(std::count(take.begin(), take.end(), uint8_t(1))), n_back, dev_hits.size());
+		if (timing) fprintf(stderr, "long targets: %zu PCR and %zu probe / padlock lists on the device, %zu of them handed back (sort_by_oligo_loc not a strict weak order on them), %zu + %zu hits\n",
+		                    size_t(std::count(take.begin(), take.end(), uint8_t(1))), size_t(std::count(take.begin(), take.end(), uint8_t(2))), n_back, dev_hits.size(), dev_hash_hits.size());
 		if (n_back && !host_copies) { // the host threads need the seeds, results and records after all
 			host_copies = true;
 			HIP_TRY(ctx->pin_bind.ensure(n_bind), ctx->err);
@@ -586,11 +615,12 @@ static int search_long_pass(tnt_ctx *ctx, tnt_db *db, const size_t u0, const siz
 			if (n_pool) HIP_TRY(hipMemcpyAsync(ctx->pin_pool.p, ctx->long_pool.p, n_pool * sizeof(BoundRec), hipMemcpyDeviceToHost, ctx->stream), ctx->err);
 			HIP_TRY(hipStreamSynchronize(ctx->stream), ctx->err);
 		}
-		lap("PCR lists (device)");
+		lap("lists on the device");
 	}
 	auto on_device = [&](size_t g) { return dev_pair && take[g] && !flagged[g]; };
 	for (size_t g = 0; g < groups.size(); g++) ctx->long_pair_stats[on_device(g) ? 0 : ((dev_pair && take[g]) ? 1 : 2)]++;
-	ctx->long_pair_stats[3] += dev_hits.size();
+	ctx->long_pair_stats[3] += dev_hits.size() + dev_hash_hits.size();
+	dev_hits.insert(dev_hits.end(), dev_hash_hits.begin(), dev_hash_hits.end()); // (a list's hits come from one side: the order below puts the lists in place)
 	const BoundRec *const pool = ctx->pin_pool.p;
 
 	// ---- row a6 on these targets: the groups of the assays that share an oligo across strand concentrations / threshold sets are

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -969,6 +970,295 @@ hipError_t long_pair_device(const Item *kept, uint32_t n_kept, const Group *h_gr
 	if (debug) fprintf(stderr, "long_pair_device: lists handed back: %u run order, %u crossing footprints, %u zero-sum footprint\n", why[0], why[1], why[2]);
 	arena.rewind(mark0);
 #undef LP_TRY
+	return hipGetLastError();
+}
+
+// =====================================================================================================================
+// The lists of probe / padlock assays of windowed targets (hybrid(), probe_search.cpp:67-230; padlock(),
+// padlock_search.cpp:62-361, on the hash overload's lists, bind_oligo.cpp:124-454): nothing is culled there -- every seed
+// is bound, the bound ones of a list are split by (strand, arm), stable-sorted by oligo_info::operator< (loc_5, loc_3, Tm
+// descending: a strict weak order, tntblast.h:230-242) and reduced to one per footprint (bind_oligo.cpp:431-453); a probe
+// assay reports every entry of its two probe lists, a padlock assay every (upstream, downstream) pair of one strand whose
+// gap is 0 .. max_len (MIPS) bases.  All lists of a pass together: the bound seeds are picked out, sorted with three stable
+// radix passes, reduced, and one thread per entry counts its hits, then writes them where the counts' prefix sum says -- the
+// order of the reference's loops.
+// =====================================================================================================================
+namespace {
+
+struct LhEntry { // a bound seed of a probe / padlock list
+	int32_t loc5, loc3;
+	int32_t rec;
+	uint32_t sub;      // list << 2 | sublist (0 minus upstream, 1 minus downstream / probe, 2 plus upstream, 3 plus downstream / probe)
+	uint32_t tm_desc;
+};
+
+__global__ __launch_bounds__(256) void lh_flag_kernel(const Item *kept, uint32_t n_kept, const uint32_t *g_first, const uint32_t *g_list, uint32_t n_groups, const int32_t *result,
+                                                     uint32_t *flag, uint32_t *list_of)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_kept; i += gridDim.x * blockDim.x) {
+		uint32_t lo = 0, hi = n_groups; // last group whose first seed is at or before i
+		while (hi - lo > 1u) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (g_first[mid] <= i) lo = mid;
+			else hi = mid;
+		}
+		const uint32_t l = g_list[lo];
+		flag[i] = (l != 0xFFFFFFFFu && i < g_first[lo + 1u] && result[i] >= 0) ? 1u : 0u;
+		list_of[i] = l;
+	}
+}
+__global__ __launch_bounds__(256) void lh_gather_kernel(const Item *kept, uint32_t n_kept, const uint32_t *flag, const uint32_t *pos, const uint32_t *list_of, const int32_t *result,
+                                                       const BoundRec *pool, LhEntry *out)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_kept; i += gridDim.x * blockDim.x) {
+		if (!flag[i]) continue;
+		const Item it = kept[i];
+		const BoundRec &r = pool[result[i]];
+		const uint32_t sub = ((it.info & ITEM_MINUS) ? 0u : 2u) + (item_role(it) == 1u ? 0u : 1u); // (the reverse oligo is the upstream arm)
+		out[pos[i]] = LhEntry{r.loc5, r.loc3, result[i], (list_of[i] << 2) | sub, lp_float_desc(r.tm)};
+	}
+}
+__global__ __launch_bounds__(256) void lh_key_kernel(const LhEntry *e, const uint32_t *idx, uint32_t n, int pass, unsigned long long *key)
+{
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const LhEntry &x = e[idx ? idx[k] : k];
+		key[k] = pass == 0 ? (unsigned long long)x.tm_desc : (pass == 1 ? (unsigned long long)lp_bias(x.loc3) : (((unsigned long long)x.sub << 32) | (unsigned long long)lp_bias(x.loc5)));
+	}
+}
+__global__ __launch_bounds__(256) void lh_unique_flag_kernel(const LhEntry *e, const uint32_t *idx, uint32_t n, uint32_t *first)
+{
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t f = 1u;
+		if (k) {
+			const LhEntry &a = e[idx[k - 1u]], &b = e[idx[k]];
+			if (a.sub == b.sub && a.loc5 == b.loc5 && a.loc3 == b.loc3) f = 0u;
+		}
+		first[k] = f;
+	}
+}
+__global__ __launch_bounds__(256) void lh_unique_scatter_kernel(const LhEntry *e, const uint32_t *idx, uint32_t n, const uint32_t *first, const uint32_t *pos, LhEntry *out, uint32_t *out_sub)
+{
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+		if (first[k]) {
+			out[pos[k]] = e[idx[k]];
+			out_sub[pos[k]] = e[idx[k]].sub;
+		}
+}
+
+// smallest and largest footprint (loc3 - loc5) of every sublist: they bound the stretch of a downstream list a ligation can come from
+__global__ __launch_bounds__(256) void lh_span_kernel(const LhEntry *e, uint32_t n, int *span_lo, int *span_hi)
+{
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const LhEntry x = e[k];
+		atomicMin(span_lo + x.sub, x.loc3 - x.loc5);
+		atomicMax(span_hi + x.sub, x.loc3 - x.loc5);
+	}
+}
+
+struct LhPairArgs {
+	const LhEntry *e;
+	const uint32_t *sub; // e[k].sub, ascending: the sublists are runs
+	const int *span_lo, *span_hi; // [sublist]
+	uint32_t n;
+	const LpList *lists;
+	const AssayDev *assays;
+	const BoundRec *pool;
+	int max_len;         // of a padlock pair's gap (0 unless MIPS)
+	uint32_t *count;
+	const uint32_t *offset;
+	Hit *hits;
+};
+__device__ inline uint32_t lh_lower(const uint32_t *sub, uint32_t n, uint32_t key) // first k with sub[k] >= key
+{
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (sub[mid] < key) lo = mid + 1u;
+		else hi = mid;
+	}
+	return lo;
+}
+// One thread per entry: a probe-list entry of a probe assay is a hit; an upstream arm of a padlock assay pairs with the
+// downstream arms of its strand whose gap fits (the walk pair_group bounds by the footprints, here by bisection on loc5 and
+// the gap test itself: the same pairs in the same order).
+template <bool WRITE> __global__ __launch_bounds__(256) void lh_pair_kernel(LhPairArgs a)
+{
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < a.n; k += gridDim.x * blockDim.x) {
+		const LhEntry E = a.e[k];
+		const LpList L = a.lists[E.sub >> 2];
+		const AssayDev A = a.assays[L.assay];
+		const uint32_t sl = E.sub & 3u;
+		uint32_t hits = 0;
+		Hit *out = WRITE ? a.hits + a.offset[k] : nullptr;
+		if (A.kind == 2) { // hybrid(): the probe lists (1: minus strand, 3: plus strand)
+			if (sl & 1u) {
+				if (WRITE) {
+					Hit &h = out[0];
+					const BoundRec &b = a.pool[E.rec];
+					init_hit(h, A, L.seq_index);
+					h.probe_tm = b.tm, h.probe_dH = b.dH, h.probe_dS = b.dS;
+					h.probe_mm = wrap8(b.mm), h.probe_gap = wrap8(b.gap);
+					h.probe_start = E.loc5, h.probe_stop = E.loc3;
+					h.probe_strand = sl == 1u ? 1 : 0;
+					copy_text(h.probe_align, b);
+				}
+				hits = 1;
+			}
+		} else if (!(sl & 1u)) { // padlock(): this entry is an upstream arm U
+			const bool minus = sl == 0u;
+			const uint32_t d0 = lh_lower(a.sub, a.n, E.sub + 1u), d1 = lh_lower(a.sub, a.n, E.sub + 2u); // the downstream arms of its strand
+			// a pair needs 0 <= gap <= max_len: that bounds the downstream arm's loc5 from both sides, on the minus strand through
+			// the smallest and largest footprint of the list (the walk of pair_group, tnt_pair.hip.h); the list is in ascending loc5 order
+			const long span_lo = a.span_lo[E.sub + 1u], span_hi = a.span_hi[E.sub + 1u];
+			const long d5_lo = minus ? long(E.loc5) - 1 - long(a.max_len) - span_hi : long(E.loc3) + 1;
+			const long d5_hi = minus ? long(E.loc5) - 1 - span_lo : long(E.loc3) + 1 + long(a.max_len);
+			uint32_t lo = d0, hi = d1; // first downstream arm with loc5 >= d5_lo
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (long(a.e[mid].loc5) < d5_lo) lo = mid + 1u;
+				else hi = mid;
+			}
+			for (uint32_t d = lo; d < d1; d++) {
+				const LhEntry D = a.e[d];
+				if (long(D.loc5) > d5_hi) break;
+				const int len = minus ? (E.loc5 - D.loc3 - 1) : (D.loc5 - E.loc3 - 1);
+				if (len < 0 || len > a.max_len) continue;
+				if (WRITE) {
+					Hit &h = out[hits];
+					const BoundRec &bu = a.pool[E.rec], &bd = a.pool[D.rec];
+					init_hit(h, A, L.seq_index);
+					h.primer_strand = minus ? 1 : 0;
+					h.amplicon_start = minus ? D.loc5 : E.loc5;
+					h.amplicon_stop = minus ? E.loc3 : D.loc3;
+					h.forward_tm = bd.tm, h.reverse_tm = bu.tm;
+					h.forward_dH = bd.dH, h.reverse_dH = bu.dH;
+					h.forward_dS = bd.dS, h.reverse_dS = bu.dS;
+					h.forward_mm = wrap8(bd.mm), h.reverse_mm = wrap8(bu.mm);
+					h.forward_gap = wrap8(bd.gap), h.reverse_gap = wrap8(bu.gap);
+					h.forward_primer_clamp = wrap8(bd.a3);
+					h.reverse_primer_clamp = wrap8(bu.a5);
+					copy_text(h.forward_align, bd);
+					copy_text(h.reverse_align, bu);
+				}
+				hits++;
+			}
+		}
+		if (!WRITE) a.count[k] = hits;
+	}
+}
+
+} // namespace
+
+size_t long_hash_bytes(size_t n_kept, size_t n_bound, size_t n_lists) { return n_kept * 16 + n_bound * (2 * sizeof(LhEntry) + 48) + n_lists * 64 + (size_t(48) << 20); }
+
+// The probe / padlock lists among h_groups (h_take[g] != 0): their hits, list after list, in the order of the reference's loops.
+hipError_t long_hash_device(const Item *kept, uint32_t n_kept, const Group *h_groups, uint32_t n_groups, const uint8_t *h_take, const int32_t *result, const BoundRec *pool,
+                            const AssayDev *assays, const AssayDev *h_assays, const uint32_t *h_unit_target, uint32_t first_seq_index, int pair_max_len, std::vector<Hit> &hits_out,
+                            DeviceArena &arena, hipStream_t stream)
+{
+	hits_out.clear();
+	std::vector<uint32_t> g_first(n_groups + 1), g_list(n_groups);
+	std::vector<LpList> lists;
+	for (uint32_t g = 0; g < n_groups; g++) {
+		g_first[g] = h_groups[g].first;
+		g_list[g] = 0xFFFFFFFFu;
+		if (!h_take[g] || !(h_groups[g].count & ~GROUP_ALIVE)) continue;
+		g_list[g] = uint32_t(lists.size());
+		lists.push_back(LpList{h_groups[g].assay & GROUP_ASSAY_MASK, 0u, int32_t(first_seq_index + h_unit_target[h_groups[g].target]), g});
+	}
+	g_first[n_groups] = n_kept;
+	if (lists.empty() || n_kept == 0) return hipSuccess;
+	if (lists.size() >= (size_t(1) << 30)) return hipErrorInvalidValue;
+	hipError_t e;
+#define LH_TRY(X)                               \
+	do {                                        \
+		if ((e = (X)) != hipSuccess) return e;  \
+	} while (0)
+	const size_t mark0 = arena.mark();
+	auto grid = [](size_t m) { return dim3(unsigned(std::min<size_t>(8192, std::max<size_t>(1, (m + 255) / 256)))); };
+	uint32_t *const d_gfirst = arena.take<uint32_t>(n_groups + 1), *const d_glist = arena.take<uint32_t>(n_groups);
+	LpList *const d_lists = arena.take<LpList>(lists.size());
+	uint32_t *const flag = arena.take<uint32_t>(n_kept), *const pos = arena.take<uint32_t>(n_kept), *const list_of = arena.take<uint32_t>(n_kept);
+	size_t scan_bytes = 0;
+	LH_TRY(lp_scan<uint32_t>(nullptr, scan_bytes, flag, pos, size_t(n_kept), stream));
+	uint8_t *const tmp = arena.take<uint8_t>(scan_bytes + 256);
+	if (!d_gfirst || !d_glist || !d_lists || !flag || !pos || !list_of || !tmp) return hipErrorOutOfMemory;
+	LH_TRY(hipMemcpyAsync(d_gfirst, g_first.data(), sizeof(uint32_t) * (n_groups + 1), hipMemcpyHostToDevice, stream));
+	LH_TRY(hipMemcpyAsync(d_glist, g_list.data(), sizeof(uint32_t) * n_groups, hipMemcpyHostToDevice, stream));
+	LH_TRY(hipMemcpyAsync(d_lists, lists.data(), sizeof(LpList) * lists.size(), hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(lh_flag_kernel, grid(n_kept), dim3(256), 0, stream, kept, n_kept, d_gfirst, d_glist, n_groups, result, flag, list_of);
+	size_t sb = scan_bytes;
+	LH_TRY(lp_scan<uint32_t>(tmp, sb, flag, pos, size_t(n_kept), stream));
+	uint32_t last[2];
+	LH_TRY(hipMemcpyAsync(&last[0], flag + (n_kept - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	LH_TRY(hipMemcpyAsync(&last[1], pos + (n_kept - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	LH_TRY(hipStreamSynchronize(stream));
+	const uint32_t n_b = last[0] + last[1];
+	if (n_b) {
+		LhEntry *const ent = arena.take<LhEntry>(n_b), *const uniq = arena.take<LhEntry>(n_b);
+		unsigned long long *const k0 = arena.take<unsigned long long>(n_b), *const k1 = arena.take<unsigned long long>(n_b);
+		uint32_t *const i0 = arena.take<uint32_t>(n_b), *const i1 = arena.take<uint32_t>(n_b), *const first = arena.take<uint32_t>(n_b), *const upos = arena.take<uint32_t>(n_b), *const usub = arena.take<uint32_t>(n_b);
+		size_t sort_bytes = 0, scan2 = 0;
+		LH_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, k0, k1, i0, i1, size_t(n_b), 0u, 64u, stream));
+		LH_TRY(lp_scan<uint32_t>(nullptr, scan2, first, upos, size_t(n_b), stream));
+		uint8_t *const stmp = arena.take<uint8_t>(std::max(sort_bytes, scan2) + 256);
+		if (!ent || !uniq || !k0 || !k1 || !i0 || !i1 || !first || !upos || !usub || !stmp) return hipErrorOutOfMemory;
+		hipLaunchKernelGGL(lh_gather_kernel, grid(n_kept), dim3(256), 0, stream, kept, n_kept, flag, pos, list_of, result, pool, ent);
+		// oligo_info::operator< per sublist, stable in list order: Tm descending, loc_3, (list, sublist, loc_5), least significant first
+		uint32_t *ia = i0, *ib = i1;
+		hipLaunchKernelGGL(lp_iota_kernel, grid(n_b), dim3(256), 0, stream, ia, n_b);
+		for (int pass = 0; pass < 3; pass++) {
+			hipLaunchKernelGGL(lh_key_kernel, grid(n_b), dim3(256), 0, stream, ent, ia, n_b, pass, k0);
+			size_t b2 = sort_bytes;
+			LH_TRY(rocprim::radix_sort_pairs(stmp, b2, k0, k1, ia, ib, size_t(n_b), 0u, 64u, stream));
+			std::swap(ia, ib);
+		}
+		hipLaunchKernelGGL(lh_unique_flag_kernel, grid(n_b), dim3(256), 0, stream, ent, ia, n_b, first);
+		size_t b3 = scan2;
+		LH_TRY(lp_scan<uint32_t>(stmp, b3, first, upos, size_t(n_b), stream));
+		hipLaunchKernelGGL(lh_unique_scatter_kernel, grid(n_b), dim3(256), 0, stream, ent, ia, n_b, first, upos, uniq, usub);
+		LH_TRY(hipMemcpyAsync(&last[0], first + (n_b - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		LH_TRY(hipMemcpyAsync(&last[1], upos + (n_b - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		LH_TRY(hipStreamSynchronize(stream));
+		const uint32_t n_u = last[0] + last[1];
+		// hits: counted, then written (first / upos are free again)
+		const size_t n_sub = lists.size() * 4 + 4;
+		int *const span_lo = arena.take<int>(n_sub), *const span_hi = arena.take<int>(n_sub);
+		if (!span_lo || !span_hi) return hipErrorOutOfMemory;
+		{
+			std::vector<int> init(n_sub, INT32_MAX);
+			LH_TRY(hipMemcpyAsync(span_lo, init.data(), sizeof(int) * n_sub, hipMemcpyHostToDevice, stream));
+			LH_TRY(hipStreamSynchronize(stream));
+			std::fill(init.begin(), init.end(), INT32_MIN);
+			LH_TRY(hipMemcpyAsync(span_hi, init.data(), sizeof(int) * n_sub, hipMemcpyHostToDevice, stream));
+			LH_TRY(hipStreamSynchronize(stream));
+		}
+		hipLaunchKernelGGL(lh_span_kernel, grid(n_u), dim3(256), 0, stream, uniq, n_u, span_lo, span_hi);
+		LhPairArgs pa;
+		pa.span_lo = span_lo, pa.span_hi = span_hi;
+		pa.e = uniq, pa.sub = usub, pa.n = n_u, pa.lists = d_lists, pa.assays = assays, pa.pool = pool, pa.max_len = pair_max_len;
+		pa.count = first, pa.offset = upos, pa.hits = nullptr;
+		hipLaunchKernelGGL(lh_pair_kernel<false>, grid(n_u), dim3(256), 0, stream, pa);
+		size_t b4 = scan2;
+		LH_TRY(lp_scan<uint32_t>(stmp, b4, first, upos, size_t(n_u), stream));
+		LH_TRY(hipMemcpyAsync(&last[0], first + (n_u - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		LH_TRY(hipMemcpyAsync(&last[1], upos + (n_u - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		LH_TRY(hipStreamSynchronize(stream));
+		const size_t n_hits = size_t(last[0]) + last[1];
+		if (n_hits) {
+			Hit *d_hits = nullptr;
+			LH_TRY(hipMalloc(reinterpret_cast<void **>(&d_hits), n_hits * sizeof(Hit)));
+			pa.hits = d_hits;
+			hipLaunchKernelGGL(lh_pair_kernel<true>, grid(n_u), dim3(256), 0, stream, pa);
+			hits_out.resize(n_hits);
+			e = hipMemcpyAsync(hits_out.data(), d_hits, n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(stream);
+			(void)hipFree(d_hits);
+			if (e != hipSuccess) return e;
+		}
+	}
+	arena.rewind(mark0);
+#undef LH_TRY
 	return hipGetLastError();
 }
 

@@ -388,7 +388,7 @@ class Engine:
         return (self.lib.tnt_ctx_warnings(self._h) or b"").decode()
 
     def long_pair_stats(self):
-        """tnt_long_pair_stats: the lists of windowed targets in the last search -- (PCR lists on the device, PCR lists handed back
+        """tnt_long_pair_stats: the lists of windowed targets in the last search -- (lists on the device, PCR lists handed back
         to the host threads, lists of the host threads from the start, hits the device reported)."""
         out = (C.c_uint64 * 4)()
         self._check(self.lib.tnt_long_pair_stats(self._h, out))
