@@ -220,6 +220,34 @@ def test_second_tier_kernel_equals_its_checker(Engine, oracle, k):
     e.close()
 
 
+def test_the_bind_stage_s_scheduling_changes_no_result(Engine, oracle, monkeypatch):
+    """The buckets' launch chains of a bind phase run on side streams, dealt by expected / measured work (round 6).  Which
+    stream takes which bucket -- one stream, three, eight, round robin, the measured times of an earlier search -- moves no
+    hit, and neither does the seed kernel's instance (short targets, large lists, general)."""
+    cases = [(2, 20000, 96), (3, 12000, 48), (5, 6000, 120)]
+    for cfg, nt, na in cases:
+        wl = synth.make_workload(cfg, n_targets=nt, n_assays=na, seed=37)
+        want = None
+        for env in ({}, {"TNT_MI355X_BIND_LANES": "1"}, {"TNT_MI355X_BIND_LANES": "8"}, {"TNT_MI355X_LANES_ROUND_ROBIN": "1"}, {"TNT_MI355X_LANES_STATIC": "1"},
+                    {"TNT_MI355X_SEED2_GENERAL": "1"}, {"TNT_MI355X_SEED2_STD_LISTS": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            e = Engine(wl.options, wl.expanded)
+            db = e.pack(wl.codes, wl.offsets)
+            got = tc.sorted_hit_keys(e.search(db))
+            again = tc.sorted_hit_keys(e.search(db))  # (the second search deals the chains by the first one's times)
+            db.close()
+            e.close()
+            for k in env:
+                monkeypatch.delenv(k)
+            if want is None:
+                want = got
+                assert len(want) > 5
+                if cfg == 2:
+                    assert want == tc.sorted_hit_keys(oracle.search(wl.options, wl.expanded, wl.codes, wl.offsets))
+            assert got == want and again == want, env
+
+
 def test_filter_changes_no_result(Engine, oracle, monkeypatch):
     """The same searches with the pre-filter on, off and in audit mode (everything is bound and the bind kernel raises an
     error if it accepts a window the filter marked): identical hits, and the filter does reject most windows."""
